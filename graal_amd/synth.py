@@ -1,0 +1,193 @@
+"""Synthetic GRAAL problems: the inputs ``simulation_loader.simulation`` hands to
+the sampler constructor (``simulation_loader.py:92-107``), generated instead of read from a pyramid.
+
+The real S1 / T. reesei tarballs are not in the tree (``README.md:99-101`` of the reference), so every
+BASELINE config runs on a stand-in produced here; the generator is seeded and committed so fixtures are
+reproducible.  Contacts are produced directly in COO form (three int32 arrays sorted by (i, j), the
+``(3, nnz)`` layout of ``pyramid_sparse.py:314-322``); nothing here densifies.
+"""
+import numpy as np
+
+FIELDS = ("pos", "id_c", "start_bp", "len_bp", "circ", "id", "prev", "next", "l_cont", "l_cont_bp", "ori",
+          "rep", "activ", "id_d")
+
+C5_CONTIG_WEIGHTS = (6.8, 6.2, 5.3, 4.6, 4.0, 3.4, 2.7)
+
+
+def rippe_np(s, p):
+    """Rippe contact model in float64 numpy (``kernels3.cu:120-133`` without the float32 rounding)."""
+    kuhn, lm, c1, slope, d, d_max, fact, v_inter = [float(x) for x in p]
+    s = np.asarray(s, dtype=np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        r = c1 * np.power(s, slope) * np.exp((d - 2.0) / ((s * lm / kuhn) ** 2 + d)) * fact
+    r = np.where((s > 0) & (s < d_max), r, 0.0)
+    return np.maximum(r, v_inter)
+
+
+def make_param_simu(kuhn=1.0, lm=9.6, slope=-1.5, d=3.0, fact=1e4, v_inter=1e-3, d_max=None):
+    """param_simu = (kuhn, lm, c1, slope, d, d_max, fact, v_inter) float32; c1 as ``cuda_lib_gl.py:1208``;
+    d_max defaults to the smallest s with rippe(s) <= v_inter (bisection)."""
+    kuhn = np.float32(kuhn)
+    lm = np.float32(lm)
+    c1 = np.float32((0.53 * np.power(lm / kuhn, slope)) * np.power(kuhn, -3))
+    if d_max is None:
+        f = lambda s: float(c1) * s ** slope * np.exp((d - 2.0) / ((s * float(lm) / float(kuhn)) ** 2 + d)) * fact
+        lo, hi = 1e-3, 1e-3
+        while f(hi) > v_inter:
+            hi *= 2.0
+        lo = hi / 2.0
+        for _ in range(100):
+            mid = 0.5 * (lo + hi)
+            if f(mid) > v_inter:
+                lo = mid
+            else:
+                hi = mid
+        d_max = hi
+    return np.array([kuhn, lm, c1, slope, d, d_max, fact, v_inter], dtype=np.float32)
+
+
+def _layout(rng, n_bins, n_sub, contig_weights, mean_len_bp, ragged):
+    """Sub-level fragments grouped into bins of <= n_sub consecutive sub-frags inside each contig."""
+    w = np.asarray(contig_weights, dtype=np.float64)
+    bins_per_contig = np.maximum(1, np.floor(w / w.sum() * n_bins).astype(np.int64))
+    bins_per_contig[0] += n_bins - bins_per_contig.sum()
+    assert bins_per_contig.min() >= 1 and bins_per_contig.sum() == n_bins
+    sub_per_bin = np.full(n_bins, n_sub, dtype=np.int32)
+    if ragged and n_sub > 1:
+        ends = np.cumsum(bins_per_contig) - 1  # last bin of each contig holds 1..n_sub sub-frags
+        sub_per_bin[ends] = rng.randint(1, n_sub + 1, size=len(ends))
+    n_sub_total = int(sub_per_bin.sum())
+    sub_len_bp = (1 + np.round(rng.exponential(mean_len_bp, size=n_sub_total))).astype(np.int32)
+    return bins_per_contig, sub_per_bin, sub_len_bp
+
+
+def make_problem(n_bins=50000, nnz=20_000_000, n_sub=1, seed=20141217, contig_weights=C5_CONTIG_WEIGHTS,
+                 mean_len_bp=660.0, accu=1, ragged=True, param=None, frac_cis=0.85, max_count_mean=50.0,
+                 grid_bp=None):
+    """Build one synthetic problem.
+
+    n_sub = 1 is the "level 0" semantics (bins = restriction fragments, accu = 1); n_sub = 3 mimics a
+    pyramid level >= 1 (bins of 3 sub-level fragments, ``simulation_loader.py:673-704``).
+    ``grid_bp``: if set, every sub-frag length is rounded up to a multiple of it (e.g. 2000 makes every
+    float32 kb coordinate exact, so dense float32 geometry is shift-invariant -- used by trace fixtures).
+    Returns a dict with the sampler-constructor inputs plus the COO lists.
+    """
+    rng = np.random.RandomState(seed)
+    bins_per_contig, sub_per_bin, sub_len_bp = _layout(rng, n_bins, n_sub, contig_weights, mean_len_bp, ragged)
+    if grid_bp:
+        sub_len_bp = (((sub_len_bp + grid_bp - 1) // grid_bp) * grid_bp).astype(np.int32)
+    n_sub_total = int(sub_per_bin.sum())
+    sub_first = np.concatenate([[0], np.cumsum(sub_per_bin)[:-1]]).astype(np.int32)
+    bin_of_sub = np.repeat(np.arange(n_bins, dtype=np.int32), sub_per_bin)
+    # bin-level fragment SoA (pyramid_sparse.py:1316-1327)
+    len_bp = np.add.reduceat(sub_len_bp.astype(np.int64), sub_first).astype(np.int32)
+    contig_of_bin = np.repeat(np.arange(len(bins_per_contig), dtype=np.int32), bins_per_contig)
+    first_bin = np.concatenate([[0], np.cumsum(bins_per_contig)[:-1]])
+    pos = (np.arange(n_bins) - first_bin[contig_of_bin]).astype(np.int32)
+    cum = np.cumsum(len_bp.astype(np.int64))
+    contig_start = np.concatenate([[0], cum])[first_bin]
+    start_bp = (cum - len_bp - contig_start[contig_of_bin]).astype(np.int32)
+    l_cont = bins_per_contig[contig_of_bin].astype(np.int32)
+    l_cont_bp = np.add.reduceat(len_bp.astype(np.int64), first_bin)[contig_of_bin].astype(np.int32)
+    idx = np.arange(n_bins, dtype=np.int32)
+    prev = np.where(pos == 0, -1, idx - 1).astype(np.int32)
+    nxt = np.where(pos == l_cont - 1, -1, idx + 1).astype(np.int32)
+    soa = dict(pos=pos, id_c=(contig_of_bin + 1).astype(np.int32), start_bp=start_bp, len_bp=len_bp,
+               circ=np.zeros(n_bins, np.int32), id=idx.copy(), prev=prev, next=nxt, l_cont=l_cont,
+               l_cont_bp=l_cont_bp, ori=np.ones(n_bins, np.int32), rep=np.zeros(n_bins, np.int32),
+               activ=np.ones(n_bins, np.int32), id_d=idx.copy())
+    # sub-frag tables (simulation_loader.py:673-704): int4 ids, float3 len in kb, int3 accu
+    sub_id = np.zeros((n_bins, 4), dtype=np.int32)
+    sub_len = np.zeros((n_bins, 3), dtype=np.float32)
+    sub_accu = np.zeros((n_bins, 3), dtype=np.int32)
+    sub_id[:, 3] = sub_per_bin
+    for k in range(3):
+        m = sub_per_bin > k
+        sub_id[m, k] = sub_first[m] + k
+        sub_len[m, k] = np.float32(sub_len_bp[sub_first[m] + k]) / np.float32(1000.0)
+        sub_accu[m, k] = accu
+    accu_all = np.full(n_sub_total, accu, dtype=np.float32)
+    nfpb = np.float32(accu_all.mean() ** 2)  # simulation_loader.py:73
+    if param is None:
+        param = make_param_simu()
+    param = np.asarray(param, dtype=np.float32)
+    # sub-level centre coordinates in kb (within contig) for drawing contacts
+    sub_contig = contig_of_bin[bin_of_sub]
+    scum = np.cumsum(sub_len_bp.astype(np.int64))
+    sub_first_of_contig = sub_first[first_bin]
+    sub_cstart = np.concatenate([[0], scum])[sub_first_of_contig]
+    centre_kb = (scum - sub_len_bp / 2.0 - sub_cstart[sub_contig]) / 1000.0
+    # ---- contacts: frac_cis cis with offset ~ rippe, rest uniform trans ---------------------
+    S = n_sub_total
+    nnz = int(min(nnz, S * (S - 1) // 2 // 2))
+    mean_kb = float(sub_len_bp.mean()) / 1000.0
+    kmax = int(min(S - 1, max(2, np.ceil(float(param[5]) / mean_kb))))
+    off_p = rippe_np(np.arange(1, kmax + 1) * mean_kb, param)
+    off_p = off_p / off_p.sum()
+    off_cdf = np.cumsum(off_p)
+    keys = np.zeros(0, dtype=np.int64)
+    target_cis = int(round(nnz * frac_cis))
+    for target, cis in ((target_cis, True), (nnz, False)):
+        while len(keys) < target:
+            need = target - len(keys)
+            m = int(need * 1.3) + 1024
+            i = rng.randint(0, S, size=m).astype(np.int64)
+            if cis:
+                k = np.searchsorted(off_cdf, rng.random_sample(m)).astype(np.int64) + 1
+                j = i + k
+                ok = (j < S)
+                ok[ok] &= sub_contig[i[ok]] == sub_contig[j[ok]]
+            else:
+                j = rng.randint(0, S, size=m).astype(np.int64)
+                lo, hi = np.minimum(i, j), np.maximum(i, j)
+                i, j = lo, hi
+                ok = (i != j) & (sub_contig[i] != sub_contig[j])
+            new = np.unique(i[ok] * S + j[ok])
+            new = new[~np.isin(new, keys, assume_unique=True)] if len(keys) else new
+            if len(new) > need:
+                new = rng.choice(new, need, replace=False)
+            keys = np.union1d(keys, new)
+    keys.sort()
+    row = (keys // S).astype(np.int32)
+    col = (keys % S).astype(np.int32)
+    same = sub_contig[row] == sub_contig[col]
+    lam = np.where(same, rippe_np(np.abs(centre_kb[col] - centre_kb[row]), param), float(param[7]))
+    lam = np.clip(lam * accu * accu / float(nfpb), 0.0, max_count_mean)
+    val = (1 + rng.poisson(lam)).astype(np.int32)
+    # bin-level COO (upper, i<j) for the neighbour proposal (cuda_lib_gl.py:2363-2390)
+    bi, bj = bin_of_sub[row].astype(np.int64), bin_of_sub[col].astype(np.int64)
+    m = bi != bj
+    bkeys = np.minimum(bi[m], bj[m]) * n_bins + np.maximum(bi[m], bj[m])
+    ub, inv = np.unique(bkeys, return_inverse=True)
+    bval = np.bincount(inv, weights=val[m].astype(np.float64)).astype(np.float32)
+    # mean_value_trans: contacts between different contigs / number of such ordered sub-frag pairs
+    n_per_contig = np.bincount(sub_contig).astype(np.float64)
+    n_trans_pairs = float(S) * S - float((n_per_contig ** 2).sum())
+    mean_value_trans = np.float32(2.0 * val[~same].sum() / max(n_trans_pairs, 1.0))
+    return dict(
+        S_o_A_frags=soa, n_frags=n_bins, n_new_frags=n_bins, init_n_sub_frags=S, n_new_sub_frags=S,
+        collector_id_repeats=np.arange(n_bins, dtype=np.int32),
+        frag_dispatcher=np.stack([np.arange(n_bins), np.arange(n_bins) + 1], axis=1).astype(np.int32),
+        id_frag_duplicated=[], id_frags_blacklisted=[],
+        np_sub_frags_id=sub_id, np_sub_frags_len_bp=sub_len, np_sub_frags_accu=sub_accu,
+        mean_squared_frags_per_bin=nfpb, mean_value_trans=mean_value_trans, param_simu=param,
+        coo_row=row, coo_col=col, coo_val=val,
+        bin_coo_row=(ub // n_bins).astype(np.int32), bin_coo_col=(ub % n_bins).astype(np.int32), bin_coo_val=bval,
+        sub_len_bp=sub_len_bp, bin_of_sub=bin_of_sub)
+
+
+def dense_from_coo(row, col, val, n, dtype=np.float32):
+    """Symmetric dense matrix with a zero diagonal, as ``simulation_loader.py:81-82`` +
+    ``cuda_lib_gl.py:155-160`` build it.  Test / oracle helper for SMALL problems only."""
+    m = np.zeros((n, n), dtype=dtype)
+    m[row, col] = val
+    m[col, row] = val
+    return m
+
+
+def with_dense(problem):
+    """Add the dense matrices the reference's sampler (and the oracle) take.  SMALL problems only."""
+    p = dict(problem)
+    p["hic_matrix"] = dense_from_coo(p["coo_row"], p["coo_col"], p["coo_val"], p["init_n_sub_frags"])
+    p["hic_matrix_sub_sampled"] = dense_from_coo(p["bin_coo_row"], p["bin_coo_col"], p["bin_coo_val"], p["n_frags"])
+    return p
