@@ -1,0 +1,112 @@
+/*
+ * graal_hip.h -- C ABI of libgraal_hip.so, the MI355X (gfx950) engine for GRAAL's per-move likelihood
+ * scan.  Plain pointers and sizes only; loaded from Python with ctypes (graal_amd/lib.py).
+ *
+ * What it replaces in the reference: the 23 PyCUDA entry points that cuda_lib_gl.sampler looks up in
+ * kernels3.cu (cuda_lib_gl.py:378-402) and the device-side state they operate on
+ * (cuda_lib_gl.py:194-360).  Each function below cites the reference call sequence it stands for.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a GRAAL_E_* code otherwise; graal_last_error() gives text.
+ *     Nothing aborts; nothing falls back to the CPU (no GPU => GRAAL_E_HIP at graal_create).
+ *   - host pointers are borrowed for the duration of the call; "d_" pointers are DEVICE pointers
+ *     (e.g. the data_ptr() of a torch tensor) and `stream` is a hipStream_t passed as void*.
+ *   - a handle is not thread safe; one host thread per handle, one handle per GPU / process.
+ *   - log-likelihood values cross the boundary either as double or as int64 fixed point
+ *     ("Q" = value * 2^GRAAL_Q_BITS, rounded per term).  Q sums are order independent, hence
+ *     bit-reproducible for any sharding of the contact list over GPUs.
+ */
+#ifndef GRAAL_HIP_H
+#define GRAAL_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GRAAL_ABI_VERSION 1
+#define GRAAL_N_OPS 13        /* candidates per (fA, fB): cuda_lib_gl.py:112 n_tmp_struct */
+#define GRAAL_MAX_NEIGHBOURS 8 /* neighbours scored by one scan pass */
+#define GRAAL_Q_BITS 30
+#define GRAAL_N_FIELDS 14     /* struct frag, kernels3.cu:9-24 */
+
+enum {
+    GRAAL_OK = 0,
+    GRAAL_E_ARG = 1,          /* bad argument / shape */
+    GRAAL_E_HIP = 2,          /* HIP runtime error (incl. no device) */
+    GRAAL_E_STATE = 3,        /* call order (e.g. eval before upload) */
+    GRAAL_E_UNSUPPORTED = 4   /* repeats / blacklist / inactive fragments: not in this round */
+};
+
+typedef struct graal_ctx graal_ctx;
+
+/* device bring-up; replaces cuda_gl_init + loadProgram (main_gl.py:690-702, cuda_lib_gl.py:708-713) */
+int graal_create(int device, graal_ctx** out);
+void graal_destroy(graal_ctx* h);
+const char* graal_last_error(const graal_ctx* h);
+int graal_abi_version(void);
+
+/* Rippe model parameters: 8 floats kuhn,lm,c1,slope,d,d_max,fact,v_inter (kernels3.cu:26-35);
+ * replaces memcpy_htod(gpu_param_simu, ...) cuda_lib_gl.py:1294, 2073 */
+int graal_set_params(graal_ctx* h, const float* param8);
+
+/* sub-fragment tables of the n_bins unique bins (simulation_loader.py:673-704):
+ * sub_id[n_bins][4] = (x,y,z,w=n_sub), sub_len_kb[n_bins][3], sub_accu[n_bins][3];
+ * replaces the uploads of cuda_lib_gl.py:210-215 */
+int graal_upload_subfrags(graal_ctx* h, const int32_t* sub_id, const float* sub_len_kb, const int32_t* sub_accu,
+                          int32_t n_bins, int32_t n_sub_total, float n_frags_per_bins);
+
+/* this rank's shard of the sub-level contact list in COO form, row < col, any order (sorted by
+ * (row, col) is fastest); counts are the observed contacts.  Replaces the dense S x S upload of
+ * cuda_lib_gl.py:194 (which simulation_loader.py:81-82 densifies first). */
+int graal_upload_contacts(graal_ctx* h, const int32_t* row, const int32_t* col, const int32_t* count, int64_t nnz);
+
+/* fragment layout: 14 arrays of n int32 in the order of struct frag; replaces GPUStruct.copy_to_gpu
+ * (cuda_lib_gl.py:264-265) / copy_from_gpu (gpustruct.py:175) */
+int graal_upload_frags(graal_ctx* h, const int32_t* const soa[GRAAL_N_FIELDS], int32_t n);
+int graal_download_frags(graal_ctx* h, int32_t* const soa[GRAAL_N_FIELDS]);
+
+/* contig relabel: id_c <- rank of the contig when contigs are sorted by (l_cont, old label);
+ * replaces modify_gl_cuda_buffer's compute half + gl_update_pos (cuda_lib_gl.py:1697-1722,
+ * kernels3.cu:3848-3851).  *max_id = n_contigs - 1.  Also rebuilds the position index. */
+int graal_relabel_contigs(graal_ctx* h, int32_t* max_id);
+
+/* layout statistics step_max_likelihood returns (cuda_lib_gl.py:1809-1816):
+ * out[0]=n_contigs out[1]=sum(l_cont) out[2]=#(start_bp==0) out[3]=sum(l_cont_bp | start_bp==0)
+ * out[4]=max(l_cont) out[5]=min(l_cont) */
+int graal_layout_stats(graal_ctx* h, int64_t out[6]);
+
+/* full log-likelihood of the current layout over this rank's contact shard, as Q fixed point:
+ *   q_out[0] = sum over contacts of ob*log(ex) - log-factorial term   (shard dependent)
+ *   q_out[1] = - expected mass of all pixels                          (identical on every rank)
+ * logL = (sum over ranks of q_out[0] + q_out[1]) / 2^GRAAL_Q_BITS.
+ * Replaces evaluate_likelihood + gpuarray.sum (cuda_lib_gl.py:543-631, 1473-1509). */
+int graal_eval_full_q(graal_ctx* h, int64_t q_out[2]);
+
+/* delta log-likelihood of the 13 candidates of each of K (<= GRAAL_MAX_NEIGHBOURS) neighbours fB[k]
+ * of fA, over this rank's contact shard; rank / world shard the expected-mass work.
+ * Writes K*13 int64 Q values to the DEVICE buffer d_q_out on `stream` (asynchronous): sum them over
+ * ranks (one RCCL all-reduce) then divide by 2^GRAAL_Q_BITS.  max_id must be the value returned by
+ * graal_relabel_contigs for the current layout.
+ * Replaces new_perform_modificationS + 13 x sub_compute_likelihood per neighbour
+ * (cuda_lib_gl.py:2392-2546). */
+int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int32_t max_id, int32_t rank,
+                            int32_t world, int64_t* d_q_out, void* stream);
+/* single-GPU convenience: same, synchronous, into a host buffer of K*13 doubles */
+int graal_eval_candidates(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int32_t max_id, double* delta);
+
+/* commit candidate `op` of (fA, fB); replaces test_copy_struct (cuda_lib_gl.py:1156-1180).
+ * *n_stale = fragments that hit the reference's unwritten paste branch (expected 0). */
+int graal_apply_move(graal_ctx* h, int32_t fA, int32_t fB, int32_t op, int32_t max_id, int32_t* n_stale);
+
+/* timing of the last graal_eval_candidates* call, HIP events on the engine's stream (milliseconds):
+ * out[0]=tables+codes out[1]=contact scan out[2]=expected-mass tasks out[3]=combine */
+int graal_last_timing(graal_ctx* h, float out[4]);
+/* counters of the last call: out[0]=contacts scanned out[1]=relevant (contact, neighbour) pairs
+ * out[2]=mass tasks out[3]=mass work items */
+int graal_last_counters(graal_ctx* h, int64_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
