@@ -520,6 +520,7 @@ __global__ __launch_bounds__(256) void k_scan(const int* __restrict__ row, const
             const unsigned dnz = (df | (df >> 1) | (df >> 2)) & 0x11111111u;
             unsigned rel = nzi & nzj & (dnz | ((ci >> 3) & 0x11111111u));
             if (rel == 0) continue;
+            if (!SINGLE_SUB && fx == fy) continue; // a bin's own pixel is never revisited (kernels3.cu:3356-3380)
             // ---- slow path ----
             const Geo gx = geo[fx], gy = geo[fy];
             const Stat sx = stat[fx], sy = stat[fy];
@@ -581,8 +582,7 @@ __global__ __launch_bounds__(64) void k_mass(const NbTables* __restrict__ tabs, 
             const Stat sx = stat[fx];
             const End X = end_xf(gx, tk.xp);
             if (tk.p == tk.q) {
-                for (int a = 0; a < sx.n; a++)
-                    for (int b = a + 1; b < sx.n; b++) acc += (double)ex_pair(X, sx, a, X, sx, b, nfpb, par);
+                // (x's own sub-fragment pairs are left out: candidates never revisit a bin's own pixel)
                 // later fragments of the same piece, walking away from x in the new layout
                 for (int iy = ix + 1; iy < np; iy++) {
                     const int fy = perm[base_p + iy];

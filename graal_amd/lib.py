@@ -1,0 +1,201 @@
+"""ctypes binding of ``libgraal_hip.so`` (C ABI: ``include/graal_hip.h``).
+
+This is the whole host<->device boundary of the engine: plain pointers and sizes.  There is no CPU
+fallback -- if the library or a HIP device is missing, :class:`Engine` raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import build as _build
+
+N_OPS = 13
+MAX_NEIGHBOURS = 8
+Q_SCALE = float(1 << 30)
+FIELDS = ("pos", "id_c", "start_bp", "len_bp", "circ", "id", "prev", "next", "l_cont", "l_cont_bp", "ori", "rep",
+          "activ", "id_d")  # struct frag, kernels3.cu:9-24
+
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_i64p = ctypes.POINTER(ctypes.c_int64)
+_f32p = ctypes.POINTER(ctypes.c_float)
+_f64p = ctypes.POINTER(ctypes.c_double)
+
+SYMBOLS = ("graal_abi_version", "graal_create", "graal_destroy", "graal_last_error", "graal_set_params",
+           "graal_upload_subfrags", "graal_upload_contacts", "graal_upload_frags", "graal_download_frags",
+           "graal_relabel_contigs", "graal_layout_stats", "graal_eval_full_q", "graal_eval_candidates_q",
+           "graal_eval_candidates", "graal_apply_move", "graal_last_timing", "graal_last_counters")
+
+_lib = None
+
+
+def lib_path():
+    return _build.HIP_LIB
+
+
+def load():
+    """Load (never build implicitly on the GPU box: the .so travels with the snapshot) the C-ABI library."""
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError("libgraal_hip.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        L = ctypes.CDLL(path)
+        L.graal_last_error.restype = ctypes.c_char_p
+        L.graal_last_error.argtypes = [ctypes.c_void_p]
+        L.graal_destroy.restype = None
+        L.graal_destroy.argtypes = [ctypes.c_void_p]
+        L.graal_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+        L.graal_set_params.argtypes = [ctypes.c_void_p, _f32p]
+        L.graal_upload_subfrags.argtypes = [ctypes.c_void_p, _i32p, _f32p, _i32p, ctypes.c_int32, ctypes.c_int32,
+                                            ctypes.c_float]
+        L.graal_upload_contacts.argtypes = [ctypes.c_void_p, _i32p, _i32p, _i32p, ctypes.c_int64]
+        L.graal_upload_frags.argtypes = [ctypes.c_void_p, ctypes.POINTER(_i32p), ctypes.c_int32]
+        L.graal_download_frags.argtypes = [ctypes.c_void_p, ctypes.POINTER(_i32p)]
+        L.graal_relabel_contigs.argtypes = [ctypes.c_void_p, _i32p]
+        L.graal_layout_stats.argtypes = [ctypes.c_void_p, _i64p]
+        L.graal_eval_full_q.argtypes = [ctypes.c_void_p, _i64p]
+        L.graal_eval_candidates_q.argtypes = [ctypes.c_void_p, ctypes.c_int32, _i32p, ctypes.c_int32, ctypes.c_int32,
+                                              ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+        L.graal_eval_candidates.argtypes = [ctypes.c_void_p, ctypes.c_int32, _i32p, ctypes.c_int32, ctypes.c_int32, _f64p]
+        L.graal_apply_move.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _i32p]
+        L.graal_last_timing.argtypes = [ctypes.c_void_p, _f32p]
+        L.graal_last_counters.argtypes = [ctypes.c_void_p, _i64p]
+        _lib = L
+    return _lib
+
+
+class GraalError(RuntimeError):
+    pass
+
+
+def _c(a, dtype):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a
+
+
+class Engine:
+    """One handle = one GPU.  Thin, typed wrapper; every failure raises :class:`GraalError`."""
+
+    def __init__(self, device=0):
+        self._L = load()
+        self._h = ctypes.c_void_p()
+        rc = self._L.graal_create(int(device), ctypes.byref(self._h))
+        if rc != 0:
+            msg = self._L.graal_last_error(self._h).decode() if self._h else "graal_create failed"
+            if self._h:
+                self._L.graal_destroy(self._h)
+                self._h = ctypes.c_void_p()
+            raise GraalError("graal_create(device=%d): %s" % (device, msg))
+        self.device = int(device)
+        self.n = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.graal_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            raise GraalError("%s: %s (code %d)" % (what, self._L.graal_last_error(self._h).decode(), rc))
+
+    # -- uploads ------------------------------------------------------------------------------
+    def set_params(self, param8):
+        p = _c(np.asarray(param8, dtype=np.float32).reshape(8), np.float32)
+        self._ck(self._L.graal_set_params(self._h, p.ctypes.data_as(_f32p)), "graal_set_params")
+
+    def upload_subfrags(self, sub_id, sub_len_kb, sub_accu, n_sub_total, n_frags_per_bins):
+        sid = _c(np.asarray(sub_id).reshape(-1, 4), np.int32)
+        sl = _c(np.asarray(sub_len_kb).reshape(-1, 3), np.float32)
+        sa = _c(np.asarray(sub_accu).reshape(-1, 3), np.int32)
+        assert len(sid) == len(sl) == len(sa)
+        self._ck(self._L.graal_upload_subfrags(self._h, sid.ctypes.data_as(_i32p), sl.ctypes.data_as(_f32p),
+                                               sa.ctypes.data_as(_i32p), len(sid), int(n_sub_total),
+                                               ctypes.c_float(float(n_frags_per_bins))), "graal_upload_subfrags")
+
+    def upload_contacts(self, row, col, count):
+        r, c, v = _c(row, np.int32), _c(col, np.int32), _c(count, np.int32)
+        assert len(r) == len(c) == len(v)
+        self._ck(self._L.graal_upload_contacts(self._h, r.ctypes.data_as(_i32p), c.ctypes.data_as(_i32p),
+                                               v.ctypes.data_as(_i32p), len(r)), "graal_upload_contacts")
+        self.nnz = len(r)
+
+    def upload_frags(self, soa):
+        arrs = [_c(soa[k], np.int32) for k in FIELDS]
+        n = len(arrs[0])
+        assert all(len(a) == n for a in arrs)
+        ptrs = (_i32p * 14)(*[a.ctypes.data_as(_i32p) for a in arrs])
+        self._ck(self._L.graal_upload_frags(self._h, ptrs, n), "graal_upload_frags")
+        self.n = n
+
+    def download_frags(self, out=None):
+        if out is None:
+            out = {k: np.empty(self.n, dtype=np.int32) for k in FIELDS}
+        ptrs = (_i32p * 14)(*[out[k].ctypes.data_as(_i32p) for k in FIELDS])
+        self._ck(self._L.graal_download_frags(self._h, ptrs), "graal_download_frags")
+        return out
+
+    # -- layout maintenance ------------------------------------------------------------------
+    def relabel_contigs(self):
+        m = ctypes.c_int32(0)
+        self._ck(self._L.graal_relabel_contigs(self._h, ctypes.byref(m)), "graal_relabel_contigs")
+        return int(m.value)
+
+    def layout_stats(self):
+        out = np.zeros(6, dtype=np.int64)
+        self._ck(self._L.graal_layout_stats(self._h, out.ctypes.data_as(_i64p)), "graal_layout_stats")
+        return out
+
+    def apply_move(self, fA, fB, op, max_id):
+        st = ctypes.c_int32(0)
+        self._ck(self._L.graal_apply_move(self._h, int(fA), int(fB), int(op), int(max_id), ctypes.byref(st)),
+                 "graal_apply_move")
+        return int(st.value)
+
+    # -- likelihood ---------------------------------------------------------------------------
+    def eval_full_q(self):
+        q = np.zeros(2, dtype=np.int64)
+        self._ck(self._L.graal_eval_full_q(self._h, q.ctypes.data_as(_i64p)), "graal_eval_full_q")
+        return q
+
+    def eval_full(self):
+        q = self.eval_full_q()
+        return float(int(q[0]) + int(q[1])) / Q_SCALE
+
+    def eval_candidates(self, fA, fB, max_id):
+        """Delta logL of the 13 candidates of every neighbour: float64 [K, 13].  Single GPU, synchronous."""
+        fb = _c(fB, np.int32)
+        out = np.zeros((len(fb), N_OPS), dtype=np.float64)
+        for k0 in range(0, len(fb), MAX_NEIGHBOURS):  # > 8 neighbours: one scan pass per group of 8
+            part = fb[k0:k0 + MAX_NEIGHBOURS]
+            buf = np.zeros(len(part) * N_OPS, dtype=np.float64)
+            self._ck(self._L.graal_eval_candidates(self._h, int(fA), part.ctypes.data_as(_i32p), len(part), int(max_id),
+                                                   buf.ctypes.data_as(_f64p)), "graal_eval_candidates")
+            out[k0:k0 + len(part)] = buf.reshape(len(part), N_OPS)
+        return out
+
+    def eval_candidates_q_async(self, fA, fB, max_id, d_out_ptr, stream_ptr, rank=0, world=1):
+        """Asynchronous Q-valued form for the multi-GPU path: K*13 int64 into a DEVICE buffer on `stream`."""
+        fb = _c(fB, np.int32)
+        assert 1 <= len(fb) <= MAX_NEIGHBOURS
+        self._ck(self._L.graal_eval_candidates_q(self._h, int(fA), fb.ctypes.data_as(_i32p), len(fb), int(max_id),
+                                                 int(rank), int(world), ctypes.c_void_p(int(d_out_ptr)),
+                                                 ctypes.c_void_p(int(stream_ptr) if stream_ptr else 0)),
+                 "graal_eval_candidates_q")
+
+    def last_timing(self):
+        t = np.zeros(4, dtype=np.float32)
+        self._ck(self._L.graal_last_timing(self._h, t.ctypes.data_as(_f32p)), "graal_last_timing")
+        return t
+
+    def last_counters(self):
+        c = np.zeros(4, dtype=np.int64)
+        self._ck(self._L.graal_last_counters(self._h, c.ctypes.data_as(_i64p)), "graal_last_counters")
+        return c
