@@ -33,7 +33,7 @@ namespace {
 constexpr double Q_SCALE = 1073741824.0; // 2^GRAAL_Q_BITS
 constexpr int MAXK = GRAAL_MAX_NEIGHBOURS;
 constexpr int NP = MAX_PIECES + 1;       // piece ids 0..6
-constexpr int MAX_TASKS = 96;            // per neighbour
+constexpr int MAX_TASKS = 21 * (N_OPS + 1); // per neighbour: 21 piece pairs x (old + 13 candidate layouts), before dedupe
 constexpr int LABEL_BITS = 20;           // relabel sort key = l_cont << 20 | label
 
 struct Par { float kuhn, lm, c1, slope, d, d_max, fact, v_inter; };
@@ -319,6 +319,7 @@ struct NbTables {        // everything the scan / mass kernels need about one ne
     unsigned long long changed[N_OPS]; // bit p*8+q (both orders): relation (p,q) changed; p==q: intra
     unsigned intra_any;                // bit p: some op changes piece p internally
     int n_tasks;
+    int item_start[MAX_TASKS + 1];     // prefix sum of 64-fragment chunks per task: the mass work list, in a fixed order
     Task task[MAX_TASKS];
 };
 
@@ -429,8 +430,7 @@ __global__ __launch_bounds__(256) void k_tables(SoaPtr s, int fA, Neigh nb, int 
     if (t == 0) {
         int n = 0;
         for (int e = 0; e < NENT; e++)
-            if (e_valid[e] && e_owner[e] == e) { if (n < MAX_TASKS) e_slot[e] = n; n++; }
-        if (n > MAX_TASKS) { atomicAdd(overflow, 1); n = MAX_TASKS; }
+            if (e_valid[e] && e_owner[e] == e) e_slot[e] = n++;   // n <= NENT == MAX_TASKS by construction
         n_tasks = n;
         T.n_tasks = n;
         T.intra_any = intra_any;
@@ -445,9 +445,24 @@ __global__ __launch_bounds__(256) void k_tables(SoaPtr s, int fA, Neigh nb, int 
         Task tk; tk.p = p; tk.q = q;
         if (e < NPAIR) { tk.xp = xf_old[p]; tk.xq = xf_old[q]; }
         else { const int op = (e - NPAIR) / NPAIR; tk.xp = xf[op][p]; tk.xq = xf[op][q]; }
+        if (T.hi[tk.p] - T.lo[tk.p] < T.hi[tk.q] - T.lo[tk.q]) { // the larger piece goes on the parallel (lane) axis
+            const int tp = tk.p; tk.p = tk.q; tk.q = tp;
+            const Xf tx = tk.xp; tk.xp = tk.xq; tk.xq = tx;
+        }
         tk.plus = e_plus[e]; tk.minus = e_minus[e];
         T.task[e_slot[e]] = tk;
     }
+    __syncthreads();
+    if (t == 0) { // work list: chunks of 64 fragments of the task's first piece, tasks in slot order
+        int acc = 0;
+        for (int i = 0; i < n_tasks; i++) {
+            T.item_start[i] = acc;
+            const int p = T.task[i].p;
+            acc += (T.hi[p] - T.lo[p] + 1 + 63) / 64;
+        }
+        T.item_start[n_tasks] = acc;
+    }
+    (void)overflow;
 }
 
 // per-fragment relevance code: 4 bits per neighbour = piece id (3) | "piece changes internally" (1)
@@ -552,25 +567,24 @@ __global__ __launch_bounds__(256) void k_scan(const int* __restrict__ row, const
 
 // ------------------------------------------------------------------ mass tasks
 // work item = (neighbour, task, chunk of 64 fragments of piece p); one wave per item, lane = fragment x.
-__global__ __launch_bounds__(64) void k_mass(const NbTables* __restrict__ tabs, int K, int n_chunk_max,
+__global__ __launch_bounds__(64) void k_mass(const NbTables* __restrict__ tabs, int K,
                                               const int* __restrict__ perm, const int* __restrict__ contig_off,
                                               const Geo* __restrict__ geo, const Stat* __restrict__ stat, float nfpb,
                                               Par par, int reach_bp, int rank, int world, long long* __restrict__ out,
                                               unsigned long long* __restrict__ n_items)
 {
     const int lane = threadIdx.x;
-    const long long total = (long long)K * MAX_TASKS * n_chunk_max;
     unsigned long long items = 0;
-    for (long long w = blockIdx.x; w < total; w += gridDim.x) {
-        const int chunk = (int)(w % n_chunk_max);
-        const int ti = (int)((w / n_chunk_max) % MAX_TASKS);
-        const int k = (int)(w / ((long long)n_chunk_max * MAX_TASKS));
-        const NbTables& T = tabs[k];
-        if (ti >= T.n_tasks) continue;
+    for (int k = 0; k < K; k++) {
+    const NbTables& T = tabs[k];
+    const int n_tasks = T.n_tasks, total = T.item_start[n_tasks];
+    // static sharding of the fixed, ordered item list over ranks; every wave reaches the loop exit
+    for (int w = blockIdx.x * world + rank; w < total; w += gridDim.x * world) {
+        int lo_t = 0, hi_t = n_tasks - 1; // task of item w: last task with item_start <= w
+        while (lo_t < hi_t) { const int mid = (lo_t + hi_t + 1) >> 1; if (T.item_start[mid] <= w) lo_t = mid; else hi_t = mid - 1; }
+        const int ti = lo_t, chunk = w - T.item_start[ti];
         const Task& tk = T.task[ti];
         const int np = T.hi[tk.p] - T.lo[tk.p] + 1, nq = T.hi[tk.q] - T.lo[tk.q] + 1;
-        if (chunk * 64 >= np) continue;
-        if ((w % world) != rank) continue; // static sharding of the (fixed) item grid over ranks
         items++;
         const int base_p = contig_off[T.contig[tk.p]] + T.lo[tk.p];
         const int base_q = contig_off[T.contig[tk.q]] + T.lo[tk.q];
@@ -625,6 +639,7 @@ __global__ __launch_bounds__(64) void k_mass(const NbTables* __restrict__ tabs, 
                 if (sgn != 0) atomicAdd((unsigned long long*)&out[k * N_OPS + op], (unsigned long long)(sgn * qv));
             }
         }
+    }
     }
     if (lane == 0 && items) atomicAdd(n_items, items);
 }
@@ -1021,10 +1036,8 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     }
     CK(hipEventRecord(h->ev[2], st));
     {
-        const int n_chunk_max = (n + 63) / 64;
-        const long long total = (long long)K * MAX_TASKS * n_chunk_max;
-        const int nbm = (int)std::min<long long>(total, 256 * 32);
-        k_mass<<<nbm, 64, 0, st>>>(h->tabs, K, n_chunk_max, h->perm, h->contig_off, h->geo, h->stat, h->nfpb, h->par,
+        const int nbm = std::min(std::max((n + 63) / 64 * 4, 256), 256 * 16);
+        k_mass<<<nbm, 64, 0, st>>>(h->tabs, K, h->perm, h->contig_off, h->geo, h->stat, h->nfpb, h->par,
                                     reach_bp(h), rank, world, (long long*)d_q_out, (unsigned long long*)(h->d_scalars + 11));
     }
     CK(hipEventRecord(h->ev[3], st));
@@ -1084,7 +1097,6 @@ int graal_last_counters(graal_ctx* h, int64_t out[4])
     long long res[3];
     CK(hipMemcpy(res, h->d_scalars + 10, sizeof res, hipMemcpyDeviceToHost));
     out[0] = h->nnz; out[1] = res[0]; out[2] = 0; out[3] = res[1];
-    if (res[2] & 0xffffffffll) return fail(h, GRAAL_E_STATE, "mass task table overflow");
     return GRAAL_OK;
 }
 

@@ -126,9 +126,20 @@ def make_problem(n_bins=50000, nnz=20_000_000, n_sub=1, seed=20141217, contig_we
     off_p = off_p / off_p.sum()
     off_cdf = np.cumsum(off_p)
     keys = np.zeros(0, dtype=np.int64)
-    target_cis = int(round(nnz * frac_cis))
+    # never ask for more distinct pairs than exist (tiny test problems): cap at half of each population
+    n_sub_contig = np.bincount(sub_contig).astype(np.int64)
+    max_cis = int((n_sub_contig * (n_sub_contig - 1) // 2).sum())
+    max_trans = S * (S - 1) // 2 - max_cis
+    ks = np.arange(1, kmax + 1)
+    reach_cis = int(sum(np.maximum(0, nc - ks).sum() for nc in n_sub_contig))  # pairs with offset <= kmax
+    target_cis = int(min(round(nnz * frac_cis), max_cis // 2, reach_cis // 2))
+    nnz = int(min(nnz, target_cis + max_trans // 2))
     for target, cis in ((target_cis, True), (nnz, False)):
+        guard = 0
         while len(keys) < target:
+            guard += 1
+            if guard > 10000:
+                raise RuntimeError("synthetic contact generation does not converge")
             need = target - len(keys)
             m = int(need * 1.3) + 1024
             i = rng.randint(0, S, size=m).astype(np.int64)

@@ -1,0 +1,199 @@
+"""GPU parity tests of the raw engine (C ABI via graal_amd.lib.Engine) against the oracle.
+
+Run on the MI355X box with ``pytest -m gpu``.  Everything goes through libgraal_hip.so; the oracle is only the checker.
+"""
+import numpy as np
+import pytest
+
+from graal_amd import synth
+from oracle import oracle as O
+from oracle.sparse_numpy import SparseScorer
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def make(n_sub, seed, n_bins=80, nnz=1500, accu=None, d_max=None, weights=(5, 3, 2), grid_bp=None):
+    accu = (1 if n_sub == 1 else 9) if accu is None else accu
+    par = synth.make_param_simu(fact=300.0, v_inter=0.03, d_max=d_max)
+    P = synth.make_problem(n_bins=n_bins, nnz=nnz, n_sub=n_sub, seed=seed, contig_weights=weights, mean_len_bp=1500.0,
+                           accu=accu, param=par, grid_bp=grid_bp)
+    return synth.with_dense(P)
+
+
+def engine_for(P, state=None):
+    from graal_amd.lib import Engine
+    e = Engine(0)
+    e.upload_subfrags(P["np_sub_frags_id"], P["np_sub_frags_len_bp"], P["np_sub_frags_accu"], P["init_n_sub_frags"],
+                      P["mean_squared_frags_per_bin"])
+    e.upload_contacts(P["coo_row"], P["coo_col"], P["coo_val"])
+    e.set_params(P["param_simu"])
+    e.upload_frags(state if state is not None else P["S_o_A_frags"])
+    return e
+
+
+def dense_for(P):
+    return O.DenseOracle(P["hic_matrix"], P["np_sub_frags_id"], P["np_sub_frags_len_bp"], P["np_sub_frags_accu"],
+                         P["frag_dispatcher"], P["collector_id_repeats"], P["n_frags"], P["mean_squared_frags_per_bin"],
+                         P["param_simu"], fix_trans_accu=True)
+
+
+def relabel_ref(state):
+    """cuda_lib_gl.py:1697-1722 with a stable argsort (oracle.OracleSampler.modify_gl_cuda_buffer)."""
+    idc_un, idx_un = np.unique(state["id_c"], return_index=True)
+    ordl = np.argsort(state["l_cont"][idx_un], kind="stable")
+    o2n = np.zeros(idc_un.max() + 1, np.int32)
+    o2n[idc_un[ordl]] = np.arange(len(idc_un), dtype=np.int32)
+    state["id_c"][:] = o2n[state["id_c"]]
+    return len(idc_un) - 1
+
+
+def random_state_for(P, rng, **kw):
+    n = P["n_frags"]
+    s = util.random_layout(rng, n, **kw)
+    s["len_bp"][:] = P["S_o_A_frags"]["len_bp"]
+    for lab in np.unique(s["id_c"]):
+        m = np.nonzero(s["id_c"] == lab)[0]
+        order = m[np.argsort(s["pos"][m])]
+        s["start_bp"][order] = np.cumsum(s["len_bp"][order]) - s["len_bp"][order]
+        s["l_cont_bp"][order] = s["len_bp"][order].sum()
+    return s
+
+
+def test_library_loads_on_gpu():
+    from graal_amd import lib
+    assert lib.load().graal_abi_version() == 1
+
+
+@pytest.mark.parametrize("n_sub,seed", [(1, 1), (3, 2)])
+def test_upload_download_relabel_stats(n_sub, seed):
+    P = make(n_sub, seed)
+    rng = np.random.RandomState(seed)
+    s = random_state_for(P, rng, p_circ=0.3)
+    s["id_c"][:] = s["id_c"] * 2 + 1  # sparse, non-dense labels
+    e = engine_for(P, s)
+    got = e.download_frags()
+    for k in O.FIELDS:
+        assert np.array_equal(got[k], s[k])
+    st = e.layout_stats()
+    heads = s["start_bp"] == 0
+    assert list(st) == [len(np.unique(s["id_c"])), s["l_cont"].sum(), heads.sum(), s["l_cont_bp"][heads].sum(),
+                        s["l_cont"].max(), s["l_cont"].min()]
+    max_id = e.relabel_contigs()
+    want = O.copy_state(s)
+    assert max_id == relabel_ref(want)
+    got = e.download_frags()
+    for k in O.FIELDS:
+        assert np.array_equal(got[k], want[k]), k
+
+
+@pytest.mark.parametrize("n_sub,seed", [(1, 3), (3, 4), (3, 5)])
+def test_full_likelihood(n_sub, seed):
+    P = make(n_sub, seed)
+    dense = dense_for(P)
+    sparse = SparseScorer(P["coo_row"], P["coo_col"], P["coo_val"], P["np_sub_frags_id"], P["np_sub_frags_len_bp"],
+                          P["np_sub_frags_accu"], P["mean_squared_frags_per_bin"], P["param_simu"])
+    rng = np.random.RandomState(seed)
+    states = [O.copy_state(P["S_o_A_frags"])] + [random_state_for(P, rng, p_circ=0.5) for _ in range(3)]
+    for s in states:
+        e = engine_for(P, s)
+        e.relabel_contigs()
+        got = e.eval_full()
+        want = dense.evaluate(s)
+        assert got == pytest.approx(want, rel=1e-6)          # north_star tolerance is 1e-5 relative
+        assert got == pytest.approx(sparse.full(s), rel=1e-6)
+        e.close()
+
+
+@pytest.mark.parametrize("n_sub,seed", [(1, 6), (3, 7), (3, 8), (1, 9)])
+def test_apply_move_bit_exact(n_sub, seed):
+    P = make(n_sub, seed, n_bins=40, nnz=300)
+    rng = np.random.RandomState(seed)
+    for _ in range(6):
+        s = random_state_for(P, rng, p_circ=0.4)
+        max_id = relabel_ref(s)
+        for _ in range(3):
+            fA, fB = [int(v) for v in rng.choice(P["n_frags"], 2, replace=False)]
+            for op in range(13):
+                e = engine_for(P, s)
+                assert e.apply_move(fA, fB, op, max_id) == 0
+                got = e.download_frags()
+                want, stale = util.oracle_candidate(s, fA, fB, op, max_id)
+                assert not stale
+                for k in O.FIELDS:
+                    assert np.array_equal(got[k], want[k]), (fA, fB, op, k)
+                e.close()
+
+
+def oracle_deltas(P, dense, s, fA, fBs, max_id):
+    per_pix = np.zeros(dense.n_pix)
+    base = dense.evaluate(s, per_pix)
+    n = P["n_frags"]
+    out = np.zeros((len(fBs), 13))
+    for k, fB in enumerate(fBs):
+        sub = np.nonzero((s["id_c"] == s["id_c"][fA]) | (s["id_c"] == s["id_c"][fB]))[0]
+        for op in range(13):
+            cand, stale = util.oracle_candidate(s, fA, fB, op, max_id)
+            assert not stale
+            out[k, op] = dense.sub_compute(cand, np.sort(sub), [], np.arange(n, dtype=np.int32), per_pix)
+    return base, out
+
+
+@pytest.mark.parametrize("n_sub,seed,p_circ", [(1, 11, 0.0), (1, 12, 0.5), (3, 13, 0.0), (3, 14, 0.5), (1, 15, 0.3)])
+def test_candidate_deltas(n_sub, seed, p_circ):
+    # grid_bp=2000: float32 kb coordinates are exact, so the dense oracle's values are shift invariant and the
+    # comparison is limited only by libm ulps on the pairs the engine actually re-evaluates
+    P = make(n_sub, seed, n_bins=70, nnz=1500, grid_bp=2000)
+    dense = dense_for(P)
+    rng = np.random.RandomState(seed)
+    worst = 0.0
+    for _ in range(4):
+        s = random_state_for(P, rng, n_contigs=int(rng.randint(2, 8)), p_circ=p_circ, len_grid=1)
+        max_id = relabel_ref(s)
+        e = engine_for(P, s)
+        assert e.relabel_contigs() == max_id
+        for _ in range(3):
+            fA = int(rng.randint(P["n_frags"]))
+            fBs = [int(v) for v in rng.choice(np.setdiff1d(np.arange(P["n_frags"]), [fA]), 3, replace=False)]
+            base, want = oracle_deltas(P, dense, s, fA, fBs, max_id)
+            got = e.eval_candidates(fA, fBs, max_id)
+            tol = 1e-7 * abs(base)
+            assert np.all(np.abs(got - want) <= tol), (fA, fBs, np.abs(got - want).max(), tol, got - want)
+            worst = max(worst, np.abs(got - want).max() / abs(base))
+        e.close()
+    assert worst < 1e-7
+
+
+def test_candidates_generic_coordinates_within_tolerance():
+    """Arbitrary bp lengths: the dense float32 reference carries coordinate rounding noise on pairs whose geometry a
+    move does not change; the engine treats those as exactly unchanged.  Agreement stays far inside 1e-5 of logL."""
+    P = make(3, 21, n_bins=70, nnz=1500)
+    dense = dense_for(P)
+    rng = np.random.RandomState(21)
+    s = random_state_for(P, rng, n_contigs=4, p_circ=0.2)
+    max_id = relabel_ref(s)
+    e = engine_for(P, s)
+    e.relabel_contigs()
+    for _ in range(4):
+        fA = int(rng.randint(P["n_frags"]))
+        fBs = [int(v) for v in rng.choice(np.setdiff1d(np.arange(P["n_frags"]), [fA]), 4, replace=False)]
+        base, want = oracle_deltas(P, dense, s, fA, fBs, max_id)
+        got = e.eval_candidates(fA, fBs, max_id)
+        assert np.all(np.abs(got - want) <= 1e-5 * abs(base))
+
+
+def test_engine_errors_are_loud():
+    from graal_amd.lib import Engine, GraalError
+    e = Engine(0)
+    with pytest.raises(GraalError):
+        e.eval_full()
+    with pytest.raises(GraalError):
+        e.set_params([1, 9.6, 0.1, -1.5, 3, 100, 10, 0.0])  # v_inter must be > 0
+    P = make(1, 1, n_bins=20, nnz=50)
+    bad = O.copy_state(P["S_o_A_frags"])
+    bad["rep"][3] = 1
+    e.upload_subfrags(P["np_sub_frags_id"], P["np_sub_frags_len_bp"], P["np_sub_frags_accu"], P["init_n_sub_frags"], 1.0)
+    with pytest.raises(GraalError):
+        e.upload_frags(bad)
+    with pytest.raises(GraalError):
+        e.upload_contacts([3], [3], [1])  # row < col required
