@@ -170,10 +170,10 @@ __global__ void k_refresh_geo(SoaPtr s, Geo* __restrict__ geo, int n)
 }
 
 // out: [0] #heads (pos==0) [1] sum l_cont [2] #(start_bp==0) [3] sum l_cont_bp over start_bp==0 [4] max l_cont
-//      [5] min l_cont [6] #(rep != 0 or activ != 1 or id_d != f)  [7] max label
+//      [5] min l_cont [6] #(rep != 0 or activ != 1 or id_d != f)  [7] max label  [14] #(circ == 1)
 __global__ void k_stats(SoaPtr s, int n, long long* __restrict__ out)
 {
-    long long heads = 0, sl = 0, nst = 0, sbp = 0, mx = 0, mn = 0x7fffffff, bad = 0, mlab = -1;
+    long long heads = 0, sl = 0, nst = 0, sbp = 0, mx = 0, mn = 0x7fffffff, bad = 0, mlab = -1, ncirc = 0;
     for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < n; f += gridDim.x * blockDim.x) {
         const int lc = s.p[F_LCONT][f];
         heads += s.p[F_POS][f] == 0;
@@ -182,12 +182,13 @@ __global__ void k_stats(SoaPtr s, int n, long long* __restrict__ out)
         mx = lc > mx ? lc : mx;
         mn = lc < mn ? lc : mn;
         bad += (s.p[F_REP][f] != 0) || (s.p[F_ACTIV][f] != 1) || (s.p[F_IDD][f] != f);
+        ncirc += s.p[F_CIRC][f] == 1;
         const int c = s.p[F_IDC][f];
         mlab = c > mlab ? c : mlab;
     }
     for (int o = 32; o > 0; o >>= 1) {
         heads += __shfl_down(heads, o, 64); sl += __shfl_down(sl, o, 64); nst += __shfl_down(nst, o, 64);
-        sbp += __shfl_down(sbp, o, 64); bad += __shfl_down(bad, o, 64);
+        sbp += __shfl_down(sbp, o, 64); bad += __shfl_down(bad, o, 64); ncirc += __shfl_down(ncirc, o, 64);
         const long long a = __shfl_down(mx, o, 64), b = __shfl_down(mn, o, 64), c = __shfl_down(mlab, o, 64);
         mx = a > mx ? a : mx; mn = b < mn ? b : mn; mlab = c > mlab ? c : mlab;
     }
@@ -200,6 +201,7 @@ __global__ void k_stats(SoaPtr s, int n, long long* __restrict__ out)
         atomicMin((long long*)&out[5], mn);
         atomicAdd((unsigned long long*)&out[6], (unsigned long long)bad);
         atomicMax((long long*)&out[7], mlab);
+        atomicAdd((unsigned long long*)&out[14], (unsigned long long)ncirc);
     }
 }
 
@@ -923,19 +925,21 @@ int graal_download_frags(graal_ctx* h, int32_t* const soa[GRAAL_N_FIELDS])
     return GRAAL_OK;
 }
 
-int graal_layout_stats(graal_ctx* h, int64_t out[6])
+int graal_layout_stats(graal_ctx* h, int64_t out[8])
 {
     if (!h || !out) return GRAAL_E_ARG;
     if (!h->have_frags) return fail(h, GRAAL_E_STATE, "no fragments uploaded");
     CK(hipSetDevice(h->device));
     long long init[8] = {0, 0, 0, 0, 0, 0x7fffffff, 0, -1};
     CK(hipMemcpyAsync(h->d_scalars, init, sizeof init, hipMemcpyHostToDevice, h->stream));
+    CK(hipMemsetAsync(h->d_scalars + 14, 0, sizeof(long long), h->stream));
     k_stats<<<std::min(blocks_for(h->n, 256), 512), 256, 0, h->stream>>>(h->soa[h->cur], h->n, h->d_scalars);
     CK(hipGetLastError());
-    long long res[8];
+    long long res[16];
     CK(hipMemcpyAsync(res, h->d_scalars, sizeof res, hipMemcpyDeviceToHost, h->stream));
     CK(hipStreamSynchronize(h->stream));
     out[0] = res[0]; out[1] = res[1]; out[2] = res[2]; out[3] = res[3]; out[4] = res[4]; out[5] = res[5];
+    out[6] = res[14]; out[7] = 0;
     h->n_contigs = (int)res[0];
     return GRAAL_OK;
 }

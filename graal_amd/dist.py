@@ -1,0 +1,64 @@
+"""Multi-GPU glue: one process per GPU, the COO contact list sharded by rank, ONE all-reduce of the per-candidate
+Q vector (13*K int64) per MCMC step.  The reference has no distributed path; its only hint is
+the comment "place where we want to spread the workload accross the network!" at ``cuda_lib_gl.py:1886``.
+
+Because every log-likelihood contribution is an int64 fixed-point number, the all-reduced vector is bit-identical
+for any number of ranks: every rank then draws the same move from its own (identically seeded) RandomState and no
+broadcast of the decision is needed.
+"""
+import os
+
+import numpy as np
+
+
+def env_world():
+    """(rank, world, local_rank) from the torchrun environment (1 process per GPU)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def shard_range(nnz, rank, world):
+    """Contiguous, equal-nnz slice [lo, hi) of the (row, col)-sorted contact list owned by `rank`."""
+    nnz, rank, world = int(nnz), int(rank), int(world)
+    assert world >= 1 and 0 <= rank < world
+    return (nnz * rank) // world, (nnz * (rank + 1)) // world
+
+
+class Group:
+    """Thin wrapper over torch.distributed (RCCL for CUDA tensors, gloo for CPU tensors); world == 1 needs no
+    process group at all."""
+
+    def __init__(self, rank=0, world=1):
+        self.rank, self.world = int(rank), int(world)
+        if self.world > 1:
+            import torch.distributed as td
+            if not td.is_initialized():
+                raise RuntimeError("torch.distributed must be initialised before building a multi-rank sampler")
+            assert td.get_world_size() == self.world and td.get_rank() == self.rank
+
+    def all_reduce_sum_(self, tensor):
+        """In-place SUM all-reduce of an int64 tensor (device tensor -> RCCL over xGMI)."""
+        if self.world > 1:
+            import torch.distributed as td
+            td.all_reduce(tensor, op=td.ReduceOp.SUM)
+        return tensor
+
+    def all_reduce_sum_int(self, value):
+        """All-reduce one Python int (used for the contact part of the full likelihood)."""
+        if self.world == 1:
+            return int(value)
+        import torch
+        import torch.distributed as td
+        dev = "cuda" if td.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([int(value)], dtype=torch.int64, device=dev)
+        td.all_reduce(t, op=td.ReduceOp.SUM)
+        return int(t.cpu()[0])
+
+    def barrier(self):
+        if self.world > 1:
+            import torch.distributed as td
+            td.barrier()
+
+
+def q_to_float(q):
+    return np.asarray(q, dtype=np.int64).astype(np.float64) / float(1 << 30)

@@ -149,7 +149,7 @@ class Engine:
         return int(m.value)
 
     def layout_stats(self):
-        out = np.zeros(6, dtype=np.int64)
+        out = np.zeros(8, dtype=np.int64)
         self._ck(self._L.graal_layout_stats(self._h, out.ctypes.data_as(_i64p)), "graal_layout_stats")
         return out
 

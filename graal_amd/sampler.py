@@ -1,0 +1,430 @@
+"""``sampler`` -- drop-in for ``cuda_lib_gl.sampler`` on the ``start_EM`` path, over the MI355X engine.
+
+Same constructor (the 30 positional arguments of ``cuda_lib_gl.py:33-42``, as ``simulation_loader.py:92-107``
+passes them), same method names, argument orders and return tuples for everything ``simulation_loader.py`` and
+``main_gl.py`` use.  What changed underneath:
+
+* no PyCUDA / OpenGL: a ctypes handle on ``libgraal_hip.so`` (``graal_amd/lib.py``); ``gl_window`` may be ``None``
+  and the display-only methods are no-ops;
+* the two contact matrices may be scipy sparse matrices or COO triples; nothing is densified
+  (``simulation_loader.py:81-82`` is what is NOT reproduced);
+* one MCMC step = relabel + ONE fused scan of the contact list for all 13*K candidates + one commit, instead of
+  ~42 launches and ~58 blocking syncs per neighbour;
+* the step's full likelihood is carried over from the accepted candidate instead of being recomputed by a full
+  dense pass every step (``cuda_lib_gl.py:1828-1848``); ``init_likelihood()`` and circular-contig events resync it;
+* the numpy RNG is an explicit ``RandomState`` (``rng=``); ``None`` keeps the reference's global ``np.random``;
+  every ``argsort`` is stable.
+
+Not supported yet (loud ``NotImplementedError``): repeated fragments and blacklisted contigs.
+"""
+import numpy as np
+
+from . import dist as gdist
+from .gpustruct import GPUStruct
+from .lib import FIELDS, MAX_NEIGHBOURS, N_OPS, Q_SCALE, Engine
+
+N_TMP_STRUCT = N_OPS  # cuda_lib_gl.py:112
+MODIFICATION_STR = ['eject frag', 'flip frag',
+                    'pop out split insert @ left or 1', 'pop out split insert @ left or -1',
+                    'pop out split insert @ right or 1', 'pop out split insert @ right or -1',
+                    'pop out insert @ right or 1', 'pop out insert @ right or -1', 'swap activity',
+                    'transloc_1', 'transloc_2', 'transloc_3', 'transloc_4']  # cuda_lib_gl.py:403-411
+
+
+# --------------------------------------------------------------------------------- host-side pure functions
+def as_coo_upper(m):
+    """(row, col, val) with row < col, sorted by (row, col), from a dense array, a scipy sparse matrix (either the
+    upper triangle or the symmetrised ``csr + csr.T`` of ``simulation_loader.py:81-82``) or a COO triple."""
+    if isinstance(m, (tuple, list)) and len(m) == 3:
+        r, c, v = (np.asarray(x) for x in m)
+    elif hasattr(m, "tocoo"):
+        coo = m.tocoo()
+        r, c, v = coo.row, coo.col, coo.data
+    else:
+        a = np.asarray(m)
+        r, c = np.nonzero(np.triu(a, k=1))
+        v = a[r, c]
+    r = np.asarray(r, dtype=np.int64)
+    c = np.asarray(c, dtype=np.int64)
+    keep = (r < c) & (np.asarray(v) != 0)  # the diagonal is zeroed by the reference (cuda_lib_gl.py:157-160)
+    r, c, v = r[keep], c[keep], np.asarray(v)[keep]
+    order = np.lexsort((c, r))
+    return r[order].astype(np.int32), c[order].astype(np.int32), v[order]
+
+
+def neighbour_distributions(bin_row, bin_col, bin_val, n_frags, n_neighbors=10, fact=3):
+    """``setup_distri_frags`` (``cuda_lib_gl.py:2363-2390``) from the bin-level COO list instead of dense rows:
+    for every bin the ``n_neighbors`` columns that come last in a stable ascending sort of its row (i.e. value
+    descending, ties by index descending; zero columns, the bin itself included, fill up short rows) and
+    ``pk`` proportional to count**3 in float32 (uniform if the row is empty)."""
+    n = int(n_frags)
+    r = np.concatenate([bin_row, bin_col]).astype(np.int64)
+    c = np.concatenate([bin_col, bin_row]).astype(np.int64)
+    v = np.concatenate([bin_val, bin_val]).astype(np.float32)
+    order = np.lexsort((-c, -v.astype(np.float64), r))
+    r, c, v = r[order], c[order], v[order]
+    start = np.searchsorted(r, np.arange(n), side="left")
+    end = np.searchsorted(r, np.arange(n), side="right")
+    k = min(n_neighbors, n)
+    xk = np.zeros((n, k), dtype=np.int32)
+    pk = np.zeros((n, k), dtype=np.float32)
+    for i in range(n):
+        cols = c[start[i]:min(end[i], start[i] + k)]
+        vals = v[start[i]:min(end[i], start[i] + k)]
+        if len(cols) < k:  # pad with zero-valued columns, largest index first
+            have = set(int(x) for x in c[start[i]:end[i]])
+            pad = []
+            j = n - 1
+            while len(cols) + len(pad) < k and j >= 0:
+                if j not in have:
+                    pad.append(j)
+                j -= 1
+            cols = np.concatenate([cols, np.asarray(pad, dtype=np.int64)])
+            vals = np.concatenate([vals, np.zeros(len(pad), dtype=np.float32)])
+        dat = vals.astype(np.float32) ** fact
+        if dat.sum() > 0:
+            p = dat / dat.sum()
+        else:
+            tmp = np.ones_like(dat, dtype=np.float32)
+            p = tmp / tmp.sum()
+        xk[i] = cols
+        pk[i] = p
+    return xk, pk
+
+
+def select_move(score, n_tmp_struct, rng, F_t=1.0):
+    """Score post-processing and sampling of ``step_max_likelihood`` (``cuda_lib_gl.py:1898-1947``): duplicate
+    eject / flip entries of neighbours >= 1 are zeroed, scores are shifted to ``max - 30`` and the move is drawn
+    with probability LINEAR in that shifted score.  Returns (sample_out, or_score[sample_out])."""
+    score = np.asarray(score, dtype=np.float64)
+    scores_2_remove = []
+    scores_2_remove.extend(range(n_tmp_struct, len(score), n_tmp_struct))      # remove extra pop
+    scores_2_remove.extend(range(n_tmp_struct + 1, len(score), n_tmp_struct))  # remove extra flip
+    id_max = score.argmax()
+    or_score = np.copy(score)
+    filtered_score = score - score.min()
+    filtered_score[scores_2_remove] = 0
+    max_score = filtered_score.max()
+    thresh_overflow = 30
+    filtered_score = filtered_score - (max_score - thresh_overflow)
+    filtered_score[filtered_score < 0] = 0
+    id_ok_4_sampling = np.ix_(filtered_score > 0)
+    sub_score = filtered_score[id_ok_4_sampling]
+    sub_score = sub_score / sub_score.sum()
+    sub_score[sub_score > 0] = np.power(sub_score[sub_score > 0], 1. / F_t)
+    sub_score = sub_score / sub_score.sum()
+    if len(id_ok_4_sampling[0]) == 1 or len(id_ok_4_sampling[0]) == 0:
+        sample_out = id_max
+    else:
+        sample_out = rng.choice(id_ok_4_sampling[0], 1, p=sub_score)[0]
+    return int(sample_out), float(or_score[sample_out])
+
+
+def dist_inter_genome(prev, nxt, ori, id_d, init_prev, init_next, init_ori, orientable, counted, n_frags_4_dist):
+    """``dist_inter_genome`` (``cuda_lib_gl.py:475-541``) vectorised; every term is a multiple of 0.5, so the
+    float64 result is identical to the reference's sequential loop."""
+    n = len(prev)
+    d = 3.0 * (n - n_frags_4_dist)
+    norm_distance = 3.0 * (n - n_frags_4_dist)
+    prev_t1 = np.where(prev != -1, id_d[np.maximum(prev, 0)], -1)
+    next_t1 = np.where(nxt != -1, id_d[np.maximum(nxt, 0)], -1)
+    p0, n0 = init_prev, init_next
+    both = ((prev_t1 == p0) & (next_t1 == n0)) | ((prev_t1 == n0) & (next_t1 == p0))
+    d -= float(np.count_nonzero(both & counted))
+    ob = counted & (orientable != 0)
+    flipped = ob & (init_ori != ori)
+    p1 = np.where(flipped, next_t1, prev_t1)
+    n1 = np.where(flipped, prev_t1, next_t1)
+    swap = np.where(flipped, -1, 1)
+    for t0, t1 in ((p0, p1), (n0, n1)):
+        m = ob & (t0 == t1)
+        is_end = m & (t0 == -1)
+        idx = np.maximum(t1, 0)
+        not_or = m & ~is_end & (orientable[idx] == 0)
+        half = m & ~is_end & ~not_or
+        same_ori = half & (init_ori[np.maximum(t0, 0)] == swap * ori[idx])
+        d -= float(np.count_nonzero(is_end)) + float(np.count_nonzero(not_or))
+        d -= 0.5 * float(np.count_nonzero(half)) + 0.5 * float(np.count_nonzero(same_ori))
+    nb = counted & (orientable == 0)
+    d -= float(np.count_nonzero(nb & ((prev_t1 == p0) | (prev_t1 == n0))))
+    d -= float(np.count_nonzero(nb & ((next_t1 == n0) | (next_t1 == p0))))
+    return d / norm_distance
+
+
+def _as_table(a, width, dtype):
+    """int4 / float3 / int3 structured arrays of simulation_loader.py:60-63 -> plain [n, width] arrays."""
+    a = np.asarray(a)
+    if a.dtype.fields is not None:
+        names = list(a.dtype.names)[:width]
+        a = np.stack([a[k] for k in names], axis=1)
+    return np.ascontiguousarray(a.reshape(-1, width), dtype=dtype)
+
+
+# --------------------------------------------------------------------------------- the sampler
+class sampler(object):
+    def __init__(self, use_rippe, S_o_A_frags, collector_id_repeats, frag_dispatcher,
+                 id_frag_duplicated, id_frags_blacklisted,
+                 n_frags, n_new_frags, init_n_sub_frags, n_new_sub_frags, np_rep_sub_frags_id,
+                 hic_matrix_sub_sampled,
+                 np_sub_frags_len_bp, np_sub_frags_id, np_sub_frags_accu,
+                 mean_squared_frags_per_bin, norm_vect_accu,
+                 S_o_A_sub_frags,
+                 hic_matrix, mean_value_trans, n_iterations, is_simu, gl_window=None, pos_vbo=None, col_vbo=None,
+                 vel=None, pos=None, raw_im_init=None, pbo_im_buffer=None, sub_sample_factor=0,
+                 device=None, rng=None, group=None, param_simu=None, compute_dist=True):
+        self.o = 0
+        self.use_rippe = use_rippe
+        self.gl_window = gl_window
+        self.sub_sample_factor = sub_sample_factor
+        self.n_iterations = n_iterations
+        self.is_simu = is_simu
+        self.rng = np.random if rng is None else rng
+        self.compute_dist = compute_dist
+        self.id_frags_blacklisted = list(id_frags_blacklisted) if id_frags_blacklisted is not None else []
+        self.id_frag_duplicated = list(id_frag_duplicated) if id_frag_duplicated is not None else []
+        if len(self.id_frag_duplicated) or int(n_new_frags) != int(n_frags):
+            raise NotImplementedError("repeated fragments (allow_repeats) are not supported by the MI355X engine yet")
+        if len(self.id_frags_blacklisted):
+            raise NotImplementedError("blacklisted contigs are not supported by the MI355X engine yet")
+        self.np_id_frag_duplicated = np.int32(self.id_frag_duplicated)
+        self.n_frags = np.int32(n_frags)
+        self.n_new_frags = np.int32(n_new_frags)
+        self.init_n_sub_frags = np.int32(init_n_sub_frags)
+        self.n_new_sub_frags = np.int32(n_new_sub_frags)
+        self.uniq_frags = np.arange(0, self.n_frags, dtype=np.int32)
+        self.n_frags_uniq = np.int32(len(self.uniq_frags))
+        self.n_tmp_struct = N_TMP_STRUCT
+        self.n_modif_metropolis = N_TMP_STRUCT
+        self.modification_str = list(MODIFICATION_STR)
+        self.norm_vect_accu = norm_vect_accu
+        self.mean_squared_frags_per_bin = np.float32(mean_squared_frags_per_bin)
+        self.mean_value_trans = mean_value_trans
+        self.S_o_A_frags = S_o_A_frags
+        self.S_o_A_sub_frags = S_o_A_sub_frags
+        self.collector_id_repeats = np.ascontiguousarray(collector_id_repeats, dtype=np.int32)
+        self.frag_dispatcher = _as_table(frag_dispatcher, 2, np.int32)
+        self.np_sub_frags_id = _as_table(np_sub_frags_id, 4, np.int32)
+        self.np_sub_frags_len_bp = _as_table(np_sub_frags_len_bp, 3, np.float32)
+        self.np_sub_frags_accu = _as_table(np_sub_frags_accu, 3, np.int32)
+        self.param_simu_rippe = np.dtype([('kuhn', np.float32), ('lm', np.float32), ('c1', np.float32),
+                                          ('slope', np.float32), ('d', np.float32), ('l_max', np.float32),
+                                          ('fact', np.float32), ('v_inter', np.float32)], align=True)
+        self.param_simu_T = self.param_simu_rippe
+        # ---- contacts: COO, never dense ------------------------------------------------------------------
+        self.sub_coo = as_coo_upper(hic_matrix)                 # sub-level (observed data of the likelihood)
+        self.bin_coo = as_coo_upper(hic_matrix_sub_sampled)     # bin level (neighbour proposal only)
+        self.sub_n_frags = self.init_n_sub_frags
+        # ---- device ------------------------------------------------------------------------------------------
+        if group is None:
+            rank, world, local = gdist.env_world()
+            group = gdist.Group(rank, world) if world > 1 else gdist.Group(0, 1)
+            if device is None:
+                device = local if world > 1 else 0
+        self.group = group
+        self.engine = Engine(0 if device is None else int(device))  # raises if the HIP library / GPU is missing
+        self.engine.upload_subfrags(self.np_sub_frags_id, self.np_sub_frags_len_bp, self.np_sub_frags_accu,
+                                    int(self.init_n_sub_frags), float(self.mean_squared_frags_per_bin))
+        lo, hi = gdist.shard_range(len(self.sub_coo[0]), group.rank, group.world)
+        counts = np.asarray(self.sub_coo[2])
+        if not np.all(counts == np.round(counts)):
+            raise NotImplementedError("non-integer contact counts (blacklist fill) are not supported yet")
+        self.engine.upload_contacts(self.sub_coo[0][lo:hi], self.sub_coo[1][lo:hi], counts[lo:hi].astype(np.int32))
+        n = int(self.n_new_frags)
+        soa = {k: np.array(S_o_A_frags[k], dtype=np.int32, copy=True) for k in FIELDS if k != "ori"}
+        soa["ori"] = np.ones((n,), dtype=np.int32)  # cuda_lib_gl.py:244,259
+        self.gpu_vect_frags = GPUStruct(self.engine, soa)
+        self.gpu_vect_frags.copy_to_gpu()
+        self.np_init_prev = np.copy(soa["prev"])
+        self.np_init_next = np.copy(soa["next"])
+        self.np_init_ori = np.ones((n,), dtype=np.int32)
+        self.np_init_orientable = (self.np_sub_frags_id[soa["id_d"], 3] > 1).astype(np.int32)
+        self.id_d = np.copy(soa["id_d"])
+        self._single_sub = bool(np.all(self.np_sub_frags_id[:, 3] == 1))
+        self._n_circ_prev = int((soa["circ"] == 1).sum())
+        self._d_q = None
+        # ---- proposal ----------------------------------------------------------------------------------------
+        self.n_neighbors = 10  # cuda_lib_gl.py:444
+        self.setup_distri_frags()
+        self.define_repeats()
+        self.param_simu = None
+        self.bins = np.zeros(0)
+        self.likelihood_t = None
+        self.n_stale_paste = 0
+        if param_simu is not None:
+            self.set_param_simu(param_simu)
+
+    # ------------------------------------------------------------------ parameters
+    def set_param_simu(self, p):
+        """param_simu as the structured array of ``cuda_lib_gl.py:1213`` (or 8 plain floats)."""
+        a = np.asarray(p)
+        if a.dtype.fields is not None:
+            flat = np.array([a[k][0] if a.shape else a[k] for k in a.dtype.names], dtype=np.float32)
+        else:
+            flat = a.astype(np.float32).reshape(8)
+        self.param_simu = np.array([tuple(flat)], dtype=self.param_simu_rippe)
+        self._param_flat = flat
+        self.engine.set_params(flat)
+
+    def setup_rippe_parameters(self, param, d_max):
+        kuhn, lm, slope, d, fact = param
+        kuhn = np.float32(kuhn)
+        lm = np.float32(lm)
+        c1 = np.float32((0.53 * np.power(lm / kuhn, slope)) * np.power(kuhn, -3))
+        return np.array([(kuhn, lm, c1, np.float32(slope), np.float32(d), np.float32(d_max), np.float32(fact),
+                          self.mean_value_trans)], dtype=self.param_simu_rippe)
+
+    def estimate_parameters(self, max_dist_kb, size_bin_kb):
+        """``cuda_lib_gl.py:1229-1294``: histogram of sub-level cis contacts vs genomic distance (a pass over the COO
+        list plus the count of zero pairs per distance bin, instead of the reference's O(S^2) Python double loop),
+        log-space least squares, fsolve for d_max."""
+        from . import rippe_fit
+        self.bins = np.arange(size_bin_kb, max_dist_kb + size_bin_kb, size_bin_kb)
+        self.mean_contacts = rippe_fit.mean_contacts_per_bin(self.S_o_A_sub_frags, self.sub_coo, self.bins, max_dist_kb,
+                                                             size_bin_kb)
+        p, self.y_estim = rippe_fit.estimate_param_rippe(self.mean_contacts, self.bins)
+        estim_max_dist = rippe_fit.estimate_max_dist_intra(p, self.mean_value_trans)
+        self.set_param_simu(self.setup_rippe_parameters(p, estim_max_dist))
+
+    # ------------------------------------------------------------------ display-only surface (no-ops)
+    def setup_texture(self):
+        self.data = None
+
+    def load_gl_cuda_vbo(self):
+        pass
+
+    def load_gl_cuda_tex_buffer(self, im_init):
+        pass
+
+    def display_current_matrix(self, file=None):
+        """Fragment order by contig (``cuda_lib_gl.py:1581-1624``); the TIFF dump is dropped (display only)."""
+        self.gpu_vect_frags.copy_from_gpu()
+        c = self.gpu_vect_frags
+        dict_contig, full_order, full_order_high = dict(), [], []
+        for k in np.unique(c.id_c):
+            id_pos = np.nonzero(c.id_c == k)[0]
+            dict_contig[k] = []
+            if np.all(c.activ[id_pos] == 1):
+                ordered_frag = c.id_d[id_pos[np.argsort(c.pos[id_pos], kind="stable")]]
+                dict_contig[k].extend(ordered_frag)
+                full_order.extend(ordered_frag)
+                for i in ordered_frag:
+                    v = list(self.np_sub_frags_id[i])
+                    id_2_push = v[:v[3]]
+                    if c.ori[i] == -1:
+                        id_2_push.reverse()
+                    full_order_high.extend(id_2_push)
+        return full_order, dict_contig, full_order_high
+
+    def free_gpu(self):
+        self.engine.close()
+
+    # ------------------------------------------------------------------ likelihood
+    def _full_likelihood(self):
+        q = self.engine.eval_full_q()
+        return float(self.group.all_reduce_sum_int(int(q[0])) + int(q[1])) / Q_SCALE
+
+    def eval_likelihood(self):
+        self.engine.relabel_contigs()
+        return self._full_likelihood()
+
+    def init_likelihood(self):
+        self.likelihood_t = self.eval_likelihood()
+
+    def _candidate_deltas(self, id_fA, id_neighbours, max_id):
+        """float64 [K, 13]; one fused scan per group of <= 8 neighbours, one all-reduce per scan when sharded."""
+        if self.group.world == 1:
+            return self.engine.eval_candidates(id_fA, id_neighbours, max_id)
+        import torch
+        out = np.zeros((len(id_neighbours), N_OPS), dtype=np.float64)
+        if self._d_q is None:
+            self._d_q = torch.zeros(MAX_NEIGHBOURS * N_OPS, dtype=torch.int64, device="cuda:%d" % self.engine.device)
+        stream = torch.cuda.current_stream(self.engine.device).cuda_stream
+        for k0 in range(0, len(id_neighbours), MAX_NEIGHBOURS):
+            part = id_neighbours[k0:k0 + MAX_NEIGHBOURS]
+            self.engine.eval_candidates_q_async(id_fA, part, max_id, self._d_q.data_ptr(), stream,
+                                                self.group.rank, self.group.world)
+            self.group.all_reduce_sum_(self._d_q)
+            q = self._d_q[:len(part) * N_OPS].cpu().numpy()
+            out[k0:k0 + len(part)] = gdist.q_to_float(q).reshape(len(part), N_OPS)
+        return out
+
+    # ------------------------------------------------------------------ layout maintenance
+    def modify_gl_cuda_buffer(self, id_fi, dt=0):
+        """Contig relabel half of ``cuda_lib_gl.py:1695-1788`` (+ ``kernels3.cu:3848-3851``); returns max_id."""
+        return np.int32(self.engine.relabel_contigs())
+
+    def test_copy_struct(self, id_fA, id_f_sampled, mode, max_id):
+        self.n_stale_paste += self.engine.apply_move(id_fA, id_f_sampled, mode, max_id)
+        self.likelihood_t = None  # a layout change outside step_max_likelihood: re-evaluate before the next step
+
+    def explode_genome(self, dt=0):
+        """``cuda_lib_gl.py:1539-1556``: eject every fragment in index order (relabel before each)."""
+        for i in range(0, int(self.n_new_frags)):
+            max_id = self.modify_gl_cuda_buffer(i, dt)
+            self.test_copy_struct(i, 0, 0, max_id)
+
+    def define_repeats(self):
+        self.is_repeat = [False] * int(self.n_new_frags)
+        self.n_frags_duplicated = 0
+        self.n_frags_4_dist = len(np.unique(self.id_frags_blacklisted))
+
+    def dist_inter_genome(self, tmp_gpu_vect_frags=None):
+        g = self.gpu_vect_frags if tmp_gpu_vect_frags is None else tmp_gpu_vect_frags
+        g.copy_from_gpu()
+        counted = np.ones(int(self.n_new_frags), dtype=bool)
+        return dist_inter_genome(g.prev, g.next, g.ori, g.id_d, self.np_init_prev, self.np_init_next, self.np_init_ori,
+                                 self.np_init_orientable, counted, self.n_frags_4_dist)
+
+    def temperature(self, t, n_step):
+        return 1.0  # cuda_lib_gl.py:2602
+
+    # ------------------------------------------------------------------ proposal
+    def setup_distri_frags(self):
+        xk, pk = neighbour_distributions(self.bin_coo[0], self.bin_coo[1], self.bin_coo[2], int(self.n_frags),
+                                         self.n_neighbors)
+        self.distri_frags = {"xk": xk, "pk": pk}
+
+    def return_neighbours(self, id_fA, delta0):
+        """``cuda_lib_gl.py:2295-2331`` (no repeats, no blacklist: the expansion loops are identities)."""
+        ori_id = self.id_d[id_fA]
+        delta = min(self.n_neighbors, delta0)
+        distri = self.distri_frags["pk"][ori_id]
+        n_max_candidates = min(delta, np.nonzero(distri != 0)[0].shape[0])
+        init_id = self.rng.choice(self.distri_frags["xk"][ori_id], n_max_candidates, p=distri, replace=False)
+        return [int(x) for x in init_id]
+
+    # ------------------------------------------------------------------ one MCMC step
+    def step_max_likelihood(self, id_fA, delta, size_block=512, dt=0, t=0, n_step=1):
+        """``cuda_lib_gl.py:1793-1980``.  Returns (o, n_contigs, min_len, mean_len_bp, max_len, op_sampled,
+        id_f_sampled, dist, F_t)."""
+        id_fA = int(id_fA)
+        st = self.engine.layout_stats()
+        n_circ = int(st[6])
+        max_id = self.modify_gl_cuda_buffer(id_fA, dt)
+        n_contigs = int(st[0])
+        mean_len_bp = float(st[3]) / float(st[2])
+        max_len = np.int32(st[4])
+        min_len = np.int32(st[5])
+        if self.likelihood_t is None:
+            self.likelihood_t = self._full_likelihood()
+        elif (n_circ or self._n_circ_prev) and not self._single_sub:
+            # candidate deltas never include a bin's own pixel (as in the reference); those pixels only change with
+            # the circular model, so resynchronise the carried-over total whenever circular contigs are around
+            self.likelihood_t = self._full_likelihood()
+        self._n_circ_prev = n_circ
+        likelihood_t = self.likelihood_t
+        id_neighbours = self.return_neighbours(id_fA, delta)
+        n_neighbours = len(id_neighbours)
+        id_neighbours.sort()
+        self.last_neighbours = list(id_neighbours)
+        deltas = self._candidate_deltas(id_fA, id_neighbours, max_id)
+        self.score = (deltas + likelihood_t).reshape(n_neighbours * self.n_tmp_struct)
+        F_t = self.temperature(t, n_step)
+        sample_out, o = select_move(self.score, self.n_tmp_struct, self.rng, F_t)
+        id_f_sampled = id_neighbours[sample_out // self.n_tmp_struct]
+        op_sampled = sample_out % self.n_tmp_struct
+        self.test_copy_struct(id_fA, id_f_sampled, op_sampled, max_id)
+        self.o = o
+        dist = self.dist_inter_genome() if self.compute_dist else 0.0
+        self.likelihood_t = o
+        return o, n_contigs, min_len, mean_len_bp, max_len, op_sampled, id_f_sampled, dist, F_t

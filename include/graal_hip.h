@@ -73,8 +73,8 @@ int graal_relabel_contigs(graal_ctx* h, int32_t* max_id);
 
 /* layout statistics step_max_likelihood returns (cuda_lib_gl.py:1809-1816):
  * out[0]=n_contigs out[1]=sum(l_cont) out[2]=#(start_bp==0) out[3]=sum(l_cont_bp | start_bp==0)
- * out[4]=max(l_cont) out[5]=min(l_cont) */
-int graal_layout_stats(graal_ctx* h, int64_t out[6]);
+ * out[4]=max(l_cont) out[5]=min(l_cont) out[6]=#(circ==1) out[7]=reserved(0) */
+int graal_layout_stats(graal_ctx* h, int64_t out[8]);
 
 /* full log-likelihood of the current layout over this rank's contact shard, as Q fixed point:
  *   q_out[0] = sum over contacts of ob*log(ex) - log-factorial term   (shard dependent)

@@ -236,7 +236,10 @@ class OracleSampler:
                                p["np_sub_frags_accu"], self.frag_dispatcher, self.collector_id_repeats,
                                int(self.n_frags), p["mean_squared_frags_per_bin"], p["param_simu"],
                                fix_trans_accu=fix_trans_accu)
-        self.param_simu = np.asarray(p["param_simu"], dtype=np.float32)
+        self.param_simu_rippe = np.dtype([('kuhn', np.float32), ('lm', np.float32), ('c1', np.float32),
+                                          ('slope', np.float32), ('d', np.float32), ('l_max', np.float32),
+                                          ('fact', np.float32), ('v_inter', np.float32)], align=True)  # cuda_lib_gl.py:136
+        self.param_simu = np.array([tuple(np.asarray(p["param_simu"], dtype=np.float32))], dtype=self.param_simu_rippe)
         # initial state, cuda_lib_gl.py:226-262
         self.np_init_prev = np.copy(np.int32(S["prev"]))
         self.np_init_next = np.copy(np.int32(S["next"]))

@@ -78,7 +78,7 @@ def test_upload_download_relabel_stats(n_sub, seed):
     st = e.layout_stats()
     heads = s["start_bp"] == 0
     assert list(st) == [len(np.unique(s["id_c"])), s["l_cont"].sum(), heads.sum(), s["l_cont_bp"][heads].sum(),
-                        s["l_cont"].max(), s["l_cont"].min()]
+                        s["l_cont"].max(), s["l_cont"].min(), (s["circ"] == 1).sum(), 0]
     max_id = e.relabel_contigs()
     want = O.copy_state(s)
     assert max_id == relabel_ref(want)

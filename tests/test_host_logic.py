@@ -1,0 +1,131 @@
+"""CPU: the product's host-side pure functions (graal_amd/sampler.py) against the oracle's literal restatement of
+cuda_lib_gl.py (oracle/oracle.py), plus the multi-GPU glue.  No engine, no GPU."""
+import numpy as np
+import pytest
+
+from graal_amd import dist as gdist
+from graal_amd import sampler as S
+from graal_amd import synth
+from oracle import oracle as O
+from tests import util
+
+
+def problem(n_sub=3, seed=5, n_bins=90, nnz=1200):
+    par = synth.make_param_simu(fact=200.0, v_inter=0.02)
+    P = synth.make_problem(n_bins=n_bins, nnz=nnz, n_sub=n_sub, seed=seed, contig_weights=(5, 4, 3), mean_len_bp=2000.0,
+                           accu=9 if n_sub > 1 else 1, param=par)
+    return synth.with_dense(P)
+
+
+def test_as_coo_upper_accepts_dense_sparse_and_triples():
+    import scipy.sparse as sp
+    P = problem(n_sub=1, nnz=400)
+    want = (P["coo_row"], P["coo_col"], P["coo_val"])
+    dense = P["hic_matrix"]
+    sym = sp.csr_matrix(dense)                      # csr + csr.T as simulation_loader.py:81-82 builds it
+    upper = sp.coo_matrix((P["coo_val"], (P["coo_row"], P["coo_col"])), shape=dense.shape)
+    for src in (dense, sym, upper, want, (P["coo_col"], P["coo_row"], P["coo_val"])[::1] and want):
+        r, c, v = S.as_coo_upper(src)
+        assert np.array_equal(r, want[0]) and np.array_equal(c, want[1]) and np.array_equal(v, want[2])
+    # a diagonal entry and an explicit zero are dropped like cuda_lib_gl.py:157-160 does
+    r, c, v = S.as_coo_upper((np.array([2, 1, 0]), np.array([2, 3, 5]), np.array([7, 0, 4])))
+    assert list(r) == [0] and list(c) == [5] and list(v) == [4]
+
+
+@pytest.mark.parametrize("n_sub,seed", [(1, 3), (3, 4)])
+def test_neighbour_distributions_match_dense_reference_logic(n_sub, seed):
+    P = problem(n_sub=n_sub, seed=seed, n_bins=60, nnz=500)
+    ora = O.OracleSampler(P, np.random.RandomState(0))
+    xk, pk = S.neighbour_distributions(P["bin_coo_row"], P["bin_coo_col"], P["bin_coo_val"], P["n_frags"])
+    for i in range(P["n_frags"]):
+        assert np.array_equal(xk[i], ora.distri_frags[i]["xk"]), i
+        assert np.array_equal(pk[i], ora.distri_frags[i]["pk"]), i
+        assert pk[i].dtype == np.float32
+
+
+def test_neighbour_distributions_short_and_empty_rows():
+    # bin 0 has 2 contacts, bin 5 none: rows are padded with zero columns, largest index first
+    n = 14
+    row = np.array([0, 0, 1]); col = np.array([3, 7, 2]); val = np.array([4.0, 4.0, 1.0], np.float32)
+    dense = synth.dense_from_coo(row, col, val, n)
+    xk, pk = S.neighbour_distributions(row, col, val, n)
+    for i in (0, 5, 7):
+        order = np.argsort(dense[i], kind="stable")[::-1][:10]
+        assert np.array_equal(xk[i], order)
+    assert pk[5] == pytest.approx(np.full(10, 0.1))
+    assert pk[0][:2] == pytest.approx([0.5, 0.5]) and np.all(pk[0][2:] == 0)
+
+
+def test_select_move_matches_literal_reference_logic():
+    rng = np.random.RandomState(3)
+    P = problem(n_sub=1, n_bins=30, nnz=100)
+    ora = O.OracleSampler(P, None)
+    for trial in range(300):
+        k = int(rng.randint(1, 6))
+        score = -1000.0 + rng.standard_normal(13 * k) * rng.choice([0.1, 5.0, 50.0])
+        if trial % 7 == 0:
+            score[:] = score[0]                      # all equal -> nothing is > 0 after the shift -> argmax
+        seed = int(rng.randint(1 << 30))
+        got = S.select_move(score, 13, np.random.RandomState(seed))
+        # literal copy of cuda_lib_gl.py:1898-1947 as restated in the oracle
+        ora.rng = np.random.RandomState(seed)
+        ora.score = np.copy(score)
+        want = _oracle_select(ora)
+        assert got[0] == want[0] and got[1] == want[1]
+
+
+def _oracle_select(ora):
+    n_tmp = ora.n_tmp_struct
+    scores_2_remove = []
+    scores_2_remove.extend(range(n_tmp, len(ora.score), n_tmp))
+    scores_2_remove.extend(range(n_tmp + 1, len(ora.score), n_tmp))
+    id_max = ora.score.argmax()
+    or_score = np.copy(ora.score)
+    filtered_score = ora.score - ora.score.min()
+    filtered_score[scores_2_remove] = 0
+    max_score = filtered_score.max()
+    filtered_score = filtered_score - (max_score - 30)
+    filtered_score[filtered_score < 0] = 0
+    ok = np.ix_(filtered_score > 0)
+    sub = filtered_score[ok]
+    sub = sub / sub.sum()
+    sub[sub > 0] = np.power(sub[sub > 0], 1.0)
+    sub = sub / sub.sum()
+    if len(ok[0]) in (0, 1):
+        s = id_max
+    else:
+        s = ora.rng.choice(ok[0], 1, p=sub)[0]
+    return int(s), float(or_score[s])
+
+
+@pytest.mark.parametrize("n_sub", [1, 3])
+def test_dist_inter_genome_matches_reference_loop(n_sub):
+    P = problem(n_sub=n_sub, n_bins=50, nnz=300)
+    ora = O.OracleSampler(P, np.random.RandomState(1))
+    n = P["n_frags"]
+    rng = np.random.RandomState(9)
+    orientable = (np.asarray(P["np_sub_frags_id"])[:, 3] > 1).astype(np.int32)
+    assert np.array_equal(orientable, ora.np_init_orientable)
+    states = [O.copy_state(ora.gpu_vect_frags)]
+    for _ in range(12):
+        s = util.random_layout(rng, n, p_circ=0.2)
+        states.append(s)
+    # also a lightly perturbed version of the initial genome (most neighbours still correct)
+    s = O.copy_state(ora.gpu_vect_frags)
+    out, _ = util.oracle_candidate(s, 7, 20, 6, int(s["id_c"].max()))
+    states.append(out)
+    for s in states:
+        want = ora.dist_inter_genome(s)
+        got = S.dist_inter_genome(s["prev"], s["next"], s["ori"], s["id_d"], ora.np_init_prev, ora.np_init_next,
+                                  ora.np_init_ori, orientable, np.ones(n, bool), ora.n_frags_4_dist)
+        assert got == want
+
+
+def test_shard_ranges_partition_the_contact_list():
+    for nnz in (0, 1, 7, 1000, 20_000_003):
+        for world in (1, 2, 3, 8):
+            edges = [gdist.shard_range(nnz, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == nnz
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in edges]
+            assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,96 @@
+"""GPU: the drop-in sampler (graal_amd.sampler.sampler over libgraal_hip.so) against the oracle's literal restatement
+of cuda_lib_gl.sampler, driven by the same headless start_EM loop and the same seeded RandomState.
+
+Bit-exact: accepted-move trace (id_fA, id_fB, op), contig statistics, distance to the initial genome, final fragment
+SoA.  Within tolerance (north_star: 1e-5 relative): log-likelihood values."""
+import numpy as np
+import pytest
+
+from graal_amd import em, synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def problem(n_sub, seed, n_bins, nnz):
+    par = synth.make_param_simu(fact=200.0, v_inter=0.02)
+    # grid_bp = 2000: every float32 kb coordinate is exact, so the dense reference arithmetic is shift invariant
+    P = synth.make_problem(n_bins=n_bins, nnz=nnz, n_sub=n_sub, seed=seed, contig_weights=(5, 4, 3), mean_len_bp=2000.0,
+                           accu=9 if n_sub > 1 else 1, param=par, grid_bp=2000)
+    return synth.with_dense(P)
+
+
+def make_gpu_sampler(P, rng, **kw):
+    from graal_amd.sampler import sampler
+    import scipy.sparse as sp
+    S = P["init_n_sub_frags"]
+    sub = sp.coo_matrix((P["coo_val"], (P["coo_row"], P["coo_col"])), shape=(S, S)).tocsr()
+    n = P["n_frags"]
+    binm = sp.coo_matrix((P["bin_coo_val"], (P["bin_coo_row"], P["bin_coo_col"])), shape=(n, n)).tocsr()
+    return sampler(True, P["S_o_A_frags"], P["collector_id_repeats"], P["frag_dispatcher"], P["id_frag_duplicated"],
+                   P["id_frags_blacklisted"], P["n_frags"], P["n_new_frags"], P["init_n_sub_frags"],
+                   P["n_new_sub_frags"], None, binm + binm.T, P["np_sub_frags_len_bp"], P["np_sub_frags_id"],
+                   P["np_sub_frags_accu"], P["mean_squared_frags_per_bin"], None, None, sub + sub.T,
+                   P["mean_value_trans"], 2, False, None, rng=rng, param_simu=P["param_simu"], **kw)
+
+
+@pytest.mark.parametrize("n_sub,seed,n_bins,nnz,cycles,delta", [(1, 41, 70, 1200, 3, 3), (3, 42, 60, 1500, 2, 4),
+                                                                (1, 43, 50, 700, 2, 5)])
+def test_trace_matches_oracle(n_sub, seed, n_bins, nnz, cycles, delta):
+    P = problem(n_sub, seed, n_bins, nnz)
+    ora = O.OracleSampler(P, np.random.RandomState(seed), fix_trans_accu=True)
+    t_ref = em.run_em(ora, cycles, delta, rng=ora.rng)
+    gpu_rng = np.random.RandomState(seed)
+    g = make_gpu_sampler(P, gpu_rng)
+    t_gpu = em.run_em(g, cycles, delta, rng=gpu_rng)
+    assert ora.n_stale_paste == 0 and g.n_stale_paste == 0
+    assert np.array_equal(t_gpu.mutations(), t_ref.mutations())          # accepted-move trace, bit-exact
+    assert t_gpu.n_contigs == t_ref.n_contigs
+    assert t_gpu.mean_len == t_ref.mean_len
+    assert t_gpu.dist == t_ref.dist
+    assert np.allclose(t_gpu.likelihood, t_ref.likelihood, rtol=1e-6, atol=0)
+    g.gpu_vect_frags.copy_from_gpu()
+    for k in O.FIELDS:                                                    # fragment ordering, bit-exact
+        assert np.array_equal(getattr(g.gpu_vect_frags, k), ora.gpu_vect_frags[k]), k
+    # the run did something: contigs were merged back from the exploded genome
+    assert t_gpu.n_contigs[-1] <= P["n_frags"] // 2
+    # full re-evaluation agrees with the carried-over likelihood
+    assert g.eval_likelihood() == pytest.approx(ora.init_likelihood(), rel=1e-6)
+    g.free_gpu()
+
+
+def test_replay_of_a_trace_reproduces_the_layout(tmp_path):
+    P = problem(1, 44, 40, 400)
+    rng = np.random.RandomState(44)
+    g = make_gpu_sampler(P, rng, compute_dist=False)
+    t = em.run_em(g, 1, 3, rng=rng)
+    em.save_behaviour_to_txt(t, str(tmp_path))
+    g.gpu_vect_frags.copy_from_gpu()
+    final = {k: np.copy(getattr(g.gpu_vect_frags, k)) for k in O.FIELDS}
+    g.free_gpu()
+    # fresh sampler: explode, then replay the saved list_mutations.txt
+    g2 = make_gpu_sampler(P, np.random.RandomState(0), compute_dist=False)
+    g2.modify_gl_cuda_buffer(0, 0)
+    g2.explode_genome(0)
+    em.replay(g2, em.load_mutations(str(tmp_path / "list_mutations.txt")))
+    g2.gpu_vect_frags.copy_from_gpu()
+    for k in O.FIELDS:
+        if k != "id_c":   # labels depend on when the last relabel happened; membership is compared below
+            assert np.array_equal(getattr(g2.gpu_vect_frags, k), final[k]), k
+    a, b = g2.gpu_vect_frags.id_c, final["id_c"]
+    assert np.array_equal(a[:, None] == a[None, :], b[:, None] == b[None, :])
+    g2.free_gpu()
+
+
+def test_unsupported_inputs_fail_loudly():
+    from graal_amd.sampler import sampler
+    P = problem(1, 45, 20, 60)
+    args = [True, P["S_o_A_frags"], P["collector_id_repeats"], P["frag_dispatcher"], [3], [], P["n_frags"],
+            P["n_new_frags"], P["init_n_sub_frags"], P["n_new_sub_frags"], None, P["hic_matrix_sub_sampled"],
+            P["np_sub_frags_len_bp"], P["np_sub_frags_id"], P["np_sub_frags_accu"], P["mean_squared_frags_per_bin"],
+            None, None, P["hic_matrix"], P["mean_value_trans"], 2, False, None]
+    with pytest.raises(NotImplementedError):
+        sampler(*args)
+    args[4], args[5] = [], [2]
+    with pytest.raises(NotImplementedError):
+        sampler(*args)
