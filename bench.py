@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py -- candidate logL evaluations per second of the per-move likelihood scan (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[4], SURVEY.md section 8d "C5"): synthetic 50,000-fragment / 20,000,000-contact map,
+generator seed 20141217; layout = exploded genome + 2,000 real MCMC warm-up steps (K = 5 neighbours).  One timed
+"step" = the scoring phase of one MCMC step: ONE fused pass over the contact list for the 13 x 5 = 65 candidates of a
+(fA, 5 neighbours) proposal, their expected-mass tasks, the RCCL all-reduce of the 65 int64 values (N > 1) and the
+device->host copy of the result.  Inputs are resident in HBM; proposals are drawn beforehand.  With N GPUs the SAME
+contact list is sharded N ways (strong scaling).
+
+Output: one JSON line on rank 0 (contract in the task statement) with `roofline` (fused scan kernel: algorithmic bytes
+= 12 B x contacts + 4 B x fragments per launch, duration from HIP events on the engine's stream) and `cpu_baseline`
+(numpy re-score of the same sparse likelihood on the host, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+
+
+def build_sampler(P, rng, group, device):
+    from graal_amd.sampler import sampler
+    return sampler(True, P["S_o_A_frags"], P["collector_id_repeats"], P["frag_dispatcher"], [], [], P["n_frags"],
+                   P["n_new_frags"], P["init_n_sub_frags"], P["n_new_sub_frags"], None,
+                   (P["bin_coo_row"], P["bin_coo_col"], P["bin_coo_val"]), P["np_sub_frags_len_bp"],
+                   P["np_sub_frags_id"], P["np_sub_frags_accu"], P["mean_squared_frags_per_bin"], None, None,
+                   (P["coo_row"], P["coo_col"], P["coo_val"]), P["mean_value_trans"], 1, False, None,
+                   device=device, rng=rng, group=group, param_simu=P["param_simu"], compute_dist=False)
+
+
+def exploded_layout(P):
+    """Every fragment its own contig (what explode_genome produces, cuda_lib_gl.py:1539-1556), built directly."""
+    n = P["n_frags"]
+    s = {k: np.array(P["S_o_A_frags"][k], dtype=np.int32, copy=True) for k in P["S_o_A_frags"]}
+    s["pos"][:] = 0
+    s["id_c"][:] = np.arange(n)
+    s["start_bp"][:] = 0
+    s["circ"][:] = 0
+    s["prev"][:] = -1
+    s["next"][:] = -1
+    s["l_cont"][:] = 1
+    s["l_cont_bp"][:] = s["len_bp"]
+    s["ori"][:] = 1
+    return s
+
+
+def cpu_baseline(P, state, budget_s=24.0):
+    """numpy re-score (oracle/sparse_numpy.py) of whole candidates on the host: the checker, timed, never shipped."""
+    from oracle import oracle as O
+    from oracle.sparse_numpy import SparseScorer
+    sc = SparseScorer(P["coo_row"], P["coo_col"], P["coo_val"], P["np_sub_frags_id"], P["np_sub_frags_len_bp"],
+                      P["np_sub_frags_accu"], P["mean_squared_frags_per_bin"], P["param_simu"])
+    n = P["n_frags"]
+    max_id = int(state["id_c"].max())
+    pop, ids = O.new_state(n), np.zeros(n, np.int32)
+    cands = []
+    fA, fB = 1234 % n, 4321 % n
+    O.DenseOracle.pop_out(pop, state, ids, fA, max_id)
+    cands.append(O.copy_state(pop))                                    # op 0: eject
+    for which, ori in ((3, 1), (1, -1), (2, 1)):                       # ops 6, 3, 4
+        out = O.new_state(n)
+        O.DenseOracle.pop_in(which, out, pop, fA, fB, int(ids.max()), ori)
+        cands.append(out)
+    done, t0 = 0, time.perf_counter()
+    for c in cands:
+        sc.full(c, same_bin=False)
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "candidate logL evals/s", "cores": 1, "kind": "port",
+            "sample": "%d whole-candidate numpy float32/float64 re-scores of the same %d-contact state (%.1f s)" % (
+                done, len(P["coo_row"]), dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--n-bins", type=int, default=int(os.environ.get("GRAAL_BENCH_NBINS", 50000)))
+    ap.add_argument("--nnz", type=int, default=int(os.environ.get("GRAAL_BENCH_NNZ", 20_000_000)))
+    ap.add_argument("--mcmc-warmup", type=int, default=int(os.environ.get("GRAAL_BENCH_MCMC_WARMUP", 2000)))
+    ap.add_argument("--neighbours", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from graal_amd import dist as gdist
+    from graal_amd import synth
+    rank, world, local = gdist.env_world()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    import torch
+    if world > 1:
+        import torch.distributed as td
+        torch.cuda.set_device(local)
+        td.init_process_group("nccl", device_id=torch.device("cuda", local))
+    group = gdist.Group(rank, world)
+
+    t_gen = time.perf_counter()
+    P = synth.make_problem(n_bins=args.n_bins, nnz=args.nnz, n_sub=1, seed=20141217)
+    P["S_o_A_frags"] = exploded_layout(P)
+    t_gen = time.perf_counter() - t_gen
+    rng = np.random.RandomState(20141217)
+    t_setup = time.perf_counter()
+    smp = build_sampler(P, rng, group, local if world > 1 else 0)
+    t_setup = time.perf_counter() - t_setup
+    n = int(smp.n_new_frags)
+    K = args.neighbours
+
+    # ---- layout: exploded genome + real MCMC warm-up steps (every rank runs the same, sharded, steps) --------
+    smp.init_likelihood()
+    t_mcmc = time.perf_counter()
+    order = np.arange(n, dtype=np.int32)
+    rng.shuffle(order)
+    for i in order[:args.mcmc_warmup]:
+        smp.step_max_likelihood(int(i), K)
+    torch.cuda.synchronize()
+    t_mcmc = time.perf_counter() - t_mcmc
+    stats = smp.engine.layout_stats()
+    max_id = smp.modify_gl_cuda_buffer(0)
+
+    # ---- proposals for the timed region, drawn beforehand ---------------------------------------------------------
+    total = args.warmup + args.steps
+    frags = rng.randint(0, n, size=total)
+    props = []
+    for f in frags:
+        nb = smp.return_neighbours(int(f), K)
+        nb.sort()
+        props.append((int(f), nb))
+
+    def sync_all():
+        group.barrier()
+        torch.cuda.synchronize()
+
+    for f, nb in props[:args.warmup]:
+        smp._candidate_deltas(f, nb, max_id)
+    scan_ms, mass_ms, tab_ms, n_cand = [], [], [], 0
+    sync_all()
+    t0 = time.perf_counter()
+    for f, nb in props[args.warmup:]:
+        smp._candidate_deltas(f, nb, max_id)
+        n_cand += 13 * len(nb)
+        tm = smp.engine.last_timing()   # HIP events recorded on the stream the kernels ran on
+        tab_ms.append(float(tm[0])); scan_ms.append(float(tm[1])); mass_ms.append(float(tm[2]))
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        elapsed = float(t.cpu()[0])
+    counters = smp.engine.last_counters()
+
+    # ---- full MCMC steps (scoring + sampling + commit + relabel), reported as an extra ----------------------------
+    t1 = time.perf_counter()
+    n_full = 200
+    for i in order[args.mcmc_warmup:args.mcmc_warmup + n_full]:
+        smp.step_max_likelihood(int(i), K)
+    torch.cuda.synchronize()
+    full_step_s = (time.perf_counter() - t1) / n_full
+
+    if rank == 0:
+        nnz_local = smp.engine.nnz
+        bytes_per_launch = 12.0 * nnz_local + 4.0 * n
+        scan_s = float(np.mean(scan_ms)) * 1e-3
+        achieved = bytes_per_launch / scan_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")  # HBM bytes / launch from a committed rocprofv3 --pmc run
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("nnz") == int(nnz_local) and tj.get("n_frags") == n:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "candidate logL evals/sec", "value": n_cand / elapsed, "unit": "candidate logL evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32 model / f64 log / int64 Q30 sums",
+            "data": "synthetic",
+            "config": {"workload": "C5 synthetic %d-fragment / %d-contact map, exploded + %d MCMC warm-up steps"
+                                   % (n, len(P["coo_row"]), args.mcmc_warmup),
+                       "neighbours_per_step": K, "candidates_per_step": 13 * K, "contacts_per_gpu": int(nnz_local),
+                       "n_contigs": int(stats[0]), "max_contig_len": int(stats[4]),
+                       "parallelism": "contacts sharded x%d, 1 all-reduce(65 x int64)/step" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_scan",
+                         "bytes_per_launch": bytes_per_launch, "avg_launch_ms": scan_s * 1e3},
+            "phase_ms": {"tables_codes": float(np.mean(tab_ms)), "scan": float(np.mean(scan_ms)),
+                         "mass": float(np.mean(mass_ms)), "host_wall_per_step": 1e3 * elapsed / args.steps},
+            "relevant_pairs_last_step": int(counters[1]), "mass_items_last_step": int(counters[3]),
+            "full_mcmc_step_ms": 1e3 * full_step_s,
+            "setup_s": {"generate": t_gen, "sampler": t_setup, "mcmc_warmup": t_mcmc},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            smp.gpu_vect_frags.copy_from_gpu()
+            out["cpu_baseline"] = cpu_baseline(P, smp.gpu_vect_frags.as_dict())
+            out["cpu_baseline"]["host_cpus"] = os.cpu_count()
+        print(json.dumps(out), flush=True)
+    smp.free_gpu()
+    if world > 1:
+        td.barrier()
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -125,7 +125,6 @@ def make_problem(n_bins=50000, nnz=20_000_000, n_sub=1, seed=20141217, contig_we
     off_p = rippe_np(np.arange(1, kmax + 1) * mean_kb, param)
     off_p = off_p / off_p.sum()
     off_cdf = np.cumsum(off_p)
-    keys = np.zeros(0, dtype=np.int64)
     # never ask for more distinct pairs than exist (tiny test problems): cap at half of each population
     n_sub_contig = np.bincount(sub_contig).astype(np.int64)
     max_cis = int((n_sub_contig * (n_sub_contig - 1) // 2).sum())
@@ -134,30 +133,59 @@ def make_problem(n_bins=50000, nnz=20_000_000, n_sub=1, seed=20141217, contig_we
     reach_cis = int(sum(np.maximum(0, nc - ks).sum() for nc in n_sub_contig))  # pairs with offset <= kmax
     target_cis = int(min(round(nnz * frac_cis), max_cis // 2, reach_cis // 2))
     nnz = int(min(nnz, target_cis + max_trans // 2))
-    for target, cis in ((target_cis, True), (nnz, False)):
-        guard = 0
-        while len(keys) < target:
-            guard += 1
-            if guard > 10000:
-                raise RuntimeError("synthetic contact generation does not converge")
-            need = target - len(keys)
-            m = int(need * 1.3) + 1024
-            i = rng.randint(0, S, size=m).astype(np.int64)
-            if cis:
-                k = np.searchsorted(off_cdf, rng.random_sample(m)).astype(np.int64) + 1
-                j = i + k
-                ok = (j < S)
-                ok[ok] &= sub_contig[i[ok]] == sub_contig[j[ok]]
+    contig_first = np.concatenate([[0], np.cumsum(n_sub_contig)[:-1]])  # first sub-fragment of every contig
+
+    def draw_cis(target):
+        """`target` distinct cis pairs (i, i + k): the count per offset k follows off_p, capped by the number of
+        pairs that exist at that offset (water filling), positions drawn without replacement per offset."""
+        n_k = np.array([np.maximum(0, n_sub_contig - k).sum() for k in ks], dtype=np.int64)
+        lo_s, hi_s = 0.0, float(target) / max(off_p[n_k > 0].min(), 1e-300) + 1.0
+        for _ in range(200):
+            mid = 0.5 * (lo_s + hi_s)
+            if np.minimum(n_k, np.floor(mid * off_p)).sum() < target:
+                lo_s = mid
             else:
-                j = rng.randint(0, S, size=m).astype(np.int64)
-                lo, hi = np.minimum(i, j), np.maximum(i, j)
-                i, j = lo, hi
-                ok = (i != j) & (sub_contig[i] != sub_contig[j])
-            new = np.unique(i[ok] * S + j[ok])
-            new = new[~np.isin(new, keys, assume_unique=True)] if len(keys) else new
-            if len(new) > need:
-                new = rng.choice(new, need, replace=False)
-            keys = np.union1d(keys, new)
+                hi_s = mid
+        m_k = np.minimum(n_k, np.floor(hi_s * off_p)).astype(np.int64)
+        excess = int(m_k.sum() - target)
+        for k in np.argsort(-m_k, kind="stable"):  # trim the rounding excess from the fullest offsets
+            if excess <= 0:
+                break
+            take = min(excess, int(m_k[k]))
+            m_k[k] -= take
+            excess -= take
+        out = []
+        for idx in np.nonzero(m_k)[0]:
+            k = int(ks[idx])
+            per = np.maximum(0, n_sub_contig - k)           # valid start positions per contig
+            cum = np.concatenate([[0], np.cumsum(per)])
+            t = rng.choice(int(cum[-1]), int(m_k[idx]), replace=False) if m_k[idx] < cum[-1] else np.arange(cum[-1])
+            c = np.searchsorted(cum, t, side="right") - 1
+            i = contig_first[c] + (t - cum[c])
+            out.append(i * S + (i + k))
+        return np.concatenate(out) if out else np.zeros(0, dtype=np.int64)
+
+    def draw_trans(target):
+        got = np.zeros(0, dtype=np.int64)
+        guard = 0
+        while len(got) < target:
+            guard += 1
+            if guard > 200:
+                raise RuntimeError("synthetic contact generation does not converge")
+            m = int((target - len(got)) * 1.15) + 4096
+            i = rng.randint(0, S, size=m).astype(np.int64)
+            j = rng.randint(0, S, size=m).astype(np.int64)
+            i, j = np.minimum(i, j), np.maximum(i, j)
+            ok = (i != j) & (sub_contig[i] != sub_contig[j])
+            new = i[ok] * S + j[ok]
+            got = np.unique(np.concatenate([got, new])) if len(got) else np.unique(new)
+        if len(got) > target:
+            keep = np.ones(len(got), dtype=bool)
+            keep[rng.choice(len(got), len(got) - target, replace=False)] = False
+            got = got[keep]
+        return got
+
+    keys = np.concatenate([draw_cis(target_cis), draw_trans(nnz - target_cis)])
     keys.sort()
     row = (keys // S).astype(np.int32)
     col = (keys % S).astype(np.int32)
