@@ -13,7 +13,8 @@ device->host copy of the result.  Inputs are resident in HBM; proposals are draw
 contact list is sharded N ways (strong scaling).
 
 Output: one JSON line on rank 0 (contract in the task statement) with `roofline` (fused scan kernel: algorithmic bytes
-= 12 B x contacts + 4 B x fragments per launch, duration from HIP events on the engine's stream) and `cpu_baseline`
+= 4 B x contacts (row words) + n/8 B (bitmap) + 16 B x queued contacts per launch; duration from HIP events on the
+engine's stream) and `cpu_baseline`
 (numpy re-score of the same sparse likelihood on the host, N = 1 only).
 """
 import argparse
@@ -174,7 +175,10 @@ def main():
 
     if rank == 0:
         nnz_local = smp.engine.nnz
-        bytes_per_launch = 12.0 * nnz_local + 4.0 * n
+        # what the streaming pass must read: the row word of every contact (4 B), the affected-fragment bitmap
+        # (n/8 B) and, for the queued contacts only, col + count + two code words (SURVEY 8d priced a naive pass
+        # at 12 B per contact; col words of affected rows that fail the second test are not counted -> conservative)
+        bytes_per_launch = 4.0 * nnz_local + n / 8.0 + 16.0 * float(counters[2])
         scan_s = float(np.mean(scan_ms)) * 1e-3
         achieved = bytes_per_launch / scan_s / 1e9
         traffic = None
@@ -199,9 +203,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_scan",
                          "bytes_per_launch": bytes_per_launch, "avg_launch_ms": scan_s * 1e3},
-            "phase_ms": {"tables_codes": float(np.mean(tab_ms)), "scan": float(np.mean(scan_ms)),
-                         "mass": float(np.mean(mass_ms)), "host_wall_per_step": 1e3 * elapsed / args.steps},
-            "relevant_pairs_last_step": int(counters[1]), "mass_items_last_step": int(counters[3]),
+            "phase_ms": {"k_prep": float(np.mean(tab_ms)), "k_scan": float(np.mean(scan_ms)),
+                         "k_post": float(np.mean(mass_ms)), "host_wall_per_step": 1e3 * elapsed / args.steps},
+            "relevant_pairs_last_step": int(counters[1]), "queued_contacts_last_step": int(counters[2]),
+            "mass_items_last_step": int(counters[3]),
             "full_mcmc_step_ms": 1e3 * full_step_s,
             "setup_s": {"generate": t_gen, "sampler": t_setup, "mcmc_warmup": t_mcmc},
         }

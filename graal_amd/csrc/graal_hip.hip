@@ -171,37 +171,43 @@ __global__ void k_refresh_geo(SoaPtr s, Geo* __restrict__ geo, int n)
 
 // out: [0] #heads (pos==0) [1] sum l_cont [2] #(start_bp==0) [3] sum l_cont_bp over start_bp==0 [4] max l_cont
 //      [5] min l_cont [6] #(rep != 0 or activ != 1 or id_d != f)  [7] max label  [14] #(circ == 1)
-__global__ void k_stats(SoaPtr s, int n, long long* __restrict__ out)
+__global__ __launch_bounds__(256) void k_stats(SoaPtr s, int n, long long* __restrict__ out)
 {
-    long long heads = 0, sl = 0, nst = 0, sbp = 0, mx = 0, mn = 0x7fffffff, bad = 0, mlab = -1, ncirc = 0;
+    long long v[9] = {0, 0, 0, 0, 0, 0x7fffffff, 0, -1, 0}; // heads, sum l_cont, #start0, sum lbp, max, min, bad, max label, #circ
     for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < n; f += gridDim.x * blockDim.x) {
         const int lc = s.p[F_LCONT][f];
-        heads += s.p[F_POS][f] == 0;
-        sl += lc;
-        if (s.p[F_START][f] == 0) { nst += 1; sbp += s.p[F_LCONTBP][f]; }
-        mx = lc > mx ? lc : mx;
-        mn = lc < mn ? lc : mn;
-        bad += (s.p[F_REP][f] != 0) || (s.p[F_ACTIV][f] != 1) || (s.p[F_IDD][f] != f);
-        ncirc += s.p[F_CIRC][f] == 1;
+        v[0] += s.p[F_POS][f] == 0;
+        v[1] += lc;
+        if (s.p[F_START][f] == 0) { v[2] += 1; v[3] += s.p[F_LCONTBP][f]; }
+        v[4] = lc > v[4] ? lc : v[4];
+        v[5] = lc < v[5] ? lc : v[5];
+        v[6] += (s.p[F_REP][f] != 0) || (s.p[F_ACTIV][f] != 1) || (s.p[F_IDD][f] != f);
         const int c = s.p[F_IDC][f];
-        mlab = c > mlab ? c : mlab;
+        v[7] = c > v[7] ? c : v[7];
+        v[8] += s.p[F_CIRC][f] == 1;
     }
-    for (int o = 32; o > 0; o >>= 1) {
-        heads += __shfl_down(heads, o, 64); sl += __shfl_down(sl, o, 64); nst += __shfl_down(nst, o, 64);
-        sbp += __shfl_down(sbp, o, 64); bad += __shfl_down(bad, o, 64); ncirc += __shfl_down(ncirc, o, 64);
-        const long long a = __shfl_down(mx, o, 64), b = __shfl_down(mn, o, 64), c = __shfl_down(mlab, o, 64);
-        mx = a > mx ? a : mx; mn = b < mn ? b : mn; mlab = c > mlab ? c : mlab;
+    __shared__ long long sh[4][9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        long long x = v[i];
+        for (int o = 32; o > 0; o >>= 1) {
+            const long long y = __shfl_down(x, o, 64);
+            x = (i == 4 || i == 7) ? (y > x ? y : x) : (i == 5 ? (y < x ? y : x) : x + y);
+        }
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][i] = x;
     }
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd((unsigned long long*)&out[0], (unsigned long long)heads);
-        atomicAdd((unsigned long long*)&out[1], (unsigned long long)sl);
-        atomicAdd((unsigned long long*)&out[2], (unsigned long long)nst);
-        atomicAdd((unsigned long long*)&out[3], (unsigned long long)sbp);
-        atomicMax((long long*)&out[4], mx);
-        atomicMin((long long*)&out[5], mn);
-        atomicAdd((unsigned long long*)&out[6], (unsigned long long)bad);
-        atomicMax((long long*)&out[7], mlab);
-        atomicAdd((unsigned long long*)&out[14], (unsigned long long)ncirc);
+    __syncthreads();
+    if (threadIdx.x < 9) { // one atomic per statistic per block
+        const int i = threadIdx.x;
+        long long x = sh[0][i];
+        for (int w = 1; w < 4; w++) {
+            const long long y = sh[w][i];
+            x = (i == 4 || i == 7) ? (y > x ? y : x) : (i == 5 ? (y < x ? y : x) : x + y);
+        }
+        const int slot = i < 8 ? i : 14;
+        if (i == 4 || i == 7) atomicMax((long long*)&out[slot], x);
+        else if (i == 5) atomicMin((long long*)&out[slot], x);
+        else atomicAdd((unsigned long long*)&out[slot], (unsigned long long)x);
     }
 }
 
@@ -327,12 +333,9 @@ struct NbTables {        // everything the scan / mass kernels need about one ne
 
 struct Neigh { int fB[MAXK]; };
 
-__global__ __launch_bounds__(256) void k_tables(SoaPtr s, int fA, Neigh nb, int max_id, NbTables* __restrict__ tabs,
-                                                 int* __restrict__ overflow)
+// one 256-thread block builds everything about one neighbour
+__device__ void tables_block(const SoaPtr& s, int fA, int fB, int max_id, NbTables& T)
 {
-    const int k = blockIdx.x;
-    const int fB = nb.fB[k];
-    NbTables& T = tabs[k];
     __shared__ Rec A0, B0;
     __shared__ int rep[NP];
     __shared__ Rec rep_old[NP];
@@ -464,116 +467,156 @@ __global__ __launch_bounds__(256) void k_tables(SoaPtr s, int fA, Neigh nb, int 
         }
         T.item_start[n_tasks] = acc;
     }
-    (void)overflow;
 }
 
-// per-fragment relevance code: 4 bits per neighbour = piece id (3) | "piece changes internally" (1)
-__global__ void k_codes(SoaPtr s, int n, int K, const NbTables* __restrict__ tabs, unsigned* __restrict__ codes)
+// ------------------------------------------------------------------ per-step kernels
+// k_prep: blocks [0, K) build the neighbour tables; the other blocks write the per-fragment relevance code
+// (4 bits per neighbour = piece id, 0 = not in contig(fA) u contig(fB_k)) and zero the step's accumulators.
+// It also writes the "affected" bitmap: bit i set iff contact-list id i (= fragment id when every bin has one
+// sub-fragment) belongs to a fragment with a non-zero code.  bitmap_by_sub != nullptr: bins own up to 3 arbitrary
+// sub-fragment ids, bits are OR-ed into a bitmap the host zeroed beforehand.
+__global__ __launch_bounds__(256) void k_prep(SoaPtr s, int n, int fA, Neigh nb, int K, int max_id, NbTables* __restrict__ tabs,
+                                               unsigned* __restrict__ codes, unsigned* __restrict__ bitmap,
+                                               const int* __restrict__ sub_ids /* [n][4] or nullptr */,
+                                               long long* __restrict__ d_q_out,
+                                               long long* __restrict__ counters /* n_rel, n_items, queue count */)
 {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= n) return;
-    const int c = s.p[F_IDC][f], pos = s.p[F_POS][f];
+    if ((int)blockIdx.x < K) { tables_block(s, fA, nb.fB[blockIdx.x], max_id, tabs[blockIdx.x]); return; }
+    const int b = blockIdx.x - K;
+    if (b == 0) {
+        for (int i = threadIdx.x; i < K * N_OPS; i += blockDim.x) d_q_out[i] = 0;
+        if (threadIdx.x < 3) counters[threadIdx.x] = 0;
+    }
+    const int f = b * blockDim.x + threadIdx.x;
     unsigned code = 0;
-    for (int k = 0; k < K; k++) {
-        const int p = (tabs[k].fB == -1) ? 0 : piece_of(tabs[k].key, c, pos);
-        const unsigned intra = (tabs[k].intra_any >> p) & 1u;
-        code |= ((unsigned)p | (intra << 3)) << (4 * k);
+    if (f < n) {
+        const int cA = s.p[F_IDC][fA], a = s.p[F_POS][fA];
+        const int c = s.p[F_IDC][f], pos = s.p[F_POS][f];
+        for (int k = 0; k < K; k++) {
+            const int fB = nb.fB[k];
+            PieceKey key; key.cA = cA; key.a = a; key.cB = s.p[F_IDC][fB]; key.b = s.p[F_POS][fB];
+            const int p = (fB == fA) ? 0 : piece_of(key, c, pos);
+            code |= (unsigned)p << (4 * k);
+        }
+        codes[f] = code;
     }
-    codes[f] = code;
+    if (sub_ids == nullptr) { // fragment id == contact-list id: one 64-bit ballot per wave, no atomics, no zeroing
+        const unsigned long long bal = __ballot(code != 0);
+        if ((threadIdx.x & 63) == 0) {
+            const int w = (b * blockDim.x + threadIdx.x) >> 5; // first 32-bit word of this wave's 64 fragments
+            bitmap[w] = (unsigned)bal;
+            bitmap[w + 1] = (unsigned)(bal >> 32);
+        }
+    } else if (f < n && code != 0) {
+        const int ns = sub_ids[4 * f + 3];
+        for (int j = 0; j < ns; j++) { const int sid = sub_ids[4 * f + j]; atomicOr(&bitmap[sid >> 5], 1u << (sid & 31)); }
+    }
 }
 
-// ------------------------------------------------------------------ the fused candidate scan
-// One pass over this rank's COO triples for all 13*K candidates.  Fast path per contact: two 4-byte gathers
-// (relevance codes, L2 resident) and ~15 integer ops.  Slow path (contact joins two different pieces of some
-// neighbour, or lies in a piece whose circular model changes): evaluate ex under the current layout and under
-// each candidate whose relation changed, add ob * (log ex_new - log ex_old) in Q to the LDS accumulators.
-template <bool SINGLE_SUB>
-__global__ __launch_bounds__(256) void k_scan(const int* __restrict__ row, const int* __restrict__ col,
-                                               const int* __restrict__ cnt, long long nnz,
+struct QEntry { unsigned idx; unsigned rel; }; // contact index in this shard, nibble mask of the neighbours it matters to
+
+// k_scan: ONE streaming pass over this rank's contact list for all 13*K candidates of the step.
+// A contact matters to neighbour k iff its two ends lie in DIFFERENT pieces of k (or in one piece whose circular model
+// changes).  Three-level test, cheapest first:
+//   1. row id in the "affected" bitmap (1 bit per id, staged in LDS: 6 KB for 50k fragments)?  The list is sorted by
+//      row, so whole waves fail this test together and never load their `col` words;
+//   2. col id in the bitmap?
+//   3. the 4-byte relevance codes of both fragments (global, L2 resident) -> nibble mask of neighbours.
+// Survivors are appended to a queue (wave-aggregated atomics) for k_post.  Counts are not read here at all.
+template <bool SINGLE_SUB, bool LDS_BITMAP>
+__global__ __launch_bounds__(256) void k_scan(const int* __restrict__ row, const int* __restrict__ col, long long nnz,
                                                const int* __restrict__ sub2bin, const unsigned* __restrict__ codes,
-                                               const Geo* __restrict__ geo, const Stat* __restrict__ stat,
-                                               const int* __restrict__ lcontbp, const NbTables* __restrict__ tabs, int K,
-                                               float nfpb, Par par, long long* __restrict__ out,
-                                               unsigned long long* __restrict__ n_relevant)
+                                               const unsigned* __restrict__ bitmap, int bitmap_words,
+                                               const NbTables* __restrict__ tabs, int K, QEntry* __restrict__ queue,
+                                               unsigned long long* __restrict__ counters /* n_rel, n_items, queue count */)
 {
-    __shared__ long long acc[MAXK * N_OPS];
-    __shared__ Xf s_xf[MAXK][N_OPS][NP];
-    __shared__ unsigned long long s_changed[MAXK][N_OPS];
-    for (int i = threadIdx.x; i < MAXK * N_OPS; i += blockDim.x) acc[i] = 0;
-    for (int i = threadIdx.x; i < K * N_OPS * NP; i += blockDim.x) {
-        const int k = i / (N_OPS * NP), r = i % (N_OPS * NP);
-        s_xf[k][r / NP][r % NP] = tabs[k].xf[r / NP][r % NP];
+    extern __shared__ unsigned s_bm[];
+    if (LDS_BITMAP) {
+        for (int i = threadIdx.x; i < bitmap_words; i += blockDim.x) s_bm[i] = bitmap[i];
+        __syncthreads();
     }
-    for (int i = threadIdx.x; i < K * N_OPS; i += blockDim.x) s_changed[i / N_OPS][i % N_OPS] = tabs[i / N_OPS].changed[i % N_OPS];
-    __syncthreads();
-    unsigned long long n_rel = 0;
+    const unsigned* bm = LDS_BITMAP ? s_bm : bitmap;
+    unsigned long long intra = 0; // bit 8k + p: piece p of neighbour k changes internally under some candidate
+    for (int k = 0; k < K; k++) intra |= (unsigned long long)(tabs[k].intra_any & 0xffu) << (8 * k);
     const long long n4 = nnz >> 2;
-    const int4* row4 = reinterpret_cast<const int4*>(row);
-    const int4* col4 = reinterpret_cast<const int4*>(col);
-    const int4* cnt4 = reinterpret_cast<const int4*>(cnt);
+    const int tail = (int)(nnz - (n4 << 2));
+    const int4* __restrict__ row4 = reinterpret_cast<const int4*>(row);
+    const int4* __restrict__ col4 = reinterpret_cast<const int4*>(col);
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n4 + 1; g += stride) {
-        int r[4], c[4], v[4], m = 4;
-        if (g < n4) {
-            const int4 r4 = row4[g], c4 = col4[g], v4 = cnt4[g];
-            r[0] = r4.x; r[1] = r4.y; r[2] = r4.z; r[3] = r4.w;
-            c[0] = c4.x; c[1] = c4.y; c[2] = c4.z; c[3] = c4.w;
-            v[0] = v4.x; v[1] = v4.y; v[2] = v4.z; v[3] = v4.w;
-        } else { // tail (nnz % 4 contacts), handled by exactly one thread
-            m = (int)(nnz - (n4 << 2));
-            for (int j = 0; j < m; j++) { r[j] = row[(n4 << 2) + j]; c[j] = col[(n4 << 2) + j]; v[j] = cnt[(n4 << 2) + j]; }
-        }
+    const int lane = threadIdx.x & 63;
+    unsigned long long n_rel = 0;
+    for (long long g0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; g0 <= n4; g0 += 2 * stride) {
+        // two groups of 4 contacts per iteration (the arrays are padded: the tail group stays in bounds)
+        const long long g1 = g0 + stride;
+        const bool has1 = g1 <= n4;
+        const int4 ra = row4[g0];
+        int4 rb = make_int4(0, 0, 0, 0);
+        if (has1) rb = row4[g1];
+        const int r[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+        const int va = g0 < n4 ? 4 : tail, vb = has1 ? (g1 < n4 ? 4 : tail) : 0;
+        unsigned hit = 0; // bit j: contact j of this lane has an affected row
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (j >= m) break;
-            int fx, fy, slx = 0, sly = 0;
-            if (SINGLE_SUB) { fx = r[j]; fy = c[j]; }
-            else { const int a = sub2bin[r[j]], b = sub2bin[c[j]]; fx = a >> 2; fy = b >> 2; slx = a & 3; sly = b & 3; }
-            const unsigned ci = codes[fx], cj = codes[fy];
-            const unsigned ti = ci & 0x77777777u, tj = cj & 0x77777777u;
-            const unsigned nzi = (ti | (ti >> 1) | (ti >> 2)) & 0x11111111u;
-            const unsigned nzj = (tj | (tj >> 1) | (tj >> 2)) & 0x11111111u;
-            const unsigned df = ti ^ tj;
-            const unsigned dnz = (df | (df >> 1) | (df >> 2)) & 0x11111111u;
-            unsigned rel = nzi & nzj & (dnz | ((ci >> 3) & 0x11111111u));
-            if (rel == 0) continue;
-            if (!SINGLE_SUB && fx == fy) continue; // a bin's own pixel is never revisited (kernels3.cu:3356-3380)
-            // ---- slow path ----
-            const Geo gx = geo[fx], gy = geo[fy];
-            const Stat sx = stat[fx], sy = stat[fy];
-            const End X0 = end_cur(gx, lcontbp, fx), Y0 = end_cur(gy, lcontbp, fy);
-            const double ln_old = log((double)ex_pair(X0, sx, slx, Y0, sy, sly, nfpb, par));
-            const double ob = (double)v[j];
-            while (rel) {
-                const int k = (__ffs((int)rel) - 1) >> 2;
-                rel &= rel - 1;
-                n_rel++;
-                const int p = (ci >> (4 * k)) & 7, q = (cj >> (4 * k)) & 7;
-                const unsigned long long bit = 1ull << (p * 8 + q);
-                for (int op = 0; op < N_OPS; op++) {
-                    if (!(s_changed[k][op] & bit)) continue;
-                    const End X = end_xf(gx, s_xf[k][op][p]), Y = end_xf(gy, s_xf[k][op][q]);
-                    const double ln_new = log((double)ex_pair(X, sx, slx, Y, sy, sly, nfpb, par));
-                    const long long qv = to_q(ob * (ln_new - ln_old));
-                    if (qv != 0) atomicAdd((unsigned long long*)&acc[k * N_OPS + op], (unsigned long long)qv);
+        for (int j = 0; j < 8; j++) {
+            const bool valid = j < 4 ? (j < va) : (j - 4 < vb);
+            if (valid && ((bm[r[j] >> 5] >> (r[j] & 31)) & 1u)) hit |= 1u << j;
+        }
+        if (__ballot(hit != 0) == 0) continue; // the common case: nobody in this wave needs its col words
+        int c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hit & 0x0fu) { const int4 ca = col4[g0]; c[0] = ca.x; c[1] = ca.y; c[2] = ca.z; c[3] = ca.w; }
+        if (hit & 0xf0u) { const int4 cb = col4[g1]; c[4] = cb.x; c[5] = cb.y; c[6] = cb.z; c[7] = cb.w; }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            unsigned rel = 0;
+            if (((hit >> j) & 1u) && ((bm[c[j] >> 5] >> (c[j] & 31)) & 1u)) {
+                int fx, fy;
+                if (SINGLE_SUB) { fx = r[j]; fy = c[j]; }
+                else { fx = sub2bin[r[j]] >> 2; fy = sub2bin[c[j]] >> 2; }
+                const unsigned ci = codes[fx], cj = codes[fy];
+                const unsigned nzi = (ci | (ci >> 1) | (ci >> 2)) & 0x11111111u;
+                const unsigned nzj = (cj | (cj >> 1) | (cj >> 2)) & 0x11111111u;
+                const unsigned df = ci ^ cj;
+                const unsigned dnz = (df | (df >> 1) | (df >> 2)) & 0x11111111u;
+                const unsigned both = nzi & nzj;
+                rel = both & dnz;
+                if (intra != 0) { // same non-empty piece: relevant only if that piece changes internally
+                    unsigned same = both & ~dnz;
+                    while (same) {
+                        const int k = (__ffs((int)same) - 1) >> 2;
+                        same &= same - 1;
+                        if ((intra >> (8 * k + ((ci >> (4 * k)) & 7u))) & 1ull) rel |= 1u << (4 * k);
+                    }
+                }
+                if (!SINGLE_SUB && fx == fy) rel = 0; // a bin's own pixel is never revisited (kernels3.cu:3356-3380)
+            }
+            const unsigned long long bal = __ballot(rel != 0);
+            if (bal) {
+                const int leader = __ffsll((long long)bal) - 1;
+                unsigned long long base = 0;
+                if (lane == leader) base = atomicAdd(&counters[2], (unsigned long long)__popcll(bal));
+                base = __shfl(base, leader, 64);
+                if (rel) {
+                    QEntry e; e.idx = (unsigned)(((j < 4 ? g0 : g1) << 2) + (j & 3)); e.rel = rel;
+                    queue[base + __popcll(bal & ((1ull << lane) - 1ull))] = e;
+                    n_rel += __popc(rel);
                 }
             }
         }
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < K * N_OPS; i += blockDim.x)
-        if (acc[i] != 0) atomicAdd((unsigned long long*)&out[i], (unsigned long long)acc[i]);
     n_rel = (unsigned long long)wave_sum_ll((long long)n_rel);
-    if ((threadIdx.x & 63) == 0 && n_rel) atomicAdd(n_relevant, n_rel);
+    if (lane == 0 && n_rel) atomicAdd(&counters[0], n_rel);
 }
 
-// ------------------------------------------------------------------ mass tasks
-// work item = (neighbour, task, chunk of 64 fragments of piece p); one wave per item, lane = fragment x.
-__global__ __launch_bounds__(64) void k_mass(const NbTables* __restrict__ tabs, int K,
+// k_post: (1) mass tasks -- work item = (neighbour, task, chunk of 64 fragments of the task's first piece), one wave per
+// item, lane = fragment x; (2) the queued contacts -- 16 lanes per contact, lane = candidate op.
+__global__ __launch_bounds__(64) void k_post(const NbTables* __restrict__ tabs, int K,
                                               const int* __restrict__ perm, const int* __restrict__ contig_off,
-                                              const Geo* __restrict__ geo, const Stat* __restrict__ stat, float nfpb,
+                                              const Geo* __restrict__ geo, const Stat* __restrict__ stat,
+                                              const int* __restrict__ lcontbp, const int* __restrict__ row,
+                                              const int* __restrict__ col, const int* __restrict__ cnt,
+                                              const int* __restrict__ sub2bin, const unsigned* __restrict__ codes,
+                                              const QEntry* __restrict__ queue, float nfpb,
                                               Par par, int reach_bp, int rank, int world, long long* __restrict__ out,
-                                              unsigned long long* __restrict__ n_items)
+                                              unsigned long long* __restrict__ counters)
 {
     const int lane = threadIdx.x;
     unsigned long long items = 0;
@@ -618,8 +661,8 @@ __global__ __launch_bounds__(64) void k_mass(const NbTables* __restrict__ tabs, 
                 const End Q0 = end_xf(geo[fq0], tk.xq);
                 const bool x_below = X.start_bp < Q0.start_bp;
                 const bool asc = (tk.xq.sigma > 0) == x_below; // walk q by increasing old position?
-                for (int s = 0; s < nq; s++) {
-                    const int iy = asc ? s : nq - 1 - s;
+                for (int st = 0; st < nq; st++) {
+                    const int iy = asc ? st : nq - 1 - st;
                     const int fy = perm[base_q + iy];
                     const Geo gy = geo[fy];
                     const End Y = end_xf(gy, tk.xq);
@@ -643,7 +686,36 @@ __global__ __launch_bounds__(64) void k_mass(const NbTables* __restrict__ tabs, 
         }
     }
     }
-    if (lane == 0 && items) atomicAdd(n_items, items);
+    if (lane == 0 && items) atomicAdd(&counters[1], items);
+    // ---- queued contacts: 4 per wave pass, lane & 15 = candidate op ----
+    const unsigned long long nq_total = counters[2]; // written by k_scan, the previous kernel on the stream
+    const int op = lane & 15;
+    for (unsigned long long e0 = (unsigned long long)blockIdx.x * 4; e0 < nq_total; e0 += (unsigned long long)gridDim.x * 4) {
+        const unsigned long long e = e0 + (lane >> 4);
+        if (e >= nq_total || op >= N_OPS) continue;
+        const QEntry qe = queue[e];
+        const int ra = row[qe.idx], ca = col[qe.idx];
+        int fx = ra, fy = ca, slx = 0, sly = 0;
+        if (sub2bin) { const int a = sub2bin[ra], b = sub2bin[ca]; fx = a >> 2; fy = b >> 2; slx = a & 3; sly = b & 3; }
+        const Geo gx = geo[fx], gy = geo[fy];
+        const Stat sx = stat[fx], sy = stat[fy];
+        const End X0 = end_cur(gx, lcontbp, fx), Y0 = end_cur(gy, lcontbp, fy);
+        const double ln_old = log((double)ex_pair(X0, sx, slx, Y0, sy, sly, nfpb, par));
+        const double ob = (double)cnt[qe.idx];
+        const unsigned ci = codes[fx], cj = codes[fy];
+        unsigned rel = qe.rel;
+        while (rel) {
+            const int k = (__ffs((int)rel) - 1) >> 2;
+            rel &= rel - 1;
+            const int p = (ci >> (4 * k)) & 7, q = (cj >> (4 * k)) & 7;
+            const NbTables& T = tabs[k];
+            if (!((T.changed[op] >> (p * 8 + q)) & 1ull)) continue;
+            const End X = end_xf(gx, T.xf[op][p]), Y = end_xf(gy, T.xf[op][q]);
+            const double ln_new = log((double)ex_pair(X, sx, slx, Y, sy, sly, nfpb, par));
+            const long long qv = to_q(ob * (ln_new - ln_old));
+            if (qv != 0) atomicAdd((unsigned long long*)&out[k * N_OPS + op], (unsigned long long)qv);
+        }
+    }
 }
 
 // ------------------------------------------------------------------ host side
@@ -674,6 +746,10 @@ struct Ctx {
     int* sub2bin = nullptr;
     int *row = nullptr, *col = nullptr, *cnt = nullptr;
     unsigned* codes = nullptr;
+    QEntry* queue = nullptr;
+    unsigned* bitmap = nullptr;   // 1 bit per contact-list id (sub-fragment id)
+    int bitmap_words = 0;
+    int* d_sub_ids = nullptr;     // [n_bins][4], only when some bin has more than one sub-fragment
     unsigned long long *keys = nullptr, *keys_sorted = nullptr;
     int *o2n = nullptr, *len_of = nullptr, *contig_off = nullptr, *perm = nullptr;
     void* cub_tmp = nullptr;
@@ -783,7 +859,7 @@ void graal_destroy(graal_ctx* h)
     if (h->stream) {
         hipSetDevice(h->device);
         hipStreamSynchronize(h->stream);
-        void* ptrs[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->stat, h->sub2bin, h->row, h->col, h->cnt, h->codes,
+        void* ptrs[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->stat, h->sub2bin, h->row, h->col, h->cnt, h->codes, h->queue, h->bitmap, h->d_sub_ids,
                         h->keys, h->keys_sorted, h->o2n, h->len_of, h->contig_off, h->perm, h->cub_tmp, h->tabs,
                         h->d_scalars, h->d_qout};
         for (void* p : ptrs) if (p) hipFree(p);
@@ -835,7 +911,14 @@ int graal_upload_subfrags(graal_ctx* h, const int32_t* sub_id, const float* sub_
     for (int v : s2b) if (v < 0) return fail(h, GRAAL_E_ARG, "every sub-fragment must belong to a bin");
     // single_sub additionally needs sub id == bin id so that the scan can skip the sub2bin gather
     for (int b = 0; single && b < n_bins; b++) single = (sub_id[4 * b] == b);
-    if (h->stat) { hipFree(h->stat); hipFree(h->sub2bin); }
+    if (h->stat) { (void)hipFree(h->stat); (void)hipFree(h->sub2bin); (void)hipFree(h->bitmap); (void)hipFree(h->d_sub_ids); h->d_sub_ids = nullptr; }
+    h->bitmap_words = (n_sub_total + 31) / 32 + 64; // + slack: k_prep writes whole 64-fragment ballots
+    CK(hipMalloc(&h->bitmap, sizeof(unsigned) * (size_t)h->bitmap_words));
+    CK(hipMemset(h->bitmap, 0, sizeof(unsigned) * (size_t)h->bitmap_words));
+    if (!single) {
+        CK(hipMalloc(&h->d_sub_ids, sizeof(int) * 4 * (size_t)n_bins));
+        CK(hipMemcpy(h->d_sub_ids, sub_id, sizeof(int) * 4 * (size_t)n_bins, hipMemcpyHostToDevice));
+    }
     CK(hipMalloc(&h->stat, sizeof(Stat) * (size_t)n_bins));
     CK(hipMalloc(&h->sub2bin, sizeof(int) * (size_t)n_sub_total));
     CK(hipMemcpy(h->stat, st.data(), sizeof(Stat) * (size_t)n_bins, hipMemcpyHostToDevice));
@@ -858,9 +941,11 @@ int graal_upload_contacts(graal_ctx* h, const int32_t* row, const int32_t* col, 
         if (count[i] <= 0) return fail(h, GRAAL_E_ARG, "contact counts must be > 0");
         c_lf += count[i] < 16 ? lf_small[count[i]] : lf_term((double)count[i]);
     }
-    if (h->row) { hipFree(h->row); hipFree(h->col); hipFree(h->cnt); h->row = h->col = h->cnt = nullptr; }
-    const size_t bytes = sizeof(int) * (size_t)(nnz + 4); // +4: int4 tail reads stay in bounds
+    if (h->row) { (void)hipFree(h->row); (void)hipFree(h->col); (void)hipFree(h->cnt); (void)hipFree(h->queue); h->row = h->col = h->cnt = nullptr; h->queue = nullptr; }
+    const size_t bytes = sizeof(int) * (size_t)(nnz + 8); // +8: int4 tail reads stay in bounds
     CK(hipMalloc(&h->row, bytes)); CK(hipMalloc(&h->col, bytes)); CK(hipMalloc(&h->cnt, bytes));
+    CK(hipMemset(h->row, 0, bytes)); CK(hipMemset(h->col, 0, bytes));
+    CK(hipMalloc(&h->queue, sizeof(QEntry) * (size_t)(nnz + 8))); // every contact may be relevant in the worst case
     if (nnz) {
         CK(hipMemcpy(h->row, row, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
         CK(hipMemcpy(h->col, col, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
@@ -933,7 +1018,7 @@ int graal_layout_stats(graal_ctx* h, int64_t out[8])
     long long init[8] = {0, 0, 0, 0, 0, 0x7fffffff, 0, -1};
     CK(hipMemcpyAsync(h->d_scalars, init, sizeof init, hipMemcpyHostToDevice, h->stream));
     CK(hipMemsetAsync(h->d_scalars + 14, 0, sizeof(long long), h->stream));
-    k_stats<<<std::min(blocks_for(h->n, 256), 512), 256, 0, h->stream>>>(h->soa[h->cur], h->n, h->d_scalars);
+    k_stats<<<std::min(blocks_for(h->n, 256), 64), 256, 0, h->stream>>>(h->soa[h->cur], h->n, h->d_scalars);
     CK(hipGetLastError());
     long long res[16];
     CK(hipMemcpyAsync(res, h->d_scalars, sizeof res, hipMemcpyDeviceToHost, h->stream));
@@ -953,7 +1038,7 @@ int graal_relabel_contigs(graal_ctx* h, int32_t* max_id)
     SoaPtr s = h->soa[h->cur];
     long long init[8] = {0, 0, 0, 0, 0, 0x7fffffff, 0, -1};
     CK(hipMemcpyAsync(h->d_scalars, init, sizeof init, hipMemcpyHostToDevice, h->stream));
-    k_stats<<<std::min(nb, 512), bs, 0, h->stream>>>(s, n, h->d_scalars);
+    k_stats<<<std::min(nb, 64), bs, 0, h->stream>>>(s, n, h->d_scalars);
     k_relabel_keys<<<nb, bs, 0, h->stream>>>(s, n, h->keys);
     CK(hipGetLastError());
     size_t tb = h->cub_tmp_bytes;
@@ -1020,29 +1105,29 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     hipStream_t st = stream_v ? (hipStream_t)stream_v : h->stream;
     SoaPtr s = h->soa[h->cur];
     const int n = h->n;
+    unsigned long long* counters = (unsigned long long*)(h->d_scalars + 10); // n_rel, n_items, queue count
     CK(hipEventRecord(h->ev[0], st));
-    CK(hipMemsetAsync(d_q_out, 0, sizeof(long long) * (size_t)K * N_OPS, st));
-    CK(hipMemsetAsync(h->d_scalars + 10, 0, 3 * sizeof(long long), st));
-    k_tables<<<K, 256, 0, st>>>(s, fA, nb, max_id, h->tabs, (int*)(h->d_scalars + 12));
-    k_codes<<<blocks_for(n, 256), 256, 0, st>>>(s, n, K, h->tabs, h->codes);
+    if (!h->single_sub) CK(hipMemsetAsync(h->bitmap, 0, sizeof(unsigned) * (size_t)h->bitmap_words, st));
+    k_prep<<<K + blocks_for(n, 256), 256, 0, st>>>(s, n, fA, nb, K, max_id, h->tabs, h->codes, h->bitmap, h->d_sub_ids,
+                                                    (long long*)d_q_out, (long long*)counters);
     CK(hipEventRecord(h->ev[1], st));
     {
         const long long groups = (h->nnz >> 2) + 1;
-        const int nbk = (int)std::min<long long>((groups + 255) / 256, 256 * 8);
-        if (h->single_sub)
-            k_scan<true><<<nbk, 256, 0, st>>>(h->row, h->col, h->cnt, h->nnz, h->sub2bin, h->codes, h->geo, h->stat,
-                                              s.p[F_LCONTBP], h->tabs, K, h->nfpb, h->par, (long long*)d_q_out,
-                                              (unsigned long long*)(h->d_scalars + 10));
-        else
-            k_scan<false><<<nbk, 256, 0, st>>>(h->row, h->col, h->cnt, h->nnz, h->sub2bin, h->codes, h->geo, h->stat,
-                                               s.p[F_LCONTBP], h->tabs, K, h->nfpb, h->par, (long long*)d_q_out,
-                                               (unsigned long long*)(h->d_scalars + 10));
+        const int nbk = (int)std::min<long long>((groups + 511) / 512, 256 * 8);
+        const int words = (h->n_sub_total + 31) / 32 + 2;
+        const bool lds = words * 4 <= 16 * 1024; // keeps 8 blocks of 256 threads per CU
+        const size_t shm = lds ? (size_t)words * 4 : 0;
+#define GRAAL_SCAN(SS, LB) k_scan<SS, LB><<<nbk, 256, shm, st>>>(h->row, h->col, h->nnz, h->sub2bin, h->codes, h->bitmap, words, h->tabs, K, h->queue, counters)
+        if (h->single_sub) { if (lds) GRAAL_SCAN(true, true); else GRAAL_SCAN(true, false); }
+        else { if (lds) GRAAL_SCAN(false, true); else GRAAL_SCAN(false, false); }
+#undef GRAAL_SCAN
     }
     CK(hipEventRecord(h->ev[2], st));
     {
         const int nbm = std::min(std::max((n + 63) / 64 * 4, 256), 256 * 16);
-        k_mass<<<nbm, 64, 0, st>>>(h->tabs, K, h->perm, h->contig_off, h->geo, h->stat, h->nfpb, h->par,
-                                    reach_bp(h), rank, world, (long long*)d_q_out, (unsigned long long*)(h->d_scalars + 11));
+        k_post<<<nbm, 64, 0, st>>>(h->tabs, K, h->perm, h->contig_off, h->geo, h->stat, s.p[F_LCONTBP], h->row, h->col,
+                                    h->cnt, h->single_sub ? nullptr : h->sub2bin, h->codes, h->queue, h->nfpb, h->par,
+                                    reach_bp(h), rank, world, (long long*)d_q_out, counters);
     }
     CK(hipEventRecord(h->ev[3], st));
     CK(hipGetLastError());
@@ -1100,7 +1185,7 @@ int graal_last_counters(graal_ctx* h, int64_t out[4])
     CK(hipSetDevice(h->device));
     long long res[3];
     CK(hipMemcpy(res, h->d_scalars + 10, sizeof res, hipMemcpyDeviceToHost));
-    out[0] = h->nnz; out[1] = res[0]; out[2] = 0; out[3] = res[1];
+    out[0] = h->nnz; out[1] = res[0]; out[2] = res[2]; out[3] = res[1];
     return GRAAL_OK;
 }
 

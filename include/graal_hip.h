@@ -100,10 +100,10 @@ int graal_eval_candidates(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K
 int graal_apply_move(graal_ctx* h, int32_t fA, int32_t fB, int32_t op, int32_t max_id, int32_t* n_stale);
 
 /* timing of the last graal_eval_candidates* call, HIP events on the engine's stream (milliseconds):
- * out[0]=tables+codes out[1]=contact scan out[2]=expected-mass tasks out[3]=combine */
+ * out[0]=k_prep (tables + codes) out[1]=k_scan (contact stream) out[2]=k_post (mass tasks + queued contacts) out[3]=0 */
 int graal_last_timing(graal_ctx* h, float out[4]);
 /* counters of the last call: out[0]=contacts scanned out[1]=relevant (contact, neighbour) pairs
- * out[2]=mass tasks out[3]=mass work items */
+ * out[2]=queued (relevant) contacts out[3]=mass work items */
 int graal_last_counters(graal_ctx* h, int64_t out[4]);
 
 #ifdef __cplusplus

@@ -53,7 +53,7 @@ def test_trace_matches_oracle(n_sub, seed, n_bins, nnz, cycles, delta):
     for k in O.FIELDS:                                                    # fragment ordering, bit-exact
         assert np.array_equal(getattr(g.gpu_vect_frags, k), ora.gpu_vect_frags[k]), k
     # the run did something: contigs were merged back from the exploded genome
-    assert t_gpu.n_contigs[-1] <= P["n_frags"] // 2
+    assert t_gpu.n_contigs[-1] < 0.7 * P["n_frags"]
     # full re-evaluation agrees with the carried-over likelihood
     assert g.eval_likelihood() == pytest.approx(ora.init_likelihood(), rel=1e-6)
     g.free_gpu()

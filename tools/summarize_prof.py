@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Reduce a rocprofv3 output tree (tools/profile_gpu.sh) to small summaries that can be committed under profiles/.
+
+  <dir>/trace : --kernel-trace --stats      -> kernel_stats (copied) + per-kernel duration stats from the trace
+  <dir>/fetch : --pmc FETCH_SIZE            -> per-kernel counter stats
+  <dir>/write : --pmc WRITE_SIZE            -> per-kernel counter stats
+
+HBM bytes per launch follow MI355X_MICROARCH.md section HBM: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 on gfx950
+(FETCH_SIZE reports half of a wide coalesced streaming read; both counters are in KiB).
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def find(d, pat):
+    r = glob.glob(os.path.join(d, "**", pat), recursive=True)
+    return r[0] if r else None
+
+
+def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    if "rocprim" in name or "hipcub" in name:
+        for key in ("merge_sort_block_merge", "merge_sort_block_sort", "radix_sort", "onesweep", "lookback_scan_state", "scan_impl", "histogram"):
+            if key in name:
+                return "rocprim::" + key
+        return "rocprim::other"
+    return name.split("(")[0].split("<")[0].strip() + ("<true>" if "k_scan<true>" in name else "<false>" if "k_scan<false>" in name else "")
+
+
+def trace_stats(path, last_n=100):
+    per = defaultdict(list)
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            per[short(row["Kernel_Name"])].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    out = {}
+    for k, v in per.items():
+        tail = v[-last_n:]
+        out[k] = {"calls": len(v), "total_ms": sum(v) / 1e6, "avg_us": sum(v) / len(v) / 1e3, "min_us": min(v) / 1e3,
+                  "max_us": max(v) / 1e3, "avg_us_last_%d" % last_n: sum(tail) / len(tail) / 1e3}
+    return out
+
+
+def counter_stats(path, last_n=100):
+    per = defaultdict(lambda: defaultdict(list))
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            per[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    out = {}
+    for k, cs in per.items():
+        out[k] = {}
+        for c, v in cs.items():
+            tail = v[-last_n:]
+            out[k][c] = {"n": len(v), "mean": sum(v) / len(v), "mean_last_%d" % last_n: sum(tail) / len(tail),
+                         "min": min(v), "max": max(v)}
+    return out
+
+
+def main():
+    d, tag = sys.argv[1], sys.argv[2]
+    res = {"tag": tag}
+    t = find(os.path.join(d, "trace"), "*kernel_trace.csv")
+    if t:
+        res["kernel_trace"] = trace_stats(t)
+    ks = find(os.path.join(d, "trace"), "*kernel_stats.csv")
+    if ks:
+        res["kernel_stats_csv"] = open(ks).read()
+    for name in ("fetch", "write"):
+        c = find(os.path.join(d, name), "*counter_collection.csv")
+        if c:
+            res["pmc_" + name] = counter_stats(c)
+    scan = [k for k in res.get("pmc_fetch", {}) if "k_scan" in k]
+    if scan and scan[0] in res.get("pmc_write", {}):
+        k = scan[0]
+        fetch = res["pmc_fetch"][k]["FETCH_SIZE"]["mean_last_100"]
+        write = res["pmc_write"][k]["WRITE_SIZE"]["mean_last_100"]
+        res["k_scan_hbm_bytes_per_launch"] = (2.0 * fetch + write) * 1024.0
+        res["k_scan_fetch_size_kib"] = fetch
+        res["k_scan_write_size_kib"] = write
+    with open(os.path.join(d, "summary_%s.json" % tag), "w") as f:
+        json.dump(res, f, indent=1)
+    # human readable
+    with open(os.path.join(d, "summary_%s.md" % tag), "w") as f:
+        f.write("# rocprofv3 summary %s\n\n## kernel trace (durations from --kernel-trace)\n\n" % tag)
+        f.write("| kernel | calls | total ms | avg us | min us | max us | avg us (last 100) |\n|---|---|---|---|---|---|---|\n")
+        for k, v in sorted(res.get("kernel_trace", {}).items(), key=lambda kv: -kv[1]["total_ms"]):
+            f.write("| %s | %d | %.3f | %.2f | %.2f | %.2f | %.2f |\n" % (k[:70], v["calls"], v["total_ms"], v["avg_us"], v["min_us"],
+                                                                  v["max_us"], v["avg_us_last_100"]))
+        for name in ("fetch", "write"):
+            if "pmc_" + name in res:
+                f.write("\n## PMC pass: %s (KiB per dispatch)\n\n| kernel | counter | n | mean | mean last 100 | min | max |\n|---|---|---|---|---|---|---|\n" % name)
+                for k, cs in res["pmc_" + name].items():
+                    for c, v in cs.items():
+                        f.write("| %s | %s | %d | %.1f | %.1f | %.1f | %.1f |\n" % (k[:70], c, v["n"], v["mean"], v["mean_last_100"], v["min"], v["max"]))
+        if "k_scan_hbm_bytes_per_launch" in res:
+            f.write("\nk_scan HBM bytes / launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 = %.0f\n" % res["k_scan_hbm_bytes_per_launch"])
+        if "kernel_stats_csv" in res:
+            f.write("\n## rocprofv3 --stats (kernel_stats.csv)\n\n```\n%s```\n" % res["kernel_stats_csv"])
+    print(open(os.path.join(d, "summary_%s.md" % tag)).read()[:6000])
+
+
+if __name__ == "__main__":
+    main()
