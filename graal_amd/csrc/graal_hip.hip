@@ -89,7 +89,12 @@ __device__ __forceinline__ float rippe_circ(float s, float s_tot, const Par& p)
 // dynamic geometry of one fragment (16-byte record, rebuilt after every layout change)
 struct Geo { int id_c, start_bp, len_bp, flags; }; // flags: bit0 ori==+1, bit1 circ
 // static data of one bin: sub-fragment lengths (kb) and RF counts (simulation_loader.py:673-704)
-struct Stat { float len[3]; int n; int accu[3]; int pad; };
+struct Stat { float l0, l1, l2; int n; int a0, a1, a2; int pad; };
+// 3-way selects instead of indexed arrays: indexed private arrays would live in scratch memory
+__device__ __forceinline__ float sel3(float x0, float x1, float x2, int i) { return i == 0 ? x0 : (i == 1 ? x1 : x2); }
+__device__ __forceinline__ int sel3(int x0, int x1, int x2, int i) { return i == 0 ? x0 : (i == 1 ? x1 : x2); }
+__device__ __forceinline__ float stat_len(const Stat& s, int i) { return sel3(s.l0, s.l1, s.l2, i); }
+__device__ __forceinline__ int stat_accu(const Stat& s, int i) { return sel3(s.a0, s.a1, s.a2, i); }
 
 // centre (kb) of the sub-fragment stored in data slot `slot`, walking the bin in its orientation with
 // the reference's float32 operation order (kernels3.cu:2997-3060)
@@ -98,13 +103,13 @@ __device__ __forceinline__ float centre_kb(int start_bp, bool fwd, const Stat& s
     const int limit = st.n - 1;
     const int w = fwd ? slot : limit - slot; // walk index of that slot
     const float s0 = (float)start_bp / 1000.0f;
-    const float l0 = fwd ? st.len[0] : st.len[limit];
+    const float l0 = stat_len(st, fwd ? 0 : limit);
     if (w == 0) return s0 + l0 / 2.0f;
     float run = s0 + l0;
-    const float l1 = fwd ? st.len[1] : st.len[limit - 1];
+    const float l1 = stat_len(st, fwd ? 1 : limit - 1);
     if (w == 1) return run + l1 / 2.0f;
     run = run + l1;
-    const float l2 = fwd ? st.len[2] : st.len[limit - 2];
+    const float l2 = stat_len(st, fwd ? 2 : limit - 2);
     return run + l2 / 2.0f;
 }
 
@@ -136,7 +141,7 @@ __device__ __forceinline__ float ex_trans(int ax, int ay, float nfpb, const Par&
 __device__ __forceinline__ float ex_pair(const End& X, const Stat& sx, int slx, const End& Y, const Stat& sy, int sly,
                                          float nfpb, const Par& p)
 {
-    const float norm = (float)(sx.accu[slx] * sy.accu[sly]) / nfpb;
+    const float norm = (float)(stat_accu(sx, slx) * stat_accu(sy, sly)) / nfpb;
     if (X.label != Y.label) return p.v_inter * norm;
     const float s = fabsf(centre_kb(Y.start_bp, Y.fwd, sy, sly) - centre_kb(X.start_bp, X.fwd, sx, slx));
     if (X.circ == 1) return rippe_circ(s, (float)X.lbp / 1000.0f, p) * norm;
@@ -304,7 +309,7 @@ __global__ __launch_bounds__(64) void k_full_mass(int n, const int* __restrict__
             const End Y = end_cur(gy, lcontbp, fy);
             for (int a = 0; a < sx.n; a++)
                 for (int b = 0; b < sy.n; b++)
-                    acc += (double)ex_pair(X, sx, a, Y, sy, b, nfpb, par) - (double)ex_trans(sx.accu[a], sy.accu[b], nfpb, par);
+                    acc += (double)ex_pair(X, sx, a, Y, sy, b, nfpb, par) - (double)ex_trans(stat_accu(sx, a), stat_accu(sy, b), nfpb, par);
         }
     }
     (void)contig_off;
@@ -314,10 +319,12 @@ __global__ __launch_bounds__(64) void k_full_mass(int n, const int* __restrict__
 
 // ------------------------------------------------------------------ candidate tables
 struct Task {            // windowed cis sum between piece p and piece q in one layout
-    int p, q;            // piece ids (p <= q); p == q: pairs inside the piece + bin diagonals
+    int p, q;            // piece ids; p == q: pairs inside the piece.  The larger piece is p (the parallel axis)
     Xf xp, xq;           // transforms of the two pieces in that layout
     unsigned plus, minus; // 13-bit op masks: layouts (ops) in which this sum is the NEW (+) / OLD (-) value
+    int base_p, np, base_q, nq; // position-index ranges of the two pieces (perm[base .. base + n))
 };
+constexpr int ITEM_CAP = 2048; // work items per neighbour with a direct item -> task table (else: binary search)
 
 struct NbTables {        // everything the scan / mass kernels need about one neighbour
     PieceKey key;
@@ -326,15 +333,17 @@ struct NbTables {        // everything the scan / mass kernels need about one ne
     Xf xf[N_OPS][NP];
     unsigned long long changed[N_OPS]; // bit p*8+q (both orders): relation (p,q) changed; p==q: intra
     unsigned intra_any;                // bit p: some op changes piece p internally
-    int n_tasks;
+    int n_tasks, n_items;
     int item_start[MAX_TASKS + 1];     // prefix sum of 64-fragment chunks per task: the mass work list, in a fixed order
+    unsigned item_tc[ITEM_CAP];        // task | chunk << 16 of item w (valid when n_items <= ITEM_CAP)
     Task task[MAX_TASKS];
 };
 
 struct Neigh { int fB[MAXK]; };
 
 // one 256-thread block builds everything about one neighbour
-__device__ void tables_block(const SoaPtr& s, int fA, int fB, int max_id, NbTables& T)
+__device__ void tables_block(const SoaPtr& s, int fA, int fB, int max_id, const int* __restrict__ contig_off, NbTables& T,
+                             int k, int* __restrict__ step_hdr)
 {
     __shared__ Rec A0, B0;
     __shared__ int rep[NP];
@@ -348,6 +357,7 @@ __device__ void tables_block(const SoaPtr& s, int fA, int fB, int max_id, NbTabl
     __shared__ int e_valid[NENT], e_owner[NENT], e_slot[NENT];
     __shared__ unsigned e_plus[NENT], e_minus[NENT];
     __shared__ int n_tasks;
+    __shared__ int s_lo[NP], s_hi[NP], s_contig[NP], s_chunks[NENT], s_start[NENT + 1];
     const int t = threadIdx.x;
     if (t == 0) {
         A0 = ld_rec(s, fA); B0 = ld_rec(s, fB);
@@ -355,19 +365,20 @@ __device__ void tables_block(const SoaPtr& s, int fA, int fB, int max_id, NbTabl
         T.key = key; T.fB = fB;
         piece_representatives(key, fA, fB, A0, B0, rep);
         intra_any = 0; n_tasks = 0;
-        for (int p = 0; p < NP; p++) { T.lo[p] = 0; T.hi[p] = -1; T.contig[p] = -1; }
+        for (int p = 0; p < NP; p++) { s_lo[p] = 0; s_hi[p] = -1; s_contig[p] = -1; }
         if (fA != fB) {
             if (key.cA != key.cB) {
-                T.lo[1] = 0; T.hi[1] = key.a - 1; T.lo[2] = T.hi[2] = key.a; T.lo[3] = key.a + 1; T.hi[3] = A0.l_cont - 1;
-                T.lo[4] = 0; T.hi[4] = key.b - 1; T.lo[5] = T.hi[5] = key.b; T.lo[6] = key.b + 1; T.hi[6] = B0.l_cont - 1;
-                for (int p = 1; p <= 3; p++) { T.contig[p] = key.cA; T.contig[p + 3] = key.cB; }
+                s_lo[1] = 0; s_hi[1] = key.a - 1; s_lo[2] = s_hi[2] = key.a; s_lo[3] = key.a + 1; s_hi[3] = A0.l_cont - 1;
+                s_lo[4] = 0; s_hi[4] = key.b - 1; s_lo[5] = s_hi[5] = key.b; s_lo[6] = key.b + 1; s_hi[6] = B0.l_cont - 1;
+                for (int p = 1; p <= 3; p++) { s_contig[p] = key.cA; s_contig[p + 3] = key.cB; }
             } else {
                 const int lo = key.a < key.b ? key.a : key.b, hi = key.a < key.b ? key.b : key.a;
-                T.lo[1] = 0; T.hi[1] = lo - 1; T.lo[2] = T.hi[2] = lo; T.lo[3] = lo + 1; T.hi[3] = hi - 1;
-                T.lo[4] = T.hi[4] = hi; T.lo[5] = hi + 1; T.hi[5] = A0.l_cont - 1;
-                for (int p = 1; p <= 5; p++) T.contig[p] = key.cA;
+                s_lo[1] = 0; s_hi[1] = lo - 1; s_lo[2] = s_hi[2] = lo; s_lo[3] = lo + 1; s_hi[3] = hi - 1;
+                s_lo[4] = s_hi[4] = hi; s_lo[5] = hi + 1; s_hi[5] = A0.l_cont - 1;
+                for (int p = 1; p <= 5; p++) s_contig[p] = key.cA;
             }
         }
+        for (int p = 0; p < NP; p++) { T.lo[p] = s_lo[p]; T.hi[p] = s_hi[p]; T.contig[p] = s_contig[p]; }
     }
     if (t < N_OPS) changed[t] = 0;
     for (int e = t; e < NENT; e += blockDim.x) { e_valid[e] = 0; e_plus[e] = 0; e_minus[e] = 0; e_owner[e] = e; e_slot[e] = -1; }
@@ -432,14 +443,29 @@ __device__ void tables_block(const SoaPtr& s, int fA, int fB, int max_id, NbTabl
     for (int e = NPAIR + t; e < NENT; e += blockDim.x)
         if (e_valid[e] && e_owner[e] != e) { atomicOr(&e_plus[e_owner[e]], e_plus[e]); }
     __syncthreads();
-    if (t == 0) {
-        int n = 0;
-        for (int e = 0; e < NENT; e++)
-            if (e_valid[e] && e_owner[e] == e) e_slot[e] = n++;   // n <= NENT == MAX_TASKS by construction
-        n_tasks = n;
-        T.n_tasks = n;
-        T.intra_any = intra_any;
-        for (int op = 0; op < N_OPS; op++) T.changed[op] = changed[op];
+    // slots of the surviving (owner) entries, in entry order: ballot prefix over two rounds of 256 entries
+    {
+        __shared__ int wave_tot[8];
+        int carry = 0;
+        for (int round = 0; round * (int)blockDim.x < NENT; round++) {
+            const int e = round * blockDim.x + t;
+            const bool flag = e < NENT && e_valid[e] && e_owner[e] == e;
+            const unsigned long long bal = __ballot(flag);
+            const int w = t >> 6, lane = t & 63;
+            if (lane == 0) wave_tot[w] = __popcll(bal);
+            __syncthreads();
+            int base = carry;
+            for (int i = 0; i < w; i++) base += wave_tot[i];
+            if (flag) e_slot[e] = base + __popcll(bal & ((1ull << lane) - 1ull));
+            for (int i = 0; i < (int)(blockDim.x >> 6); i++) carry += wave_tot[i];
+            __syncthreads();
+        }
+        if (t == 0) {
+            n_tasks = carry;
+            T.n_tasks = carry;
+            T.intra_any = intra_any;
+            for (int op = 0; op < N_OPS; op++) T.changed[op] = changed[op];
+        }
     }
     __syncthreads();
     for (int e = t; e < NENT; e += blockDim.x) {
@@ -450,24 +476,53 @@ __device__ void tables_block(const SoaPtr& s, int fA, int fB, int max_id, NbTabl
         Task tk; tk.p = p; tk.q = q;
         if (e < NPAIR) { tk.xp = xf_old[p]; tk.xq = xf_old[q]; }
         else { const int op = (e - NPAIR) / NPAIR; tk.xp = xf[op][p]; tk.xq = xf[op][q]; }
-        if (T.hi[tk.p] - T.lo[tk.p] < T.hi[tk.q] - T.lo[tk.q]) { // the larger piece goes on the parallel (lane) axis
+        if (s_hi[tk.p] - s_lo[tk.p] < s_hi[tk.q] - s_lo[tk.q]) { // the larger piece goes on the parallel (lane) axis
             const int tp = tk.p; tk.p = tk.q; tk.q = tp;
             const Xf tx = tk.xp; tk.xp = tk.xq; tk.xq = tx;
         }
         tk.plus = e_plus[e]; tk.minus = e_minus[e];
+        tk.np = s_hi[tk.p] - s_lo[tk.p] + 1; tk.nq = s_hi[tk.q] - s_lo[tk.q] + 1;
+        tk.base_p = contig_off[s_contig[tk.p]] + s_lo[tk.p];
+        tk.base_q = contig_off[s_contig[tk.q]] + s_lo[tk.q];
         T.task[e_slot[e]] = tk;
+        s_chunks[e_slot[e]] = (tk.np + 63) / 64;
     }
     __syncthreads();
-    if (t == 0) { // work list: chunks of 64 fragments of the task's first piece, tasks in slot order
+    if (t == 0) { // work list: chunks of 64 fragments of the task's first piece, tasks in slot order (fixed order)
         int acc = 0;
-        for (int i = 0; i < n_tasks; i++) {
-            T.item_start[i] = acc;
-            const int p = T.task[i].p;
-            acc += (T.hi[p] - T.lo[p] + 1 + 63) / 64;
-        }
-        T.item_start[n_tasks] = acc;
+        for (int i = 0; i < n_tasks; i++) { s_start[i] = acc; acc += s_chunks[i]; }
+        s_start[n_tasks] = acc;
+        T.n_items = acc;
     }
+    __syncthreads();
+    for (int i = t; i <= n_tasks; i += blockDim.x) T.item_start[i] = s_start[i];
+    if (s_start[n_tasks] <= ITEM_CAP)
+        for (int i = t; i < n_tasks; i += blockDim.x)
+            for (int w = s_start[i]; w < s_start[i + 1]; w++) T.item_tc[w] = (unsigned)i | ((unsigned)(w - s_start[i]) << 16);
+    if (t == 0) step_hdr[k] = s_start[n_tasks]; // all neighbours' item counts in one cache line for k_post
 }
+
+// Everything the per-step kernels need that does not change from step to step lives in ONE device-resident block
+// (one per layout buffer).  Kernel arguments are fetched by serialised scalar loads from the uncached kernarg
+// segment (~1 us each); with 20+ arguments that prologue cost more than the kernels' work.  Now each kernel
+// takes this pointer plus a handful of per-step scalars.
+struct QEntry;
+struct DevArgs {
+    SoaPtr soa;
+    long long nnz;
+    int n, n_sub_total, bitmap_words, reach_bp;
+    const int *row, *col, *cnt, *sub2bin, *sub2bin_multi /* nullptr when every bin has one sub-fragment */, *sub_ids;
+    const int *contig_off, *perm;
+    const Geo* geo;
+    const Stat* stat;
+    unsigned *codes, *bitmap;
+    NbTables* tabs;
+    int* step_hdr;
+    QEntry* queue;
+    unsigned long long* counters; // n_rel, n_items, queue count
+    float nfpb;
+    Par par;
+};
 
 // ------------------------------------------------------------------ per-step kernels
 // k_prep: blocks [0, K) build the neighbour tables; the other blocks write the per-fragment relevance code
@@ -475,13 +530,19 @@ __device__ void tables_block(const SoaPtr& s, int fA, int fB, int max_id, NbTabl
 // It also writes the "affected" bitmap: bit i set iff contact-list id i (= fragment id when every bin has one
 // sub-fragment) belongs to a fragment with a non-zero code.  bitmap_by_sub != nullptr: bins own up to 3 arbitrary
 // sub-fragment ids, bits are OR-ed into a bitmap the host zeroed beforehand.
-__global__ __launch_bounds__(256) void k_prep(SoaPtr s, int n, int fA, Neigh nb, int K, int max_id, NbTables* __restrict__ tabs,
-                                               unsigned* __restrict__ codes, unsigned* __restrict__ bitmap,
-                                               const int* __restrict__ sub_ids /* [n][4] or nullptr */,
-                                               long long* __restrict__ d_q_out,
-                                               long long* __restrict__ counters /* n_rel, n_items, queue count */)
+__global__ __launch_bounds__(256) void k_prep(const DevArgs* __restrict__ A, int fA, Neigh nb, int K, int max_id,
+                                               long long* __restrict__ d_q_out)
 {
-    if ((int)blockIdx.x < K) { tables_block(s, fA, nb.fB[blockIdx.x], max_id, tabs[blockIdx.x]); return; }
+    const SoaPtr s = A->soa;
+    const int n = A->n;
+    NbTables* __restrict__ tabs = A->tabs;
+    unsigned* __restrict__ codes = A->codes;
+    unsigned* __restrict__ bitmap = A->bitmap;
+    const int* __restrict__ sub_ids = A->sub_ids;
+    const int* __restrict__ contig_off = A->contig_off;
+    int* __restrict__ step_hdr = A->step_hdr;
+    long long* __restrict__ counters = (long long*)A->counters;
+    if ((int)blockIdx.x < K) { tables_block(s, fA, nb.fB[blockIdx.x], max_id, contig_off, tabs[blockIdx.x], blockIdx.x, step_hdr); return; }
     const int b = blockIdx.x - K;
     if (b == 0) {
         for (int i = threadIdx.x; i < K * N_OPS; i += blockDim.x) d_q_out[i] = 0;
@@ -513,7 +574,15 @@ __global__ __launch_bounds__(256) void k_prep(SoaPtr s, int n, int fA, Neigh nb,
     }
 }
 
-struct QEntry { unsigned idx; unsigned rel; }; // contact index in this shard, nibble mask of the neighbours it matters to
+struct QEntry { unsigned idx; unsigned rel; };
+
+// 16-byte streaming (nontemporal) load
+__device__ __forceinline__ int4 ld_stream(const int4* p)
+{
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    const v4i v = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(p));
+    return make_int4(v.x, v.y, v.z, v.w);
+} // contact index in this shard, nibble mask of the neighbours it matters to
 
 // k_scan: ONE streaming pass over this rank's contact list for all 13*K candidates of the step.
 // A contact matters to neighbour k iff its two ends lie in DIFFERENT pieces of k (or in one piece whose circular model
@@ -524,12 +593,18 @@ struct QEntry { unsigned idx; unsigned rel; }; // contact index in this shard, n
 //   3. the 4-byte relevance codes of both fragments (global, L2 resident) -> nibble mask of neighbours.
 // Survivors are appended to a queue (wave-aggregated atomics) for k_post.  Counts are not read here at all.
 template <bool SINGLE_SUB, bool LDS_BITMAP>
-__global__ __launch_bounds__(256) void k_scan(const int* __restrict__ row, const int* __restrict__ col, long long nnz,
-                                               const int* __restrict__ sub2bin, const unsigned* __restrict__ codes,
-                                               const unsigned* __restrict__ bitmap, int bitmap_words,
-                                               const NbTables* __restrict__ tabs, int K, QEntry* __restrict__ queue,
-                                               unsigned long long* __restrict__ counters /* n_rel, n_items, queue count */)
+__global__ __launch_bounds__(256) void k_scan(const DevArgs* __restrict__ A, int K)
 {
+    const int* __restrict__ row = A->row;
+    const int* __restrict__ col = A->col;
+    const long long nnz = A->nnz;
+    const int* __restrict__ sub2bin = A->sub2bin;
+    const unsigned* __restrict__ codes = A->codes;
+    const unsigned* __restrict__ bitmap = A->bitmap;
+    const int bitmap_words = A->bitmap_words;
+    const NbTables* __restrict__ tabs = A->tabs;
+    QEntry* __restrict__ queue = A->queue;
+    unsigned long long* __restrict__ counters = A->counters;
     extern __shared__ unsigned s_bm[];
     if (LDS_BITMAP) {
         for (int i = threadIdx.x; i < bitmap_words; i += blockDim.x) s_bm[i] = bitmap[i];
@@ -549,9 +624,10 @@ __global__ __launch_bounds__(256) void k_scan(const int* __restrict__ row, const
         // two groups of 4 contacts per iteration (the arrays are padded: the tail group stays in bounds)
         const long long g1 = g0 + stride;
         const bool has1 = g1 <= n4;
-        const int4 ra = row4[g0];
+        // nontemporal: the stream must not evict the tables (and the other kernels' code) from L2
+        const int4 ra = ld_stream(row4 + g0);
         int4 rb = make_int4(0, 0, 0, 0);
-        if (has1) rb = row4[g1];
+        if (has1) rb = ld_stream(row4 + g1);
         const int r[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
         const int va = g0 < n4 ? 4 : tail, vb = has1 ? (g1 < n4 ? 4 : tail) : 0;
         unsigned hit = 0; // bit j: contact j of this lane has an affected row
@@ -562,8 +638,8 @@ __global__ __launch_bounds__(256) void k_scan(const int* __restrict__ row, const
         }
         if (__ballot(hit != 0) == 0) continue; // the common case: nobody in this wave needs its col words
         int c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (hit & 0x0fu) { const int4 ca = col4[g0]; c[0] = ca.x; c[1] = ca.y; c[2] = ca.z; c[3] = ca.w; }
-        if (hit & 0xf0u) { const int4 cb = col4[g1]; c[4] = cb.x; c[5] = cb.y; c[6] = cb.z; c[7] = cb.w; }
+        if (hit & 0x0fu) { const int4 ca = ld_stream(col4 + g0); c[0] = ca.x; c[1] = ca.y; c[2] = ca.z; c[3] = ca.w; }
+        if (hit & 0xf0u) { const int4 cb = ld_stream(col4 + g1); c[4] = cb.x; c[5] = cb.y; c[6] = cb.z; c[7] = cb.w; }
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             unsigned rel = 0;
@@ -606,36 +682,71 @@ __global__ __launch_bounds__(256) void k_scan(const int* __restrict__ row, const
     if (lane == 0 && n_rel) atomicAdd(&counters[0], n_rel);
 }
 
+__device__ __forceinline__ int sel_base(const int (&a)[MAXK + 1], int i)
+{
+    int v = a[0];
+#pragma unroll
+    for (int j = 1; j <= MAXK; j++) v = (i == j) ? a[j] : v;
+    return v;
+}
+
 // k_post: (1) mass tasks -- work item = (neighbour, task, chunk of 64 fragments of the task's first piece), one wave per
 // item, lane = fragment x; (2) the queued contacts -- 16 lanes per contact, lane = candidate op.
-__global__ __launch_bounds__(64) void k_post(const NbTables* __restrict__ tabs, int K,
-                                              const int* __restrict__ perm, const int* __restrict__ contig_off,
-                                              const Geo* __restrict__ geo, const Stat* __restrict__ stat,
-                                              const int* __restrict__ lcontbp, const int* __restrict__ row,
-                                              const int* __restrict__ col, const int* __restrict__ cnt,
-                                              const int* __restrict__ sub2bin, const unsigned* __restrict__ codes,
-                                              const QEntry* __restrict__ queue, float nfpb,
-                                              Par par, int reach_bp, int rank, int world, long long* __restrict__ out,
-                                              unsigned long long* __restrict__ counters)
+__global__ __launch_bounds__(64) void k_post(const DevArgs* __restrict__ A, int K, int rank, int world,
+                                              long long* __restrict__ out)
 {
+    const NbTables* __restrict__ tabs = A->tabs;
+    const int* __restrict__ perm = A->perm;
+    const Geo* __restrict__ geo = A->geo;
+    const Stat* __restrict__ stat = A->stat;
+    const int* __restrict__ lcontbp = A->soa.p[F_LCONTBP];
+    const int* __restrict__ row = A->row;
+    const int* __restrict__ col = A->col;
+    const int* __restrict__ cnt = A->cnt;
+    const int* __restrict__ sub2bin = A->sub2bin_multi;
+    const unsigned* __restrict__ codes = A->codes;
+    const QEntry* __restrict__ queue = A->queue;
+    const int* __restrict__ step_hdr = A->step_hdr;
+    const float nfpb = A->nfpb;
+    const Par par = A->par;
+    const int reach_bp = A->reach_bp;
+    unsigned long long* __restrict__ counters = A->counters;
     const int lane = threadIdx.x;
     unsigned long long items = 0;
-    for (int k = 0; k < K; k++) {
-    const NbTables& T = tabs[k];
-    const int n_tasks = T.n_tasks, total = T.item_start[n_tasks];
-    // static sharding of the fixed, ordered item list over ranks; every wave reaches the loop exit
-    for (int w = blockIdx.x * world + rank; w < total; w += gridDim.x * world) {
-        int lo_t = 0, hi_t = n_tasks - 1; // task of item w: last task with item_start <= w
-        while (lo_t < hi_t) { const int mid = (lo_t + hi_t + 1) >> 1; if (T.item_start[mid] <= w) lo_t = mid; else hi_t = mid - 1; }
-        const int ti = lo_t, chunk = w - T.item_start[ti];
-        const Task& tk = T.task[ti];
-        const int np = T.hi[tk.p] - T.lo[tk.p] + 1, nq = T.hi[tk.q] - T.lo[tk.q] + 1;
+    int n_items_k[MAXK];
+#pragma unroll
+    for (int k = 0; k < MAXK; k++) n_items_k[k] = step_hdr[k]; // one cache line, independent loads
+    const unsigned long long nq_total = counters[2]; // written by k_scan, the previous kernel on the stream
+    // one flat, fixed-order list of work items over all neighbours: item W -> (neighbour k, local item w)
+    int item_base[MAXK + 1];
+    item_base[0] = 0;
+#pragma unroll
+    for (int k = 0; k < MAXK; k++) item_base[k + 1] = item_base[k] + (k < K ? n_items_k[k] : 0);
+    const int total_all = item_base[MAXK];
+    // static sharding of the item list over ranks; every wave reaches the loop exit
+    for (int W = blockIdx.x * world + rank; W < total_all; W += gridDim.x * world) {
+        int k = 0;
+#pragma unroll
+        for (int j = 1; j < MAXK; j++) k += (W >= item_base[j]) ? 1 : 0;
+        const int w = W - sel_base(item_base, k);
+        const NbTables& T = tabs[k];
+        const int total = sel_base(item_base, k + 1) - sel_base(item_base, k);
+        int ti, chunk;
+        if (total <= ITEM_CAP) { const unsigned tc = T.item_tc[w]; ti = (int)(tc & 0xffffu); chunk = (int)(tc >> 16); }
+        else { // task of item w: last task with item_start <= w
+            int lo_t = 0, hi_t = T.n_tasks - 1;
+            while (lo_t < hi_t) { const int mid = (lo_t + hi_t + 1) >> 1; if (T.item_start[mid] <= w) lo_t = mid; else hi_t = mid - 1; }
+            ti = lo_t; chunk = w - T.item_start[ti];
+        }
+        const Task tk = T.task[ti];
+        const int np = tk.np, nq = tk.nq, base_p = tk.base_p, base_q = tk.base_q;
         items++;
-        const int base_p = contig_off[T.contig[tk.p]] + T.lo[tk.p];
-        const int base_q = contig_off[T.contig[tk.q]] + T.lo[tk.q];
-        const int ix = chunk * 64 + lane;
+        // lanes: 16 fragments x of the chunk (4 passes cover its 64) times 4 interleaved phases of the y walk
+        const int xi = lane & 15, yph = lane >> 4;
         double acc = 0.0;
-        if (ix < np) {
+        for (int pass = 0; pass < 4; pass++) {
+            const int ix = chunk * 64 + pass * 16 + xi;
+            if (ix >= np) continue;
             const int fx = perm[base_p + ix];
             const Geo gx = geo[fx];
             const Stat sx = stat[fx];
@@ -643,7 +754,7 @@ __global__ __launch_bounds__(64) void k_post(const NbTables* __restrict__ tabs, 
             if (tk.p == tk.q) {
                 // (x's own sub-fragment pairs are left out: candidates never revisit a bin's own pixel)
                 // later fragments of the same piece, walking away from x in the new layout
-                for (int iy = ix + 1; iy < np; iy++) {
+                for (int iy = ix + 1 + yph; iy < np; iy += 4) {
                     const int fy = perm[base_p + iy];
                     const Geo gy = geo[fy];
                     const End Y = end_xf(gy, tk.xp);
@@ -652,7 +763,7 @@ __global__ __launch_bounds__(64) void k_post(const NbTables* __restrict__ tabs, 
                     const Stat sy = stat[fy];
                     for (int a = 0; a < sx.n; a++)
                         for (int b = 0; b < sy.n; b++)
-                            acc += (double)ex_pair(X, sx, a, Y, sy, b, nfpb, par) - (double)ex_trans(sx.accu[a], sy.accu[b], nfpb, par);
+                            acc += (double)ex_pair(X, sx, a, Y, sy, b, nfpb, par) - (double)ex_trans(stat_accu(sx, a), stat_accu(sy, b), nfpb, par);
                 }
             } else {
                 // q's fragment nearest to x in this layout: pieces map to disjoint intervals, so the side is
@@ -661,7 +772,7 @@ __global__ __launch_bounds__(64) void k_post(const NbTables* __restrict__ tabs, 
                 const End Q0 = end_xf(geo[fq0], tk.xq);
                 const bool x_below = X.start_bp < Q0.start_bp;
                 const bool asc = (tk.xq.sigma > 0) == x_below; // walk q by increasing old position?
-                for (int st = 0; st < nq; st++) {
+                for (int st = yph; st < nq; st += 4) {
                     const int iy = asc ? st : nq - 1 - st;
                     const int fy = perm[base_q + iy];
                     const Geo gy = geo[fy];
@@ -671,11 +782,11 @@ __global__ __launch_bounds__(64) void k_post(const NbTables* __restrict__ tabs, 
                     const Stat sy = stat[fy];
                     for (int a = 0; a < sx.n; a++)
                         for (int b = 0; b < sy.n; b++)
-                            acc += (double)ex_pair(X, sx, a, Y, sy, b, nfpb, par) - (double)ex_trans(sx.accu[a], sy.accu[b], nfpb, par);
+                            acc += (double)ex_pair(X, sx, a, Y, sy, b, nfpb, par) - (double)ex_trans(stat_accu(sx, a), stat_accu(sy, b), nfpb, par);
                 }
             }
         }
-        // one Q rounding per fragment x: the partition is fixed by the layout, not by the launch
+        // one Q rounding per (fragment pass, y phase) lane sum: the partition is fixed by the layout, not by the launch
         const long long qv = wave_sum_ll(to_q(acc));
         if (lane == 0 && qv != 0) {
             // logL = contacts - mass: the NEW layout's mass counts negative, the OLD one positive
@@ -685,12 +796,11 @@ __global__ __launch_bounds__(64) void k_post(const NbTables* __restrict__ tabs, 
             }
         }
     }
-    }
     if (lane == 0 && items) atomicAdd(&counters[1], items);
-    // ---- queued contacts: 4 per wave pass, lane & 15 = candidate op ----
-    const unsigned long long nq_total = counters[2]; // written by k_scan, the previous kernel on the stream
+    // ---- queued contacts: 4 per wave pass, lane & 15 = candidate op; taken from the far end of the grid so that they
+    // do not queue up behind the mass items of the low-numbered blocks ----
     const int op = lane & 15;
-    for (unsigned long long e0 = (unsigned long long)blockIdx.x * 4; e0 < nq_total; e0 += (unsigned long long)gridDim.x * 4) {
+    for (unsigned long long e0 = (unsigned long long)(gridDim.x - 1 - blockIdx.x) * 4; e0 < nq_total; e0 += (unsigned long long)gridDim.x * 4) {
         const unsigned long long e = e0 + (lane >> 4);
         if (e >= nq_total || op >= N_OPS) continue;
         const QEntry qe = queue[e];
@@ -755,6 +865,8 @@ struct Ctx {
     void* cub_tmp = nullptr;
     size_t cub_tmp_bytes = 0;
     NbTables* tabs = nullptr;
+    int* step_hdr = nullptr;      // [MAXK] mass work items per neighbour of the current step
+    DevArgs* d_args = nullptr;    // [2]: one argument block per layout buffer
     long long* d_scalars = nullptr; // [0..7] stats, [8..9] full q, [10] n_relevant, [11] n_items, [12] overflow/stale (int)
     long long* d_qout = nullptr;    // K*13
     long long counters[4] = {0, 0, 0, 0};
@@ -815,6 +927,27 @@ void compute_t_all(Ctx* h)
 
 int reach_bp(const Ctx* h) { return (int)ceil((double)h->par.d_max * 1000.0) + 1000; }
 
+// (re)write the two device-resident argument blocks; called whenever a pointer, size or parameter changes
+int sync_args(Ctx* h)
+{
+    DevArgs a[2];
+    for (int b = 0; b < 2; b++) {
+        memset(&a[b], 0, sizeof(DevArgs));
+        a[b].soa = h->soa[b];
+        a[b].nnz = h->nnz; a[b].n = h->n; a[b].n_sub_total = h->n_sub_total;
+        a[b].bitmap_words = (h->n_sub_total + 31) / 32 + 2;
+        a[b].reach_bp = h->have_par ? reach_bp(h) : 0;
+        a[b].row = h->row; a[b].col = h->col; a[b].cnt = h->cnt; a[b].sub2bin = h->sub2bin;
+        a[b].sub2bin_multi = h->single_sub ? nullptr : h->sub2bin; a[b].sub_ids = h->d_sub_ids;
+        a[b].contig_off = h->contig_off; a[b].perm = h->perm; a[b].geo = h->geo; a[b].stat = h->stat;
+        a[b].codes = h->codes; a[b].bitmap = h->bitmap; a[b].tabs = h->tabs; a[b].step_hdr = h->step_hdr;
+        a[b].queue = h->queue; a[b].counters = (unsigned long long*)(h->d_scalars + 10);
+        a[b].nfpb = h->nfpb; a[b].par = h->par;
+    }
+    CK(hipMemcpy(h->d_args, a, sizeof a, hipMemcpyHostToDevice));
+    return GRAAL_OK;
+}
+
 int refresh(Ctx* h)
 {
     k_refresh_geo<<<blocks_for(h->n, 256), 256, 0, h->stream>>>(h->soa[h->cur], h->geo, h->n);
@@ -850,6 +983,8 @@ int graal_create(int device, graal_ctx** out)
     CK(hipMalloc(&h->d_scalars, 16 * sizeof(long long)));
     CK(hipMalloc(&h->d_qout, MAXK * N_OPS * sizeof(long long)));
     CK(hipMalloc(&h->tabs, MAXK * sizeof(NbTables)));
+    CK(hipMalloc(&h->step_hdr, MAXK * sizeof(int)));
+    CK(hipMalloc(&h->d_args, 2 * sizeof(DevArgs)));
     return GRAAL_OK;
 }
 
@@ -857,14 +992,14 @@ void graal_destroy(graal_ctx* h)
 {
     if (!h) return;
     if (h->stream) {
-        hipSetDevice(h->device);
-        hipStreamSynchronize(h->stream);
+        (void)hipSetDevice(h->device);
+        (void)hipStreamSynchronize(h->stream);
         void* ptrs[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->stat, h->sub2bin, h->row, h->col, h->cnt, h->codes, h->queue, h->bitmap, h->d_sub_ids,
-                        h->keys, h->keys_sorted, h->o2n, h->len_of, h->contig_off, h->perm, h->cub_tmp, h->tabs,
+                        h->keys, h->keys_sorted, h->o2n, h->len_of, h->contig_off, h->perm, h->cub_tmp, h->tabs, h->step_hdr, h->d_args,
                         h->d_scalars, h->d_qout};
-        for (void* p : ptrs) if (p) hipFree(p);
-        for (auto& ev : h->ev) if (ev) hipEventDestroy(ev);
-        hipStreamDestroy(h->stream);
+        for (void* p : ptrs) if (p) (void)hipFree(p);
+        for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
+        (void)hipStreamDestroy(h->stream);
     }
     delete h;
 }
@@ -879,7 +1014,8 @@ int graal_set_params(graal_ctx* h, const float* p)
     if (!(h->par.d_max > 0.0f) || !(h->par.d_max < 2.0e6f)) return fail(h, GRAAL_E_ARG, "d_max out of range");
     h->have_par = true;
     compute_t_all(h);
-    return GRAAL_OK;
+    CK(hipSetDevice(h->device));
+    return sync_args(h);
 }
 
 int graal_upload_subfrags(graal_ctx* h, const int32_t* sub_id, const float* sub_len, const int32_t* sub_accu, int32_t n_bins,
@@ -899,7 +1035,8 @@ int graal_upload_subfrags(graal_ctx* h, const int32_t* sub_id, const float* sub_
         h->h_nsub[b] = ns;
         Stat s{};
         s.n = ns;
-        for (int k = 0; k < 3; k++) { s.len[k] = k < ns ? sub_len[3 * b + k] : 0.0f; s.accu[k] = k < ns ? sub_accu[3 * b + k] : 0; }
+        s.l0 = sub_len[3 * b]; s.l1 = ns > 1 ? sub_len[3 * b + 1] : 0.0f; s.l2 = ns > 2 ? sub_len[3 * b + 2] : 0.0f;
+        s.a0 = sub_accu[3 * b]; s.a1 = ns > 1 ? sub_accu[3 * b + 1] : 0; s.a2 = ns > 2 ? sub_accu[3 * b + 2] : 0;
         for (int k = 0; k < ns; k++) {
             const int sid = sub_id[4 * b + k];
             if (sid < 0 || sid >= n_sub_total || s2b[sid] != -1) return fail(h, GRAAL_E_ARG, "sub_id must map sub-fragments to bins one-to-one");
@@ -925,7 +1062,7 @@ int graal_upload_subfrags(graal_ctx* h, const int32_t* sub_id, const float* sub_
     CK(hipMemcpy(h->sub2bin, s2b.data(), sizeof(int) * (size_t)n_sub_total, hipMemcpyHostToDevice));
     h->n_bins = n_bins; h->n_sub_total = n_sub_total; h->nfpb = nfpb; h->single_sub = single; h->have_sub = true;
     compute_t_all(h);
-    return GRAAL_OK;
+    return sync_args(h);
 }
 
 int graal_upload_contacts(graal_ctx* h, const int32_t* row, const int32_t* col, const int32_t* count, int64_t nnz)
@@ -952,7 +1089,7 @@ int graal_upload_contacts(graal_ctx* h, const int32_t* row, const int32_t* col, 
         CK(hipMemcpy(h->cnt, count, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
     }
     h->nnz = nnz; h->c_lf = c_lf; h->have_contacts = true;
-    return GRAAL_OK;
+    return sync_args(h);
 }
 
 int graal_upload_frags(graal_ctx* h, const int32_t* const soa[GRAAL_N_FIELDS], int32_t n)
@@ -969,7 +1106,7 @@ int graal_upload_frags(graal_ctx* h, const int32_t* const soa[GRAAL_N_FIELDS], i
     }
     if (h->n != n) {
         void* old[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->codes, h->keys, h->keys_sorted, h->o2n, h->len_of, h->contig_off, h->perm, h->cub_tmp};
-        for (void* p : old) if (p) hipFree(p);
+        for (void* p : old) if (p) (void)hipFree(p);
         for (int b = 0; b < 2; b++) {
             CK(hipMalloc(&h->soa_mem[b], sizeof(int) * (size_t)n * GRAAL_N_FIELDS));
             for (int k = 0; k < GRAAL_N_FIELDS; k++) h->soa[b].p[k] = h->soa_mem[b] + (size_t)k * n;
@@ -983,8 +1120,8 @@ int graal_upload_frags(graal_ctx* h, const int32_t* const soa[GRAAL_N_FIELDS], i
         CK(hipMalloc(&h->contig_off, sizeof(int) * (size_t)(n + 1)));
         CK(hipMalloc(&h->perm, sizeof(int) * (size_t)n));
         size_t b1 = 0, b2 = 0;
-        hipcub::DeviceRadixSort::SortKeys(nullptr, b1, h->keys, h->keys_sorted, n, 0, 2 * LABEL_BITS, h->stream);
-        hipcub::DeviceScan::ExclusiveSum(nullptr, b2, h->len_of, h->contig_off, n, h->stream);
+        (void)hipcub::DeviceRadixSort::SortKeys(nullptr, b1, h->keys, h->keys_sorted, n, 0, 2 * LABEL_BITS, h->stream);
+        (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b2, h->len_of, h->contig_off, n, h->stream);
         h->cub_tmp_bytes = b1 > b2 ? b1 : b2;
         CK(hipMalloc(&h->cub_tmp, h->cub_tmp_bytes));
         h->n = n;
@@ -996,7 +1133,7 @@ int graal_upload_frags(graal_ctx* h, const int32_t* const soa[GRAAL_N_FIELDS], i
     int rc = refresh(h);
     if (rc) return rc;
     CK(hipStreamSynchronize(h->stream));
-    return GRAAL_OK;
+    return sync_args(h);
 }
 
 int graal_download_frags(graal_ctx* h, int32_t* const soa[GRAAL_N_FIELDS])
@@ -1105,11 +1242,10 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     hipStream_t st = stream_v ? (hipStream_t)stream_v : h->stream;
     SoaPtr s = h->soa[h->cur];
     const int n = h->n;
-    unsigned long long* counters = (unsigned long long*)(h->d_scalars + 10); // n_rel, n_items, queue count
     CK(hipEventRecord(h->ev[0], st));
+    const DevArgs* A = h->d_args + h->cur;
     if (!h->single_sub) CK(hipMemsetAsync(h->bitmap, 0, sizeof(unsigned) * (size_t)h->bitmap_words, st));
-    k_prep<<<K + blocks_for(n, 256), 256, 0, st>>>(s, n, fA, nb, K, max_id, h->tabs, h->codes, h->bitmap, h->d_sub_ids,
-                                                    (long long*)d_q_out, (long long*)counters);
+    k_prep<<<K + blocks_for(n, 256), 256, 0, st>>>(A, fA, nb, K, max_id, (long long*)d_q_out);
     CK(hipEventRecord(h->ev[1], st));
     {
         const long long groups = (h->nnz >> 2) + 1;
@@ -1117,7 +1253,7 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
         const int words = (h->n_sub_total + 31) / 32 + 2;
         const bool lds = words * 4 <= 16 * 1024; // keeps 8 blocks of 256 threads per CU
         const size_t shm = lds ? (size_t)words * 4 : 0;
-#define GRAAL_SCAN(SS, LB) k_scan<SS, LB><<<nbk, 256, shm, st>>>(h->row, h->col, h->nnz, h->sub2bin, h->codes, h->bitmap, words, h->tabs, K, h->queue, counters)
+#define GRAAL_SCAN(SS, LB) k_scan<SS, LB><<<nbk, 256, shm, st>>>(A, K)
         if (h->single_sub) { if (lds) GRAAL_SCAN(true, true); else GRAAL_SCAN(true, false); }
         else { if (lds) GRAAL_SCAN(false, true); else GRAAL_SCAN(false, false); }
 #undef GRAAL_SCAN
@@ -1125,9 +1261,7 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     CK(hipEventRecord(h->ev[2], st));
     {
         const int nbm = std::min(std::max((n + 63) / 64 * 4, 256), 256 * 16);
-        k_post<<<nbm, 64, 0, st>>>(h->tabs, K, h->perm, h->contig_off, h->geo, h->stat, s.p[F_LCONTBP], h->row, h->col,
-                                    h->cnt, h->single_sub ? nullptr : h->sub2bin, h->codes, h->queue, h->nfpb, h->par,
-                                    reach_bp(h), rank, world, (long long*)d_q_out, counters);
+        k_post<<<nbm, 64, 0, st>>>(A, K, rank, world, (long long*)d_q_out);
     }
     CK(hipEventRecord(h->ev[3], st));
     CK(hipGetLastError());

@@ -1,0 +1,102 @@
+"""CPU, world_size = 2 over gloo: the multi-GPU glue of the sampler (graal_amd/dist.py).
+
+Each rank owns a contiguous shard of the contact list, computes the fixed-point (Q30, rounded per contact) sum of its
+contacts' log-likelihood terms with the numpy re-score (the engine's arithmetic convention, oracle/sparse_numpy.py),
+and ONE integer all-reduce yields the total: bit-identical to the unsharded sum, for any world size -- the property
+that lets every rank draw the same move without a broadcast."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as td
+import torch.multiprocessing as mp
+
+from graal_amd import dist as gdist
+from graal_amd import synth
+from oracle.sparse_numpy import SparseScorer
+
+Q = float(1 << 30)
+
+
+def _problem():
+    par = synth.make_param_simu(fact=200.0, v_inter=0.02)
+    return synth.make_problem(n_bins=80, nnz=1500, n_sub=3, seed=9, contig_weights=(5, 4, 3), mean_len_bp=2000.0, accu=9,
+                              param=par)
+
+
+def _q_terms(P, lo, hi):
+    sc = SparseScorer(P["coo_row"], P["coo_col"], P["coo_val"], P["np_sub_frags_id"], P["np_sub_frags_len_bp"],
+                      P["np_sub_frags_accu"], P["mean_squared_frags_per_bin"], P["param_simu"])
+    state = {k: np.asarray(P["S_o_A_frags"][k], np.int32) for k in P["S_o_A_frags"]}
+    centres = sc.centres(state)
+    ex, _ = sc._ex(state, centres, sc.row[lo:hi], sc.col[lo:hi])
+    return np.rint(sc.count[lo:hi] * np.log(ex.astype(np.float64)) * Q).astype(np.int64)
+
+
+def _worker(rank, world, port, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        group = gdist.Group(rank, world)
+        P = _problem()
+        lo, hi = gdist.shard_range(len(P["coo_row"]), rank, world)
+        local = int(_q_terms(P, lo, hi).sum())
+        total = group.all_reduce_sum_int(local)
+        # the per-candidate vector path: one SUM all-reduce of an int64 tensor (13 * K values)
+        vec = torch.arange(65, dtype=torch.int64) * (rank + 1) + local
+        group.all_reduce_sum_(vec)
+        group.barrier()
+        out_q.put((rank, lo, hi, local, total, vec.tolist()))
+    finally:
+        td.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.timeout(180)
+def test_sharded_q_sums_are_bit_identical_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=150) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    P = _problem()
+    want = int(_q_terms(P, 0, len(P["coo_row"])).sum())
+    assert res[0][1] == 0 and res[0][2] == res[1][1] and res[1][2] == len(P["coo_row"])   # shards tile the list
+    assert res[0][4] == res[1][4] == want                                               # every rank: exact total
+    assert res[0][3] + res[1][3] == want
+    locals_sum = res[0][3] + res[1][3]
+    want_vec = [i * 3 + locals_sum for i in range(65)]
+    assert res[0][5] == want_vec and res[1][5] == want_vec
+
+
+def test_group_world1_needs_no_process_group():
+    g = gdist.Group(0, 1)
+    t = torch.arange(5, dtype=torch.int64)
+    assert g.all_reduce_sum_(t).tolist() == [0, 1, 2, 3, 4]
+    assert g.all_reduce_sum_int(7) == 7
+    g.barrier()
+    assert np.array_equal(gdist.q_to_float(np.array([1 << 30, -(1 << 29)])), [1.0, -0.5])
+
+
+def test_env_world_defaults(monkeypatch):
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    assert gdist.env_world() == (0, 1, 0)
+    monkeypatch.setenv("RANK", "3"); monkeypatch.setenv("WORLD_SIZE", "8"); monkeypatch.setenv("LOCAL_RANK", "3")
+    assert gdist.env_world() == (3, 8, 3)

