@@ -336,16 +336,20 @@ class sampler(object):
             return self.engine.eval_candidates(id_fA, id_neighbours, max_id)
         import torch
         out = np.zeros((len(id_neighbours), N_OPS), dtype=np.float64)
+        dev = torch.device("cuda", self.engine.device)
         if self._d_q is None:
-            self._d_q = torch.zeros(MAX_NEIGHBOURS * N_OPS, dtype=torch.int64, device="cuda:%d" % self.engine.device)
-        stream = torch.cuda.current_stream(self.engine.device).cuda_stream
-        for k0 in range(0, len(id_neighbours), MAX_NEIGHBOURS):
-            part = id_neighbours[k0:k0 + MAX_NEIGHBOURS]
-            self.engine.eval_candidates_q_async(id_fA, part, max_id, self._d_q.data_ptr(), stream,
-                                                self.group.rank, self.group.world)
-            self.group.all_reduce_sum_(self._d_q)
-            q = self._d_q[:len(part) * N_OPS].cpu().numpy()
-            out[k0:k0 + len(part)] = gdist.q_to_float(q).reshape(len(part), N_OPS)
+            self._d_q = torch.zeros(MAX_NEIGHBOURS * N_OPS, dtype=torch.int64, device=dev)
+            # a dedicated, non-null stream: the C ABI reads a null handle as "the engine's own stream", and the
+            # collective must be ordered after the kernels that fill the buffer
+            self._torch_stream = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(self._torch_stream):
+            for k0 in range(0, len(id_neighbours), MAX_NEIGHBOURS):
+                part = id_neighbours[k0:k0 + MAX_NEIGHBOURS]
+                self.engine.eval_candidates_q_async(id_fA, part, max_id, self._d_q.data_ptr(),
+                                                    self._torch_stream.cuda_stream, self.group.rank, self.group.world)
+                self.group.all_reduce_sum_(self._d_q)
+                q = self._d_q[:len(part) * N_OPS].cpu().numpy()
+                out[k0:k0 + len(part)] = gdist.q_to_float(q).reshape(len(part), N_OPS)
         return out
 
     # ------------------------------------------------------------------ layout maintenance

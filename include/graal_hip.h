@@ -85,7 +85,8 @@ int graal_eval_full_q(graal_ctx* h, int64_t q_out[2]);
 
 /* delta log-likelihood of the 13 candidates of each of K (<= GRAAL_MAX_NEIGHBOURS) neighbours fB[k]
  * of fA, over this rank's contact shard; rank / world shard the expected-mass work.
- * Writes K*13 int64 Q values to the DEVICE buffer d_q_out on `stream` (asynchronous): sum them over
+ * Writes K*13 int64 Q values to the DEVICE buffer d_q_out on `stream` (asynchronous; a NULL stream means the
+ * engine's own stream, NOT the HIP default stream -- pass an explicit stream to order a collective after it): sum them over
  * ranks (one RCCL all-reduce) then divide by 2^GRAAL_Q_BITS.  max_id must be the value returned by
  * graal_relabel_contigs for the current layout.
  * Replaces new_perform_modificationS + 13 x sub_compute_likelihood per neighbour

@@ -1,0 +1,77 @@
+"""GPU: the sharded (multi-rank) engine path, exercised with TWO ranks on ONE GPU (gloo backend, both on cuda:0):
+contact shards, rank-sharded mass items, one int64 all-reduce per step.  The per-candidate deltas -- and therefore the
+accepted-move trace -- must be bit-identical to the single-rank run (Q30 integer sums are order independent)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem():
+    from graal_amd import synth
+    par = synth.make_param_simu(fact=200.0, v_inter=0.02)
+    return synth.make_problem(n_bins=90, nnz=2500, n_sub=3, seed=17, contig_weights=(5, 4, 3), mean_len_bp=2000.0, accu=9,
+                              param=par, grid_bp=2000)
+
+
+def _make(P, rng, group):
+    from graal_amd.sampler import sampler
+    return sampler(True, P["S_o_A_frags"], P["collector_id_repeats"], P["frag_dispatcher"], [], [], P["n_frags"],
+                   P["n_new_frags"], P["init_n_sub_frags"], P["n_new_sub_frags"], None,
+                   (P["bin_coo_row"], P["bin_coo_col"], P["bin_coo_val"]), P["np_sub_frags_len_bp"], P["np_sub_frags_id"],
+                   P["np_sub_frags_accu"], P["mean_squared_frags_per_bin"], None, None,
+                   (P["coo_row"], P["coo_col"], P["coo_val"]), P["mean_value_trans"], 1, False, None,
+                   device=0, rng=rng, group=group, param_simu=P["param_simu"], compute_dist=False)
+
+
+def _run(group, steps=150):
+    from graal_amd import em
+    P = _problem()
+    rng = np.random.RandomState(5)
+    g = _make(P, rng, group)
+    scores = []
+    t = em.run_em(g, 1, 4, rng=rng, on_step=lambda j, i, tr: scores.append(np.copy(g.score)))
+    g.gpu_vect_frags.copy_from_gpu()
+    out = (t.mutations(), np.concatenate(scores), {k: np.copy(v) for k, v in g.gpu_vect_frags.as_dict().items()},
+           g.eval_likelihood())
+    g.free_gpu()
+    return out
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as td
+    from graal_amd import dist as gdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mut, scores, soa, full = _run(gdist.Group(rank, world))
+        q.put((rank, mut, scores, soa, full))
+    finally:
+        td.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_reproduce_the_single_rank_run_bit_for_bit():
+    import torch.multiprocessing as mp
+    from graal_amd import dist as gdist
+    ref_mut, ref_scores, ref_soa, ref_full = _run(gdist.Group(0, 1))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=500) for _ in range(2)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, mut, scores, soa, full in res:
+        assert np.array_equal(mut, ref_mut), rank
+        assert np.array_equal(scores, ref_scores), rank          # bit-identical float64 scores
+        for k in ref_soa:
+            assert np.array_equal(soa[k], ref_soa[k]), (rank, k)
+        assert full == ref_full

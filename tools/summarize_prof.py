@@ -72,7 +72,7 @@ def main():
         c = find(os.path.join(d, name), "*counter_collection.csv")
         if c:
             res["pmc_" + name] = counter_stats(c)
-    scan = [k for k in res.get("pmc_fetch", {}) if "k_scan" in k]
+    scan = [k for k in res.get("pmc_fetch", {}) if k.startswith("k_scan")]
     if scan and scan[0] in res.get("pmc_write", {}):
         k = scan[0]
         fetch = res["pmc_fetch"][k]["FETCH_SIZE"]["mean_last_100"]
