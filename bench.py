@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--mcmc-warmup", type=int, default=int(os.environ.get("GRAAL_BENCH_MCMC_WARMUP", 2000)))
     ap.add_argument("--neighbours", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layout", choices=("exploded", "original"), default="exploded",
+                    help="exploded (+ MCMC warm-up) is the BASELINE workload; original = the 7 reference contigs (late-stage regime)")
     args = ap.parse_args()
 
     from graal_amd import dist as gdist
@@ -113,7 +115,8 @@ def main():
 
     t_gen = time.perf_counter()
     P = synth.make_problem(n_bins=args.n_bins, nnz=args.nnz, n_sub=1, seed=20141217)
-    P["S_o_A_frags"] = exploded_layout(P)
+    if args.layout == "exploded":
+        P["S_o_A_frags"] = exploded_layout(P)
     t_gen = time.perf_counter() - t_gen
     rng = np.random.RandomState(20141217)
     t_setup = time.perf_counter()
@@ -167,7 +170,7 @@ def main():
 
     # ---- full MCMC steps (scoring + sampling + commit + relabel), reported as an extra ----------------------------
     t1 = time.perf_counter()
-    n_full = 200
+    n_full = min(200, max(1, args.steps))
     for i in order[args.mcmc_warmup:args.mcmc_warmup + n_full]:
         smp.step_max_likelihood(int(i), K)
     torch.cuda.synchronize()
@@ -195,8 +198,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32 model / f64 log / int64 Q30 sums",
             "data": "synthetic",
-            "config": {"workload": "C5 synthetic %d-fragment / %d-contact map, exploded + %d MCMC warm-up steps"
-                                   % (n, len(P["coo_row"]), args.mcmc_warmup),
+            "config": {"workload": "C5 synthetic %d-fragment / %d-contact map, %s + %d MCMC warm-up steps"
+                                   % (n, len(P["coo_row"]), args.layout, args.mcmc_warmup),
                        "neighbours_per_step": K, "candidates_per_step": 13 * K, "contacts_per_gpu": int(nnz_local),
                        "n_contigs": int(stats[0]), "max_contig_len": int(stats[4]),
                        "parallelism": "contacts sharded x%d, 1 all-reduce(65 x int64)/step" % world},

@@ -40,16 +40,19 @@ def estimate_param_rippe(y_meas, x_bins):
     return plsq_out, y_estim
 
 
+def _residual_4_max_dist(x, p):
+    kuhn, lm, slope, d, A, y = p
+    rippe = A * (0.53 * (kuhn ** -3.) * np.power((lm * x / kuhn), slope) *
+                 np.exp((d - 2) / ((np.power((lm * x / kuhn), 2) + d))))
+    return y - rippe
+
+
 def estimate_max_dist_intra(p, val_inter):
+    """``optim_rippe_curve_update.py:117-135``: distance at which the fitted curve meets the trans level, MINPACK
+    ``fsolve`` from s0 = 500 (silently returns ~500 when the solver wanders off, SURVEY.md H6 -- kept)."""
     kuhn, lm, slope, d, A = p
-
-    def residual(x, _):
-        rippe = A * (0.53 * (kuhn ** -3.) * np.power((lm * x / kuhn), slope) *
-                     np.exp((d - 2) / ((np.power((lm * x / kuhn), 2) + d))))
-        return val_inter - rippe
-
     with np.errstate(all="ignore"):
-        x = fsolve(residual, 500, args=(None,))
+        x = fsolve(_residual_4_max_dist, 500, args=([kuhn, lm, slope, d, A, val_inter]))
     return x[0]
 
 

@@ -285,6 +285,75 @@ class sampler(object):
         estim_max_dist = rippe_fit.estimate_max_dist_intra(p, self.mean_value_trans)
         self.set_param_simu(self.setup_rippe_parameters(p, estim_max_dist))
 
+    def return_rippe_vals(self, p0):
+        from . import rippe_fit
+        return rippe_fit.peval(self.bins, p0)  # cuda_lib_gl.py:1982-1984 (5-list: p0[3] = d is the amplitude, kept)
+
+    def compute_likelihood_4_nuisance(self, test_param):
+        """Full likelihood of the current layout under TEST parameters (``cuda_lib_gl.py:1986-2017``)."""
+        keep = np.copy(self._param_flat)
+        self.engine.set_params(test_param)
+        try:
+            return self.eval_likelihood()
+        finally:
+            self.engine.set_params(keep)
+
+    def step_nuisance_parameters(self, dt=0, t=0, n_step=1):
+        """Random-walk Metropolis step on (fact, slope, d_max, v_inter): ``cuda_lib_gl.py:2022-2107`` with its quirks kept
+        (``np.random.choice(4)`` never picks the ``d`` branch; ``peval`` gets a 5-list so ``d`` acts as the amplitude)."""
+        from . import rippe_fit as opti
+        curr_param = np.copy(self.param_simu)
+        kuhn, lm, c1, slope, d, d_max, fact, d_nuc = curr_param[0]
+        self.sigma_fact = 10 ** (np.log10(fact) - 2)
+        self.sigma_slope = 0.05
+        self.sigma_d_max = 100
+        self.sigma_d_nuc = 0.5
+        self.sigma_d = 10
+        id_modif = self.rng.choice(4)
+        if id_modif == 0:
+            new_fact = fact + self.rng.normal(loc=0.0, scale=self.sigma_fact)
+            new_d_max = opti.estimate_max_dist_intra([kuhn, lm, slope, d, new_fact], d_nuc)
+            c1 = np.float32((0.53 * np.power(lm / kuhn, slope)) * np.power(kuhn, -3))
+            out_test_param = [(kuhn, lm, c1, slope, d, new_d_max, new_fact, d_nuc)]
+        elif id_modif == 1:
+            new_slope = slope + self.rng.normal(loc=0.0, scale=self.sigma_slope)
+            new_d_max = opti.estimate_max_dist_intra([kuhn, lm, new_slope, d, fact], d_nuc)
+            c1 = np.float32((0.53 * np.power(lm / kuhn, new_slope)) * np.power(kuhn, -3))
+            out_test_param = [(kuhn, lm, c1, new_slope, d, new_d_max, fact, d_nuc)]
+        elif id_modif == 2:
+            new_d_max = d_max + self.rng.normal(loc=0.0, scale=self.sigma_d_max)
+            new_d_nuc = opti.peval(new_d_max, [kuhn, lm, slope, d, fact])
+            c1 = np.float32((0.53 * np.power(lm / kuhn, slope)) * np.power(kuhn, -3))
+            out_test_param = [(kuhn, lm, c1, slope, d, new_d_max, fact, new_d_nuc)]
+        elif id_modif == 3:
+            new_d_nuc = d_nuc + self.rng.normal(loc=0.0, scale=self.sigma_d_nuc)
+            new_d_max = opti.estimate_max_dist_intra([kuhn, lm, slope, d, fact], new_d_nuc)
+            c1 = np.float32((0.53 * np.power(lm / kuhn, slope)) * np.power(kuhn, -3))
+            out_test_param = [(kuhn, lm, c1, slope, d, new_d_max, fact, new_d_nuc)]
+        else:
+            new_d = d + self.rng.normal(loc=0.0, scale=self.sigma_d)
+            new_d_max = opti.estimate_max_dist_intra([kuhn, lm, slope, new_d, fact], d_nuc)
+            c1 = np.float32((0.53 * np.power(lm / kuhn, slope)) * np.power(kuhn, -3))
+            out_test_param = [(kuhn, lm, c1, slope, new_d, new_d_max, fact, d_nuc)]
+        out_test_param = np.array(out_test_param, dtype=self.param_simu_T)
+        flat = np.array([out_test_param[0][k] for k in out_test_param.dtype.names], dtype=np.float32)
+        if self.likelihood_t is None:
+            self.likelihood_t = self.eval_likelihood()
+        valid = bool(np.isfinite(flat).all() and flat[7] > 0 and 0 < flat[5] < 2.0e6)
+        test_likelihood = self.compute_likelihood_4_nuisance(flat) if valid else -np.inf
+        F_t = self.temperature(t, n_step)
+        with np.errstate(over="ignore"):
+            ratio = np.exp((test_likelihood - self.likelihood_t) / F_t)
+        u = self.rng.rand()
+        success = 0
+        if ratio >= u:
+            success = 1
+            self.set_param_simu(out_test_param)
+            self.likelihood_t = test_likelihood
+        kuhn, lm, c1, slope, d, d_max, fact, d_nuc = self.param_simu[0]
+        y_rippe = self.return_rippe_vals([kuhn, lm, slope, d, fact])
+        return fact, d, d_max, d_nuc, slope, self.likelihood_t, success, y_rippe
+
     # ------------------------------------------------------------------ display-only surface (no-ops)
     def setup_texture(self):
         self.data = None

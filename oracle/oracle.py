@@ -259,6 +259,7 @@ class OracleSampler:
         self.gpu_sub_index = np.zeros((n,), dtype=np.int32)
         self.curr_likelihood = np.zeros((self.dev.n_pix,), dtype=np.float64)
         self.n_neighbors = 10  # cuda_lib_gl.py:444
+        self.bins = np.asarray(p.get("bins", np.zeros(0)), dtype=np.float64)  # cuda_lib_gl.py:1236 (set by estimate_parameters)
         self.n_stale_paste = 0  # how often the stale-slot branch of paste_contigs was hit
         self.setup_distri_frags()
         self.define_repeats()
@@ -471,6 +472,76 @@ class OracleSampler:
         dist = self.dist_inter_genome(g)
         self.likelihood_t = o
         return o, n_contigs, min_len, mean_len_bp, max_len, op_sampled, id_f_sampled, dist, F_t
+
+    # cuda_lib_gl.py:1986-2017 : full evaluation with the TEST parameters
+    def compute_likelihood_4_nuisance(self):
+        keep = np.copy(self.dev.param)
+        self.dev.set_param(self._flat(self.param_simu_test))
+        out = self.dev.evaluate(self.gpu_vect_frags, None)
+        self.dev.set_param(keep)
+        return out
+
+    @staticmethod
+    def _flat(p):
+        return np.array([p[0][k] for k in p.dtype.names], dtype=np.float32)
+
+    # cuda_lib_gl.py:2022-2107 (optim_rippe_curve_update.peval / estimate_max_dist_intra restated in oracle/optim_ref.py)
+    def step_nuisance_parameters(self, dt, t, n_step):
+        from oracle import optim_ref as opti
+        curr_param = np.copy(self.param_simu)
+        kuhn, lm, c1, slope, d, d_max, fact, d_nuc = curr_param[0]
+        self.sigma_fact = 10 ** (np.log10(fact) - 2)
+        self.sigma_slope = 0.05
+        self.sigma_d_max = 100
+        self.sigma_d_nuc = 0.5
+        self.sigma_d = 10
+        id_modif = self.rng.choice(4)
+        if id_modif == 0:  # scale factor
+            new_fact = fact + self.rng.normal(loc=0.0, scale=self.sigma_fact)
+            test_param = [kuhn, lm, slope, d, new_fact]
+            new_d_max = opti.estimate_max_dist_intra(test_param, d_nuc)
+            c1 = np.float32((0.53 * np.power(lm / kuhn, slope)) * np.power(kuhn, -3))
+            out_test_param = [(kuhn, lm, c1, slope, d, new_d_max, new_fact, d_nuc)]
+        elif id_modif == 1:  # slope
+            new_slope = slope + self.rng.normal(loc=0.0, scale=self.sigma_slope)
+            test_param = [kuhn, lm, new_slope, d, fact]
+            new_d_max = opti.estimate_max_dist_intra(test_param, d_nuc)
+            c1 = np.float32((0.53 * np.power(lm / kuhn, new_slope)) * np.power(kuhn, -3))
+            out_test_param = [(kuhn, lm, c1, new_slope, d, new_d_max, fact, d_nuc)]
+        elif id_modif == 2:  # max distance intra
+            new_d_max = d_max + self.rng.normal(loc=0.0, scale=self.sigma_d_max)
+            test_param = [kuhn, lm, slope, d, fact]
+            new_d_nuc = opti.peval(new_d_max, test_param)  # 5-list: param[3] = d is used as the amplitude (H3)
+            c1 = np.float32((0.53 * np.power(lm / kuhn, slope)) * np.power(kuhn, -3))
+            out_test_param = [(kuhn, lm, c1, slope, d, new_d_max, fact, new_d_nuc)]
+        elif id_modif == 3:  # val trans
+            new_d_nuc = d_nuc + self.rng.normal(loc=0.0, scale=self.sigma_d_nuc)
+            test_param = [kuhn, lm, slope, d, fact]
+            new_d_max = opti.estimate_max_dist_intra(test_param, new_d_nuc)
+            c1 = np.float32((0.53 * np.power(lm / kuhn, slope)) * np.power(kuhn, -3))
+            out_test_param = [(kuhn, lm, c1, slope, d, new_d_max, fact, new_d_nuc)]
+        else:  # d -- unreachable: choice(4) never returns 4 (H3)
+            new_d = d + self.rng.normal(loc=0.0, scale=self.sigma_d)
+            test_param = [kuhn, lm, slope, new_d, fact]
+            new_d_max = opti.estimate_max_dist_intra(test_param, d_nuc)
+            c1 = np.float32((0.53 * np.power(lm / kuhn, slope)) * np.power(kuhn, -3))
+            out_test_param = [(kuhn, lm, c1, slope, new_d, new_d_max, fact, d_nuc)]
+        out_test_param = np.array(out_test_param, dtype=self.param_simu_rippe)
+        self.param_simu_test = out_test_param
+        test_likelihood = self.compute_likelihood_4_nuisance()
+        F_t = self.temperature(t, n_step)
+        ratio = np.exp((test_likelihood - self.likelihood_t) / F_t)
+        u = self.rng.rand()
+        success = 0
+        if ratio >= u:
+            success = 1
+            self.dev.set_param(self._flat(out_test_param))
+            self.param_simu = out_test_param
+            self.likelihood_t = test_likelihood
+        kuhn, lm, c1, slope, d, d_max, fact, d_nuc = self.param_simu[0]
+        p0 = [kuhn, lm, slope, d, fact]
+        y_rippe = opti.peval(self.bins, p0)
+        return fact, d, d_max, d_nuc, slope, self.likelihood_t, success, y_rippe
 
     # cuda_lib_gl.py:2295
     def return_neighbours(self, id_fA, delta0):

@@ -59,6 +59,28 @@ def test_trace_matches_oracle(n_sub, seed, n_bins, nnz, cycles, delta):
     g.free_gpu()
 
 
+def test_trace_with_nuisance_parameter_sampling_matches_oracle():
+    """start_EM with "sample parameters" on (main_gl.py:258-262): the random walk on (fact, slope, d_max, v_inter) draws
+    from the same RandomState and re-evaluates the FULL likelihood under test parameters every step."""
+    P = problem(3, 46, 45, 900)
+    P["bins"] = np.arange(2.0, 60.0, 2.0)
+    ora = O.OracleSampler(P, np.random.RandomState(46), fix_trans_accu=True)
+    t_ref = em.run_em(ora, 1, 3, rng=ora.rng, sample_param=True)
+    gpu_rng = np.random.RandomState(46)
+    g = make_gpu_sampler(P, gpu_rng)
+    g.bins = P["bins"]
+    t_gpu = em.run_em(g, 1, 3, rng=gpu_rng, sample_param=True)
+    assert np.array_equal(t_gpu.mutations(), t_ref.mutations())
+    assert t_gpu.success == t_ref.success and 0 < sum(t_ref.success) < len(t_ref.success)
+    for a, b in ((t_gpu.fact, t_ref.fact), (t_gpu.slope, t_ref.slope), (t_gpu.d_max, t_ref.d_max), (t_gpu.d_nuc, t_ref.d_nuc)):
+        assert np.array_equal(np.asarray(a, np.float32), np.asarray(b, np.float32))   # parameters are float32: bit-exact
+    assert np.allclose(t_gpu.likelihood_nuisance, t_ref.likelihood_nuisance, rtol=1e-6, atol=0)
+    g.gpu_vect_frags.copy_from_gpu()
+    for k in O.FIELDS:
+        assert np.array_equal(getattr(g.gpu_vect_frags, k), ora.gpu_vect_frags[k]), k
+    g.free_gpu()
+
+
 def test_replay_of_a_trace_reproduces_the_layout(tmp_path):
     P = problem(1, 44, 40, 400)
     rng = np.random.RandomState(44)
