@@ -19,6 +19,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include <string>
 #include <vector>
@@ -499,7 +500,7 @@ __device__ void tables_block(const SoaPtr& s, int fA, int fB, int max_id, const 
     if (s_start[n_tasks] <= ITEM_CAP)
         for (int i = t; i < n_tasks; i += blockDim.x)
             for (int w = s_start[i]; w < s_start[i + 1]; w++) T.item_tc[w] = (unsigned)i | ((unsigned)(w - s_start[i]) << 16);
-    if (t == 0) step_hdr[k] = s_start[n_tasks]; // all neighbours' item counts in one cache line for k_post
+    if (t == 0) { step_hdr[k] = s_start[n_tasks]; step_hdr[MAXK + k] = (int)intra_any; } // one cache line for k_scan / k_post
 }
 
 // Everything the per-step kernels need that does not change from step to step lives in ONE device-resident block
@@ -511,6 +512,7 @@ struct DevArgs {
     SoaPtr soa;
     long long nnz;
     int n, n_sub_total, bitmap_words, reach_bp;
+    int rows_sorted; // contact list sorted by row id: enables the wave-uniform range test of k_scan
     const int *row, *col, *cnt, *sub2bin, *sub2bin_multi /* nullptr when every bin has one sub-fragment */, *sub_ids;
     const int *contig_off, *perm;
     const Geo* geo;
@@ -593,7 +595,7 @@ __device__ __forceinline__ int4 ld_stream(const int4* p)
 //   3. the 4-byte relevance codes of both fragments (global, L2 resident) -> nibble mask of neighbours.
 // Survivors are appended to a queue (wave-aggregated atomics) for k_post.  Counts are not read here at all.
 template <bool SINGLE_SUB, bool LDS_BITMAP>
-__global__ __launch_bounds__(256) void k_scan(const DevArgs* __restrict__ A, int K)
+__global__ __launch_bounds__(1024) void k_scan(const DevArgs* __restrict__ A, int K, int dry /* timing replays: count, do not queue */)
 {
     const int* __restrict__ row = A->row;
     const int* __restrict__ col = A->col;
@@ -602,7 +604,6 @@ __global__ __launch_bounds__(256) void k_scan(const DevArgs* __restrict__ A, int
     const unsigned* __restrict__ codes = A->codes;
     const unsigned* __restrict__ bitmap = A->bitmap;
     const int bitmap_words = A->bitmap_words;
-    const NbTables* __restrict__ tabs = A->tabs;
     QEntry* __restrict__ queue = A->queue;
     unsigned long long* __restrict__ counters = A->counters;
     extern __shared__ unsigned s_bm[];
@@ -612,7 +613,8 @@ __global__ __launch_bounds__(256) void k_scan(const DevArgs* __restrict__ A, int
     }
     const unsigned* bm = LDS_BITMAP ? s_bm : bitmap;
     unsigned long long intra = 0; // bit 8k + p: piece p of neighbour k changes internally under some candidate
-    for (int k = 0; k < K; k++) intra |= (unsigned long long)(tabs[k].intra_any & 0xffu) << (8 * k);
+#pragma unroll
+    for (int k = 0; k < MAXK; k++) intra |= (k < K) ? ((unsigned long long)(A->step_hdr[MAXK + k] & 0xff) << (8 * k)) : 0ull;
     const long long n4 = nnz >> 2;
     const int tail = (int)(nnz - (n4 << 2));
     const int4* __restrict__ row4 = reinterpret_cast<const int4*>(row);
@@ -664,7 +666,8 @@ __global__ __launch_bounds__(256) void k_scan(const DevArgs* __restrict__ A, int
                 }
                 if (!SINGLE_SUB && fx == fy) rel = 0; // a bin's own pixel is never revisited (kernels3.cu:3356-3380)
             }
-            const unsigned long long bal = __ballot(rel != 0);
+            const unsigned long long bal = dry ? 0ull : __ballot(rel != 0);
+            if (dry) n_rel += __popc(rel);
             if (bal) {
                 const int leader = __ffsll((long long)bal) - 1;
                 unsigned long long base = 0;
@@ -679,7 +682,7 @@ __global__ __launch_bounds__(256) void k_scan(const DevArgs* __restrict__ A, int
         }
     }
     n_rel = (unsigned long long)wave_sum_ll((long long)n_rel);
-    if (lane == 0 && n_rel) atomicAdd(&counters[0], n_rel);
+    if (lane == 0 && n_rel && !dry) atomicAdd(&counters[0], n_rel);
 }
 
 __device__ __forceinline__ int sel_base(const int (&a)[MAXK + 1], int i)
@@ -839,6 +842,7 @@ struct Ctx {
     int n = 0, n_bins = 0, n_sub_total = 0;
     long long nnz = 0;
     bool single_sub = true;
+    bool rows_sorted = false;
     float nfpb = 1.0f;
     Par par{};
     bool have_par = false, have_sub = false, have_frags = false, have_contacts = false, order_valid = false;
@@ -937,6 +941,7 @@ int sync_args(Ctx* h)
         a[b].nnz = h->nnz; a[b].n = h->n; a[b].n_sub_total = h->n_sub_total;
         a[b].bitmap_words = (h->n_sub_total + 31) / 32 + 2;
         a[b].reach_bp = h->have_par ? reach_bp(h) : 0;
+        a[b].rows_sorted = h->rows_sorted ? 1 : 0;
         a[b].row = h->row; a[b].col = h->col; a[b].cnt = h->cnt; a[b].sub2bin = h->sub2bin;
         a[b].sub2bin_multi = h->single_sub ? nullptr : h->sub2bin; a[b].sub_ids = h->d_sub_ids;
         a[b].contig_off = h->contig_off; a[b].perm = h->perm; a[b].geo = h->geo; a[b].stat = h->stat;
@@ -951,6 +956,26 @@ int sync_args(Ctx* h)
 int refresh(Ctx* h)
 {
     k_refresh_geo<<<blocks_for(h->n, 256), 256, 0, h->stream>>>(h->soa[h->cur], h->geo, h->n);
+    CK(hipGetLastError());
+    return GRAAL_OK;
+}
+
+// the streaming pass (see k_scan); dry = timing replay that counts relevant contacts but queues nothing
+int launch_scan(Ctx* h, const DevArgs* A, int K, int dry, hipStream_t st)
+{
+    {
+        const long long groups = (h->nnz >> 2) + 1;
+        static const int scan_blocks = getenv("GRAAL_SCAN_BLOCKS") ? atoi(getenv("GRAAL_SCAN_BLOCKS")) : 256 * 2;
+        static const int scan_threads = getenv("GRAAL_SCAN_THREADS") ? atoi(getenv("GRAAL_SCAN_THREADS")) : 1024;
+        const int nbk = (int)std::min<long long>((groups + 2 * scan_threads - 1) / (2 * scan_threads), scan_blocks);
+        const int words = (h->n_sub_total + 31) / 32 + 2;
+        const bool lds = words * 4 <= 16 * 1024; // keeps the CU full (LDS per block x resident blocks <= 160 KB)
+        const size_t shm = lds ? (size_t)words * 4 : 0;
+#define GRAAL_SCAN(SS, LB) k_scan<SS, LB><<<nbk, scan_threads, shm, st>>>(A, K, dry)
+        if (h->single_sub) { if (lds) GRAAL_SCAN(true, true); else GRAAL_SCAN(true, false); }
+        else { if (lds) GRAAL_SCAN(false, true); else GRAAL_SCAN(false, false); }
+#undef GRAAL_SCAN
+    }
     CK(hipGetLastError());
     return GRAAL_OK;
 }
@@ -983,7 +1008,8 @@ int graal_create(int device, graal_ctx** out)
     CK(hipMalloc(&h->d_scalars, 16 * sizeof(long long)));
     CK(hipMalloc(&h->d_qout, MAXK * N_OPS * sizeof(long long)));
     CK(hipMalloc(&h->tabs, MAXK * sizeof(NbTables)));
-    CK(hipMalloc(&h->step_hdr, MAXK * sizeof(int)));
+    CK(hipMalloc(&h->step_hdr, 2 * MAXK * sizeof(int)));
+    CK(hipMemset(h->step_hdr, 0, 2 * MAXK * sizeof(int)));
     CK(hipMalloc(&h->d_args, 2 * sizeof(DevArgs)));
     return GRAAL_OK;
 }
@@ -1071,13 +1097,16 @@ int graal_upload_contacts(graal_ctx* h, const int32_t* row, const int32_t* col, 
     if (!h->have_sub) return fail(h, GRAAL_E_STATE, "upload_subfrags first");
     CK(hipSetDevice(h->device));
     double c_lf = 0.0;
+    bool sorted = true;
     double lf_small[16];
     for (int i = 0; i < 16; i++) lf_small[i] = lf_term((double)i);
     for (int64_t i = 0; i < nnz; i++) {
         if (row[i] < 0 || col[i] >= h->n_sub_total || row[i] >= col[i]) return fail(h, GRAAL_E_ARG, "contacts need 0 <= row < col < n_sub_total");
         if (count[i] <= 0) return fail(h, GRAAL_E_ARG, "contact counts must be > 0");
         c_lf += count[i] < 16 ? lf_small[count[i]] : lf_term((double)count[i]);
+        if (i > 0 && row[i] < row[i - 1]) sorted = false;
     }
+    h->rows_sorted = sorted;
     if (h->row) { (void)hipFree(h->row); (void)hipFree(h->col); (void)hipFree(h->cnt); (void)hipFree(h->queue); h->row = h->col = h->cnt = nullptr; h->queue = nullptr; }
     const size_t bytes = sizeof(int) * (size_t)(nnz + 8); // +8: int4 tail reads stay in bounds
     CK(hipMalloc(&h->row, bytes)); CK(hipMalloc(&h->col, bytes)); CK(hipMalloc(&h->cnt, bytes));
@@ -1247,17 +1276,7 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     if (!h->single_sub) CK(hipMemsetAsync(h->bitmap, 0, sizeof(unsigned) * (size_t)h->bitmap_words, st));
     k_prep<<<K + blocks_for(n, 256), 256, 0, st>>>(A, fA, nb, K, max_id, (long long*)d_q_out);
     CK(hipEventRecord(h->ev[1], st));
-    {
-        const long long groups = (h->nnz >> 2) + 1;
-        const int nbk = (int)std::min<long long>((groups + 511) / 512, 256 * 8);
-        const int words = (h->n_sub_total + 31) / 32 + 2;
-        const bool lds = words * 4 <= 16 * 1024; // keeps 8 blocks of 256 threads per CU
-        const size_t shm = lds ? (size_t)words * 4 : 0;
-#define GRAAL_SCAN(SS, LB) k_scan<SS, LB><<<nbk, 256, shm, st>>>(A, K)
-        if (h->single_sub) { if (lds) GRAAL_SCAN(true, true); else GRAAL_SCAN(true, false); }
-        else { if (lds) GRAAL_SCAN(false, true); else GRAAL_SCAN(false, false); }
-#undef GRAAL_SCAN
-    }
+    { int rc_ = launch_scan(h, A, K, 0, st); if (rc_) return rc_; }
     CK(hipEventRecord(h->ev[2], st));
     {
         const int nbm = std::min(std::max((n + 63) / 64 * 4, 256), 256 * 16);
@@ -1310,6 +1329,23 @@ int graal_last_timing(graal_ctx* h, float out[4])
     CK(hipEventSynchronize(h->ev[3]));
     for (int i = 0; i < 3; i++) CK(hipEventElapsedTime(&out[i], h->ev[i], h->ev[i + 1]));
     out[3] = 0.0f;
+    return GRAAL_OK;
+}
+
+int graal_time_scan(graal_ctx* h, int32_t K, int32_t reps, float* avg_ms)
+{
+    if (!h || !avg_ms || reps < 1 || K < 1 || K > MAXK) return GRAAL_E_ARG;
+    if (!h->timing_valid) return fail(h, GRAAL_E_STATE, "run graal_eval_candidates first (the replays reuse its tables)");
+    CK(hipSetDevice(h->device));
+    const DevArgs* A = h->d_args + h->cur;
+    for (int i = 0; i < 3; i++) { int rc = launch_scan(h, A, K, 1, h->stream); if (rc) return rc; }
+    CK(hipEventRecord(h->ev[0], h->stream));
+    for (int i = 0; i < reps; i++) { int rc = launch_scan(h, A, K, 1, h->stream); if (rc) return rc; }
+    CK(hipEventRecord(h->ev[4], h->stream));
+    CK(hipEventSynchronize(h->ev[4]));
+    float ms = 0.0f;
+    CK(hipEventElapsedTime(&ms, h->ev[0], h->ev[4]));
+    *avg_ms = ms / (float)reps;
     return GRAAL_OK;
 }
 

@@ -24,7 +24,7 @@ _f64p = ctypes.POINTER(ctypes.c_double)
 SYMBOLS = ("graal_abi_version", "graal_create", "graal_destroy", "graal_last_error", "graal_set_params",
            "graal_upload_subfrags", "graal_upload_contacts", "graal_upload_frags", "graal_download_frags",
            "graal_relabel_contigs", "graal_layout_stats", "graal_eval_full_q", "graal_eval_candidates_q",
-           "graal_eval_candidates", "graal_apply_move", "graal_last_timing", "graal_last_counters")
+           "graal_eval_candidates", "graal_apply_move", "graal_last_timing", "graal_time_scan", "graal_last_counters")
 
 _lib = None
 
@@ -62,6 +62,7 @@ def load():
         L.graal_apply_move.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _i32p]
         L.graal_last_timing.argtypes = [ctypes.c_void_p, _f32p]
         L.graal_last_counters.argtypes = [ctypes.c_void_p, _i64p]
+        L.graal_time_scan.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, _f32p]
         _lib = L
     return _lib
 
@@ -194,6 +195,12 @@ class Engine:
         t = np.zeros(4, dtype=np.float32)
         self._ck(self._L.graal_last_timing(self._h, t.ctypes.data_as(_f32p)), "graal_last_timing")
         return t
+
+    def time_scan(self, K, reps=50):
+        """Average k_scan duration (ms) over `reps` back-to-back replays between two HIP events."""
+        ms = ctypes.c_float(0.0)
+        self._ck(self._L.graal_time_scan(self._h, int(K), int(reps), ctypes.byref(ms)), "graal_time_scan")
+        return float(ms.value)
 
     def last_counters(self):
         c = np.zeros(4, dtype=np.int64)

@@ -103,6 +103,10 @@ int graal_apply_move(graal_ctx* h, int32_t fA, int32_t fB, int32_t op, int32_t m
 /* timing of the last graal_eval_candidates* call, HIP events on the engine's stream (milliseconds):
  * out[0]=k_prep (tables + codes) out[1]=k_scan (contact stream) out[2]=k_post (mass tasks + queued contacts) out[3]=0 */
 int graal_last_timing(graal_ctx* h, float out[4]);
+/* average duration (ms) of the streaming scan kernel over `reps` back-to-back replays of the last call's scan between
+ * two HIP events on the engine's stream (the replays count relevant contacts but queue nothing): the per-launch
+ * event overhead of graal_last_timing is amortised away. */
+int graal_time_scan(graal_ctx* h, int32_t K, int32_t reps, float* avg_ms);
 /* counters of the last call: out[0]=contacts scanned out[1]=relevant (contact, neighbour) pairs
  * out[2]=queued (relevant) contacts out[3]=mass work items */
 int graal_last_counters(graal_ctx* h, int64_t out[4]);

@@ -197,3 +197,23 @@ def test_engine_errors_are_loud():
         e.upload_frags(bad)
     with pytest.raises(GraalError):
         e.upload_contacts([3], [3], [1])  # row < col required
+
+
+def test_unsorted_contact_list_gives_the_same_deltas():
+    """The wave-uniform row-range shortcut of the scan is only taken for a row-sorted list; any order must work."""
+    P = make(1, 31, n_bins=70, nnz=1500, grid_bp=2000)
+    rng = np.random.RandomState(31)
+    s = random_state_for(P, rng, n_contigs=5, p_circ=0.2)
+    max_id = relabel_ref(s)
+    e1 = engine_for(P, s)
+    e1.relabel_contigs()
+    perm = rng.permutation(len(P["coo_row"]))
+    P2 = dict(P)
+    P2["coo_row"], P2["coo_col"], P2["coo_val"] = P["coo_row"][perm], P["coo_col"][perm], P["coo_val"][perm]
+    e2 = engine_for(P2, s)
+    e2.relabel_contigs()
+    for _ in range(5):
+        fA = int(rng.randint(P["n_frags"]))
+        fBs = [int(v) for v in rng.choice(np.setdiff1d(np.arange(P["n_frags"]), [fA]), 4, replace=False)]
+        assert np.array_equal(e1.eval_candidates(fA, fBs, max_id), e2.eval_candidates(fA, fBs, max_id))
+    assert e1.eval_full() == e2.eval_full()
