@@ -549,6 +549,7 @@ __global__ __launch_bounds__(256) void k_prep(const DevArgs* __restrict__ A, int
     if (b == 0) {
         for (int i = threadIdx.x; i < K * N_OPS; i += blockDim.x) d_q_out[i] = 0;
         if (threadIdx.x < 3) counters[threadIdx.x] = 0;
+        if (threadIdx.x == 5) counters[5] = 0; // k_post completion ticket
     }
     const int f = b * blockDim.x + threadIdx.x;
     unsigned code = 0;
@@ -695,8 +696,12 @@ __device__ __forceinline__ int sel_base(const int (&a)[MAXK + 1], int i)
 
 // k_post: (1) mass tasks -- work item = (neighbour, task, chunk of 64 fragments of the task's first piece), one wave per
 // item, lane = fragment x; (2) the queued contacts -- 16 lanes per contact, lane = candidate op.
-__global__ __launch_bounds__(64) void k_post(const DevArgs* __restrict__ A, int K, int rank, int world,
-                                              long long* __restrict__ out)
+// Completion: the last block to finish (ticket counter) reads the K*13 sums with atomic loads and, if host_res is given,
+// publishes them to PINNED HOST memory followed by the step's sequence number; the host spins on that word instead of
+// paying for a device->host copy launch and a stream-synchronise wake-up.
+__global__ __launch_bounds__(256) void k_post(const DevArgs* __restrict__ A, int K, int rank, int world,
+                                               long long* __restrict__ out, volatile long long* host_res,
+                                               long long seq)
 {
     const NbTables* __restrict__ tabs = A->tabs;
     const int* __restrict__ perm = A->perm;
@@ -714,7 +719,8 @@ __global__ __launch_bounds__(64) void k_post(const DevArgs* __restrict__ A, int 
     const Par par = A->par;
     const int reach_bp = A->reach_bp;
     unsigned long long* __restrict__ counters = A->counters;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
     unsigned long long items = 0;
     int n_items_k[MAXK];
 #pragma unroll
@@ -727,7 +733,7 @@ __global__ __launch_bounds__(64) void k_post(const DevArgs* __restrict__ A, int 
     for (int k = 0; k < MAXK; k++) item_base[k + 1] = item_base[k] + (k < K ? n_items_k[k] : 0);
     const int total_all = item_base[MAXK];
     // static sharding of the item list over ranks; every wave reaches the loop exit
-    for (int W = blockIdx.x * world + rank; W < total_all; W += gridDim.x * world) {
+    for (int W = wave * world + rank; W < total_all; W += n_waves * world) {
         int k = 0;
 #pragma unroll
         for (int j = 1; j < MAXK; j++) k += (W >= item_base[j]) ? 1 : 0;
@@ -803,7 +809,7 @@ __global__ __launch_bounds__(64) void k_post(const DevArgs* __restrict__ A, int 
     // ---- queued contacts: 4 per wave pass, lane & 15 = candidate op; taken from the far end of the grid so that they
     // do not queue up behind the mass items of the low-numbered blocks ----
     const int op = lane & 15;
-    for (unsigned long long e0 = (unsigned long long)(gridDim.x - 1 - blockIdx.x) * 4; e0 < nq_total; e0 += (unsigned long long)gridDim.x * 4) {
+    for (unsigned long long e0 = (unsigned long long)(n_waves - 1 - wave) * 4; e0 < nq_total; e0 += (unsigned long long)n_waves * 4) {
         const unsigned long long e = e0 + (lane >> 4);
         if (e >= nq_total || op >= N_OPS) continue;
         const QEntry qe = queue[e];
@@ -829,6 +835,23 @@ __global__ __launch_bounds__(64) void k_post(const DevArgs* __restrict__ A, int 
             if (qv != 0) atomicAdd((unsigned long long*)&out[k * N_OPS + op], (unsigned long long)qv);
         }
     }
+    if (host_res == nullptr) return;
+    // ---- completion ticket: every block releases its atomics, the last one publishes ----
+    __shared__ int s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned long long ticket = atomicAdd(&counters[5], 1ull);
+        s_last = (ticket == (unsigned long long)gridDim.x - 1ull);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    for (int i = threadIdx.x; i < K * N_OPS; i += blockDim.x)
+        host_res[1 + i] = (long long)atomicAdd((unsigned long long*)&out[i], 0ull); // coherent read of the final sum
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) { host_res[0] = seq; __threadfence_system(); }
 }
 
 // ------------------------------------------------------------------ host side
@@ -837,7 +860,12 @@ struct Ctx {
     std::string err;
     hipStream_t stream = nullptr;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> ring; // pairs of events around k_scan, one pair per call (graal_scan_times)
+    long long ring_calls = 0;
     bool timing_valid = false;
+    bool scan_ready = false;
+    bool publish = false;         // k_post publishes the sums to pinned host memory (synchronous single-GPU path)
+    bool want_events = true;      // record the per-kernel HIP events (graal_last_timing)
     // problem
     int n = 0, n_bins = 0, n_sub_total = 0;
     long long nnz = 0;
@@ -871,6 +899,8 @@ struct Ctx {
     NbTables* tabs = nullptr;
     int* step_hdr = nullptr;      // [MAXK] mass work items per neighbour of the current step
     DevArgs* d_args = nullptr;    // [2]: one argument block per layout buffer
+    long long* h_res = nullptr;   // pinned host: [0] sequence number of the published step, [1..] K*13 sums
+    long long seq = 0;
     long long* d_scalars = nullptr; // [0..7] stats, [8..9] full q, [10] n_relevant, [11] n_items, [12] overflow/stale (int)
     long long* d_qout = nullptr;    // K*13
     long long counters[4] = {0, 0, 0, 0};
@@ -1005,12 +1035,16 @@ int graal_create(int device, graal_ctx** out)
     CK(hipSetDevice(device));
     CK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     for (auto& ev : h->ev) CK(hipEventCreate(&ev));
+    h->ring.resize(2 * 1024, nullptr);
+    for (auto& ev : h->ring) CK(hipEventCreate(&ev));
     CK(hipMalloc(&h->d_scalars, 16 * sizeof(long long)));
     CK(hipMalloc(&h->d_qout, MAXK * N_OPS * sizeof(long long)));
     CK(hipMalloc(&h->tabs, MAXK * sizeof(NbTables)));
     CK(hipMalloc(&h->step_hdr, 2 * MAXK * sizeof(int)));
     CK(hipMemset(h->step_hdr, 0, 2 * MAXK * sizeof(int)));
     CK(hipMalloc(&h->d_args, 2 * sizeof(DevArgs)));
+    CK(hipHostMalloc((void**)&h->h_res, (1 + MAXK * N_OPS) * sizeof(long long), hipHostMallocDefault));
+    memset(h->h_res, 0, (1 + MAXK * N_OPS) * sizeof(long long));
     return GRAAL_OK;
 }
 
@@ -1024,7 +1058,9 @@ void graal_destroy(graal_ctx* h)
                         h->keys, h->keys_sorted, h->o2n, h->len_of, h->contig_off, h->perm, h->cub_tmp, h->tabs, h->step_hdr, h->d_args,
                         h->d_scalars, h->d_qout};
         for (void* p : ptrs) if (p) (void)hipFree(p);
+        if (h->h_res) (void)hipHostFree(h->h_res);
         for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
+        for (auto& ev : h->ring) if (ev) (void)hipEventDestroy(ev);
         (void)hipStreamDestroy(h->stream);
     }
     delete h;
@@ -1271,32 +1307,55 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     hipStream_t st = stream_v ? (hipStream_t)stream_v : h->stream;
     SoaPtr s = h->soa[h->cur];
     const int n = h->n;
-    CK(hipEventRecord(h->ev[0], st));
     const DevArgs* A = h->d_args + h->cur;
     if (!h->single_sub) CK(hipMemsetAsync(h->bitmap, 0, sizeof(unsigned) * (size_t)h->bitmap_words, st));
     k_prep<<<K + blocks_for(n, 256), 256, 0, st>>>(A, fA, nb, K, max_id, (long long*)d_q_out);
-    CK(hipEventRecord(h->ev[1], st));
+    const size_t slot = (size_t)(h->ring_calls % (long long)(h->ring.size() / 2));
+    if (h->want_events) CK(hipEventRecord(h->ring[2 * slot], st));
     { int rc_ = launch_scan(h, A, K, 0, st); if (rc_) return rc_; }
-    CK(hipEventRecord(h->ev[2], st));
+    if (h->want_events) { CK(hipEventRecord(h->ring[2 * slot + 1], st)); h->ring_calls += 1; }
     {
-        const int nbm = std::min(std::max((n + 63) / 64 * 4, 256), 256 * 16);
-        k_post<<<nbm, 64, 0, st>>>(A, K, rank, world, (long long*)d_q_out);
+        k_post<<<512, 256, 0, st>>>(A, K, rank, world, (long long*)d_q_out, h->publish ? h->h_res : nullptr, h->seq);
     }
-    CK(hipEventRecord(h->ev[3], st));
     CK(hipGetLastError());
-    h->timing_valid = true;
+    h->timing_valid = h->want_events;
+    h->scan_ready = true;
     return GRAAL_OK;
 }
 
 int graal_eval_candidates(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int32_t max_id, double* delta)
 {
     if (!h || !delta) return GRAAL_E_ARG;
+    h->publish = true;
+    h->seq += 1;
+    const long long want = h->seq;
     int rc = graal_eval_candidates_q(h, fA, fB, K, max_id, 0, 1, (int64_t*)h->d_qout, nullptr);
+    h->publish = false;
     if (rc) return rc;
-    long long q[MAXK * N_OPS];
-    CK(hipMemcpyAsync(q, h->d_qout, sizeof(long long) * (size_t)K * N_OPS, hipMemcpyDeviceToHost, h->stream));
-    CK(hipStreamSynchronize(h->stream));
-    for (int i = 0; i < K * N_OPS; i++) delta[i] = (double)q[i] / Q_SCALE;
+    // spin on the sequence word the last block of k_post writes into pinned host memory; fall back to a stream
+    // synchronise if it does not show up (it always does unless the launch failed)
+    volatile long long* res = h->h_res;
+    bool seen = false;
+    for (long long spin = 0; spin < 200000000ll; spin++) {
+        if (res[0] == want) { seen = true; break; }
+        if ((spin & 0xfffff) == 0xfffff && hipStreamQuery(h->stream) != hipErrorNotReady) { seen = (res[0] == want); break; }
+        __builtin_ia32_pause();
+    }
+    if (!seen) {
+        CK(hipStreamSynchronize(h->stream));
+        if (res[0] != want) return fail(h, GRAAL_E_HIP, "k_post did not publish its results");
+    }
+    __sync_synchronize();
+    for (int i = 0; i < K * N_OPS; i++) delta[i] = (double)res[1 + i] / Q_SCALE;
+    return GRAAL_OK;
+}
+
+/* per-kernel HIP events (graal_last_timing) cost ~2 us each on the host: a driver may switch them off */
+int graal_set_timing(graal_ctx* h, int32_t enabled)
+{
+    if (!h) return GRAAL_E_ARG;
+    h->want_events = enabled != 0;
+    if (!h->want_events) h->timing_valid = false;
     return GRAAL_OK;
 }
 
@@ -1324,18 +1383,28 @@ int graal_apply_move(graal_ctx* h, int32_t fA, int32_t fB, int32_t op, int32_t m
 int graal_last_timing(graal_ctx* h, float out[4])
 {
     if (!h || !out) return GRAAL_E_ARG;
-    if (!h->timing_valid) return fail(h, GRAAL_E_STATE, "no candidate evaluation yet");
+    out[0] = out[1] = out[2] = out[3] = 0.0f;
+    return graal_scan_times(h, 1, &out[1]);
+}
+
+int graal_scan_times(graal_ctx* h, int32_t n, float* out_ms)
+{
+    if (!h || !out_ms || n < 1) return GRAAL_E_ARG;
+    const long long cap = (long long)(h->ring.size() / 2);
+    if (!h->timing_valid || h->ring_calls < n || n > cap) return fail(h, GRAAL_E_STATE, "not enough timed candidate evaluations");
     CK(hipSetDevice(h->device));
-    CK(hipEventSynchronize(h->ev[3]));
-    for (int i = 0; i < 3; i++) CK(hipEventElapsedTime(&out[i], h->ev[i], h->ev[i + 1]));
-    out[3] = 0.0f;
+    for (int i = 0; i < n; i++) {
+        const size_t slot = (size_t)((h->ring_calls - n + i) % cap);
+        CK(hipEventSynchronize(h->ring[2 * slot + 1]));
+        CK(hipEventElapsedTime(&out_ms[i], h->ring[2 * slot], h->ring[2 * slot + 1]));
+    }
     return GRAAL_OK;
 }
 
 int graal_time_scan(graal_ctx* h, int32_t K, int32_t reps, float* avg_ms)
 {
     if (!h || !avg_ms || reps < 1 || K < 1 || K > MAXK) return GRAAL_E_ARG;
-    if (!h->timing_valid) return fail(h, GRAAL_E_STATE, "run graal_eval_candidates first (the replays reuse its tables)");
+    if (!h->scan_ready) return fail(h, GRAAL_E_STATE, "run graal_eval_candidates first (the replays reuse its tables)");
     CK(hipSetDevice(h->device));
     const DevArgs* A = h->d_args + h->cur;
     for (int i = 0; i < 3; i++) { int rc = launch_scan(h, A, K, 1, h->stream); if (rc) return rc; }

@@ -24,7 +24,7 @@ _f64p = ctypes.POINTER(ctypes.c_double)
 SYMBOLS = ("graal_abi_version", "graal_create", "graal_destroy", "graal_last_error", "graal_set_params",
            "graal_upload_subfrags", "graal_upload_contacts", "graal_upload_frags", "graal_download_frags",
            "graal_relabel_contigs", "graal_layout_stats", "graal_eval_full_q", "graal_eval_candidates_q",
-           "graal_eval_candidates", "graal_apply_move", "graal_last_timing", "graal_time_scan", "graal_last_counters")
+           "graal_eval_candidates", "graal_apply_move", "graal_set_timing", "graal_last_timing", "graal_scan_times", "graal_time_scan", "graal_last_counters")
 
 _lib = None
 
@@ -62,6 +62,8 @@ def load():
         L.graal_apply_move.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _i32p]
         L.graal_last_timing.argtypes = [ctypes.c_void_p, _f32p]
         L.graal_last_counters.argtypes = [ctypes.c_void_p, _i64p]
+        L.graal_set_timing.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+        L.graal_scan_times.argtypes = [ctypes.c_void_p, ctypes.c_int32, _f32p]
         L.graal_time_scan.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, _f32p]
         _lib = L
     return _lib
@@ -191,9 +193,18 @@ class Engine:
                                                  ctypes.c_void_p(int(stream_ptr) if stream_ptr else 0)),
                  "graal_eval_candidates_q")
 
+    def set_timing(self, enabled):
+        self._ck(self._L.graal_set_timing(self._h, 1 if enabled else 0), "graal_set_timing")
+
     def last_timing(self):
         t = np.zeros(4, dtype=np.float32)
         self._ck(self._L.graal_last_timing(self._h, t.ctypes.data_as(_f32p)), "graal_last_timing")
+        return t
+
+    def scan_times(self, n):
+        """k_scan durations (ms) of the last n candidate evaluations (HIP event pairs recorded around each launch)."""
+        t = np.zeros(int(n), dtype=np.float32)
+        self._ck(self._L.graal_scan_times(self._h, int(n), t.ctypes.data_as(_f32p)), "graal_scan_times")
         return t
 
     def time_scan(self, K, reps=50):

@@ -93,16 +93,21 @@ int graal_eval_full_q(graal_ctx* h, int64_t q_out[2]);
  * (cuda_lib_gl.py:2392-2546). */
 int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int32_t max_id, int32_t rank,
                             int32_t world, int64_t* d_q_out, void* stream);
-/* single-GPU convenience: same, synchronous, into a host buffer of K*13 doubles */
+/* single-GPU convenience: same, synchronous, into a host buffer of K*13 doubles (the last block of the last kernel
+ * publishes the sums to pinned host memory; the call spins on that instead of a copy + stream synchronise) */
 int graal_eval_candidates(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int32_t max_id, double* delta);
 
 /* commit candidate `op` of (fA, fB); replaces test_copy_struct (cuda_lib_gl.py:1156-1180).
  * *n_stale = fragments that hit the reference's unwritten paste branch (expected 0). */
 int graal_apply_move(graal_ctx* h, int32_t fA, int32_t fB, int32_t op, int32_t max_id, int32_t* n_stale);
 
-/* timing of the last graal_eval_candidates* call, HIP events on the engine's stream (milliseconds):
- * out[0]=k_prep (tables + codes) out[1]=k_scan (contact stream) out[2]=k_post (mass tasks + queued contacts) out[3]=0 */
+/* switch the per-kernel HIP event records of graal_eval_candidates* on (default) or off */
+int graal_set_timing(graal_ctx* h, int32_t enabled);
+/* duration (ms) of the streaming scan kernel of the last graal_eval_candidates* call: a pair of HIP events recorded
+ * around it on the stream it ran on; out[1] = k_scan, the other entries are 0 (per-kernel times of k_prep / k_post come
+ * from rocprofv3).  graal_scan_times returns the last n calls (a ring of 1024 event pairs). */
 int graal_last_timing(graal_ctx* h, float out[4]);
+int graal_scan_times(graal_ctx* h, int32_t n, float* out_ms);
 /* average duration (ms) of the streaming scan kernel over `reps` back-to-back replays of the last call's scan between
  * two HIP events on the engine's stream (the replays count relevant contacts but queue nothing): the per-launch
  * event overhead of graal_last_timing is amortised away. */
