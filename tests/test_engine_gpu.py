@@ -217,3 +217,92 @@ def test_unsorted_contact_list_gives_the_same_deltas():
         fBs = [int(v) for v in rng.choice(np.setdiff1d(np.arange(P["n_frags"]), [fA]), 4, replace=False)]
         assert np.array_equal(e1.eval_candidates(fA, fBs, max_id), e2.eval_candidates(fA, fBs, max_id))
     assert e1.eval_full() == e2.eval_full()
+
+
+# ------------------------------------------------------------------------------------------------ edge cases
+def _deltas_match(P, s, fA, fBs, tol_rel=1e-7):
+    dense = dense_for(P)
+    want_state = O.copy_state(s)
+    max_id = relabel_ref(want_state)
+    e = engine_for(P, s)
+    assert e.relabel_contigs() == max_id
+    base, want = oracle_deltas(P, dense, want_state, fA, fBs, max_id)
+    got = e.eval_candidates(fA, fBs, max_id)
+    e.close()
+    assert got.shape == (len(fBs), 13)
+    assert np.all(np.abs(got - want) <= tol_rel * max(abs(base), 1.0)), np.abs(got - want).max()
+    return got, want
+
+
+def test_more_than_eight_neighbours_take_two_scan_passes():
+    P = make(1, 51, n_bins=60, nnz=900, grid_bp=2000)
+    s = random_state_for(P, np.random.RandomState(51), n_contigs=6, p_circ=0.2)
+    _deltas_match(P, s, 7, [1, 2, 3, 10, 11, 20, 30, 31, 40, 41, 50])
+
+
+def test_empty_contact_list():
+    P = make(1, 52, n_bins=30, nnz=200, grid_bp=2000)
+    P["coo_row"], P["coo_col"], P["coo_val"] = P["coo_row"][:0], P["coo_col"][:0], P["coo_val"][:0]
+    P["hic_matrix"] = np.zeros_like(P["hic_matrix"])
+    s = random_state_for(P, np.random.RandomState(52), n_contigs=3, p_circ=0.0)
+    got, want = _deltas_match(P, s, 4, [5, 17, 22])
+    e = engine_for(P, s)
+    e.relabel_contigs()
+    assert e.eval_full() == pytest.approx(dense_for(P).evaluate(s), rel=1e-6)   # pure expected mass
+    assert np.any(np.abs(want) > 0)
+
+
+def test_identical_fragments_score_a_no_op():
+    P = make(1, 53, n_bins=30, nnz=200, grid_bp=2000)
+    s = random_state_for(P, np.random.RandomState(53), n_contigs=3)
+    max_id = relabel_ref(s)
+    e = engine_for(P, s)
+    e.relabel_contigs()
+    got = e.eval_candidates(9, [9, 12], max_id)
+    assert np.all(got[0] == 0) and np.any(got[1] != 0)
+    before = e.download_frags()
+    assert e.apply_move(9, 9, 6, max_id) == 0
+    after = e.download_frags()
+    for k in O.FIELDS:
+        assert np.array_equal(before[k], after[k])
+
+
+def test_window_smaller_than_a_bin_and_single_contig():
+    # d_max = 0.5 kb < every bin: every cis pair is priced at the trans level; one single contig
+    P = make(3, 54, n_bins=40, nnz=600, d_max=0.5, weights=(1,), grid_bp=2000)
+    s = O.copy_state(P["S_o_A_frags"])
+    _deltas_match(P, s, 10, [11, 30, 3])
+
+
+def test_large_counts_use_the_stirling_branches():
+    P = make(1, 55, n_bins=40, nnz=500, grid_bp=2000)
+    v = P["coo_val"].copy()
+    v[::3] = 15 + (np.arange(len(v[::3])) % 200)      # ob >= 15: Stirling in double
+    v[1::3] = 10 + (np.arange(len(v[1::3])) % 5)      # 10..14: float32 Stirling (kernels3.cu:80-93)
+    P["coo_val"] = v
+    P["hic_matrix"] = synth.dense_from_coo(P["coo_row"], P["coo_col"], v, P["init_n_sub_frags"])
+    s = random_state_for(P, np.random.RandomState(55), n_contigs=4, p_circ=0.3)
+    e = engine_for(P, s)
+    e.relabel_contigs()
+    assert e.eval_full() == pytest.approx(dense_for(P).evaluate(s), rel=1e-6)
+    _deltas_match(P, s, 3, [4, 20, 33])
+
+
+def test_two_sub_fragments_per_bin():
+    par = synth.make_param_simu(fact=300.0, v_inter=0.03)
+    P = synth.with_dense(synth.make_problem(n_bins=50, nnz=900, n_sub=2, seed=56, contig_weights=(5, 3, 2), mean_len_bp=1500.0,
+                                            accu=3, param=par, grid_bp=2000))
+    s = random_state_for(P, np.random.RandomState(56), n_contigs=5, p_circ=0.3)
+    e = engine_for(P, s)
+    e.relabel_contigs()
+    assert e.eval_full() == pytest.approx(dense_for(P).evaluate(s), rel=1e-6)
+    _deltas_match(P, s, 8, [9, 25, 41, 2])
+
+
+def test_every_fragment_a_singleton():
+    P = make(3, 57, n_bins=40, nnz=700, grid_bp=2000)
+    n = P["n_frags"]
+    s = O.copy_state(P["S_o_A_frags"])
+    s["pos"][:] = 0; s["id_c"][:] = np.arange(n); s["start_bp"][:] = 0; s["prev"][:] = -1; s["next"][:] = -1
+    s["l_cont"][:] = 1; s["l_cont_bp"][:] = s["len_bp"]
+    _deltas_match(P, s, 5, [6, 7, 30])
