@@ -227,11 +227,15 @@ __global__ void k_relabel_keys(SoaPtr s, int n, unsigned long long* __restrict__
                   : ((1ull << (2 * LABEL_BITS)) - 1ull);
 }
 
-__global__ void k_relabel_o2n(const unsigned long long* __restrict__ sorted, int n_contigs, int* __restrict__ o2n,
-                              int* __restrict__ len_of)
+// the number of contigs is read from the statistics block on the device (k_stats ran earlier on the stream): no host
+// round trip in the middle of the relabel
+__global__ void k_relabel_o2n(const unsigned long long* __restrict__ sorted, int n, const long long* __restrict__ stats,
+                              int* __restrict__ o2n, int* __restrict__ len_of)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_contigs) return;
+    if (i >= n) return;
+    const int n_contigs = (int)stats[0];
+    if (i >= n_contigs) { len_of[i] = 0; return; }
     const unsigned long long k = sorted[i];
     o2n[(int)(k & ((1u << LABEL_BITS) - 1u))] = i;
     len_of[i] = (int)(k >> LABEL_BITS);
@@ -1231,7 +1235,7 @@ int graal_layout_stats(graal_ctx* h, int64_t out[8])
     return GRAAL_OK;
 }
 
-int graal_relabel_contigs(graal_ctx* h, int32_t* max_id)
+int graal_begin_step(graal_ctx* h, int64_t stats[8], int32_t* max_id)
 {
     if (!h) return GRAAL_E_ARG;
     if (!h->have_frags) return fail(h, GRAAL_E_STATE, "no fragments uploaded");
@@ -1240,31 +1244,41 @@ int graal_relabel_contigs(graal_ctx* h, int32_t* max_id)
     SoaPtr s = h->soa[h->cur];
     long long init[8] = {0, 0, 0, 0, 0, 0x7fffffff, 0, -1};
     CK(hipMemcpyAsync(h->d_scalars, init, sizeof init, hipMemcpyHostToDevice, h->stream));
+    CK(hipMemsetAsync(h->d_scalars + 14, 0, sizeof(long long), h->stream));
     k_stats<<<std::min(nb, 64), bs, 0, h->stream>>>(s, n, h->d_scalars);
     k_relabel_keys<<<nb, bs, 0, h->stream>>>(s, n, h->keys);
     CK(hipGetLastError());
     size_t tb = h->cub_tmp_bytes;
     CK(hipcub::DeviceRadixSort::SortKeys(h->cub_tmp, tb, h->keys, h->keys_sorted, n, 0, 2 * LABEL_BITS, h->stream));
-    long long res[8];
-    CK(hipMemcpyAsync(res, h->d_scalars, sizeof res, hipMemcpyDeviceToHost, h->stream));
-    CK(hipStreamSynchronize(h->stream));
-    const int nc = (int)res[0];
-    if (nc <= 0 || nc > n || res[7] >= 2 * n + 8) return fail(h, GRAAL_E_STATE, "corrupt layout: contig heads / labels out of range");
-    if (res[6] != 0) return fail(h, GRAAL_E_UNSUPPORTED, "repeats / inactive fragments are not supported yet");
-    k_relabel_o2n<<<blocks_for(nc, bs), bs, 0, h->stream>>>(h->keys_sorted, nc, h->o2n, h->len_of);
+    k_relabel_o2n<<<nb, bs, 0, h->stream>>>(h->keys_sorted, n, h->d_scalars, h->o2n, h->len_of);
     k_relabel_apply<<<nb, bs, 0, h->stream>>>(s, n, h->o2n);
     CK(hipGetLastError());
     tb = h->cub_tmp_bytes;
-    CK(hipcub::DeviceScan::ExclusiveSum(h->cub_tmp, tb, h->len_of, h->contig_off, nc, h->stream));
+    CK(hipcub::DeviceScan::ExclusiveSum(h->cub_tmp, tb, h->len_of, h->contig_off, n, h->stream));
     k_build_perm<<<nb, bs, 0, h->stream>>>(s, n, h->contig_off, h->perm);
     CK(hipGetLastError());
     int rc = refresh(h);
     if (rc) return rc;
+    long long res[16];
+    CK(hipMemcpyAsync(res, h->d_scalars, sizeof res, hipMemcpyDeviceToHost, h->stream));
     CK(hipStreamSynchronize(h->stream));
+    const int nc = (int)res[0];
+    // (a corrupt layout could have made the kernels above index out of range; the uploads validate labels and the
+    // mutations keep them in [0, n_contigs + 2], so this is a consistency check, not a guard)
+    if (nc <= 0 || nc > n || res[7] >= 2 * n + 8) return fail(h, GRAAL_E_STATE, "corrupt layout: contig heads / labels out of range");
+    if (res[6] != 0) return fail(h, GRAAL_E_UNSUPPORTED, "repeats / inactive fragments are not supported yet");
     h->n_contigs = nc; h->order_valid = true;
     if (max_id) *max_id = nc - 1;
+    if (stats) {
+        for (int i = 0; i < 6; i++) stats[i] = res[i];
+        stats[6] = res[14];                      // #(circ == 1)
+        stats[7] = (long long)*(int*)&res[13];   // fragments that hit the unwritten paste branch since the last begin_step
+    }
+    CK(hipMemsetAsync(h->d_scalars + 13, 0, sizeof(long long), h->stream));
     return GRAAL_OK;
 }
+
+int graal_relabel_contigs(graal_ctx* h, int32_t* max_id) { return graal_begin_step(h, nullptr, max_id); }
 
 int graal_eval_full_q(graal_ctx* h, int64_t q_out[2])
 {
@@ -1366,17 +1380,16 @@ int graal_apply_move(graal_ctx* h, int32_t fA, int32_t fB, int32_t op, int32_t m
     if (fA < 0 || fA >= h->n || fB < 0 || fB >= h->n) return fail(h, GRAAL_E_ARG, "fragment index out of range");
     CK(hipSetDevice(h->device));
     int* d_stale = (int*)(h->d_scalars + 13);
-    CK(hipMemsetAsync(d_stale, 0, sizeof(int), h->stream));
     k_apply<<<blocks_for(h->n, 256), 256, 0, h->stream>>>(h->soa[h->cur], h->soa[1 - h->cur], h->n, op, fA, fB, max_id, d_stale);
     CK(hipGetLastError());
     h->cur = 1 - h->cur;
-    h->order_valid = false;
-    int rc = refresh(h);
-    if (rc) return rc;
-    int stale = 0;
-    CK(hipMemcpyAsync(&stale, d_stale, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    CK(hipStreamSynchronize(h->stream));
-    if (n_stale) *n_stale = stale;
+    h->order_valid = false; // graal_begin_step (relabel) rebuilds the index and the geometry records
+    if (n_stale) { // asking for the count costs a synchronisation; pass NULL and read it from graal_begin_step's stats[7]
+        int stale = 0;
+        CK(hipMemcpyAsync(&stale, d_stale, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        CK(hipStreamSynchronize(h->stream));
+        *n_stale = stale;
+    }
     return GRAAL_OK;
 }
 

@@ -23,7 +23,7 @@ _f64p = ctypes.POINTER(ctypes.c_double)
 
 SYMBOLS = ("graal_abi_version", "graal_create", "graal_destroy", "graal_last_error", "graal_set_params",
            "graal_upload_subfrags", "graal_upload_contacts", "graal_upload_frags", "graal_download_frags",
-           "graal_relabel_contigs", "graal_layout_stats", "graal_eval_full_q", "graal_eval_candidates_q",
+           "graal_relabel_contigs", "graal_begin_step", "graal_layout_stats", "graal_eval_full_q", "graal_eval_candidates_q",
            "graal_eval_candidates", "graal_apply_move", "graal_set_timing", "graal_last_timing", "graal_scan_times", "graal_time_scan", "graal_last_counters")
 
 _lib = None
@@ -55,6 +55,7 @@ def load():
         L.graal_download_frags.argtypes = [ctypes.c_void_p, ctypes.POINTER(_i32p)]
         L.graal_relabel_contigs.argtypes = [ctypes.c_void_p, _i32p]
         L.graal_layout_stats.argtypes = [ctypes.c_void_p, _i64p]
+        L.graal_begin_step.argtypes = [ctypes.c_void_p, _i64p, _i32p]
         L.graal_eval_full_q.argtypes = [ctypes.c_void_p, _i64p]
         L.graal_eval_candidates_q.argtypes = [ctypes.c_void_p, ctypes.c_int32, _i32p, ctypes.c_int32, ctypes.c_int32,
                                               ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
@@ -151,15 +152,23 @@ class Engine:
         self._ck(self._L.graal_relabel_contigs(self._h, ctypes.byref(m)), "graal_relabel_contigs")
         return int(m.value)
 
+    def begin_step(self):
+        """(stats[8], max_id): layout statistics + contig relabel + index rebuild with one synchronisation."""
+        out = np.zeros(8, dtype=np.int64)
+        m = ctypes.c_int32(0)
+        self._ck(self._L.graal_begin_step(self._h, out.ctypes.data_as(_i64p), ctypes.byref(m)), "graal_begin_step")
+        return out, int(m.value)
+
     def layout_stats(self):
         out = np.zeros(8, dtype=np.int64)
         self._ck(self._L.graal_layout_stats(self._h, out.ctypes.data_as(_i64p)), "graal_layout_stats")
         return out
 
-    def apply_move(self, fA, fB, op, max_id):
+    def apply_move(self, fA, fB, op, max_id, wait=True):
+        """Commit a candidate.  wait=False does not synchronise (the stale-paste count then comes with begin_step)."""
         st = ctypes.c_int32(0)
-        self._ck(self._L.graal_apply_move(self._h, int(fA), int(fB), int(op), int(max_id), ctypes.byref(st)),
-                 "graal_apply_move")
+        self._ck(self._L.graal_apply_move(self._h, int(fA), int(fB), int(op), int(max_id),
+                                          ctypes.byref(st) if wait else None), "graal_apply_move")
         return int(st.value)
 
     # -- likelihood ---------------------------------------------------------------------------

@@ -393,7 +393,7 @@ class sampler(object):
         return float(self.group.all_reduce_sum_int(int(q[0])) + int(q[1])) / Q_SCALE
 
     def eval_likelihood(self):
-        self.engine.relabel_contigs()
+        self.modify_gl_cuda_buffer(0)
         return self._full_likelihood()
 
     def init_likelihood(self):
@@ -424,10 +424,12 @@ class sampler(object):
     # ------------------------------------------------------------------ layout maintenance
     def modify_gl_cuda_buffer(self, id_fi, dt=0):
         """Contig relabel half of ``cuda_lib_gl.py:1695-1788`` (+ ``kernels3.cu:3848-3851``); returns max_id."""
-        return np.int32(self.engine.relabel_contigs())
+        st, max_id = self.engine.begin_step()
+        self.n_stale_paste += int(st[7])
+        return np.int32(max_id)
 
     def test_copy_struct(self, id_fA, id_f_sampled, mode, max_id):
-        self.n_stale_paste += self.engine.apply_move(id_fA, id_f_sampled, mode, max_id)
+        self.engine.apply_move(id_fA, id_f_sampled, mode, max_id, wait=False)  # stale-paste count: next begin_step
         self.likelihood_t = None  # a layout change outside step_max_likelihood: re-evaluate before the next step
 
     def explode_genome(self, dt=0):
@@ -471,9 +473,10 @@ class sampler(object):
         """``cuda_lib_gl.py:1793-1980``.  Returns (o, n_contigs, min_len, mean_len_bp, max_len, op_sampled,
         id_f_sampled, dist, F_t)."""
         id_fA = int(id_fA)
-        st = self.engine.layout_stats()
+        st, max_id = self.engine.begin_step()   # statistics + relabel + index, one synchronisation
+        max_id = np.int32(max_id)
         n_circ = int(st[6])
-        max_id = self.modify_gl_cuda_buffer(id_fA, dt)
+        self.n_stale_paste += int(st[7])
         n_contigs = int(st[0])
         mean_len_bp = float(st[3]) / float(st[2])
         max_len = np.int32(st[4])

@@ -70,6 +70,10 @@ int graal_download_frags(graal_ctx* h, int32_t* const soa[GRAAL_N_FIELDS]);
  * replaces modify_gl_cuda_buffer's compute half + gl_update_pos (cuda_lib_gl.py:1697-1722,
  * kernels3.cu:3848-3851).  *max_id = n_contigs - 1.  Also rebuilds the position index. */
 int graal_relabel_contigs(graal_ctx* h, int32_t* max_id);
+/* start of an MCMC step in ONE call and one synchronisation: the statistics of graal_layout_stats (stats[0..6], taken
+ * before the relabel, which does not change them) + stats[7] = fragments that hit the unwritten paste branch in the
+ * commits since the previous call, then the relabel of graal_relabel_contigs.  stats may be NULL. */
+int graal_begin_step(graal_ctx* h, int64_t stats[8], int32_t* max_id);
 
 /* layout statistics step_max_likelihood returns (cuda_lib_gl.py:1809-1816):
  * out[0]=n_contigs out[1]=sum(l_cont) out[2]=#(start_bp==0) out[3]=sum(l_cont_bp | start_bp==0)
@@ -98,7 +102,8 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
 int graal_eval_candidates(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int32_t max_id, double* delta);
 
 /* commit candidate `op` of (fA, fB); replaces test_copy_struct (cuda_lib_gl.py:1156-1180).
- * *n_stale = fragments that hit the reference's unwritten paste branch (expected 0). */
+ * *n_stale = fragments that hit the reference's unwritten paste branch (expected 0); NULL = do not wait for the
+ * commit (the count is then reported by the next graal_begin_step).  The geometry index is stale until then. */
 int graal_apply_move(graal_ctx* h, int32_t fA, int32_t fB, int32_t op, int32_t max_id, int32_t* n_stale);
 
 /* switch the per-kernel HIP event records of graal_eval_candidates* on (default) or off */
