@@ -235,7 +235,8 @@ __global__ void k_relabel_o2n(const unsigned long long* __restrict__ sorted, int
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int n_contigs = (int)stats[0];
-    if (i >= n_contigs) { len_of[i] = 0; return; }
+    if (i >= n_contigs) { len_of[i] = 0; if (i == n - 1) len_of[n] = 0; return; }
+    if (i == n - 1) len_of[n] = 0;
     const unsigned long long k = sorted[i];
     o2n[(int)(k & ((1u << LABEL_BITS) - 1u))] = i;
     len_of[i] = (int)(k >> LABEL_BITS);
@@ -255,8 +256,18 @@ __global__ void k_build_perm(SoaPtr s, int n, const int* __restrict__ contig_off
     perm[contig_off[s.p[F_IDC][f]] + s.p[F_POS][f]] = f;
 }
 
-// commit one candidate (test_copy_struct, cuda_lib_gl.py:1156): out = apply_move(in)
-__global__ void k_apply(SoaPtr in, SoaPtr out, int n, int op, int fA, int fB, int max_id, int* __restrict__ n_stale)
+// What one commit did to the contig set: only contig(fA), contig(fB) and up to two fresh labels can change.
+struct Changed {
+    int cA, cB;        // labels (= ranks) of the two touched contigs before the commit
+    int lab[4];        // candidate labels after the commit: cA, cB, max_id + 1, max_id + 2
+    int len[4];        // l_cont of the contig carrying that label after the commit
+    int exists[4];
+};
+
+// commit one candidate (test_copy_struct, cuda_lib_gl.py:1156): out = apply_move(in); also records which contigs exist
+// afterwards among the <= 4 labels the move can touch (for the incremental relabel of the next graal_begin_step)
+__global__ void k_apply(SoaPtr in, SoaPtr out, int n, int op, int fA, int fB, int max_id, int* __restrict__ n_stale,
+                        Changed* __restrict__ chg)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n) return;
@@ -266,6 +277,96 @@ __global__ void k_apply(SoaPtr in, SoaPtr out, int n, int op, int fA, int fB, in
     const Rec r = apply_move(m, f, ld_rec(in, f), &stale);
     st_rec(out, f, r);
     if (stale) atomicAdd(n_stale, 1);
+    if (f == 0) { chg->cA = A0.id_c; chg->cB = B0.id_c; chg->lab[0] = A0.id_c; chg->lab[1] = B0.id_c; chg->lab[2] = max_id + 1; chg->lab[3] = max_id + 2; }
+    if (r.pos == 0) {
+        const int c = r.id_c;
+        const int j = c == A0.id_c ? 0 : (c == B0.id_c ? 1 : (c == max_id + 1 ? 2 : (c == max_id + 2 ? 3 : -1)));
+        if (j >= 0) { chg->len[j] = r.l_cont; chg->exists[j] = 1; }
+    }
+}
+
+// ---- incremental relabel.  Invariant after every graal_begin_step: labels ARE ranks (contigs sorted by (l_cont, label)),
+// len_of[rank] is sorted and contig_off is its exclusive prefix sum.  One commit changes <= 4 contigs, so the new stable
+// ranking follows from the old one by counting: rank' = rank - #removed before + #inserted before.  Same result as the
+// full sort (cuda_lib_gl.py:1697-1722 with a stable argsort), without sorting 50k keys per step.
+struct IncrPlan {
+    int n_removed, removed[2], removed_len[2];   // old ranks of contig(fA), contig(fB) and their old lengths
+    int n_new, new_lab[4], new_len[4], new_rank[4], new_off[4];
+    int nc_new;
+};
+
+__device__ __forceinline__ bool key_less(int l1, int c1, int l2, int c2) { return l1 < l2 || (l1 == l2 && c1 < c2); }
+
+__global__ void k_incr_plan(const Changed* __restrict__ chg, const int* __restrict__ len_old, const int* __restrict__ off_old,
+                            int nc_old, int n, IncrPlan* __restrict__ plan)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    IncrPlan p;
+    p.n_removed = 0;
+    const int cand[2] = {chg->cA, chg->cB};
+    for (int i = 0; i < 2; i++) {
+        if (i == 1 && cand[1] == cand[0]) continue;
+        p.removed[p.n_removed] = cand[i]; p.removed_len[p.n_removed] = len_old[cand[i]]; p.n_removed++;
+    }
+    for (int i = p.n_removed; i < 2; i++) { p.removed[i] = -1; p.removed_len[i] = 0; }
+    p.n_new = 0;
+    for (int j = 0; j < 4; j++) {
+        if (!chg->exists[j]) continue;
+        if (j == 1 && chg->lab[1] == chg->lab[0]) continue;
+        p.new_lab[p.n_new] = chg->lab[j]; p.new_len[p.n_new] = chg->len[j]; p.n_new++;
+    }
+    for (int i = p.n_new; i < 4; i++) { p.new_lab[i] = -1; p.new_len[i] = 0; p.new_rank[i] = -1; p.new_off[i] = 0; }
+    for (int i = 0; i < p.n_new; i++) {
+        const int l = p.new_len[i], c = p.new_lab[i];
+        // old contigs with key < (l, c): binary searches in the sorted length array
+        int lo = 0, hi = nc_old;
+        while (lo < hi) { const int m = (lo + hi) >> 1; if (len_old[m] < l) lo = m + 1; else hi = m; }
+        const int lb = lo;
+        hi = nc_old;
+        while (lo < hi) { const int m = (lo + hi) >> 1; if (len_old[m] <= l) lo = m + 1; else hi = m; }
+        const int ub = lo;
+        int within = c - lb; within = within < 0 ? 0 : (within > ub - lb ? ub - lb : within);
+        const int pcount = lb + within;                    // number of old contigs with a smaller key
+        int rank = pcount, off = pcount < nc_old ? off_old[pcount] : n;
+        for (int r = 0; r < p.n_removed; r++)
+            if (key_less(p.removed_len[r], p.removed[r], l, c)) { rank -= 1; off -= p.removed_len[r]; }
+        for (int j = 0; j < p.n_new; j++)
+            if (j != i && key_less(p.new_len[j], p.new_lab[j], l, c)) { rank += 1; off += p.new_len[j]; }
+        p.new_rank[i] = rank; p.new_off[i] = off;
+    }
+    p.nc_new = nc_old - p.n_removed + p.n_new;
+    *plan = p;
+}
+
+// one elementwise pass: new label of every fragment, sorted-length / offset arrays (contig heads write them), position
+// index and geometry records
+__global__ void k_incr_apply(SoaPtr s, int n, const IncrPlan* __restrict__ planp, const int* __restrict__ len_old,
+                             const int* __restrict__ off_old, int* __restrict__ len_new, int* __restrict__ off_new,
+                             int* __restrict__ perm, Geo* __restrict__ geo)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    const IncrPlan p = *planp;
+    if (f == 0) off_new[p.nc_new] = n;
+    if (f >= p.nc_new && f < n) len_new[f] = 0; // keep the tail of the length array zero
+    if (f >= n) return;
+    const int c = s.p[F_IDC][f];
+    int rank = -1, off = 0, lenc = 0;
+    for (int i = 0; i < 4; i++)
+        if (i < p.n_new && c == p.new_lab[i]) { rank = p.new_rank[i]; off = p.new_off[i]; lenc = p.new_len[i]; }
+    if (rank < 0) { // untouched contig: c is its old rank
+        lenc = len_old[c]; rank = c; off = off_old[c];
+        for (int r = 0; r < 2; r++)
+            if (r < p.n_removed && p.removed[r] < c) { rank -= 1; off -= p.removed_len[r]; }
+        for (int i = 0; i < 4; i++)
+            if (i < p.n_new && key_less(p.new_len[i], p.new_lab[i], lenc, c)) { rank += 1; off += p.new_len[i]; }
+    }
+    const int pos = s.p[F_POS][f];
+    s.p[F_IDC][f] = rank;
+    if (pos == 0) { len_new[rank] = lenc; off_new[rank] = off; }
+    perm[off + pos] = f;
+    Geo g; g.id_c = rank; g.start_bp = s.p[F_START][f]; g.len_bp = s.p[F_LEN][f];
+    g.flags = (s.p[F_ORI][f] == 1 ? 1 : 0) | (s.p[F_CIRC][f] == 1 ? 2 : 0);
+    geo[f] = g;
 }
 
 // ------------------------------------------------------------------ full likelihood
@@ -897,7 +998,13 @@ struct Ctx {
     int bitmap_words = 0;
     int* d_sub_ids = nullptr;     // [n_bins][4], only when some bin has more than one sub-fragment
     unsigned long long *keys = nullptr, *keys_sorted = nullptr;
-    int *o2n = nullptr, *len_of = nullptr, *contig_off = nullptr, *perm = nullptr;
+    int *o2n = nullptr, *perm = nullptr;
+    int *len_of2[2] = {nullptr, nullptr}, *contig_off2[2] = {nullptr, nullptr}; // per layout buffer (see k_incr_apply)
+    Changed* d_chg = nullptr;
+    IncrPlan* d_plan = nullptr;
+    bool ranks_valid = false;     // labels of buffer `cur` are ranks and its len/offset arrays are current
+    int pending_commits = 0;      // commits since the last graal_begin_step
+    bool incr_ok = false;         // the single pending commit started from a ranked layout with the right max_id
     void* cub_tmp = nullptr;
     size_t cub_tmp_bytes = 0;
     NbTables* tabs = nullptr;
@@ -978,7 +1085,7 @@ int sync_args(Ctx* h)
         a[b].rows_sorted = h->rows_sorted ? 1 : 0;
         a[b].row = h->row; a[b].col = h->col; a[b].cnt = h->cnt; a[b].sub2bin = h->sub2bin;
         a[b].sub2bin_multi = h->single_sub ? nullptr : h->sub2bin; a[b].sub_ids = h->d_sub_ids;
-        a[b].contig_off = h->contig_off; a[b].perm = h->perm; a[b].geo = h->geo; a[b].stat = h->stat;
+        a[b].contig_off = h->contig_off2[b]; a[b].perm = h->perm; a[b].geo = h->geo; a[b].stat = h->stat;
         a[b].codes = h->codes; a[b].bitmap = h->bitmap; a[b].tabs = h->tabs; a[b].step_hdr = h->step_hdr;
         a[b].queue = h->queue; a[b].counters = (unsigned long long*)(h->d_scalars + 10);
         a[b].nfpb = h->nfpb; a[b].par = h->par;
@@ -1047,6 +1154,8 @@ int graal_create(int device, graal_ctx** out)
     CK(hipMalloc(&h->step_hdr, 2 * MAXK * sizeof(int)));
     CK(hipMemset(h->step_hdr, 0, 2 * MAXK * sizeof(int)));
     CK(hipMalloc(&h->d_args, 2 * sizeof(DevArgs)));
+    CK(hipMalloc(&h->d_chg, sizeof(Changed)));
+    CK(hipMalloc(&h->d_plan, sizeof(IncrPlan)));
     CK(hipHostMalloc((void**)&h->h_res, (1 + MAXK * N_OPS) * sizeof(long long), hipHostMallocDefault));
     memset(h->h_res, 0, (1 + MAXK * N_OPS) * sizeof(long long));
     return GRAAL_OK;
@@ -1059,7 +1168,7 @@ void graal_destroy(graal_ctx* h)
         (void)hipSetDevice(h->device);
         (void)hipStreamSynchronize(h->stream);
         void* ptrs[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->stat, h->sub2bin, h->row, h->col, h->cnt, h->codes, h->queue, h->bitmap, h->d_sub_ids,
-                        h->keys, h->keys_sorted, h->o2n, h->len_of, h->contig_off, h->perm, h->cub_tmp, h->tabs, h->step_hdr, h->d_args,
+                        h->keys, h->keys_sorted, h->o2n, h->len_of2[0], h->len_of2[1], h->contig_off2[0], h->contig_off2[1], h->perm, h->cub_tmp, h->tabs, h->step_hdr, h->d_args, h->d_chg, h->d_plan,
                         h->d_scalars, h->d_qout};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (h->h_res) (void)hipHostFree(h->h_res);
@@ -1174,7 +1283,7 @@ int graal_upload_frags(graal_ctx* h, const int32_t* const soa[GRAAL_N_FIELDS], i
             return fail(h, GRAAL_E_UNSUPPORTED, "repeats / inactive fragments are not supported yet");
     }
     if (h->n != n) {
-        void* old[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->codes, h->keys, h->keys_sorted, h->o2n, h->len_of, h->contig_off, h->perm, h->cub_tmp};
+        void* old[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->codes, h->keys, h->keys_sorted, h->o2n, h->len_of2[0], h->len_of2[1], h->contig_off2[0], h->contig_off2[1], h->perm, h->cub_tmp};
         for (void* p : old) if (p) (void)hipFree(p);
         for (int b = 0; b < 2; b++) {
             CK(hipMalloc(&h->soa_mem[b], sizeof(int) * (size_t)n * GRAAL_N_FIELDS));
@@ -1185,17 +1294,19 @@ int graal_upload_frags(graal_ctx* h, const int32_t* const soa[GRAAL_N_FIELDS], i
         CK(hipMalloc(&h->keys, sizeof(unsigned long long) * (size_t)n));
         CK(hipMalloc(&h->keys_sorted, sizeof(unsigned long long) * (size_t)n));
         CK(hipMalloc(&h->o2n, sizeof(int) * (size_t)(2 * n + 8)));
-        CK(hipMalloc(&h->len_of, sizeof(int) * (size_t)(n + 1)));
-        CK(hipMalloc(&h->contig_off, sizeof(int) * (size_t)(n + 1)));
+        for (int b = 0; b < 2; b++) {
+            CK(hipMalloc(&h->len_of2[b], sizeof(int) * (size_t)(n + 2)));
+            CK(hipMalloc(&h->contig_off2[b], sizeof(int) * (size_t)(n + 2)));
+        }
         CK(hipMalloc(&h->perm, sizeof(int) * (size_t)n));
         size_t b1 = 0, b2 = 0;
         (void)hipcub::DeviceRadixSort::SortKeys(nullptr, b1, h->keys, h->keys_sorted, n, 0, 2 * LABEL_BITS, h->stream);
-        (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b2, h->len_of, h->contig_off, n, h->stream);
+        (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b2, h->len_of2[0], h->contig_off2[0], n + 1, h->stream);
         h->cub_tmp_bytes = b1 > b2 ? b1 : b2;
         CK(hipMalloc(&h->cub_tmp, h->cub_tmp_bytes));
         h->n = n;
     }
-    h->cur = 0;
+    h->cur = 0; h->ranks_valid = false; h->pending_commits = 0;
     for (int k = 0; k < GRAAL_N_FIELDS; k++)
         CK(hipMemcpy(h->soa[0].p[k], soa[k], sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
     h->have_frags = true; h->order_valid = false;
@@ -1241,24 +1352,36 @@ int graal_begin_step(graal_ctx* h, int64_t stats[8], int32_t* max_id)
     if (!h->have_frags) return fail(h, GRAAL_E_STATE, "no fragments uploaded");
     CK(hipSetDevice(h->device));
     const int n = h->n, bs = 256, nb = blocks_for(n, bs);
-    SoaPtr s = h->soa[h->cur];
+    const int cur = h->cur;
+    SoaPtr s = h->soa[cur];
     long long init[8] = {0, 0, 0, 0, 0, 0x7fffffff, 0, -1};
     CK(hipMemcpyAsync(h->d_scalars, init, sizeof init, hipMemcpyHostToDevice, h->stream));
     CK(hipMemsetAsync(h->d_scalars + 14, 0, sizeof(long long), h->stream));
     k_stats<<<std::min(nb, 64), bs, 0, h->stream>>>(s, n, h->d_scalars);
-    k_relabel_keys<<<nb, bs, 0, h->stream>>>(s, n, h->keys);
-    CK(hipGetLastError());
-    size_t tb = h->cub_tmp_bytes;
-    CK(hipcub::DeviceRadixSort::SortKeys(h->cub_tmp, tb, h->keys, h->keys_sorted, n, 0, 2 * LABEL_BITS, h->stream));
-    k_relabel_o2n<<<nb, bs, 0, h->stream>>>(h->keys_sorted, n, h->d_scalars, h->o2n, h->len_of);
-    k_relabel_apply<<<nb, bs, 0, h->stream>>>(s, n, h->o2n);
-    CK(hipGetLastError());
-    tb = h->cub_tmp_bytes;
-    CK(hipcub::DeviceScan::ExclusiveSum(h->cub_tmp, tb, h->len_of, h->contig_off, n, h->stream));
-    k_build_perm<<<nb, bs, 0, h->stream>>>(s, n, h->contig_off, h->perm);
-    CK(hipGetLastError());
-    int rc = refresh(h);
-    if (rc) return rc;
+    static const bool no_incr = getenv("GRAAL_NO_INCREMENTAL_RELABEL") != nullptr;
+    if (h->ranks_valid && h->pending_commits == 0) {
+        // nothing changed since the last call: labels are ranks already
+    } else if (h->ranks_valid && h->pending_commits == 1 && h->incr_ok && !no_incr) {
+        // exactly one commit since the last ranking: count instead of sort (rank arrays of buffer 1-cur -> buffer cur)
+        k_incr_plan<<<1, 64, 0, h->stream>>>(h->d_chg, h->len_of2[1 - cur], h->contig_off2[1 - cur], h->n_contigs, n, h->d_plan);
+        k_incr_apply<<<blocks_for(n + 1, bs), bs, 0, h->stream>>>(s, n, h->d_plan, h->len_of2[1 - cur], h->contig_off2[1 - cur],
+                                                                 h->len_of2[cur], h->contig_off2[cur], h->perm, h->geo);
+        CK(hipGetLastError());
+    } else {
+        k_relabel_keys<<<nb, bs, 0, h->stream>>>(s, n, h->keys);
+        CK(hipGetLastError());
+        size_t tb = h->cub_tmp_bytes;
+        CK(hipcub::DeviceRadixSort::SortKeys(h->cub_tmp, tb, h->keys, h->keys_sorted, n, 0, 2 * LABEL_BITS, h->stream));
+        k_relabel_o2n<<<nb, bs, 0, h->stream>>>(h->keys_sorted, n, h->d_scalars, h->o2n, h->len_of2[cur]);
+        k_relabel_apply<<<nb, bs, 0, h->stream>>>(s, n, h->o2n);
+        CK(hipGetLastError());
+        tb = h->cub_tmp_bytes;
+        CK(hipcub::DeviceScan::ExclusiveSum(h->cub_tmp, tb, h->len_of2[cur], h->contig_off2[cur], n + 1, h->stream));
+        k_build_perm<<<nb, bs, 0, h->stream>>>(s, n, h->contig_off2[cur], h->perm);
+        CK(hipGetLastError());
+        int rc = refresh(h);
+        if (rc) return rc;
+    }
     long long res[16];
     CK(hipMemcpyAsync(res, h->d_scalars, sizeof res, hipMemcpyDeviceToHost, h->stream));
     CK(hipStreamSynchronize(h->stream));
@@ -1267,7 +1390,7 @@ int graal_begin_step(graal_ctx* h, int64_t stats[8], int32_t* max_id)
     // mutations keep them in [0, n_contigs + 2], so this is a consistency check, not a guard)
     if (nc <= 0 || nc > n || res[7] >= 2 * n + 8) return fail(h, GRAAL_E_STATE, "corrupt layout: contig heads / labels out of range");
     if (res[6] != 0) return fail(h, GRAAL_E_UNSUPPORTED, "repeats / inactive fragments are not supported yet");
-    h->n_contigs = nc; h->order_valid = true;
+    h->n_contigs = nc; h->order_valid = true; h->ranks_valid = true; h->pending_commits = 0; h->incr_ok = false;
     if (max_id) *max_id = nc - 1;
     if (stats) {
         for (int i = 0; i < 6; i++) stats[i] = res[i];
@@ -1293,7 +1416,7 @@ int graal_eval_full_q(graal_ctx* h, int64_t q_out[2])
         k_full_nnz<<<nb, 256, 0, h->stream>>>(h->row, h->col, h->cnt, h->nnz, h->sub2bin, h->geo, h->stat, s.p[F_LCONTBP],
                                                h->nfpb, h->par, h->d_scalars + 8);
     }
-    k_full_mass<<<blocks_for(h->n, 64), 64, 0, h->stream>>>(h->n, h->perm, h->contig_off, h->geo, h->stat, s.p[F_LCONT],
+    k_full_mass<<<blocks_for(h->n, 64), 64, 0, h->stream>>>(h->n, h->perm, h->contig_off2[h->cur], h->geo, h->stat, s.p[F_LCONT],
                                                              s.p[F_LCONTBP], s.p[F_POS], h->nfpb, h->par, reach_bp(h),
                                                              h->d_scalars + 9);
     CK(hipGetLastError());
@@ -1380,8 +1503,11 @@ int graal_apply_move(graal_ctx* h, int32_t fA, int32_t fB, int32_t op, int32_t m
     if (fA < 0 || fA >= h->n || fB < 0 || fB >= h->n) return fail(h, GRAAL_E_ARG, "fragment index out of range");
     CK(hipSetDevice(h->device));
     int* d_stale = (int*)(h->d_scalars + 13);
-    k_apply<<<blocks_for(h->n, 256), 256, 0, h->stream>>>(h->soa[h->cur], h->soa[1 - h->cur], h->n, op, fA, fB, max_id, d_stale);
+    CK(hipMemsetAsync(h->d_chg, 0, sizeof(Changed), h->stream));
+    k_apply<<<blocks_for(h->n, 256), 256, 0, h->stream>>>(h->soa[h->cur], h->soa[1 - h->cur], h->n, op, fA, fB, max_id, d_stale, h->d_chg);
     CK(hipGetLastError());
+    h->incr_ok = h->ranks_valid && h->pending_commits == 0 && max_id == h->n_contigs - 1;
+    h->pending_commits += 1;
     h->cur = 1 - h->cur;
     h->order_valid = false; // graal_begin_step (relabel) rebuilds the index and the geometry records
     if (n_stale) { // asking for the count costs a synchronisation; pass NULL and read it from graal_begin_step's stats[7]

@@ -306,3 +306,60 @@ def test_every_fragment_a_singleton():
     s["pos"][:] = 0; s["id_c"][:] = np.arange(n); s["start_bp"][:] = 0; s["prev"][:] = -1; s["next"][:] = -1
     s["l_cont"][:] = 1; s["l_cont_bp"][:] = s["len_bp"]
     _deltas_match(P, s, 5, [6, 7, 30])
+
+
+@pytest.mark.parametrize("n_sub,seed,p_circ", [(1, 31, 0.0), (1, 32, 0.5), (3, 33, 0.3)])
+def test_incremental_relabel_matches_the_sort(n_sub, seed, p_circ):
+    """graal_begin_step after one commit derives the new ranking by counting (k_incr_plan / k_incr_apply); it must give
+    the labels of the stable sort (cuda_lib_gl.py:1697-1722) and the same position index as a fresh upload."""
+    P = make(n_sub, seed, n_bins=60, nnz=800)
+    rng = np.random.RandomState(seed)
+    s = random_state_for(P, rng, p_circ=p_circ)
+    n = P["n_frags"]
+    e = engine_for(P, s)
+    ref = O.copy_state(s)
+    _, max_id = e.begin_step()
+    assert max_id == relabel_ref(ref)
+    for step in range(120):
+        fA, fB = [int(v) for v in rng.choice(n, 2, replace=False)]
+        op = int(rng.randint(13))
+        e.apply_move(fA, fB, op, max_id, wait=False)
+        ref, stale = util.oracle_candidate(ref, fA, fB, op, max_id)
+        assert not stale
+        stats, max_id = e.begin_step()
+        assert max_id == relabel_ref(ref), step
+        got = e.download_frags()
+        for k in O.FIELDS:
+            assert np.array_equal(got[k], ref[k]), (step, op, k)
+        heads = ref["start_bp"] == 0
+        assert list(stats[:6]) == [max_id + 1, ref["l_cont"].sum(), heads.sum(), ref["l_cont_bp"][heads].sum(),
+                                   ref["l_cont"].max(), ref["l_cont"].min()]
+        if step % 10 == 0:  # the position index / offsets feed the candidate tables: compare with a fresh engine
+            fBs = np.array([int(v) for v in rng.choice(np.setdiff1d(np.arange(n), [fA]), 4, replace=False)], np.int32)
+            e2 = engine_for(P, ref)
+            _, m2 = e2.begin_step()
+            assert m2 == max_id
+            assert np.array_equal(e.eval_candidates(fA, fBs, max_id), e2.eval_candidates(fA, fBs, max_id))
+            assert np.array_equal(e.eval_full_q(), e2.eval_full_q())
+            e2.close()
+    e.close()
+
+
+def test_two_commits_between_begin_steps_fall_back_to_the_sort():
+    P = make(1, 35, n_bins=50, nnz=500)
+    rng = np.random.RandomState(35)
+    s = random_state_for(P, rng, p_circ=0.2)
+    e = engine_for(P, s)
+    ref = O.copy_state(s)
+    _, max_id = e.begin_step()
+    relabel_ref(ref)
+    for op, (fA, fB) in [(2, (3, 17)), (10, (8, 30))]:
+        e.apply_move(fA, fB, op, max_id, wait=False)
+        ref, _ = util.oracle_candidate(ref, fA, fB, op, max_id)
+        max_id += 2  # labels of the second commit must not collide with the first one's fresh labels
+    _, max_id = e.begin_step()
+    assert max_id == relabel_ref(ref)
+    got = e.download_frags()
+    for k in O.FIELDS:
+        assert np.array_equal(got[k], ref[k]), k
+    e.close()
