@@ -88,7 +88,9 @@ __device__ __forceinline__ float rippe_circ(float s, float s_tot, const Par& p)
 }
 
 // dynamic geometry of one fragment (16-byte record, rebuilt after every layout change)
-struct Geo { int id_c, start_bp, len_bp, flags; }; // flags: bit0 ori==+1, bit1 circ
+struct Geo { int id_c, flags, start_bp, len_bp; }; // flags: bit0 ori==+1, bit1 circ, bits 2..31 pos
+__device__ __forceinline__ int geo_flags(int ori, int circ, int pos) { return (ori == 1 ? 1 : 0) | (circ == 1 ? 2 : 0) | (pos << 2); }
+__device__ __forceinline__ int geo_pos(int flags) { return (int)((unsigned)flags >> 2); }
 // static data of one bin: sub-fragment lengths (kb) and RF counts (simulation_loader.py:673-704)
 struct Stat { float l0, l1, l2; int n; int a0, a1, a2; int pad; };
 // 3-way selects instead of indexed arrays: indexed private arrays would live in scratch memory
@@ -171,7 +173,7 @@ __global__ void k_refresh_geo(SoaPtr s, Geo* __restrict__ geo, int n)
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n) return;
     Geo g; g.id_c = s.p[F_IDC][f]; g.start_bp = s.p[F_START][f]; g.len_bp = s.p[F_LEN][f];
-    g.flags = (s.p[F_ORI][f] == 1 ? 1 : 0) | (s.p[F_CIRC][f] == 1 ? 2 : 0);
+    g.flags = geo_flags(s.p[F_ORI][f], s.p[F_CIRC][f], s.p[F_POS][f]);
     geo[f] = g;
 }
 
@@ -365,7 +367,7 @@ __global__ void k_incr_apply(SoaPtr s, int n, const IncrPlan* __restrict__ planp
     if (pos == 0) { len_new[rank] = lenc; off_new[rank] = off; }
     perm[off + pos] = f;
     Geo g; g.id_c = rank; g.start_bp = s.p[F_START][f]; g.len_bp = s.p[F_LEN][f];
-    g.flags = (s.p[F_ORI][f] == 1 ? 1 : 0) | (s.p[F_CIRC][f] == 1 ? 2 : 0);
+    g.flags = geo_flags(s.p[F_ORI][f], s.p[F_CIRC][f], pos);
     geo[f] = g;
 }
 
@@ -430,9 +432,10 @@ struct Task {            // windowed cis sum between piece p and piece q in one 
     unsigned plus, minus; // 13-bit op masks: layouts (ops) in which this sum is the NEW (+) / OLD (-) value
     int base_p, np, base_q, nq; // position-index ranges of the two pieces (perm[base .. base + n))
 };
-constexpr int ITEM_CAP = 2048; // work items per neighbour with a direct item -> task table (else: binary search)
+constexpr int ITEM_CAP = 2048;     // work items per neighbour with a direct item -> task table (else: binary search)
+constexpr int INLINE_PAIRS = 1024; // fragment pairs per neighbour that the table block prices itself (k_tm)
 
-struct NbTables {        // everything the scan / mass kernels need about one neighbour
+struct NbTables {        // everything the finishing kernel needs about one neighbour
     PieceKey key;
     int fB;
     int lo[NP], hi[NP], contig[NP];  // old pos range / contig label of every piece (hi < lo: empty)
@@ -447,9 +450,43 @@ struct NbTables {        // everything the scan / mass kernels need about one ne
 
 struct Neigh { int fB[MAXK]; };
 
-// one 256-thread block builds everything about one neighbour
-__device__ void tables_block(const SoaPtr& s, int fA, int fB, int max_id, const int* __restrict__ contig_off, NbTables& T,
-                             int k, int* __restrict__ step_hdr)
+// exclusive prefix sum of vals[0..n) into out[0..n) and the total into out[n]; vals / out in LDS, whole block calls it
+__device__ void block_excl_scan(const int* vals, int* out, int n)
+{
+    __shared__ int s_wtot[16];
+    __shared__ int s_carry;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, nw = blockDim.x >> 6;
+    if (t == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += blockDim.x) {
+        const int i = base + t;
+        const int v = i < n ? vals[i] : 0;
+        int x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+        if (lane == 63) s_wtot[w] = x;
+        __syncthreads();
+        int off = s_carry;
+        for (int j = 0; j < w; j++) off += s_wtot[j];
+        if (i < n) out[i] = off + x - v;
+        __syncthreads();
+        if (t == 0) { int tot = 0; for (int j = 0; j < nw; j++) tot += s_wtot[j]; s_carry += tot; }
+        __syncthreads();
+    }
+    if (t == 0) out[n] = s_carry;
+    __syncthreads();
+}
+
+__device__ __forceinline__ void pair_of_index(int idx, int& p, int& q)
+{
+    p = 1; q = 1;
+    for (p = 1; p <= MAX_PIECES; p++) { const int row = MAX_PIECES - p + 1; if (idx < row) { q = p + idx; break; } idx -= row; }
+}
+
+// one block builds everything about one neighbour; tasks are left in s_task (LDS) too, with the exclusive prefix of
+// their fragment-pair counts in s_pp.  Returns the number of tasks.
+__device__ int tables_block(const SoaPtr& s, int fA, int fB, int max_id, const int* __restrict__ contig_off, NbTables& T,
+                            int k, int* __restrict__ step_hdr, Task* s_task, int* s_pp)
 {
     __shared__ Rec A0, B0;
     __shared__ int rep[NP];
@@ -460,17 +497,16 @@ __device__ void tables_block(const SoaPtr& s, int fA, int fB, int max_id, const 
     __shared__ unsigned intra_any;
     // dedupe table: entries 0..20 = old relation of (p<=q); then 13*21 new relations
     constexpr int NPAIR = 21, NENT = NPAIR * (N_OPS + 1);
-    __shared__ int e_valid[NENT], e_owner[NENT], e_slot[NENT];
+    __shared__ int e_valid[NENT], e_owner[NENT], e_slot[NENT], e_flag[NENT];
     __shared__ unsigned e_plus[NENT], e_minus[NENT];
-    __shared__ int n_tasks;
-    __shared__ int s_lo[NP], s_hi[NP], s_contig[NP], s_chunks[NENT], s_start[NENT + 1];
+    __shared__ int s_lo[NP], s_hi[NP], s_contig[NP], s_cbase[NP], s_chunks[NENT], s_start[NENT + 1], s_pairs[NENT];
     const int t = threadIdx.x;
     if (t == 0) {
         A0 = ld_rec(s, fA); B0 = ld_rec(s, fB);
         PieceKey key; key.cA = A0.id_c; key.a = A0.pos; key.cB = B0.id_c; key.b = B0.pos;
         T.key = key; T.fB = fB;
         piece_representatives(key, fA, fB, A0, B0, rep);
-        intra_any = 0; n_tasks = 0;
+        intra_any = 0;
         for (int p = 0; p < NP; p++) { s_lo[p] = 0; s_hi[p] = -1; s_contig[p] = -1; }
         if (fA != fB) {
             if (key.cA != key.cB) {
@@ -492,6 +528,7 @@ __device__ void tables_block(const SoaPtr& s, int fA, int fB, int max_id, const 
     if (t < NP) {
         if (rep[t] >= 0) { rep_old[t] = ld_rec(s, rep[t]); xf_old[t] = xf_identity(rep_old[t]); }
         else { Xf x; x.label = -1 - t; x.sigma = 1; x.off = 0; x.circ = 0; x.lbp = 0; xf_old[t] = x; }
+        s_cbase[t] = s_contig[t] >= 0 ? contig_off[s_contig[t]] : 0;
     }
     __syncthreads();
     // transforms: one thread per (op, piece)
@@ -511,8 +548,8 @@ __device__ void tables_block(const SoaPtr& s, int fA, int fB, int max_id, const 
     // relations: one thread per (op, p <= q)
     for (int e = t; e < N_OPS * NPAIR; e += blockDim.x) {
         const int op = e / NPAIR;
-        int idx = e % NPAIR, p = 1, q = 1;
-        for (p = 1; p <= MAX_PIECES; p++) { const int row = MAX_PIECES - p + 1; if (idx < row) { q = p + idx; break; } idx -= row; }
+        int p, q;
+        pair_of_index(e % NPAIR, p, q);
         if (rep[p] < 0 || rep[q] < 0) continue;
         const bool chg = (p == q) ? intra_changed(xf_old[p], xf[op][p]) : rel_changed(xf_old[p], xf_old[q], xf[op][p], xf[op][q]);
         if (!chg) continue;
@@ -528,8 +565,8 @@ __device__ void tables_block(const SoaPtr& s, int fA, int fB, int max_id, const 
     for (int e = NPAIR + t; e < NENT; e += blockDim.x) {
         if (!e_valid[e]) continue;
         const int ee = e - NPAIR, op = ee / NPAIR, pair = ee % NPAIR;
-        int idx = pair, p = 1, q = 1;
-        for (p = 1; p <= MAX_PIECES; p++) { const int row = MAX_PIECES - p + 1; if (idx < row) { q = p + idx; break; } idx -= row; }
+        int p, q;
+        pair_of_index(pair, p, q);
         const Xf xp = xf[op][p], xq = xf[op][q];
         int owner = e;
         // same pair in the old layout?
@@ -549,36 +586,23 @@ __device__ void tables_block(const SoaPtr& s, int fA, int fB, int max_id, const 
     for (int e = NPAIR + t; e < NENT; e += blockDim.x)
         if (e_valid[e] && e_owner[e] != e) { atomicOr(&e_plus[e_owner[e]], e_plus[e]); }
     __syncthreads();
-    // slots of the surviving (owner) entries, in entry order: ballot prefix over two rounds of 256 entries
-    {
-        __shared__ int wave_tot[8];
-        int carry = 0;
-        for (int round = 0; round * (int)blockDim.x < NENT; round++) {
-            const int e = round * blockDim.x + t;
-            const bool flag = e < NENT && e_valid[e] && e_owner[e] == e;
-            const unsigned long long bal = __ballot(flag);
-            const int w = t >> 6, lane = t & 63;
-            if (lane == 0) wave_tot[w] = __popcll(bal);
-            __syncthreads();
-            int base = carry;
-            for (int i = 0; i < w; i++) base += wave_tot[i];
-            if (flag) e_slot[e] = base + __popcll(bal & ((1ull << lane) - 1ull));
-            for (int i = 0; i < (int)(blockDim.x >> 6); i++) carry += wave_tot[i];
-            __syncthreads();
-        }
-        if (t == 0) {
-            n_tasks = carry;
-            T.n_tasks = carry;
-            T.intra_any = intra_any;
-            for (int op = 0; op < N_OPS; op++) T.changed[op] = changed[op];
-        }
-    }
+    // slots of the surviving (owner) entries, in entry order
+    for (int e = t; e < NENT; e += blockDim.x) e_flag[e] = (e_valid[e] && e_owner[e] == e) ? 1 : 0;
     __syncthreads();
+    block_excl_scan(e_flag, s_start, NENT); // s_start used as scratch: slot of entry e
+    const int n_tasks = s_start[NENT];
+    for (int e = t; e < NENT; e += blockDim.x) if (e_flag[e]) e_slot[e] = s_start[e];
+    __syncthreads();
+    if (t == 0) {
+        T.n_tasks = n_tasks;
+        T.intra_any = intra_any;
+        for (int op = 0; op < N_OPS; op++) T.changed[op] = changed[op];
+    }
     for (int e = t; e < NENT; e += blockDim.x) {
         if (e_slot[e] < 0) continue;
         const int pair = (e < NPAIR) ? e : (e - NPAIR) % NPAIR;
-        int idx = pair, p = 1, q = 1;
-        for (p = 1; p <= MAX_PIECES; p++) { const int row = MAX_PIECES - p + 1; if (idx < row) { q = p + idx; break; } idx -= row; }
+        int p, q;
+        pair_of_index(pair, p, q);
         Task tk; tk.p = p; tk.q = q;
         if (e < NPAIR) { tk.xp = xf_old[p]; tk.xq = xf_old[q]; }
         else { const int op = (e - NPAIR) / NPAIR; tk.xp = xf[op][p]; tk.xq = xf[op][q]; }
@@ -588,101 +612,126 @@ __device__ void tables_block(const SoaPtr& s, int fA, int fB, int max_id, const 
         }
         tk.plus = e_plus[e]; tk.minus = e_minus[e];
         tk.np = s_hi[tk.p] - s_lo[tk.p] + 1; tk.nq = s_hi[tk.q] - s_lo[tk.q] + 1;
-        tk.base_p = contig_off[s_contig[tk.p]] + s_lo[tk.p];
-        tk.base_q = contig_off[s_contig[tk.q]] + s_lo[tk.q];
-        T.task[e_slot[e]] = tk;
-        s_chunks[e_slot[e]] = (tk.np + 63) / 64;
+        tk.base_p = s_cbase[tk.p] + s_lo[tk.p];
+        tk.base_q = s_cbase[tk.q] + s_lo[tk.q];
+        const int slot = e_slot[e];
+        s_task[slot] = tk;
+        T.task[slot] = tk;
+        s_chunks[slot] = (tk.np + 63) / 64;
+        const long long pr = (long long)tk.np * (long long)(tk.p == tk.q ? tk.np : tk.nq);
+        s_pairs[slot] = pr > (1 << 20) ? (1 << 20) : (int)pr; // saturated: only compared with INLINE_PAIRS
     }
     __syncthreads();
-    if (t == 0) { // work list: chunks of 64 fragments of the task's first piece, tasks in slot order (fixed order)
-        int acc = 0;
-        for (int i = 0; i < n_tasks; i++) { s_start[i] = acc; acc += s_chunks[i]; }
-        s_start[n_tasks] = acc;
-        T.n_items = acc;
-    }
-    __syncthreads();
+    // work list: chunks of 64 fragments of the task's first piece, tasks in slot order (fixed order)
+    block_excl_scan(s_chunks, s_start, n_tasks);
+    block_excl_scan(s_pairs, s_pp, n_tasks);
+    const int n_items = s_start[n_tasks];
+    if (t == 0) { T.n_items = n_items; step_hdr[k] = n_items; }
     for (int i = t; i <= n_tasks; i += blockDim.x) T.item_start[i] = s_start[i];
-    if (s_start[n_tasks] <= ITEM_CAP)
+    if (n_items <= ITEM_CAP)
         for (int i = t; i < n_tasks; i += blockDim.x)
             for (int w = s_start[i]; w < s_start[i + 1]; w++) T.item_tc[w] = (unsigned)i | ((unsigned)(w - s_start[i]) << 16);
-    if (t == 0) { step_hdr[k] = s_start[n_tasks]; step_hdr[MAXK + k] = (int)intra_any; } // one cache line for k_scan / k_post
+    return n_tasks;
 }
 
 // Everything the per-step kernels need that does not change from step to step lives in ONE device-resident block
 // (one per layout buffer).  Kernel arguments are fetched by serialised scalar loads from the uncached kernarg
 // segment (~1 us each); with 20+ arguments that prologue cost more than the kernels' work.  Now each kernel
 // takes this pointer plus a handful of per-step scalars.
-struct QEntry;
+struct QEntry { unsigned idx; unsigned rel; }; // contact index in this shard, nibble mask of the neighbours it matters to
 struct DevArgs {
     SoaPtr soa;
     long long nnz;
     int n, n_sub_total, bitmap_words, reach_bp;
-    int rows_sorted; // contact list sorted by row id: enables the wave-uniform range test of k_scan
     const int *row, *col, *cnt, *sub2bin, *sub2bin_multi /* nullptr when every bin has one sub-fragment */, *sub_ids;
     const int *contig_off, *perm;
     const Geo* geo;
     const Stat* stat;
-    unsigned *codes, *bitmap;
     NbTables* tabs;
-    int* step_hdr;
+    int* step_hdr;                // [k] mass work items of neighbour k, [MAXK + k] 1 = k_tm priced them already
+    long long* tm_done;           // [k] sequence number of the step whose tables of neighbour k are complete
     QEntry* queue;
-    unsigned long long* counters; // n_rel, n_items, queue count
+    long long* acc;               // K*13 running sums of the step (zeroed again by k_fin once it has read them)
+    unsigned long long* counters; // [0] n_rel [1] n_items [2] queue count [5] ticket [6] error; [8..10] copy of [0..2] of the last step
     float nfpb;
     Par par;
 };
 
-// ------------------------------------------------------------------ per-step kernels
-// k_prep: blocks [0, K) build the neighbour tables; the other blocks write the per-fragment relevance code
-// (4 bits per neighbour = piece id, 0 = not in contig(fA) u contig(fB_k)) and zero the step's accumulators.
-// It also writes the "affected" bitmap: bit i set iff contact-list id i (= fragment id when every bin has one
-// sub-fragment) belongs to a fragment with a non-zero code.  bitmap_by_sub != nullptr: bins own up to 3 arbitrary
-// sub-fragment ids, bits are OR-ed into a bitmap the host zeroed beforehand.
-__global__ __launch_bounds__(256) void k_prep(const DevArgs* __restrict__ A, int fA, Neigh nb, int K, int max_id,
-                                               long long* __restrict__ d_q_out)
+// windowed mass of one fragment pair in some layout, rounded to Q ONCE per pair: the partition of the work over lanes,
+// kernels and ranks is then irrelevant to the sum
+__device__ __forceinline__ long long pair_mass_q(const End& X, const Stat& sx, const End& Y, const Stat& sy, float nfpb,
+                                                 const Par& par)
 {
-    const SoaPtr s = A->soa;
-    const int n = A->n;
-    NbTables* __restrict__ tabs = A->tabs;
-    unsigned* __restrict__ codes = A->codes;
-    unsigned* __restrict__ bitmap = A->bitmap;
-    const int* __restrict__ sub_ids = A->sub_ids;
-    const int* __restrict__ contig_off = A->contig_off;
-    int* __restrict__ step_hdr = A->step_hdr;
-    long long* __restrict__ counters = (long long*)A->counters;
-    if ((int)blockIdx.x < K) { tables_block(s, fA, nb.fB[blockIdx.x], max_id, contig_off, tabs[blockIdx.x], blockIdx.x, step_hdr); return; }
-    const int b = blockIdx.x - K;
-    if (b == 0) {
-        for (int i = threadIdx.x; i < K * N_OPS; i += blockDim.x) d_q_out[i] = 0;
-        if (threadIdx.x < 3) counters[threadIdx.x] = 0;
-        if (threadIdx.x == 5) counters[5] = 0; // k_post completion ticket
-    }
-    const int f = b * blockDim.x + threadIdx.x;
-    unsigned code = 0;
-    if (f < n) {
-        const int cA = s.p[F_IDC][fA], a = s.p[F_POS][fA];
-        const int c = s.p[F_IDC][f], pos = s.p[F_POS][f];
-        for (int k = 0; k < K; k++) {
-            const int fB = nb.fB[k];
-            PieceKey key; key.cA = cA; key.a = a; key.cB = s.p[F_IDC][fB]; key.b = s.p[F_POS][fB];
-            const int p = (fB == fA) ? 0 : piece_of(key, c, pos);
-            code |= (unsigned)p << (4 * k);
-        }
-        codes[f] = code;
-    }
-    if (sub_ids == nullptr) { // fragment id == contact-list id: one 64-bit ballot per wave, no atomics, no zeroing
-        const unsigned long long bal = __ballot(code != 0);
-        if ((threadIdx.x & 63) == 0) {
-            const int w = (b * blockDim.x + threadIdx.x) >> 5; // first 32-bit word of this wave's 64 fragments
-            bitmap[w] = (unsigned)bal;
-            bitmap[w + 1] = (unsigned)(bal >> 32);
-        }
-    } else if (f < n && code != 0) {
-        const int ns = sub_ids[4 * f + 3];
-        for (int j = 0; j < ns; j++) { const int sid = sub_ids[4 * f + j]; atomicOr(&bitmap[sid >> 5], 1u << (sid & 31)); }
-    }
+    double acc = 0.0;
+    for (int a = 0; a < sx.n; a++)
+        for (int b = 0; b < sy.n; b++)
+            acc += (double)ex_pair(X, sx, a, Y, sy, b, nfpb, par) - (double)ex_trans(stat_accu(sx, a), stat_accu(sy, b), nfpb, par);
+    return to_q(acc);
 }
 
-struct QEntry { unsigned idx; unsigned rel; };
+__device__ __forceinline__ int gap_bp(const End& X, int len_x, const End& Y, int len_y)
+{
+    return X.start_bp < Y.start_bp ? Y.start_bp - (X.start_bp + len_x) : X.start_bp - (Y.start_bp + len_y);
+}
+
+// ------------------------------------------------------------------ per-step kernels
+// k_tm (K blocks, launched on the auxiliary stream so that it overlaps k_scan): block k builds the tables of neighbour k
+// and, when the expected-mass work of that neighbour is small (<= INLINE_PAIRS fragment pairs: the regime of short
+// contigs), prices it on the spot -- one thread per fragment pair -- instead of leaving it to k_fin.
+__global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, int fA, Neigh nb, int K, int max_id, int rank,
+                                             int world, long long seq)
+{
+    __shared__ Task s_task[MAX_TASKS];
+    __shared__ int s_pp[MAX_TASKS + 1];
+    const int k = blockIdx.x, t = threadIdx.x;
+    if (k >= K) return;
+    NbTables& T = A->tabs[k];
+    const int n_tasks = tables_block(A->soa, fA, nb.fB[k], max_id, A->contig_off, T, k, A->step_hdr, s_task, s_pp);
+    const int total = s_pp[n_tasks];
+    const bool inl = total <= INLINE_PAIRS;
+    if (inl && total > 0) {
+        const int* __restrict__ perm = A->perm;
+        const Geo* __restrict__ geo = A->geo;
+        const Stat* __restrict__ stat = A->stat;
+        const float nfpb = A->nfpb;
+        const Par par = A->par;
+        const int reach_bp = A->reach_bp;
+        long long acc[N_OPS];
+#pragma unroll
+        for (int op = 0; op < N_OPS; op++) acc[op] = 0;
+        for (int i = rank + world * t; i < total; i += world * (int)blockDim.x) {
+            int lo_t = 0, hi_t = n_tasks - 1; // last task with s_pp <= i
+            while (lo_t < hi_t) { const int mid = (lo_t + hi_t + 1) >> 1; if (s_pp[mid] <= i) lo_t = mid; else hi_t = mid - 1; }
+            const Task& tk = s_task[lo_t];
+            const bool same = tk.p == tk.q;
+            const int li = i - s_pp[lo_t], width = same ? tk.np : tk.nq;
+            const int ix = li / width, iy = li - ix * width;
+            if (same && iy <= ix) continue;
+            const int fx = perm[tk.base_p + ix], fy = perm[(same ? tk.base_p : tk.base_q) + iy];
+            const Geo gx = geo[fx], gy = geo[fy];
+            const End X = end_xf(gx, tk.xp), Y = end_xf(gy, same ? tk.xp : tk.xq);
+            if (gap_bp(X, gx.len_bp, Y, gy.len_bp) > reach_bp) continue;
+            const long long qv = pair_mass_q(X, stat[fx], Y, stat[fy], nfpb, par);
+            if (qv == 0) continue;
+            // logL = contacts - mass: the NEW layout's mass counts negative, the OLD one positive
+#pragma unroll
+            for (int op = 0; op < N_OPS; op++)
+                acc[op] += ((long long)((tk.minus >> op) & 1u) - (long long)((tk.plus >> op) & 1u)) * qv;
+        }
+#pragma unroll
+        for (int op = 0; op < N_OPS; op++) {
+            const long long v = wave_sum_ll(acc[op]);
+            if ((t & 63) == 0 && v != 0) atomicAdd((unsigned long long*)&A->acc[k * N_OPS + op], (unsigned long long)v);
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
+        if (inl && rank == 0) atomicAdd(&A->counters[1], (unsigned long long)A->step_hdr[k]);
+        A->step_hdr[MAXK + k] = inl ? 1 : 0;
+        __threadfence();
+        atomicExch((unsigned long long*)&A->tm_done[k], (unsigned long long)seq); // release: tables of neighbour k are complete
+    }
+}
 
 // 16-byte streaming (nontemporal) load
 __device__ __forceinline__ int4 ld_stream(const int4* p)
@@ -690,59 +739,139 @@ __device__ __forceinline__ int4 ld_stream(const int4* p)
     typedef int v4i __attribute__((ext_vector_type(4)));
     const v4i v = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(p));
     return make_int4(v.x, v.y, v.z, v.w);
-} // contact index in this shard, nibble mask of the neighbours it matters to
+}
+
+struct StepKeys {
+    PieceKey key[MAXK];
+    unsigned live;   // bit k: neighbour k is a real pair (fB != fA)
+    unsigned intra;  // bit 4k: some candidate of neighbour k may change the geometry INSIDE a piece (circular model)
+};
+
+// relevance code of a fragment: 4 bits per neighbour = piece id, 0 = not in contig(fA) u contig(fB_k)
+__device__ __forceinline__ unsigned code_of(const StepKeys& S, int K, int id_c, int pos)
+{
+    unsigned code = 0;
+    for (int k = 0; k < K; k++)
+        if ((S.live >> k) & 1u) code |= (unsigned)piece_of(S.key[k], id_c, pos) << (4 * k);
+    return code;
+}
+
+// can one of the 13 candidates of (fA, fB) change the circular model of a contig?  Contigs that are circular now can be
+// linearised / change length; a new circle only comes out of paste_contigs (ops 9-12) when, after the two splits, fA and
+// fB are the two ends of one contig (kernels3.cu:1960-1976)
+__device__ bool circ_may_change(int fA, int fB, int max_id, const Rec& A0, const Rec& B0)
+{
+    if (A0.circ == 1 || B0.circ == 1) return true;
+    if (A0.id_c != B0.id_c) return false;
+    for (int op = 9; op < N_OPS; op++) {
+        const Move m = make_move(op, fA, fB, max_id, A0, B0);
+        if (m.A2.id_c != m.B2.id_c) continue;
+        const int last = m.A2.l_cont - 1;
+        if ((m.A2.pos == 0 && m.B2.pos == last) || (m.A2.pos == last && m.B2.pos == 0)) return true;
+    }
+    return false;
+}
 
 // k_scan: ONE streaming pass over this rank's contact list for all 13*K candidates of the step.
 // A contact matters to neighbour k iff its two ends lie in DIFFERENT pieces of k (or in one piece whose circular model
-// changes).  Three-level test, cheapest first:
-//   1. row id in the "affected" bitmap (1 bit per id, staged in LDS: 6 KB for 50k fragments)?  The list is sorted by
-//      row, so whole waves fail this test together and never load their `col` words;
+// may change).  Every block first marks the "affected" ids -- the fragments of contig(fA) and of the contigs of the
+// neighbours -- in a 1-bit-per-id LDS bitmap (6 KB for 50k fragments) straight from the position index, so the pass
+// needs no preparation kernel.  Then, cheapest test first:
+//   1. row id in the bitmap?  The list is sorted by row, so whole waves fail this test together and never load their
+//      `col` words;
 //   2. col id in the bitmap?
-//   3. the 4-byte relevance codes of both fragments (global, L2 resident) -> nibble mask of neighbours.
-// Survivors are appended to a queue (wave-aggregated atomics) for k_post.  Counts are not read here at all.
-template <bool SINGLE_SUB, bool LDS_BITMAP>
-__global__ __launch_bounds__(1024) void k_scan(const DevArgs* __restrict__ A, int K, int dry /* timing replays: count, do not queue */)
+//   3. piece ids of both fragments (8-byte gathers of the geometry records) -> nibble mask of neighbours.
+// Survivors are appended to a queue (wave-aggregated atomics) for k_fin.  Counts are not read here at all.
+template <bool SINGLE_SUB>
+__global__ __launch_bounds__(1024) void k_scan(const DevArgs* __restrict__ A, int fA, Neigh nb, int K, int max_id,
+                                                int dry /* timing replays: count, do not queue */)
 {
     const int* __restrict__ row = A->row;
     const int* __restrict__ col = A->col;
     const long long nnz = A->nnz;
     const int* __restrict__ sub2bin = A->sub2bin;
-    const unsigned* __restrict__ codes = A->codes;
-    const unsigned* __restrict__ bitmap = A->bitmap;
-    const int bitmap_words = A->bitmap_words;
+    const int2* __restrict__ geo2 = reinterpret_cast<const int2*>(A->geo); // (id_c, flags) = first half of a Geo record
     QEntry* __restrict__ queue = A->queue;
     unsigned long long* __restrict__ counters = A->counters;
     extern __shared__ unsigned s_bm[];
-    if (LDS_BITMAP) {
-        for (int i = threadIdx.x; i < bitmap_words; i += blockDim.x) s_bm[i] = bitmap[i];
-        __syncthreads();
-    }
-    const unsigned* bm = LDS_BITMAP ? s_bm : bitmap;
-    unsigned long long intra = 0; // bit 8k + p: piece p of neighbour k changes internally under some candidate
-#pragma unroll
-    for (int k = 0; k < MAXK; k++) intra |= (k < K) ? ((unsigned long long)(A->step_hdr[MAXK + k] & 0xff) << (8 * k)) : 0ull;
+    __shared__ StepKeys S;
+    __shared__ Rec s_rec[MAXK + 1];
+    __shared__ int s_cbase[MAXK + 1], s_clen[MAXK + 1], s_pref[MAXK + 2];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
     const long long n4 = nnz >> 2;
     const int tail = (int)(nnz - (n4 << 2));
     const int4* __restrict__ row4 = reinterpret_cast<const int4*>(row);
     const int4* __restrict__ col4 = reinterpret_cast<const int4*>(col);
     const long long stride = (long long)gridDim.x * blockDim.x;
-    const int lane = threadIdx.x & 63;
+    long long g0 = (long long)blockIdx.x * blockDim.x + t;
+    // the first row words are requested before the bitmap is built: HBM latency overlaps the prologue
+    int4 ra = make_int4(0, 0, 0, 0), rb = make_int4(0, 0, 0, 0);
+    if (g0 <= n4) ra = ld_stream(row4 + g0);
+    if (g0 + stride <= n4) rb = ld_stream(row4 + g0 + stride);
+    // ---- prologue: keys of the K neighbours and the affected bitmap --------------------------------------------
+    const int bitmap_words = A->bitmap_words;
+    if (t <= K) s_rec[t] = ld_rec(A->soa, t == 0 ? fA : nb.fB[t - 1]);
+    if (t == 0) { S.live = 0; S.intra = 0; }
+    for (int i = t; i < bitmap_words; i += blockDim.x) s_bm[i] = 0;
+    __syncthreads();
+    if (t < K) {
+        const Rec& A0 = s_rec[0];
+        const Rec& B0 = s_rec[t + 1];
+        const int fB = nb.fB[t];
+        PieceKey key; key.cA = A0.id_c; key.a = A0.pos; key.cB = B0.id_c; key.b = B0.pos;
+        S.key[t] = key;
+        bool dup = (fB == fA) || (B0.id_c == A0.id_c);
+        if (fB != fA) {
+            atomicOr(&S.live, 1u << t);
+            if (circ_may_change(fA, fB, max_id, A0, B0)) atomicOr(&S.intra, 1u << (4 * t));
+            for (int j = 0; j < t; j++) if (nb.fB[j] != fA && s_rec[j + 1].id_c == B0.id_c) dup = true;
+        }
+        s_clen[t + 1] = dup ? 0 : B0.l_cont;
+        s_cbase[t + 1] = dup ? 0 : A->contig_off[B0.id_c];
+    } else if (t == (int)blockDim.x - 1) { // another wave: the two index loads go out together
+        s_clen[0] = s_rec[0].l_cont;
+        s_cbase[0] = A->contig_off[s_rec[0].id_c];
+    }
+    __syncthreads();
+    if (t == 0) { int acc = 0; for (int j = 0; j <= K; j++) { s_pref[j] = acc; acc += s_clen[j]; } s_pref[K + 1] = acc; }
+    __syncthreads();
+    {
+        const int total = s_pref[K + 1];
+        const int* __restrict__ perm = A->perm;
+        const int* __restrict__ sub_ids = A->sub_ids;
+        for (int e = t; e < total; e += blockDim.x) {
+            int j = 0;
+            while (j < K && e >= s_pref[j + 1]) j++;
+            const int f = perm[s_cbase[j] + (e - s_pref[j])];
+            if (SINGLE_SUB) atomicOr(&s_bm[f >> 5], 1u << (f & 31));
+            else {
+                const int4 ids = reinterpret_cast<const int4*>(sub_ids)[f];
+                atomicOr(&s_bm[ids.x >> 5], 1u << (ids.x & 31));
+                if (ids.w > 1) atomicOr(&s_bm[ids.y >> 5], 1u << (ids.y & 31));
+                if (ids.w > 2) atomicOr(&s_bm[ids.z >> 5], 1u << (ids.z & 31));
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned intra = S.intra;
     unsigned long long n_rel = 0;
-    for (long long g0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; g0 <= n4; g0 += 2 * stride) {
+    for (; g0 <= n4; g0 += 2 * stride) {
         // two groups of 4 contacts per iteration (the arrays are padded: the tail group stays in bounds)
         const long long g1 = g0 + stride;
         const bool has1 = g1 <= n4;
-        // nontemporal: the stream must not evict the tables (and the other kernels' code) from L2
-        const int4 ra = ld_stream(row4 + g0);
-        int4 rb = make_int4(0, 0, 0, 0);
-        if (has1) rb = ld_stream(row4 + g1);
         const int r[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
         const int va = g0 < n4 ? 4 : tail, vb = has1 ? (g1 < n4 ? 4 : tail) : 0;
+        // next iteration's row words (nontemporal: the stream must not evict the tables from L2)
+        const long long h0 = g0 + 2 * stride, h1 = h0 + stride;
+        if (h0 <= n4) ra = ld_stream(row4 + h0);
+        rb = make_int4(0, 0, 0, 0);
+        if (h1 <= n4) rb = ld_stream(row4 + h1);
         unsigned hit = 0; // bit j: contact j of this lane has an affected row
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const bool valid = j < 4 ? (j < va) : (j - 4 < vb);
-            if (valid && ((bm[r[j] >> 5] >> (r[j] & 31)) & 1u)) hit |= 1u << j;
+            if (valid && ((s_bm[r[j] >> 5] >> (r[j] & 31)) & 1u)) hit |= 1u << j;
         }
         if (__ballot(hit != 0) == 0) continue; // the common case: nobody in this wave needs its col words
         int c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -751,25 +880,20 @@ __global__ __launch_bounds__(1024) void k_scan(const DevArgs* __restrict__ A, in
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             unsigned rel = 0;
-            if (((hit >> j) & 1u) && ((bm[c[j] >> 5] >> (c[j] & 31)) & 1u)) {
+            if (((hit >> j) & 1u) && ((s_bm[c[j] >> 5] >> (c[j] & 31)) & 1u)) {
                 int fx, fy;
                 if (SINGLE_SUB) { fx = r[j]; fy = c[j]; }
                 else { fx = sub2bin[r[j]] >> 2; fy = sub2bin[c[j]] >> 2; }
-                const unsigned ci = codes[fx], cj = codes[fy];
+                const int2 gi = geo2[2 * fx], gj = geo2[2 * fy];
+                const unsigned ci = code_of(S, K, gi.x, geo_pos(gi.y)), cj = code_of(S, K, gj.x, geo_pos(gj.y));
                 const unsigned nzi = (ci | (ci >> 1) | (ci >> 2)) & 0x11111111u;
                 const unsigned nzj = (cj | (cj >> 1) | (cj >> 2)) & 0x11111111u;
                 const unsigned df = ci ^ cj;
                 const unsigned dnz = (df | (df >> 1) | (df >> 2)) & 0x11111111u;
                 const unsigned both = nzi & nzj;
-                rel = both & dnz;
-                if (intra != 0) { // same non-empty piece: relevant only if that piece changes internally
-                    unsigned same = both & ~dnz;
-                    while (same) {
-                        const int k = (__ffs((int)same) - 1) >> 2;
-                        same &= same - 1;
-                        if ((intra >> (8 * k + ((ci >> (4 * k)) & 7u))) & 1ull) rel |= 1u << (4 * k);
-                    }
-                }
+                // different pieces, or the same piece of a neighbour whose circular model may change (k_fin filters
+                // by the exact per-candidate relation masks)
+                rel = both & (dnz | intra);
                 if (!SINGLE_SUB && fx == fy) rel = 0; // a bin's own pixel is never revisited (kernels3.cu:3356-3380)
             }
             const unsigned long long bal = dry ? 0ull : __ballot(rel != 0);
@@ -799,14 +923,15 @@ __device__ __forceinline__ int sel_base(const int (&a)[MAXK + 1], int i)
     return v;
 }
 
-// k_post: (1) mass tasks -- work item = (neighbour, task, chunk of 64 fragments of the task's first piece), one wave per
-// item, lane = fragment x; (2) the queued contacts -- 16 lanes per contact, lane = candidate op.
-// Completion: the last block to finish (ticket counter) reads the K*13 sums with atomic loads and, if host_res is given,
-// publishes them to PINNED HOST memory followed by the step's sequence number; the host spins on that word instead of
-// paying for a device->host copy launch and a stream-synchronise wake-up.
-__global__ __launch_bounds__(256) void k_post(const DevArgs* __restrict__ A, int K, int rank, int world,
-                                               long long* __restrict__ out, volatile long long* host_res,
-                                               long long seq)
+// k_fin: (0) waits for k_tm's tables (normally long complete: k_tm was launched before k_scan); (1) the mass tasks k_tm
+// left over -- work item = (neighbour, task, chunk of 64 fragments of the task's first piece), one wave per item;
+// (2) the queued contacts -- 16 lanes per contact, lane = candidate op.
+// Completion: the last block to finish (ticket counter) reads the K*13 sums, zeroes the accumulators for the next step,
+// and hands the sums out: to d_q_out (device; the caller all-reduces them) or, if host_res is given, to PINNED HOST
+// memory followed by the step's sequence number -- the host spins on that word instead of paying for a device->host
+// copy launch and a stream-synchronise wake-up.
+__global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, int K, int rank, int world,
+                                              long long* __restrict__ d_q_out, volatile long long* host_res, long long seq)
 {
     const NbTables* __restrict__ tabs = A->tabs;
     const int* __restrict__ perm = A->perm;
@@ -817,131 +942,146 @@ __global__ __launch_bounds__(256) void k_post(const DevArgs* __restrict__ A, int
     const int* __restrict__ col = A->col;
     const int* __restrict__ cnt = A->cnt;
     const int* __restrict__ sub2bin = A->sub2bin_multi;
-    const unsigned* __restrict__ codes = A->codes;
     const QEntry* __restrict__ queue = A->queue;
     const int* __restrict__ step_hdr = A->step_hdr;
+    long long* __restrict__ out = A->acc;
     const float nfpb = A->nfpb;
     const Par par = A->par;
     const int reach_bp = A->reach_bp;
     unsigned long long* __restrict__ counters = A->counters;
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
-    unsigned long long items = 0;
-    int n_items_k[MAXK];
-#pragma unroll
-    for (int k = 0; k < MAXK; k++) n_items_k[k] = step_hdr[k]; // one cache line, independent loads
-    const unsigned long long nq_total = counters[2]; // written by k_scan, the previous kernel on the stream
-    // one flat, fixed-order list of work items over all neighbours: item W -> (neighbour k, local item w)
-    int item_base[MAXK + 1];
-    item_base[0] = 0;
-#pragma unroll
-    for (int k = 0; k < MAXK; k++) item_base[k + 1] = item_base[k] + (k < K ? n_items_k[k] : 0);
-    const int total_all = item_base[MAXK];
-    // static sharding of the item list over ranks; every wave reaches the loop exit
-    for (int W = wave * world + rank; W < total_all; W += n_waves * world) {
-        int k = 0;
-#pragma unroll
-        for (int j = 1; j < MAXK; j++) k += (W >= item_base[j]) ? 1 : 0;
-        const int w = W - sel_base(item_base, k);
-        const NbTables& T = tabs[k];
-        const int total = sel_base(item_base, k + 1) - sel_base(item_base, k);
-        int ti, chunk;
-        if (total <= ITEM_CAP) { const unsigned tc = T.item_tc[w]; ti = (int)(tc & 0xffffu); chunk = (int)(tc >> 16); }
-        else { // task of item w: last task with item_start <= w
-            int lo_t = 0, hi_t = T.n_tasks - 1;
-            while (lo_t < hi_t) { const int mid = (lo_t + hi_t + 1) >> 1; if (T.item_start[mid] <= w) lo_t = mid; else hi_t = mid - 1; }
-            ti = lo_t; chunk = w - T.item_start[ti];
+    // ---- wait for the tables (bounded spin: every wave reaches the exit even if k_tm never ran) ----
+    __shared__ int s_ok;
+    if (threadIdx.x == 0) s_ok = 1;
+    __syncthreads();
+    if ((int)threadIdx.x < K) {
+        bool ok = false;
+        for (int spin = 0; spin < (1 << 22); spin++) {
+            if ((long long)atomicAdd((unsigned long long*)&A->tm_done[threadIdx.x], 0ull) == seq) { ok = true; break; }
+            __builtin_amdgcn_s_sleep(2);
         }
-        const Task tk = T.task[ti];
-        const int np = tk.np, nq = tk.nq, base_p = tk.base_p, base_q = tk.base_q;
-        items++;
-        // lanes: 16 fragments x of the chunk (4 passes cover its 64) times 4 interleaved phases of the y walk
-        const int xi = lane & 15, yph = lane >> 4;
-        double acc = 0.0;
-        for (int pass = 0; pass < 4; pass++) {
-            const int ix = chunk * 64 + pass * 16 + xi;
-            if (ix >= np) continue;
-            const int fx = perm[base_p + ix];
-            const Geo gx = geo[fx];
-            const Stat sx = stat[fx];
-            const End X = end_xf(gx, tk.xp);
-            if (tk.p == tk.q) {
-                // (x's own sub-fragment pairs are left out: candidates never revisit a bin's own pixel)
-                // later fragments of the same piece, walking away from x in the new layout
-                for (int iy = ix + 1 + yph; iy < np; iy += 4) {
-                    const int fy = perm[base_p + iy];
-                    const Geo gy = geo[fy];
-                    const End Y = end_xf(gy, tk.xp);
-                    const int gap = X.start_bp < Y.start_bp ? Y.start_bp - (X.start_bp + gx.len_bp) : X.start_bp - (Y.start_bp + gy.len_bp);
-                    if (gap > reach_bp) break;
-                    const Stat sy = stat[fy];
-                    for (int a = 0; a < sx.n; a++)
-                        for (int b = 0; b < sy.n; b++)
-                            acc += (double)ex_pair(X, sx, a, Y, sy, b, nfpb, par) - (double)ex_trans(stat_accu(sx, a), stat_accu(sy, b), nfpb, par);
-                }
-            } else {
-                // q's fragment nearest to x in this layout: pieces map to disjoint intervals, so the side is
-                // fixed by comparing x with q's first fragment
-                const int fq0 = perm[base_q];
-                const End Q0 = end_xf(geo[fq0], tk.xq);
-                const bool x_below = X.start_bp < Q0.start_bp;
-                const bool asc = (tk.xq.sigma > 0) == x_below; // walk q by increasing old position?
-                for (int st = yph; st < nq; st += 4) {
-                    const int iy = asc ? st : nq - 1 - st;
-                    const int fy = perm[base_q + iy];
-                    const Geo gy = geo[fy];
-                    const End Y = end_xf(gy, tk.xq);
-                    const int gap = x_below ? Y.start_bp - (X.start_bp + gx.len_bp) : X.start_bp - (Y.start_bp + gy.len_bp);
-                    if (gap > reach_bp) break;
-                    const Stat sy = stat[fy];
-                    for (int a = 0; a < sx.n; a++)
-                        for (int b = 0; b < sy.n; b++)
-                            acc += (double)ex_pair(X, sx, a, Y, sy, b, nfpb, par) - (double)ex_trans(stat_accu(sx, a), stat_accu(sy, b), nfpb, par);
-                }
-            }
-        }
-        // one Q rounding per (fragment pass, y phase) lane sum: the partition is fixed by the layout, not by the launch
-        const long long qv = wave_sum_ll(to_q(acc));
-        if (lane == 0 && qv != 0) {
-            // logL = contacts - mass: the NEW layout's mass counts negative, the OLD one positive
-            for (int op = 0; op < N_OPS; op++) {
-                const long long sgn = (long long)((tk.minus >> op) & 1u) - (long long)((tk.plus >> op) & 1u);
-                if (sgn != 0) atomicAdd((unsigned long long*)&out[k * N_OPS + op], (unsigned long long)(sgn * qv));
-            }
-        }
+        if (!ok) { s_ok = 0; atomicOr((unsigned long long*)&counters[6], 1ull); }
     }
-    if (lane == 0 && items) atomicAdd(&counters[1], items);
-    // ---- queued contacts: 4 per wave pass, lane & 15 = candidate op; taken from the far end of the grid so that they
-    // do not queue up behind the mass items of the low-numbered blocks ----
-    const int op = lane & 15;
-    for (unsigned long long e0 = (unsigned long long)(n_waves - 1 - wave) * 4; e0 < nq_total; e0 += (unsigned long long)n_waves * 4) {
-        const unsigned long long e = e0 + (lane >> 4);
-        if (e >= nq_total || op >= N_OPS) continue;
-        const QEntry qe = queue[e];
-        const int ra = row[qe.idx], ca = col[qe.idx];
-        int fx = ra, fy = ca, slx = 0, sly = 0;
-        if (sub2bin) { const int a = sub2bin[ra], b = sub2bin[ca]; fx = a >> 2; fy = b >> 2; slx = a & 3; sly = b & 3; }
-        const Geo gx = geo[fx], gy = geo[fy];
-        const Stat sx = stat[fx], sy = stat[fy];
-        const End X0 = end_cur(gx, lcontbp, fx), Y0 = end_cur(gy, lcontbp, fy);
-        const double ln_old = log((double)ex_pair(X0, sx, slx, Y0, sy, sly, nfpb, par));
-        const double ob = (double)cnt[qe.idx];
-        const unsigned ci = codes[fx], cj = codes[fy];
-        unsigned rel = qe.rel;
-        while (rel) {
-            const int k = (__ffs((int)rel) - 1) >> 2;
-            rel &= rel - 1;
-            const int p = (ci >> (4 * k)) & 7, q = (cj >> (4 * k)) & 7;
+    __syncthreads();
+    __threadfence();
+    if (s_ok) {
+        unsigned long long items = 0;
+        // one flat, fixed-order list of the work items this rank owns (local item w of a neighbour belongs to rank w % world),
+        // over the neighbours k_tm did not price itself
+        int item_base[MAXK + 1];
+        item_base[0] = 0;
+#pragma unroll
+        for (int k = 0; k < MAXK; k++) {
+            int own = 0;
+            if (k < K && step_hdr[MAXK + k] == 0) { const int ni = step_hdr[k]; own = ni > rank ? (ni - rank + world - 1) / world : 0; }
+            item_base[k + 1] = item_base[k] + own;
+        }
+        const int total_all = item_base[MAXK];
+        const unsigned long long nq_total = counters[2]; // written by k_scan, the previous kernel on the stream
+        for (int W = wave; W < total_all; W += n_waves) {
+            int k = 0;
+#pragma unroll
+            for (int j = 1; j < MAXK; j++) k += (W >= item_base[j]) ? 1 : 0;
+            const int w = rank + world * (W - sel_base(item_base, k));
             const NbTables& T = tabs[k];
-            if (!((T.changed[op] >> (p * 8 + q)) & 1ull)) continue;
-            const End X = end_xf(gx, T.xf[op][p]), Y = end_xf(gy, T.xf[op][q]);
-            const double ln_new = log((double)ex_pair(X, sx, slx, Y, sy, sly, nfpb, par));
-            const long long qv = to_q(ob * (ln_new - ln_old));
-            if (qv != 0) atomicAdd((unsigned long long*)&out[k * N_OPS + op], (unsigned long long)qv);
+            int ti, chunk;
+            if (T.n_items <= ITEM_CAP) { const unsigned tc = T.item_tc[w]; ti = (int)(tc & 0xffffu); chunk = (int)(tc >> 16); }
+            else { // task of item w: last task with item_start <= w
+                int lo_t = 0, hi_t = T.n_tasks - 1;
+                while (lo_t < hi_t) { const int mid = (lo_t + hi_t + 1) >> 1; if (T.item_start[mid] <= w) lo_t = mid; else hi_t = mid - 1; }
+                ti = lo_t; chunk = w - T.item_start[ti];
+            }
+            const Task tk = T.task[ti];
+            const int np = tk.np, nq = tk.nq, base_p = tk.base_p, base_q = tk.base_q;
+            items++;
+            // lanes: 16 fragments x of the chunk (4 passes cover its 64) times 4 interleaved phases of the y walk
+            const int xi = lane & 15, yph = lane >> 4;
+            long long accq = 0;
+            for (int pass = 0; pass < 4; pass++) {
+                const int ix = chunk * 64 + pass * 16 + xi;
+                if (ix >= np) continue;
+                const int fx = perm[base_p + ix];
+                const Geo gx = geo[fx];
+                const Stat sx = stat[fx];
+                const End X = end_xf(gx, tk.xp);
+                if (tk.p == tk.q) {
+                    // (x's own sub-fragment pairs are left out: candidates never revisit a bin's own pixel)
+                    // later fragments of the same piece, walking away from x in the new layout
+                    for (int iy = ix + 1 + yph; iy < np; iy += 4) {
+                        const int fy = perm[base_p + iy];
+                        const Geo gy = geo[fy];
+                        const End Y = end_xf(gy, tk.xp);
+                        if (gap_bp(X, gx.len_bp, Y, gy.len_bp) > reach_bp) break;
+                        accq += pair_mass_q(X, sx, Y, stat[fy], nfpb, par);
+                    }
+                } else {
+                    // q's fragment nearest to x in this layout: pieces map to disjoint intervals, so the side is
+                    // fixed by comparing x with q's first fragment
+                    const int fq0 = perm[base_q];
+                    const End Q0 = end_xf(geo[fq0], tk.xq);
+                    const bool x_below = X.start_bp < Q0.start_bp;
+                    const bool asc = (tk.xq.sigma > 0) == x_below; // walk q by increasing old position?
+                    for (int st = yph; st < nq; st += 4) {
+                        const int iy = asc ? st : nq - 1 - st;
+                        const int fy = perm[base_q + iy];
+                        const Geo gy = geo[fy];
+                        const End Y = end_xf(gy, tk.xq);
+                        const int gap = x_below ? Y.start_bp - (X.start_bp + gx.len_bp) : X.start_bp - (Y.start_bp + gy.len_bp);
+                        if (gap > reach_bp) break;
+                        accq += pair_mass_q(X, sx, Y, stat[fy], nfpb, par);
+                    }
+                }
+            }
+            const long long qv = wave_sum_ll(accq);
+            if (lane == 0 && qv != 0) {
+                // logL = contacts - mass: the NEW layout's mass counts negative, the OLD one positive
+                for (int op = 0; op < N_OPS; op++) {
+                    const long long sgn = (long long)((tk.minus >> op) & 1u) - (long long)((tk.plus >> op) & 1u);
+                    if (sgn != 0) atomicAdd((unsigned long long*)&out[k * N_OPS + op], (unsigned long long)(sgn * qv));
+                }
+            }
+        }
+        if (lane == 0 && items) atomicAdd(&counters[1], items);
+        // ---- queued contacts: 4 per wave pass, lane & 15 = candidate op; taken from the far end of the grid so that they
+        // do not queue up behind the mass items of the low-numbered blocks ----
+        const int op = lane & 15;
+        for (unsigned long long e0 = (unsigned long long)(n_waves - 1 - wave) * 4; e0 < nq_total; e0 += (unsigned long long)n_waves * 4) {
+            const unsigned long long e = e0 + (lane >> 4);
+            if (e >= nq_total || op >= N_OPS) continue;
+            const QEntry qe = queue[e];
+            const int ra = row[qe.idx], ca = col[qe.idx];
+            int fx = ra, fy = ca, slx = 0, sly = 0;
+            if (sub2bin) { const int a = sub2bin[ra], b = sub2bin[ca]; fx = a >> 2; fy = b >> 2; slx = a & 3; sly = b & 3; }
+            const Geo gx = geo[fx], gy = geo[fy];
+            unsigned rel = qe.rel;
+            // candidates of this lane's op that change the relation of the two fragments
+            unsigned todo = 0;
+            while (rel) {
+                const int k = (__ffs((int)rel) - 1) >> 2;
+                rel &= rel - 1;
+                const NbTables& T = tabs[k];
+                const int p = piece_of(T.key, gx.id_c, geo_pos(gx.flags)), q = piece_of(T.key, gy.id_c, geo_pos(gy.flags));
+                if ((T.changed[op] >> (p * 8 + q)) & 1ull) todo |= 1u << k;
+            }
+            if (!todo) continue;
+            const Stat sx = stat[fx], sy = stat[fy];
+            const End X0 = end_cur(gx, lcontbp, fx), Y0 = end_cur(gy, lcontbp, fy);
+            const double ln_old = log((double)ex_pair(X0, sx, slx, Y0, sy, sly, nfpb, par));
+            const double ob = (double)cnt[qe.idx];
+            while (todo) {
+                const int k = __ffs((int)todo) - 1;
+                todo &= todo - 1;
+                const NbTables& T = tabs[k];
+                const int p = piece_of(T.key, gx.id_c, geo_pos(gx.flags)), q = piece_of(T.key, gy.id_c, geo_pos(gy.flags));
+                const End X = end_xf(gx, T.xf[op][p]), Y = end_xf(gy, T.xf[op][q]);
+                const double ln_new = log((double)ex_pair(X, sx, slx, Y, sy, sly, nfpb, par));
+                const long long qv = to_q(ob * (ln_new - ln_old));
+                if (qv != 0) atomicAdd((unsigned long long*)&out[k * N_OPS + op], (unsigned long long)qv);
+            }
         }
     }
-    if (host_res == nullptr) return;
-    // ---- completion ticket: every block releases its atomics, the last one publishes ----
+    // ---- completion ticket: every block releases its atomics, the last one hands the sums out ----
     __shared__ int s_last;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -952,11 +1092,16 @@ __global__ __launch_bounds__(256) void k_post(const DevArgs* __restrict__ A, int
     __syncthreads();
     if (!s_last) return;
     __threadfence();
-    for (int i = threadIdx.x; i < K * N_OPS; i += blockDim.x)
-        host_res[1 + i] = (long long)atomicAdd((unsigned long long*)&out[i], 0ull); // coherent read of the final sum
+    const bool failed = atomicAdd(&counters[6], 0ull) != 0ull;
+    for (int i = threadIdx.x; i < K * N_OPS; i += blockDim.x) {
+        const long long v = (long long)atomicExch((unsigned long long*)&out[i], 0ull); // read the final sum, reset for the next step
+        if (host_res) host_res[1 + i] = v; else d_q_out[i] = v;
+    }
+    if (threadIdx.x < 3) counters[8 + threadIdx.x] = atomicExch(&counters[threadIdx.x], 0ull);
+    if (threadIdx.x == 3) { counters[5] = 0; counters[6] = 0; }
     __threadfence_system();
     __syncthreads();
-    if (threadIdx.x == 0) { host_res[0] = seq; __threadfence_system(); }
+    if (threadIdx.x == 0 && host_res) { host_res[0] = failed ? -seq : seq; __threadfence_system(); }
 }
 
 // ------------------------------------------------------------------ host side
@@ -964,6 +1109,9 @@ struct Ctx {
     int device = 0;
     std::string err;
     hipStream_t stream = nullptr;
+    hipStream_t aux = nullptr;    // k_tm runs here, concurrently with k_scan on the main stream
+    hipEvent_t ev_fin = nullptr;  // end of the last asynchronous evaluation (orders the next k_tm after it)
+    bool fin_pending = false;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> ring; // pairs of events around k_scan, one pair per call (graal_scan_times)
     long long ring_calls = 0;
@@ -975,7 +1123,6 @@ struct Ctx {
     int n = 0, n_bins = 0, n_sub_total = 0;
     long long nnz = 0;
     bool single_sub = true;
-    bool rows_sorted = false;
     float nfpb = 1.0f;
     Par par{};
     bool have_par = false, have_sub = false, have_frags = false, have_contacts = false, order_valid = false;
@@ -992,10 +1139,10 @@ struct Ctx {
     Stat* stat = nullptr;
     int* sub2bin = nullptr;
     int *row = nullptr, *col = nullptr, *cnt = nullptr;
-    unsigned* codes = nullptr;
     QEntry* queue = nullptr;
-    unsigned* bitmap = nullptr;   // 1 bit per contact-list id (sub-fragment id)
-    int bitmap_words = 0;
+    int last_fA = 0, last_K = 0, last_max_id = 0; // proposal of the last evaluation (timing replays of the scan)
+    int last_fB[MAXK] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int max_lcont = 0;            // longest contig at the last graal_begin_step (sizes k_fin's grid)
     int* d_sub_ids = nullptr;     // [n_bins][4], only when some bin has more than one sub-fragment
     unsigned long long *keys = nullptr, *keys_sorted = nullptr;
     int *o2n = nullptr, *perm = nullptr;
@@ -1008,11 +1155,14 @@ struct Ctx {
     void* cub_tmp = nullptr;
     size_t cub_tmp_bytes = 0;
     NbTables* tabs = nullptr;
-    int* step_hdr = nullptr;      // [MAXK] mass work items per neighbour of the current step
+    int* step_hdr = nullptr;      // [MAXK] mass work items per neighbour of the current step, [MAXK..] priced by k_tm
+    long long* tm_done = nullptr; // [MAXK] sequence number of the step whose tables are complete
+    long long* d_acc = nullptr;   // K*13 running sums (self-cleaning: k_fin zeroes them after reading)
     DevArgs* d_args = nullptr;    // [2]: one argument block per layout buffer
     long long* h_res = nullptr;   // pinned host: [0] sequence number of the published step, [1..] K*13 sums
     long long seq = 0;
-    long long* d_scalars = nullptr; // [0..7] stats, [8..9] full q, [10] n_relevant, [11] n_items, [12] overflow/stale (int)
+    long long* d_scalars = nullptr; // [0..7] stats, [8..9] full q, [10..12] step counters, [13] stale (int), [14] #circ,
+                                    // [15] ticket, [16] error, [18..20] counters of the last finished step
     long long* d_qout = nullptr;    // K*13
     long long counters[4] = {0, 0, 0, 0};
     float timing[4] = {0, 0, 0, 0};
@@ -1082,11 +1232,10 @@ int sync_args(Ctx* h)
         a[b].nnz = h->nnz; a[b].n = h->n; a[b].n_sub_total = h->n_sub_total;
         a[b].bitmap_words = (h->n_sub_total + 31) / 32 + 2;
         a[b].reach_bp = h->have_par ? reach_bp(h) : 0;
-        a[b].rows_sorted = h->rows_sorted ? 1 : 0;
         a[b].row = h->row; a[b].col = h->col; a[b].cnt = h->cnt; a[b].sub2bin = h->sub2bin;
         a[b].sub2bin_multi = h->single_sub ? nullptr : h->sub2bin; a[b].sub_ids = h->d_sub_ids;
         a[b].contig_off = h->contig_off2[b]; a[b].perm = h->perm; a[b].geo = h->geo; a[b].stat = h->stat;
-        a[b].codes = h->codes; a[b].bitmap = h->bitmap; a[b].tabs = h->tabs; a[b].step_hdr = h->step_hdr;
+        a[b].tabs = h->tabs; a[b].step_hdr = h->step_hdr; a[b].tm_done = h->tm_done; a[b].acc = h->d_acc;
         a[b].queue = h->queue; a[b].counters = (unsigned long long*)(h->d_scalars + 10);
         a[b].nfpb = h->nfpb; a[b].par = h->par;
     }
@@ -1101,22 +1250,19 @@ int refresh(Ctx* h)
     return GRAAL_OK;
 }
 
+constexpr int SCAN_LDS_MAX = 48 * 1024; // affected bitmap of k_scan: 1 bit per contact-list id -> <= 393,216 ids
+
 // the streaming pass (see k_scan); dry = timing replay that counts relevant contacts but queues nothing
-int launch_scan(Ctx* h, const DevArgs* A, int K, int dry, hipStream_t st)
+int launch_scan(Ctx* h, const DevArgs* A, int fA, const Neigh& nb, int K, int max_id, int dry, hipStream_t st)
 {
-    {
-        const long long groups = (h->nnz >> 2) + 1;
-        static const int scan_blocks = getenv("GRAAL_SCAN_BLOCKS") ? atoi(getenv("GRAAL_SCAN_BLOCKS")) : 256 * 2;
-        static const int scan_threads = getenv("GRAAL_SCAN_THREADS") ? atoi(getenv("GRAAL_SCAN_THREADS")) : 1024;
-        const int nbk = (int)std::min<long long>((groups + 2 * scan_threads - 1) / (2 * scan_threads), scan_blocks);
-        const int words = (h->n_sub_total + 31) / 32 + 2;
-        const bool lds = words * 4 <= 16 * 1024; // keeps the CU full (LDS per block x resident blocks <= 160 KB)
-        const size_t shm = lds ? (size_t)words * 4 : 0;
-#define GRAAL_SCAN(SS, LB) k_scan<SS, LB><<<nbk, scan_threads, shm, st>>>(A, K, dry)
-        if (h->single_sub) { if (lds) GRAAL_SCAN(true, true); else GRAAL_SCAN(true, false); }
-        else { if (lds) GRAAL_SCAN(false, true); else GRAAL_SCAN(false, false); }
-#undef GRAAL_SCAN
-    }
+    const long long groups = (h->nnz >> 2) + 1;
+    static const int scan_blocks = getenv("GRAAL_SCAN_BLOCKS") ? atoi(getenv("GRAAL_SCAN_BLOCKS")) : 256 * 2;
+    static const int scan_threads = getenv("GRAAL_SCAN_THREADS") ? atoi(getenv("GRAAL_SCAN_THREADS")) : 1024;
+    const int nbk = (int)std::min<long long>((groups + 2 * scan_threads - 1) / (2 * scan_threads), scan_blocks);
+    const size_t shm = (size_t)((h->n_sub_total + 31) / 32 + 2) * 4;
+    if (shm > (size_t)SCAN_LDS_MAX) return fail(h, GRAAL_E_UNSUPPORTED, "more than 393,216 sub-fragments: the affected bitmap does not fit the scan's LDS budget");
+    if (h->single_sub) k_scan<true><<<nbk, scan_threads, shm, st>>>(A, fA, nb, K, max_id, dry);
+    else k_scan<false><<<nbk, scan_threads, shm, st>>>(A, fA, nb, K, max_id, dry);
     CK(hipGetLastError());
     return GRAAL_OK;
 }
@@ -1145,10 +1291,17 @@ int graal_create(int device, graal_ctx** out)
     if (device < 0 || device >= count) { h->err = "device index out of range"; return GRAAL_E_ARG; }
     CK(hipSetDevice(device));
     CK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    CK(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
+    CK(hipEventCreateWithFlags(&h->ev_fin, hipEventDisableTiming));
     for (auto& ev : h->ev) CK(hipEventCreate(&ev));
     h->ring.resize(2 * 1024, nullptr);
     for (auto& ev : h->ring) CK(hipEventCreate(&ev));
-    CK(hipMalloc(&h->d_scalars, 16 * sizeof(long long)));
+    CK(hipMalloc(&h->d_scalars, 32 * sizeof(long long)));
+    CK(hipMemset(h->d_scalars, 0, 32 * sizeof(long long)));
+    CK(hipMalloc(&h->d_acc, MAXK * N_OPS * sizeof(long long)));
+    CK(hipMemset(h->d_acc, 0, MAXK * N_OPS * sizeof(long long)));
+    CK(hipMalloc(&h->tm_done, MAXK * sizeof(long long)));
+    CK(hipMemset(h->tm_done, 0, MAXK * sizeof(long long)));
     CK(hipMalloc(&h->d_qout, MAXK * N_OPS * sizeof(long long)));
     CK(hipMalloc(&h->tabs, MAXK * sizeof(NbTables)));
     CK(hipMalloc(&h->step_hdr, 2 * MAXK * sizeof(int)));
@@ -1167,13 +1320,16 @@ void graal_destroy(graal_ctx* h)
     if (h->stream) {
         (void)hipSetDevice(h->device);
         (void)hipStreamSynchronize(h->stream);
-        void* ptrs[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->stat, h->sub2bin, h->row, h->col, h->cnt, h->codes, h->queue, h->bitmap, h->d_sub_ids,
+        if (h->aux) (void)hipStreamSynchronize(h->aux);
+        void* ptrs[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->stat, h->sub2bin, h->row, h->col, h->cnt, h->queue, h->d_sub_ids, h->d_acc, h->tm_done,
                         h->keys, h->keys_sorted, h->o2n, h->len_of2[0], h->len_of2[1], h->contig_off2[0], h->contig_off2[1], h->perm, h->cub_tmp, h->tabs, h->step_hdr, h->d_args, h->d_chg, h->d_plan,
                         h->d_scalars, h->d_qout};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (h->h_res) (void)hipHostFree(h->h_res);
         for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
         for (auto& ev : h->ring) if (ev) (void)hipEventDestroy(ev);
+        if (h->ev_fin) (void)hipEventDestroy(h->ev_fin);
+        if (h->aux) (void)hipStreamDestroy(h->aux);
         (void)hipStreamDestroy(h->stream);
     }
     delete h;
@@ -1223,10 +1379,7 @@ int graal_upload_subfrags(graal_ctx* h, const int32_t* sub_id, const float* sub_
     for (int v : s2b) if (v < 0) return fail(h, GRAAL_E_ARG, "every sub-fragment must belong to a bin");
     // single_sub additionally needs sub id == bin id so that the scan can skip the sub2bin gather
     for (int b = 0; single && b < n_bins; b++) single = (sub_id[4 * b] == b);
-    if (h->stat) { (void)hipFree(h->stat); (void)hipFree(h->sub2bin); (void)hipFree(h->bitmap); (void)hipFree(h->d_sub_ids); h->d_sub_ids = nullptr; }
-    h->bitmap_words = (n_sub_total + 31) / 32 + 64; // + slack: k_prep writes whole 64-fragment ballots
-    CK(hipMalloc(&h->bitmap, sizeof(unsigned) * (size_t)h->bitmap_words));
-    CK(hipMemset(h->bitmap, 0, sizeof(unsigned) * (size_t)h->bitmap_words));
+    if (h->stat) { (void)hipFree(h->stat); (void)hipFree(h->sub2bin); (void)hipFree(h->d_sub_ids); h->d_sub_ids = nullptr; }
     if (!single) {
         CK(hipMalloc(&h->d_sub_ids, sizeof(int) * 4 * (size_t)n_bins));
         CK(hipMemcpy(h->d_sub_ids, sub_id, sizeof(int) * 4 * (size_t)n_bins, hipMemcpyHostToDevice));
@@ -1246,16 +1399,13 @@ int graal_upload_contacts(graal_ctx* h, const int32_t* row, const int32_t* col, 
     if (!h->have_sub) return fail(h, GRAAL_E_STATE, "upload_subfrags first");
     CK(hipSetDevice(h->device));
     double c_lf = 0.0;
-    bool sorted = true;
     double lf_small[16];
     for (int i = 0; i < 16; i++) lf_small[i] = lf_term((double)i);
     for (int64_t i = 0; i < nnz; i++) {
         if (row[i] < 0 || col[i] >= h->n_sub_total || row[i] >= col[i]) return fail(h, GRAAL_E_ARG, "contacts need 0 <= row < col < n_sub_total");
         if (count[i] <= 0) return fail(h, GRAAL_E_ARG, "contact counts must be > 0");
         c_lf += count[i] < 16 ? lf_small[count[i]] : lf_term((double)count[i]);
-        if (i > 0 && row[i] < row[i - 1]) sorted = false;
     }
-    h->rows_sorted = sorted;
     if (h->row) { (void)hipFree(h->row); (void)hipFree(h->col); (void)hipFree(h->cnt); (void)hipFree(h->queue); h->row = h->col = h->cnt = nullptr; h->queue = nullptr; }
     const size_t bytes = sizeof(int) * (size_t)(nnz + 8); // +8: int4 tail reads stay in bounds
     CK(hipMalloc(&h->row, bytes)); CK(hipMalloc(&h->col, bytes)); CK(hipMalloc(&h->cnt, bytes));
@@ -1283,14 +1433,13 @@ int graal_upload_frags(graal_ctx* h, const int32_t* const soa[GRAAL_N_FIELDS], i
             return fail(h, GRAAL_E_UNSUPPORTED, "repeats / inactive fragments are not supported yet");
     }
     if (h->n != n) {
-        void* old[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->codes, h->keys, h->keys_sorted, h->o2n, h->len_of2[0], h->len_of2[1], h->contig_off2[0], h->contig_off2[1], h->perm, h->cub_tmp};
+        void* old[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->keys, h->keys_sorted, h->o2n, h->len_of2[0], h->len_of2[1], h->contig_off2[0], h->contig_off2[1], h->perm, h->cub_tmp};
         for (void* p : old) if (p) (void)hipFree(p);
         for (int b = 0; b < 2; b++) {
             CK(hipMalloc(&h->soa_mem[b], sizeof(int) * (size_t)n * GRAAL_N_FIELDS));
             for (int k = 0; k < GRAAL_N_FIELDS; k++) h->soa[b].p[k] = h->soa_mem[b] + (size_t)k * n;
         }
         CK(hipMalloc(&h->geo, sizeof(Geo) * (size_t)n));
-        CK(hipMalloc(&h->codes, sizeof(unsigned) * (size_t)n));
         CK(hipMalloc(&h->keys, sizeof(unsigned long long) * (size_t)n));
         CK(hipMalloc(&h->keys_sorted, sizeof(unsigned long long) * (size_t)n));
         CK(hipMalloc(&h->o2n, sizeof(int) * (size_t)(2 * n + 8)));
@@ -1391,6 +1540,7 @@ int graal_begin_step(graal_ctx* h, int64_t stats[8], int32_t* max_id)
     if (nc <= 0 || nc > n || res[7] >= 2 * n + 8) return fail(h, GRAAL_E_STATE, "corrupt layout: contig heads / labels out of range");
     if (res[6] != 0) return fail(h, GRAAL_E_UNSUPPORTED, "repeats / inactive fragments are not supported yet");
     h->n_contigs = nc; h->order_valid = true; h->ranks_valid = true; h->pending_commits = 0; h->incr_ok = false;
+    h->max_lcont = (int)res[4];
     if (max_id) *max_id = nc - 1;
     if (stats) {
         for (int i = 0; i < 6; i++) stats[i] = res[i];
@@ -1442,21 +1592,29 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     }
     CK(hipSetDevice(h->device));
     hipStream_t st = stream_v ? (hipStream_t)stream_v : h->stream;
-    SoaPtr s = h->soa[h->cur];
-    const int n = h->n;
     const DevArgs* A = h->d_args + h->cur;
-    if (!h->single_sub) CK(hipMemsetAsync(h->bitmap, 0, sizeof(unsigned) * (size_t)h->bitmap_words, st));
-    k_prep<<<K + blocks_for(n, 256), 256, 0, st>>>(A, fA, nb, K, max_id, (long long*)d_q_out);
+    h->seq += 1;
+    // (1) tables + small mass work on the auxiliary stream: overlaps the scan.  A previous asynchronous evaluation must
+    // have finished with the tables first (the synchronous path has waited for its results already).
+    if (h->fin_pending) { CK(hipStreamWaitEvent(h->aux, h->ev_fin, 0)); h->fin_pending = false; }
+    k_tm<<<K, 256, 0, h->aux>>>(A, fA, nb, K, max_id, rank, world, h->seq);
+    CK(hipGetLastError());
+    // (2) the streaming pass
     const size_t slot = (size_t)(h->ring_calls % (long long)(h->ring.size() / 2));
     if (h->want_events) CK(hipEventRecord(h->ring[2 * slot], st));
-    { int rc_ = launch_scan(h, A, K, 0, st); if (rc_) return rc_; }
+    { int rc_ = launch_scan(h, A, fA, nb, K, max_id, 0, st); if (rc_) return rc_; }
     if (h->want_events) { CK(hipEventRecord(h->ring[2 * slot + 1], st)); h->ring_calls += 1; }
-    {
-        k_post<<<512, 256, 0, st>>>(A, K, rank, world, (long long*)d_q_out, h->publish ? h->h_res : nullptr, h->seq);
-    }
+    // (3) left-over mass items, queued contacts, hand-out.  Short contigs leave it a handful of contacts: a small grid
+    // keeps its launch and completion ticket cheap; long contigs get the whole chip.
+    static const int fin_blocks_env = getenv("GRAAL_FIN_BLOCKS") ? atoi(getenv("GRAAL_FIN_BLOCKS")) : 0;
+    const int fin_blocks = fin_blocks_env > 0 ? fin_blocks_env : (h->max_lcont > 0 && h->max_lcont <= 16 ? 32 : 512);
+    k_fin<<<fin_blocks, 256, 0, st>>>(A, K, rank, world, (long long*)d_q_out, h->publish ? h->h_res : nullptr, h->seq);
     CK(hipGetLastError());
+    if (!h->publish) { CK(hipEventRecord(h->ev_fin, st)); h->fin_pending = true; }
     h->timing_valid = h->want_events;
     h->scan_ready = true;
+    h->last_fA = fA; h->last_K = K; h->last_max_id = max_id;
+    for (int k = 0; k < MAXK; k++) h->last_fB[k] = nb.fB[k];
     return GRAAL_OK;
 }
 
@@ -1464,8 +1622,7 @@ int graal_eval_candidates(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K
 {
     if (!h || !delta) return GRAAL_E_ARG;
     h->publish = true;
-    h->seq += 1;
-    const long long want = h->seq;
+    const long long want = h->seq + 1;
     int rc = graal_eval_candidates_q(h, fA, fB, K, max_id, 0, 1, (int64_t*)h->d_qout, nullptr);
     h->publish = false;
     if (rc) return rc;
@@ -1474,14 +1631,15 @@ int graal_eval_candidates(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K
     volatile long long* res = h->h_res;
     bool seen = false;
     for (long long spin = 0; spin < 200000000ll; spin++) {
-        if (res[0] == want) { seen = true; break; }
-        if ((spin & 0xfffff) == 0xfffff && hipStreamQuery(h->stream) != hipErrorNotReady) { seen = (res[0] == want); break; }
+        if (res[0] == want || res[0] == -want) { seen = true; break; }
+        if ((spin & 0xfffff) == 0xfffff && hipStreamQuery(h->stream) != hipErrorNotReady) { seen = (res[0] == want || res[0] == -want); break; }
         __builtin_ia32_pause();
     }
     if (!seen) {
         CK(hipStreamSynchronize(h->stream));
-        if (res[0] != want) return fail(h, GRAAL_E_HIP, "k_post did not publish its results");
+        if (res[0] != want && res[0] != -want) return fail(h, GRAAL_E_HIP, "k_fin did not publish its results");
     }
+    if (res[0] == -want) return fail(h, GRAAL_E_HIP, "k_fin timed out waiting for the candidate tables (k_tm did not run)");
     __sync_synchronize();
     for (int i = 0; i < K * N_OPS; i++) delta[i] = (double)res[1 + i] / Q_SCALE;
     return GRAAL_OK;
@@ -1546,9 +1704,12 @@ int graal_time_scan(graal_ctx* h, int32_t K, int32_t reps, float* avg_ms)
     if (!h->scan_ready) return fail(h, GRAAL_E_STATE, "run graal_eval_candidates first (the replays reuse its tables)");
     CK(hipSetDevice(h->device));
     const DevArgs* A = h->d_args + h->cur;
-    for (int i = 0; i < 3; i++) { int rc = launch_scan(h, A, K, 1, h->stream); if (rc) return rc; }
+    if (K != h->last_K) return fail(h, GRAAL_E_ARG, "K differs from the last evaluation");
+    Neigh nb;
+    for (int k = 0; k < MAXK; k++) nb.fB[k] = h->last_fB[k];
+    for (int i = 0; i < 3; i++) { int rc = launch_scan(h, A, h->last_fA, nb, K, h->last_max_id, 1, h->stream); if (rc) return rc; }
     CK(hipEventRecord(h->ev[0], h->stream));
-    for (int i = 0; i < reps; i++) { int rc = launch_scan(h, A, K, 1, h->stream); if (rc) return rc; }
+    for (int i = 0; i < reps; i++) { int rc = launch_scan(h, A, h->last_fA, nb, K, h->last_max_id, 1, h->stream); if (rc) return rc; }
     CK(hipEventRecord(h->ev[4], h->stream));
     CK(hipEventSynchronize(h->ev[4]));
     float ms = 0.0f;
@@ -1562,7 +1723,8 @@ int graal_last_counters(graal_ctx* h, int64_t out[4])
     if (!h || !out) return GRAAL_E_ARG;
     CK(hipSetDevice(h->device));
     long long res[3];
-    CK(hipMemcpy(res, h->d_scalars + 10, sizeof res, hipMemcpyDeviceToHost));
+    CK(hipStreamSynchronize(h->stream));
+    CK(hipMemcpy(res, h->d_scalars + 18, sizeof res, hipMemcpyDeviceToHost));
     out[0] = h->nnz; out[1] = res[0]; out[2] = res[2]; out[3] = res[1];
     return GRAAL_OK;
 }
