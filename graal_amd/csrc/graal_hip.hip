@@ -91,6 +91,10 @@ __device__ __forceinline__ float rippe_circ(float s, float s_tot, const Par& p)
 struct Geo { int id_c, flags, start_bp, len_bp; }; // flags: bit0 ori==+1, bit1 circ, bits 2..31 pos
 __device__ __forceinline__ int geo_flags(int ori, int circ, int pos) { return (ori == 1 ? 1 : 0) | (circ == 1 ? 2 : 0) | (pos << 2); }
 __device__ __forceinline__ int geo_pos(int flags) { return (int)((unsigned)flags >> 2); }
+// the rest of a fragment's layout record, 16 bytes: with Geo it replaces 13 scattered SoA words by two 16-byte loads
+struct Link { int l_cont, l_cont_bp, prev, next; };
+constexpr int N_MATES = 8; // mates[f][0..8): the first fragments of f's contig in position order (-1 padded)
+
 // static data of one bin: sub-fragment lengths (kb) and RF counts (simulation_loader.py:673-704)
 struct Stat { float l0, l1, l2; int n; int a0, a1, a2; int pad; };
 // 3-way selects instead of indexed arrays: indexed private arrays would live in scratch memory
@@ -167,14 +171,41 @@ __device__ __forceinline__ double wave_sum_d(double v)
     return v;
 }
 
+// layout record of fragment f from its Geo + Link (no repeats: rep = 0, activ = 1, id_d = f -- checked at upload)
+__device__ __forceinline__ Rec rec_gl(const Geo& g, const Link& l, int f)
+{
+    Rec r;
+    r.pos = geo_pos(g.flags); r.id_c = g.id_c; r.start_bp = g.start_bp; r.len_bp = g.len_bp; r.circ = (g.flags >> 1) & 1;
+    r.prev = l.prev; r.next = l.next; r.l_cont = l.l_cont; r.l_cont_bp = l.l_cont_bp; r.ori = (g.flags & 1) ? 1 : -1;
+    r.rep = 0; r.activ = 1; r.id_d = f;
+    return r;
+}
+
 // ------------------------------------------------------------------ small maintenance kernels
-__global__ void k_refresh_geo(SoaPtr s, Geo* __restrict__ geo, int n)
+__global__ void k_refresh_geo(SoaPtr s, Geo* __restrict__ geo, Link* __restrict__ link, int n)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n) return;
     Geo g; g.id_c = s.p[F_IDC][f]; g.start_bp = s.p[F_START][f]; g.len_bp = s.p[F_LEN][f];
     g.flags = geo_flags(s.p[F_ORI][f], s.p[F_CIRC][f], s.p[F_POS][f]);
     geo[f] = g;
+    Link l; l.l_cont = s.p[F_LCONT][f]; l.l_cont_bp = s.p[F_LCONTBP][f]; l.prev = s.p[F_PREV][f]; l.next = s.p[F_NEXT][f];
+    link[f] = l;
+}
+
+// mates rows (see N_MATES); runs after the position index is complete
+__global__ void k_mates(int n, const int* __restrict__ perm, const int* __restrict__ cbase, const Link* __restrict__ link,
+                        int* __restrict__ mates)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n) return;
+    const int base = cbase[f], lc = link[f].l_cont;
+    int m[N_MATES];
+#pragma unroll
+    for (int i = 0; i < N_MATES; i++) m[i] = i < lc ? perm[base + i] : -1;
+    int4* out = reinterpret_cast<int4*>(mates + (size_t)f * N_MATES);
+    out[0] = make_int4(m[0], m[1], m[2], m[3]);
+    out[1] = make_int4(m[4], m[5], m[6], m[7]);
 }
 
 // out: [0] #heads (pos==0) [1] sum l_cont [2] #(start_bp==0) [3] sum l_cont_bp over start_bp==0 [4] max l_cont
@@ -251,11 +282,13 @@ __global__ void k_relabel_apply(SoaPtr s, int n, const int* __restrict__ o2n)
     s.p[F_IDC][f] = o2n[s.p[F_IDC][f]];
 }
 
-__global__ void k_build_perm(SoaPtr s, int n, const int* __restrict__ contig_off, int* __restrict__ perm)
+__global__ void k_build_perm(SoaPtr s, int n, const int* __restrict__ contig_off, int* __restrict__ perm, int* __restrict__ cbase)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n) return;
-    perm[contig_off[s.p[F_IDC][f]] + s.p[F_POS][f]] = f;
+    const int base = contig_off[s.p[F_IDC][f]];
+    cbase[f] = base; // first slot of the fragment's contig in the position index
+    perm[base + s.p[F_POS][f]] = f;
 }
 
 // What one commit did to the contig set: only contig(fA), contig(fB) and up to two fresh labels can change.
@@ -344,7 +377,7 @@ __global__ void k_incr_plan(const Changed* __restrict__ chg, const int* __restri
 // index and geometry records
 __global__ void k_incr_apply(SoaPtr s, int n, const IncrPlan* __restrict__ planp, const int* __restrict__ len_old,
                              const int* __restrict__ off_old, int* __restrict__ len_new, int* __restrict__ off_new,
-                             int* __restrict__ perm, Geo* __restrict__ geo)
+                             int* __restrict__ perm, int* __restrict__ cbase, Geo* __restrict__ geo, Link* __restrict__ link)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     const IncrPlan p = *planp;
@@ -366,9 +399,12 @@ __global__ void k_incr_apply(SoaPtr s, int n, const IncrPlan* __restrict__ planp
     s.p[F_IDC][f] = rank;
     if (pos == 0) { len_new[rank] = lenc; off_new[rank] = off; }
     perm[off + pos] = f;
+    cbase[f] = off;
     Geo g; g.id_c = rank; g.start_bp = s.p[F_START][f]; g.len_bp = s.p[F_LEN][f];
     g.flags = geo_flags(s.p[F_ORI][f], s.p[F_CIRC][f], pos);
     geo[f] = g;
+    Link l; l.l_cont = s.p[F_LCONT][f]; l.l_cont_bp = s.p[F_LCONTBP][f]; l.prev = s.p[F_PREV][f]; l.next = s.p[F_NEXT][f];
+    link[f] = l;
 }
 
 // ------------------------------------------------------------------ full likelihood
@@ -485,10 +521,11 @@ __device__ __forceinline__ void pair_of_index(int idx, int& p, int& q)
 
 // one block builds everything about one neighbour; tasks are left in s_task (LDS) too, with the exclusive prefix of
 // their fragment-pair counts in s_pp.  Returns the number of tasks.
-__device__ int tables_block(const SoaPtr& s, int fA, int fB, int max_id, const int* __restrict__ contig_off, NbTables& T,
-                            int k, int* __restrict__ step_hdr, Task* s_task, int* s_pp)
+__device__ int tables_block(const Geo* __restrict__ geo, const Link* __restrict__ link, const int* __restrict__ cbase, int fA,
+                            int fB, int max_id, NbTables& T, int k, int* __restrict__ step_hdr, Task* s_task, int* s_pp)
 {
     __shared__ Rec A0, B0;
+    __shared__ int s_baseA, s_baseB;
     __shared__ int rep[NP];
     __shared__ Rec rep_old[NP];
     __shared__ Xf xf_old[NP];
@@ -502,7 +539,10 @@ __device__ int tables_block(const SoaPtr& s, int fA, int fB, int max_id, const i
     __shared__ int s_lo[NP], s_hi[NP], s_contig[NP], s_cbase[NP], s_chunks[NENT], s_start[NENT + 1], s_pairs[NENT];
     const int t = threadIdx.x;
     if (t == 0) {
-        A0 = ld_rec(s, fA); B0 = ld_rec(s, fB);
+        const Geo gA = geo[fA], gB = geo[fB];
+        const Link lA = link[fA], lB = link[fB];
+        s_baseA = cbase[fA]; s_baseB = cbase[fB];
+        A0 = rec_gl(gA, lA, fA); B0 = rec_gl(gB, lB, fB);
         PieceKey key; key.cA = A0.id_c; key.a = A0.pos; key.cB = B0.id_c; key.b = B0.pos;
         T.key = key; T.fB = fB;
         piece_representatives(key, fA, fB, A0, B0, rep);
@@ -526,9 +566,9 @@ __device__ int tables_block(const SoaPtr& s, int fA, int fB, int max_id, const i
     for (int e = t; e < NENT; e += blockDim.x) { e_valid[e] = 0; e_plus[e] = 0; e_minus[e] = 0; e_owner[e] = e; e_slot[e] = -1; }
     __syncthreads();
     if (t < NP) {
-        if (rep[t] >= 0) { rep_old[t] = ld_rec(s, rep[t]); xf_old[t] = xf_identity(rep_old[t]); }
+        if (rep[t] >= 0) { rep_old[t] = rec_gl(geo[rep[t]], link[rep[t]], rep[t]); xf_old[t] = xf_identity(rep_old[t]); }
         else { Xf x; x.label = -1 - t; x.sigma = 1; x.off = 0; x.circ = 0; x.lbp = 0; xf_old[t] = x; }
-        s_cbase[t] = s_contig[t] >= 0 ? contig_off[s_contig[t]] : 0;
+        s_cbase[t] = s_contig[t] < 0 ? 0 : (s_contig[t] == A0.id_c ? s_baseA : s_baseB);
     }
     __syncthreads();
     // transforms: one thread per (op, piece)
@@ -638,7 +678,13 @@ __device__ int tables_block(const SoaPtr& s, int fA, int fB, int max_id, const i
 // (one per layout buffer).  Kernel arguments are fetched by serialised scalar loads from the uncached kernarg
 // segment (~1 us each); with 20+ arguments that prologue cost more than the kernels' work.  Now each kernel
 // takes this pointer plus a handful of per-step scalars.
-struct QEntry { unsigned idx; unsigned rel; }; // contact index in this shard, nibble mask of the neighbours it matters to
+// one relevant contact, everything k_fin needs to price it without further index loads (32 bytes)
+struct QEntry {
+    unsigned idx, rel;   // contact index in this shard; nibble mask of the neighbours it matters to
+    unsigned ci, cj;     // relevance codes of its two fragments: 4 bits per neighbour = piece id
+    int fx, fy, cnt;     // fragments (bins) and observed count
+    int slots;           // sub-fragment slots: slx | sly << 2
+};
 struct DevArgs {
     SoaPtr soa;
     long long nnz;
@@ -646,6 +692,8 @@ struct DevArgs {
     const int *row, *col, *cnt, *sub2bin, *sub2bin_multi /* nullptr when every bin has one sub-fragment */, *sub_ids;
     const int *contig_off, *perm;
     const Geo* geo;
+    const Link* link;
+    const int* cbase;
     const Stat* stat;
     NbTables* tabs;
     int* step_hdr;                // [k] mass work items of neighbour k, [MAXK + k] 1 = k_tm priced them already
@@ -678,20 +726,38 @@ __device__ __forceinline__ int gap_bp(const End& X, int len_x, const End& Y, int
 // k_tm (K blocks, launched on the auxiliary stream so that it overlaps k_scan): block k builds the tables of neighbour k
 // and, when the expected-mass work of that neighbour is small (<= INLINE_PAIRS fragment pairs: the regime of short
 // contigs), prices it on the spot -- one thread per fragment pair -- instead of leaving it to k_fin.
-__global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, int fA, Neigh nb, int K, int max_id, int rank,
+// element j of 8 values held in registers (a select chain: an indexed private array would live in scratch memory)
+__device__ __forceinline__ int sel8(int x0, int x1, int x2, int x3, int x4, int x5, int x6, int x7, int j)
+{
+    int v = x0;
+    v = j == 1 ? x1 : v; v = j == 2 ? x2 : v; v = j == 3 ? x3 : v; v = j == 4 ? x4 : v;
+    v = j == 5 ? x5 : v; v = j == 6 ? x6 : v; v = j == 7 ? x7 : v;
+    return v;
+}
+
+struct TmArgs { // first-needed pointers by value (see ScanArgs)
+    const Geo* geo;
+    const Link* link;
+    const int* cbase;
+    NbTables* tabs;
+    int* step_hdr;
+};
+
+__global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArgs ta, int fA, Neigh nb, int K, int max_id, int rank,
                                              int world, long long seq)
 {
     __shared__ Task s_task[MAX_TASKS];
     __shared__ int s_pp[MAX_TASKS + 1];
     const int k = blockIdx.x, t = threadIdx.x;
     if (k >= K) return;
-    NbTables& T = A->tabs[k];
-    const int n_tasks = tables_block(A->soa, fA, nb.fB[k], max_id, A->contig_off, T, k, A->step_hdr, s_task, s_pp);
+    NbTables& T = ta.tabs[k];
+    const int my_fB = sel8(nb.fB[0], nb.fB[1], nb.fB[2], nb.fB[3], nb.fB[4], nb.fB[5], nb.fB[6], nb.fB[7], k);
+    const int n_tasks = tables_block(ta.geo, ta.link, ta.cbase, fA, my_fB, max_id, T, k, ta.step_hdr, s_task, s_pp);
     const int total = s_pp[n_tasks];
     const bool inl = total <= INLINE_PAIRS;
     if (inl && total > 0) {
         const int* __restrict__ perm = A->perm;
-        const Geo* __restrict__ geo = A->geo;
+        const Geo* __restrict__ geo = ta.geo;
         const Stat* __restrict__ stat = A->stat;
         const float nfpb = A->nfpb;
         const Par par = A->par;
@@ -726,10 +792,11 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, int f
     }
     __syncthreads();
     if (t == 0) {
-        if (inl && rank == 0) atomicAdd(&A->counters[1], (unsigned long long)A->step_hdr[k]);
-        A->step_hdr[MAXK + k] = inl ? 1 : 0;
-        __threadfence();
-        atomicExch((unsigned long long*)&A->tm_done[k], (unsigned long long)seq); // release: tables of neighbour k are complete
+        if (inl && rank == 0) atomicAdd(&A->counters[1], (unsigned long long)ta.step_hdr[k]);
+        ta.step_hdr[MAXK + k] = inl ? 1 : 0;
+        // release: the tables of neighbour k are complete; the word carries the work-list header for k_fin
+        const unsigned long long w = ((unsigned long long)(unsigned)seq << 32) | (inl ? 0x80000000ull : 0ull) | (unsigned long long)(unsigned)ta.step_hdr[k];
+        __hip_atomic_store((unsigned long long*)&A->tm_done[k], w, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -782,134 +849,211 @@ __device__ bool circ_may_change(int fA, int fB, int max_id, const Rec& A0, const
 //   2. col id in the bitmap?
 //   3. piece ids of both fragments (8-byte gathers of the geometry records) -> nibble mask of neighbours.
 // Survivors are appended to a queue (wave-aggregated atomics) for k_fin.  Counts are not read here at all.
+#ifndef GRAAL_SCAN_PRE
+#define GRAAL_SCAN_PRE 4
+#endif
+// groups of row words (of the first four) requested ABOVE the prologue.  All of them would flood the memory system with
+// 32 MB at once and the prologue's second dependent load would come back behind that burst; none would leave HBM idle
+// during the prologue.
+constexpr int SCAN_PRE = GRAAL_SCAN_PRE;
+
+struct ScanArgs { // by value: kernel-argument pointers are known to be GLOBAL (pointers read from a struct in memory are
+                  // generic -> FLAT instructions, whose out-of-order completion forces full counter drains on the hot path)
+    const Geo* geo;
+    const Link* link;
+    const int *cbase, *perm, *mates, *sub_ids, *sub2bin, *cnt;
+    const int4 *row4, *col4;
+    const int2* geo2;             // (id_c, flags) = first half of a Geo record
+    QEntry* queue;
+    unsigned long long* counters;
+    long long nnz;
+    int bitmap_words;
+};
+
 template <bool SINGLE_SUB>
-__global__ __launch_bounds__(1024) void k_scan(const DevArgs* __restrict__ A, int fA, Neigh nb, int K, int max_id,
+__global__ __launch_bounds__(1024) void k_scan(ScanArgs sa, int fA, Neigh nb, int K, int max_id,
                                                 int dry /* timing replays: count, do not queue */)
 {
-    const int* __restrict__ row = A->row;
-    const int* __restrict__ col = A->col;
-    const long long nnz = A->nnz;
-    const int* __restrict__ sub2bin = A->sub2bin;
-    const int2* __restrict__ geo2 = reinterpret_cast<const int2*>(A->geo); // (id_c, flags) = first half of a Geo record
-    QEntry* __restrict__ queue = A->queue;
-    unsigned long long* __restrict__ counters = A->counters;
     extern __shared__ unsigned s_bm[];
     __shared__ StepKeys S;
     __shared__ Rec s_rec[MAXK + 1];
-    __shared__ int s_cbase[MAXK + 1], s_clen[MAXK + 1], s_pref[MAXK + 2];
+    __shared__ int s_cbase[MAXK + 1], s_clen[MAXK + 1], s_pref[MAXK + 2], s_fB[MAXK], s_mates[MAXK + 1][N_MATES];
     const int t = threadIdx.x;
     const int lane = t & 63;
-    const long long n4 = nnz >> 2;
-    const int tail = (int)(nnz - (n4 << 2));
-    const int4* __restrict__ row4 = reinterpret_cast<const int4*>(row);
-    const int4* __restrict__ col4 = reinterpret_cast<const int4*>(col);
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    long long g0 = (long long)blockIdx.x * blockDim.x + t;
-    // the first row words are requested before the bitmap is built: HBM latency overlaps the prologue
-    int4 ra = make_int4(0, 0, 0, 0), rb = make_int4(0, 0, 0, 0);
-    if (g0 <= n4) ra = ld_stream(row4 + g0);
-    if (g0 + stride <= n4) rb = ld_stream(row4 + g0 + stride);
-    // ---- prologue: keys of the K neighbours and the affected bitmap --------------------------------------------
-    const int bitmap_words = A->bitmap_words;
-    if (t <= K) s_rec[t] = ld_rec(A->soa, t == 0 ? fA : nb.fB[t - 1]);
+    // ---- prologue: keys of the K neighbours and the affected bitmap.  Its dependent loads (fragment records -> position
+    // index) go out first; the first row words are requested right behind them, so the stream is already running while
+    // the bitmap is built ----
+    // (select chains, not nb.fB[t]: a dynamically indexed kernel argument is fetched from memory)
+    const int my_fB = sel8(nb.fB[0], nb.fB[1], nb.fB[2], nb.fB[3], nb.fB[4], nb.fB[5], nb.fB[6], nb.fB[7], t & 7);
+    const int my_fPrev = sel8(fA, nb.fB[0], nb.fB[1], nb.fB[2], nb.fB[3], nb.fB[4], nb.fB[5], nb.fB[6], t & 7);
+    int my_cbase = 0;
+    if (dry >= 3) K = 0; // experiment: no neighbours at all
+    if (t <= K) {
+        const int f = t == 8 ? nb.fB[7] : my_fPrev; // t == 0: fA, t >= 1: fB[t - 1]
+        const Geo g = sa.geo[f];
+        const Link l = sa.link[f];
+        const int4 m0 = reinterpret_cast<const int4*>(sa.mates)[2 * f], m1 = reinterpret_cast<const int4*>(sa.mates)[2 * f + 1];
+        my_cbase = sa.cbase[f];
+        s_rec[t] = rec_gl(g, l, f);
+        s_mates[t][0] = m0.x; s_mates[t][1] = m0.y; s_mates[t][2] = m0.z; s_mates[t][3] = m0.w;
+        s_mates[t][4] = m1.x; s_mates[t][5] = m1.y; s_mates[t][6] = m1.z; s_mates[t][7] = m1.w;
+    }
+    const long long nnz = sa.nnz;
+    const int n4 = (int)(nnz >> 2);           // groups of 4 contacts: 0 .. n4 (the last one partial or empty; nnz < 2^33)
+    const int4* __restrict__ row4 = sa.row4;
+    const int stride = (int)(gridDim.x * blockDim.x);
+    int g0 = (int)(blockIdx.x * blockDim.x) + t;
+    // unconditional loads with a clamped group index (group n4 is in bounds: the arrays are padded): branch-free, so the
+    // compiler keeps all four in flight together.  The first iteration's loads are issued here, ABOVE the prologue: 40 % of
+    // the list is on its way while the bitmap is built -- except by wave 0, which builds it: vector-memory results return in
+    // order, so its dependent prologue loads would queue up behind its own stream loads.
+    auto ldg = [&](long long g) { return ld_stream(row4 + (g < n4 ? g : (long long)n4)); };
+    int4 f0, f1, f2, f3;
+    static_assert(SCAN_PRE >= 0 && SCAN_PRE <= 4, "");
+    if (t >= 64) {
+        if (SCAN_PRE > 0) f0 = ldg(g0);
+        if (SCAN_PRE > 1) f1 = ldg((long long)g0 + stride);
+        if (SCAN_PRE > 2) f2 = ldg((long long)g0 + 2 * stride);
+        if (SCAN_PRE > 3) f3 = ldg((long long)g0 + 3 * stride);
+    }
     if (t == 0) { S.live = 0; S.intra = 0; }
-    for (int i = t; i < bitmap_words; i += blockDim.x) s_bm[i] = 0;
+    for (int i = t; i < sa.bitmap_words; i += blockDim.x) s_bm[i] = 0;
+    if (t <= K) s_cbase[t] = my_cbase;
+    if (t < MAXK) s_fB[t] = my_fB;
     __syncthreads();
     if (t < K) {
         const Rec& A0 = s_rec[0];
         const Rec& B0 = s_rec[t + 1];
-        const int fB = nb.fB[t];
+        const int fB = my_fB;
         PieceKey key; key.cA = A0.id_c; key.a = A0.pos; key.cB = B0.id_c; key.b = B0.pos;
         S.key[t] = key;
         bool dup = (fB == fA) || (B0.id_c == A0.id_c);
         if (fB != fA) {
             atomicOr(&S.live, 1u << t);
             if (circ_may_change(fA, fB, max_id, A0, B0)) atomicOr(&S.intra, 1u << (4 * t));
-            for (int j = 0; j < t; j++) if (nb.fB[j] != fA && s_rec[j + 1].id_c == B0.id_c) dup = true;
+            for (int j = 0; j < t; j++) if (s_fB[j] != fA && s_rec[j + 1].id_c == B0.id_c) dup = true;
         }
-        s_clen[t + 1] = dup ? 0 : B0.l_cont;
-        s_cbase[t + 1] = dup ? 0 : A->contig_off[B0.id_c];
-    } else if (t == (int)blockDim.x - 1) { // another wave: the two index loads go out together
-        s_clen[0] = s_rec[0].l_cont;
-        s_cbase[0] = A->contig_off[s_rec[0].id_c];
+        s_clen[t + 1] = (dup || dry >= 2) ? 0 : B0.l_cont;
     }
+    if (t == 0) s_clen[0] = dry >= 2 ? 0 : s_rec[0].l_cont; // experiment (dry >= 2): empty bitmap, no position-index hop
     __syncthreads();
     if (t == 0) { int acc = 0; for (int j = 0; j <= K; j++) { s_pref[j] = acc; acc += s_clen[j]; } s_pref[K + 1] = acc; }
     __syncthreads();
     {
         const int total = s_pref[K + 1];
-        const int* __restrict__ perm = A->perm;
-        const int* __restrict__ sub_ids = A->sub_ids;
+        const int* __restrict__ perm = sa.perm;
         for (int e = t; e < total; e += blockDim.x) {
             int j = 0;
             while (j < K && e >= s_pref[j + 1]) j++;
-            const int f = perm[s_cbase[j] + (e - s_pref[j])];
+            // short contigs come with the fragment's own record (mates row): no second dependent load
+            const int i = e - s_pref[j];
+            const int f = s_clen[j] <= N_MATES ? s_mates[j][i] : perm[s_cbase[j] + i];
             if (SINGLE_SUB) atomicOr(&s_bm[f >> 5], 1u << (f & 31));
             else {
-                const int4 ids = reinterpret_cast<const int4*>(sub_ids)[f];
+                const int4 ids = reinterpret_cast<const int4*>(sa.sub_ids)[f];
                 atomicOr(&s_bm[ids.x >> 5], 1u << (ids.x & 31));
                 if (ids.w > 1) atomicOr(&s_bm[ids.y >> 5], 1u << (ids.y & 31));
                 if (ids.w > 2) atomicOr(&s_bm[ids.z >> 5], 1u << (ids.z & 31));
             }
         }
     }
+    const int4* __restrict__ col4 = sa.col4;
+    const int* __restrict__ sub2bin = sa.sub2bin;
+    const int2* __restrict__ geo2 = sa.geo2;
+    QEntry* __restrict__ queue = sa.queue;
+    unsigned long long* __restrict__ counters = sa.counters;
     __syncthreads();
     const unsigned intra = S.intra;
     unsigned long long n_rel = 0;
-    for (; g0 <= n4; g0 += 2 * stride) {
-        // two groups of 4 contacts per iteration (the arrays are padded: the tail group stays in bounds)
-        const long long g1 = g0 + stride;
-        const bool has1 = g1 <= n4;
-        const int r[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
-        const int va = g0 < n4 ? 4 : tail, vb = has1 ? (g1 < n4 ? 4 : tail) : 0;
-        // next iteration's row words (nontemporal: the stream must not evict the tables from L2)
-        const long long h0 = g0 + 2 * stride, h1 = h0 + stride;
-        if (h0 <= n4) ra = ld_stream(row4 + h0);
-        rb = make_int4(0, 0, 0, 0);
-        if (h1 <= n4) rb = ld_stream(row4 + h1);
+    // one iteration: four groups of 4 contacts (ga + i * stride)
+    auto process = [&](const int4 r0, const int4 r1, const int4 r2, const int4 r3, const long long ga) {
+        const int r[16] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
+        unsigned vmask = 0; // valid contacts of the four groups
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const long long rem = nnz - ((ga + (long long)i * stride) << 2);
+            const int v = rem >= 4 ? 4 : (rem > 0 ? (int)rem : 0);
+            vmask |= ((1u << v) - 1u) << (4 * i);
+        }
         unsigned hit = 0; // bit j: contact j of this lane has an affected row
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const bool valid = j < 4 ? (j < va) : (j - 4 < vb);
-            if (valid && ((s_bm[r[j] >> 5] >> (r[j] & 31)) & 1u)) hit |= 1u << j;
-        }
-        if (__ballot(hit != 0) == 0) continue; // the common case: nobody in this wave needs its col words
-        int c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (hit & 0x0fu) { const int4 ca = ld_stream(col4 + g0); c[0] = ca.x; c[1] = ca.y; c[2] = ca.z; c[3] = ca.w; }
-        if (hit & 0xf0u) { const int4 cb = ld_stream(col4 + g1); c[4] = cb.x; c[5] = cb.y; c[6] = cb.z; c[7] = cb.w; }
+        for (int j = 0; j < 16; j++) hit |= ((s_bm[r[j] >> 5] >> (r[j] & 31)) & 1u) << j;
+        hit &= vmask;
+        if (__ballot(hit != 0) == 0) return; // the common case: nobody in this wave needs its col words
+        // second test, still wide: the col words of the groups with an affected row (up to four 16-byte loads in flight
+        // together), all sixteen bitmap tests at once
+        int4 c0 = make_int4(0, 0, 0, 0), c1 = c0, c2 = c0, c3 = c0;
+        if (hit & 0x000fu) c0 = ld_stream(col4 + ga);
+        if (hit & 0x00f0u) c1 = ld_stream(col4 + ga + stride);
+        if (hit & 0x0f00u) c2 = ld_stream(col4 + ga + 2 * (long long)stride);
+        if (hit & 0xf000u) c3 = ld_stream(col4 + ga + 3 * (long long)stride);
+        {
+            const int c[16] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w};
+            unsigned hit2 = 0;
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            unsigned rel = 0;
-            if (((hit >> j) & 1u) && ((s_bm[c[j] >> 5] >> (c[j] & 31)) & 1u)) {
-                int fx, fy;
-                if (SINGLE_SUB) { fx = r[j]; fy = c[j]; }
-                else { fx = sub2bin[r[j]] >> 2; fy = sub2bin[c[j]] >> 2; }
-                const int2 gi = geo2[2 * fx], gj = geo2[2 * fy];
-                const unsigned ci = code_of(S, K, gi.x, geo_pos(gi.y)), cj = code_of(S, K, gj.x, geo_pos(gj.y));
-                const unsigned nzi = (ci | (ci >> 1) | (ci >> 2)) & 0x11111111u;
-                const unsigned nzj = (cj | (cj >> 1) | (cj >> 2)) & 0x11111111u;
-                const unsigned df = ci ^ cj;
-                const unsigned dnz = (df | (df >> 1) | (df >> 2)) & 0x11111111u;
-                const unsigned both = nzi & nzj;
-                // different pieces, or the same piece of a neighbour whose circular model may change (k_fin filters
-                // by the exact per-candidate relation masks)
-                rel = both & (dnz | intra);
-                if (!SINGLE_SUB && fx == fy) rel = 0; // a bin's own pixel is never revisited (kernels3.cu:3356-3380)
+            for (int j = 0; j < 16; j++) hit2 |= ((s_bm[c[j] >> 5] >> (c[j] & 31)) & 1u) << j;
+            hit &= hit2;
+        }
+        // third test: one doubly-affected contact per lane and pass (a loop, not a 16-fold unrolled body: rare when contigs
+        // are short)
+        while (__ballot(hit != 0) != 0) {
+            unsigned rel = 0, q_ci = 0, q_cj = 0;
+            int j = 0, q_fx = 0, q_fy = 0, q_slots = 0;
+            long long cidx = 0;
+            if (hit) {
+                j = __ffs((int)hit) - 1;
+                hit &= hit - 1;
+                const int rj = (j & 8) ? sel8(r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w, j & 7)
+                                       : sel8(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, j & 7);
+                const int cj_ = (j & 8) ? sel8(c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w, j & 7)
+                                        : sel8(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, j & 7);
+                cidx = ((ga + (long long)(j >> 2) * stride) << 2) + (j & 3);
+                {
+                    int fx, fy;
+                    if (SINGLE_SUB) { fx = rj; fy = cj_; }
+                    else { const int a = sub2bin[rj], b = sub2bin[cj_]; fx = a >> 2; fy = b >> 2; q_slots = (a & 3) | ((b & 3) << 2); }
+                    q_fx = fx; q_fy = fy;
+                    const int2 gi = geo2[2 * fx], gj = geo2[2 * fy];
+                    const unsigned ci = code_of(S, K, gi.x, geo_pos(gi.y)), cj = code_of(S, K, gj.x, geo_pos(gj.y));
+                    const unsigned nzi = (ci | (ci >> 1) | (ci >> 2)) & 0x11111111u;
+                    const unsigned nzj = (cj | (cj >> 1) | (cj >> 2)) & 0x11111111u;
+                    const unsigned df = ci ^ cj;
+                    const unsigned dnz = (df | (df >> 1) | (df >> 2)) & 0x11111111u;
+                    const unsigned both = nzi & nzj;
+                    // different pieces, or the same piece of a neighbour whose circular model may change (k_fin filters
+                    // by the exact per-candidate relation masks)
+                    rel = both & (dnz | intra);
+                    if (!SINGLE_SUB && fx == fy) rel = 0; // a bin's own pixel is never revisited (kernels3.cu:3356-3380)
+                    q_ci = ci; q_cj = cj;
+                }
             }
-            const unsigned long long bal = dry ? 0ull : __ballot(rel != 0);
-            if (dry) n_rel += __popc(rel);
+            if (dry) { n_rel += __popc(rel); continue; }
+            const unsigned long long bal = __ballot(rel != 0);
             if (bal) {
                 const int leader = __ffsll((long long)bal) - 1;
                 unsigned long long base = 0;
                 if (lane == leader) base = atomicAdd(&counters[2], (unsigned long long)__popcll(bal));
                 base = __shfl(base, leader, 64);
                 if (rel) {
-                    QEntry e; e.idx = (unsigned)(((j < 4 ? g0 : g1) << 2) + (j & 3)); e.rel = rel;
+                    QEntry e; e.idx = (unsigned)cidx; e.rel = rel; e.ci = q_ci; e.cj = q_cj; e.fx = q_fx; e.fy = q_fy;
+                    e.slots = q_slots; e.cnt = sa.cnt[cidx];
                     queue[base + __popcll(bal & ((1ull << lane) - 1ull))] = e;
                     n_rel += __popc(rel);
                 }
             }
         }
+    };
+    {
+        const bool w0 = t < 64;
+        if (w0 || SCAN_PRE < 1) f0 = ldg(g0);
+        if (w0 || SCAN_PRE < 2) f1 = ldg((long long)g0 + stride);
+        if (w0 || SCAN_PRE < 3) f2 = ldg((long long)g0 + 2 * stride);
+        if (w0 || SCAN_PRE < 4) f3 = ldg((long long)g0 + 3 * stride);
+    }
+    process(f0, f1, f2, f3, g0);
+    for (long long g = (long long)g0 + 4 * stride; g <= n4; g += 4 * stride) {
+        const int4 q0 = ldg(g), q1 = ldg(g + stride), q2 = ldg(g + 2 * stride), q3 = ldg(g + 3 * stride);
+        process(q0, q1, q2, q3, g);
     }
     n_rel = (unsigned long long)wave_sum_ll((long long)n_rel);
     if (lane == 0 && n_rel && !dry) atomicAdd(&counters[0], n_rel);
@@ -930,41 +1074,54 @@ __device__ __forceinline__ int sel_base(const int (&a)[MAXK + 1], int i)
 // and hands the sums out: to d_q_out (device; the caller all-reduces them) or, if host_res is given, to PINNED HOST
 // memory followed by the step's sequence number -- the host spins on that word instead of paying for a device->host
 // copy launch and a stream-synchronise wake-up.
-__global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, int K, int rank, int world,
+struct FinArgs { // first-needed pointers by value (see ScanArgs)
+    long long* tm_done;
+    const int* step_hdr;
+    unsigned long long* counters;
+    const QEntry* queue;
+    const NbTables* tabs;
+    const Geo* geo;
+    const Stat* stat;
+    long long* acc;
+};
+
+__global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinArgs fa, int K, int rank, int world,
                                               long long* __restrict__ d_q_out, volatile long long* host_res, long long seq)
 {
-    const NbTables* __restrict__ tabs = A->tabs;
-    const int* __restrict__ perm = A->perm;
-    const Geo* __restrict__ geo = A->geo;
-    const Stat* __restrict__ stat = A->stat;
-    const int* __restrict__ lcontbp = A->soa.p[F_LCONTBP];
-    const int* __restrict__ row = A->row;
-    const int* __restrict__ col = A->col;
-    const int* __restrict__ cnt = A->cnt;
-    const int* __restrict__ sub2bin = A->sub2bin_multi;
-    const QEntry* __restrict__ queue = A->queue;
-    const int* __restrict__ step_hdr = A->step_hdr;
-    long long* __restrict__ out = A->acc;
-    const float nfpb = A->nfpb;
-    const Par par = A->par;
-    const int reach_bp = A->reach_bp;
-    unsigned long long* __restrict__ counters = A->counters;
+    const NbTables* __restrict__ tabs = fa.tabs;
+    const Geo* __restrict__ geo = fa.geo;
+    const Stat* __restrict__ stat = fa.stat;
+    const QEntry* __restrict__ queue = fa.queue;
+    long long* __restrict__ out = fa.acc;
+    unsigned long long* __restrict__ counters = fa.counters;
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
-    // ---- wait for the tables (bounded spin: every wave reaches the exit even if k_tm never ran) ----
+    const unsigned long long nq_total = counters[2]; // written by k_scan, the previous kernel on the stream
+    // ---- wait for the tables (bounded spin: every wave reaches the exit even if k_tm never ran).  The word k_tm
+    // releases carries the neighbour's work list header with the sequence number: seq << 32 | priced << 31 | n_items ----
     __shared__ int s_ok;
+    __shared__ unsigned s_hdr[MAXK];
     if (threadIdx.x == 0) s_ok = 1;
+    if (threadIdx.x < MAXK) s_hdr[threadIdx.x] = 0x80000000u;
     __syncthreads();
     if ((int)threadIdx.x < K) {
         bool ok = false;
         for (int spin = 0; spin < (1 << 22); spin++) {
-            if ((long long)atomicAdd((unsigned long long*)&A->tm_done[threadIdx.x], 0ull) == seq) { ok = true; break; }
+            const unsigned long long w = (unsigned long long)__hip_atomic_load(&fa.tm_done[threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(w >> 32) == (unsigned)seq) { s_hdr[threadIdx.x] = (unsigned)w; ok = true; break; }
             __builtin_amdgcn_s_sleep(2);
         }
         if (!ok) { s_ok = 0; atomicOr((unsigned long long*)&counters[6], 1ull); }
     }
     __syncthreads();
-    __threadfence();
+    int n_items_k[MAXK], done_k[MAXK];
+#pragma unroll
+    for (int k = 0; k < MAXK; k++) { const unsigned w = s_hdr[k]; n_items_k[k] = (int)(w & 0x7fffffffu); done_k[k] = (int)(w >> 31); }
+    const int* __restrict__ perm = A->perm;
+    const int* __restrict__ lcontbp = A->soa.p[F_LCONTBP];
+    const float nfpb = A->nfpb;
+    const Par par = A->par;
+    const int reach_bp = A->reach_bp;
     if (s_ok) {
         unsigned long long items = 0;
         // one flat, fixed-order list of the work items this rank owns (local item w of a neighbour belongs to rank w % world),
@@ -974,11 +1131,10 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, int 
 #pragma unroll
         for (int k = 0; k < MAXK; k++) {
             int own = 0;
-            if (k < K && step_hdr[MAXK + k] == 0) { const int ni = step_hdr[k]; own = ni > rank ? (ni - rank + world - 1) / world : 0; }
+            if (k < K && done_k[k] == 0) { const int ni = n_items_k[k]; own = ni > rank ? (ni - rank + world - 1) / world : 0; }
             item_base[k + 1] = item_base[k] + own;
         }
         const int total_all = item_base[MAXK];
-        const unsigned long long nq_total = counters[2]; // written by k_scan, the previous kernel on the stream
         for (int W = wave; W < total_all; W += n_waves) {
             int k = 0;
 #pragma unroll
@@ -1050,30 +1206,26 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, int 
             const unsigned long long e = e0 + (lane >> 4);
             if (e >= nq_total || op >= N_OPS) continue;
             const QEntry qe = queue[e];
-            const int ra = row[qe.idx], ca = col[qe.idx];
-            int fx = ra, fy = ca, slx = 0, sly = 0;
-            if (sub2bin) { const int a = sub2bin[ra], b = sub2bin[ca]; fx = a >> 2; fy = b >> 2; slx = a & 3; sly = b & 3; }
-            const Geo gx = geo[fx], gy = geo[fy];
-            unsigned rel = qe.rel;
-            // candidates of this lane's op that change the relation of the two fragments
-            unsigned todo = 0;
+            const int fx = qe.fx, fy = qe.fy, slx = qe.slots & 3, sly = (qe.slots >> 2) & 3;
+            // candidates of this lane's op that change the relation of the two fragments (piece ids from the codes)
+            unsigned rel = qe.rel, todo = 0;
             while (rel) {
                 const int k = (__ffs((int)rel) - 1) >> 2;
                 rel &= rel - 1;
-                const NbTables& T = tabs[k];
-                const int p = piece_of(T.key, gx.id_c, geo_pos(gx.flags)), q = piece_of(T.key, gy.id_c, geo_pos(gy.flags));
-                if ((T.changed[op] >> (p * 8 + q)) & 1ull) todo |= 1u << k;
+                const int p = (qe.ci >> (4 * k)) & 7, q = (qe.cj >> (4 * k)) & 7;
+                if ((tabs[k].changed[op] >> (p * 8 + q)) & 1ull) todo |= 1u << k;
             }
             if (!todo) continue;
+            const Geo gx = geo[fx], gy = geo[fy];
             const Stat sx = stat[fx], sy = stat[fy];
             const End X0 = end_cur(gx, lcontbp, fx), Y0 = end_cur(gy, lcontbp, fy);
             const double ln_old = log((double)ex_pair(X0, sx, slx, Y0, sy, sly, nfpb, par));
-            const double ob = (double)cnt[qe.idx];
+            const double ob = (double)qe.cnt;
             while (todo) {
                 const int k = __ffs((int)todo) - 1;
                 todo &= todo - 1;
                 const NbTables& T = tabs[k];
-                const int p = piece_of(T.key, gx.id_c, geo_pos(gx.flags)), q = piece_of(T.key, gy.id_c, geo_pos(gy.flags));
+                const int p = (qe.ci >> (4 * k)) & 7, q = (qe.cj >> (4 * k)) & 7;
                 const End X = end_xf(gx, T.xf[op][p]), Y = end_xf(gy, T.xf[op][q]);
                 const double ln_new = log((double)ex_pair(X, sx, slx, Y, sy, sly, nfpb, par));
                 const long long qv = to_q(ob * (ln_new - ln_old));
@@ -1136,6 +1288,8 @@ struct Ctx {
     SoaPtr soa[2];
     int cur = 0;
     Geo* geo = nullptr;
+    Link* link = nullptr;
+    int* mates = nullptr;
     Stat* stat = nullptr;
     int* sub2bin = nullptr;
     int *row = nullptr, *col = nullptr, *cnt = nullptr;
@@ -1145,7 +1299,7 @@ struct Ctx {
     int max_lcont = 0;            // longest contig at the last graal_begin_step (sizes k_fin's grid)
     int* d_sub_ids = nullptr;     // [n_bins][4], only when some bin has more than one sub-fragment
     unsigned long long *keys = nullptr, *keys_sorted = nullptr;
-    int *o2n = nullptr, *perm = nullptr;
+    int *o2n = nullptr, *perm = nullptr, *cbase = nullptr;
     int *len_of2[2] = {nullptr, nullptr}, *contig_off2[2] = {nullptr, nullptr}; // per layout buffer (see k_incr_apply)
     Changed* d_chg = nullptr;
     IncrPlan* d_plan = nullptr;
@@ -1235,6 +1389,7 @@ int sync_args(Ctx* h)
         a[b].row = h->row; a[b].col = h->col; a[b].cnt = h->cnt; a[b].sub2bin = h->sub2bin;
         a[b].sub2bin_multi = h->single_sub ? nullptr : h->sub2bin; a[b].sub_ids = h->d_sub_ids;
         a[b].contig_off = h->contig_off2[b]; a[b].perm = h->perm; a[b].geo = h->geo; a[b].stat = h->stat;
+        a[b].link = h->link; a[b].cbase = h->cbase;
         a[b].tabs = h->tabs; a[b].step_hdr = h->step_hdr; a[b].tm_done = h->tm_done; a[b].acc = h->d_acc;
         a[b].queue = h->queue; a[b].counters = (unsigned long long*)(h->d_scalars + 10);
         a[b].nfpb = h->nfpb; a[b].par = h->par;
@@ -1245,7 +1400,7 @@ int sync_args(Ctx* h)
 
 int refresh(Ctx* h)
 {
-    k_refresh_geo<<<blocks_for(h->n, 256), 256, 0, h->stream>>>(h->soa[h->cur], h->geo, h->n);
+    k_refresh_geo<<<blocks_for(h->n, 256), 256, 0, h->stream>>>(h->soa[h->cur], h->geo, h->link, h->n);
     CK(hipGetLastError());
     return GRAAL_OK;
 }
@@ -1261,8 +1416,15 @@ int launch_scan(Ctx* h, const DevArgs* A, int fA, const Neigh& nb, int K, int ma
     const int nbk = (int)std::min<long long>((groups + 2 * scan_threads - 1) / (2 * scan_threads), scan_blocks);
     const size_t shm = (size_t)((h->n_sub_total + 31) / 32 + 2) * 4;
     if (shm > (size_t)SCAN_LDS_MAX) return fail(h, GRAAL_E_UNSUPPORTED, "more than 393,216 sub-fragments: the affected bitmap does not fit the scan's LDS budget");
-    if (h->single_sub) k_scan<true><<<nbk, scan_threads, shm, st>>>(A, fA, nb, K, max_id, dry);
-    else k_scan<false><<<nbk, scan_threads, shm, st>>>(A, fA, nb, K, max_id, dry);
+    ScanArgs sa;
+    sa.geo = h->geo; sa.link = h->link; sa.mates = h->mates; sa.cnt = h->cnt;
+    sa.cbase = h->cbase; sa.perm = h->perm; sa.sub_ids = h->d_sub_ids;
+    sa.row4 = reinterpret_cast<const int4*>(h->row); sa.nnz = h->nnz; sa.bitmap_words = (int)(shm / 4);
+    sa.col4 = reinterpret_cast<const int4*>(h->col); sa.geo2 = reinterpret_cast<const int2*>(h->geo); sa.sub2bin = h->sub2bin;
+    sa.queue = h->queue; sa.counters = (unsigned long long*)(h->d_scalars + 10);
+    (void)A;
+    if (h->single_sub) k_scan<true><<<nbk, scan_threads, shm, st>>>(sa, fA, nb, K, max_id, dry);
+    else k_scan<false><<<nbk, scan_threads, shm, st>>>(sa, fA, nb, K, max_id, dry);
     CK(hipGetLastError());
     return GRAAL_OK;
 }
@@ -1322,7 +1484,7 @@ void graal_destroy(graal_ctx* h)
         (void)hipStreamSynchronize(h->stream);
         if (h->aux) (void)hipStreamSynchronize(h->aux);
         void* ptrs[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->stat, h->sub2bin, h->row, h->col, h->cnt, h->queue, h->d_sub_ids, h->d_acc, h->tm_done,
-                        h->keys, h->keys_sorted, h->o2n, h->len_of2[0], h->len_of2[1], h->contig_off2[0], h->contig_off2[1], h->perm, h->cub_tmp, h->tabs, h->step_hdr, h->d_args, h->d_chg, h->d_plan,
+                        h->keys, h->keys_sorted, h->o2n, h->len_of2[0], h->len_of2[1], h->contig_off2[0], h->contig_off2[1], h->perm, h->cbase, h->link, h->mates, h->cub_tmp, h->tabs, h->step_hdr, h->d_args, h->d_chg, h->d_plan,
                         h->d_scalars, h->d_qout};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (h->h_res) (void)hipHostFree(h->h_res);
@@ -1433,7 +1595,7 @@ int graal_upload_frags(graal_ctx* h, const int32_t* const soa[GRAAL_N_FIELDS], i
             return fail(h, GRAAL_E_UNSUPPORTED, "repeats / inactive fragments are not supported yet");
     }
     if (h->n != n) {
-        void* old[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->keys, h->keys_sorted, h->o2n, h->len_of2[0], h->len_of2[1], h->contig_off2[0], h->contig_off2[1], h->perm, h->cub_tmp};
+        void* old[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->keys, h->keys_sorted, h->o2n, h->len_of2[0], h->len_of2[1], h->contig_off2[0], h->contig_off2[1], h->perm, h->cbase, h->link, h->mates, h->cub_tmp};
         for (void* p : old) if (p) (void)hipFree(p);
         for (int b = 0; b < 2; b++) {
             CK(hipMalloc(&h->soa_mem[b], sizeof(int) * (size_t)n * GRAAL_N_FIELDS));
@@ -1448,6 +1610,9 @@ int graal_upload_frags(graal_ctx* h, const int32_t* const soa[GRAAL_N_FIELDS], i
             CK(hipMalloc(&h->contig_off2[b], sizeof(int) * (size_t)(n + 2)));
         }
         CK(hipMalloc(&h->perm, sizeof(int) * (size_t)n));
+        CK(hipMalloc(&h->cbase, sizeof(int) * (size_t)n));
+        CK(hipMalloc(&h->link, sizeof(Link) * (size_t)n));
+        CK(hipMalloc(&h->mates, sizeof(int) * N_MATES * (size_t)n));
         size_t b1 = 0, b2 = 0;
         (void)hipcub::DeviceRadixSort::SortKeys(nullptr, b1, h->keys, h->keys_sorted, n, 0, 2 * LABEL_BITS, h->stream);
         (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b2, h->len_of2[0], h->contig_off2[0], n + 1, h->stream);
@@ -1514,7 +1679,8 @@ int graal_begin_step(graal_ctx* h, int64_t stats[8], int32_t* max_id)
         // exactly one commit since the last ranking: count instead of sort (rank arrays of buffer 1-cur -> buffer cur)
         k_incr_plan<<<1, 64, 0, h->stream>>>(h->d_chg, h->len_of2[1 - cur], h->contig_off2[1 - cur], h->n_contigs, n, h->d_plan);
         k_incr_apply<<<blocks_for(n + 1, bs), bs, 0, h->stream>>>(s, n, h->d_plan, h->len_of2[1 - cur], h->contig_off2[1 - cur],
-                                                                 h->len_of2[cur], h->contig_off2[cur], h->perm, h->geo);
+                                                                 h->len_of2[cur], h->contig_off2[cur], h->perm, h->cbase, h->geo, h->link);
+        k_mates<<<nb, bs, 0, h->stream>>>(n, h->perm, h->cbase, h->link, h->mates);
         CK(hipGetLastError());
     } else {
         k_relabel_keys<<<nb, bs, 0, h->stream>>>(s, n, h->keys);
@@ -1526,10 +1692,12 @@ int graal_begin_step(graal_ctx* h, int64_t stats[8], int32_t* max_id)
         CK(hipGetLastError());
         tb = h->cub_tmp_bytes;
         CK(hipcub::DeviceScan::ExclusiveSum(h->cub_tmp, tb, h->len_of2[cur], h->contig_off2[cur], n + 1, h->stream));
-        k_build_perm<<<nb, bs, 0, h->stream>>>(s, n, h->contig_off2[cur], h->perm);
+        k_build_perm<<<nb, bs, 0, h->stream>>>(s, n, h->contig_off2[cur], h->perm, h->cbase);
         CK(hipGetLastError());
         int rc = refresh(h);
         if (rc) return rc;
+        k_mates<<<nb, bs, 0, h->stream>>>(n, h->perm, h->cbase, h->link, h->mates);
+        CK(hipGetLastError());
     }
     long long res[16];
     CK(hipMemcpyAsync(res, h->d_scalars, sizeof res, hipMemcpyDeviceToHost, h->stream));
@@ -1597,7 +1765,10 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     // (1) tables + small mass work on the auxiliary stream: overlaps the scan.  A previous asynchronous evaluation must
     // have finished with the tables first (the synchronous path has waited for its results already).
     if (h->fin_pending) { CK(hipStreamWaitEvent(h->aux, h->ev_fin, 0)); h->fin_pending = false; }
-    k_tm<<<K, 256, 0, h->aux>>>(A, fA, nb, K, max_id, rank, world, h->seq);
+    static const bool tm_serial = getenv("GRAAL_TM_SERIAL") != nullptr; // experiment: tables before the scan, same stream
+    TmArgs ta;
+    ta.geo = h->geo; ta.link = h->link; ta.cbase = h->cbase; ta.tabs = h->tabs; ta.step_hdr = h->step_hdr;
+    k_tm<<<K, 256, 0, tm_serial ? st : h->aux>>>(A, ta, fA, nb, K, max_id, rank, world, h->seq);
     CK(hipGetLastError());
     // (2) the streaming pass
     const size_t slot = (size_t)(h->ring_calls % (long long)(h->ring.size() / 2));
@@ -1608,7 +1779,10 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     // keeps its launch and completion ticket cheap; long contigs get the whole chip.
     static const int fin_blocks_env = getenv("GRAAL_FIN_BLOCKS") ? atoi(getenv("GRAAL_FIN_BLOCKS")) : 0;
     const int fin_blocks = fin_blocks_env > 0 ? fin_blocks_env : (h->max_lcont > 0 && h->max_lcont <= 16 ? 32 : 512);
-    k_fin<<<fin_blocks, 256, 0, st>>>(A, K, rank, world, (long long*)d_q_out, h->publish ? h->h_res : nullptr, h->seq);
+    FinArgs fa;
+    fa.tm_done = h->tm_done; fa.step_hdr = h->step_hdr; fa.counters = (unsigned long long*)(h->d_scalars + 10); fa.queue = h->queue;
+    fa.tabs = h->tabs; fa.geo = h->geo; fa.stat = h->stat; fa.acc = h->d_acc;
+    k_fin<<<fin_blocks, 256, 0, st>>>(A, fa, K, rank, world, (long long*)d_q_out, h->publish ? h->h_res : nullptr, h->seq);
     CK(hipGetLastError());
     if (!h->publish) { CK(hipEventRecord(h->ev_fin, st)); h->fin_pending = true; }
     h->timing_valid = h->want_events;
@@ -1709,7 +1883,8 @@ int graal_time_scan(graal_ctx* h, int32_t K, int32_t reps, float* avg_ms)
     for (int k = 0; k < MAXK; k++) nb.fB[k] = h->last_fB[k];
     for (int i = 0; i < 3; i++) { int rc = launch_scan(h, A, h->last_fA, nb, K, h->last_max_id, 1, h->stream); if (rc) return rc; }
     CK(hipEventRecord(h->ev[0], h->stream));
-    for (int i = 0; i < reps; i++) { int rc = launch_scan(h, A, h->last_fA, nb, K, h->last_max_id, 1, h->stream); if (rc) return rc; }
+    static const int dry_mode = getenv("GRAAL_DRY") ? atoi(getenv("GRAAL_DRY")) : 1;
+    for (int i = 0; i < reps; i++) { int rc = launch_scan(h, A, h->last_fA, nb, K, h->last_max_id, dry_mode, h->stream); if (rc) return rc; }
     CK(hipEventRecord(h->ev[4], h->stream));
     CK(hipEventSynchronize(h->ev[4]));
     float ms = 0.0f;
