@@ -485,32 +485,34 @@ struct NbTables {        // everything the finishing kernel needs about one neig
 };
 
 struct Neigh { int fB[MAXK]; };
+constexpr int FLAG_STRIDE = 32; // words between two blocks' completion flags: one 128-byte line each (partial writes to one
+                                // line from many XCDs serialise at the memory side)
 
-// exclusive prefix sum of vals[0..n) into out[0..n) and the total into out[n]; vals / out in LDS, whole block calls it
-__device__ void block_excl_scan(const int* vals, int* out, int n)
+// Debug build (-DGRAAL_STAMPS): selected threads write the 100 MHz wall clock at a few points of the per-step kernels
+#ifdef GRAAL_STAMPS
+__device__ unsigned long long g_stamps[32];
+#define STAMP(i, cond) do { if (cond) g_stamps[i] = wall_clock64(); } while (0)
+#else
+#define STAMP(i, cond) do { } while (0)
+#endif
+
+// exclusive prefix sum of vals[0..n) into out[0..n) and the total into out[n]; vals / out in LDS.  Executed by ONE wave
+// (all 64 lanes of it), no block barrier inside: a few hundred entries are cheaper to scan in one wave than to
+// synchronise four waves around.  The caller puts __syncthreads() before (vals complete) and after (out visible).
+__device__ __forceinline__ void wave_excl_scan(const int* vals, int* out, int n)
 {
-    __shared__ int s_wtot[16];
-    __shared__ int s_carry;
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6, nw = blockDim.x >> 6;
-    if (t == 0) s_carry = 0;
-    __syncthreads();
-    for (int base = 0; base < n; base += blockDim.x) {
-        const int i = base + t;
+    const int lane = threadIdx.x & 63;
+    int carry = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
         const int v = i < n ? vals[i] : 0;
         int x = v;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
-        if (lane == 63) s_wtot[w] = x;
-        __syncthreads();
-        int off = s_carry;
-        for (int j = 0; j < w; j++) off += s_wtot[j];
-        if (i < n) out[i] = off + x - v;
-        __syncthreads();
-        if (t == 0) { int tot = 0; for (int j = 0; j < nw; j++) tot += s_wtot[j]; s_carry += tot; }
-        __syncthreads();
+        if (i < n) out[i] = carry + x - v;
+        carry += __shfl(x, 63, 64);
     }
-    if (t == 0) out[n] = s_carry;
-    __syncthreads();
+    if (lane == 0) out[n] = carry;
 }
 
 __device__ __forceinline__ void pair_of_index(int idx, int& p, int& q)
@@ -562,6 +564,7 @@ __device__ int tables_block(const Geo* __restrict__ geo, const Link* __restrict_
         }
         for (int p = 0; p < NP; p++) { T.lo[p] = s_lo[p]; T.hi[p] = s_hi[p]; T.contig[p] = s_contig[p]; }
     }
+    STAMP(24, k == 0 && t == 0); // A0 / B0 loaded
     if (t < N_OPS) changed[t] = 0;
     for (int e = t; e < NENT; e += blockDim.x) { e_valid[e] = 0; e_plus[e] = 0; e_minus[e] = 0; e_owner[e] = e; e_slot[e] = -1; }
     __syncthreads();
@@ -571,6 +574,7 @@ __device__ int tables_block(const Geo* __restrict__ geo, const Link* __restrict_
         s_cbase[t] = s_contig[t] < 0 ? 0 : (s_contig[t] == A0.id_c ? s_baseA : s_baseB);
     }
     __syncthreads();
+    STAMP(25, k == 0 && t == 0); // representatives loaded
     // transforms: one thread per (op, piece)
     if (t < N_OPS * NP) {
         const int op = t / NP, p = t % NP;
@@ -585,6 +589,7 @@ __device__ int tables_block(const Geo* __restrict__ geo, const Link* __restrict_
         T.xf[op][p] = x;
     }
     __syncthreads();
+    STAMP(26, k == 0 && t == 0); // transforms
     // relations: one thread per (op, p <= q)
     for (int e = t; e < N_OPS * NPAIR; e += blockDim.x) {
         const int op = e / NPAIR;
@@ -601,6 +606,7 @@ __device__ int tables_block(const Geo* __restrict__ geo, const Link* __restrict_
         if (xf[op][p].label == xf[op][q].label) { e_valid[NPAIR + e] = 1; atomicOr(&e_plus[NPAIR + e], 1u << op); }
     }
     __syncthreads();
+    STAMP(27, k == 0 && t == 0); // relations
     // dedupe new-relation entries against every earlier entry with the same relative geometry
     for (int e = NPAIR + t; e < NENT; e += blockDim.x) {
         if (!e_valid[e]) continue;
@@ -626,13 +632,16 @@ __device__ int tables_block(const Geo* __restrict__ geo, const Link* __restrict_
     for (int e = NPAIR + t; e < NENT; e += blockDim.x)
         if (e_valid[e] && e_owner[e] != e) { atomicOr(&e_plus[e_owner[e]], e_plus[e]); }
     __syncthreads();
+    STAMP(28, k == 0 && t == 0); // dedupe
     // slots of the surviving (owner) entries, in entry order
     for (int e = t; e < NENT; e += blockDim.x) e_flag[e] = (e_valid[e] && e_owner[e] == e) ? 1 : 0;
     __syncthreads();
-    block_excl_scan(e_flag, s_start, NENT); // s_start used as scratch: slot of entry e
+    if (t < 64) wave_excl_scan(e_flag, s_start, NENT); // s_start used as scratch: slot of entry e
+    __syncthreads();
     const int n_tasks = s_start[NENT];
     for (int e = t; e < NENT; e += blockDim.x) if (e_flag[e]) e_slot[e] = s_start[e];
     __syncthreads();
+    STAMP(29, k == 0 && t == 0); // slots
     if (t == 0) {
         T.n_tasks = n_tasks;
         T.intra_any = intra_any;
@@ -656,21 +665,26 @@ __device__ int tables_block(const Geo* __restrict__ geo, const Link* __restrict_
         tk.base_q = s_cbase[tk.q] + s_lo[tk.q];
         const int slot = e_slot[e];
         s_task[slot] = tk;
-        T.task[slot] = tk;
         s_chunks[slot] = (tk.np + 63) / 64;
         const long long pr = (long long)tk.np * (long long)(tk.p == tk.q ? tk.np : tk.nq);
         s_pairs[slot] = pr > (1 << 20) ? (1 << 20) : (int)pr; // saturated: only compared with INLINE_PAIRS
     }
     __syncthreads();
-    // work list: chunks of 64 fragments of the task's first piece, tasks in slot order (fixed order)
-    block_excl_scan(s_chunks, s_start, n_tasks);
-    block_excl_scan(s_pairs, s_pp, n_tasks);
+    STAMP(30, k == 0 && t == 0); // tasks in LDS
+    // fragment-pair prefix (for the block's own pricing) and work list (chunks of 64 fragments of the task's first piece,
+    // tasks in slot order = a fixed order), one wave each
+    if (t < 64) wave_excl_scan(s_pairs, s_pp, n_tasks);
+    else if (t < 128) wave_excl_scan(s_chunks, s_start, n_tasks);
+    __syncthreads();
     const int n_items = s_start[n_tasks];
     if (t == 0) { T.n_items = n_items; step_hdr[k] = n_items; }
-    for (int i = t; i <= n_tasks; i += blockDim.x) T.item_start[i] = s_start[i];
-    if (n_items <= ITEM_CAP)
-        for (int i = t; i < n_tasks; i += blockDim.x)
-            for (int w = s_start[i]; w < s_start[i + 1]; w++) T.item_tc[w] = (unsigned)i | ((unsigned)(w - s_start[i]) << 16);
+    if (s_pp[n_tasks] > INLINE_PAIRS) { // k_fin will price this neighbour: it needs the tasks and the work list in memory
+        for (int i = t; i < n_tasks; i += blockDim.x) T.task[i] = s_task[i];
+        for (int i = t; i <= n_tasks; i += blockDim.x) T.item_start[i] = s_start[i];
+        if (n_items <= ITEM_CAP)
+            for (int i = t; i < n_tasks; i += blockDim.x)
+                for (int w = s_start[i]; w < s_start[i + 1]; w++) T.item_tc[w] = (unsigned)i | ((unsigned)(w - s_start[i]) << 16);
+    }
     return n_tasks;
 }
 
@@ -722,6 +736,78 @@ __device__ __forceinline__ int gap_bp(const End& X, int len_x, const End& Y, int
     return X.start_bp < Y.start_bp ? Y.start_bp - (X.start_bp + len_x) : X.start_bp - (Y.start_bp + len_y);
 }
 
+
+// the queued contacts: 16 lanes per contact (lane & 15 = candidate op), 4 contacts per wave pass.  Everything a contact
+// needs is addressable from its queue entry, so the loads below go out together: entry -> {relation masks, geometry,
+// statistics, transforms} -> arithmetic.
+struct PriceArgs {
+    const QEntry* queue;
+    const NbTables* tabs;
+    const Geo* geo;
+    const Stat* stat;
+    const int* lcontbp;
+    long long* out;
+    float nfpb;
+    Par par;
+};
+__device__ __forceinline__ void price_contacts(const PriceArgs& pa, unsigned long long nq_total, int first, int n_waves, int lane)
+{
+    const int op = lane & 15;
+    for (unsigned long long e0 = (unsigned long long)first * 4; e0 < nq_total; e0 += (unsigned long long)n_waves * 4) {
+        const unsigned long long e = e0 + (lane >> 4);
+        if (e >= nq_total || op >= N_OPS) continue;
+        const QEntry qe = pa.queue[e];
+        const int fx = qe.fx, fy = qe.fy, slx = qe.slots & 3, sly = (qe.slots >> 2) & 3;
+        // speculative: geometry and statistics are needed by (nearly) every queued contact
+        const Geo gx = pa.geo[fx], gy = pa.geo[fy];
+        const Stat sx = pa.stat[fx], sy = pa.stat[fy];
+        // candidates of this lane's op that change the relation of the two fragments (piece ids from the codes)
+        unsigned rel = qe.rel, todo = 0;
+        while (rel) {
+            const int k = (__ffs((int)rel) - 1) >> 2;
+            rel &= rel - 1;
+            const int p = (qe.ci >> (4 * k)) & 7, q = (qe.cj >> (4 * k)) & 7;
+            if ((pa.tabs[k].changed[op] >> (p * 8 + q)) & 1ull) todo |= 1u << k;
+        }
+        if (!todo) continue;
+        const End X0 = end_cur(gx, pa.lcontbp, fx), Y0 = end_cur(gy, pa.lcontbp, fy);
+        const double ln_old = log((double)ex_pair(X0, sx, slx, Y0, sy, sly, pa.nfpb, pa.par));
+        const double ob = (double)qe.cnt;
+        while (todo) {
+            const int k = __ffs((int)todo) - 1;
+            todo &= todo - 1;
+            const NbTables& T = pa.tabs[k];
+            const int p = (qe.ci >> (4 * k)) & 7, q = (qe.cj >> (4 * k)) & 7;
+            const End X = end_xf(gx, T.xf[op][p]), Y = end_xf(gy, T.xf[op][q]);
+            const double ln_new = log((double)ex_pair(X, sx, slx, Y, sy, sly, pa.nfpb, pa.par));
+            const long long qv = to_q(ob * (ln_new - ln_old));
+            if (qv != 0) atomicAdd((unsigned long long*)&pa.out[k * N_OPS + op], (unsigned long long)qv);
+        }
+    }
+}
+
+// the last block of a step: read the K*13 sums, reset the accumulators and counters for the next step, hand the sums
+// out -- to d_q_out (device; the caller all-reduces them) or to PINNED HOST memory followed by the step's sequence
+// number (the host spins on that word instead of paying for a device->host copy and a stream-synchronise wake-up).
+// sync[0] = k_tm ticket, sync[1] = finished k_scan blocks.
+__device__ __forceinline__ void hand_out(long long* out, unsigned long long* counters, unsigned long long* sync, int K,
+                                         long long* d_q_out, volatile long long* host_res, long long seq)
+{
+    const bool failed = atomicAdd(&counters[6], 0ull) != 0ull;
+    for (int i = threadIdx.x; i < K * N_OPS; i += blockDim.x) {
+        const long long v = (long long)atomicExch((unsigned long long*)&out[i], 0ull); // read the final sum, reset for the next step
+        if (host_res) host_res[1 + i] = v; else d_q_out[i] = v;
+    }
+    if (threadIdx.x < 3) counters[8 + threadIdx.x] = atomicExch(&counters[threadIdx.x], 0ull);
+    if (threadIdx.x == 3) { counters[5] = 0; counters[6] = 0; sync[0] = 0; }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0 && host_res) { host_res[0] = failed ? -seq : seq; __threadfence_system(); }
+}
+
+constexpr long long NEED_FIN = 1ll << 62; // published instead of the sums: k_tm left work for k_fin, launch it
+constexpr int FIN_INLINE_Q = 64;          // queued contacts the finishing block of k_tm prices itself
+
 // ------------------------------------------------------------------ per-step kernels
 // k_tm (K blocks, launched on the auxiliary stream so that it overlaps k_scan): block k builds the tables of neighbour k
 // and, when the expected-mass work of that neighbour is small (<= INLINE_PAIRS fragment pairs: the regime of short
@@ -741,8 +827,24 @@ struct TmArgs { // first-needed pointers by value (see ScanArgs)
     const int* cbase;
     NbTables* tabs;
     int* step_hdr;
+    unsigned long long* sync;      // [0] k_tm ticket (+ 2^16 per neighbour left to k_fin)
+    const unsigned* flags;         // k_scan's per-block completion flags
+    volatile long long* host_res;  // non-null: the last block of k_tm finishes the step itself when the work is small
+    int n_scan_blocks;
+    // the finishing block's pointers, by value too
+    unsigned long long* counters;
+    const QEntry* queue;
+    const Stat* stat;
+    const int* lcontbp;
+    long long* acc;
+    float nfpb;
+    Par par;
 };
 
+// In the regime of short contigs a step leaves a handful of queued contacts and no mass work beyond what the table
+// blocks price themselves.  Then the LAST table block to finish waits for k_scan's blocks (a counter), prices the queued
+// contacts and publishes the result: no third kernel, no launch gap.  Otherwise it publishes NEED_FIN and the host launches
+// k_fin with the whole chip.
 __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArgs ta, int fA, Neigh nb, int K, int max_id, int rank,
                                              int world, long long seq)
 {
@@ -750,11 +852,13 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
     __shared__ int s_pp[MAX_TASKS + 1];
     const int k = blockIdx.x, t = threadIdx.x;
     if (k >= K) return;
+    STAMP(0, k == 0 && t == 0);
     NbTables& T = ta.tabs[k];
     const int my_fB = sel8(nb.fB[0], nb.fB[1], nb.fB[2], nb.fB[3], nb.fB[4], nb.fB[5], nb.fB[6], nb.fB[7], k);
     const int n_tasks = tables_block(ta.geo, ta.link, ta.cbase, fA, my_fB, max_id, T, k, ta.step_hdr, s_task, s_pp);
     const int total = s_pp[n_tasks];
     const bool inl = total <= INLINE_PAIRS;
+    STAMP(1, k == 0 && t == 0);
     if (inl && total > 0) {
         const int* __restrict__ perm = A->perm;
         const Geo* __restrict__ geo = ta.geo;
@@ -791,13 +895,63 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
         }
     }
     __syncthreads();
+    STAMP(2, k == 0 && t == 0);
     if (t == 0) {
         if (inl && rank == 0) atomicAdd(&A->counters[1], (unsigned long long)ta.step_hdr[k]);
         ta.step_hdr[MAXK + k] = inl ? 1 : 0;
         // release: the tables of neighbour k are complete; the word carries the work-list header for k_fin
         const unsigned long long w = ((unsigned long long)(unsigned)seq << 32) | (inl ? 0x80000000ull : 0ull) | (unsigned long long)(unsigned)ta.step_hdr[k];
         __hip_atomic_store((unsigned long long*)&A->tm_done[k], w, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        STAMP(3, k == 0);
     }
+    if (ta.host_res == nullptr) return;
+    // ---- finisher: the last table block ----
+    __shared__ int s_fin; // 0 = not the last block, 1 = finish here, 2 = leave it to k_fin
+    __shared__ unsigned long long s_nq;
+    if (t == 0) {
+        int mode = 0;
+        __threadfence();
+        // one atomic: count of finished table blocks in the low 16 bits, neighbours left to k_fin above
+        const unsigned long long ticket = atomicAdd(&ta.sync[0], inl ? 1ull : (1ull + (1ull << 16)));
+        const unsigned long long after = ticket + (inl ? 1ull : (1ull + (1ull << 16)));
+        if ((after & 0xffffull) == (unsigned long long)K) mode = (after >> 16) ? 2 : 1;
+        s_fin = mode;
+    }
+    __syncthreads();
+    if (s_fin == 0) return;
+    {   // all blocks of k_scan done?  Every thread polls its share of the flags (bounded: every wave reaches the exit)
+        bool ok = false;
+        for (int spin = 0; spin < (1 << 22); spin++) {
+            bool mine = true;
+            for (int b = t; b < ta.n_scan_blocks; b += (int)blockDim.x)
+                mine = mine && (__hip_atomic_load(&ta.flags[FLAG_STRIDE * b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)seq);
+            if (__syncthreads_and(mine)) { ok = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (t == 0) {
+            if (!ok) atomicOr(&ta.counters[6], 1ull);
+            s_nq = ok ? __hip_atomic_load(&ta.counters[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            if (ok && s_nq > (unsigned long long)FIN_INLINE_Q) s_fin = 2;
+            if (!ok) s_fin = 1;
+        }
+    }
+    __syncthreads();
+    STAMP(4, t == 0);
+    if (s_fin == 2) { // (nothing was reset: k_fin finds the step as k_scan and k_tm left it)
+        if (t == 0) { ta.sync[0] = 0; __threadfence_system(); ta.host_res[0] = seq | NEED_FIN; __threadfence_system(); }
+        return;
+    }
+    {
+        PriceArgs pa;
+        pa.queue = ta.queue; pa.tabs = ta.tabs; pa.geo = ta.geo; pa.stat = ta.stat; pa.lcontbp = ta.lcontbp;
+        pa.out = ta.acc; pa.nfpb = ta.nfpb; pa.par = ta.par;
+        price_contacts(pa, s_nq, t >> 6, (int)(blockDim.x >> 6), t & 63);
+    }
+    __syncthreads(); // (waits for this block's atomics: they are complete, at the memory side, before hand_out reads the sums)
+    STAMP(5, t == 0);
+    hand_out(ta.acc, ta.counters, ta.sync, K, nullptr, ta.host_res, seq);
+    STAMP(6, t == 0);
 }
 
 // 16-byte streaming (nontemporal) load
@@ -866,6 +1020,8 @@ struct ScanArgs { // by value: kernel-argument pointers are known to be GLOBAL (
     const int2* geo2;             // (id_c, flags) = first half of a Geo record
     QEntry* queue;
     unsigned long long* counters;
+    unsigned* flags;              // [block] sequence number of the last step this block finished
+    unsigned seq32;
     long long nnz;
     int bitmap_words;
 };
@@ -878,8 +1034,10 @@ __global__ __launch_bounds__(1024) void k_scan(ScanArgs sa, int fA, Neigh nb, in
     __shared__ StepKeys S;
     __shared__ Rec s_rec[MAXK + 1];
     __shared__ int s_cbase[MAXK + 1], s_clen[MAXK + 1], s_pref[MAXK + 2], s_fB[MAXK], s_mates[MAXK + 1][N_MATES];
+    __shared__ int s_waves_done;
     const int t = threadIdx.x;
     const int lane = t & 63;
+    STAMP(8, blockIdx.x == 0 && t == 0 && !dry);
     // ---- prologue: keys of the K neighbours and the affected bitmap.  Its dependent loads (fragment records -> position
     // index) go out first; the first row words are requested right behind them, so the stream is already running while
     // the bitmap is built ----
@@ -887,7 +1045,6 @@ __global__ __launch_bounds__(1024) void k_scan(ScanArgs sa, int fA, Neigh nb, in
     const int my_fB = sel8(nb.fB[0], nb.fB[1], nb.fB[2], nb.fB[3], nb.fB[4], nb.fB[5], nb.fB[6], nb.fB[7], t & 7);
     const int my_fPrev = sel8(fA, nb.fB[0], nb.fB[1], nb.fB[2], nb.fB[3], nb.fB[4], nb.fB[5], nb.fB[6], t & 7);
     int my_cbase = 0;
-    if (dry >= 3) K = 0; // experiment: no neighbours at all
     if (t <= K) {
         const int f = t == 8 ? nb.fB[7] : my_fPrev; // t == 0: fA, t >= 1: fB[t - 1]
         const Geo g = sa.geo[f];
@@ -916,7 +1073,7 @@ __global__ __launch_bounds__(1024) void k_scan(ScanArgs sa, int fA, Neigh nb, in
         if (SCAN_PRE > 2) f2 = ldg((long long)g0 + 2 * stride);
         if (SCAN_PRE > 3) f3 = ldg((long long)g0 + 3 * stride);
     }
-    if (t == 0) { S.live = 0; S.intra = 0; }
+    if (t == 0) { S.live = 0; S.intra = 0; s_waves_done = 0; }
     for (int i = t; i < sa.bitmap_words; i += blockDim.x) s_bm[i] = 0;
     if (t <= K) s_cbase[t] = my_cbase;
     if (t < MAXK) s_fB[t] = my_fB;
@@ -933,9 +1090,9 @@ __global__ __launch_bounds__(1024) void k_scan(ScanArgs sa, int fA, Neigh nb, in
             if (circ_may_change(fA, fB, max_id, A0, B0)) atomicOr(&S.intra, 1u << (4 * t));
             for (int j = 0; j < t; j++) if (s_fB[j] != fA && s_rec[j + 1].id_c == B0.id_c) dup = true;
         }
-        s_clen[t + 1] = (dup || dry >= 2) ? 0 : B0.l_cont;
+        s_clen[t + 1] = dup ? 0 : B0.l_cont;
     }
-    if (t == 0) s_clen[0] = dry >= 2 ? 0 : s_rec[0].l_cont; // experiment (dry >= 2): empty bitmap, no position-index hop
+    if (t == 0) s_clen[0] = s_rec[0].l_cont;
     __syncthreads();
     if (t == 0) { int acc = 0; for (int j = 0; j <= K; j++) { s_pref[j] = acc; acc += s_clen[j]; } s_pref[K + 1] = acc; }
     __syncthreads();
@@ -965,6 +1122,7 @@ __global__ __launch_bounds__(1024) void k_scan(ScanArgs sa, int fA, Neigh nb, in
     __syncthreads();
     const unsigned intra = S.intra;
     unsigned long long n_rel = 0;
+    STAMP(9, blockIdx.x == 0 && t == 0 && !dry);
     // one iteration: four groups of 4 contacts (ga + i * stride)
     auto process = [&](const int4 r0, const int4 r1, const int4 r2, const int4 r3, const long long ga) {
         const int r[16] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
@@ -1035,9 +1193,14 @@ __global__ __launch_bounds__(1024) void k_scan(ScanArgs sa, int fA, Neigh nb, in
                 if (lane == leader) base = atomicAdd(&counters[2], (unsigned long long)__popcll(bal));
                 base = __shfl(base, leader, 64);
                 if (rel) {
-                    QEntry e; e.idx = (unsigned)cidx; e.rel = rel; e.ci = q_ci; e.cj = q_cj; e.fx = q_fx; e.fy = q_fy;
-                    e.slots = q_slots; e.cnt = sa.cnt[cidx];
-                    queue[base + __popcll(bal & ((1ull << lane) - 1ull))] = e;
+                    // device-scope (write-through) stores: the entry must reach the reader -- possibly a block of k_tm on
+                    // another XCD -- without an L2 write-back fence, which costs this kernel several microseconds
+                    unsigned long long* qw = reinterpret_cast<unsigned long long*>(queue + base + __popcll(bal & ((1ull << lane) - 1ull)));
+                    const unsigned cnt_w = (unsigned)sa.cnt[cidx];
+                    __hip_atomic_store(qw + 0, (unsigned long long)(unsigned)cidx | ((unsigned long long)rel << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(qw + 1, (unsigned long long)q_ci | ((unsigned long long)q_cj << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(qw + 2, (unsigned long long)(unsigned)q_fx | ((unsigned long long)(unsigned)q_fy << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(qw + 3, (unsigned long long)cnt_w | ((unsigned long long)(unsigned)q_slots << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     n_rel += __popc(rel);
                 }
             }
@@ -1055,8 +1218,19 @@ __global__ __launch_bounds__(1024) void k_scan(ScanArgs sa, int fA, Neigh nb, in
         const int4 q0 = ldg(g), q1 = ldg(g + stride), q2 = ldg(g + 2 * stride), q3 = ldg(g + 3 * stride);
         process(q0, q1, q2, q3, g);
     }
+    STAMP(10, blockIdx.x == 0 && t == 0 && !dry);
     n_rel = (unsigned long long)wave_sum_ll((long long)n_rel);
     if (lane == 0 && n_rel && !dry) atomicAdd(&counters[0], n_rel);
+    if (dry == 0) {
+        // completion flag for k_tm's finishing block: one word (on its own cache line) per block holding the step's
+        // sequence number -- a shared counter would serialise 512 device-scope atomics at the memory side.  No block
+        // barrier here (a trailing __syncthreads measurably costs this kernel 5 us): each wave waits for its own
+        // (write-through) queue stores and counts itself in LDS; the last wave of the block writes the flag.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        int last = 0;
+        if (lane == 0) last = (atomicAdd(&s_waves_done, 1) == (int)(blockDim.x >> 6) - 1);
+        if (last) __hip_atomic_store(sa.flags + FLAG_STRIDE * blockIdx.x, sa.seq32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 __device__ __forceinline__ int sel_base(const int (&a)[MAXK + 1], int i)
@@ -1083,6 +1257,7 @@ struct FinArgs { // first-needed pointers by value (see ScanArgs)
     const Geo* geo;
     const Stat* stat;
     long long* acc;
+    unsigned long long* sync;
 };
 
 __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinArgs fa, int K, int rank, int world,
@@ -1096,6 +1271,7 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
     unsigned long long* __restrict__ counters = fa.counters;
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
+    STAMP(16, blockIdx.x == 0 && threadIdx.x == 0);
     const unsigned long long nq_total = counters[2]; // written by k_scan, the previous kernel on the stream
     // ---- wait for the tables (bounded spin: every wave reaches the exit even if k_tm never ran).  The word k_tm
     // releases carries the neighbour's work list header with the sequence number: seq << 32 | priced << 31 | n_items ----
@@ -1114,6 +1290,7 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
         if (!ok) { s_ok = 0; atomicOr((unsigned long long*)&counters[6], 1ull); }
     }
     __syncthreads();
+    STAMP(17, blockIdx.x == 0 && threadIdx.x == 0);
     int n_items_k[MAXK], done_k[MAXK];
 #pragma unroll
     for (int k = 0; k < MAXK; k++) { const unsigned w = s_hdr[k]; n_items_k[k] = (int)(w & 0x7fffffffu); done_k[k] = (int)(w >> 31); }
@@ -1199,43 +1376,16 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
             }
         }
         if (lane == 0 && items) atomicAdd(&counters[1], items);
-        // ---- queued contacts: 4 per wave pass, lane & 15 = candidate op; taken from the far end of the grid so that they
-        // do not queue up behind the mass items of the low-numbered blocks ----
-        const int op = lane & 15;
-        for (unsigned long long e0 = (unsigned long long)(n_waves - 1 - wave) * 4; e0 < nq_total; e0 += (unsigned long long)n_waves * 4) {
-            const unsigned long long e = e0 + (lane >> 4);
-            if (e >= nq_total || op >= N_OPS) continue;
-            const QEntry qe = queue[e];
-            const int fx = qe.fx, fy = qe.fy, slx = qe.slots & 3, sly = (qe.slots >> 2) & 3;
-            // candidates of this lane's op that change the relation of the two fragments (piece ids from the codes)
-            unsigned rel = qe.rel, todo = 0;
-            while (rel) {
-                const int k = (__ffs((int)rel) - 1) >> 2;
-                rel &= rel - 1;
-                const int p = (qe.ci >> (4 * k)) & 7, q = (qe.cj >> (4 * k)) & 7;
-                if ((tabs[k].changed[op] >> (p * 8 + q)) & 1ull) todo |= 1u << k;
-            }
-            if (!todo) continue;
-            const Geo gx = geo[fx], gy = geo[fy];
-            const Stat sx = stat[fx], sy = stat[fy];
-            const End X0 = end_cur(gx, lcontbp, fx), Y0 = end_cur(gy, lcontbp, fy);
-            const double ln_old = log((double)ex_pair(X0, sx, slx, Y0, sy, sly, nfpb, par));
-            const double ob = (double)qe.cnt;
-            while (todo) {
-                const int k = __ffs((int)todo) - 1;
-                todo &= todo - 1;
-                const NbTables& T = tabs[k];
-                const int p = (qe.ci >> (4 * k)) & 7, q = (qe.cj >> (4 * k)) & 7;
-                const End X = end_xf(gx, T.xf[op][p]), Y = end_xf(gy, T.xf[op][q]);
-                const double ln_new = log((double)ex_pair(X, sx, slx, Y, sy, sly, nfpb, par));
-                const long long qv = to_q(ob * (ln_new - ln_old));
-                if (qv != 0) atomicAdd((unsigned long long*)&out[k * N_OPS + op], (unsigned long long)qv);
-            }
-        }
+        // ---- queued contacts, taken from the far end of the grid so that they do not queue up behind the mass items of
+        // the low-numbered blocks ----
+        PriceArgs pa;
+        pa.queue = queue; pa.tabs = tabs; pa.geo = geo; pa.stat = stat; pa.lcontbp = lcontbp; pa.out = out; pa.nfpb = nfpb; pa.par = par;
+        price_contacts(pa, nq_total, n_waves - 1 - wave, n_waves, lane);
     }
     // ---- completion ticket: every block releases its atomics, the last one hands the sums out ----
     __shared__ int s_last;
     __syncthreads();
+    STAMP(18, blockIdx.x == gridDim.x - 1 && threadIdx.x == 0);
     if (threadIdx.x == 0) {
         __threadfence();
         const unsigned long long ticket = atomicAdd(&counters[5], 1ull);
@@ -1243,17 +1393,10 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
     }
     __syncthreads();
     if (!s_last) return;
+    STAMP(19, threadIdx.x == 0);
     __threadfence();
-    const bool failed = atomicAdd(&counters[6], 0ull) != 0ull;
-    for (int i = threadIdx.x; i < K * N_OPS; i += blockDim.x) {
-        const long long v = (long long)atomicExch((unsigned long long*)&out[i], 0ull); // read the final sum, reset for the next step
-        if (host_res) host_res[1 + i] = v; else d_q_out[i] = v;
-    }
-    if (threadIdx.x < 3) counters[8 + threadIdx.x] = atomicExch(&counters[threadIdx.x], 0ull);
-    if (threadIdx.x == 3) { counters[5] = 0; counters[6] = 0; }
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0 && host_res) { host_res[0] = failed ? -seq : seq; __threadfence_system(); }
+    hand_out(out, counters, fa.sync, K, d_q_out, host_res, seq);
+    STAMP(21, threadIdx.x == 0);
 }
 
 // ------------------------------------------------------------------ host side
@@ -1311,7 +1454,11 @@ struct Ctx {
     NbTables* tabs = nullptr;
     int* step_hdr = nullptr;      // [MAXK] mass work items per neighbour of the current step, [MAXK..] priced by k_tm
     long long* tm_done = nullptr; // [MAXK] sequence number of the step whose tables are complete
-    long long* d_acc = nullptr;   // K*13 running sums (self-cleaning: k_fin zeroes them after reading)
+    long long* d_acc = nullptr;   // K*13 running sums (self-cleaning: the step's last block zeroes them after reading)
+    unsigned long long* d_sync = nullptr; // [0] k_tm ticket
+    unsigned* d_flags = nullptr;          // k_scan's per-block completion flags
+    int event_every = 8;          // a HIP event pair around k_scan on every n-th evaluation (they cost a few us of gaps)
+    long long eval_calls = 0;
     DevArgs* d_args = nullptr;    // [2]: one argument block per layout buffer
     long long* h_res = nullptr;   // pinned host: [0] sequence number of the published step, [1..] K*13 sums
     long long seq = 0;
@@ -1405,15 +1552,27 @@ int refresh(Ctx* h)
     return GRAAL_OK;
 }
 
+constexpr int MAX_SCAN_BLOCKS = 4096;
 constexpr int SCAN_LDS_MAX = 48 * 1024; // affected bitmap of k_scan: 1 bit per contact-list id -> <= 393,216 ids
 
-// the streaming pass (see k_scan); dry = timing replay that counts relevant contacts but queues nothing
-int launch_scan(Ctx* h, const DevArgs* A, int fA, const Neigh& nb, int K, int max_id, int dry, hipStream_t st)
+int scan_threads_cfg()
 {
-    const long long groups = (h->nnz >> 2) + 1;
+    static const int v = getenv("GRAAL_SCAN_THREADS") ? atoi(getenv("GRAAL_SCAN_THREADS")) : 1024;
+    return v;
+}
+
+int scan_grid(const Ctx* h)
+{
     static const int scan_blocks = getenv("GRAAL_SCAN_BLOCKS") ? atoi(getenv("GRAAL_SCAN_BLOCKS")) : 256 * 2;
-    static const int scan_threads = getenv("GRAAL_SCAN_THREADS") ? atoi(getenv("GRAAL_SCAN_THREADS")) : 1024;
-    const int nbk = (int)std::min<long long>((groups + 2 * scan_threads - 1) / (2 * scan_threads), scan_blocks);
+    const long long groups = (h->nnz >> 2) + 1;
+    const long long per_block = 4ll * scan_threads_cfg(); // groups one block takes per iteration
+    return (int)std::max<long long>(1, std::min<long long>((groups + per_block - 1) / per_block, scan_blocks));
+}
+
+// the streaming pass (see k_scan); dry = timing replay that counts relevant contacts but queues nothing
+int launch_scan(Ctx* h, int fA, const Neigh& nb, int K, int max_id, int dry, hipStream_t st)
+{
+    const int nbk = scan_grid(h), scan_threads = scan_threads_cfg();
     const size_t shm = (size_t)((h->n_sub_total + 31) / 32 + 2) * 4;
     if (shm > (size_t)SCAN_LDS_MAX) return fail(h, GRAAL_E_UNSUPPORTED, "more than 393,216 sub-fragments: the affected bitmap does not fit the scan's LDS budget");
     ScanArgs sa;
@@ -1422,9 +1581,24 @@ int launch_scan(Ctx* h, const DevArgs* A, int fA, const Neigh& nb, int K, int ma
     sa.row4 = reinterpret_cast<const int4*>(h->row); sa.nnz = h->nnz; sa.bitmap_words = (int)(shm / 4);
     sa.col4 = reinterpret_cast<const int4*>(h->col); sa.geo2 = reinterpret_cast<const int2*>(h->geo); sa.sub2bin = h->sub2bin;
     sa.queue = h->queue; sa.counters = (unsigned long long*)(h->d_scalars + 10);
-    (void)A;
+    sa.flags = h->d_flags; sa.seq32 = (unsigned)h->seq;
+    if (nbk > MAX_SCAN_BLOCKS) return fail(h, GRAAL_E_ARG, "GRAAL_SCAN_BLOCKS too large");
     if (h->single_sub) k_scan<true><<<nbk, scan_threads, shm, st>>>(sa, fA, nb, K, max_id, dry);
     else k_scan<false><<<nbk, scan_threads, shm, st>>>(sa, fA, nb, K, max_id, dry);
+    CK(hipGetLastError());
+    return GRAAL_OK;
+}
+
+// left-over mass items, queued contacts, hand-out.  Short contigs leave it a handful of contacts: a small grid keeps its
+// launch and completion ticket cheap; long contigs get the whole chip.
+int launch_fin(Ctx* h, int K, int rank, int world, long long* d_q_out, bool publish, hipStream_t st)
+{
+    static const int fin_blocks_env = getenv("GRAAL_FIN_BLOCKS") ? atoi(getenv("GRAAL_FIN_BLOCKS")) : 0;
+    const int fin_blocks = fin_blocks_env > 0 ? fin_blocks_env : (h->max_lcont > 0 && h->max_lcont <= 16 ? 32 : 512);
+    FinArgs fa;
+    fa.tm_done = h->tm_done; fa.step_hdr = h->step_hdr; fa.counters = (unsigned long long*)(h->d_scalars + 10); fa.queue = h->queue;
+    fa.tabs = h->tabs; fa.geo = h->geo; fa.stat = h->stat; fa.acc = h->d_acc; fa.sync = h->d_sync;
+    k_fin<<<fin_blocks, 256, 0, st>>>(h->d_args + h->cur, fa, K, rank, world, d_q_out, publish ? h->h_res : nullptr, h->seq);
     CK(hipGetLastError());
     return GRAAL_OK;
 }
@@ -1453,7 +1627,14 @@ int graal_create(int device, graal_ctx** out)
     if (device < 0 || device >= count) { h->err = "device index out of range"; return GRAAL_E_ARG; }
     CK(hipSetDevice(device));
     CK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    CK(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
+    {
+        // k_tm's last block may WAIT for k_scan (see k_tm), so the two must never share a hardware queue (where they would
+        // run one after the other): the runtime keeps separate queue pools per priority, and a high-priority queue also
+        // gets the small latency-bound kernel dispatched ahead of the streaming one
+        int least = 0, greatest = 0;
+        CK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        CK(hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, greatest));
+    }
     CK(hipEventCreateWithFlags(&h->ev_fin, hipEventDisableTiming));
     for (auto& ev : h->ev) CK(hipEventCreate(&ev));
     h->ring.resize(2 * 1024, nullptr);
@@ -1464,6 +1645,11 @@ int graal_create(int device, graal_ctx** out)
     CK(hipMemset(h->d_acc, 0, MAXK * N_OPS * sizeof(long long)));
     CK(hipMalloc(&h->tm_done, MAXK * sizeof(long long)));
     CK(hipMemset(h->tm_done, 0, MAXK * sizeof(long long)));
+    CK(hipMalloc(&h->d_sync, 16 * sizeof(unsigned long long)));
+    CK(hipMemset(h->d_sync, 0, 16 * sizeof(unsigned long long)));
+    CK(hipMalloc(&h->d_flags, (size_t)MAX_SCAN_BLOCKS * FLAG_STRIDE * sizeof(unsigned)));
+    CK(hipMemset(h->d_flags, 0, (size_t)MAX_SCAN_BLOCKS * FLAG_STRIDE * sizeof(unsigned)));
+    if (getenv("GRAAL_EVENT_EVERY")) h->event_every = std::max(1, atoi(getenv("GRAAL_EVENT_EVERY")));
     CK(hipMalloc(&h->d_qout, MAXK * N_OPS * sizeof(long long)));
     CK(hipMalloc(&h->tabs, MAXK * sizeof(NbTables)));
     CK(hipMalloc(&h->step_hdr, 2 * MAXK * sizeof(int)));
@@ -1483,7 +1669,7 @@ void graal_destroy(graal_ctx* h)
         (void)hipSetDevice(h->device);
         (void)hipStreamSynchronize(h->stream);
         if (h->aux) (void)hipStreamSynchronize(h->aux);
-        void* ptrs[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->stat, h->sub2bin, h->row, h->col, h->cnt, h->queue, h->d_sub_ids, h->d_acc, h->tm_done,
+        void* ptrs[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->stat, h->sub2bin, h->row, h->col, h->cnt, h->queue, h->d_sub_ids, h->d_acc, h->tm_done, h->d_sync, h->d_flags,
                         h->keys, h->keys_sorted, h->o2n, h->len_of2[0], h->len_of2[1], h->contig_off2[0], h->contig_off2[1], h->perm, h->cbase, h->link, h->mates, h->cub_tmp, h->tabs, h->step_hdr, h->d_args, h->d_chg, h->d_plan,
                         h->d_scalars, h->d_qout};
         for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -1763,28 +1949,31 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     const DevArgs* A = h->d_args + h->cur;
     h->seq += 1;
     // (1) tables + small mass work on the auxiliary stream: overlaps the scan.  A previous asynchronous evaluation must
-    // have finished with the tables first (the synchronous path has waited for its results already).
+    // have finished with the tables first (the synchronous path has waited for its results already).  In the synchronous
+    // single-rank path (h->publish) its last block also finishes the step when the work is small.
     if (h->fin_pending) { CK(hipStreamWaitEvent(h->aux, h->ev_fin, 0)); h->fin_pending = false; }
-    static const bool tm_serial = getenv("GRAAL_TM_SERIAL") != nullptr; // experiment: tables before the scan, same stream
     TmArgs ta;
     ta.geo = h->geo; ta.link = h->link; ta.cbase = h->cbase; ta.tabs = h->tabs; ta.step_hdr = h->step_hdr;
-    k_tm<<<K, 256, 0, tm_serial ? st : h->aux>>>(A, ta, fA, nb, K, max_id, rank, world, h->seq);
+    static const bool no_finisher = getenv("GRAAL_NO_FINISHER") != nullptr; // always finish with k_fin (diagnostics)
+    ta.flags = h->d_flags;
+    ta.sync = h->d_sync; ta.host_res = (h->publish && world == 1 && !no_finisher) ? h->h_res : nullptr; ta.n_scan_blocks = scan_grid(h);
+    ta.counters = (unsigned long long*)(h->d_scalars + 10); ta.queue = h->queue; ta.stat = h->stat;
+    ta.lcontbp = h->soa[h->cur].p[F_LCONTBP]; ta.acc = h->d_acc; ta.nfpb = h->nfpb; ta.par = h->par;
+    k_tm<<<K, 256, 0, h->aux>>>(A, ta, fA, nb, K, max_id, rank, world, h->seq);
     CK(hipGetLastError());
-    // (2) the streaming pass
+    // (2) the streaming pass, with a HIP event pair around it on every event_every-th call
+    const bool ev = h->want_events && (h->eval_calls % h->event_every == 0);
+    h->eval_calls += 1;
     const size_t slot = (size_t)(h->ring_calls % (long long)(h->ring.size() / 2));
-    if (h->want_events) CK(hipEventRecord(h->ring[2 * slot], st));
-    { int rc_ = launch_scan(h, A, fA, nb, K, max_id, 0, st); if (rc_) return rc_; }
-    if (h->want_events) { CK(hipEventRecord(h->ring[2 * slot + 1], st)); h->ring_calls += 1; }
-    // (3) left-over mass items, queued contacts, hand-out.  Short contigs leave it a handful of contacts: a small grid
-    // keeps its launch and completion ticket cheap; long contigs get the whole chip.
-    static const int fin_blocks_env = getenv("GRAAL_FIN_BLOCKS") ? atoi(getenv("GRAAL_FIN_BLOCKS")) : 0;
-    const int fin_blocks = fin_blocks_env > 0 ? fin_blocks_env : (h->max_lcont > 0 && h->max_lcont <= 16 ? 32 : 512);
-    FinArgs fa;
-    fa.tm_done = h->tm_done; fa.step_hdr = h->step_hdr; fa.counters = (unsigned long long*)(h->d_scalars + 10); fa.queue = h->queue;
-    fa.tabs = h->tabs; fa.geo = h->geo; fa.stat = h->stat; fa.acc = h->d_acc;
-    k_fin<<<fin_blocks, 256, 0, st>>>(A, fa, K, rank, world, (long long*)d_q_out, h->publish ? h->h_res : nullptr, h->seq);
-    CK(hipGetLastError());
-    if (!h->publish) { CK(hipEventRecord(h->ev_fin, st)); h->fin_pending = true; }
+    if (ev) CK(hipEventRecord(h->ring[2 * slot], st));
+    { int rc_ = launch_scan(h, fA, nb, K, max_id, 0, st); if (rc_) return rc_; }
+    if (ev) { CK(hipEventRecord(h->ring[2 * slot + 1], st)); h->ring_calls += 1; }
+    // (3) finishing kernel -- unless k_tm's last block does that job (it asks for k_fin through the result word if not)
+    if (ta.host_res == nullptr) {
+        int rc_ = launch_fin(h, K, rank, world, (long long*)d_q_out, h->publish, st);
+        if (rc_) return rc_;
+        if (!h->publish) { CK(hipEventRecord(h->ev_fin, st)); h->fin_pending = true; }
+    }
     h->timing_valid = h->want_events;
     h->scan_ready = true;
     h->last_fA = fA; h->last_K = K; h->last_max_id = max_id;
@@ -1805,15 +1994,29 @@ int graal_eval_candidates(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K
     volatile long long* res = h->h_res;
     bool seen = false;
     for (long long spin = 0; spin < 200000000ll; spin++) {
-        if (res[0] == want || res[0] == -want) { seen = true; break; }
-        if ((spin & 0xfffff) == 0xfffff && hipStreamQuery(h->stream) != hipErrorNotReady) { seen = (res[0] == want || res[0] == -want); break; }
+        const long long v = res[0];
+        if (v == want || v == -want) { seen = true; break; }
+        if (v == (want | NEED_FIN)) { // k_tm left the heavy part of the step to k_fin
+            res[0] = 0;
+            h->publish = true;
+            rc = launch_fin(h, K, 0, 1, (long long*)h->d_qout, true, h->stream);
+            h->publish = false;
+            if (rc) return rc;
+            continue;
+        }
+        if ((spin & 0xfffff) == 0xfffff && hipStreamQuery(h->stream) != hipErrorNotReady && hipStreamQuery(h->aux) != hipErrorNotReady) {
+            seen = (res[0] == want || res[0] == -want);
+            if (!seen && res[0] == (want | NEED_FIN)) continue;
+            break;
+        }
         __builtin_ia32_pause();
     }
     if (!seen) {
         CK(hipStreamSynchronize(h->stream));
-        if (res[0] != want && res[0] != -want) return fail(h, GRAAL_E_HIP, "k_fin did not publish its results");
+        CK(hipStreamSynchronize(h->aux));
+        if (res[0] != want && res[0] != -want) return fail(h, GRAAL_E_HIP, "the step's last block did not publish its results");
     }
-    if (res[0] == -want) return fail(h, GRAAL_E_HIP, "k_fin timed out waiting for the candidate tables (k_tm did not run)");
+    if (res[0] == -want) return fail(h, GRAAL_E_HIP, "timed out waiting for the candidate tables / the scan (a kernel of the step did not run)");
     __sync_synchronize();
     for (int i = 0; i < K * N_OPS; i++) delta[i] = (double)res[1 + i] / Q_SCALE;
     return GRAAL_OK;
@@ -1824,6 +2027,7 @@ int graal_set_timing(graal_ctx* h, int32_t enabled)
 {
     if (!h) return GRAAL_E_ARG;
     h->want_events = enabled != 0;
+    if (enabled > 0) h->event_every = enabled; // an event pair around k_scan on every enabled-th evaluation
     if (!h->want_events) h->timing_valid = false;
     return GRAAL_OK;
 }
@@ -1877,20 +2081,32 @@ int graal_time_scan(graal_ctx* h, int32_t K, int32_t reps, float* avg_ms)
     if (!h || !avg_ms || reps < 1 || K < 1 || K > MAXK) return GRAAL_E_ARG;
     if (!h->scan_ready) return fail(h, GRAAL_E_STATE, "run graal_eval_candidates first (the replays reuse its tables)");
     CK(hipSetDevice(h->device));
-    const DevArgs* A = h->d_args + h->cur;
     if (K != h->last_K) return fail(h, GRAAL_E_ARG, "K differs from the last evaluation");
     Neigh nb;
     for (int k = 0; k < MAXK; k++) nb.fB[k] = h->last_fB[k];
-    for (int i = 0; i < 3; i++) { int rc = launch_scan(h, A, h->last_fA, nb, K, h->last_max_id, 1, h->stream); if (rc) return rc; }
+    for (int i = 0; i < 3; i++) { int rc = launch_scan(h, h->last_fA, nb, K, h->last_max_id, 1, h->stream); if (rc) return rc; }
     CK(hipEventRecord(h->ev[0], h->stream));
-    static const int dry_mode = getenv("GRAAL_DRY") ? atoi(getenv("GRAAL_DRY")) : 1;
-    for (int i = 0; i < reps; i++) { int rc = launch_scan(h, A, h->last_fA, nb, K, h->last_max_id, dry_mode, h->stream); if (rc) return rc; }
+    for (int i = 0; i < reps; i++) { int rc = launch_scan(h, h->last_fA, nb, K, h->last_max_id, 1, h->stream); if (rc) return rc; }
     CK(hipEventRecord(h->ev[4], h->stream));
     CK(hipEventSynchronize(h->ev[4]));
     float ms = 0.0f;
     CK(hipEventElapsedTime(&ms, h->ev[0], h->ev[4]));
     *avg_ms = ms / (float)reps;
     return GRAAL_OK;
+}
+
+/* debug builds only (-DGRAAL_STAMPS): 32 wall-clock stamps (100 MHz) of the last step's kernels */
+int graal_debug_stamps(graal_ctx* h, uint64_t out[32])
+{
+    if (!h || !out) return GRAAL_E_ARG;
+#ifdef GRAAL_STAMPS
+    CK(hipSetDevice(h->device));
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), 32 * sizeof(unsigned long long)));
+    return GRAAL_OK;
+#else
+    return fail(h, GRAAL_E_UNSUPPORTED, "library built without GRAAL_STAMPS");
+#endif
 }
 
 int graal_last_counters(graal_ctx* h, int64_t out[4])

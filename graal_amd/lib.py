@@ -203,7 +203,7 @@ class Engine:
                  "graal_eval_candidates_q")
 
     def set_timing(self, enabled):
-        self._ck(self._L.graal_set_timing(self._h, 1 if enabled else 0), "graal_set_timing")
+        self._ck(self._L.graal_set_timing(self._h, int(enabled)), "graal_set_timing")
 
     def last_timing(self):
         t = np.zeros(4, dtype=np.float32)

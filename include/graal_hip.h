@@ -106,7 +106,8 @@ int graal_eval_candidates(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K
  * commit (the count is then reported by the next graal_begin_step).  The geometry index is stale until then. */
 int graal_apply_move(graal_ctx* h, int32_t fA, int32_t fB, int32_t op, int32_t max_id, int32_t* n_stale);
 
-/* switch the per-kernel HIP event records of graal_eval_candidates* on (default) or off */
+/* HIP event pairs around the streaming kernel of graal_eval_candidates*: enabled = n > 0 records a pair on every n-th
+ * call (default 8; each pair costs a few microseconds of command-processor gaps on the step's critical path), 0 = off */
 int graal_set_timing(graal_ctx* h, int32_t enabled);
 /* duration (ms) of the streaming scan kernel of the last graal_eval_candidates* call: a pair of HIP events recorded
  * around it on the stream it ran on; out[1] = k_scan, the other entries are 0 (per-kernel times of k_prep / k_post come

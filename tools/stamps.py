@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""GPU box, debug build (-DGRAAL_STAMPS): in-kernel wall-clock stamps of one scoring step, averaged over many steps."""
+import ctypes, os, sys, subprocess
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+so = os.path.join(ROOT, "graal_amd", "libgraal_hip_stamps.so")
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+                       "-DGRAAL_STAMPS", "-o", so, os.path.join(ROOT, "graal_amd", "csrc", "graal_hip.hip")])
+from graal_amd import build
+build.HIP_LIB = so
+from graal_amd import lib, synth
+import bench
+P = synth.make_problem(n_bins=50000, nnz=20_000_000, n_sub=1, seed=20141217)
+P["S_o_A_frags"] = bench.exploded_layout(P)
+rng = np.random.RandomState(20141217)
+smp = bench.build_sampler(P, rng, None, 0)
+smp.init_likelihood()
+order = np.arange(50000, dtype=np.int32); rng.shuffle(order)
+for i in order[:2000]:
+    smp.step_max_likelihood(int(i), 5)
+max_id = smp.modify_gl_cuda_buffer(0)
+L = lib.load()
+L.graal_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+acc = np.zeros(32); n = 0
+for f in rng.randint(0, 50000, size=300):
+    nb = smp.return_neighbours(int(f), 5); nb.sort()
+    smp._candidate_deltas(int(f), nb, max_id)
+    st = np.zeros(32, dtype=np.uint64)
+    assert L.graal_debug_stamps(smp.engine._h, st.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))) == 0
+    st = st.astype(np.float64)
+    t0 = min(st[0], st[8])
+    acc += (st - t0) * 0.01; n += 1   # 100 MHz -> us
+a = acc / n
+st_mask = None
+names = {0: "tm start", 1: "tm tables done", 2: "tm mass done", 3: "tm released", 4: "tm finisher: scan seen", 5: "tm finisher: contacts priced", 6: "tm finisher: published", 8: "scan start", 9: "scan prologue done", 10: "scan block0 loop done",
+         24: "tm: A0/B0 loaded", 25: "tm: representatives loaded", 26: "tm: transforms", 27: "tm: relations", 28: "tm: dedupe", 29: "tm: slots", 30: "tm: tasks written",
+         16: "fin start", 17: "fin tables seen", 18: "fin last-indexed block at ticket", 19: "fin last block past ticket", 20: "fin sums handed out", 21: "fin seq published"}
+for i in sorted(names):
+    if abs(a[i]) < 1e6:
+        print("%-36s %7.2f us" % (names[i], a[i]))
