@@ -492,8 +492,11 @@ constexpr int FLAG_STRIDE = 32; // words between two blocks' completion flags: o
 #ifdef GRAAL_STAMPS
 __device__ unsigned long long g_stamps[32];
 #define STAMP(i, cond) do { if (cond) g_stamps[i] = wall_clock64(); } while (0)
+__device__ unsigned long long g_blk[4096 * 4]; // per block of k_scan: start, past prologue, loop done
+#define STAMP_BLK(j, cond) do { if (cond) g_blk[4 * blockIdx.x + (j)] = wall_clock64(); } while (0)
 #else
 #define STAMP(i, cond) do { } while (0)
+#define STAMP_BLK(j, cond) do { } while (0)
 #endif
 
 // exclusive prefix sum of vals[0..n) into out[0..n) and the total into out[n]; vals / out in LDS.  Executed by ONE wave
@@ -806,6 +809,7 @@ __device__ __forceinline__ void hand_out(long long* out, unsigned long long* cou
 }
 
 constexpr long long NEED_FIN = 1ll << 62; // published instead of the sums: k_tm left work for k_fin, launch it
+constexpr long long GAVE_UP = 1ll << 61;  // (with NEED_FIN) k_tm's last block stopped waiting for k_scan
 constexpr int FIN_INLINE_Q = 64;          // queued contacts the finishing block of k_tm prices itself
 
 // ------------------------------------------------------------------ per-step kernels
@@ -831,6 +835,7 @@ struct TmArgs { // first-needed pointers by value (see ScanArgs)
     const unsigned* flags;         // k_scan's per-block completion flags
     volatile long long* host_res;  // non-null: the last block of k_tm finishes the step itself when the work is small
     int n_scan_blocks;
+    int wait_ticks;                // how long that block waits for k_scan (100 MHz ticks)
     // the finishing block's pointers, by value too
     unsigned long long* counters;
     const QEntry* queue;
@@ -919,27 +924,31 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
     }
     __syncthreads();
     if (s_fin == 0) return;
-    {   // all blocks of k_scan done?  Every thread polls its share of the flags (bounded: every wave reaches the exit)
+    {   // all blocks of k_scan done?  Every thread polls its share of the flags, for a bounded TIME: when the two kernels
+        // do not actually run concurrently (a profiler or debugger serialising dispatches, streams sharing a hardware
+        // queue) the scan cannot even start before this block exits -- then the step is handed to k_fin, which the host
+        // launches behind the scan.
         bool ok = false;
-        for (int spin = 0; spin < (1 << 22); spin++) {
+        const unsigned long long t_end = wall_clock64() + (unsigned long long)ta.wait_ticks;
+        for (;;) {
             bool mine = true;
             for (int b = t; b < ta.n_scan_blocks; b += (int)blockDim.x)
                 mine = mine && (__hip_atomic_load(&ta.flags[FLAG_STRIDE * b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)seq);
             if (__syncthreads_and(mine)) { ok = true; break; }
+            if (__syncthreads_or(wall_clock64() > t_end)) break;
             __builtin_amdgcn_s_sleep(1);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         if (t == 0) {
-            if (!ok) atomicOr(&ta.counters[6], 1ull);
             s_nq = ok ? __hip_atomic_load(&ta.counters[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
             if (ok && s_nq > (unsigned long long)FIN_INLINE_Q) s_fin = 2;
-            if (!ok) s_fin = 1;
+            if (!ok) s_fin = 3; // gave up waiting
         }
     }
     __syncthreads();
     STAMP(4, t == 0);
-    if (s_fin == 2) { // (nothing was reset: k_fin finds the step as k_scan and k_tm left it)
-        if (t == 0) { ta.sync[0] = 0; __threadfence_system(); ta.host_res[0] = seq | NEED_FIN; __threadfence_system(); }
+    if (s_fin >= 2) { // (nothing was reset: k_fin finds the step as k_scan and k_tm left it)
+        if (t == 0) { ta.sync[0] = 0; __threadfence_system(); ta.host_res[0] = seq | NEED_FIN | (s_fin == 3 ? GAVE_UP : 0ll); __threadfence_system(); }
         return;
     }
     {
@@ -1027,7 +1036,7 @@ struct ScanArgs { // by value: kernel-argument pointers are known to be GLOBAL (
 };
 
 template <bool SINGLE_SUB>
-__global__ __launch_bounds__(1024) void k_scan(ScanArgs sa, int fA, Neigh nb, int K, int max_id,
+__global__ __launch_bounds__(1024, 8) void k_scan(ScanArgs sa, int fA, Neigh nb, int K, int max_id,
                                                 int dry /* timing replays: count, do not queue */)
 {
     extern __shared__ unsigned s_bm[];
@@ -1038,6 +1047,7 @@ __global__ __launch_bounds__(1024) void k_scan(ScanArgs sa, int fA, Neigh nb, in
     const int t = threadIdx.x;
     const int lane = t & 63;
     STAMP(8, blockIdx.x == 0 && t == 0 && !dry);
+    STAMP_BLK(0, t == 0 && !dry);
     // ---- prologue: keys of the K neighbours and the affected bitmap.  Its dependent loads (fragment records -> position
     // index) go out first; the first row words are requested right behind them, so the stream is already running while
     // the bitmap is built ----
@@ -1073,33 +1083,40 @@ __global__ __launch_bounds__(1024) void k_scan(ScanArgs sa, int fA, Neigh nb, in
         if (SCAN_PRE > 2) f2 = ldg((long long)g0 + 2 * stride);
         if (SCAN_PRE > 3) f3 = ldg((long long)g0 + 3 * stride);
     }
-    if (t == 0) { S.live = 0; S.intra = 0; s_waves_done = 0; }
-    for (int i = t; i < sa.bitmap_words; i += blockDim.x) s_bm[i] = 0;
-    if (t <= K) s_cbase[t] = my_cbase;
-    if (t < MAXK) s_fB[t] = my_fB;
-    __syncthreads();
-    if (t < K) {
-        const Rec& A0 = s_rec[0];
-        const Rec& B0 = s_rec[t + 1];
-        const int fB = my_fB;
-        PieceKey key; key.cA = A0.id_c; key.a = A0.pos; key.cB = B0.id_c; key.b = B0.pos;
-        S.key[t] = key;
-        bool dup = (fB == fA) || (B0.id_c == A0.id_c);
-        if (fB != fA) {
-            atomicOr(&S.live, 1u << t);
-            if (circ_may_change(fA, fB, max_id, A0, B0)) atomicOr(&S.intra, 1u << (4 * t));
-            for (int j = 0; j < t; j++) if (s_fB[j] != fA && s_rec[j + 1].id_c == B0.id_c) dup = true;
+    // Wave 0 alone builds the bitmap (the other waves go straight to the one barrier below: a block-wide barrier this early
+    // waits for the block's last wave to be LAUNCHED, and there were four of them).  Inside one wave, LDS operations
+    // execute in program order; WSYNC only keeps the compiler from reordering them across lanes' dependencies.
+#define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+    constexpr int SMALL_TOTAL = 256; // affected fragments wave 0 marks itself; above that the whole block helps
+    if (t < 64) {
+        if (t == 0) { S.live = 0; S.intra = 0; s_waves_done = 0; }
+        for (int i = t; i < sa.bitmap_words; i += 64) s_bm[i] = 0;
+        if (t <= K) s_cbase[t] = my_cbase;
+        if (t < MAXK) s_fB[t] = my_fB;
+        WSYNC();
+        if (t < K) {
+            const Rec& A0 = s_rec[0];
+            const Rec& B0 = s_rec[t + 1];
+            const int fB = my_fB;
+            PieceKey key; key.cA = A0.id_c; key.a = A0.pos; key.cB = B0.id_c; key.b = B0.pos;
+            S.key[t] = key;
+            bool dup = (fB == fA) || (B0.id_c == A0.id_c);
+            if (fB != fA) {
+                atomicOr(&S.live, 1u << t);
+                if (circ_may_change(fA, fB, max_id, A0, B0)) atomicOr(&S.intra, 1u << (4 * t));
+                for (int j = 0; j < t; j++) if (s_fB[j] != fA && s_rec[j + 1].id_c == B0.id_c) dup = true;
+            }
+            s_clen[t + 1] = dup ? 0 : B0.l_cont;
         }
-        s_clen[t + 1] = dup ? 0 : B0.l_cont;
+        if (t == 0) s_clen[0] = s_rec[0].l_cont;
+        WSYNC();
+        if (t == 0) { int acc = 0; for (int j = 0; j <= K; j++) { s_pref[j] = acc; acc += s_clen[j]; } s_pref[K + 1] = acc; }
+        WSYNC();
     }
-    if (t == 0) s_clen[0] = s_rec[0].l_cont;
-    __syncthreads();
-    if (t == 0) { int acc = 0; for (int j = 0; j <= K; j++) { s_pref[j] = acc; acc += s_clen[j]; } s_pref[K + 1] = acc; }
-    __syncthreads();
-    {
+    auto mark = [&](int e0, int step) {
         const int total = s_pref[K + 1];
         const int* __restrict__ perm = sa.perm;
-        for (int e = t; e < total; e += blockDim.x) {
+        for (int e = e0; e < total; e += step) {
             int j = 0;
             while (j < K && e >= s_pref[j + 1]) j++;
             // short contigs come with the fragment's own record (mates row): no second dependent load
@@ -1113,15 +1130,22 @@ __global__ __launch_bounds__(1024) void k_scan(ScanArgs sa, int fA, Neigh nb, in
                 if (ids.w > 2) atomicOr(&s_bm[ids.z >> 5], 1u << (ids.z & 31));
             }
         }
+    };
+    if (t < 64 && s_pref[K + 1] <= SMALL_TOTAL) mark(t, 64);
+#undef WSYNC
+    __syncthreads();
+    if (s_pref[K + 1] > SMALL_TOTAL) { // long contigs: everybody marks (the extra barrier is nothing next to that regime's work)
+        mark(t, (int)blockDim.x);
+        __syncthreads();
     }
     const int4* __restrict__ col4 = sa.col4;
     const int* __restrict__ sub2bin = sa.sub2bin;
     const int2* __restrict__ geo2 = sa.geo2;
     QEntry* __restrict__ queue = sa.queue;
     unsigned long long* __restrict__ counters = sa.counters;
-    __syncthreads();
     const unsigned intra = S.intra;
     unsigned long long n_rel = 0;
+    STAMP_BLK(1, t == 0 && !dry);
     STAMP(9, blockIdx.x == 0 && t == 0 && !dry);
     // one iteration: four groups of 4 contacts (ga + i * stride)
     auto process = [&](const int4 r0, const int4 r1, const int4 r2, const int4 r3, const long long ga) {
@@ -1195,7 +1219,9 @@ __global__ __launch_bounds__(1024) void k_scan(ScanArgs sa, int fA, Neigh nb, in
                 if (rel) {
                     // device-scope (write-through) stores: the entry must reach the reader -- possibly a block of k_tm on
                     // another XCD -- without an L2 write-back fence, which costs this kernel several microseconds
-                    unsigned long long* qw = reinterpret_cast<unsigned long long*>(queue + base + __popcll(bal & ((1ull << lane) - 1ull)));
+                    // (rank among the set lanes below this one: mbcnt, no loop-invariant lane mask to keep in registers)
+                    const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                    unsigned long long* qw = reinterpret_cast<unsigned long long*>(queue + base + below);
                     const unsigned cnt_w = (unsigned)sa.cnt[cidx];
                     __hip_atomic_store(qw + 0, (unsigned long long)(unsigned)cidx | ((unsigned long long)rel << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(qw + 1, (unsigned long long)q_ci | ((unsigned long long)q_cj << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1219,6 +1245,7 @@ __global__ __launch_bounds__(1024) void k_scan(ScanArgs sa, int fA, Neigh nb, in
         process(q0, q1, q2, q3, g);
     }
     STAMP(10, blockIdx.x == 0 && t == 0 && !dry);
+    STAMP_BLK(2, t == 0 && !dry);
     n_rel = (unsigned long long)wave_sum_ll((long long)n_rel);
     if (lane == 0 && n_rel && !dry) atomicAdd(&counters[0], n_rel);
     if (dry == 0) {
@@ -1457,6 +1484,9 @@ struct Ctx {
     long long* d_acc = nullptr;   // K*13 running sums (self-cleaning: the step's last block zeroes them after reading)
     unsigned long long* d_sync = nullptr; // [0] k_tm ticket
     unsigned* d_flags = nullptr;          // k_scan's per-block completion flags
+    bool finisher_ok = true;      // k_tm's last block may finish short-contig steps (switched off when the kernels turn
+                                  // out not to run concurrently, e.g. under a profiler that serialises dispatches)
+    int gave_up = 0;
     int event_every = 8;          // a HIP event pair around k_scan on every n-th evaluation (they cost a few us of gaps)
     long long eval_calls = 0;
     DevArgs* d_args = nullptr;    // [2]: one argument block per layout buffer
@@ -1956,7 +1986,10 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     ta.geo = h->geo; ta.link = h->link; ta.cbase = h->cbase; ta.tabs = h->tabs; ta.step_hdr = h->step_hdr;
     static const bool no_finisher = getenv("GRAAL_NO_FINISHER") != nullptr; // always finish with k_fin (diagnostics)
     ta.flags = h->d_flags;
-    ta.sync = h->d_sync; ta.host_res = (h->publish && world == 1 && !no_finisher) ? h->h_res : nullptr; ta.n_scan_blocks = scan_grid(h);
+    ta.sync = h->d_sync; ta.n_scan_blocks = scan_grid(h);
+    ta.host_res = (h->publish && world == 1 && !no_finisher && h->finisher_ok) ? h->h_res : nullptr;
+    // a generous multiple of the time the streaming pass needs at 2 TB/s, plus launch slack
+    ta.wait_ticks = (int)std::min<long long>(100ll * 50 + (long long)(4.0 * 4.0 * (double)h->nnz / 2.0e12 * 1.0e8), 1ll << 30);
     ta.counters = (unsigned long long*)(h->d_scalars + 10); ta.queue = h->queue; ta.stat = h->stat;
     ta.lcontbp = h->soa[h->cur].p[F_LCONTBP]; ta.acc = h->d_acc; ta.nfpb = h->nfpb; ta.par = h->par;
     k_tm<<<K, 256, 0, h->aux>>>(A, ta, fA, nb, K, max_id, rank, world, h->seq);
@@ -1996,7 +2029,8 @@ int graal_eval_candidates(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K
     for (long long spin = 0; spin < 200000000ll; spin++) {
         const long long v = res[0];
         if (v == want || v == -want) { seen = true; break; }
-        if (v == (want | NEED_FIN)) { // k_tm left the heavy part of the step to k_fin
+        if (v == (want | NEED_FIN) || v == (want | NEED_FIN | GAVE_UP)) { // k_tm left (the heavy part of) the step to k_fin
+            if ((v & GAVE_UP) && ++h->gave_up >= 3) h->finisher_ok = false;
             res[0] = 0;
             h->publish = true;
             rc = launch_fin(h, K, 0, 1, (long long*)h->d_qout, true, h->stream);
@@ -2006,7 +2040,7 @@ int graal_eval_candidates(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K
         }
         if ((spin & 0xfffff) == 0xfffff && hipStreamQuery(h->stream) != hipErrorNotReady && hipStreamQuery(h->aux) != hipErrorNotReady) {
             seen = (res[0] == want || res[0] == -want);
-            if (!seen && res[0] == (want | NEED_FIN)) continue;
+            if (!seen && (res[0] & ~GAVE_UP) == (want | NEED_FIN)) continue;
             break;
         }
         __builtin_ia32_pause();
@@ -2103,6 +2137,19 @@ int graal_debug_stamps(graal_ctx* h, uint64_t out[32])
     CK(hipSetDevice(h->device));
     CK(hipDeviceSynchronize());
     CK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), 32 * sizeof(unsigned long long)));
+    return GRAAL_OK;
+#else
+    return fail(h, GRAAL_E_UNSUPPORTED, "library built without GRAAL_STAMPS");
+#endif
+}
+
+int graal_debug_block_stamps(graal_ctx* h, uint64_t* out /* [4096][4] */)
+{
+    if (!h || !out) return GRAAL_E_ARG;
+#ifdef GRAAL_STAMPS
+    CK(hipSetDevice(h->device));
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blk), 4096 * 4 * sizeof(unsigned long long)));
     return GRAAL_OK;
 #else
     return fail(h, GRAAL_E_UNSUPPORTED, "library built without GRAAL_STAMPS");

@@ -22,6 +22,8 @@ for i in order[:2000]:
 max_id = smp.modify_gl_cuda_buffer(0)
 L = lib.load()
 L.graal_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+L.graal_debug_block_stamps.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+blk_acc = np.zeros(6)
 acc = np.zeros(32); n = 0
 for f in rng.randint(0, 50000, size=300):
     nb = smp.return_neighbours(int(f), 5); nb.sort()
@@ -31,6 +33,10 @@ for f in rng.randint(0, 50000, size=300):
     st = st.astype(np.float64)
     t0 = min(st[0], st[8])
     acc += (st - t0) * 0.01; n += 1   # 100 MHz -> us
+    bs = np.zeros(4096 * 4, dtype=np.uint64)
+    assert L.graal_debug_block_stamps(smp.engine._h, bs.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))) == 0
+    bs = bs.reshape(4096, 4)[:512].astype(np.float64)
+    blk_acc += np.array([bs[:, 0].min() - t0, bs[:, 0].max() - t0, bs[:, 1].min() - t0, bs[:, 1].max() - t0, bs[:, 2].min() - t0, bs[:, 2].max() - t0]) * 0.01
 a = acc / n
 st_mask = None
 names = {0: "tm start", 1: "tm tables done", 2: "tm mass done", 3: "tm released", 4: "tm finisher: scan seen", 5: "tm finisher: contacts priced", 6: "tm finisher: published", 8: "scan start", 9: "scan prologue done", 10: "scan block0 loop done",
@@ -39,3 +45,6 @@ names = {0: "tm start", 1: "tm tables done", 2: "tm mass done", 3: "tm released"
 for i in sorted(names):
     if abs(a[i]) < 1e6:
         print("%-36s %7.2f us" % (names[i], a[i]))
+
+for name, v in zip(("first block start", "last block start", "first block past prologue", "last block past prologue", "first block loop done", "last block loop done"), blk_acc / n):
+    print("scan: %-31s %7.2f us" % (name, v))
