@@ -524,10 +524,21 @@ __device__ __forceinline__ void pair_of_index(int idx, int& p, int& q)
     for (p = 1; p <= MAX_PIECES; p++) { const int row = MAX_PIECES - p + 1; if (idx < row) { q = p + idx; break; } idx -= row; }
 }
 
+// short contigs (<= N_MATES fragments each): the geometry and statistics of every fragment of contig(fA) and contig(fB)
+// are fetched into LDS while the tables are being built, so the block's own mass pricing needs no global loads
+struct SmallCtx {
+    int small;                 // both contigs are short
+    int base[2], len[2];       // position-index base / length of contig(fA), contig(fB)
+    int mates[2][N_MATES];
+    Geo geo[2 * N_MATES];
+    Stat stat[2 * N_MATES];
+};
+
 // one block builds everything about one neighbour; tasks are left in s_task (LDS) too, with the exclusive prefix of
 // their fragment-pair counts in s_pp.  Returns the number of tasks.
-__device__ int tables_block(const Geo* __restrict__ geo, const Link* __restrict__ link, const int* __restrict__ cbase, int fA,
-                            int fB, int max_id, NbTables& T, int k, int* __restrict__ step_hdr, Task* s_task, int* s_pp)
+__device__ int tables_block(const Geo* __restrict__ geo, const Link* __restrict__ link, const int* __restrict__ cbase,
+                            const int* __restrict__ mates, const Stat* __restrict__ stat, int fA, int fB, int max_id, NbTables& T,
+                            int k, int* __restrict__ step_hdr, Task* s_task, int* s_pp, SmallCtx& sc)
 {
     __shared__ Rec A0, B0;
     __shared__ int s_baseA, s_baseB;
@@ -546,8 +557,16 @@ __device__ int tables_block(const Geo* __restrict__ geo, const Link* __restrict_
     if (t == 0) {
         const Geo gA = geo[fA], gB = geo[fB];
         const Link lA = link[fA], lB = link[fB];
+        const int4 mA0 = reinterpret_cast<const int4*>(mates)[2 * fA], mA1 = reinterpret_cast<const int4*>(mates)[2 * fA + 1];
+        const int4 mB0 = reinterpret_cast<const int4*>(mates)[2 * fB], mB1 = reinterpret_cast<const int4*>(mates)[2 * fB + 1];
         s_baseA = cbase[fA]; s_baseB = cbase[fB];
         A0 = rec_gl(gA, lA, fA); B0 = rec_gl(gB, lB, fB);
+        sc.base[0] = s_baseA; sc.base[1] = s_baseB; sc.len[0] = lA.l_cont; sc.len[1] = lB.l_cont;
+        sc.small = (lA.l_cont <= N_MATES && lB.l_cont <= N_MATES) ? 1 : 0;
+        sc.mates[0][0] = mA0.x; sc.mates[0][1] = mA0.y; sc.mates[0][2] = mA0.z; sc.mates[0][3] = mA0.w;
+        sc.mates[0][4] = mA1.x; sc.mates[0][5] = mA1.y; sc.mates[0][6] = mA1.z; sc.mates[0][7] = mA1.w;
+        sc.mates[1][0] = mB0.x; sc.mates[1][1] = mB0.y; sc.mates[1][2] = mB0.z; sc.mates[1][3] = mB0.w;
+        sc.mates[1][4] = mB1.x; sc.mates[1][5] = mB1.y; sc.mates[1][6] = mB1.z; sc.mates[1][7] = mB1.w;
         PieceKey key; key.cA = A0.id_c; key.a = A0.pos; key.cB = B0.id_c; key.b = B0.pos;
         T.key = key; T.fB = fB;
         piece_representatives(key, fA, fB, A0, B0, rep);
@@ -575,6 +594,11 @@ __device__ int tables_block(const Geo* __restrict__ geo, const Link* __restrict_
         if (rep[t] >= 0) { rep_old[t] = rec_gl(geo[rep[t]], link[rep[t]], rep[t]); xf_old[t] = xf_identity(rep_old[t]); }
         else { Xf x; x.label = -1 - t; x.sigma = 1; x.off = 0; x.circ = 0; x.lbp = 0; xf_old[t] = x; }
         s_cbase[t] = s_contig[t] < 0 ? 0 : (s_contig[t] == A0.id_c ? s_baseA : s_baseB);
+    }
+    if (t >= 64 && t < 64 + 2 * N_MATES && sc.small) { // another wave: these loads overlap the table construction
+        const int i = t - 64, w = i / N_MATES, j = i % N_MATES;
+        const int f = j < sc.len[w] ? sc.mates[w][j] : -1;
+        if (f >= 0) { sc.geo[i] = geo[f]; sc.stat[i] = stat[f]; }
     }
     __syncthreads();
     STAMP(25, k == 0 && t == 0); // representatives loaded
@@ -828,7 +852,7 @@ __device__ __forceinline__ int sel8(int x0, int x1, int x2, int x3, int x4, int 
 struct TmArgs { // first-needed pointers by value (see ScanArgs)
     const Geo* geo;
     const Link* link;
-    const int* cbase;
+    const int *cbase, *mates;
     NbTables* tabs;
     int* step_hdr;
     unsigned long long* sync;      // [0] k_tm ticket (+ 2^16 per neighbour left to k_fin)
@@ -860,20 +884,21 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
     STAMP(0, k == 0 && t == 0);
     NbTables& T = ta.tabs[k];
     const int my_fB = sel8(nb.fB[0], nb.fB[1], nb.fB[2], nb.fB[3], nb.fB[4], nb.fB[5], nb.fB[6], nb.fB[7], k);
-    const int n_tasks = tables_block(ta.geo, ta.link, ta.cbase, fA, my_fB, max_id, T, k, ta.step_hdr, s_task, s_pp);
+    __shared__ SmallCtx sc;
+    __shared__ long long s_acc[N_OPS];
+    if (t < N_OPS) s_acc[t] = 0;
+    const int n_tasks = tables_block(ta.geo, ta.link, ta.cbase, ta.mates, ta.stat, fA, my_fB, max_id, T, k, ta.step_hdr, s_task, s_pp, sc);
     const int total = s_pp[n_tasks];
     const bool inl = total <= INLINE_PAIRS;
     STAMP(1, k == 0 && t == 0);
     if (inl && total > 0) {
         const int* __restrict__ perm = A->perm;
         const Geo* __restrict__ geo = ta.geo;
-        const Stat* __restrict__ stat = A->stat;
-        const float nfpb = A->nfpb;
-        const Par par = A->par;
+        const Stat* __restrict__ stat = ta.stat;
+        const float nfpb = ta.nfpb;
+        const Par par = ta.par;
         const int reach_bp = A->reach_bp;
-        long long acc[N_OPS];
-#pragma unroll
-        for (int op = 0; op < N_OPS; op++) acc[op] = 0;
+        // (sums of the block in LDS: a handful of lanes have anything to add, and 13 wave reductions cost microseconds)
         for (int i = rank + world * t; i < total; i += world * (int)blockDim.x) {
             int lo_t = 0, hi_t = n_tasks - 1; // last task with s_pp <= i
             while (lo_t < hi_t) { const int mid = (lo_t + hi_t + 1) >> 1; if (s_pp[mid] <= i) lo_t = mid; else hi_t = mid - 1; }
@@ -882,23 +907,34 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
             const int li = i - s_pp[lo_t], width = same ? tk.np : tk.nq;
             const int ix = li / width, iy = li - ix * width;
             if (same && iy <= ix) continue;
-            const int fx = perm[tk.base_p + ix], fy = perm[(same ? tk.base_p : tk.base_q) + iy];
-            const Geo gx = geo[fx], gy = geo[fy];
+            const int px = tk.base_p + ix, py = (same ? tk.base_p : tk.base_q) + iy; // slots of the position index
+            Geo gx, gy;
+            Stat sx, sy;
+            if (sc.small) { // both fragments sit in LDS: slot -> (contig, position)
+                const int wx = (px >= sc.base[0] && px < sc.base[0] + sc.len[0]) ? 0 : 1;
+                const int wy = (py >= sc.base[0] && py < sc.base[0] + sc.len[0]) ? 0 : 1;
+                const int jx = wx * N_MATES + (px - sc.base[wx]), jy = wy * N_MATES + (py - sc.base[wy]);
+                gx = sc.geo[jx]; gy = sc.geo[jy]; sx = sc.stat[jx]; sy = sc.stat[jy];
+            } else {
+                const int fx = perm[px], fy = perm[py];
+                gx = geo[fx]; gy = geo[fy]; sx = stat[fx]; sy = stat[fy];
+            }
             const End X = end_xf(gx, tk.xp), Y = end_xf(gy, same ? tk.xp : tk.xq);
             if (gap_bp(X, gx.len_bp, Y, gy.len_bp) > reach_bp) continue;
-            const long long qv = pair_mass_q(X, stat[fx], Y, stat[fy], nfpb, par);
+            const long long qv = pair_mass_q(X, sx, Y, sy, nfpb, par);
             if (qv == 0) continue;
             // logL = contacts - mass: the NEW layout's mass counts negative, the OLD one positive
-#pragma unroll
-            for (int op = 0; op < N_OPS; op++)
-                acc[op] += ((long long)((tk.minus >> op) & 1u) - (long long)((tk.plus >> op) & 1u)) * qv;
-        }
-#pragma unroll
-        for (int op = 0; op < N_OPS; op++) {
-            const long long v = wave_sum_ll(acc[op]);
-            if ((t & 63) == 0 && v != 0) atomicAdd((unsigned long long*)&A->acc[k * N_OPS + op], (unsigned long long)v);
+            unsigned ops = tk.minus | tk.plus;
+            while (ops) {
+                const int op = __ffs((int)ops) - 1;
+                ops &= ops - 1;
+                const long long sgn = (long long)((tk.minus >> op) & 1u) - (long long)((tk.plus >> op) & 1u);
+                if (sgn != 0) atomicAdd((unsigned long long*)&s_acc[op], (unsigned long long)(sgn * qv));
+            }
         }
     }
+    __syncthreads();
+    if (t < N_OPS && s_acc[t] != 0) atomicAdd((unsigned long long*)&ta.acc[k * N_OPS + t], (unsigned long long)s_acc[t]);
     __syncthreads();
     STAMP(2, k == 0 && t == 0);
     if (t == 0) {
@@ -1593,7 +1629,9 @@ int scan_threads_cfg()
 
 int scan_grid(const Ctx* h)
 {
-    static const int scan_blocks = getenv("GRAAL_SCAN_BLOCKS") ? atoi(getenv("GRAAL_SCAN_BLOCKS")) : 256 * 2;
+    // two 1024-thread blocks per CU fill the 256 CUs; 16 fewer leave room for k_tm's blocks, which run at the same time (a
+    // CU that hosts one of them takes only one scan block, and a scan block that has to wait for a slot ends 8 us late)
+    static const int scan_blocks = getenv("GRAAL_SCAN_BLOCKS") ? atoi(getenv("GRAAL_SCAN_BLOCKS")) : 256 * 2 - 16;
     const long long groups = (h->nnz >> 2) + 1;
     const long long per_block = 4ll * scan_threads_cfg(); // groups one block takes per iteration
     return (int)std::max<long long>(1, std::min<long long>((groups + per_block - 1) / per_block, scan_blocks));
@@ -1983,7 +2021,7 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     // single-rank path (h->publish) its last block also finishes the step when the work is small.
     if (h->fin_pending) { CK(hipStreamWaitEvent(h->aux, h->ev_fin, 0)); h->fin_pending = false; }
     TmArgs ta;
-    ta.geo = h->geo; ta.link = h->link; ta.cbase = h->cbase; ta.tabs = h->tabs; ta.step_hdr = h->step_hdr;
+    ta.geo = h->geo; ta.link = h->link; ta.cbase = h->cbase; ta.mates = h->mates; ta.tabs = h->tabs; ta.step_hdr = h->step_hdr;
     static const bool no_finisher = getenv("GRAAL_NO_FINISHER") != nullptr; // always finish with k_fin (diagnostics)
     ta.flags = h->d_flags;
     ta.sync = h->d_sync; ta.n_scan_blocks = scan_grid(h);
@@ -2053,6 +2091,14 @@ int graal_eval_candidates(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K
     if (res[0] == -want) return fail(h, GRAAL_E_HIP, "timed out waiting for the candidate tables / the scan (a kernel of the step did not run)");
     __sync_synchronize();
     for (int i = 0; i < K * N_OPS; i++) delta[i] = (double)res[1 + i] / Q_SCALE;
+    return GRAAL_OK;
+}
+
+int graal_set_finisher(graal_ctx* h, int32_t enabled)
+{
+    if (!h) return GRAAL_E_ARG;
+    h->finisher_ok = enabled != 0;
+    h->gave_up = 0;
     return GRAAL_OK;
 }
 

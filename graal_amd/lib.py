@@ -24,7 +24,7 @@ _f64p = ctypes.POINTER(ctypes.c_double)
 SYMBOLS = ("graal_abi_version", "graal_create", "graal_destroy", "graal_last_error", "graal_set_params",
            "graal_upload_subfrags", "graal_upload_contacts", "graal_upload_frags", "graal_download_frags",
            "graal_relabel_contigs", "graal_begin_step", "graal_layout_stats", "graal_eval_full_q", "graal_eval_candidates_q",
-           "graal_eval_candidates", "graal_apply_move", "graal_set_timing", "graal_last_timing", "graal_scan_times", "graal_time_scan", "graal_last_counters")
+           "graal_eval_candidates", "graal_apply_move", "graal_set_finisher", "graal_set_timing", "graal_last_timing", "graal_scan_times", "graal_time_scan", "graal_last_counters")
 
 _lib = None
 
@@ -64,6 +64,7 @@ def load():
         L.graal_last_timing.argtypes = [ctypes.c_void_p, _f32p]
         L.graal_last_counters.argtypes = [ctypes.c_void_p, _i64p]
         L.graal_set_timing.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+        L.graal_set_finisher.argtypes = [ctypes.c_void_p, ctypes.c_int32]
         L.graal_scan_times.argtypes = [ctypes.c_void_p, ctypes.c_int32, _f32p]
         L.graal_time_scan.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, _f32p]
         _lib = L
@@ -201,6 +202,10 @@ class Engine:
                                                  int(rank), int(world), ctypes.c_void_p(int(d_out_ptr)),
                                                  ctypes.c_void_p(int(stream_ptr) if stream_ptr else 0)),
                  "graal_eval_candidates_q")
+
+    def set_finisher(self, enabled):
+        """Let the table kernel's last block finish short-contig steps (default) or always use the finishing kernel."""
+        self._ck(self._L.graal_set_finisher(self._h, 1 if enabled else 0), "graal_set_finisher")
 
     def set_timing(self, enabled):
         self._ck(self._L.graal_set_timing(self._h, int(enabled)), "graal_set_timing")

@@ -101,6 +101,12 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
  * publishes the sums to pinned host memory; the call spins on that instead of a copy + stream synchronise) */
 int graal_eval_candidates(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int32_t max_id, double* delta);
 
+/* In the synchronous single-GPU call, a step that leaves little work (short contigs) is finished by the last block of the
+ * table kernel, which runs concurrently with the streaming kernel and waits for it; otherwise a third kernel finishes it.
+ * Both give bit-identical sums.  enabled = 0 always uses the third kernel (the library does that by itself after noticing
+ * that the two kernels do not run concurrently, e.g. under a profiler that serialises dispatches); 1 re-enables. */
+int graal_set_finisher(graal_ctx* h, int32_t enabled);
+
 /* commit candidate `op` of (fA, fB); replaces test_copy_struct (cuda_lib_gl.py:1156-1180).
  * *n_stale = fragments that hit the reference's unwritten paste branch (expected 0); NULL = do not wait for the
  * commit (the count is then reported by the next graal_begin_step).  The geometry index is stale until then. */

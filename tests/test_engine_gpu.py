@@ -308,6 +308,33 @@ def test_every_fragment_a_singleton():
     _deltas_match(P, s, 5, [6, 7, 30])
 
 
+@pytest.mark.parametrize("n_sub,seed,p_circ", [(1, 61, 0.0), (1, 62, 0.4), (3, 63, 0.3)])
+def test_short_contigs_finished_by_the_table_kernel(n_sub, seed, p_circ):
+    """Many short contigs (<= 8 fragments: the regime of an exploded genome): the step is finished by the last block of the
+    table kernel, from LDS-resident geometry.  Against the oracle, and bit-identical to the path through the finishing
+    kernel (graal_set_finisher(0))."""
+    P = make(n_sub, seed, n_bins=90, nnz=2500, grid_bp=2000)
+    rng = np.random.RandomState(seed)
+    for _ in range(50):
+        s = random_state_for(P, rng, n_contigs=36, p_circ=p_circ)
+        if s["l_cont"].max() <= 8:
+            break
+    assert s["l_cont"].max() <= 8
+    max_id = relabel_ref(s)
+    e1, e2 = engine_for(P, s), engine_for(P, s)
+    e2.set_finisher(False)
+    assert e1.relabel_contigs() == max_id and e2.relabel_contigs() == max_id
+    dense = dense_for(P)
+    for _ in range(6):
+        fA = int(rng.randint(P["n_frags"]))
+        fBs = sorted(int(v) for v in rng.choice(np.setdiff1d(np.arange(P["n_frags"]), [fA]), 5, replace=False))
+        got = e1.eval_candidates(fA, fBs, max_id)
+        assert np.array_equal(got, e2.eval_candidates(fA, fBs, max_id))
+        base, want = oracle_deltas(P, dense, s, fA, fBs, max_id)
+        assert np.all(np.abs(got - want) <= 1e-7 * max(abs(base), 1.0)), np.abs(got - want).max()
+    e1.close(); e2.close()
+
+
 @pytest.mark.parametrize("n_sub,seed,p_circ", [(1, 31, 0.0), (1, 32, 0.5), (3, 33, 0.3)])
 def test_incremental_relabel_matches_the_sort(n_sub, seed, p_circ):
     """graal_begin_step after one commit derives the new ranking by counting (k_incr_plan / k_incr_apply); it must give

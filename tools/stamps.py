@@ -35,7 +35,13 @@ for f in rng.randint(0, 50000, size=300):
     acc += (st - t0) * 0.01; n += 1   # 100 MHz -> us
     bs = np.zeros(4096 * 4, dtype=np.uint64)
     assert L.graal_debug_block_stamps(smp.engine._h, bs.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))) == 0
-    bs = bs.reshape(4096, 4)[:512].astype(np.float64)
+    nblk = int(os.environ.get("GRAAL_SCAN_BLOCKS", 512))
+    bs = bs.reshape(4096, 4)[:nblk].astype(np.float64)
+    if n == 250:
+        st0 = np.sort((bs[:, 0] - t0) * 0.01)
+        print("block start times (us), sorted, every 32nd:", np.round(st0[::32], 1))
+        en0 = np.sort((bs[:, 2] - t0) * 0.01)
+        print("block loop-done times (us), sorted, every 32nd:", np.round(en0[::32], 1))
     blk_acc += np.array([bs[:, 0].min() - t0, bs[:, 0].max() - t0, bs[:, 1].min() - t0, bs[:, 1].max() - t0, bs[:, 2].min() - t0, bs[:, 2].max() - t0]) * 0.01
 a = acc / n
 st_mask = None
