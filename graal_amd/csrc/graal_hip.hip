@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) void k_full_nnz(const int* __restrict__ row, c
         const int fx = a >> 2, fy = b >> 2;
         const End X = end_cur(geo[fx], lcontbp, fx), Y = end_cur(geo[fy], lcontbp, fy);
         const float ex = ex_pair(X, stat[fx], a & 3, Y, stat[fy], b & 3, nfpb, par);
-        acc += to_q((double)cnt[i] * log((double)ex));
+        acc += to_q((double)__int_as_float(cnt[i]) * log((double)ex)); // counts are stored as float32 (the reference's obs type)
     }
     acc = wave_sum_ll(acc);
     if ((threadIdx.x & 63) == 0 && acc != 0) atomicAdd((unsigned long long*)out, (unsigned long long)acc);
@@ -723,7 +723,7 @@ __device__ int tables_block(const Geo* __restrict__ geo, const Link* __restrict_
 struct QEntry {
     unsigned idx, rel;   // contact index in this shard; nibble mask of the neighbours it matters to
     unsigned ci, cj;     // relevance codes of its two fragments: 4 bits per neighbour = piece id
-    int fx, fy, cnt;     // fragments (bins) and observed count
+    int fx, fy, cnt;     // fragments (bins) and observed count (float32 bits)
     int slots;           // sub-fragment slots: slx | sly << 2
 };
 struct DevArgs {
@@ -799,7 +799,7 @@ __device__ __forceinline__ void price_contacts(const PriceArgs& pa, unsigned lon
         if (!todo) continue;
         const End X0 = end_cur(gx, pa.lcontbp, fx), Y0 = end_cur(gy, pa.lcontbp, fy);
         const double ln_old = log((double)ex_pair(X0, sx, slx, Y0, sy, sly, pa.nfpb, pa.par));
-        const double ob = (double)qe.cnt;
+        const double ob = (double)__int_as_float(qe.cnt);
         while (todo) {
             const int k = __ffs((int)todo) - 1;
             todo &= todo - 1;
@@ -1809,18 +1809,22 @@ int graal_upload_subfrags(graal_ctx* h, const int32_t* sub_id, const float* sub_
     return sync_args(h);
 }
 
-int graal_upload_contacts(graal_ctx* h, const int32_t* row, const int32_t* col, const int32_t* count, int64_t nnz)
+// counts as float32: what the reference's dense observation matrix holds (cuda_lib_gl.py:153-156).  Integer counts are
+// exact up to 2^24; the blacklist fill (cuda_lib_gl.py:161-172) makes them non-integer.
+static int upload_contacts_impl(graal_ctx* h, const int32_t* row, const int32_t* col, const float* count, int64_t nnz)
 {
-    if (!h || nnz < 0 || (nnz > 0 && (!row || !col || !count))) return GRAAL_E_ARG;
     if (!h->have_sub) return fail(h, GRAAL_E_STATE, "upload_subfrags first");
+    if (nnz >= (1ll << 32)) return fail(h, GRAAL_E_ARG, "at most 2^32 - 1 contacts per shard");
     CK(hipSetDevice(h->device));
     double c_lf = 0.0;
     double lf_small[16];
     for (int i = 0; i < 16; i++) lf_small[i] = lf_term((double)i);
     for (int64_t i = 0; i < nnz; i++) {
         if (row[i] < 0 || col[i] >= h->n_sub_total || row[i] >= col[i]) return fail(h, GRAAL_E_ARG, "contacts need 0 <= row < col < n_sub_total");
-        if (count[i] <= 0) return fail(h, GRAAL_E_ARG, "contact counts must be > 0");
-        c_lf += count[i] < 16 ? lf_small[count[i]] : lf_term((double)count[i]);
+        const float c = count[i];
+        if (!(c > 0.0f) || !(c < 1.0e30f)) return fail(h, GRAAL_E_ARG, "contact counts must be > 0 and finite");
+        const int ci = (int)c;
+        c_lf += (c < 16.0f && (float)ci == c) ? lf_small[ci] : lf_term((double)c);
     }
     if (h->row) { (void)hipFree(h->row); (void)hipFree(h->col); (void)hipFree(h->cnt); (void)hipFree(h->queue); h->row = h->col = h->cnt = nullptr; h->queue = nullptr; }
     const size_t bytes = sizeof(int) * (size_t)(nnz + 8); // +8: int4 tail reads stay in bounds
@@ -1830,10 +1834,28 @@ int graal_upload_contacts(graal_ctx* h, const int32_t* row, const int32_t* col, 
     if (nnz) {
         CK(hipMemcpy(h->row, row, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
         CK(hipMemcpy(h->col, col, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
-        CK(hipMemcpy(h->cnt, count, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
+        CK(hipMemcpy(h->cnt, count, sizeof(float) * (size_t)nnz, hipMemcpyHostToDevice));
     }
     h->nnz = nnz; h->c_lf = c_lf; h->have_contacts = true;
     return sync_args(h);
+}
+
+int graal_upload_contacts(graal_ctx* h, const int32_t* row, const int32_t* col, const int32_t* count, int64_t nnz)
+{
+    if (!h || nnz < 0 || (nnz > 0 && (!row || !col || !count))) return GRAAL_E_ARG;
+    std::vector<float> f((size_t)nnz);
+    for (int64_t i = 0; i < nnz; i++) {
+        if (count[i] <= 0) return fail(h, GRAAL_E_ARG, "contact counts must be > 0");
+        if (count[i] > (1 << 24)) return fail(h, GRAAL_E_ARG, "integer contact counts above 2^24 are not exact in float32");
+        f[(size_t)i] = (float)count[i];
+    }
+    return upload_contacts_impl(h, row, col, f.data(), nnz);
+}
+
+int graal_upload_contacts_f32(graal_ctx* h, const int32_t* row, const int32_t* col, const float* count, int64_t nnz)
+{
+    if (!h || nnz < 0 || (nnz > 0 && (!row || !col || !count))) return GRAAL_E_ARG;
+    return upload_contacts_impl(h, row, col, count, nnz);
 }
 
 int graal_upload_frags(graal_ctx* h, const int32_t* const soa[GRAAL_N_FIELDS], int32_t n)

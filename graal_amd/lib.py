@@ -22,7 +22,7 @@ _f32p = ctypes.POINTER(ctypes.c_float)
 _f64p = ctypes.POINTER(ctypes.c_double)
 
 SYMBOLS = ("graal_abi_version", "graal_create", "graal_destroy", "graal_last_error", "graal_set_params",
-           "graal_upload_subfrags", "graal_upload_contacts", "graal_upload_frags", "graal_download_frags",
+           "graal_upload_subfrags", "graal_upload_contacts", "graal_upload_contacts_f32", "graal_upload_frags", "graal_download_frags",
            "graal_relabel_contigs", "graal_begin_step", "graal_layout_stats", "graal_eval_full_q", "graal_eval_candidates_q",
            "graal_eval_candidates", "graal_apply_move", "graal_set_finisher", "graal_set_timing", "graal_last_timing", "graal_scan_times", "graal_time_scan", "graal_last_counters")
 
@@ -51,6 +51,7 @@ def load():
         L.graal_upload_subfrags.argtypes = [ctypes.c_void_p, _i32p, _f32p, _i32p, ctypes.c_int32, ctypes.c_int32,
                                             ctypes.c_float]
         L.graal_upload_contacts.argtypes = [ctypes.c_void_p, _i32p, _i32p, _i32p, ctypes.c_int64]
+        L.graal_upload_contacts_f32.argtypes = [ctypes.c_void_p, _i32p, _i32p, _f32p, ctypes.c_int64]
         L.graal_upload_frags.argtypes = [ctypes.c_void_p, ctypes.POINTER(_i32p), ctypes.c_int32]
         L.graal_download_frags.argtypes = [ctypes.c_void_p, ctypes.POINTER(_i32p)]
         L.graal_relabel_contigs.argtypes = [ctypes.c_void_p, _i32p]
@@ -126,10 +127,18 @@ class Engine:
                                                ctypes.c_float(float(n_frags_per_bins))), "graal_upload_subfrags")
 
     def upload_contacts(self, row, col, count):
-        r, c, v = _c(row, np.int32), _c(col, np.int32), _c(count, np.int32)
-        assert len(r) == len(c) == len(v)
-        self._ck(self._L.graal_upload_contacts(self._h, r.ctypes.data_as(_i32p), c.ctypes.data_as(_i32p),
-                                               v.ctypes.data_as(_i32p), len(r)), "graal_upload_contacts")
+        """Counts may be integers or float32 (blacklist fill); integer arrays go through the int32 entry point."""
+        r, c = _c(row, np.int32), _c(col, np.int32)
+        count = np.asarray(count)
+        assert len(r) == len(c) == len(count)
+        if np.issubdtype(count.dtype, np.integer):
+            v = _c(count, np.int32)
+            self._ck(self._L.graal_upload_contacts(self._h, r.ctypes.data_as(_i32p), c.ctypes.data_as(_i32p),
+                                                   v.ctypes.data_as(_i32p), len(r)), "graal_upload_contacts")
+        else:
+            v = _c(count, np.float32)
+            self._ck(self._L.graal_upload_contacts_f32(self._h, r.ctypes.data_as(_i32p), c.ctypes.data_as(_i32p),
+                                                       v.ctypes.data_as(_f32p), len(r)), "graal_upload_contacts_f32")
         self.nnz = len(r)
 
     def upload_frags(self, soa):

@@ -15,7 +15,8 @@ passes them), same method names, argument orders and return tuples for everythin
 * the numpy RNG is an explicit ``RandomState`` (``rng=``); ``None`` keeps the reference's global ``np.random``;
   every ``argsort`` is stable.
 
-Not supported yet (loud ``NotImplementedError``): repeated fragments and blacklisted contigs.
+Blacklisted bins (``cuda_lib_gl.py:161-172``) are supported: their rows of the observation matrix become explicit
+contacts with the float32 fill value.  Not supported yet (loud ``NotImplementedError``): repeated fragments.
 """
 import numpy as np
 
@@ -50,6 +51,42 @@ def as_coo_upper(m):
     r, c, v = r[keep], c[keep], np.asarray(v)[keep]
     order = np.lexsort((c, r))
     return r[order].astype(np.int32), c[order].astype(np.int32), v[order]
+
+
+def blacklist_fill(sub_coo, bin_coo, sub_ids_of_bins, black_bins, fill_value, n_sub_total):
+    """The blacklist fill of ``cuda_lib_gl.py:161-172`` on COO lists instead of dense matrices.
+
+    Bin level (neighbour proposal): rows and columns of blacklisted bins are zeroed -> their entries are dropped.
+    Sub level (observations): every row and column of every sub-fragment of a blacklisted bin is overwritten with
+    ``fill_value`` (= mean_value_trans, float32) -- a dense, non-integer observation for all pairs with that
+    sub-fragment.  They become explicit contacts: (#blacklisted sub-fragments) x n_sub_total entries.
+    Returns (sub_coo, bin_coo) with float32 counts at the sub level, both sorted by (row, col)."""
+    black_bins = np.unique(np.asarray(black_bins, dtype=np.int64))
+    r, c, v = (np.asarray(x) for x in sub_coo)
+    br, bc, bv = (np.asarray(x) for x in bin_coo)
+    if len(black_bins) == 0:
+        return (r, c, v), (br, bc, bv)
+    is_black_bin = np.zeros(int(max(br.max(initial=0), bc.max(initial=0), black_bins.max()) + 1), dtype=bool)
+    is_black_bin[black_bins] = True
+    keep = ~(is_black_bin[br] | is_black_bin[bc])
+    br, bc, bv = br[keep], bc[keep], bv[keep]
+    black_sub = np.zeros(int(n_sub_total), dtype=bool)
+    for b in black_bins:
+        ids = sub_ids_of_bins[b]
+        black_sub[ids[:ids[3]]] = True
+    keep = ~(black_sub[r] | black_sub[c])
+    r, c, v = r[keep].astype(np.int64), c[keep].astype(np.int64), np.asarray(v)[keep].astype(np.float32)
+    subs = np.nonzero(black_sub)[0]
+    all_ids = np.arange(int(n_sub_total), dtype=np.int64)
+    rr, cc = [], []
+    for s_ in subs:   # pairs (s_, y): every y != s_; a pair of two blacklisted sub-fragments is listed once
+        y = all_ids[(all_ids != s_) & ~(black_sub & (all_ids < s_))]
+        rr.append(np.minimum(s_, y)); cc.append(np.maximum(s_, y))
+    rr, cc = np.concatenate(rr), np.concatenate(cc)
+    r = np.concatenate([r, rr]); c = np.concatenate([c, cc])
+    v = np.concatenate([v, np.full(len(rr), np.float32(fill_value), dtype=np.float32)])
+    order = np.lexsort((c, r))
+    return (r[order].astype(np.int32), c[order].astype(np.int32), v[order]), (br, bc, bv)
 
 
 def neighbour_distributions(bin_row, bin_col, bin_val, n_frags, n_neighbors=10, fact=3):
@@ -184,8 +221,6 @@ class sampler(object):
         self.id_frag_duplicated = list(id_frag_duplicated) if id_frag_duplicated is not None else []
         if len(self.id_frag_duplicated) or int(n_new_frags) != int(n_frags):
             raise NotImplementedError("repeated fragments (allow_repeats) are not supported by the MI355X engine yet")
-        if len(self.id_frags_blacklisted):
-            raise NotImplementedError("blacklisted contigs are not supported by the MI355X engine yet")
         self.np_id_frag_duplicated = np.int32(self.id_frag_duplicated)
         self.n_frags = np.int32(n_frags)
         self.n_new_frags = np.int32(n_new_frags)
@@ -213,6 +248,12 @@ class sampler(object):
         # ---- contacts: COO, never dense ------------------------------------------------------------------
         self.sub_coo = as_coo_upper(hic_matrix)                 # sub-level (observed data of the likelihood)
         self.bin_coo = as_coo_upper(hic_matrix_sub_sampled)     # bin level (neighbour proposal only)
+        if len(self.id_frags_blacklisted):                      # cuda_lib_gl.py:161-172
+            if mean_value_trans is None or not float(mean_value_trans) > 0:
+                raise ValueError("blacklisted fragments need mean_value_trans > 0 (the fill value of their observations)")
+            black_bins = np.asarray(S_o_A_frags["id_d"])[np.asarray(self.id_frags_blacklisted, dtype=np.int64)]
+            self.sub_coo, self.bin_coo = blacklist_fill(self.sub_coo, self.bin_coo, self.np_sub_frags_id, black_bins,
+                                                        np.float32(mean_value_trans), int(self.init_n_sub_frags))
         self.sub_n_frags = self.init_n_sub_frags
         # ---- device ------------------------------------------------------------------------------------------
         if group is None:
@@ -226,9 +267,11 @@ class sampler(object):
                                     int(self.init_n_sub_frags), float(self.mean_squared_frags_per_bin))
         lo, hi = gdist.shard_range(len(self.sub_coo[0]), group.rank, group.world)
         counts = np.asarray(self.sub_coo[2])
-        if not np.all(counts == np.round(counts)):
-            raise NotImplementedError("non-integer contact counts (blacklist fill) are not supported yet")
-        self.engine.upload_contacts(self.sub_coo[0][lo:hi], self.sub_coo[1][lo:hi], counts[lo:hi].astype(np.int32))
+        if np.all(counts == np.round(counts)) and (len(counts) == 0 or counts.max() < 2 ** 24):
+            counts = counts.astype(np.int32)
+        else:
+            counts = counts.astype(np.float32)   # the reference's observation type (blacklist fill: non-integer)
+        self.engine.upload_contacts(self.sub_coo[0][lo:hi], self.sub_coo[1][lo:hi], counts[lo:hi])
         n = int(self.n_new_frags)
         soa = {k: np.array(S_o_A_frags[k], dtype=np.int32, copy=True) for k in FIELDS if k != "ori"}
         soa["ori"] = np.ones((n,), dtype=np.int32)  # cuda_lib_gl.py:244,259
@@ -439,6 +482,7 @@ class sampler(object):
             self.test_copy_struct(i, 0, 0, max_id)
 
     def define_repeats(self):
+        self._black_set = set(int(x) for x in self.id_frags_blacklisted)
         self.is_repeat = [False] * int(self.n_new_frags)
         self.n_frags_duplicated = 0
         self.n_frags_4_dist = len(np.unique(self.id_frags_blacklisted))
@@ -447,6 +491,8 @@ class sampler(object):
         g = self.gpu_vect_frags if tmp_gpu_vect_frags is None else tmp_gpu_vect_frags
         g.copy_from_gpu()
         counted = np.ones(int(self.n_new_frags), dtype=bool)
+        if len(self.id_frags_blacklisted):                      # cuda_lib_gl.py:485
+            counted[np.asarray(self.id_frags_blacklisted, dtype=np.int64)] = False
         return dist_inter_genome(g.prev, g.next, g.ori, g.id_d, self.np_init_prev, self.np_init_next, self.np_init_ori,
                                  self.np_init_orientable, counted, self.n_frags_4_dist)
 
@@ -466,7 +512,8 @@ class sampler(object):
         distri = self.distri_frags["pk"][ori_id]
         n_max_candidates = min(delta, np.nonzero(distri != 0)[0].shape[0])
         init_id = self.rng.choice(self.distri_frags["xk"][ori_id], n_max_candidates, p=distri, replace=False)
-        return [int(x) for x in init_id]
+        black = self._black_set
+        return [int(x) for x in init_id if int(x) not in black]   # cuda_lib_gl.py:2326-2329
 
     # ------------------------------------------------------------------ one MCMC step
     def step_max_likelihood(self, id_fA, delta, size_block=512, dt=0, t=0, n_step=1):
@@ -481,6 +528,11 @@ class sampler(object):
         mean_len_bp = float(st[3]) / float(st[2])
         max_len = np.int32(st[4])
         min_len = np.int32(st[5])
+        if id_fA in self._black_set:            # cuda_lib_gl.py:1962-1978: nothing is proposed for a blacklisted fragment
+            o = self.o
+            dist = self.dist_inter_genome() if self.compute_dist else 0.0
+            self.likelihood_t = o
+            return o, n_contigs, min_len, mean_len_bp, max_len, -1, id_fA, dist, self.temperature(t, n_step)
         if self.likelihood_t is None:
             self.likelihood_t = self._full_likelihood()
         elif (n_circ or self._n_circ_prev) and not self._single_sub:

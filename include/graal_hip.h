@@ -35,7 +35,7 @@ enum {
     GRAAL_E_ARG = 1,          /* bad argument / shape */
     GRAAL_E_HIP = 2,          /* HIP runtime error (incl. no device) */
     GRAAL_E_STATE = 3,        /* call order (e.g. eval before upload) */
-    GRAAL_E_UNSUPPORTED = 4   /* repeats / blacklist / inactive fragments: not in this round */
+    GRAAL_E_UNSUPPORTED = 4   /* repeated / inactive fragments: not in this round */
 };
 
 typedef struct graal_ctx graal_ctx;
@@ -60,6 +60,9 @@ int graal_upload_subfrags(graal_ctx* h, const int32_t* sub_id, const float* sub_
  * (row, col) is fastest); counts are the observed contacts.  Replaces the dense S x S upload of
  * cuda_lib_gl.py:194 (which simulation_loader.py:81-82 densifies first). */
 int graal_upload_contacts(graal_ctx* h, const int32_t* row, const int32_t* col, const int32_t* count, int64_t nnz);
+/* same with float32 counts -- the type of the reference's observation matrix; needed when blacklisted bins carry the
+ * non-integer fill value mean_value_trans (cuda_lib_gl.py:161-172) */
+int graal_upload_contacts_f32(graal_ctx* h, const int32_t* row, const int32_t* col, const float* count, int64_t nnz);
 
 /* fragment layout: 14 arrays of n int32 in the order of struct frag; replaces GPUStruct.copy_to_gpu
  * (cuda_lib_gl.py:264-265) / copy_from_gpu (gpustruct.py:175) */

@@ -129,3 +129,31 @@ def test_shard_ranges_partition_the_contact_list():
             assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in edges]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_blacklist_fill_equals_the_dense_fill():
+    """blacklist_fill on COO lists == the reference's dense overwrite (cuda_lib_gl.py:161-172)."""
+    from graal_amd.sampler import as_coo_upper, blacklist_fill
+    rng = np.random.RandomState(5)
+    n_bins, S = 12, 30
+    sub_ids = np.zeros((n_bins, 4), dtype=np.int32)
+    k = 0
+    for b in range(n_bins):
+        ns = 3 if b < 9 else 1
+        sub_ids[b, :ns] = np.arange(k, k + ns); sub_ids[b, 3] = ns; k += ns
+    assert k == S
+    dense = np.triu(rng.poisson(0.8, size=(S, S)).astype(np.float32), 1); dense = dense + dense.T
+    bdense = np.triu(rng.poisson(2.0, size=(n_bins, n_bins)).astype(np.float32), 1); bdense = bdense + bdense.T
+    black, v = [2, 10], np.float32(0.037)
+    want, bwant = dense.copy(), bdense.copy()
+    for b in black:
+        bwant[b, :] = 0; bwant[:, b] = 0
+        for i in range(sub_ids[b, 3]):
+            want[sub_ids[b, i], :] = v; want[:, sub_ids[b, i]] = v
+    (r, c, val), (br, bc, bv) = blacklist_fill(as_coo_upper(dense), as_coo_upper(bdense), sub_ids, black, v, S)
+    got = np.zeros((S, S), dtype=np.float32); got[r, c] = val; got[c, r] = val
+    np.fill_diagonal(want, 0)
+    assert np.array_equal(got, want)
+    assert np.all(r < c) and np.all(np.diff(r.astype(np.int64) * S + c) > 0)      # upper, sorted, no duplicates
+    bgot = np.zeros((n_bins, n_bins), dtype=np.float32); bgot[br, bc] = bv; bgot[bc, br] = bv
+    assert np.array_equal(bgot, bwant)

@@ -111,8 +111,27 @@ def test_unsupported_inputs_fail_loudly():
             P["n_new_frags"], P["init_n_sub_frags"], P["n_new_sub_frags"], None, P["hic_matrix_sub_sampled"],
             P["np_sub_frags_len_bp"], P["np_sub_frags_id"], P["np_sub_frags_accu"], P["mean_squared_frags_per_bin"],
             None, None, P["hic_matrix"], P["mean_value_trans"], 2, False, None]
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError):   # repeated fragments
         sampler(*args)
-    args[4], args[5] = [], [2]
-    with pytest.raises(NotImplementedError):
-        sampler(*args)
+
+
+@pytest.mark.parametrize("n_sub,seed", [(1, 47), (3, 48)])
+def test_trace_with_blacklisted_fragments_matches_oracle(n_sub, seed):
+    """Blacklisted bins (cuda_lib_gl.py:161-172, 1796, 1962-1978, 2326-2329): their observations are the non-integer fill
+    value for EVERY pair, they are never proposed and never moved on their own, and they do not count in the distance."""
+    P = problem(n_sub, seed, 50, 900)
+    P["id_frags_blacklisted"] = [3, 4, 5, 17, 31]
+    ora = O.OracleSampler(P, np.random.RandomState(seed), fix_trans_accu=True)
+    t_ref = em.run_em(ora, 2, 4, rng=ora.rng)
+    gpu_rng = np.random.RandomState(seed)
+    g = make_gpu_sampler(P, gpu_rng)
+    assert g.eval_likelihood() == pytest.approx(O.OracleSampler(P, np.random.RandomState(0), fix_trans_accu=True).init_likelihood(), rel=1e-6)
+    t_gpu = em.run_em(g, 2, 4, rng=gpu_rng)
+    assert np.array_equal(t_gpu.mutations(), t_ref.mutations())
+    assert (np.asarray(t_ref.mutations())[:, 2] == -1).sum() == 2 * len(P["id_frags_blacklisted"])   # skipped steps are in the trace
+    assert t_gpu.n_contigs == t_ref.n_contigs and t_gpu.dist == t_ref.dist
+    assert np.allclose(t_gpu.likelihood, t_ref.likelihood, rtol=1e-6, atol=0)
+    g.gpu_vect_frags.copy_from_gpu()
+    for k in O.FIELDS:
+        assert np.array_equal(getattr(g.gpu_vect_frags, k), ora.gpu_vect_frags[k]), k
+    g.free_gpu()
