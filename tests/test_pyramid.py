@@ -1,0 +1,176 @@
+"""CPU: the pyramid builder / loader (graal_amd/pyramid.py) and the FASTA export (f4) on a small
+hand-made dataset in the reference's 3-file text format.  The expectations are computed here independently, from the
+definitions in pyramid_sparse.py (cited in graal_amd/pyramid.py), not by calling the module under test."""
+import os
+
+import numpy as np
+import pytest
+
+from graal_amd import pyramid as pyr
+
+
+def make_dataset(tmp, rng, contig_sizes=(11, 7, 5), n_pairs=6000, empty=(4, 15)):
+    """info_contigs.txt / fragments_list.txt / abs_fragments_contacts_weighted.txt (README.md:111-113)."""
+    frag_rows, contig_rows, seqs = [], [], {}
+    cum = 0
+    for ci, nf in enumerate(contig_sizes):
+        name = "chr%d" % (ci + 1)
+        pos = 0
+        for k in range(1, nf + 1):
+            size = int(rng.randint(300, 3000))
+            frag_rows.append([k, name, pos, pos + size, size, round(float(rng.rand()), 3)])
+            pos += size
+        contig_rows.append([name, pos, nf, cum])
+        cum += nf
+        seqs[name] = "".join(rng.choice(list("ACGT"), size=pos))
+    n = cum
+    os.makedirs(tmp, exist_ok=True)
+    pyr._write_table(os.path.join(tmp, "info_contigs.txt"), ["contig", "length_kb", "n_frags", "cumul_length"], contig_rows)
+    pyr._write_table(os.path.join(tmp, "fragments_list.txt"), ["id", "chrom", "start_pos", "end_pos", "size", "gc_content"], frag_rows)
+    ok = np.setdiff1d(np.arange(n), empty)
+    a = rng.choice(ok, size=n_pairs)
+    b = np.clip(a + rng.geometric(0.35, size=n_pairs) * rng.choice([-1, 1], size=n_pairs), 0, n - 1)
+    b = np.where(np.isin(b, empty), a, b)
+    extra = [(e, e + 1) for e in empty]           # the "empty" fragments get one contact each: very sparse rows
+    pairs = np.concatenate([np.stack([a, b], 1), np.array(extra)]) + 1
+    with open(os.path.join(tmp, "abs_fragments_contacts_weighted.txt"), "w") as f:
+        f.write("id_read_a\tid_read_b\tw\n")
+        for x, y in pairs:
+            f.write("%d\t%d\t1.0\n" % (x, y))
+    with open(os.path.join(tmp, "genome.fa"), "w") as f:
+        for name in seqs:
+            f.write(">%s\n" % name)
+            for i in range(0, len(seqs[name]), 70):
+                f.write(seqs[name][i:i + 70] + "\n")
+    return n, pairs - 1, frag_rows, seqs
+
+
+def test_build_and_filter_and_levels(tmp_path):
+    rng = np.random.RandomState(3)
+    base = str(tmp_path / "ds")
+    n, pairs, frag_rows, _ = make_dataset(base, rng)
+    P = pyr.build_and_filter(base, 3, 3)
+    # ---- level 0 before filtering: symmetrised counts
+    dense = np.zeros((n, n), np.int64)
+    for x, y in pairs:
+        dense[min(x, y), max(x, y)] += 1
+    a0, b0, v0 = pyr.read_coo(os.path.join(base, "pyramids", "pyramid_1_no_thresh", "level_0", "0_abs_frag_contacts.txt"))
+    got = np.zeros_like(dense); got[a0, b0] = v0
+    assert np.array_equal(got, dense)
+    # ---- the filter: fraction of non-zero entries per row of M + M^T, threshold mean - 1.01 sigma (float32)
+    full = dense + dense.T
+    spars = np.float32((full != 0).sum(axis=1)) / np.float32(n)
+    thresh = spars.mean() - 1.01 * spars.std()
+    locked = set(np.nonzero(spars <= thresh)[0].tolist())
+    assert locked == {4, 15}                       # the two starved fragments
+    assert float(P.data["thresh"]) == pytest.approx(float(thresh))
+    # a locked fragment is merged into the next unlocked one of its contig: fragment 4 -> bin of fragment 5, 15 -> 16
+    o2n, new = {}, 0
+    contig_of = [r[1] for r in frag_rows]
+    run = []
+    for i in range(n):
+        run.append(i)
+        if i not in locked:
+            for j in run:
+                o2n[j] = new
+            new += 1; run = []
+        if i + 1 == n or contig_of[i + 1] != contig_of[i]:
+            run = []                               # (an open run at the end of a contig would be destroyed; none here)
+    lv0 = P.get_level(0)
+    assert lv0.n_frags == new == n - 2
+    want = np.zeros((new, new), np.int64)
+    for x, y in pairs:
+        p, q = o2n[min(x, y)], o2n[max(x, y)]
+        want[min(p, q), max(p, q)] += 1
+    a, b, v = P.level_coo(0)
+    got = np.zeros_like(want); got[a, b] = v
+    assert np.array_equal(got, want)
+    # merged bin: size and accu add up, start of the first, end of the last
+    S = lv0.S_o_A_frags
+    assert S["len_bp"][o2n[4]] == frag_rows[4][4] + frag_rows[5][4] and S["n_accu"][o2n[4]] == 2
+    assert S["start_bp"][o2n[4]] == frag_rows[4][2]
+    assert np.array_equal(S["l_cont"][[0, 10, 17]], [10, 6, 5])     # 11-1, 7-1, 5 fragments per contig
+    assert np.array_equal(np.unique(S["id_c"]), [1, 2, 3]) and S["prev"][0] == -1 and S["next"][9] == -1 and S["next"][0] == 1
+    # ---- level 1: bins of 3 consecutive level-0 fragments per contig; the reference drops the first contact line
+    sizes0 = [10, 6, 5]
+    sup, k, base0 = {}, 0, 0
+    for s in sizes0:
+        for r in range(s):
+            sup[base0 + r] = k + r // 3
+        k += (s + 2) // 3; base0 += s
+    lv1 = P.get_level(1)
+    assert lv1.n_frags == k == 4 + 2 + 2
+    want1 = np.zeros((k, k), np.int64)
+    for (x, y, c) in list(zip(a, b, v))[1:]:
+        p, q = sup[x], sup[y]
+        want1[min(p, q), max(p, q)] += c
+    a1, b1, v1 = P.level_coo(1)
+    got1 = np.zeros_like(want1); got1[a1, b1] = v1
+    assert np.array_equal(got1, want1)
+    frs = P.spec_level["1"]["fragments"]
+    assert [f["sub_low_index"] for f in frs[:4]] == [1, 4, 7, 10] and frs[3]["sub_high_index"] == 10
+    assert lv1.S_o_A_frags["n_accu"][0] == 3 and lv1.S_o_A_frags["l_cont"][0] == 4 and lv1.S_o_A_frags["sub_l_cont"][0] == 10
+    assert P.spec_level["0"]["fragments"][4]["super_index"] == 2      # sub -> super index file
+    # mean trans value: stored (upper) entries whose row and column lie in different contigs / #such ordered pairs
+    cid = lv1.S_o_A_frags["id_c"]
+    tot = sum(int(c) for x, y, c in zip(a1, b1, v1) if cid[x] != cid[y])
+    n_tot = sum(s * k - s * s for s in (4, 2, 2))
+    assert lv1.mean_value_trans == pytest.approx(tot / n_tot, rel=1e-6)
+
+
+def test_simulation_inputs_feed_the_sampler_constructor(tmp_path):
+    rng = np.random.RandomState(4)
+    base = str(tmp_path / "ds")
+    make_dataset(base, rng)
+    P = pyr.build_and_filter(base, 3, 3)
+    inp = pyr.simulation_inputs(P, 1, candidates_blacklist=[3])
+    n = inp["n_frags"]
+    assert n == 8 and inp["init_n_sub_frags"] == 21
+    ids = inp["np_sub_frags_id"]
+    assert np.array_equal(ids[0], [0, 1, 2, 3]) and np.array_equal(ids[3], [9, 0, 0, 1]) and np.array_equal(ids[4, :3], [10, 11, 12])
+    sub = P.get_level(0)
+    assert inp["np_sub_frags_len_bp"][0, 1] == np.float32(sub.S_o_A_frags["len_bp"][1]) / np.float32(1000.0)
+    assert inp["np_sub_frags_accu"][1].tolist() == [1, 2, 1]          # the merged level-0 bin carries 2 restriction fragments
+    assert inp["id_frags_blacklisted"] == [6, 7]                      # the bins of contig 3
+    assert inp["mean_squared_frags_per_bin"] == np.float32(np.float32(sub.S_o_A_frags["n_accu"]).mean() ** 2)
+    assert inp["hic_matrix"][0].max() < 21 and inp["hic_matrix_sub_sampled"][0].max() < 8
+    # the host side of the sampler accepts them as they are (COO triples, nothing densified)
+    from graal_amd.sampler import as_coo_upper, blacklist_fill, neighbour_distributions
+    r, c, v = as_coo_upper(inp["hic_matrix_sub_sampled"])
+    xk, pk = neighbour_distributions(r, c, v, n)
+    assert xk.shape == (n, 8) and np.allclose(pk.sum(axis=1), 1.0)
+    (sr, sc, sv), _ = blacklist_fill(as_coo_upper(inp["hic_matrix"]), (r, c, v), ids, [6, 7], inp["mean_value_trans"], 21)
+    assert sv.dtype == np.float32 and len(sr) >= 5 * 20
+
+
+def test_fasta_export(tmp_path):
+    rng = np.random.RandomState(5)
+    base = str(tmp_path / "ds")
+    n, _, frag_rows, seqs = make_dataset(base, rng)
+    P = pyr.build_and_filter(base, 2, 3)
+    P.load_reference_sequence(os.path.join(base, "genome.fa"), strict_reference=False)
+    assert P.dict_sequence_contigs == seqs
+    lv = P.get_level(1)
+    frs = P.spec_level["1"]["fragments"]
+
+    class V:   # a layout: contig 7 = bins 1 (reversed) then 0; everything else a singleton
+        pass
+    m = lv.n_frags
+    v = V()
+    v.id_c = np.arange(m) + 10; v.pos = np.zeros(m, int); v.ori = np.ones(m, int); v.activ = np.ones(m, int); v.id_d = np.arange(m)
+    v.id_c[0] = v.id_c[1] = 7; v.pos[0] = 1; v.ori[1] = -1
+    out, info = str(tmp_path / "g.fa"), str(tmp_path / "info.txt")
+    lv.generate_new_fasta(v, out, info)
+    txt = open(out).read().split(">")[1:]
+    assert txt[0].startswith("3C-assembly|contig_7\n")
+    body = "".join(txt[0].split("\n")[1:])
+    s0 = seqs["chr1"][frs[0]["start_pos"]:frs[0]["end_pos"]]
+    s1 = seqs["chr1"][frs[1]["start_pos"]:frs[1]["end_pos"]]
+    rc = s1[::-1].translate(str.maketrans("ACGT", "TGCA"))
+    assert body == rc + s0
+    assert all(len(line) == 61 for line in txt[0].split("\n")[1:-2])
+    lines = open(info).read().split("\n")
+    assert lines[0] == ">3C-assembly|contig_7" and lines[2].split("\t") == ["chr1", "1", "-1", str(frs[1]["start_pos"]), str(frs[1]["end_pos"])]
+    # the reference's reader: last record keeps its newlines and loses its last line
+    strict = P.load_reference_sequence(os.path.join(base, "genome.fa"), strict_reference=True)
+    assert strict["chr1"] == seqs["chr1"] and "\n" in strict["chr3"] and len(strict["chr3"].replace("\n", "")) < len(seqs["chr3"])

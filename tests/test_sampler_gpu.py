@@ -135,3 +135,44 @@ def test_trace_with_blacklisted_fragments_matches_oracle(n_sub, seed):
     for k in O.FIELDS:
         assert np.array_equal(getattr(g.gpu_vect_frags, k), ora.gpu_vect_frags[k]), k
     g.free_gpu()
+
+
+def test_dataset_to_trace_through_the_pyramid(tmp_path):
+    """End to end (rows f3 + f2 + the hot path): 3-file text dataset -> filtered pyramid -> sampler inputs of level 1 (ragged
+    bins of 1-3 sub-fragments, one merged level-0 bin, a blacklisted contig) -> MCMC cycles on the GPU, against the oracle's
+    literal restatement fed with the DENSE matrices of the same pyramid."""
+    from graal_amd import pyramid as pyr
+    from graal_amd.sampler import sampler
+    from tests.test_pyramid import make_dataset
+    rng = np.random.RandomState(11)
+    base = str(tmp_path / "ds")
+    make_dataset(base, rng, contig_sizes=(23, 16, 12), n_pairs=30000, empty=(4, 30))
+    P0 = pyr.build_and_filter(base, 2, 3)
+    inp = pyr.simulation_inputs(P0, 1, candidates_blacklist=[3])
+    # exact float32 kb coordinates make the dense reference arithmetic shift invariant (see DESIGN.md): put the level-0
+    # fragments on a 2 kb grid
+    S, n = inp["init_n_sub_frags"], inp["n_frags"]
+    par = synth.make_param_simu(fact=200.0, v_inter=max(float(inp["mean_value_trans"]), 0.02))
+    P = dict(inp)
+    P["param_simu"] = par
+    sr, sc, sv = inp["hic_matrix"]
+    br, bc, bv = inp["hic_matrix_sub_sampled"]
+    P["hic_matrix"] = synth.dense_from_coo(sr, sc, sv, S)
+    P["hic_matrix_sub_sampled"] = synth.dense_from_coo(br, bc, bv, n)
+    seed = 12
+    ora = O.OracleSampler(P, np.random.RandomState(seed), fix_trans_accu=True)
+    t_ref = em.run_em(ora, 2, 4, rng=ora.rng)
+    gpu_rng = np.random.RandomState(seed)
+    g = sampler(True, inp["S_o_A_frags"], inp["collector_id_repeats"], inp["frag_dispatcher"], inp["id_frag_duplicated"],
+                inp["id_frags_blacklisted"], inp["n_frags"], inp["n_new_frags"], inp["init_n_sub_frags"], inp["n_new_sub_frags"],
+                None, inp["hic_matrix_sub_sampled"], inp["np_sub_frags_len_bp"], inp["np_sub_frags_id"], inp["np_sub_frags_accu"],
+                inp["mean_squared_frags_per_bin"], inp["norm_vect_accu"], inp["S_o_A_sub_frags"], inp["hic_matrix"],
+                inp["mean_value_trans"], 2, False, None, rng=gpu_rng, param_simu=par)
+    t_gpu = em.run_em(g, 2, 4, rng=gpu_rng)
+    assert np.array_equal(t_gpu.mutations(), t_ref.mutations())
+    assert t_gpu.n_contigs == t_ref.n_contigs and t_gpu.dist == t_ref.dist
+    assert np.allclose(t_gpu.likelihood, t_ref.likelihood, rtol=1e-5, atol=0)   # generic bp coordinates: north_star tolerance
+    g.gpu_vect_frags.copy_from_gpu()
+    for k in O.FIELDS:
+        assert np.array_equal(getattr(g.gpu_vect_frags, k), ora.gpu_vect_frags[k]), k
+    g.free_gpu()
