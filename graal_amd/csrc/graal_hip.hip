@@ -61,12 +61,16 @@ __device__ __forceinline__ void st_rec(const SoaPtr& s, int f, const Rec& r)
 }
 
 // ------------------------------------------------------------------ contact model (float32, as the reference)
+// pow(x, 2.0f) of the reference: the correctly rounded square IS the single float32 multiplication (what a correctly
+// rounded powf returns, e.g. glibc's in the oracle); the general powf costs ~100 instructions more
+__device__ __forceinline__ float sq(float x) { return x * x; }
+
 // rippe_contacts kernels3.cu:120
 __device__ __forceinline__ float rippe(float s, const Par& p)
 {
     float result = 0.0f;
     if ((s > 0.0f) && (s < p.d_max))
-        result = (p.c1 * powf(s, p.slope) * expf((p.d - 2) / (powf(s * p.lm / p.kuhn, 2.0f) + p.d))) * p.fact;
+        result = (p.c1 * powf(s, p.slope) * expf((p.d - 2) / (sq(s * p.lm / p.kuhn) + p.d))) * p.fact;
     return fmaxf(result, p.v_inter);
 }
 
@@ -80,8 +84,8 @@ __device__ __forceinline__ float rippe_circ(float s, float s_tot, const Par& p)
         const float n = K * s * (s_tot - s) / s_tot;
         const float norm_lin = rippe(s, p);
         const float norm_circ =
-            (powf(p.kuhn, -3.0f) * powf(nmax, p.slope) * expf((p.d - 2.0f) / (powf(nmax, 2.0f) + p.d))) * p.fact;
-        const float val = (powf(p.kuhn, -3.0f) * powf(n, p.slope) * expf((p.d - 2.0f) / (powf(n, 2.0f) + p.d))) * p.fact;
+            (powf(p.kuhn, -3.0f) * powf(nmax, p.slope) * expf((p.d - 2.0f) / (sq(nmax) + p.d))) * p.fact;
+        const float val = (powf(p.kuhn, -3.0f) * powf(n, p.slope) * expf((p.d - 2.0f) / (sq(n) + p.d))) * p.fact;
         result = val * norm_lin / norm_circ;
     }
     return fmaxf(result, p.v_inter);
@@ -485,6 +489,13 @@ struct NbTables {        // everything the finishing kernel needs about one neig
 };
 
 struct Neigh { int fB[MAXK]; };
+
+// LDS hand-over between the lanes of ONE wave: LDS operations of a wave execute in program order, so no hardware barrier is
+// needed -- only the compiler must not move them across lanes' dependencies
+#define WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+// one staged fragment y of the mass walk (k_fin): transformed geometry + statistics, 64 bytes
+struct YTile { int start_bp, len_bp, flags, label, lbp, pad0, pad1, pad2; Stat st; };
 constexpr int FLAG_STRIDE = 32; // words between two blocks' completion flags: one 128-byte line each (partial writes to one
                                 // line from many XCDs serialise at the memory side)
 
@@ -1334,6 +1345,7 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
     unsigned long long* __restrict__ counters = fa.counters;
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
+    __shared__ YTile s_tile[4][64];
     STAMP(16, blockIdx.x == 0 && threadIdx.x == 0);
     const unsigned long long nq_total = counters[2]; // written by k_scan, the previous kernel on the stream
     // ---- wait for the tables (bounded spin: every wave reaches the exit even if k_tm never ran).  The word k_tm
@@ -1391,43 +1403,56 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
             const Task tk = T.task[ti];
             const int np = tk.np, nq = tk.nq, base_p = tk.base_p, base_q = tk.base_q;
             items++;
-            // lanes: 16 fragments x of the chunk (4 passes cover its 64) times 4 interleaved phases of the y walk
-            const int xi = lane & 15, yph = lane >> 4;
+            // lane = one fragment x of the chunk.  The fragments y it is paired with are walked AWAY from the chunk, 64 at a
+            // time: the wave stages their transformed geometry and statistics in LDS once (one dependent-load chain per 64
+            // y instead of one per pair -- the loop used to be bound by that latency), then every lane runs over the tile
+            // reading LDS broadcasts.  A lane is done at its first y beyond the window (distances only grow from there).
+            const int ix = chunk * 64 + lane;
+            const bool has_x = ix < np;
+            const bool same = tk.p == tk.q;
+            Geo gx = {0, 0, 0, 0};
+            Stat sx = {0.0f, 0.0f, 0.0f, 0, 0, 0, 0, 0};
+            if (has_x) { const int fx = perm[base_p + ix]; gx = geo[fx]; sx = stat[fx]; }
+            const End X = end_xf(gx, tk.xp);
+            bool x_below = true, asc = true;
+            if (!same) {
+                // q's fragment nearest to x in this layout: pieces map to disjoint intervals, so the side is fixed by
+                // comparing x with q's first fragment (the same for every x of the piece: taken from lane 0)
+                const End Q0 = end_xf(geo[perm[base_q]], tk.xq);
+                x_below = __shfl((int)(X.start_bp < Q0.start_bp), 0, 64) != 0;
+                asc = (tk.xq.sigma > 0) == x_below; // walk q by increasing old position?
+            }
+            const int ny = same ? np : nq;                 // length of the walk
+            YTile* tile = s_tile[threadIdx.x >> 6];
+            bool done = !has_x;
             long long accq = 0;
-            for (int pass = 0; pass < 4; pass++) {
-                const int ix = chunk * 64 + pass * 16 + xi;
-                if (ix >= np) continue;
-                const int fx = perm[base_p + ix];
-                const Geo gx = geo[fx];
-                const Stat sx = stat[fx];
-                const End X = end_xf(gx, tk.xp);
-                if (tk.p == tk.q) {
-                    // (x's own sub-fragment pairs are left out: candidates never revisit a bin's own pixel)
-                    // later fragments of the same piece, walking away from x in the new layout
-                    for (int iy = ix + 1 + yph; iy < np; iy += 4) {
-                        const int fy = perm[base_p + iy];
-                        const Geo gy = geo[fy];
-                        const End Y = end_xf(gy, tk.xp);
-                        if (gap_bp(X, gx.len_bp, Y, gy.len_bp) > reach_bp) break;
-                        accq += pair_mass_q(X, sx, Y, stat[fy], nfpb, par);
-                    }
-                } else {
-                    // q's fragment nearest to x in this layout: pieces map to disjoint intervals, so the side is
-                    // fixed by comparing x with q's first fragment
-                    const int fq0 = perm[base_q];
-                    const End Q0 = end_xf(geo[fq0], tk.xq);
-                    const bool x_below = X.start_bp < Q0.start_bp;
-                    const bool asc = (tk.xq.sigma > 0) == x_below; // walk q by increasing old position?
-                    for (int st = yph; st < nq; st += 4) {
-                        const int iy = asc ? st : nq - 1 - st;
-                        const int fy = perm[base_q + iy];
-                        const Geo gy = geo[fy];
-                        const End Y = end_xf(gy, tk.xq);
-                        const int gap = x_below ? Y.start_bp - (X.start_bp + gx.len_bp) : X.start_bp - (Y.start_bp + gy.len_bp);
-                        if (gap > reach_bp) break;
-                        accq += pair_mass_q(X, sx, Y, stat[fy], nfpb, par);
-                    }
+            for (int tb = same ? chunk * 64 + 1 : 0; tb < ny; tb += 64) {
+                const int st = tb + lane;
+                if (st < ny) {
+                    const int iy = same ? st : (asc ? st : nq - 1 - st);
+                    const int fy = perm[(same ? base_p : base_q) + iy];
+                    const Geo gy = geo[fy];
+                    const End Y = end_xf(gy, same ? tk.xp : tk.xq);
+                    YTile y;
+                    y.start_bp = Y.start_bp; y.len_bp = gy.len_bp; y.flags = (Y.fwd ? 1 : 0) | (Y.circ << 1); y.label = Y.label;
+                    y.lbp = Y.lbp; y.st = stat[fy];
+                    tile[lane] = y;
                 }
+                WAVE_LDS_SYNC();
+                const int cnt = ny - tb < 64 ? ny - tb : 64;
+                for (int j = 0; j < cnt; j++) {
+                    // (x's own sub-fragment pairs and earlier fragments of the same piece are left out: candidates never
+                    // revisit a bin's own pixel, and every pair is priced once, from its lower fragment)
+                    if (done || (same && tb + j <= ix)) continue;
+                    const YTile& y = tile[j];
+                    End Y; Y.label = y.label; Y.start_bp = y.start_bp; Y.fwd = y.flags & 1; Y.circ = (y.flags >> 1) & 1; Y.lbp = y.lbp;
+                    const int gap = same ? gap_bp(X, gx.len_bp, Y, y.len_bp)
+                                         : (x_below ? Y.start_bp - (X.start_bp + gx.len_bp) : X.start_bp - (Y.start_bp + y.len_bp));
+                    if (gap > reach_bp) { done = true; continue; }
+                    accq += pair_mass_q(X, sx, Y, y.st, nfpb, par);
+                }
+                if (__ballot(!done) == 0) break;
+                WAVE_LDS_SYNC();
             }
             const long long qv = wave_sum_ll(accq);
             if (lane == 0 && qv != 0) {
