@@ -1,0 +1,68 @@
+"""GPU, BASELINE.json's full size (C5: 50,000 fragments / 20,000,000 contacts, the bench.py workload): properties that do not
+need the dense oracle (which cannot run at this size).
+
+* the reference's implied invariant (cuda_lib_gl.py:2196-2220): candidate delta == full likelihood after the move - before;
+* the step finished inside k_tm == the step finished by k_fin, bit for bit;
+* determinism: the same seed gives the same accepted-move trace and the same final layout twice;
+* structural invariants of the layout after 1,500 real MCMC steps (cuda_lib_gl.py:1530-1537)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def c5():
+    import bench
+    from graal_amd import synth
+    P = synth.make_problem(n_bins=50000, nnz=20_000_000, n_sub=1, seed=20141217)
+    P["S_o_A_frags"] = bench.exploded_layout(P)
+    return P
+
+
+def run(P, seed, n_steps, finisher=True):
+    import bench
+    rng = np.random.RandomState(seed)
+    smp = bench.build_sampler(P, rng, None, 0)
+    smp.engine.set_finisher(finisher)
+    smp.init_likelihood()
+    order = np.arange(int(smp.n_new_frags), dtype=np.int32)
+    rng.shuffle(order)
+    trace = []
+    for i in order[:n_steps]:
+        o, n_contigs, _, _, _, op, fB, _, _ = smp.step_max_likelihood(int(i), 5)
+        trace.append((int(i), int(fB), int(op), float(o), int(n_contigs)))
+    return smp, trace
+
+
+def test_c5_properties(c5):
+    smp, trace = run(c5, 7, 1500)
+    n = int(smp.n_new_frags)
+    # ---- delta of the accepted move == full(after) - full(before), on the carried-over total
+    carried = trace[-1][3]
+    full = smp.eval_likelihood()
+    assert carried == pytest.approx(full, rel=1e-9)      # 1,500 accumulated deltas vs one full evaluation (|logL| ~ 1e8)
+    for fA in (11, 2222, 33333):
+        max_id = smp.modify_gl_cuda_buffer(0)
+        before = smp._full_likelihood()
+        nb = smp.return_neighbours(fA, 5); nb.sort()
+        d = smp._candidate_deltas(fA, nb, max_id)
+        k, op = np.unravel_index(np.argmax(np.abs(d)), d.shape)
+        smp.test_copy_struct(fA, nb[k], int(op), max_id)
+        after = smp.eval_likelihood()
+        assert d[k, op] == pytest.approx(after - before, rel=1e-6, abs=2e-6 * abs(before) * 1e-3)
+    # ---- layout invariants
+    smp.gpu_vect_frags.copy_from_gpu()
+    g = smp.gpu_vect_frags
+    heads = g.pos == 0
+    assert g.l_cont[heads].sum() == n and (g.prev[heads & (g.circ == 0)] == -1).all()
+    assert (g.start_bp[heads] == 0).all() and (g.activ == 1).all()
+    for c in np.unique(g.id_c)[:200]:
+        m = np.nonzero(g.id_c == c)[0]
+        o = m[np.argsort(g.pos[m])]
+        assert np.array_equal(g.pos[o], np.arange(len(o))) and (g.l_cont[o] == len(o)).all()
+        assert np.array_equal(g.start_bp[o], np.cumsum(g.len_bp[o]) - g.len_bp[o]) and (g.l_cont_bp[o] == g.len_bp[o].sum()).all()
+    # ---- determinism and finisher == k_fin at full size
+    smp2, trace2 = run(c5, 7, 300, finisher=False)
+    assert trace2 == trace[:300]
+    smp.free_gpu(); smp2.free_gpu()
