@@ -254,6 +254,22 @@ __global__ __launch_bounds__(256) void k_stats(SoaPtr s, int n, long long* __res
     }
 }
 
+// last kernel of graal_begin_step / graal_layout_stats: publishes the 16 statistics words to pinned host memory (followed by
+// a sequence number the host spins on: no device->host copy, no stream synchronise) and re-arms the accumulators for the
+// next k_stats (no host->device copy of initial values either)
+__global__ void k_stats_fin(long long* __restrict__ sc, volatile long long* host, long long seq, int reset_stale)
+{
+    const int t = threadIdx.x;
+    if (t < 16) host[1 + t] = sc[t];
+    __syncthreads();
+    if (t < 8) sc[t] = (t == 5) ? 0x7fffffffll : (t == 7 ? -1ll : 0ll);
+    if (t == 13 && reset_stale) sc[13] = 0;
+    if (t == 14) sc[14] = 0;
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) { host[0] = seq; __threadfence_system(); }
+}
+
 // relabel: sort key of every contig head
 __global__ void k_relabel_keys(SoaPtr s, int n, unsigned long long* __restrict__ keys)
 {
@@ -1552,6 +1568,8 @@ struct Ctx {
     long long eval_calls = 0;
     DevArgs* d_args = nullptr;    // [2]: one argument block per layout buffer
     long long* h_res = nullptr;   // pinned host: [0] sequence number of the published step, [1..] K*13 sums
+    long long* h_stats = nullptr; // pinned host: [0] sequence number, [1..16] the statistics words of k_stats_fin
+    long long stats_seq = 0;
     long long seq = 0;
     long long* d_scalars = nullptr; // [0..7] stats, [8..9] full q, [10..12] step counters, [13] stale (int), [14] #circ,
                                     // [15] ticket, [16] error, [18..20] counters of the last finished step
@@ -1698,6 +1716,28 @@ int launch_fin(Ctx* h, int K, int rank, int world, long long* d_q_out, bool publ
 
 } // namespace
 
+// statistics of the layout (k_stats ran earlier on the stream): publish + wait; res[0..15] on return
+static int fetch_stats(Ctx* h, long long res[16], bool reset_stale)
+{
+    h->stats_seq += 1;
+    k_stats_fin<<<1, 64, 0, h->stream>>>(h->d_scalars, h->h_stats, h->stats_seq, reset_stale ? 1 : 0);
+    CK(hipGetLastError());
+    volatile long long* p = h->h_stats;
+    bool seen = false;
+    for (long long spin = 0; spin < 400000000ll; spin++) {
+        if (p[0] == h->stats_seq) { seen = true; break; }
+        if ((spin & 0xfffff) == 0xfffff && hipStreamQuery(h->stream) != hipErrorNotReady) { seen = (p[0] == h->stats_seq); break; }
+        __builtin_ia32_pause();
+    }
+    if (!seen) {
+        CK(hipStreamSynchronize(h->stream));
+        if (p[0] != h->stats_seq) return fail(h, GRAAL_E_HIP, "k_stats_fin did not publish the layout statistics");
+    }
+    __sync_synchronize();
+    for (int i = 0; i < 16; i++) res[i] = p[1 + i];
+    return GRAAL_OK;
+}
+
 struct graal_ctx : Ctx {};
 
 extern "C" {
@@ -1752,6 +1792,12 @@ int graal_create(int device, graal_ctx** out)
     CK(hipMalloc(&h->d_plan, sizeof(IncrPlan)));
     CK(hipHostMalloc((void**)&h->h_res, (1 + MAXK * N_OPS) * sizeof(long long), hipHostMallocDefault));
     memset(h->h_res, 0, (1 + MAXK * N_OPS) * sizeof(long long));
+    CK(hipHostMalloc((void**)&h->h_stats, 17 * sizeof(long long), hipHostMallocDefault));
+    memset(h->h_stats, 0, 17 * sizeof(long long));
+    {
+        const long long init[8] = {0, 0, 0, 0, 0, 0x7fffffff, 0, -1}; // k_stats accumulators (re-armed by k_stats_fin)
+        CK(hipMemcpy(h->d_scalars, init, sizeof init, hipMemcpyHostToDevice));
+    }
     return GRAAL_OK;
 }
 
@@ -1767,6 +1813,7 @@ void graal_destroy(graal_ctx* h)
                         h->d_scalars, h->d_qout};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (h->h_res) (void)hipHostFree(h->h_res);
+        if (h->h_stats) (void)hipHostFree(h->h_stats);
         for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
         for (auto& ev : h->ring) if (ev) (void)hipEventDestroy(ev);
         if (h->ev_fin) (void)hipEventDestroy(h->ev_fin);
@@ -1947,14 +1994,10 @@ int graal_layout_stats(graal_ctx* h, int64_t out[8])
     if (!h || !out) return GRAAL_E_ARG;
     if (!h->have_frags) return fail(h, GRAAL_E_STATE, "no fragments uploaded");
     CK(hipSetDevice(h->device));
-    long long init[8] = {0, 0, 0, 0, 0, 0x7fffffff, 0, -1};
-    CK(hipMemcpyAsync(h->d_scalars, init, sizeof init, hipMemcpyHostToDevice, h->stream));
-    CK(hipMemsetAsync(h->d_scalars + 14, 0, sizeof(long long), h->stream));
     k_stats<<<std::min(blocks_for(h->n, 256), 64), 256, 0, h->stream>>>(h->soa[h->cur], h->n, h->d_scalars);
     CK(hipGetLastError());
     long long res[16];
-    CK(hipMemcpyAsync(res, h->d_scalars, sizeof res, hipMemcpyDeviceToHost, h->stream));
-    CK(hipStreamSynchronize(h->stream));
+    { int rc = fetch_stats(h, res, false); if (rc) return rc; }
     out[0] = res[0]; out[1] = res[1]; out[2] = res[2]; out[3] = res[3]; out[4] = res[4]; out[5] = res[5];
     out[6] = res[14]; out[7] = 0;
     h->n_contigs = (int)res[0];
@@ -1969,9 +2012,6 @@ int graal_begin_step(graal_ctx* h, int64_t stats[8], int32_t* max_id)
     const int n = h->n, bs = 256, nb = blocks_for(n, bs);
     const int cur = h->cur;
     SoaPtr s = h->soa[cur];
-    long long init[8] = {0, 0, 0, 0, 0, 0x7fffffff, 0, -1};
-    CK(hipMemcpyAsync(h->d_scalars, init, sizeof init, hipMemcpyHostToDevice, h->stream));
-    CK(hipMemsetAsync(h->d_scalars + 14, 0, sizeof(long long), h->stream));
     k_stats<<<std::min(nb, 64), bs, 0, h->stream>>>(s, n, h->d_scalars);
     static const bool no_incr = getenv("GRAAL_NO_INCREMENTAL_RELABEL") != nullptr;
     if (h->ranks_valid && h->pending_commits == 0) {
@@ -2001,8 +2041,7 @@ int graal_begin_step(graal_ctx* h, int64_t stats[8], int32_t* max_id)
         CK(hipGetLastError());
     }
     long long res[16];
-    CK(hipMemcpyAsync(res, h->d_scalars, sizeof res, hipMemcpyDeviceToHost, h->stream));
-    CK(hipStreamSynchronize(h->stream));
+    { int rc = fetch_stats(h, res, true); if (rc) return rc; }
     const int nc = (int)res[0];
     // (a corrupt layout could have made the kernels above index out of range; the uploads validate labels and the
     // mutations keep them in [0, n_contigs + 2], so this is a consistency check, not a guard)
@@ -2016,7 +2055,6 @@ int graal_begin_step(graal_ctx* h, int64_t stats[8], int32_t* max_id)
         stats[6] = res[14];                      // #(circ == 1)
         stats[7] = (long long)*(int*)&res[13];   // fragments that hit the unwritten paste branch since the last begin_step
     }
-    CK(hipMemsetAsync(h->d_scalars + 13, 0, sizeof(long long), h->stream));
     return GRAAL_OK;
 }
 
