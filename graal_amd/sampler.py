@@ -285,6 +285,8 @@ class sampler(object):
         self._single_sub = bool(np.all(self.np_sub_frags_id[:, 3] == 1))
         self._n_circ_prev = int((soa["circ"] == 1).sum())
         self._d_q = None
+        self.resync_every = 512        # MCMC steps between full re-evaluations of the carried-over likelihood
+        self._steps_since_full = 0
         # ---- proposal ----------------------------------------------------------------------------------------
         self.n_neighbors = 10  # cuda_lib_gl.py:444
         self.setup_distri_frags()
@@ -533,8 +535,12 @@ class sampler(object):
             dist = self.dist_inter_genome() if self.compute_dist else 0.0
             self.likelihood_t = o
             return o, n_contigs, min_len, mean_len_bp, max_len, -1, id_fA, dist, self.temperature(t, n_step)
-        if self.likelihood_t is None:
+        self._steps_since_full += 1
+        if self.likelihood_t is None or self._steps_since_full >= self.resync_every:
+            # the carried-over total drifts by ~1e-10 |logL| per step against a full evaluation (deviation 1):
+            # re-evaluate now and then (the reference does it every step, cuda_lib_gl.py:1828-1848)
             self.likelihood_t = self._full_likelihood()
+            self._steps_since_full = 0
         elif (n_circ or self._n_circ_prev) and not self._single_sub:
             # candidate deltas never include a bin's own pixel (as in the reference); those pixels only change with
             # the circular model, so resynchronise the carried-over total whenever circular contigs are around
