@@ -92,9 +92,13 @@ __device__ __forceinline__ float rippe_circ(float s, float s_tot, const Par& p)
 }
 
 // dynamic geometry of one fragment (16-byte record, rebuilt after every layout change)
-struct Geo { int id_c, flags, start_bp, len_bp; }; // flags: bit0 ori==+1, bit1 circ, bits 2..31 pos
-__device__ __forceinline__ int geo_flags(int ori, int circ, int pos) { return (ori == 1 ? 1 : 0) | (circ == 1 ? 2 : 0) | (pos << 2); }
-__device__ __forceinline__ int geo_pos(int flags) { return (int)((unsigned)flags >> 2); }
+struct Geo { int id_c, flags, start_bp, len_bp; }; // flags: bit0 ori==+1, bit1 circ, bit2 inactive, bit3 rep, bits 4..31 pos
+__device__ __forceinline__ int geo_flags(int ori, int circ, int pos, int activ, int rep)
+{
+    return (ori == 1 ? 1 : 0) | (circ == 1 ? 2 : 0) | (activ == 1 ? 0 : 4) | (rep == 1 ? 8 : 0) | (pos << 4);
+}
+__device__ __forceinline__ int geo_pos(int flags) { return (int)((unsigned)flags >> 4); }
+__device__ __forceinline__ bool geo_active(int flags) { return (flags & 4) == 0; }
 // the rest of a fragment's layout record, 16 bytes: with Geo it replaces 13 scattered SoA words by two 16-byte loads
 struct Link { int l_cont, l_cont_bp, prev, next; };
 constexpr int N_MATES = 8; // mates[f][0..8): the first fragments of f's contig in position order (-1 padded)
@@ -175,13 +179,13 @@ __device__ __forceinline__ double wave_sum_d(double v)
     return v;
 }
 
-// layout record of fragment f from its Geo + Link (no repeats: rep = 0, activ = 1, id_d = f -- checked at upload)
+// layout record of fragment f from its Geo + Link
 __device__ __forceinline__ Rec rec_gl(const Geo& g, const Link& l, int f)
 {
     Rec r;
     r.pos = geo_pos(g.flags); r.id_c = g.id_c; r.start_bp = g.start_bp; r.len_bp = g.len_bp; r.circ = (g.flags >> 1) & 1;
     r.prev = l.prev; r.next = l.next; r.l_cont = l.l_cont; r.l_cont_bp = l.l_cont_bp; r.ori = (g.flags & 1) ? 1 : -1;
-    r.rep = 0; r.activ = 1; r.id_d = f;
+    r.rep = (g.flags >> 3) & 1; r.activ = geo_active(g.flags) ? 1 : 0; r.id_d = f; // (id_d is not used by any mutation)
     return r;
 }
 
@@ -191,7 +195,7 @@ __global__ void k_refresh_geo(SoaPtr s, Geo* __restrict__ geo, Link* __restrict_
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n) return;
     Geo g; g.id_c = s.p[F_IDC][f]; g.start_bp = s.p[F_START][f]; g.len_bp = s.p[F_LEN][f];
-    g.flags = geo_flags(s.p[F_ORI][f], s.p[F_CIRC][f], s.p[F_POS][f]);
+    g.flags = geo_flags(s.p[F_ORI][f], s.p[F_CIRC][f], s.p[F_POS][f], s.p[F_ACTIV][f], s.p[F_REP][f]);
     geo[f] = g;
     Link l; l.l_cont = s.p[F_LCONT][f]; l.l_cont_bp = s.p[F_LCONTBP][f]; l.prev = s.p[F_PREV][f]; l.next = s.p[F_NEXT][f];
     link[f] = l;
@@ -421,7 +425,7 @@ __global__ void k_incr_apply(SoaPtr s, int n, const IncrPlan* __restrict__ planp
     perm[off + pos] = f;
     cbase[f] = off;
     Geo g; g.id_c = rank; g.start_bp = s.p[F_START][f]; g.len_bp = s.p[F_LEN][f];
-    g.flags = geo_flags(s.p[F_ORI][f], s.p[F_CIRC][f], pos);
+    g.flags = geo_flags(s.p[F_ORI][f], s.p[F_CIRC][f], pos, s.p[F_ACTIV][f], s.p[F_REP][f]);
     geo[f] = g;
     Link l; l.l_cont = s.p[F_LCONT][f]; l.l_cont_bp = s.p[F_LCONTBP][f]; l.prev = s.p[F_PREV][f]; l.next = s.p[F_NEXT][f];
     link[f] = l;
@@ -1503,6 +1507,188 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
     STAMP(21, threadIdx.x == 0);
 }
 
+// ------------------------------------------------------------------ repeated bins (allow_repeats)
+// A repeated ("duplicated") bin has several fragment copies (frag_dispatcher / collector_id_repeats,
+// simulation_loader.py:258-277); the expected value of a pixel is the float32 sum over the ACTIVE copy pairs of its two
+// bins (kernels3.cu:2915-2930) and there is no sparse shortcut for it.  Like the reference (kernels3.cu:3356-3380: the
+// "repeats x all unique bins", "repeats x repeats" and "repeat diagonal" ranges) the engine prices every pixel of a
+// repeated bin densely -- full likelihood and candidates -- while the sparse path above sees those bins with zero
+// sub-fragments (no mass, no contacts).
+struct RepArgs {
+    int n_dup, n_bins, n_sub_total;
+    const int* dup_bins;        // [n_dup] unique-bin ids
+    const int* dup_index;       // [n_bins] index into dup_bins, -1 = not repeated
+    const int* dispatcher;      // [n_bins][2]
+    const int* collector;       // fragment ids, copies of a bin contiguous
+    const float* obs;           // [n_dup][3][n_sub_total] observation rows of the repeated bins' sub-fragments
+    const int* sub_ids;         // [n_bins][4]
+    const Stat* stat_bin;       // [n_bins] sub-fragment lengths / accu of the BIN (shared by its copies)
+    const Geo* geo;
+    const int* lcontbp;
+    float nfpb;
+    Par par;
+};
+
+// float factorial of kernels3.cu:80-93 and evaluate_likelihood_double (kernels3.cu:191-210)
+__device__ __forceinline__ float factorial_f(float n)
+{
+    float result = 1.0f;
+    n = floorf(n);
+    if (n < 10.0f) { for (int c = 1; c <= (int)n; c++) result = result * (float)c; }
+    else result = powf(n, n) * expf(-n) * sqrtf((float)(2.0 * M_PI * (double)n));
+    return result;
+}
+__device__ __forceinline__ double lik_double(double ex, double ob)
+{
+    double res = 0.0;
+    if (ex != 0.0) {
+        if (ob >= 15.0) res = ob * log(ex) - ex - (ob * log(ob) - ob + log(sqrt(ob * 2.0 * M_PI)));
+        else if (ob > 0.0) res = ob * log(ex) - ex - log((double)factorial_f((float)ob));
+        else if (ob == 0.0) res = -ex;
+    }
+    return res;
+}
+
+// one copy of a bin in some layout
+struct CopyView { End e; bool active; };
+
+// View of fragment f in the CURRENT layout (VIEW = 0) or under candidate `op` of a neighbour (VIEW = 1)
+struct CandCtx { const NbTables* T; int op, fA; };
+template <int VIEW>
+__device__ __forceinline__ CopyView copy_view(const RepArgs& R, int f, const CandCtx& C)
+{
+    const Geo g = R.geo[f];
+    CopyView v;
+    v.active = geo_active(g.flags);
+    if (VIEW == 0) { v.e = end_cur(g, R.lcontbp, f); return v; }
+    const int p = piece_of(C.T->key, g.id_c, geo_pos(g.flags));
+    if (p > 0) v.e = end_xf(g, C.T->xf[C.op][p]); else v.e = end_cur(g, R.lcontbp, f);
+    if (C.op == 8 && f == C.fA && ((g.flags >> 3) & 1)) v.active = !v.active; // swap_activity_frag (kernels3.cu:283)
+    return v;
+}
+
+// Poisson log-likelihood of the pixel (bin lo < bin hi), or of bin lo's own upper triangle (lo == hi); body of
+// evaluate_likelihood / sub_compute_likelihood for bins with copies (kernels3.cu:2895-3220): float32 expected values
+// accumulated over the active copy pairs in dispatcher order, float64 log-likelihood summed over the slots.
+template <int VIEW>
+__device__ double pixel_lik(const RepArgs& R, int lo, int hi, const CandCtx& C)
+{
+    const bool diag = lo == hi;
+    const Stat si = R.stat_bin[lo], sj = R.stat_bin[hi];
+    float ex[3][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+    const int i0 = R.dispatcher[2 * lo], i1 = R.dispatcher[2 * lo + 1], j0 = R.dispatcher[2 * hi], j1 = R.dispatcher[2 * hi + 1];
+    for (int ri = i0; ri < i1; ri++) {
+        const CopyView vi = copy_view<VIEW>(R, R.collector[ri], C);
+        if (!vi.active) continue;
+        for (int rj = j0; rj < j1; rj++) {
+            const CopyView vj = copy_view<VIEW>(R, R.collector[rj], C);
+            if (!vj.active) continue;
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int b = 0; b < 3; b++)
+                    if (a < si.n && b < sj.n) ex[a][b] = ex[a][b] + ex_pair(vi.e, si, a, vj.e, sj, b, R.nfpb, R.par);
+        }
+    }
+    // observations: symmetric matrix, stored by rows of the repeated bins' sub-fragments
+    const int di = R.dup_index[lo], dj = R.dup_index[hi];
+    const int* ids_i = R.sub_ids + 4 * lo;
+    const int* ids_j = R.sub_ids + 4 * hi;
+    double val = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            if (a >= si.n || b >= sj.n || (diag && b <= a)) continue;
+            const float ob = di >= 0 ? R.obs[((size_t)di * 3 + a) * R.n_sub_total + ids_j[b]]
+                                     : R.obs[((size_t)dj * 3 + b) * R.n_sub_total + ids_i[a]];
+            val = lik_double((double)ex[a][b], (double)ob) + val;
+        }
+    return val;
+}
+
+// which pixel does thread (ui, v) own?  Every pixel with at least one repeated bin exactly once.
+__device__ __forceinline__ bool rep_pixel(const RepArgs& R, int ui, int v, int& lo, int& hi)
+{
+    const int u = R.dup_bins[ui];
+    if (v != u && R.dup_index[v] >= 0 && v < u) return false; // pair of two repeated bins: owned by the smaller one
+    lo = u < v ? u : v; hi = u < v ? v : u;
+    return true;
+}
+
+// full likelihood of the repeated bins' pixels in the current layout (Q sum)
+__global__ __launch_bounds__(256) void k_rep_full(RepArgs R, long long* __restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long q = 0;
+    if (i < (long long)R.n_dup * R.n_bins) {
+        int lo, hi;
+        CandCtx C; C.T = nullptr; C.op = 0; C.fA = -1;
+        if (rep_pixel(R, (int)(i / R.n_bins), (int)(i % R.n_bins), lo, hi)) q = to_q(pixel_lik<0>(R, lo, hi, C));
+    }
+    q = wave_sum_ll(q);
+    if ((threadIdx.x & 63) == 0 && q != 0) atomicAdd((unsigned long long*)out, (unsigned long long)q);
+}
+
+// candidate deltas of the repeated bins' pixels: thread = (neighbour k, repeated bin, other bin); skipped when no copy of the
+// repeated bin lies in contig(fA) u contig(fB_k) (the reference's list of repeats in the sub-index, cuda_lib_gl.py:2466)
+__global__ __launch_bounds__(256) void k_rep_delta(RepArgs R, const NbTables* __restrict__ tabs, const long long* tm_done,
+                                                    long long seq, int fA, int K, int rank, int world,
+                                                    long long* __restrict__ acc, unsigned long long* counters)
+{
+    __shared__ long long s_acc[MAXK * N_OPS];
+    __shared__ int s_ok;
+    const int t = threadIdx.x;
+    for (int i = t; i < MAXK * N_OPS; i += blockDim.x) s_acc[i] = 0;
+    if (t == 0) s_ok = 1;
+    __syncthreads();
+    if (t < K) { // the tables come from k_tm on another stream
+        bool ok = false;
+        for (int spin = 0; spin < (1 << 22); spin++) {
+            const unsigned long long w = (unsigned long long)__hip_atomic_load(&tm_done[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(w >> 32) == (unsigned)seq) { ok = true; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (!ok) { s_ok = 0; atomicOr(&counters[6], 1ull); }
+    }
+    __syncthreads();
+    const long long per_k = (long long)R.n_dup * R.n_bins;
+    const long long i = (long long)blockIdx.x * blockDim.x + t;
+    if (s_ok && i < per_k * K && (i % world) == rank) {
+        const int k = (int)(i / per_k);
+        const long long j = i % per_k;
+        const NbTables* T = tabs + k;
+        int lo, hi;
+        if (T->fB != fA && rep_pixel(R, (int)(j / R.n_bins), (int)(j % R.n_bins), lo, hi)) {
+            const int u = R.dup_bins[j / R.n_bins];
+            bool touched = false;
+            for (int r = R.dispatcher[2 * u]; r < R.dispatcher[2 * u + 1]; r++) {
+                const Geo g = R.geo[R.collector[r]];
+                touched = touched || piece_of(T->key, g.id_c, geo_pos(g.flags)) > 0;
+            }
+            if (hi != lo && R.dup_index[lo] >= 0 && R.dup_index[hi] >= 0) { // both repeated: either one may be the touched one
+                const int w = lo == u ? hi : lo;
+                for (int r = R.dispatcher[2 * w]; r < R.dispatcher[2 * w + 1]; r++) {
+                    const Geo g = R.geo[R.collector[r]];
+                    touched = touched || piece_of(T->key, g.id_c, geo_pos(g.flags)) > 0;
+                }
+            }
+            if (touched) {
+                CandCtx C; C.T = T; C.op = 0; C.fA = fA;
+                const long long q_old = to_q(pixel_lik<0>(R, lo, hi, C));
+                for (int op = 0; op < N_OPS; op++) {
+                    C.op = op;
+                    const long long dq = to_q(pixel_lik<1>(R, lo, hi, C)) - q_old;
+                    if (dq != 0) atomicAdd((unsigned long long*)&s_acc[k * N_OPS + op], (unsigned long long)dq);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i2 = t; i2 < K * N_OPS; i2 += blockDim.x)
+        if (s_acc[i2] != 0) atomicAdd((unsigned long long*)&acc[i2], (unsigned long long)s_acc[i2]);
+}
+
 // ------------------------------------------------------------------ host side
 struct Ctx {
     int device = 0;
@@ -1530,6 +1716,16 @@ struct Ctx {
     double c_lf = 0.0;          // sum of log-factorial terms of this shard's contacts
     std::vector<int> h_accu;    // [n_bins][3]
     std::vector<int> h_nsub;
+    std::vector<Stat> h_stat;   // per bin (host copy: the per-fragment table is derived from it at upload_frags)
+    std::vector<int> h_sub_id;  // [n_bins][4]
+    std::vector<int> h_sub2bin; // [n_sub_total] bin << 2 | slot
+    // repeated bins (graal_upload_repeats)
+    bool has_rep = false;
+    int n_dup = 0;
+    std::vector<int> h_dup_index; // [n_bins] -> index into the repeated bins, -1
+    int *d_dup_bins = nullptr, *d_dup_index = nullptr, *d_dispatcher = nullptr, *d_collector = nullptr, *d_sub_ids_all = nullptr;
+    float* d_rep_obs = nullptr;
+    Stat* stat_frag = nullptr;    // [n] statistics per FRAGMENT (copies of repeated bins: zero sub-fragments)
     // device
     int* soa_mem[2] = {nullptr, nullptr};
     SoaPtr soa[2];
@@ -1611,8 +1807,9 @@ void compute_t_all(Ctx* h)
     // T_all = sum over pairs of DIFFERENT bins, all slot pairs, of float32(v * float32(float32(ax*ay)/nfpb))
     if (!h->have_par || !h->have_sub) return;
     std::vector<long long> hist;
+    auto nsub = [&](int b) { return (h->has_rep && h->h_dup_index[b] >= 0) ? 0 : h->h_nsub[b]; }; // repeated bins: priced densely
     for (int b = 0; b < h->n_bins; b++)
-        for (int s = 0; s < h->h_nsub[b]; s++) {
+        for (int s = 0; s < nsub(b); s++) {
             const int a = h->h_accu[3 * b + s];
             if ((size_t)a >= hist.size()) hist.resize(a + 1, 0);
             hist[a]++;
@@ -1625,8 +1822,8 @@ void compute_t_all(Ctx* h)
                 if (hist[w]) all += (double)hist[u] * (double)hist[w] * c((long long)u * (long long)w);
     double self = 0.0;
     for (int b = 0; b < h->n_bins; b++)
-        for (int s = 0; s < h->h_nsub[b]; s++)
-            for (int t = 0; t < h->h_nsub[b]; t++) self += c((long long)h->h_accu[3 * b + s] * h->h_accu[3 * b + t]);
+        for (int s = 0; s < nsub(b); s++)
+            for (int t = 0; t < nsub(b); t++) self += c((long long)h->h_accu[3 * b + s] * h->h_accu[3 * b + t]);
     h->t_all = 0.5 * (all - self);
 }
 
@@ -1644,7 +1841,7 @@ int sync_args(Ctx* h)
         a[b].reach_bp = h->have_par ? reach_bp(h) : 0;
         a[b].row = h->row; a[b].col = h->col; a[b].cnt = h->cnt; a[b].sub2bin = h->sub2bin;
         a[b].sub2bin_multi = h->single_sub ? nullptr : h->sub2bin; a[b].sub_ids = h->d_sub_ids;
-        a[b].contig_off = h->contig_off2[b]; a[b].perm = h->perm; a[b].geo = h->geo; a[b].stat = h->stat;
+        a[b].contig_off = h->contig_off2[b]; a[b].perm = h->perm; a[b].geo = h->geo; a[b].stat = h->stat_frag;
         a[b].link = h->link; a[b].cbase = h->cbase;
         a[b].tabs = h->tabs; a[b].step_hdr = h->step_hdr; a[b].tm_done = h->tm_done; a[b].acc = h->d_acc;
         a[b].queue = h->queue; a[b].counters = (unsigned long long*)(h->d_scalars + 10);
@@ -1708,7 +1905,7 @@ int launch_fin(Ctx* h, int K, int rank, int world, long long* d_q_out, bool publ
     const int fin_blocks = fin_blocks_env > 0 ? fin_blocks_env : (h->max_lcont > 0 && h->max_lcont <= 16 ? 32 : 512);
     FinArgs fa;
     fa.tm_done = h->tm_done; fa.step_hdr = h->step_hdr; fa.counters = (unsigned long long*)(h->d_scalars + 10); fa.queue = h->queue;
-    fa.tabs = h->tabs; fa.geo = h->geo; fa.stat = h->stat; fa.acc = h->d_acc; fa.sync = h->d_sync;
+    fa.tabs = h->tabs; fa.geo = h->geo; fa.stat = h->stat_frag; fa.acc = h->d_acc; fa.sync = h->d_sync;
     k_fin<<<fin_blocks, 256, 0, st>>>(h->d_args + h->cur, fa, K, rank, world, d_q_out, publish ? h->h_res : nullptr, h->seq);
     CK(hipGetLastError());
     return GRAAL_OK;
@@ -1808,7 +2005,8 @@ void graal_destroy(graal_ctx* h)
         (void)hipSetDevice(h->device);
         (void)hipStreamSynchronize(h->stream);
         if (h->aux) (void)hipStreamSynchronize(h->aux);
-        void* ptrs[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->stat, h->sub2bin, h->row, h->col, h->cnt, h->queue, h->d_sub_ids, h->d_acc, h->tm_done, h->d_sync, h->d_flags,
+        void* ptrs[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->stat, h->sub2bin, h->row, h->col, h->cnt, h->queue, h->d_sub_ids, h->d_acc, h->tm_done, h->d_sync, h->d_flags, h->stat_frag, h->d_dup_bins, h->d_dup_index,
+                        h->d_dispatcher, h->d_collector, h->d_sub_ids_all, h->d_rep_obs,
                         h->keys, h->keys_sorted, h->o2n, h->len_of2[0], h->len_of2[1], h->contig_off2[0], h->contig_off2[1], h->perm, h->cbase, h->link, h->mates, h->cub_tmp, h->tabs, h->step_hdr, h->d_args, h->d_chg, h->d_plan,
                         h->d_scalars, h->d_qout};
         for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -1865,6 +2063,10 @@ int graal_upload_subfrags(graal_ctx* h, const int32_t* sub_id, const float* sub_
         st[b] = s;
     }
     for (int v : s2b) if (v < 0) return fail(h, GRAAL_E_ARG, "every sub-fragment must belong to a bin");
+    h->h_stat = st;
+    h->h_sub2bin = s2b;
+    h->h_sub_id.assign(sub_id, sub_id + 4 * (size_t)n_bins);
+    h->has_rep = false; h->n_dup = 0; h->h_dup_index.assign((size_t)n_bins, -1); // (graal_upload_repeats comes after)
     // single_sub additionally needs sub id == bin id so that the scan can skip the sub2bin gather
     for (int b = 0; single && b < n_bins; b++) single = (sub_id[4 * b] == b);
     if (h->stat) { (void)hipFree(h->stat); (void)hipFree(h->sub2bin); (void)hipFree(h->d_sub_ids); h->d_sub_ids = nullptr; }
@@ -1877,6 +2079,61 @@ int graal_upload_subfrags(graal_ctx* h, const int32_t* sub_id, const float* sub_
     CK(hipMemcpy(h->stat, st.data(), sizeof(Stat) * (size_t)n_bins, hipMemcpyHostToDevice));
     CK(hipMemcpy(h->sub2bin, s2b.data(), sizeof(int) * (size_t)n_sub_total, hipMemcpyHostToDevice));
     h->n_bins = n_bins; h->n_sub_total = n_sub_total; h->nfpb = nfpb; h->single_sub = single; h->have_sub = true;
+    compute_t_all(h);
+    return sync_args(h);
+}
+
+// bin of a sub-fragment id (host copy of the sub-fragment table)
+static int s2b_host(const Ctx* h, int sid)
+{
+    if (h->h_sub2bin.empty()) return 0;
+    return h->h_sub2bin[(size_t)sid] >> 2;
+}
+
+static RepArgs rep_args(const Ctx* h)
+{
+    RepArgs R;
+    R.n_dup = h->n_dup; R.n_bins = h->n_bins; R.n_sub_total = h->n_sub_total;
+    R.dup_bins = h->d_dup_bins; R.dup_index = h->d_dup_index; R.dispatcher = h->d_dispatcher; R.collector = h->d_collector;
+    R.obs = h->d_rep_obs; R.sub_ids = h->d_sub_ids_all; R.stat_bin = h->stat; R.geo = h->geo;
+    R.lcontbp = h->soa[h->cur].p[F_LCONTBP]; R.nfpb = h->nfpb; R.par = h->par;
+    return R;
+}
+
+int graal_upload_repeats(graal_ctx* h, const int32_t* dup_bins, int32_t n_dup, const int32_t* dispatcher, const int32_t* collector,
+                         int32_t n_collector, const float* obs_rows)
+{
+    if (!h || n_dup < 0 || (n_dup > 0 && (!dup_bins || !dispatcher || !collector || !obs_rows))) return GRAAL_E_ARG;
+    if (!h->have_sub) return fail(h, GRAAL_E_STATE, "upload_subfrags first");
+    CK(hipSetDevice(h->device));
+    void* old[] = {h->d_dup_bins, h->d_dup_index, h->d_dispatcher, h->d_collector, h->d_sub_ids_all, h->d_rep_obs};
+    for (void* p : old) if (p) (void)hipFree(p);
+    h->d_dup_bins = h->d_dup_index = h->d_dispatcher = h->d_collector = h->d_sub_ids_all = nullptr; h->d_rep_obs = nullptr;
+    h->h_dup_index.assign((size_t)h->n_bins, -1);
+    h->has_rep = n_dup > 0; h->n_dup = n_dup;
+    h->have_frags = false; h->have_contacts = false; h->order_valid = false; // both depend on which bins are repeated
+    if (n_dup == 0) { compute_t_all(h); return sync_args(h); }
+    for (int i = 0; i < n_dup; i++) {
+        if (dup_bins[i] < 0 || dup_bins[i] >= h->n_bins || h->h_dup_index[dup_bins[i]] >= 0) return fail(h, GRAAL_E_ARG, "repeated bins must be distinct bin ids");
+        h->h_dup_index[dup_bins[i]] = i;
+    }
+    for (int b = 0; b < h->n_bins; b++) {
+        const int lo = dispatcher[2 * b], hi = dispatcher[2 * b + 1];
+        if (lo < 0 || hi > n_collector || hi <= lo) return fail(h, GRAAL_E_ARG, "dispatcher ranges must be non-empty and inside the collector");
+        if (h->h_dup_index[b] < 0 && (hi - lo != 1 || collector[lo] != b)) return fail(h, GRAAL_E_ARG, "a non-repeated bin has exactly one copy: itself");
+    }
+    CK(hipMalloc(&h->d_dup_bins, sizeof(int) * (size_t)n_dup));
+    CK(hipMalloc(&h->d_dup_index, sizeof(int) * (size_t)h->n_bins));
+    CK(hipMalloc(&h->d_dispatcher, sizeof(int) * 2 * (size_t)h->n_bins));
+    CK(hipMalloc(&h->d_collector, sizeof(int) * (size_t)n_collector));
+    CK(hipMalloc(&h->d_sub_ids_all, sizeof(int) * 4 * (size_t)h->n_bins));
+    CK(hipMalloc(&h->d_rep_obs, sizeof(float) * 3 * (size_t)n_dup * (size_t)h->n_sub_total));
+    CK(hipMemcpy(h->d_dup_bins, dup_bins, sizeof(int) * (size_t)n_dup, hipMemcpyHostToDevice));
+    CK(hipMemcpy(h->d_dup_index, h->h_dup_index.data(), sizeof(int) * (size_t)h->n_bins, hipMemcpyHostToDevice));
+    CK(hipMemcpy(h->d_dispatcher, dispatcher, sizeof(int) * 2 * (size_t)h->n_bins, hipMemcpyHostToDevice));
+    CK(hipMemcpy(h->d_collector, collector, sizeof(int) * (size_t)n_collector, hipMemcpyHostToDevice));
+    CK(hipMemcpy(h->d_sub_ids_all, h->h_sub_id.data(), sizeof(int) * 4 * (size_t)h->n_bins, hipMemcpyHostToDevice));
+    CK(hipMemcpy(h->d_rep_obs, obs_rows, sizeof(float) * 3 * (size_t)n_dup * (size_t)h->n_sub_total, hipMemcpyHostToDevice));
     compute_t_all(h);
     return sync_args(h);
 }
@@ -1895,6 +2152,8 @@ static int upload_contacts_impl(graal_ctx* h, const int32_t* row, const int32_t*
         if (row[i] < 0 || col[i] >= h->n_sub_total || row[i] >= col[i]) return fail(h, GRAAL_E_ARG, "contacts need 0 <= row < col < n_sub_total");
         const float c = count[i];
         if (!(c > 0.0f) || !(c < 1.0e30f)) return fail(h, GRAAL_E_ARG, "contact counts must be > 0 and finite");
+        if (h->has_rep && (h->h_dup_index[s2b_host(h, row[i])] >= 0 || h->h_dup_index[s2b_host(h, col[i])] >= 0))
+            return fail(h, GRAAL_E_ARG, "contacts of repeated bins belong to graal_upload_repeats (observation rows), not to the contact list");
         const int ci = (int)c;
         c_lf += (c < 16.0f && (float)ci == c) ? lf_small[ci] : lf_term((double)c);
     }
@@ -1934,13 +2193,19 @@ int graal_upload_frags(graal_ctx* h, const int32_t* const soa[GRAAL_N_FIELDS], i
 {
     if (!h || !soa || n <= 0) return GRAAL_E_ARG;
     if (!h->have_sub) return fail(h, GRAAL_E_STATE, "upload_subfrags first");
-    if (n != h->n_bins) return fail(h, GRAAL_E_UNSUPPORTED, "repeated fragments (n_new_frags != n_frags) are not supported yet");
+    if (n != h->n_bins && !h->has_rep) return fail(h, GRAAL_E_STATE, "n differs from the number of bins: upload the repeats (graal_upload_repeats) first");
+    if (n < h->n_bins) return fail(h, GRAAL_E_ARG, "fewer fragments than bins");
     if ((long long)n >= (1ll << LABEL_BITS) / 2 - 4) return fail(h, GRAAL_E_ARG, "too many fragments for the relabel key");
     CK(hipSetDevice(h->device));
     for (int i = 0; i < n; i++) {
         if (soa[F_IDC][i] < 0 || soa[F_IDC][i] >= 2 * n + 4) return fail(h, GRAAL_E_ARG, "id_c must be in [0, 2n+4)");
-        if (soa[F_REP][i] != 0 || soa[F_ACTIV][i] != 1 || soa[F_IDD][i] != i)
-            return fail(h, GRAAL_E_UNSUPPORTED, "repeats / inactive fragments are not supported yet");
+        const int b = soa[F_IDD][i];
+        if (b < 0 || b >= h->n_bins) return fail(h, GRAAL_E_ARG, "id_d out of range");
+        const bool special = h->has_rep && h->h_dup_index[b] >= 0;
+        if (!special && (soa[F_REP][i] != 0 || soa[F_ACTIV][i] != 1 || b != i))
+            return fail(h, GRAAL_E_ARG, "rep / activ / id_d of a fragment of a non-repeated bin must be 0 / 1 / its own index");
+        if ((soa[F_REP][i] != 0 && soa[F_REP][i] != 1) || (soa[F_ACTIV][i] != 0 && soa[F_ACTIV][i] != 1))
+            return fail(h, GRAAL_E_ARG, "rep and activ must be 0 or 1");
     }
     if (h->n != n) {
         void* old[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->keys, h->keys_sorted, h->o2n, h->len_of2[0], h->len_of2[1], h->contig_off2[0], h->contig_off2[1], h->perm, h->cbase, h->link, h->mates, h->cub_tmp};
@@ -1971,6 +2236,18 @@ int graal_upload_frags(graal_ctx* h, const int32_t* const soa[GRAAL_N_FIELDS], i
     h->cur = 0; h->ranks_valid = false; h->pending_commits = 0;
     for (int k = 0; k < GRAAL_N_FIELDS; k++)
         CK(hipMemcpy(h->soa[0].p[k], soa[k], sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+    {   // statistics per fragment: those of its bin; copies of repeated bins (original included) carry no sub-fragments in
+        // the sparse path -- their pixels are priced by the dense repeat kernels
+        std::vector<Stat> sf((size_t)n);
+        for (int i = 0; i < n; i++) {
+            const int b = soa[F_IDD][i];
+            sf[(size_t)i] = h->h_stat[(size_t)b];
+            if (h->has_rep && h->h_dup_index[b] >= 0) sf[(size_t)i].n = 0;
+        }
+        if (h->stat_frag) (void)hipFree(h->stat_frag);
+        CK(hipMalloc(&h->stat_frag, sizeof(Stat) * (size_t)n));
+        CK(hipMemcpy(h->stat_frag, sf.data(), sizeof(Stat) * (size_t)n, hipMemcpyHostToDevice));
+    }
     h->have_frags = true; h->order_valid = false;
     int rc = refresh(h);
     if (rc) return rc;
@@ -2046,7 +2323,7 @@ int graal_begin_step(graal_ctx* h, int64_t stats[8], int32_t* max_id)
     // (a corrupt layout could have made the kernels above index out of range; the uploads validate labels and the
     // mutations keep them in [0, n_contigs + 2], so this is a consistency check, not a guard)
     if (nc <= 0 || nc > n || res[7] >= 2 * n + 8) return fail(h, GRAAL_E_STATE, "corrupt layout: contig heads / labels out of range");
-    if (res[6] != 0) return fail(h, GRAAL_E_UNSUPPORTED, "repeats / inactive fragments are not supported yet");
+    if (res[6] != 0 && !h->has_rep) return fail(h, GRAAL_E_STATE, "corrupt layout: rep / activ / id_d changed without repeats");
     h->n_contigs = nc; h->order_valid = true; h->ranks_valid = true; h->pending_commits = 0; h->incr_ok = false;
     h->max_lcont = (int)res[4];
     if (max_id) *max_id = nc - 1;
@@ -2067,21 +2344,28 @@ int graal_eval_full_q(graal_ctx* h, int64_t q_out[2])
     if (!h->order_valid) return fail(h, GRAAL_E_STATE, "call graal_relabel_contigs after changing the layout");
     CK(hipSetDevice(h->device));
     CK(hipMemsetAsync(h->d_scalars + 8, 0, 2 * sizeof(long long), h->stream));
+    if (h->has_rep) CK(hipMemsetAsync(h->d_scalars + 17, 0, sizeof(long long), h->stream));
     SoaPtr s = h->soa[h->cur];
     if (h->nnz) {
         const int nb = (int)std::min<long long>((h->nnz + 255) / 256, 256 * 16);
-        k_full_nnz<<<nb, 256, 0, h->stream>>>(h->row, h->col, h->cnt, h->nnz, h->sub2bin, h->geo, h->stat, s.p[F_LCONTBP],
+        k_full_nnz<<<nb, 256, 0, h->stream>>>(h->row, h->col, h->cnt, h->nnz, h->sub2bin, h->geo, h->stat_frag, s.p[F_LCONTBP],
                                                h->nfpb, h->par, h->d_scalars + 8);
     }
-    k_full_mass<<<blocks_for(h->n, 64), 64, 0, h->stream>>>(h->n, h->perm, h->contig_off2[h->cur], h->geo, h->stat, s.p[F_LCONT],
+    k_full_mass<<<blocks_for(h->n, 64), 64, 0, h->stream>>>(h->n, h->perm, h->contig_off2[h->cur], h->geo, h->stat_frag, s.p[F_LCONT],
                                                              s.p[F_LCONTBP], s.p[F_POS], h->nfpb, h->par, reach_bp(h),
                                                              h->d_scalars + 9);
+    if (h->has_rep) { // every pixel of a repeated bin, densely (identical on every rank: it goes with the mass part)
+        const RepArgs R = rep_args(h);
+        k_rep_full<<<blocks_for((long long)h->n_dup * h->n_bins, 256), 256, 0, h->stream>>>(R, h->d_scalars + 17);
+    }
     CK(hipGetLastError());
     long long res[2];
+    long long rep_q = 0;
+    if (h->has_rep) CK(hipMemcpyAsync(&rep_q, h->d_scalars + 17, sizeof rep_q, hipMemcpyDeviceToHost, h->stream));
     CK(hipMemcpyAsync(res, h->d_scalars + 8, sizeof res, hipMemcpyDeviceToHost, h->stream));
     CK(hipStreamSynchronize(h->stream));
     q_out[0] = res[0] - (int64_t)llrint(h->c_lf * Q_SCALE);
-    q_out[1] = -(res[1] + (int64_t)llrint(h->t_all * Q_SCALE));
+    q_out[1] = -(res[1] + (int64_t)llrint(h->t_all * Q_SCALE)) + rep_q;
     return GRAAL_OK;
 }
 
@@ -2110,10 +2394,10 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     static const bool no_finisher = getenv("GRAAL_NO_FINISHER") != nullptr; // always finish with k_fin (diagnostics)
     ta.flags = h->d_flags;
     ta.sync = h->d_sync; ta.n_scan_blocks = scan_grid(h);
-    ta.host_res = (h->publish && world == 1 && !no_finisher && h->finisher_ok) ? h->h_res : nullptr;
+    ta.host_res = (h->publish && world == 1 && !no_finisher && h->finisher_ok && !h->has_rep) ? h->h_res : nullptr;
     // a generous multiple of the time the streaming pass needs at 2 TB/s, plus launch slack
     ta.wait_ticks = (int)std::min<long long>(100ll * 50 + (long long)(4.0 * 4.0 * (double)h->nnz / 2.0e12 * 1.0e8), 1ll << 30);
-    ta.counters = (unsigned long long*)(h->d_scalars + 10); ta.queue = h->queue; ta.stat = h->stat;
+    ta.counters = (unsigned long long*)(h->d_scalars + 10); ta.queue = h->queue; ta.stat = h->stat_frag;
     ta.lcontbp = h->soa[h->cur].p[F_LCONTBP]; ta.acc = h->d_acc; ta.nfpb = h->nfpb; ta.par = h->par;
     k_tm<<<K, 256, 0, h->aux>>>(A, ta, fA, nb, K, max_id, rank, world, h->seq);
     CK(hipGetLastError());
@@ -2125,6 +2409,12 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     { int rc_ = launch_scan(h, fA, nb, K, max_id, 0, st); if (rc_) return rc_; }
     if (ev) { CK(hipEventRecord(h->ring[2 * slot + 1], st)); h->ring_calls += 1; }
     // (3) finishing kernel -- unless k_tm's last block does that job (it asks for k_fin through the result word if not)
+    if (h->has_rep) { // the repeated bins' pixels, densely, for all 13 K candidates (waits for k_tm's tables itself)
+        const RepArgs R = rep_args(h);
+        k_rep_delta<<<blocks_for((long long)h->n_dup * h->n_bins * K, 256), 256, 0, st>>>(R, h->tabs, h->tm_done, h->seq, fA, K, rank, world,
+                                                                                         h->d_acc, (unsigned long long*)(h->d_scalars + 10));
+        CK(hipGetLastError());
+    }
     if (ta.host_res == nullptr) {
         int rc_ = launch_fin(h, K, rank, world, (long long*)d_q_out, h->publish, st);
         if (rc_) return rc_;

@@ -22,7 +22,7 @@ _f32p = ctypes.POINTER(ctypes.c_float)
 _f64p = ctypes.POINTER(ctypes.c_double)
 
 SYMBOLS = ("graal_abi_version", "graal_create", "graal_destroy", "graal_last_error", "graal_set_params",
-           "graal_upload_subfrags", "graal_upload_contacts", "graal_upload_contacts_f32", "graal_upload_frags", "graal_download_frags",
+           "graal_upload_subfrags", "graal_upload_repeats", "graal_upload_contacts", "graal_upload_contacts_f32", "graal_upload_frags", "graal_download_frags",
            "graal_relabel_contigs", "graal_begin_step", "graal_layout_stats", "graal_eval_full_q", "graal_eval_candidates_q",
            "graal_eval_candidates", "graal_apply_move", "graal_set_finisher", "graal_set_timing", "graal_last_timing", "graal_scan_times", "graal_time_scan", "graal_last_counters")
 
@@ -50,6 +50,7 @@ def load():
         L.graal_set_params.argtypes = [ctypes.c_void_p, _f32p]
         L.graal_upload_subfrags.argtypes = [ctypes.c_void_p, _i32p, _f32p, _i32p, ctypes.c_int32, ctypes.c_int32,
                                             ctypes.c_float]
+        L.graal_upload_repeats.argtypes = [ctypes.c_void_p, _i32p, ctypes.c_int32, _i32p, _i32p, ctypes.c_int32, _f32p]
         L.graal_upload_contacts.argtypes = [ctypes.c_void_p, _i32p, _i32p, _i32p, ctypes.c_int64]
         L.graal_upload_contacts_f32.argtypes = [ctypes.c_void_p, _i32p, _i32p, _f32p, ctypes.c_int64]
         L.graal_upload_frags.argtypes = [ctypes.c_void_p, ctypes.POINTER(_i32p), ctypes.c_int32]
@@ -125,6 +126,17 @@ class Engine:
         self._ck(self._L.graal_upload_subfrags(self._h, sid.ctypes.data_as(_i32p), sl.ctypes.data_as(_f32p),
                                                sa.ctypes.data_as(_i32p), len(sid), int(n_sub_total),
                                                ctypes.c_float(float(n_frags_per_bins))), "graal_upload_subfrags")
+
+    def upload_repeats(self, dup_bins, dispatcher, collector, obs_rows):
+        """Repeated bins: their ids, the copies of every bin, and their rows of the observation matrix
+        ([n_dup, 3, n_sub_total] float32).  Call between upload_subfrags and upload_contacts / upload_frags."""
+        d = _c(dup_bins, np.int32)
+        disp = _c(np.asarray(dispatcher).reshape(-1, 2), np.int32)
+        coll = _c(collector, np.int32)
+        obs = _c(np.asarray(obs_rows, dtype=np.float32).reshape(len(d), 3, -1), np.float32)
+        self._ck(self._L.graal_upload_repeats(self._h, d.ctypes.data_as(_i32p), len(d), disp.ctypes.data_as(_i32p),
+                                              coll.ctypes.data_as(_i32p), len(coll), obs.ctypes.data_as(_f32p)),
+                 "graal_upload_repeats")
 
     def upload_contacts(self, row, col, count):
         """Counts may be integers or float32 (blacklist fill); integer arrays go through the int32 entry point."""

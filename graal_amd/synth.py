@@ -215,6 +215,37 @@ def make_problem(n_bins=50000, nnz=20_000_000, n_sub=1, seed=20141217, contig_we
         sub_len_bp=sub_len_bp, bin_of_sub=bin_of_sub)
 
 
+def add_repeats(problem, dup_bins, n_copies):
+    """Repeated fragments as ``simulation_loader.modify_vect_frags`` appends them (``simulation_loader.py:182-280``): every bin
+    of `dup_bins` gets `n_copies` extra fragments, each a singleton contig of its own (fresh label, ``rep = 1``,
+    ``activ = 1``, ``id_d`` = the bin); ``collector_id_repeats`` / ``frag_dispatcher`` list the copies of every bin."""
+    p = dict(problem)
+    S = {k: np.array(v, dtype=np.int32, copy=True) for k, v in p["S_o_A_frags"].items()}
+    n0 = int(p["n_frags"])
+    S.setdefault("rep", np.zeros(n0, np.int32)); S.setdefault("activ", np.ones(n0, np.int32))
+    S.setdefault("id_d", np.arange(n0, dtype=np.int32)); S.setdefault("ori", np.ones(n0, np.int32))
+    add = {k: [] for k in S}
+    max_f, max_c = n0, int(S["id_c"].max()) + 1
+    dup_bins = [int(b) for b in dup_bins]
+    for b in dup_bins:
+        for _ in range(int(n_copies)):
+            row = dict(pos=0, id_c=max_c, start_bp=0, len_bp=int(S["len_bp"][b]), circ=int(S["circ"][b]), id=max_f, prev=-1,
+                       next=-1, l_cont=1, l_cont_bp=int(S["len_bp"][b]), ori=1, rep=1, activ=1, id_d=b)
+            for k in add:
+                add[k].append(row[k])
+            max_f += 1; max_c += 1
+    S = {k: np.concatenate([S[k], np.asarray(add[k], dtype=np.int32)]) for k in S}
+    collector, dispatcher, x = [], [], 0
+    for b in range(n0):
+        ids = np.nonzero(S["id_d"] == b)[0] if b in dup_bins else np.array([b])
+        collector.extend(int(i) for i in ids)
+        dispatcher.append((x, x + len(ids)))
+        x += len(ids)
+    p.update(S_o_A_frags=S, n_new_frags=max_f, collector_id_repeats=np.asarray(collector, np.int32),
+             frag_dispatcher=np.asarray(dispatcher, np.int32), id_frag_duplicated=dup_bins)
+    return p
+
+
 def dense_from_coo(row, col, val, n, dtype=np.float32):
     """Symmetric dense matrix with a zero diagonal, as ``simulation_loader.py:81-82`` +
     ``cuda_lib_gl.py:155-160`` build it.  Test / oracle helper for SMALL problems only."""

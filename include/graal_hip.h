@@ -35,7 +35,7 @@ enum {
     GRAAL_E_ARG = 1,          /* bad argument / shape */
     GRAAL_E_HIP = 2,          /* HIP runtime error (incl. no device) */
     GRAAL_E_STATE = 3,        /* call order (e.g. eval before upload) */
-    GRAAL_E_UNSUPPORTED = 4   /* repeated / inactive fragments: not in this round */
+    GRAAL_E_UNSUPPORTED = 4   /* e.g. more sub-fragments than the scan's LDS bitmap holds */
 };
 
 typedef struct graal_ctx graal_ctx;
@@ -55,6 +55,16 @@ int graal_set_params(graal_ctx* h, const float* param8);
  * replaces the uploads of cuda_lib_gl.py:210-215 */
 int graal_upload_subfrags(graal_ctx* h, const int32_t* sub_id, const float* sub_len_kb, const int32_t* sub_accu,
                           int32_t n_bins, int32_t n_sub_total, float n_frags_per_bins);
+
+/* Repeated bins (allow_repeats; simulation_loader.py:182-280, kernels3.cu:2915-2930, 3356-3380).  Call after
+ * graal_upload_subfrags and before graal_upload_contacts / graal_upload_frags (which may then hold more fragments than
+ * bins).  dup_bins[n_dup]: the repeated unique bins; dispatcher[n_bins][2], collector[n_collector]: the fragment copies of
+ * every bin (frag_dispatcher / collector_id_repeats); obs_rows[n_dup][3][n_sub_total]: the rows of the sub-level
+ * observation matrix of the repeated bins' sub-fragments (row of slot a of dup_bins[i] at (i*3 + a)*n_sub_total; unused
+ * slots ignored).  Every pixel of a repeated bin is priced densely from these rows, summed over the ACTIVE copies; the
+ * contact list must then contain no contact of a repeated bin.  n_dup = 0 switches repeats off. */
+int graal_upload_repeats(graal_ctx* h, const int32_t* dup_bins, int32_t n_dup, const int32_t* dispatcher, const int32_t* collector,
+                         int32_t n_collector, const float* obs_rows);
 
 /* this rank's shard of the sub-level contact list in COO form, row < col, any order (sorted by
  * (row, col) is fastest); counts are the observed contacts.  Replaces the dense S x S upload of
