@@ -1666,12 +1666,17 @@ __global__ __launch_bounds__(256) void k_rep_delta(RepArgs R, const NbTables* __
                 const Geo g = R.geo[R.collector[r]];
                 touched = touched || piece_of(T->key, g.id_c, geo_pos(g.flags)) > 0;
             }
-            if (hi != lo && R.dup_index[lo] >= 0 && R.dup_index[hi] >= 0) { // both repeated: either one may be the touched one
+            if (hi != lo && R.dup_index[lo] >= 0 && R.dup_index[hi] >= 0) {
+                // both repeated: the reference re-evaluates the pixel only if BOTH bins have a copy in the two contigs (its
+                // "repeats x repeats" range runs over the repeats of the sub-index, kernels3.cu:3368-3373) -- also when an
+                // activity swap of one of them would change it: kept, so that candidate scores are the reference's
                 const int w = lo == u ? hi : lo;
+                bool touched_w = false;
                 for (int r = R.dispatcher[2 * w]; r < R.dispatcher[2 * w + 1]; r++) {
                     const Geo g = R.geo[R.collector[r]];
-                    touched = touched || piece_of(T->key, g.id_c, geo_pos(g.flags)) > 0;
+                    touched_w = touched_w || piece_of(T->key, g.id_c, geo_pos(g.flags)) > 0;
                 }
+                touched = touched && touched_w;
             }
             if (touched) {
                 CandCtx C; C.T = T; C.op = 0; C.fA = fA;

@@ -16,7 +16,9 @@ passes them), same method names, argument orders and return tuples for everythin
   every ``argsort`` is stable.
 
 Blacklisted bins (``cuda_lib_gl.py:161-172``) are supported: their rows of the observation matrix become explicit
-contacts with the float32 fill value.  Not supported yet (loud ``NotImplementedError``): repeated fragments.
+contacts with the float32 fill value.  Repeated fragments (``allow_repeats``): the observations of the repeated bins leave
+the contact list and go to the engine as dense rows (``split_repeat_observations``); every pixel of a repeated bin is
+priced over the active copies like ``kernels3.cu:2915-2930``.
 """
 import numpy as np
 
@@ -51,6 +53,31 @@ def as_coo_upper(m):
     r, c, v = r[keep], c[keep], np.asarray(v)[keep]
     order = np.lexsort((c, r))
     return r[order].astype(np.int32), c[order].astype(np.int32), v[order]
+
+
+def split_repeat_observations(sub_coo, sub_ids_of_bins, dup_bins, n_sub_total):
+    """Contacts without the repeated bins' sub-fragments + the rows of the (symmetric, zero-diagonal) observation matrix
+    of those sub-fragments, [n_dup, 3, n_sub_total] float32 -- what ``graal_upload_repeats`` takes."""
+    r, c, v = (np.asarray(x) for x in sub_coo)
+    dup_bins = [int(b) for b in dup_bins]
+    S = int(n_sub_total)
+    slot_of = {}
+    for i, b in enumerate(dup_bins):
+        ids = sub_ids_of_bins[b]
+        for a in range(int(ids[3])):
+            slot_of[int(ids[a])] = (i, a)
+    dup_sub = np.zeros(S, dtype=bool)
+    dup_sub[list(slot_of)] = True
+    obs = np.zeros((len(dup_bins), 3, S), dtype=np.float32)
+    touch = np.nonzero(dup_sub[r] | dup_sub[c])[0]
+    for k in touch:
+        rk, ck, vk = int(r[k]), int(c[k]), np.float32(v[k])
+        if rk in slot_of:
+            i, a = slot_of[rk]; obs[i, a, ck] = vk
+        if ck in slot_of:
+            i, a = slot_of[ck]; obs[i, a, rk] = vk
+    keep = ~(dup_sub[r] | dup_sub[c])
+    return (r[keep], c[keep], np.asarray(v)[keep]), obs
 
 
 def blacklist_fill(sub_coo, bin_coo, sub_ids_of_bins, black_bins, fill_value, n_sub_total):
@@ -219,14 +246,15 @@ class sampler(object):
         self.compute_dist = compute_dist
         self.id_frags_blacklisted = list(id_frags_blacklisted) if id_frags_blacklisted is not None else []
         self.id_frag_duplicated = list(id_frag_duplicated) if id_frag_duplicated is not None else []
-        if len(self.id_frag_duplicated) or int(n_new_frags) != int(n_frags):
-            raise NotImplementedError("repeated fragments (allow_repeats) are not supported by the MI355X engine yet")
+        self.id_frag_duplicated = [int(x) for x in self.id_frag_duplicated]
+        if (int(n_new_frags) != int(n_frags)) != bool(len(self.id_frag_duplicated)):
+            raise ValueError("n_new_frags != n_frags needs the list of duplicated bins (and vice versa)")
         self.np_id_frag_duplicated = np.int32(self.id_frag_duplicated)
         self.n_frags = np.int32(n_frags)
         self.n_new_frags = np.int32(n_new_frags)
         self.init_n_sub_frags = np.int32(init_n_sub_frags)
         self.n_new_sub_frags = np.int32(n_new_sub_frags)
-        self.uniq_frags = np.arange(0, self.n_frags, dtype=np.int32)
+        self.uniq_frags = np.int32(np.setdiff1d(np.arange(0, self.n_frags, dtype=np.int32), self.np_id_frag_duplicated))
         self.n_frags_uniq = np.int32(len(self.uniq_frags))
         self.n_tmp_struct = N_TMP_STRUCT
         self.n_modif_metropolis = N_TMP_STRUCT
@@ -265,6 +293,10 @@ class sampler(object):
         self.engine = Engine(0 if device is None else int(device))  # raises if the HIP library / GPU is missing
         self.engine.upload_subfrags(self.np_sub_frags_id, self.np_sub_frags_len_bp, self.np_sub_frags_accu,
                                     int(self.init_n_sub_frags), float(self.mean_squared_frags_per_bin))
+        if len(self.id_frag_duplicated):   # repeated bins: observation rows to the engine, their contacts out of the list
+            self.sub_coo, obs_rows = split_repeat_observations(self.sub_coo, self.np_sub_frags_id, self.id_frag_duplicated,
+                                                               int(self.init_n_sub_frags))
+            self.engine.upload_repeats(self.id_frag_duplicated, self.frag_dispatcher, self.collector_id_repeats, obs_rows)
         lo, hi = gdist.shard_range(len(self.sub_coo[0]), group.rank, group.world)
         counts = np.asarray(self.sub_coo[2])
         if np.all(counts == np.round(counts)) and (len(counts) == 0 or counts.max() < 2 ** 24):
@@ -285,7 +317,10 @@ class sampler(object):
         self._single_sub = bool(np.all(self.np_sub_frags_id[:, 3] == 1))
         self._n_circ_prev = int((soa["circ"] == 1).sum())
         self._d_q = None
-        self.resync_every = 512        # MCMC steps between full re-evaluations of the carried-over likelihood
+        # MCMC steps between full re-evaluations of the carried-over likelihood.  With repeats every step: the reference's
+        # candidate pixel ranges miss some pixels an activity swap changes (kernels3.cu:3368-3373), so its per-step total
+        # (always a full evaluation, cuda_lib_gl.py:1828-1848) is not the previous score
+        self.resync_every = 1 if len(self.id_frag_duplicated) else 512
         self._steps_since_full = 0
         # ---- proposal ----------------------------------------------------------------------------------------
         self.n_neighbors = 10  # cuda_lib_gl.py:444
@@ -484,16 +519,19 @@ class sampler(object):
             self.test_copy_struct(i, 0, 0, max_id)
 
     def define_repeats(self):
+        """``cuda_lib_gl.py:452-473``: every copy of a duplicated bin (the original included) is a "repeat"."""
         self._black_set = set(int(x) for x in self.id_frags_blacklisted)
-        self.is_repeat = [False] * int(self.n_new_frags)
-        self.n_frags_duplicated = 0
-        self.n_frags_4_dist = len(np.unique(self.id_frags_blacklisted))
+        dup = set(self.id_frag_duplicated)
+        self.is_repeat = [int(d) in dup for d in self.id_d]
+        self.n_frags_duplicated = int(sum(self.is_repeat))
+        self.n_frags_4_dist = len(set(self._black_set) | set(i for i, r in enumerate(self.is_repeat) if r))
+        self._dup_set = dup
 
     def dist_inter_genome(self, tmp_gpu_vect_frags=None):
         g = self.gpu_vect_frags if tmp_gpu_vect_frags is None else tmp_gpu_vect_frags
         g.copy_from_gpu()
-        counted = np.ones(int(self.n_new_frags), dtype=bool)
-        if len(self.id_frags_blacklisted):                      # cuda_lib_gl.py:485
+        counted = ~np.asarray(self.is_repeat, dtype=bool)       # cuda_lib_gl.py:485
+        if len(self.id_frags_blacklisted):
             counted[np.asarray(self.id_frags_blacklisted, dtype=np.int64)] = False
         return dist_inter_genome(g.prev, g.next, g.ori, g.id_d, self.np_init_prev, self.np_init_next, self.np_init_ori,
                                  self.np_init_orientable, counted, self.n_frags_4_dist)
@@ -514,8 +552,15 @@ class sampler(object):
         distri = self.distri_frags["pk"][ori_id]
         n_max_candidates = min(delta, np.nonzero(distri != 0)[0].shape[0])
         init_id = self.rng.choice(self.distri_frags["xk"][ori_id], n_max_candidates, p=distri, replace=False)
+        out = []
+        if int(ori_id) in self._dup_set:      # the other copies of a repeated fragment are candidates too (:2314-2318)
+            d = self.frag_dispatcher[ori_id]
+            out.extend(int(x) for x in np.setdiff1d(self.collector_id_repeats[d[0]:d[1]], id_fA))
+        for id_fB in init_id:                 # every copy of a proposed bin (:2320-2322)
+            d = self.frag_dispatcher[id_fB]
+            out.extend(int(x) for x in self.collector_id_repeats[d[0]:d[1]])
         black = self._black_set
-        return [int(x) for x in init_id if int(x) not in black]   # cuda_lib_gl.py:2326-2329
+        return [x for x in out if x not in black]   # cuda_lib_gl.py:2326-2329
 
     # ------------------------------------------------------------------ one MCMC step
     def step_max_likelihood(self, id_fA, delta, size_block=512, dt=0, t=0, n_step=1):

