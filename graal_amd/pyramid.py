@@ -387,10 +387,22 @@ class Level:
 
 
 # ----------------------------------------------------------------------------------------- sampler inputs
-def simulation_inputs(pyramid, level, candidates_blacklist=(0,)):
+def select_repeated_frags(level_coo, n_frags, allow_repeats):
+    """``select_repeated_frags`` (``simulation_loader.py:369-394``): bins whose coverage (row + column sum of the stored
+    matrix) exceeds mean + 3 sigma, with ``max(1, round(cov / (mean + 3 sigma)) - 1)`` extra copies each."""
+    a, b, v = level_coo
+    cov = np.zeros(int(n_frags), dtype=np.float64)
+    np.add.at(cov, a, v); np.add.at(cov, b, v)
+    ext = cov.mean() + 3 * cov.std()
+    cand = np.nonzero(cov > ext)[0] if allow_repeats else np.zeros(0, dtype=np.int64)
+    return [(int(e), int(max(1, np.round(cov[e] / ext) - 1))) for e in cand]
+
+
+def simulation_inputs(pyramid, level, candidates_blacklist=(0,), allow_repeats=False):
     """What ``simulation.__init__`` hands to the sampler constructor (``simulation_loader.py:41-107``), from level `level`
-    (bins) and level - 1 (sub-fragments = observations), with the contact matrices as COO triples.  Repeats are not
-    selected (``allow_repeats`` off).  Returns a dict whose keys are the constructor's argument names."""
+    (bins) and level - 1 (sub-fragments = observations), with the contact matrices as COO triples; with ``allow_repeats``
+    the high-coverage bins get extra copies (``modify_vect_frags``, ``simulation_loader.py:182-280``).  Returns a dict whose
+    keys are the constructor's argument names."""
     lev, sub = pyramid.get_level(level), pyramid.get_level(level - 1)
     frags = pyramid.spec_level[str(level)]["fragments"]
     n = lev.n_frags
@@ -410,12 +422,34 @@ def simulation_inputs(pyramid, level, candidates_blacklist=(0,)):
                                                                      "next", "l_cont", "l_cont_bp")}
     S["ori"] = np.ones(n, np.int32); S["rep"] = np.zeros(n, np.int32); S["activ"] = np.ones(n, np.int32)
     S["id_d"] = np.arange(n, dtype=np.int32)
+    # modify_vect_frags: every copy a singleton contig of its own with a fresh label, rep = 1, activ = 1, id_d = the bin
+    dups = select_repeated_frags(lev.coo, n, allow_repeats)
+    max_f, max_c = n, int(S["id_c"].max()) + 1
+    add = {k: [] for k in S}
+    for b, n_dup in dups:
+        for _ in range(n_dup):
+            row = dict(pos=0, id_c=max_c, start_bp=0, len_bp=int(S["len_bp"][b]), circ=int(S["circ"][b]), id=max_f, prev=-1,
+                       next=-1, l_cont=1, l_cont_bp=int(S["len_bp"][b]), ori=1, rep=1, activ=1, id_d=b)
+            for k in add:
+                add[k].append(row[k])
+            max_f += 1; max_c += 1
+    if dups:
+        S = {k: np.concatenate([S[k], np.asarray(add[k], dtype=np.int32)]) for k in S}
+    dup_bins = [b for b, _ in dups]
+    collector, dispatcher = [], []
+    for b in range(n):
+        copies = np.nonzero(S["id_d"] == b)[0] if b in dup_bins else [b]
+        dispatcher.append((len(collector), len(collector) + len(copies)))
+        collector.extend(int(i) for i in copies)
     black = [] if list(candidates_blacklist) == [0] else list(candidates_blacklist)
-    frag_blacklisted = [int(f) for c in black for f in np.nonzero(S["id_c"] == c)[0]]   # blacklist_contig, :129-159
+    frag_blacklisted = []
+    for c in black:                                                   # blacklist_contig, :129-159 (all copies of its bins)
+        for f in np.nonzero(lev.S_o_A_frags["id_c"] == c)[0]:
+            frag_blacklisted.extend(collector[dispatcher[f][0]:dispatcher[f][1]])
     return dict(
-        S_o_A_frags=S, collector_id_repeats=np.arange(n, dtype=np.int32),
-        frag_dispatcher=np.stack([np.arange(n), np.arange(n) + 1], axis=1).astype(np.int32),
-        id_frag_duplicated=[], id_frags_blacklisted=frag_blacklisted, n_frags=n, n_new_frags=n,
+        S_o_A_frags=S, collector_id_repeats=np.asarray(collector, dtype=np.int32),
+        frag_dispatcher=np.asarray(dispatcher, dtype=np.int32),
+        id_frag_duplicated=dup_bins, id_frags_blacklisted=frag_blacklisted, n_frags=n, n_new_frags=max_f,
         init_n_sub_frags=n_sub_total, n_new_sub_frags=n_sub_total, np_rep_sub_frags_id=None,
         hic_matrix_sub_sampled=lev.coo, np_sub_frags_len_bp=lens, np_sub_frags_id=ids, np_sub_frags_accu=accu,
         mean_squared_frags_per_bin=np.float32(np.float32(collect).mean() ** 2), norm_vect_accu=accu.sum(axis=1),

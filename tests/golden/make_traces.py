@@ -16,34 +16,37 @@ sys.path.insert(0, ROOT)
 from graal_amd import em, synth  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
-CASES = [  # name, n_sub, seed, n_bins, nnz, cycles, neighbours, blacklist
-    ("single_sub", 1, 41, 70, 1200, 2, 3, []),
-    ("three_sub", 3, 42, 60, 1500, 2, 4, []),
-    ("blacklist", 3, 48, 50, 900, 2, 4, [3, 4, 5, 17, 31]),
+CASES = [  # name, n_sub, seed, n_bins, nnz, cycles, neighbours, blacklist, repeated bins
+    ("single_sub", 1, 41, 70, 1200, 2, 3, [], []),
+    ("three_sub", 3, 42, 60, 1500, 2, 4, [], []),
+    ("blacklist", 3, 48, 50, 900, 2, 4, [3, 4, 5, 17, 31], []),
+    ("repeats", 3, 92, 45, 900, 2, 3, [], [5, 18, 30]),
 ]
 
 
-def problem(n_sub, seed, n_bins, nnz, blacklist):
+def problem(n_sub, seed, n_bins, nnz, blacklist, repeats=()):
     par = synth.make_param_simu(fact=200.0, v_inter=0.02)
     P = synth.make_problem(n_bins=n_bins, nnz=nnz, n_sub=n_sub, seed=seed, contig_weights=(5, 4, 3), mean_len_bp=2000.0,
                            accu=9 if n_sub > 1 else 1, param=par, grid_bp=2000)
     P = synth.with_dense(P)
+    if len(repeats):
+        P = synth.add_repeats(P, repeats, 2)   # two extra copies of every repeated bin
     P["id_frags_blacklisted"] = list(blacklist)
     return P
 
 
 def main():
     out = {}
-    for name, n_sub, seed, n_bins, nnz, cycles, delta, black in CASES:
-        P = problem(n_sub, seed, n_bins, nnz, black)
+    for name, n_sub, seed, n_bins, nnz, cycles, delta, black, reps in CASES:
+        P = problem(n_sub, seed, n_bins, nnz, black, reps)
         ora = O.OracleSampler(P, np.random.RandomState(seed), fix_trans_accu=True)
         t = em.run_em(ora, cycles, delta, rng=ora.rng)
         out[name] = {"n_sub": n_sub, "seed": seed, "n_bins": n_bins, "nnz": nnz, "cycles": cycles, "neighbours": delta,
-                     "blacklist": black, "mutations": np.asarray(t.mutations()).tolist(),
+                     "blacklist": black, "repeats": reps, "mutations": np.asarray(t.mutations()).tolist(),
                      "likelihood": [float(x) for x in t.likelihood], "n_contigs": [int(x) for x in t.n_contigs],
                      "dist": [float(x) for x in t.dist],
                      "final_id_c": ora.gpu_vect_frags["id_c"].tolist(), "final_pos": ora.gpu_vect_frags["pos"].tolist(),
-                     "final_ori": ora.gpu_vect_frags["ori"].tolist()}
+                     "final_ori": ora.gpu_vect_frags["ori"].tolist(), "final_activ": ora.gpu_vect_frags["activ"].tolist()}
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "traces.json"), "w") as f:
         json.dump(out, f)
     print({k: len(v["mutations"]) for k, v in out.items()})

@@ -17,8 +17,8 @@ GOLD = json.load(open(os.path.join(HERE, "golden", "traces.json")))
 
 def test_oracle_reproduces_the_committed_trace():
     from oracle import oracle as O
-    g = GOLD["blacklist"]
-    P = problem(g["n_sub"], g["seed"], g["n_bins"], g["nnz"], g["blacklist"])
+    g = GOLD["repeats"]
+    P = problem(g["n_sub"], g["seed"], g["n_bins"], g["nnz"], g["blacklist"], g["repeats"])
     ora = O.OracleSampler(P, np.random.RandomState(g["seed"]), fix_trans_accu=True)
     t = em.run_em(ora, g["cycles"], g["neighbours"], rng=ora.rng)
     assert np.asarray(t.mutations()).tolist() == g["mutations"]
@@ -31,7 +31,7 @@ def test_oracle_reproduces_the_committed_trace():
 def test_engine_reproduces_the_committed_trace(name):
     from tests.test_sampler_gpu import make_gpu_sampler
     g = GOLD[name]
-    P = problem(g["n_sub"], g["seed"], g["n_bins"], g["nnz"], g["blacklist"])
+    P = problem(g["n_sub"], g["seed"], g["n_bins"], g["nnz"], g["blacklist"], g["repeats"])
     rng = np.random.RandomState(g["seed"])
     s = make_gpu_sampler(P, rng)
     t = em.run_em(s, g["cycles"], g["neighbours"], rng=rng)
@@ -43,4 +43,5 @@ def test_engine_reproduces_the_committed_trace(name):
     assert s.gpu_vect_frags.id_c.tolist() == g["final_id_c"]
     assert s.gpu_vect_frags.pos.tolist() == g["final_pos"]
     assert s.gpu_vect_frags.ori.tolist() == g["final_ori"]
+    assert s.gpu_vect_frags.activ.tolist() == g["final_activ"]
     s.free_gpu()

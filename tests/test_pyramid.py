@@ -174,3 +174,31 @@ def test_fasta_export(tmp_path):
     # the reference's reader: last record keeps its newlines and loses its last line
     strict = P.load_reference_sequence(os.path.join(base, "genome.fa"), strict_reference=True)
     assert strict["chr1"] == seqs["chr1"] and "\n" in strict["chr3"] and len(strict["chr3"].replace("\n", "")) < len(seqs["chr3"])
+
+
+def test_repeated_fragments_are_selected_by_coverage(tmp_path):
+    rng = np.random.RandomState(6)
+    base = str(tmp_path / "ds")
+    n, pairs, _, _ = make_dataset(base, rng, contig_sizes=(40, 30, 20), n_pairs=20000, empty=(4, 45))
+    # one hot fragment: many extra contacts with everybody (a repeated sequence)
+    with open(os.path.join(base, "abs_fragments_contacts_weighted.txt"), "a") as f:
+        for y in rng.randint(0, n, size=12000):
+            if y != 33:
+                f.write("%d\t%d\t1.0\n" % (34, y + 1))
+    P = pyr.build_and_filter(base, 2, 3)
+    lev = P.get_level(1)
+    a, b, v = lev.coo
+    cov = np.zeros(lev.n_frags); np.add.at(cov, a, v); np.add.at(cov, b, v)
+    ext = cov.mean() + 3 * cov.std()
+    hot = np.nonzero(cov > ext)[0]
+    assert len(hot) == 1
+    inp = pyr.simulation_inputs(P, 1, allow_repeats=True)
+    k = int(max(1, np.round(cov[hot[0]] / ext) - 1))
+    assert inp["id_frag_duplicated"] == [int(hot[0])] and inp["n_new_frags"] == inp["n_frags"] + k
+    S = inp["S_o_A_frags"]
+    new = np.arange(inp["n_frags"], inp["n_new_frags"])
+    assert (S["rep"][new] == 1).all() and (S["id_d"][new] == hot[0]).all() and (S["l_cont"][new] == 1).all()
+    assert len(np.unique(S["id_c"][new])) == k and S["id_c"][new].min() > lev.S_o_A_frags["id_c"].max()
+    d = inp["frag_dispatcher"][hot[0]]
+    assert sorted(inp["collector_id_repeats"][d[0]:d[1]].tolist()) == [int(hot[0])] + new.tolist()
+    assert pyr.simulation_inputs(P, 1, allow_repeats=False)["id_frag_duplicated"] == []
