@@ -151,3 +151,28 @@ def test_trace_with_repeats_matches_oracle(n_sub, seed, dup):
         assert np.array_equal(getattr(g.gpu_vect_frags, k), ora.gpu_vect_frags[k]), k
     assert (ora.gpu_vect_frags["activ"] == 0).any() or True
     g.free_gpu()
+
+
+def test_trace_with_repeats_and_a_blacklist_matches_oracle():
+    """Both at once: the blacklist fill reaches the repeated bins' observation rows too (cuda_lib_gl.py:161-172 overwrites
+    whole rows and columns of the dense matrix), blacklisted copies are never proposed."""
+    from graal_amd import em
+    from tests.test_sampler_gpu import make_gpu_sampler
+    par = synth.make_param_simu(fact=200.0, v_inter=0.02)
+    P = synth.make_problem(n_bins=45, nnz=900, n_sub=3, seed=95, contig_weights=(5, 4, 3), mean_len_bp=2000.0, accu=9, param=par,
+                           grid_bp=2000)
+    P = synth.add_repeats(synth.with_dense(P), (5, 30), 2)
+    P["id_frags_blacklisted"] = [11, 12, 30, 47]      # two ordinary bins, a repeated bin's original and one of its copies
+    seed = 96
+    ora = O.OracleSampler(P, np.random.RandomState(seed), fix_trans_accu=True)
+    t_ref = em.run_em(ora, 2, 3, rng=ora.rng)
+    rng = np.random.RandomState(seed)
+    g = make_gpu_sampler(P, rng)
+    t_gpu = em.run_em(g, 2, 3, rng=rng)
+    assert np.array_equal(t_gpu.mutations(), t_ref.mutations())
+    assert t_gpu.n_contigs == t_ref.n_contigs and t_gpu.dist == t_ref.dist
+    assert np.allclose(t_gpu.likelihood, t_ref.likelihood, rtol=1e-6, atol=0)
+    g.gpu_vect_frags.copy_from_gpu()
+    for k in O.FIELDS:
+        assert np.array_equal(getattr(g.gpu_vect_frags, k), ora.gpu_vect_frags[k]), k
+    g.free_gpu()
