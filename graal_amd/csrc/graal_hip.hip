@@ -816,9 +816,12 @@ __device__ __forceinline__ void price_contacts(const PriceArgs& pa, unsigned lon
         if (e >= nq_total || op >= N_OPS) continue;
         const QEntry qe = pa.queue[e];
         const int fx = qe.fx, fy = qe.fy, slx = qe.slots & 3, sly = (qe.slots >> 2) & 3;
-        // speculative: geometry and statistics are needed by (nearly) every queued contact
+        // speculative: geometry, statistics and the transforms of the first neighbour are needed by (nearly) every queued
+        // contact -- requested together with the relation masks instead of one dependent load after the other
         const Geo gx = pa.geo[fx], gy = pa.geo[fy];
         const Stat sx = pa.stat[fx], sy = pa.stat[fy];
+        const int k0 = (__ffs((int)qe.rel) - 1) >> 2;
+        const Xf xp0 = pa.tabs[k0].xf[op][(qe.ci >> (4 * k0)) & 7], xq0 = pa.tabs[k0].xf[op][(qe.cj >> (4 * k0)) & 7];
         // candidates of this lane's op that change the relation of the two fragments (piece ids from the codes)
         unsigned rel = qe.rel, todo = 0;
         while (rel) {
@@ -836,7 +839,7 @@ __device__ __forceinline__ void price_contacts(const PriceArgs& pa, unsigned lon
             todo &= todo - 1;
             const NbTables& T = pa.tabs[k];
             const int p = (qe.ci >> (4 * k)) & 7, q = (qe.cj >> (4 * k)) & 7;
-            const End X = end_xf(gx, T.xf[op][p]), Y = end_xf(gy, T.xf[op][q]);
+            const End X = end_xf(gx, k == k0 ? xp0 : T.xf[op][p]), Y = end_xf(gy, k == k0 ? xq0 : T.xf[op][q]);
             const double ln_new = log((double)ex_pair(X, sx, slx, Y, sy, sly, pa.nfpb, pa.par));
             const long long qv = to_q(ob * (ln_new - ln_old));
             if (qv != 0) atomicAdd((unsigned long long*)&pa.out[k * N_OPS + op], (unsigned long long)qv);
@@ -995,16 +998,23 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
         // do not actually run concurrently (a profiler or debugger serialising dispatches, streams sharing a hardware
         // queue) the scan cannot even start before this block exits -- then the step is handed to k_fin, which the host
         // launches behind the scan.
-        bool ok = false;
-        const unsigned long long t_end = wall_clock64() + (unsigned long long)ta.wait_ticks;
-        for (;;) {
-            bool mine = true;
-            for (int b = t; b < ta.n_scan_blocks; b += (int)blockDim.x)
-                mine = mine && (__hip_atomic_load(&ta.flags[FLAG_STRIDE * b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)seq);
-            if (__syncthreads_and(mine)) { ok = true; break; }
-            if (__syncthreads_or(wall_clock64() > t_end)) break;
-            __builtin_amdgcn_s_sleep(1);
+        // (only wave 0 polls -- all its flag loads of a round are in flight together, no block barrier inside the loop; the
+        // other waves wait at the barrier below)
+        __shared__ int s_seen;
+        if (t < 64) {
+            bool ok0 = false;
+            const unsigned long long t_end = wall_clock64() + (unsigned long long)ta.wait_ticks;
+            for (;;) {
+                unsigned missing = 0; // (no short-circuit: the loads of a round must not wait for each other)
+                for (int b = t; b < ta.n_scan_blocks; b += 64)
+                    missing |= __hip_atomic_load(&ta.flags[FLAG_STRIDE * b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ^ (unsigned)seq;
+                if (__ballot(missing != 0) == 0) { ok0 = true; break; }
+                if (__ballot(wall_clock64() > t_end) != 0) break; // wave-uniform exit
+            }
+            if (t == 0) s_seen = ok0 ? 1 : 0;
         }
+        __syncthreads();
+        const bool ok = s_seen != 0;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         if (t == 0) {
             s_nq = ok ? __hip_atomic_load(&ta.counters[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
