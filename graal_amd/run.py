@@ -1,0 +1,78 @@
+"""Headless run from a dataset folder -- what pressing "start" in the reference's GUI does (``main_window.py:617-650`` ->
+``simulation_loader.simulation.__init__`` -> ``main_gl.window.start_EM``), without wx / GLUT:
+
+    python -m graal_amd.run --dataset DIR [--fasta genome.fa] --level 3 --cycles 100 --neighbours 3 --out OUT
+
+DIR holds ``info_contigs.txt``, ``fragments_list.txt``, ``abs_fragments_contacts_weighted.txt`` (``README.md:111-113``).
+Steps: build (or reuse) the pyramid, build the sampler inputs of the chosen level, fit the Rippe contact model, run the
+MCMC cycles on the MI355X, write the trace files of ``main_gl.py:321-342`` and -- if a FASTA file is given -- the
+scaffolded genome (``pyramid_sparse.py:1430-1488``)."""
+import argparse
+import os
+import time
+
+import numpy as np
+
+from . import em
+from . import pyramid as pyr
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("--dataset", required=True)
+    ap.add_argument("--fasta", default=None)
+    ap.add_argument("--size-pyramid", type=int, default=4)
+    ap.add_argument("--factor", type=int, default=3)
+    ap.add_argument("--level", type=int, default=3, help="pyramid level of the bins (1 .. size-pyramid - 1)")
+    ap.add_argument("--cycles", type=int, default=10)
+    ap.add_argument("--neighbours", type=int, default=3)
+    ap.add_argument("--blacklist", type=int, nargs="*", default=[0], help="contig ids to blacklist (0 = none)")
+    ap.add_argument("--allow-repeats", action="store_true")
+    ap.add_argument("--sample-params", action="store_true")
+    ap.add_argument("--no-explode", action="store_true")
+    ap.add_argument("--seed", type=int, default=None, help="seed of the numpy RandomState (the reference never seeds)")
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args(argv)
+    if not 1 <= args.level < args.size_pyramid:
+        raise SystemExit("--level must be in 1 .. size-pyramid - 1 (the level below it holds the observations)")
+    from .sampler import sampler
+    root = os.path.join(args.dataset, "pyramids", "pyramid_%d_thresh_auto" % args.size_pyramid)
+    if os.path.exists(os.path.join(root, "pyramid.npz")):
+        P = pyr.Pyramid(root, args.size_pyramid)
+    else:
+        P = pyr.build_and_filter(args.dataset, args.size_pyramid, args.factor)
+    inp = pyr.simulation_inputs(P, args.level, candidates_blacklist=args.blacklist, allow_repeats=args.allow_repeats)
+    rng = np.random.RandomState(args.seed) if args.seed is not None else None
+    smp = sampler(True, inp["S_o_A_frags"], inp["collector_id_repeats"], inp["frag_dispatcher"], inp["id_frag_duplicated"],
+                  inp["id_frags_blacklisted"], inp["n_frags"], inp["n_new_frags"], inp["init_n_sub_frags"], inp["n_new_sub_frags"],
+                  None, inp["hic_matrix_sub_sampled"], inp["np_sub_frags_len_bp"], inp["np_sub_frags_id"], inp["np_sub_frags_accu"],
+                  inp["mean_squared_frags_per_bin"], inp["norm_vect_accu"], inp["S_o_A_sub_frags"], inp["hic_matrix"],
+                  inp["mean_value_trans"], args.cycles, False, None, device=args.device, rng=rng)
+    # simulation_loader.py:109-123: window and bin size of the fit from the initial layout
+    g = smp.gpu_vect_frags
+    g.copy_from_gpu()
+    mean_dist_kb = float(g.l_cont_bp[g.start_bp == 0].mean()) / 1000.0
+    size_bin_kb = float(g.len_bp.mean()) / 1000.0
+    smp.estimate_parameters(mean_dist_kb, size_bin_kb)
+    t0 = time.perf_counter()
+    trace = em.run_em(smp, args.cycles, args.neighbours, rng=rng, sample_param=args.sample_params, scrambled=not args.no_explode)
+    dt = time.perf_counter() - t0
+    out = args.out or os.path.join(args.dataset, "graal_out")
+    em.save_behaviour_to_txt(trace, out)
+    lev = P.get_level(args.level)
+    if args.fasta:
+        P.load_reference_sequence(args.fasta)
+        g.copy_from_gpu()
+        lev.generate_new_fasta(g, os.path.join(out, "genome.fasta"), os.path.join(out, "info_frags.txt"))
+    n_steps = len(trace.likelihood)
+    print("%d bins (%d fragments, %d sub-fragments), %d MCMC steps in %.1f s (%.0f us/step): %d contigs, logL %.6e, "
+          "distance to the initial genome %.4f; traces in %s" % (inp["n_frags"], inp["n_new_frags"], inp["init_n_sub_frags"], n_steps,
+                                                                 dt, 1e6 * dt / max(n_steps, 1), trace.n_contigs[-1],
+                                                                 trace.likelihood[-1], trace.dist[-1], out))
+    smp.free_gpu()
+    return trace
+
+
+if __name__ == "__main__":
+    main()

@@ -293,6 +293,7 @@ class sampler(object):
         self.engine = Engine(0 if device is None else int(device))  # raises if the HIP library / GPU is missing
         self.engine.upload_subfrags(self.np_sub_frags_id, self.np_sub_frags_len_bp, self.np_sub_frags_accu,
                                     int(self.init_n_sub_frags), float(self.mean_squared_frags_per_bin))
+        self.sub_coo_full = self.sub_coo   # (what estimate_parameters fits: the whole observation matrix, cuda_lib_gl.py:1244)
         if len(self.id_frag_duplicated):   # repeated bins: observation rows to the engine, their contacts out of the list
             self.sub_coo, obs_rows = split_repeat_observations(self.sub_coo, self.np_sub_frags_id, self.id_frag_duplicated,
                                                                int(self.init_n_sub_frags))
@@ -359,7 +360,7 @@ class sampler(object):
         log-space least squares, fsolve for d_max."""
         from . import rippe_fit
         self.bins = np.arange(size_bin_kb, max_dist_kb + size_bin_kb, size_bin_kb)
-        self.mean_contacts = rippe_fit.mean_contacts_per_bin(self.S_o_A_sub_frags, self.sub_coo, self.bins, max_dist_kb,
+        self.mean_contacts = rippe_fit.mean_contacts_per_bin(self.S_o_A_sub_frags, self.sub_coo_full, self.bins, max_dist_kb,
                                                              size_bin_kb)
         p, self.y_estim = rippe_fit.estimate_param_rippe(self.mean_contacts, self.bins)
         estim_max_dist = rippe_fit.estimate_max_dist_intra(p, self.mean_value_trans)

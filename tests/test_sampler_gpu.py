@@ -176,3 +176,26 @@ def test_dataset_to_trace_through_the_pyramid(tmp_path):
     for k in O.FIELDS:
         assert np.array_equal(getattr(g.gpu_vect_frags, k), ora.gpu_vect_frags[k]), k
     g.free_gpu()
+
+
+def test_headless_run_from_a_dataset_folder(tmp_path):
+    """python -m graal_amd.run: dataset folder -> pyramid -> fit -> MCMC -> trace files + scaffolded FASTA."""
+    import os
+    from graal_amd import run
+    from tests.test_pyramid import make_dataset
+    base = str(tmp_path / "ds")
+    make_dataset(base, np.random.RandomState(21), contig_sizes=(40, 30, 20), n_pairs=40000, empty=(4, 45))
+    out = str(tmp_path / "out")
+    tr = run.main(["--dataset", base, "--fasta", os.path.join(base, "genome.fa"), "--size-pyramid", "3", "--level", "1",
+                   "--cycles", "3", "--neighbours", "3", "--seed", "5", "--out", out])
+    n = len(tr.likelihood)
+    assert n == 3 * 27 and np.isfinite(tr.likelihood).all()   # (toy contacts are not polymer-like: no claim on the assembly)
+    muts = em.load_mutations(os.path.join(out, "list_mutations.txt"))
+    assert muts.shape == (n, 3) and np.array_equal(muts, tr.mutations())
+    fa = open(os.path.join(out, "genome.fasta")).read()
+    assert fa.count(">3C-assembly|contig_") == tr.n_contigs[-1] or fa.count(">") > 0
+    assert sum(len(line) for line in fa.split("\n") if not line.startswith(">")) > 0
+    # same seed, same trace
+    tr2 = run.main(["--dataset", base, "--size-pyramid", "3", "--level", "1", "--cycles", "3", "--neighbours", "3", "--seed", "5",
+                    "--out", str(tmp_path / "out2")])
+    assert np.array_equal(tr2.mutations(), tr.mutations())
