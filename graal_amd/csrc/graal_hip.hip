@@ -1112,8 +1112,23 @@ struct ScanArgs { // by value: kernel-argument pointers are known to be GLOBAL (
     int bitmap_words;
 };
 
-template <bool SINGLE_SUB>
-__global__ __launch_bounds__(1024, 8) void k_scan(ScanArgs sa, int fA, Neigh nb, int K, int max_id,
+// word j (0 .. 4G-1) of G groups held in registers (select chain over constant indices: stays in registers)
+template <int G> __device__ __forceinline__ int sel_words(const int4 (&a)[G], int j)
+{
+    int v = 0;
+#pragma unroll
+    for (int i = 0; i < G; i++) {
+        const int4 q = a[i];
+        const int w = (j & 3) == 0 ? q.x : ((j & 3) == 1 ? q.y : ((j & 3) == 2 ? q.z : q.w));
+        v = (j >> 2) == i ? w : v;
+    }
+    return v;
+}
+
+// G = groups of 4 contacts per thread and iteration.  G = 4 with two 1024-thread blocks per CU (8 waves/SIMD, <= 64 VGPRs);
+// G = 8 with one block per CU (half the waves to launch, the same bytes in flight).
+template <bool SINGLE_SUB, int G>
+__global__ __launch_bounds__(1024, (G == 4 ? 8 : 4)) void k_scan(ScanArgs sa, int fA, Neigh nb, int K, int max_id,
                                                 int dry /* timing replays: count, do not queue */)
 {
     extern __shared__ unsigned s_bm[];
@@ -1151,14 +1166,12 @@ __global__ __launch_bounds__(1024, 8) void k_scan(ScanArgs sa, int fA, Neigh nb,
     // compiler keeps all four in flight together.  The first iteration's loads are issued here, ABOVE the prologue: 40 % of
     // the list is on its way while the bitmap is built -- except by wave 0, which builds it: vector-memory results return in
     // order, so its dependent prologue loads would queue up behind its own stream loads.
-    auto ldg = [&](long long g) { return ld_stream(row4 + (g < n4 ? g : (long long)n4)); };
-    int4 f0, f1, f2, f3;
-    static_assert(SCAN_PRE >= 0 && SCAN_PRE <= 4, "");
-    if (t >= 64) {
-        if (SCAN_PRE > 0) f0 = ldg(g0);
-        if (SCAN_PRE > 1) f1 = ldg((long long)g0 + stride);
-        if (SCAN_PRE > 2) f2 = ldg((long long)g0 + 2 * stride);
-        if (SCAN_PRE > 3) f3 = ldg((long long)g0 + 3 * stride);
+    auto ldg = [&](int g) { return ld_stream(row4 + (g < n4 ? g : n4)); }; // (group indices fit 32 bits: nnz < 2^32)
+    int4 f[G];
+    static_assert(SCAN_PRE == 0 || SCAN_PRE == 4, "");
+    if (t >= 64 && SCAN_PRE) {
+#pragma unroll
+        for (int i = 0; i < G; i++) f[i] = ldg(g0 + i * stride);
     }
     // Wave 0 alone builds the bitmap (the other waves go straight to the one barrier below: a block-wide barrier this early
     // waits for the block's last wave to be LAUNCHED, and there were four of them).  Inside one wave, LDS operations
@@ -1224,33 +1237,43 @@ __global__ __launch_bounds__(1024, 8) void k_scan(ScanArgs sa, int fA, Neigh nb,
     unsigned long long n_rel = 0;
     STAMP_BLK(1, t == 0 && !dry);
     STAMP(9, blockIdx.x == 0 && t == 0 && !dry);
-    // one iteration: four groups of 4 contacts (ga + i * stride)
-    auto process = [&](const int4 r0, const int4 r1, const int4 r2, const int4 r3, const long long ga) {
-        const int r[16] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
-        unsigned vmask = 0; // valid contacts of the four groups
+    // one iteration: G groups of 4 contacts (ga + i * stride)
+    auto process = [&](const int4 (&rr)[G], const int ga) {
+        unsigned vmask = 0xffffffffu >> (32 - 4 * G); // valid contacts of the G groups: all of them, except at the very end
+        if (ga + (G - 1) * stride >= n4) {
+            vmask = 0;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const long long rem = nnz - ((ga + (long long)i * stride) << 2);
-            const int v = rem >= 4 ? 4 : (rem > 0 ? (int)rem : 0);
-            vmask |= ((1u << v) - 1u) << (4 * i);
+            for (int i = 0; i < G; i++) {
+                const long long rem = nnz - ((long long)(ga + i * stride) << 2);
+                const int v = rem >= 4 ? 4 : (rem > 0 ? (int)rem : 0);
+                vmask |= ((1u << v) - 1u) << (4 * i);
+            }
         }
-        unsigned hit = 0; // bit j: contact j of this lane has an affected row
+        unsigned hit = 0;   // bit j: contact j of this lane has an affected row
 #pragma unroll
-        for (int j = 0; j < 16; j++) hit |= ((s_bm[r[j] >> 5] >> (r[j] & 31)) & 1u) << j;
+        for (int i = 0; i < G; i++) {
+            const int4 q = rr[i];
+            hit |= (((s_bm[q.x >> 5] >> (q.x & 31)) & 1u) | (((s_bm[q.y >> 5] >> (q.y & 31)) & 1u) << 1)
+                    | (((s_bm[q.z >> 5] >> (q.z & 31)) & 1u) << 2) | (((s_bm[q.w >> 5] >> (q.w & 31)) & 1u) << 3)) << (4 * i);
+        }
         hit &= vmask;
         if (__ballot(hit != 0) == 0) return; // the common case: nobody in this wave needs its col words
-        // second test, still wide: the col words of the groups with an affected row (up to four 16-byte loads in flight
-        // together), all sixteen bitmap tests at once
-        int4 c0 = make_int4(0, 0, 0, 0), c1 = c0, c2 = c0, c3 = c0;
-        if (hit & 0x000fu) c0 = ld_stream(col4 + ga);
-        if (hit & 0x00f0u) c1 = ld_stream(col4 + ga + stride);
-        if (hit & 0x0f00u) c2 = ld_stream(col4 + ga + 2 * (long long)stride);
-        if (hit & 0xf000u) c3 = ld_stream(col4 + ga + 3 * (long long)stride);
+        // second test, still wide: the col words of the groups with an affected row (up to G 16-byte loads in flight
+        // together), all bitmap tests at once
+        int4 cc[G];
         {
-            const int c[16] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w};
             unsigned hit2 = 0;
 #pragma unroll
-            for (int j = 0; j < 16; j++) hit2 |= ((s_bm[c[j] >> 5] >> (c[j] & 31)) & 1u) << j;
+            for (int i = 0; i < G; i++) {
+                cc[i] = make_int4(0, 0, 0, 0);
+                if ((hit >> (4 * i)) & 0xfu) cc[i] = ld_stream(col4 + (ga + i * stride));
+            }
+#pragma unroll
+            for (int i = 0; i < G; i++) {
+                const int4 q = cc[i];
+                hit2 |= (((s_bm[q.x >> 5] >> (q.x & 31)) & 1u) | (((s_bm[q.y >> 5] >> (q.y & 31)) & 1u) << 1)
+                         | (((s_bm[q.z >> 5] >> (q.z & 31)) & 1u) << 2) | (((s_bm[q.w >> 5] >> (q.w & 31)) & 1u) << 3)) << (4 * i);
+            }
             hit &= hit2;
         }
         // third test: one doubly-affected contact per lane and pass (a loop, not a 16-fold unrolled body: rare when contigs
@@ -1262,11 +1285,8 @@ __global__ __launch_bounds__(1024, 8) void k_scan(ScanArgs sa, int fA, Neigh nb,
             if (hit) {
                 j = __ffs((int)hit) - 1;
                 hit &= hit - 1;
-                const int rj = (j & 8) ? sel8(r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w, j & 7)
-                                       : sel8(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, j & 7);
-                const int cj_ = (j & 8) ? sel8(c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w, j & 7)
-                                        : sel8(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, j & 7);
-                cidx = ((ga + (long long)(j >> 2) * stride) << 2) + (j & 3);
+                const int rj = sel_words<G>(rr, j), cj_ = sel_words<G>(cc, j);
+                cidx = ((long long)(ga + (j >> 2) * stride) << 2) + (j & 3);
                 {
                     int fx, fy;
                     if (SINGLE_SUB) { fx = rj; fy = cj_; }
@@ -1309,17 +1329,16 @@ __global__ __launch_bounds__(1024, 8) void k_scan(ScanArgs sa, int fA, Neigh nb,
             }
         }
     };
-    {
-        const bool w0 = t < 64;
-        if (w0 || SCAN_PRE < 1) f0 = ldg(g0);
-        if (w0 || SCAN_PRE < 2) f1 = ldg((long long)g0 + stride);
-        if (w0 || SCAN_PRE < 3) f2 = ldg((long long)g0 + 2 * stride);
-        if (w0 || SCAN_PRE < 4) f3 = ldg((long long)g0 + 3 * stride);
+    if (t < 64 || !SCAN_PRE) {
+#pragma unroll
+        for (int i = 0; i < G; i++) f[i] = ldg(g0 + i * stride);
     }
-    process(f0, f1, f2, f3, g0);
-    for (long long g = (long long)g0 + 4 * stride; g <= n4; g += 4 * stride) {
-        const int4 q0 = ldg(g), q1 = ldg(g + stride), q2 = ldg(g + 2 * stride), q3 = ldg(g + 3 * stride);
-        process(q0, q1, q2, q3, g);
+    process(f, g0);
+    for (int g = g0 + G * stride; g <= n4; g += G * stride) {
+        int4 q[G];
+#pragma unroll
+        for (int i = 0; i < G; i++) q[i] = ldg(g + i * stride);
+        process(q, g);
     }
     STAMP(10, blockIdx.x == 0 && t == 0 && !dry);
     STAMP_BLK(2, t == 0 && !dry);
@@ -1882,13 +1901,20 @@ int scan_threads_cfg()
     return v;
 }
 
+int scan_groups_cfg()
+{
+    static const int v = (getenv("GRAAL_SCAN_G") && atoi(getenv("GRAAL_SCAN_G")) == 8) ? 8 : 4;
+    return v;
+}
+
 int scan_grid(const Ctx* h)
 {
     // two 1024-thread blocks per CU fill the 256 CUs; 16 fewer leave room for k_tm's blocks, which run at the same time (a
     // CU that hosts one of them takes only one scan block, and a scan block that has to wait for a slot ends 8 us late)
-    static const int scan_blocks = getenv("GRAAL_SCAN_BLOCKS") ? atoi(getenv("GRAAL_SCAN_BLOCKS")) : 256 * 2 - 16;
+    static const int scan_blocks = getenv("GRAAL_SCAN_BLOCKS") ? atoi(getenv("GRAAL_SCAN_BLOCKS"))
+                                                               : (scan_groups_cfg() == 8 ? 256 - 8 : 256 * 2 - 16);
     const long long groups = (h->nnz >> 2) + 1;
-    const long long per_block = 4ll * scan_threads_cfg(); // groups one block takes per iteration
+    const long long per_block = (long long)scan_groups_cfg() * scan_threads_cfg(); // groups one block takes per iteration
     return (int)std::max<long long>(1, std::min<long long>((groups + per_block - 1) / per_block, scan_blocks));
 }
 
@@ -1906,8 +1932,13 @@ int launch_scan(Ctx* h, int fA, const Neigh& nb, int K, int max_id, int dry, hip
     sa.queue = h->queue; sa.counters = (unsigned long long*)(h->d_scalars + 10);
     sa.flags = h->d_flags; sa.seq32 = (unsigned)h->seq;
     if (nbk > MAX_SCAN_BLOCKS) return fail(h, GRAAL_E_ARG, "GRAAL_SCAN_BLOCKS too large");
-    if (h->single_sub) k_scan<true><<<nbk, scan_threads, shm, st>>>(sa, fA, nb, K, max_id, dry);
-    else k_scan<false><<<nbk, scan_threads, shm, st>>>(sa, fA, nb, K, max_id, dry);
+    if (scan_groups_cfg() == 8) {
+        if (h->single_sub) k_scan<true, 8><<<nbk, scan_threads, shm, st>>>(sa, fA, nb, K, max_id, dry);
+        else k_scan<false, 8><<<nbk, scan_threads, shm, st>>>(sa, fA, nb, K, max_id, dry);
+    } else {
+        if (h->single_sub) k_scan<true, 4><<<nbk, scan_threads, shm, st>>>(sa, fA, nb, K, max_id, dry);
+        else k_scan<false, 4><<<nbk, scan_threads, shm, st>>>(sa, fA, nb, K, max_id, dry);
+    }
     CK(hipGetLastError());
     return GRAAL_OK;
 }
