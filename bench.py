@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--mcmc-warmup", type=int, default=int(os.environ.get("GRAAL_BENCH_MCMC_WARMUP", 2000)))
     ap.add_argument("--neighbours", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
+                                                      "the multi-rank code path with several ranks on ONE GPU)")
     ap.add_argument("--layout", choices=("exploded", "original"), default="exploded",
                     help="exploded (+ MCMC warm-up) is the BASELINE workload; original = the 7 reference contigs (late-stage regime)")
     args = ap.parse_args()
@@ -109,8 +111,13 @@ def main():
     import torch
     if world > 1:
         import torch.distributed as td
-        torch.cuda.set_device(local)
-        td.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            torch.cuda.set_device(local)
+            td.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            local = 0
+            torch.cuda.set_device(0)
+            td.init_process_group(args.backend)
     group = gdist.Group(rank, world)
 
     t_gen = time.perf_counter()
