@@ -8,8 +8,10 @@
 Workload (BASELINE.json configs[4], SURVEY.md section 8d "C5"): synthetic 50,000-fragment / 20,000,000-contact map,
 generator seed 20141217; layout = exploded genome + 2,000 real MCMC warm-up steps (K = 5 neighbours).  One timed
 "step" = the scoring phase of one MCMC step: ONE fused pass over the contact list for the 13 x 5 = 65 candidates of a
-(fA, 5 neighbours) proposal, their expected-mass tasks, the RCCL all-reduce of the 65 int64 values (N > 1) and the
-device->host copy of the result.  Inputs are resident in HBM; proposals are drawn beforehand.  With N GPUs the SAME
+(fA, 5 neighbours) proposal, their expected-mass tasks, the exchange of the ranks' 65 int64 values (N > 1) and the
+device->host hand-over of the result (N > 1: each rank's GPU publishes its 65 int64 sums to pinned host memory shared by
+the ranks of the node and every host adds them up; the same region is then timed once more with an all-reduce of a device
+buffer instead, reported as `exchange_alt`).  Inputs are resident in HBM; proposals are drawn beforehand.  With N GPUs the SAME
 contact list is sharded N ways (strong scaling).
 
 Output: one JSON line on rank 0 (contract in the task statement) with `roofline` (fused scan kernel: algorithmic bytes
@@ -175,6 +177,25 @@ def main():
         td.all_reduce(t, op=td.ReduceOp.MAX)
         elapsed = float(t.cpu()[0])
     counters = smp.engine.last_counters()
+    # N > 1: the same timed region once more with the OTHER way of summing the ranks' 13*K int64 values (one all-reduce of a
+    # device buffer per step through torch.distributed -- RCCL with the nccl backend), reported next to the default
+    alt = None
+    if world > 1 and smp.exchange == "host":
+        smp.exchange = "rccl"
+        for f, nb in props[:args.warmup]:
+            smp._candidate_deltas(f, nb, max_id)
+        sync_all()
+        ta = time.perf_counter()
+        for f, nb in props[args.warmup:]:
+            smp._candidate_deltas(f, nb, max_id)
+        sync_all()
+        ta = time.perf_counter() - ta
+        smp.exchange = "host"
+        t = torch.tensor([ta], dtype=torch.float64, device="cuda")
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        ta = float(t.cpu()[0])
+        alt = {"exchange": "%s all-reduce of a device buffer (graal_eval_candidates_q + torch.distributed)" % args.backend,
+               "value": n_cand / ta, "ms_per_step": 1e3 * ta / args.steps}
     # for reference: back-to-back replays of the last step's scan between two events (per-launch event overhead amortised)
     scan_replay_ms = smp.engine.time_scan(len(props[-1][1]), reps=100)
 
@@ -219,7 +240,10 @@ def main():
                                    % (n, len(P["coo_row"]), args.layout, args.mcmc_warmup),
                        "neighbours_per_step": K, "candidates_per_step": 13 * K, "contacts_per_gpu": int(nnz_local),
                        "n_contigs": int(stats[0]), "max_contig_len": int(stats[4]),
-                       "parallelism": "contacts sharded x%d, 1 all-reduce(65 x int64)/step" % world},
+                       "parallelism": "contacts sharded x%d, %s" % (world, {
+                           "none": "single rank", "rccl": "1 all-reduce(65 x int64)/step (%s)" % args.backend,
+                           "host": "65 x int64 per rank and step published to pinned host memory shared by the ranks, summed by every host"
+                       }[smp.exchange])},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_scan",
                          "bytes_per_launch": bytes_per_launch, "avg_launch_ms": scan_s * 1e3,
@@ -232,6 +256,8 @@ def main():
             "full_mcmc_step_ms": 1e3 * full_step_s,
             "setup_s": {"generate": t_gen, "sampler": t_setup, "mcmc_warmup": t_mcmc},
         }
+        if alt is not None:
+            out["exchange_alt"] = alt
         if world == 1 and not args.no_cpu_baseline:
             smp.gpu_vect_frags.copy_from_gpu()
             out["cpu_baseline"] = cpu_baseline(P, smp.gpu_vect_frags.as_dict())

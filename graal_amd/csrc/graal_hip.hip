@@ -21,6 +21,7 @@
 #include <string.h>
 #include <stdlib.h>
 
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -868,6 +869,8 @@ __device__ __forceinline__ void hand_out(long long* out, unsigned long long* cou
 
 constexpr long long NEED_FIN = 1ll << 62; // published instead of the sums: k_tm left work for k_fin, launch it
 constexpr long long GAVE_UP = 1ll << 61;  // (with NEED_FIN) k_tm's last block stopped waiting for k_scan
+constexpr int X_SLOT_WORDS = 128;         // exchange slot: sequence word + MAXK*13 sums, padded to 1 KB
+static_assert(1 + MAXK * N_OPS <= X_SLOT_WORDS, "exchange slot too small");
 constexpr int FIN_INLINE_Q = 64;          // queued contacts the finishing block of k_tm prices itself
 
 // ------------------------------------------------------------------ per-step kernels
@@ -1799,6 +1802,14 @@ struct Ctx {
     DevArgs* d_args = nullptr;    // [2]: one argument block per layout buffer
     long long* h_res = nullptr;   // pinned host: [0] sequence number of the published step, [1..] K*13 sums
     long long* h_stats = nullptr; // pinned host: [0] sequence number, [1..16] the statistics words of k_stats_fin
+    // where the step's last block publishes: h_res, or -- with an exchange attached -- this rank's slot of the step's
+    // parity in a host segment shared by the ranks of the node (host and device views of the same memory)
+    long long* res_host = nullptr;
+    long long* res_dev = nullptr;
+    long long* x_host = nullptr;  // exchange segment: [2 parities][world ranks][X_SLOT_WORDS], registered with HIP
+    long long* x_dev = nullptr;
+    size_t x_bytes = 0;
+    int x_rank = 0, x_world = 1;
     long long stats_seq = 0;
     long long seq = 0;
     long long* d_scalars = nullptr; // [0..7] stats, [8..9] full q, [10..12] step counters, [13] stale (int), [14] #circ,
@@ -1952,7 +1963,7 @@ int launch_fin(Ctx* h, int K, int rank, int world, long long* d_q_out, bool publ
     FinArgs fa;
     fa.tm_done = h->tm_done; fa.step_hdr = h->step_hdr; fa.counters = (unsigned long long*)(h->d_scalars + 10); fa.queue = h->queue;
     fa.tabs = h->tabs; fa.geo = h->geo; fa.stat = h->stat_frag; fa.acc = h->d_acc; fa.sync = h->d_sync;
-    k_fin<<<fin_blocks, 256, 0, st>>>(h->d_args + h->cur, fa, K, rank, world, d_q_out, publish ? h->h_res : nullptr, h->seq);
+    k_fin<<<fin_blocks, 256, 0, st>>>(h->d_args + h->cur, fa, K, rank, world, d_q_out, publish ? h->res_dev : nullptr, h->seq);
     CK(hipGetLastError());
     return GRAAL_OK;
 }
@@ -2035,6 +2046,7 @@ int graal_create(int device, graal_ctx** out)
     CK(hipMalloc(&h->d_plan, sizeof(IncrPlan)));
     CK(hipHostMalloc((void**)&h->h_res, (1 + MAXK * N_OPS) * sizeof(long long), hipHostMallocDefault));
     memset(h->h_res, 0, (1 + MAXK * N_OPS) * sizeof(long long));
+    h->res_host = h->res_dev = h->h_res;
     CK(hipHostMalloc((void**)&h->h_stats, 17 * sizeof(long long), hipHostMallocDefault));
     memset(h->h_stats, 0, 17 * sizeof(long long));
     {
@@ -2056,6 +2068,7 @@ void graal_destroy(graal_ctx* h)
                         h->keys, h->keys_sorted, h->o2n, h->len_of2[0], h->len_of2[1], h->contig_off2[0], h->contig_off2[1], h->perm, h->cbase, h->link, h->mates, h->cub_tmp, h->tabs, h->step_hdr, h->d_args, h->d_chg, h->d_plan,
                         h->d_scalars, h->d_qout};
         for (void* p : ptrs) if (p) (void)hipFree(p);
+        if (h->x_host) (void)hipHostUnregister(h->x_host);
         if (h->h_res) (void)hipHostFree(h->h_res);
         if (h->h_stats) (void)hipHostFree(h->h_stats);
         for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
@@ -2440,7 +2453,7 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     static const bool no_finisher = getenv("GRAAL_NO_FINISHER") != nullptr; // always finish with k_fin (diagnostics)
     ta.flags = h->d_flags;
     ta.sync = h->d_sync; ta.n_scan_blocks = scan_grid(h);
-    ta.host_res = (h->publish && world == 1 && !no_finisher && h->finisher_ok && !h->has_rep) ? h->h_res : nullptr;
+    ta.host_res = (h->publish && (world == 1 || h->x_host) && !no_finisher && h->finisher_ok && !h->has_rep) ? h->res_dev : nullptr;
     // a generous multiple of the time the streaming pass needs at 2 TB/s, plus launch slack
     ta.wait_ticks = (int)std::min<long long>(100ll * 50 + (long long)(4.0 * 4.0 * (double)h->nnz / 2.0e12 * 1.0e8), 1ll << 30);
     ta.counters = (unsigned long long*)(h->d_scalars + 10); ta.queue = h->queue; ta.stat = h->stat_frag;
@@ -2473,17 +2486,23 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     return GRAAL_OK;
 }
 
-int graal_eval_candidates(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int32_t max_id, double* delta)
+// synchronous evaluation: launch the step, spin on the sequence word its last block writes into pinned host memory (fall
+// back to a stream synchronise if it does not show up -- it always does unless the launch failed); q_sum[K*13] = the Q sums
+// of this rank, plus -- with an exchange attached -- those the other ranks of the node published for the same step
+static int eval_sync(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int32_t max_id, int rank, int world, long long* q_sum)
 {
-    if (!h || !delta) return GRAAL_E_ARG;
-    h->publish = true;
     const long long want = h->seq + 1;
-    int rc = graal_eval_candidates_q(h, fA, fB, K, max_id, 0, 1, (int64_t*)h->d_qout, nullptr);
+    if (world > 1) { // this rank's slot of the step's parity (two steps later the slot is reused: every rank has read it by then,
+                     // because nobody finishes step s+1 before everybody has published it, i.e. has finished reading step s)
+        const size_t off = ((size_t)(want & 1) * (size_t)world + (size_t)rank) * X_SLOT_WORDS;
+        h->res_host = h->x_host + off;
+        h->res_dev = h->x_dev + off;
+    } else { h->res_host = h->res_dev = h->h_res; }
+    h->publish = true;
+    int rc = graal_eval_candidates_q(h, fA, fB, K, max_id, rank, world, (int64_t*)h->d_qout, nullptr);
     h->publish = false;
     if (rc) return rc;
-    // spin on the sequence word the last block of k_post writes into pinned host memory; fall back to a stream
-    // synchronise if it does not show up (it always does unless the launch failed)
-    volatile long long* res = h->h_res;
+    volatile long long* res = h->res_host;
     bool seen = false;
     for (long long spin = 0; spin < 200000000ll; spin++) {
         const long long v = res[0];
@@ -2492,7 +2511,7 @@ int graal_eval_candidates(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K
             if ((v & GAVE_UP) && ++h->gave_up >= 3) h->finisher_ok = false;
             res[0] = 0;
             h->publish = true;
-            rc = launch_fin(h, K, 0, 1, (long long*)h->d_qout, true, h->stream);
+            rc = launch_fin(h, K, rank, world, (long long*)h->d_qout, true, h->stream);
             h->publish = false;
             if (rc) return rc;
             continue;
@@ -2511,7 +2530,75 @@ int graal_eval_candidates(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K
     }
     if (res[0] == -want) return fail(h, GRAAL_E_HIP, "timed out waiting for the candidate tables / the scan (a kernel of the step did not run)");
     __sync_synchronize();
-    for (int i = 0; i < K * N_OPS; i++) delta[i] = (double)res[1 + i] / Q_SCALE;
+    for (int i = 0; i < K * N_OPS; i++) q_sum[i] = res[1 + i];
+    // the other ranks' slots: their GPUs write them, this host reads them (coherent host memory; 8-byte words, the
+    // sequence word last).  A rank that died leaves its word behind: give up after ~60 s instead of spinning for ever.
+    for (int r = 0; r < world; r++) {
+        if (r == rank) continue;
+        volatile long long* o = h->x_host + ((size_t)(want & 1) * (size_t)world + (size_t)r) * X_SLOT_WORDS;
+        const auto t0 = std::chrono::steady_clock::now();
+        long long spin = 0;
+        for (;;) {
+            const long long v = o[0];
+            if (v == want) break;
+            if (v == -want) return fail(h, GRAAL_E_HIP, "another rank's step failed (exchange)");
+            if ((++spin & 0xfffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60))
+                return fail(h, GRAAL_E_STATE, "exchange: another rank did not publish this step within 60 s (ranks out of step, or a rank died)");
+            __builtin_ia32_pause();
+        }
+        __sync_synchronize();
+        for (int i = 0; i < K * N_OPS; i++) q_sum[i] += o[1 + i];
+    }
+    return GRAAL_OK;
+}
+
+int graal_eval_candidates(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int32_t max_id, double* delta)
+{
+    if (!h || !delta) return GRAAL_E_ARG;
+    long long q[MAXK * N_OPS];
+    const int rc = eval_sync(h, fA, fB, K, max_id, 0, 1, q);
+    if (rc) return rc;
+    for (int i = 0; i < K * N_OPS; i++) delta[i] = (double)q[i] / Q_SCALE;
+    return GRAAL_OK;
+}
+
+int graal_exchange_bytes(int32_t world, int64_t* bytes)
+{
+    if (!bytes || world < 1) return GRAAL_E_ARG;
+    *bytes = (int64_t)(2 * (size_t)world * X_SLOT_WORDS * sizeof(long long));
+    return GRAAL_OK;
+}
+
+int graal_attach_exchange(graal_ctx* h, void* segment, int64_t bytes, int32_t rank, int32_t world, int64_t seq_floor, int64_t* seq_now)
+{
+    if (!h) return GRAAL_E_ARG;
+    if (seq_now) *seq_now = h->seq;
+    if (!segment) return GRAAL_OK; // query only
+    if (world < 2 || rank < 0 || rank >= world) return fail(h, GRAAL_E_ARG, "exchange: bad rank / world");
+    if (bytes < (int64_t)(2 * (size_t)world * X_SLOT_WORDS * sizeof(long long))) return fail(h, GRAAL_E_ARG, "exchange: segment too small (graal_exchange_bytes)");
+    if (h->x_host) return fail(h, GRAAL_E_STATE, "exchange: already attached");
+    CK(hipSetDevice(h->device));
+    CK(hipStreamSynchronize(h->stream));
+    CK(hipStreamSynchronize(h->aux));
+    CK(hipHostRegister(segment, (size_t)bytes, hipHostRegisterMapped | hipHostRegisterPortable));
+    void* dp = nullptr;
+    hipError_t e = hipHostGetDevicePointer(&dp, segment, 0);
+    if (e != hipSuccess) { (void)hipHostUnregister(segment); h->err = std::string("hipHostGetDevicePointer failed: ") + hipGetErrorString(e); return GRAAL_E_HIP; }
+    h->x_host = (long long*)segment; h->x_dev = (long long*)dp; h->x_bytes = (size_t)bytes; h->x_rank = rank; h->x_world = world;
+    // the published word is the step's sequence number: all ranks continue from the same one
+    if (seq_floor > h->seq) h->seq = seq_floor;
+    if (seq_now) *seq_now = h->seq;
+    return GRAAL_OK;
+}
+
+int graal_eval_candidates_x(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int32_t max_id, int64_t* q_sum)
+{
+    if (!h || !q_sum) return GRAAL_E_ARG;
+    if (!h->x_host) return fail(h, GRAAL_E_STATE, "graal_attach_exchange first");
+    long long q[MAXK * N_OPS];
+    const int rc = eval_sync(h, fA, fB, K, max_id, h->x_rank, h->x_world, q);
+    if (rc) return rc;
+    for (int i = 0; i < K * N_OPS; i++) q_sum[i] = q[i];
     return GRAAL_OK;
 }
 

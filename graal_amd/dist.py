@@ -1,5 +1,7 @@
-"""Multi-GPU glue: one process per GPU, the COO contact list sharded by rank, ONE all-reduce of the per-candidate
-Q vector (13*K int64) per MCMC step.  The reference has no distributed path; its only hint is
+"""Multi-GPU glue: one process per GPU, the COO contact list sharded by rank, ONE exchange of the per-candidate
+Q vector (13*K int64 = 520 bytes) per MCMC step -- either an RCCL all-reduce of a device buffer, or (ranks of one node,
+the default there) through pinned host memory the ranks share: each rank's GPU publishes its sums to its slot, each host
+adds up the slots (``Group.shared_host_segment``, ``graal_attach_exchange`` in include/graal_hip.h).  The reference has no distributed path; its only hint is
 the comment "place where we want to spread the workload accross the network!" at ``cuda_lib_gl.py:1886``.
 
 Because every log-likelihood contribution is an int64 fixed-point number, the all-reduced vector is bit-identical
@@ -54,10 +56,56 @@ class Group:
         td.all_reduce(t, op=td.ReduceOp.SUM)
         return int(t.cpu()[0])
 
+    def all_reduce_max_int(self, value):
+        if self.world == 1:
+            return int(value)
+        import torch
+        import torch.distributed as td
+        dev = "cuda" if td.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([int(value)], dtype=torch.int64, device=dev)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        return int(t.cpu()[0])
+
     def barrier(self):
         if self.world > 1:
             import torch.distributed as td
             td.barrier()
+
+    def single_node(self):
+        """True if every rank of the group runs on this host (then the ranks can share host memory)."""
+        if self.world == 1:
+            return True
+        import socket
+        import torch.distributed as td
+        names = [None] * self.world
+        td.all_gather_object(names, (socket.gethostname(), os.path.exists("/dev/shm")))
+        return all(n == names[0] and n[1] for n in names)
+
+    def shared_host_segment(self, nbytes):
+        """A zero-filled, page-aligned host memory segment mapped by every rank of the (single-node) group: rank 0
+        creates a /dev/shm file, the others open it, and the name is removed once all of them have it mapped.  Setup
+        traffic (the file name, two barriers) goes through torch.distributed; the per-step exchange does not."""
+        import mmap
+        import secrets
+        import torch.distributed as td
+        nbytes = (int(nbytes) + mmap.PAGESIZE - 1) // mmap.PAGESIZE * mmap.PAGESIZE
+        name = ["/dev/shm/graal_x_%d_%s" % (os.getpid(), secrets.token_hex(6))] if self.rank == 0 else [None]
+        td.broadcast_object_list(name, src=0)
+        path = name[0]
+        if self.rank == 0:
+            fd = os.open(path, os.O_CREAT | os.O_EXCL | os.O_RDWR, 0o600)
+            os.ftruncate(fd, nbytes)
+        td.barrier()
+        try:
+            if self.rank != 0:
+                fd = os.open(path, os.O_RDWR)
+            m = mmap.mmap(fd, nbytes, mmap.MAP_SHARED, mmap.PROT_READ | mmap.PROT_WRITE)
+            os.close(fd)
+        finally:
+            td.barrier()
+            if self.rank == 0:
+                os.unlink(path)
+        return m
 
 
 def q_to_float(q):

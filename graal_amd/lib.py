@@ -24,7 +24,7 @@ _f64p = ctypes.POINTER(ctypes.c_double)
 SYMBOLS = ("graal_abi_version", "graal_create", "graal_destroy", "graal_last_error", "graal_set_params",
            "graal_upload_subfrags", "graal_upload_repeats", "graal_upload_contacts", "graal_upload_contacts_f32", "graal_upload_frags", "graal_download_frags",
            "graal_relabel_contigs", "graal_begin_step", "graal_layout_stats", "graal_eval_full_q", "graal_eval_candidates_q",
-           "graal_eval_candidates", "graal_apply_move", "graal_set_finisher", "graal_set_timing", "graal_last_timing", "graal_scan_times", "graal_time_scan", "graal_last_counters")
+           "graal_eval_candidates", "graal_exchange_bytes", "graal_attach_exchange", "graal_eval_candidates_x", "graal_apply_move", "graal_set_finisher", "graal_set_timing", "graal_last_timing", "graal_scan_times", "graal_time_scan", "graal_last_counters")
 
 _lib = None
 
@@ -62,6 +62,10 @@ def load():
         L.graal_eval_candidates_q.argtypes = [ctypes.c_void_p, ctypes.c_int32, _i32p, ctypes.c_int32, ctypes.c_int32,
                                               ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
         L.graal_eval_candidates.argtypes = [ctypes.c_void_p, ctypes.c_int32, _i32p, ctypes.c_int32, ctypes.c_int32, _f64p]
+        L.graal_exchange_bytes.argtypes = [ctypes.c_int32, _i64p]
+        L.graal_attach_exchange.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+                                            ctypes.c_int64, _i64p]
+        L.graal_eval_candidates_x.argtypes = [ctypes.c_void_p, ctypes.c_int32, _i32p, ctypes.c_int32, ctypes.c_int32, _i64p]
         L.graal_apply_move.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _i32p]
         L.graal_last_timing.argtypes = [ctypes.c_void_p, _f32p]
         L.graal_last_counters.argtypes = [ctypes.c_void_p, _i64p]
@@ -97,11 +101,19 @@ class Engine:
             raise GraalError("graal_create(device=%d): %s" % (device, msg))
         self.device = int(device)
         self.n = 0
+        self._x_map = self._x_view = None
 
     def close(self):
         if getattr(self, "_h", None):
-            self._L.graal_destroy(self._h)
+            self._L.graal_destroy(self._h)   # (unregisters the exchange segment before its mapping goes away)
             self._h = ctypes.c_void_p()
+        if getattr(self, "_x_view", None) is not None:
+            self._x_view = None
+            try:
+                self._x_map.close()
+            except (BufferError, ValueError):
+                pass
+            self._x_map = None
 
     def __del__(self):
         try:
@@ -213,6 +225,40 @@ class Engine:
             self._ck(self._L.graal_eval_candidates(self._h, int(fA), part.ctypes.data_as(_i32p), len(part), int(max_id),
                                                    buf.ctypes.data_as(_f64p)), "graal_eval_candidates")
             out[k0:k0 + len(part)] = buf.reshape(len(part), N_OPS)
+        return out
+
+    # -- node-local exchange through pinned host memory (one process per GPU) ------------------
+    def exchange_bytes(self, world):
+        b = ctypes.c_int64(0)
+        self._ck(self._L.graal_exchange_bytes(int(world), ctypes.byref(b)), "graal_exchange_bytes")
+        return int(b.value)
+
+    def step_seq(self):
+        """Sequence number of the last candidate evaluation of this handle."""
+        s = ctypes.c_int64(0)
+        self._ck(self._L.graal_attach_exchange(self._h, None, 0, 0, 1, 0, ctypes.byref(s)), "graal_attach_exchange")
+        return int(s.value)
+
+    def attach_exchange(self, shared_map, rank, world, seq_floor):
+        """`shared_map`: an ``mmap`` of the segment all ranks of the node share (>= exchange_bytes(world), zero filled).
+        The engine keeps it alive; from now on :meth:`eval_candidates_x` returns sums over all ranks."""
+        view = ctypes.c_char.from_buffer(shared_map)
+        s = ctypes.c_int64(0)
+        self._ck(self._L.graal_attach_exchange(self._h, ctypes.c_void_p(ctypes.addressof(view)), len(shared_map), int(rank),
+                                               int(world), int(seq_floor), ctypes.byref(s)), "graal_attach_exchange")
+        self._x_map, self._x_view = shared_map, view
+        return int(s.value)
+
+    def eval_candidates_x(self, fA, fB, max_id):
+        """Sharded, synchronous: float64 [K, 13] = (sum over ALL ranks of the int64 sums) / 2^30; every rank calls it."""
+        fb = _c(fB, np.int32)
+        out = np.zeros((len(fb), N_OPS), dtype=np.float64)
+        for k0 in range(0, len(fb), MAX_NEIGHBOURS):
+            part = fb[k0:k0 + MAX_NEIGHBOURS]
+            q = np.zeros(len(part) * N_OPS, dtype=np.int64)
+            self._ck(self._L.graal_eval_candidates_x(self._h, int(fA), part.ctypes.data_as(_i32p), len(part), int(max_id),
+                                                     q.ctypes.data_as(_i64p)), "graal_eval_candidates_x")
+            out[k0:k0 + len(part)] = (q.astype(np.float64) / Q_SCALE).reshape(len(part), N_OPS)
         return out
 
     def eval_candidates_q_async(self, fA, fB, max_id, d_out_ptr, stream_ptr, rank=0, world=1):

@@ -235,7 +235,7 @@ class sampler(object):
                  S_o_A_sub_frags,
                  hic_matrix, mean_value_trans, n_iterations, is_simu, gl_window=None, pos_vbo=None, col_vbo=None,
                  vel=None, pos=None, raw_im_init=None, pbo_im_buffer=None, sub_sample_factor=0,
-                 device=None, rng=None, group=None, param_simu=None, compute_dist=True):
+                 device=None, rng=None, group=None, param_simu=None, compute_dist=True, exchange=None):
         self.o = 0
         self.use_rippe = use_rippe
         self.gl_window = gl_window
@@ -318,6 +318,7 @@ class sampler(object):
         self._single_sub = bool(np.all(self.np_sub_frags_id[:, 3] == 1))
         self._n_circ_prev = int((soa["circ"] == 1).sum())
         self._d_q = None
+        self.exchange = self._setup_exchange(exchange)
         # MCMC steps between full re-evaluations of the carried-over likelihood.  With repeats every step: the reference's
         # candidate pixel ranges miss some pixels an activity swap changes (kernels3.cu:3368-3373), so its per-step total
         # (always a full evaluation, cuda_lib_gl.py:1828-1848) is not the previous score
@@ -480,10 +481,34 @@ class sampler(object):
     def init_likelihood(self):
         self.likelihood_t = self.eval_likelihood()
 
+    def _setup_exchange(self, mode):
+        """How the ranks' per-step Q vectors (13*K int64) are summed.  ``"host"``: through pinned host memory shared by the
+        ranks of one node -- no collective launch, no device->host copy, the step costs what a single-rank step costs;
+        ``"rccl"``: one RCCL all-reduce of a device buffer per step (the only choice across nodes).  Both are bit
+        identical (int64 sums).  Default: ``GRAAL_EXCHANGE`` or "host" when every rank is on this node."""
+        import os
+        if self.group.world == 1:
+            return "none"
+        mode = mode or os.environ.get("GRAAL_EXCHANGE", "auto")
+        if mode not in ("auto", "host", "rccl"):
+            raise ValueError("exchange must be 'host', 'rccl' or 'auto'")
+        same_node = self.group.single_node()          # (collective: every rank asks)
+        if mode == "host" and not same_node:
+            raise RuntimeError("exchange='host' needs every rank on one node")
+        if mode == "rccl" or not same_node:
+            return "rccl"
+        seg = self.group.shared_host_segment(self.engine.exchange_bytes(self.group.world))
+        floor = self.group.all_reduce_max_int(self.engine.step_seq())
+        self.engine.attach_exchange(seg, self.group.rank, self.group.world, floor)
+        self.group.barrier()
+        return "host"
+
     def _candidate_deltas(self, id_fA, id_neighbours, max_id):
-        """float64 [K, 13]; one fused scan per group of <= 8 neighbours, one all-reduce per scan when sharded."""
+        """float64 [K, 13]; one fused scan per group of <= 8 neighbours, one exchange per scan when sharded."""
         if self.group.world == 1:
             return self.engine.eval_candidates(id_fA, id_neighbours, max_id)
+        if self.exchange == "host":
+            return self.engine.eval_candidates_x(id_fA, id_neighbours, max_id)
         import torch
         out = np.zeros((len(id_neighbours), N_OPS), dtype=np.float64)
         dev = torch.device("cuda", self.engine.device)

@@ -114,6 +114,22 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
  * publishes the sums to pinned host memory; the call spins on that instead of a copy + stream synchronise) */
 int graal_eval_candidates(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int32_t max_id, double* delta);
 
+/* Node-local exchange of the per-rank Q vectors through pinned HOST memory (one process per GPU, all on one node).
+ * The reference has no distributed path (its only hint: "place where we want to spread the workload accross the network!",
+ * cuda_lib_gl.py:1886).  The per-step message is K*13 int64 = 520 bytes: every rank's GPU already publishes its sums to
+ * pinned host memory (graal_eval_candidates); with an exchange attached that memory is this rank's slot of a segment
+ * shared by the ranks (e.g. an mmap of a /dev/shm file, page aligned, graal_exchange_bytes(world) bytes, zero filled,
+ * which the library registers with HIP), and graal_eval_candidates_x returns the sum over all ranks' slots -- bit
+ * identical on every rank and for every world size (int64 sums).  No collective kernel, no device->host copy; the
+ * alternative is graal_eval_candidates_q + one RCCL all-reduce (graal_amd/sampler.py implements both).
+ * graal_attach_exchange(segment = NULL) only reports the context's step sequence number in *seq_now; ranks attach with
+ * seq_floor = the maximum over ranks so that all continue from the same number.  The segment must outlive the handle. */
+int graal_exchange_bytes(int32_t world, int64_t* bytes);
+int graal_attach_exchange(graal_ctx* h, void* segment, int64_t bytes, int32_t rank, int32_t world, int64_t seq_floor,
+                          int64_t* seq_now);
+/* synchronous, sharded: K*13 int64 Q sums over ALL ranks into a host buffer (every rank must make the same call) */
+int graal_eval_candidates_x(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int32_t max_id, int64_t* q_sum);
+
 /* In the synchronous single-GPU call, a step that leaves little work (short contigs) is finished by the last block of the
  * table kernel, which runs concurrently with the streaming kernel and waits for it; otherwise a third kernel finishes it.
  * Both give bit-identical sums.  enabled = 0 always uses the third kernel (the library does that by itself after noticing

@@ -49,7 +49,20 @@ def _worker(rank, world, port, out_q):
         vec = torch.arange(65, dtype=torch.int64) * (rank + 1) + local
         group.all_reduce_sum_(vec)
         group.barrier()
-        out_q.put((rank, lo, hi, local, total, vec.tolist()))
+        # the node-local exchange segment: every rank maps the same zero-filled host memory (the engine's GPUs write
+        # their slots there; here the hosts do), and it needs no name in /dev/shm once everybody has it
+        assert group.single_node()
+        seg = group.shared_host_segment(2 * world * 1024)
+        words = np.frombuffer(seg, dtype=np.int64)
+        assert len(words) * 8 >= 2 * world * 1024 and not words.any()
+        words[rank * 128:rank * 128 + 4] = [rank + 1, 10 * (rank + 1), local, group.all_reduce_max_int(rank + 5)]
+        group.barrier()
+        seen = [words[r * 128:r * 128 + 4].tolist() for r in range(world)]
+        group.barrier()
+        del words
+        seg.close()
+        leftovers = [f for f in os.listdir("/dev/shm") if f.startswith("graal_x_")]
+        out_q.put((rank, lo, hi, local, total, vec.tolist(), seen, leftovers))
     finally:
         td.destroy_process_group()
 
@@ -83,6 +96,9 @@ def test_sharded_q_sums_are_bit_identical_world2():
     locals_sum = res[0][3] + res[1][3]
     want_vec = [i * 3 + locals_sum for i in range(65)]
     assert res[0][5] == want_vec and res[1][5] == want_vec
+    for r in res:   # every rank saw every rank's slot; MAX all-reduce; no file left behind
+        assert r[6] == [[1, 10, res[0][3], world + 4], [2, 20, res[1][3], world + 4]]
+        assert r[7] == []
 
 
 def test_group_world1_needs_no_process_group():

@@ -1,5 +1,7 @@
-"""GPU: the sharded (multi-rank) engine path, exercised with TWO ranks on ONE GPU (gloo backend, both on cuda:0):
-contact shards, rank-sharded mass items, one int64 all-reduce per step.  The per-candidate deltas -- and therefore the
+"""GPU: the sharded (multi-rank) engine path, exercised with 2-3 ranks on ONE GPU (gloo backend, all on cuda:0):
+contact shards, rank-sharded mass items, one exchange of 13*K int64 sums per step -- through the pinned host segment the
+ranks share (exchange="host": graal_attach_exchange / graal_eval_candidates_x) or as one all-reduce of a device buffer
+(exchange="rccl": graal_eval_candidates_q + torch.distributed).  The per-candidate deltas -- and therefore the
 accepted-move trace -- must be bit-identical to the single-rank run (Q30 integer sums are order independent)."""
 import os
 import socket
@@ -17,21 +19,22 @@ def _problem():
                               param=par, grid_bp=2000)
 
 
-def _make(P, rng, group):
+def _make(P, rng, group, exchange=None):
     from graal_amd.sampler import sampler
     return sampler(True, P["S_o_A_frags"], P["collector_id_repeats"], P["frag_dispatcher"], [], [], P["n_frags"],
                    P["n_new_frags"], P["init_n_sub_frags"], P["n_new_sub_frags"], None,
                    (P["bin_coo_row"], P["bin_coo_col"], P["bin_coo_val"]), P["np_sub_frags_len_bp"], P["np_sub_frags_id"],
                    P["np_sub_frags_accu"], P["mean_squared_frags_per_bin"], None, None,
                    (P["coo_row"], P["coo_col"], P["coo_val"]), P["mean_value_trans"], 1, False, None,
-                   device=0, rng=rng, group=group, param_simu=P["param_simu"], compute_dist=False)
+                   device=0, rng=rng, group=group, param_simu=P["param_simu"], compute_dist=False, exchange=exchange)
 
 
-def _run(group, steps=150):
+def _run(group, exchange=None):
     from graal_amd import em
     P = _problem()
     rng = np.random.RandomState(5)
-    g = _make(P, rng, group)
+    g = _make(P, rng, group, exchange)
+    assert g.exchange == ("none" if group.world == 1 else exchange)
     scores = []
     t = em.run_em(g, 1, 4, rng=rng, on_step=lambda j, i, tr: scores.append(np.copy(g.score)))
     g.gpu_vect_frags.copy_from_gpu()
@@ -41,31 +44,37 @@ def _run(group, steps=150):
     return out
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, exchange):
     import torch.distributed as td
     from graal_amd import dist as gdist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     td.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        mut, scores, soa, full = _run(gdist.Group(rank, world))
+        mut, scores, soa, full = _run(gdist.Group(rank, world), exchange)
         q.put((rank, mut, scores, soa, full))
     finally:
         td.destroy_process_group()
 
 
+_REF = {}
+
+
 @pytest.mark.timeout(600)
-def test_two_ranks_reproduce_the_single_rank_run_bit_for_bit():
+@pytest.mark.parametrize("world,exchange", [(2, "host"), (3, "host"), (2, "rccl")])
+def test_ranks_reproduce_the_single_rank_run_bit_for_bit(world, exchange):
     import torch.multiprocessing as mp
     from graal_amd import dist as gdist
-    ref_mut, ref_scores, ref_soa, ref_full = _run(gdist.Group(0, 1))
+    if "ref" not in _REF:
+        _REF["ref"] = _run(gdist.Group(0, 1))
+    ref_mut, ref_scores, ref_soa, ref_full = _REF["ref"]
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=500) for _ in range(2)), key=lambda r: r[0])
+    res = sorted((q.get(timeout=500) for _ in range(world)), key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
