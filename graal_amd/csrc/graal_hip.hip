@@ -219,7 +219,10 @@ __global__ void k_mates(int n, const int* __restrict__ perm, const int* __restri
 
 // out: [0] #heads (pos==0) [1] sum l_cont [2] #(start_bp==0) [3] sum l_cont_bp over start_bp==0 [4] max l_cont
 //      [5] min l_cont [6] #(rep != 0 or activ != 1 or id_d != f)  [7] max label  [14] #(circ == 1)
-__global__ __launch_bounds__(256) void k_stats(SoaPtr s, int n, long long* __restrict__ out)
+// With `host` the LAST block (ticket) also does k_stats_fin's job -- publish to pinned host memory, re-arm the accumulators
+// -- so that the host has the statistics while the kernels queued behind this one (the relabel) still run.
+__global__ __launch_bounds__(256) void k_stats(SoaPtr s, int n, long long* __restrict__ out, volatile long long* host = nullptr,
+                                               long long seq = 0, int reset_stale = 0)
 {
     long long v[9] = {0, 0, 0, 0, 0, 0x7fffffff, 0, -1, 0}; // heads, sum l_cont, #start0, sum lbp, max, min, bad, max label, #circ
     for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < n; f += gridDim.x * blockDim.x) {
@@ -257,6 +260,25 @@ __global__ __launch_bounds__(256) void k_stats(SoaPtr s, int n, long long* __res
         else if (i == 5) atomicMin((long long*)&out[slot], x);
         else atomicAdd((unsigned long long*)&out[slot], (unsigned long long)x);
     }
+    if (host == nullptr) return;
+    __shared__ int s_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd((unsigned long long*)&out[21], 1ull) == (unsigned long long)gridDim.x - 1ull;
+    __syncthreads();
+    if (!s_last) return;
+    const int t = threadIdx.x;
+    // (device-scope atomic reads: the other blocks' atomics were performed at the memory side, a plain load could hit a
+    // stale line of this XCD's L2)
+    if (t < 16) host[1 + t] = (long long)atomicAdd((unsigned long long*)&out[t], 0ull);
+    __syncthreads();
+    if (t < 8) out[t] = (t == 5) ? 0x7fffffffll : (t == 7 ? -1ll : 0ll);
+    if (t == 13 && reset_stale) out[13] = 0;
+    if (t == 14) out[14] = 0;
+    if (t == 21) out[21] = 0;
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) { host[0] = seq; __threadfence_system(); }
 }
 
 // last kernel of graal_begin_step / graal_layout_stats: publishes the 16 statistics words to pinned host memory (followed by
@@ -273,6 +295,59 @@ __global__ void k_stats_fin(long long* __restrict__ sc, volatile long long* host
     __threadfence_system();
     __syncthreads();
     if (t == 0) { host[0] = seq; __threadfence_system(); }
+}
+
+// Genome distance of dist_inter_genome (cuda_lib_gl.py:475-541) in HALF units: the reference subtracts, per fragment, terms
+// that are multiples of 0.5 from 3 * (fragments counted); this kernel returns twice the sum of those terms (an integer, so
+// the host's float64 result is exactly the reference loop's).  ref[f] = (initial prev, initial next, initial ori,
+// bit 0 orientable | bit 1 counted).  Like the reference, bin ids (id_d) index the per-fragment arrays.
+__global__ __launch_bounds__(256) void k_dist(SoaPtr s, int n, const int4* __restrict__ ref, unsigned long long* __restrict__ acc,
+                                              volatile long long* host, long long seq)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    int h = 0;
+    if (f < n) {
+        const int4 r = ref[f];
+        if (r.w & 2) {
+            const int* __restrict__ id_d = s.p[F_IDD];
+            const int* __restrict__ ori = s.p[F_ORI];
+            const int pv = s.p[F_PREV][f], nx = s.p[F_NEXT][f];
+            const int prev_t1 = pv != -1 ? id_d[pv] : -1, next_t1 = nx != -1 ? id_d[nx] : -1;
+            const int p0 = r.x, n0 = r.y;
+            if ((prev_t1 == p0 && next_t1 == n0) || (prev_t1 == n0 && next_t1 == p0)) h += 2;
+            if (r.w & 1) {
+                const bool flipped = r.z != ori[f];
+                const int p1 = flipped ? next_t1 : prev_t1, n1 = flipped ? prev_t1 : next_t1, swap = flipped ? -1 : 1;
+                for (int side = 0; side < 2; side++) {
+                    const int t0 = side ? n0 : p0, t1 = side ? n1 : p1;
+                    if (t0 != t1) continue;
+                    if (t0 == -1) { h += 2; continue; }
+                    const int idx = min(max(t1, 0), n - 1);
+                    if ((ref[idx].w & 1) == 0) { h += 2; continue; }
+                    h += 1 + (ref[min(max(t0, 0), n - 1)].z == swap * ori[idx] ? 1 : 0);
+                }
+            } else {
+                h += (prev_t1 == p0 || prev_t1 == n0) ? 2 : 0;
+                h += (next_t1 == n0 || next_t1 == p0) ? 2 : 0;
+            }
+        }
+    }
+    __shared__ int s_h[4];
+    const long long w = wave_sum_ll((long long)h);
+    if ((threadIdx.x & 63) == 0) s_h[threadIdx.x >> 6] = (int)w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&acc[0], (unsigned long long)(s_h[0] + s_h[1] + s_h[2] + s_h[3]));
+        __threadfence();
+        if (atomicAdd(&acc[1], 1ull) == (unsigned long long)gridDim.x - 1ull) { // last block: publish to pinned host memory
+            __threadfence();
+            host[1] = (long long)atomicExch(&acc[0], 0ull);
+            acc[1] = 0;
+            __threadfence_system();
+            host[0] = seq;
+            __threadfence_system();
+        }
+    }
 }
 
 // relabel: sort key of every contig head
@@ -1733,6 +1808,8 @@ struct Ctx {
     hipStream_t stream = nullptr;
     hipStream_t aux = nullptr;    // k_tm runs here, concurrently with k_scan on the main stream
     hipEvent_t ev_fin = nullptr;  // end of the last asynchronous evaluation (orders the next k_tm after it)
+    hipEvent_t ev_relabel = nullptr; // end of the relabel kernels graal_begin_step left running (orders the next k_tm, on aux)
+    bool relabel_pending = false;
     bool fin_pending = false;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> ring; // pairs of events around k_scan, one pair per call (graal_scan_times)
@@ -1811,6 +1888,10 @@ struct Ctx {
     size_t x_bytes = 0;
     int x_rank = 0, x_world = 1;
     long long stats_seq = 0;
+    int4* d_dref = nullptr;       // genome-distance reference (graal_upload_distance_ref)
+    unsigned long long* d_dist = nullptr; // [0] sum, [1] ticket
+    long long* h_dist = nullptr;  // pinned host: [0] sequence number, [1] half units
+    long long dist_seq = 0;
     long long seq = 0;
     long long* d_scalars = nullptr; // [0..7] stats, [8..9] full q, [10..12] step counters, [13] stale (int), [14] #circ,
                                     // [15] ticket, [16] error, [18..20] counters of the last finished step
@@ -1971,11 +2052,8 @@ int launch_fin(Ctx* h, int K, int rank, int world, long long* d_q_out, bool publ
 } // namespace
 
 // statistics of the layout (k_stats ran earlier on the stream): publish + wait; res[0..15] on return
-static int fetch_stats(Ctx* h, long long res[16], bool reset_stale)
+static int wait_stats(Ctx* h, long long res[16])
 {
-    h->stats_seq += 1;
-    k_stats_fin<<<1, 64, 0, h->stream>>>(h->d_scalars, h->h_stats, h->stats_seq, reset_stale ? 1 : 0);
-    CK(hipGetLastError());
     volatile long long* p = h->h_stats;
     bool seen = false;
     for (long long spin = 0; spin < 400000000ll; spin++) {
@@ -1985,11 +2063,19 @@ static int fetch_stats(Ctx* h, long long res[16], bool reset_stale)
     }
     if (!seen) {
         CK(hipStreamSynchronize(h->stream));
-        if (p[0] != h->stats_seq) return fail(h, GRAAL_E_HIP, "k_stats_fin did not publish the layout statistics");
+        if (p[0] != h->stats_seq) return fail(h, GRAAL_E_HIP, "the layout statistics were not published");
     }
     __sync_synchronize();
     for (int i = 0; i < 16; i++) res[i] = p[1 + i];
     return GRAAL_OK;
+}
+
+static int fetch_stats(Ctx* h, long long res[16], bool reset_stale)
+{
+    h->stats_seq += 1;
+    k_stats_fin<<<1, 64, 0, h->stream>>>(h->d_scalars, h->h_stats, h->stats_seq, reset_stale ? 1 : 0);
+    CK(hipGetLastError());
+    return wait_stats(h, res);
 }
 
 struct graal_ctx : Ctx {};
@@ -2023,6 +2109,7 @@ int graal_create(int device, graal_ctx** out)
         CK(hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, greatest));
     }
     CK(hipEventCreateWithFlags(&h->ev_fin, hipEventDisableTiming));
+    CK(hipEventCreateWithFlags(&h->ev_relabel, hipEventDisableTiming));
     for (auto& ev : h->ev) CK(hipEventCreate(&ev));
     h->ring.resize(2 * 1024, nullptr);
     for (auto& ev : h->ring) CK(hipEventCreate(&ev));
@@ -2047,6 +2134,10 @@ int graal_create(int device, graal_ctx** out)
     CK(hipHostMalloc((void**)&h->h_res, (1 + MAXK * N_OPS) * sizeof(long long), hipHostMallocDefault));
     memset(h->h_res, 0, (1 + MAXK * N_OPS) * sizeof(long long));
     h->res_host = h->res_dev = h->h_res;
+    CK(hipHostMalloc((void**)&h->h_dist, 2 * sizeof(long long), hipHostMallocDefault));
+    memset(h->h_dist, 0, 2 * sizeof(long long));
+    CK(hipMalloc(&h->d_dist, 2 * sizeof(unsigned long long)));
+    CK(hipMemset(h->d_dist, 0, 2 * sizeof(unsigned long long)));
     CK(hipHostMalloc((void**)&h->h_stats, 17 * sizeof(long long), hipHostMallocDefault));
     memset(h->h_stats, 0, 17 * sizeof(long long));
     {
@@ -2066,14 +2157,16 @@ void graal_destroy(graal_ctx* h)
         void* ptrs[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->stat, h->sub2bin, h->row, h->col, h->cnt, h->queue, h->d_sub_ids, h->d_acc, h->tm_done, h->d_sync, h->d_flags, h->stat_frag, h->d_dup_bins, h->d_dup_index,
                         h->d_dispatcher, h->d_collector, h->d_sub_ids_all, h->d_rep_obs,
                         h->keys, h->keys_sorted, h->o2n, h->len_of2[0], h->len_of2[1], h->contig_off2[0], h->contig_off2[1], h->perm, h->cbase, h->link, h->mates, h->cub_tmp, h->tabs, h->step_hdr, h->d_args, h->d_chg, h->d_plan,
-                        h->d_scalars, h->d_qout};
+                        h->d_scalars, h->d_qout, h->d_dref, h->d_dist};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (h->x_host) (void)hipHostUnregister(h->x_host);
         if (h->h_res) (void)hipHostFree(h->h_res);
         if (h->h_stats) (void)hipHostFree(h->h_stats);
+        if (h->h_dist) (void)hipHostFree(h->h_dist);
         for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
         for (auto& ev : h->ring) if (ev) (void)hipEventDestroy(ev);
         if (h->ev_fin) (void)hipEventDestroy(h->ev_fin);
+        if (h->ev_relabel) (void)hipEventDestroy(h->ev_relabel);
         if (h->aux) (void)hipStreamDestroy(h->aux);
         (void)hipStreamDestroy(h->stream);
     }
@@ -2084,6 +2177,7 @@ const char* graal_last_error(const graal_ctx* h) { return h ? h->err.c_str() : "
 
 int graal_set_params(graal_ctx* h, const float* p)
 {
+    if (h && h->stream) (void)hipStreamSynchronize(h->stream); // (graal_begin_step may have left its relabel kernels running)
     if (!h || !p) return GRAAL_E_ARG;
     memcpy(&h->par, p, sizeof(Par));
     if (!(h->par.v_inter > 0.0f)) return fail(h, GRAAL_E_ARG, "v_inter must be > 0 (the sparse form prices every pixel at >= v_inter)");
@@ -2097,6 +2191,7 @@ int graal_set_params(graal_ctx* h, const float* p)
 int graal_upload_subfrags(graal_ctx* h, const int32_t* sub_id, const float* sub_len, const int32_t* sub_accu, int32_t n_bins,
                           int32_t n_sub_total, float nfpb)
 {
+    if (h && h->stream) (void)hipStreamSynchronize(h->stream); // (graal_begin_step may have left its relabel kernels running)
     if (!h || !sub_id || !sub_len || !sub_accu || n_bins <= 0 || n_sub_total < n_bins || !(nfpb > 0)) return GRAAL_E_ARG;
     CK(hipSetDevice(h->device));
     std::vector<Stat> st(n_bins);
@@ -2162,6 +2257,7 @@ static RepArgs rep_args(const Ctx* h)
 int graal_upload_repeats(graal_ctx* h, const int32_t* dup_bins, int32_t n_dup, const int32_t* dispatcher, const int32_t* collector,
                          int32_t n_collector, const float* obs_rows)
 {
+    if (h && h->stream) (void)hipStreamSynchronize(h->stream); // (graal_begin_step may have left its relabel kernels running)
     if (!h || n_dup < 0 || (n_dup > 0 && (!dup_bins || !dispatcher || !collector || !obs_rows))) return GRAAL_E_ARG;
     if (!h->have_sub) return fail(h, GRAAL_E_STATE, "upload_subfrags first");
     CK(hipSetDevice(h->device));
@@ -2201,6 +2297,7 @@ int graal_upload_repeats(graal_ctx* h, const int32_t* dup_bins, int32_t n_dup, c
 // exact up to 2^24; the blacklist fill (cuda_lib_gl.py:161-172) makes them non-integer.
 static int upload_contacts_impl(graal_ctx* h, const int32_t* row, const int32_t* col, const float* count, int64_t nnz)
 {
+    if (h && h->stream) (void)hipStreamSynchronize(h->stream); // (graal_begin_step may have left its relabel kernels running)
     if (!h->have_sub) return fail(h, GRAAL_E_STATE, "upload_subfrags first");
     if (nnz >= (1ll << 32)) return fail(h, GRAAL_E_ARG, "at most 2^32 - 1 contacts per shard");
     CK(hipSetDevice(h->device));
@@ -2250,6 +2347,7 @@ int graal_upload_contacts_f32(graal_ctx* h, const int32_t* row, const int32_t* c
 
 int graal_upload_frags(graal_ctx* h, const int32_t* const soa[GRAAL_N_FIELDS], int32_t n)
 {
+    if (h && h->stream) (void)hipStreamSynchronize(h->stream); // (graal_begin_step may have left its relabel kernels running)
     if (!h || !soa || n <= 0) return GRAAL_E_ARG;
     if (!h->have_sub) return fail(h, GRAAL_E_STATE, "upload_subfrags first");
     if (n != h->n_bins && !h->has_rep) return fail(h, GRAAL_E_STATE, "n differs from the number of bins: upload the repeats (graal_upload_repeats) first");
@@ -2348,8 +2446,15 @@ int graal_begin_step(graal_ctx* h, int64_t stats[8], int32_t* max_id)
     const int n = h->n, bs = 256, nb = blocks_for(n, bs);
     const int cur = h->cur;
     SoaPtr s = h->soa[cur];
-    k_stats<<<std::min(nb, 64), bs, 0, h->stream>>>(s, n, h->d_scalars);
     static const bool no_incr = getenv("GRAAL_NO_INCREMENTAL_RELABEL") != nullptr;
+    // the statistics do not depend on the relabel.  When the relabel does not need them on the device (the counting paths),
+    // the statistics kernel publishes them itself: the host reads them -- and goes on to draw the step's proposal -- while
+    // the relabel kernels behind it still run (everything the host launches next is ordered after them by the stream)
+    const bool early = h->ranks_valid && (h->pending_commits == 0 || (h->pending_commits == 1 && h->incr_ok && !no_incr));
+    if (early) {
+        h->stats_seq += 1;
+        k_stats<<<std::min(nb, 64), bs, 0, h->stream>>>(s, n, h->d_scalars, h->h_stats, h->stats_seq, 1);
+    } else k_stats<<<std::min(nb, 64), bs, 0, h->stream>>>(s, n, h->d_scalars);
     if (h->ranks_valid && h->pending_commits == 0) {
         // nothing changed since the last call: labels are ranks already
     } else if (h->ranks_valid && h->pending_commits == 1 && h->incr_ok && !no_incr) {
@@ -2359,6 +2464,9 @@ int graal_begin_step(graal_ctx* h, int64_t stats[8], int32_t* max_id)
                                                                  h->len_of2[cur], h->contig_off2[cur], h->perm, h->cbase, h->geo, h->link);
         k_mates<<<nb, bs, 0, h->stream>>>(n, h->perm, h->cbase, h->link, h->mates);
         CK(hipGetLastError());
+        // the host does not wait for these three: whatever runs on the OTHER stream next (k_tm) must
+        CK(hipEventRecord(h->ev_relabel, h->stream));
+        h->relabel_pending = true;
     } else {
         k_relabel_keys<<<nb, bs, 0, h->stream>>>(s, n, h->keys);
         CK(hipGetLastError());
@@ -2377,7 +2485,7 @@ int graal_begin_step(graal_ctx* h, int64_t stats[8], int32_t* max_id)
         CK(hipGetLastError());
     }
     long long res[16];
-    { int rc = fetch_stats(h, res, true); if (rc) return rc; }
+    { int rc = early ? wait_stats(h, res) : fetch_stats(h, res, true); if (rc) return rc; }
     const int nc = (int)res[0];
     // (a corrupt layout could have made the kernels above index out of range; the uploads validate labels and the
     // mutations keep them in [0, n_contigs + 2], so this is a consistency check, not a guard)
@@ -2448,6 +2556,11 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     // have finished with the tables first (the synchronous path has waited for its results already).  In the synchronous
     // single-rank path (h->publish) its last block also finishes the step when the work is small.
     if (h->fin_pending) { CK(hipStreamWaitEvent(h->aux, h->ev_fin, 0)); h->fin_pending = false; }
+    if (h->relabel_pending) { // graal_begin_step left its relabel kernels running on the engine's stream
+        CK(hipStreamWaitEvent(h->aux, h->ev_relabel, 0));
+        if (st != h->stream) CK(hipStreamWaitEvent(st, h->ev_relabel, 0));
+        h->relabel_pending = false;
+    }
     TmArgs ta;
     ta.geo = h->geo; ta.link = h->link; ta.cbase = h->cbase; ta.mates = h->mates; ta.tabs = h->tabs; ta.step_hdr = h->step_hdr;
     static const bool no_finisher = getenv("GRAAL_NO_FINISHER") != nullptr; // always finish with k_fin (diagnostics)
@@ -2599,6 +2712,44 @@ int graal_eval_candidates_x(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     const int rc = eval_sync(h, fA, fB, K, max_id, h->x_rank, h->x_world, q);
     if (rc) return rc;
     for (int i = 0; i < K * N_OPS; i++) q_sum[i] = q[i];
+    return GRAAL_OK;
+}
+
+int graal_upload_distance_ref(graal_ctx* h, const int32_t* init_prev, const int32_t* init_next, const int32_t* init_ori,
+                              const int32_t* orientable, const uint8_t* counted, int32_t n)
+{
+    if (!h || !init_prev || !init_next || !init_ori || !orientable || !counted) return GRAAL_E_ARG;
+    if (!h->have_frags || n != h->n) return fail(h, GRAAL_E_STATE, "upload the fragments first (same n)");
+    CK(hipSetDevice(h->device));
+    std::vector<int4> ref((size_t)n);
+    for (int i = 0; i < n; i++) ref[(size_t)i] = make_int4(init_prev[i], init_next[i], init_ori[i], (orientable[i] != 0 ? 1 : 0) | (counted[i] ? 2 : 0));
+    if (h->d_dref) { CK(hipFree(h->d_dref)); h->d_dref = nullptr; }
+    CK(hipMalloc(&h->d_dref, (size_t)n * sizeof(int4)));
+    CK(hipMemcpy(h->d_dref, ref.data(), (size_t)n * sizeof(int4), hipMemcpyHostToDevice));
+    return GRAAL_OK;
+}
+
+int graal_genome_distance(graal_ctx* h, int64_t* half_units)
+{
+    if (!h || !half_units) return GRAAL_E_ARG;
+    if (!h->d_dref) return fail(h, GRAAL_E_STATE, "graal_upload_distance_ref first");
+    CK(hipSetDevice(h->device));
+    h->dist_seq += 1;
+    k_dist<<<blocks_for(h->n, 256), 256, 0, h->stream>>>(h->soa[h->cur], h->n, h->d_dref, h->d_dist, h->h_dist, h->dist_seq);
+    CK(hipGetLastError());
+    volatile long long* p = h->h_dist;
+    bool seen = false;
+    for (long long spin = 0; spin < 400000000ll; spin++) {
+        if (p[0] == h->dist_seq) { seen = true; break; }
+        if ((spin & 0xfffff) == 0xfffff && hipStreamQuery(h->stream) != hipErrorNotReady) { seen = (p[0] == h->dist_seq); break; }
+        __builtin_ia32_pause();
+    }
+    if (!seen) {
+        CK(hipStreamSynchronize(h->stream));
+        if (p[0] != h->dist_seq) return fail(h, GRAAL_E_HIP, "k_dist did not publish the genome distance");
+    }
+    __sync_synchronize();
+    *half_units = p[1];
     return GRAAL_OK;
 }
 

@@ -24,7 +24,7 @@ _f64p = ctypes.POINTER(ctypes.c_double)
 SYMBOLS = ("graal_abi_version", "graal_create", "graal_destroy", "graal_last_error", "graal_set_params",
            "graal_upload_subfrags", "graal_upload_repeats", "graal_upload_contacts", "graal_upload_contacts_f32", "graal_upload_frags", "graal_download_frags",
            "graal_relabel_contigs", "graal_begin_step", "graal_layout_stats", "graal_eval_full_q", "graal_eval_candidates_q",
-           "graal_eval_candidates", "graal_exchange_bytes", "graal_attach_exchange", "graal_eval_candidates_x", "graal_apply_move", "graal_set_finisher", "graal_set_timing", "graal_last_timing", "graal_scan_times", "graal_time_scan", "graal_last_counters")
+           "graal_eval_candidates", "graal_exchange_bytes", "graal_attach_exchange", "graal_eval_candidates_x", "graal_upload_distance_ref", "graal_genome_distance", "graal_apply_move", "graal_set_finisher", "graal_set_timing", "graal_last_timing", "graal_scan_times", "graal_time_scan", "graal_last_counters")
 
 _lib = None
 
@@ -66,6 +66,9 @@ def load():
         L.graal_attach_exchange.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
                                             ctypes.c_int64, _i64p]
         L.graal_eval_candidates_x.argtypes = [ctypes.c_void_p, ctypes.c_int32, _i32p, ctypes.c_int32, ctypes.c_int32, _i64p]
+        L.graal_upload_distance_ref.argtypes = [ctypes.c_void_p, _i32p, _i32p, _i32p, _i32p, ctypes.POINTER(ctypes.c_uint8),
+                                                ctypes.c_int32]
+        L.graal_genome_distance.argtypes = [ctypes.c_void_p, _i64p]
         L.graal_apply_move.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _i32p]
         L.graal_last_timing.argtypes = [ctypes.c_void_p, _f32p]
         L.graal_last_counters.argtypes = [ctypes.c_void_p, _i64p]
@@ -226,6 +229,20 @@ class Engine:
                                                    buf.ctypes.data_as(_f64p)), "graal_eval_candidates")
             out[k0:k0 + len(part)] = buf.reshape(len(part), N_OPS)
         return out
+
+    # -- genome distance ------------------------------------------------------------------------
+    def upload_distance_ref(self, init_prev, init_next, init_ori, orientable, counted):
+        a = [_c(x, np.int32) for x in (init_prev, init_next, init_ori, orientable)]
+        c = _c(counted, np.uint8)
+        assert all(len(x) == len(c) for x in a)
+        self._ck(self._L.graal_upload_distance_ref(self._h, *[x.ctypes.data_as(_i32p) for x in a],
+                                                   c.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), len(c)),
+                 "graal_upload_distance_ref")
+
+    def genome_distance_half_units(self):
+        v = ctypes.c_int64(0)
+        self._ck(self._L.graal_genome_distance(self._h, ctypes.byref(v)), "graal_genome_distance")
+        return int(v.value)
 
     # -- node-local exchange through pinned host memory (one process per GPU) ------------------
     def exchange_bytes(self, world):

@@ -20,6 +20,8 @@ contacts with the float32 fill value.  Repeated fragments (``allow_repeats``): t
 the contact list and go to the engine as dense rows (``split_repeat_observations``); every pixel of a repeated bin is
 priced over the active copies like ``kernels3.cu:2915-2930``.
 """
+import bisect
+
 import numpy as np
 
 from . import dist as gdist
@@ -159,29 +161,73 @@ def neighbour_distributions(bin_row, bin_col, bin_val, n_frags, n_neighbors=10, 
 def select_move(score, n_tmp_struct, rng, F_t=1.0):
     """Score post-processing and sampling of ``step_max_likelihood`` (``cuda_lib_gl.py:1898-1947``): duplicate
     eject / flip entries of neighbours >= 1 are zeroed, scores are shifted to ``max - 30`` and the move is drawn
-    with probability LINEAR in that shifted score.  Returns (sample_out, or_score[sample_out])."""
+    with probability LINEAR in that shifted score.  Returns (sample_out, or_score[sample_out]).
+
+    Same float64 operations in the same order as the reference's lines (tests/test_host_logic.py holds the literal
+    restatement, results AND the generator's state afterwards are compared), with fewer temporaries; the final
+    ``choice(ids, 1, p=sub_score)`` is spelled out (``legacy_choice_one``)."""
     score = np.asarray(score, dtype=np.float64)
-    scores_2_remove = []
-    scores_2_remove.extend(range(n_tmp_struct, len(score), n_tmp_struct))      # remove extra pop
-    scores_2_remove.extend(range(n_tmp_struct + 1, len(score), n_tmp_struct))  # remove extra flip
-    id_max = score.argmax()
-    or_score = np.copy(score)
+    id_max = int(score.argmax())
     filtered_score = score - score.min()
-    filtered_score[scores_2_remove] = 0
-    max_score = filtered_score.max()
+    filtered_score[n_tmp_struct::n_tmp_struct] = 0          # remove extra pop
+    filtered_score[n_tmp_struct + 1::n_tmp_struct] = 0      # remove extra flip
     thresh_overflow = 30
-    filtered_score = filtered_score - (max_score - thresh_overflow)
+    filtered_score -= filtered_score.max() - thresh_overflow
     filtered_score[filtered_score < 0] = 0
-    id_ok_4_sampling = np.ix_(filtered_score > 0)
-    sub_score = filtered_score[id_ok_4_sampling]
-    sub_score = sub_score / sub_score.sum()
-    sub_score[sub_score > 0] = np.power(sub_score[sub_score > 0], 1. / F_t)
-    sub_score = sub_score / sub_score.sum()
-    if len(id_ok_4_sampling[0]) == 1 or len(id_ok_4_sampling[0]) == 0:
+    ids = np.flatnonzero(filtered_score > 0)
+    if len(ids) <= 1:                                       # (also when a NaN score leaves nothing to sample from)
         sample_out = id_max
     else:
-        sample_out = rng.choice(id_ok_4_sampling[0], 1, p=sub_score)[0]
-    return int(sample_out), float(or_score[sample_out])
+        sub_score = filtered_score[ids]
+        sub_score /= sub_score.sum()
+        pos = sub_score > 0
+        if pos.all():
+            sub_score = np.power(sub_score, 1. / F_t)
+        else:
+            sub_score[pos] = np.power(sub_score[pos], 1. / F_t)
+        sub_score /= sub_score.sum()
+        sample_out = int(ids[legacy_choice_one(rng, sub_score)])
+    return int(sample_out), float(score[sample_out])
+
+
+def legacy_choice_one(rng, p):
+    """Index drawn by ``RandomState.choice(len(p), 1, p=p)`` (replace=True): one uniform, inverse CDF
+    (``cdf = p.cumsum(); cdf /= cdf[-1]; cdf.searchsorted(u, side='right')``) -- numpy's legacy algorithm, whose
+    stream numpy guarantees stable; without its argument validation (p here is a freshly normalised float64 vector;
+    anything else goes to numpy itself, so errors stay numpy's)."""
+    cdf = p.cumsum()
+    tot = cdf[-1]
+    if not (abs(tot - 1.0) < 1e-9):          # not normalised / NaN: let numpy judge (and raise)
+        return int(rng.choice(len(p), 1, p=p)[0])
+    cdf /= tot
+    return int(cdf.searchsorted(rng.random_sample(1), side='right')[0])
+
+
+def legacy_choice_without_replacement(rng, a, size, p):
+    """``RandomState.choice(a, size, replace=False, p=p)`` for a handful of entries (the neighbour proposal draws <= 10 of
+    10): numpy's legacy algorithm -- draw ``size - found`` uniforms, inverse CDF of p with the found entries zeroed, keep
+    the first occurrences, repeat -- on Python floats (the float32 -> float64 conversion, the running sum and the division
+    are the same IEEE operations as numpy's ``cumsum`` / ``/=``).  Anything unusual (size 0, p not summing to 1) is left
+    to numpy, so its errors and corner cases stay its own."""
+    pl = [float(v) for v in p]
+    if size < 1 or size > len(pl) or not (abs(sum(pl) - 1.0) < 1e-4) or min(pl) < 0.0 or sum(1 for v in pl if v > 0) < size:
+        return rng.choice(a, size, p=p, replace=False)
+    found = []
+    while len(found) < size:
+        x = rng.random_sample(size - len(found)).tolist()
+        for f in found:
+            pl[f] = 0.0
+        acc, cdf = 0.0, []
+        for v in pl:
+            acc += v
+            cdf.append(acc)
+        tot = cdf[-1]
+        cdf = [c / tot for c in cdf]
+        for u in x:
+            i = bisect.bisect_right(cdf, u)
+            if i not in found:
+                found.append(i)
+    return a[found]
 
 
 def dist_inter_genome(prev, nxt, ori, id_d, init_prev, init_next, init_ori, orientable, counted, n_frags_4_dist):
@@ -318,6 +364,8 @@ class sampler(object):
         self._single_sub = bool(np.all(self.np_sub_frags_id[:, 3] == 1))
         self._n_circ_prev = int((soa["circ"] == 1).sum())
         self._d_q = None
+        self._dist_ref_uploaded = False
+        self._dist_counted_mask = None
         self.exchange = self._setup_exchange(exchange)
         # MCMC steps between full re-evaluations of the carried-over likelihood.  With repeats every step: the reference's
         # candidate pixel ranges miss some pixels an activity swap changes (kernels3.cu:3368-3373), so its per-step total
@@ -554,13 +602,30 @@ class sampler(object):
         self._dup_set = dup
 
     def dist_inter_genome(self, tmp_gpu_vect_frags=None):
-        g = self.gpu_vect_frags if tmp_gpu_vect_frags is None else tmp_gpu_vect_frags
+        """``cuda_lib_gl.py:475-541``.  The current layout is evaluated on the device (``k_dist``: the per-fragment terms
+        are multiples of 0.5, summed there as integers, so the float64 value is the reference loop's exactly); a layout
+        passed explicitly goes through the host function of the same name."""
+        counted = self._dist_counted()
+        if tmp_gpu_vect_frags is None:
+            if not self._dist_ref_uploaded:
+                self.engine.upload_distance_ref(self.np_init_prev, self.np_init_next, self.np_init_ori,
+                                                self.np_init_orientable, counted)
+                self._dist_ref_uploaded = True
+            n = len(self.np_init_prev)
+            norm_distance = 3.0 * (n - self.n_frags_4_dist)
+            return (norm_distance - 0.5 * self.engine.genome_distance_half_units()) / norm_distance
+        g = tmp_gpu_vect_frags
         g.copy_from_gpu()
-        counted = ~np.asarray(self.is_repeat, dtype=bool)       # cuda_lib_gl.py:485
-        if len(self.id_frags_blacklisted):
-            counted[np.asarray(self.id_frags_blacklisted, dtype=np.int64)] = False
         return dist_inter_genome(g.prev, g.next, g.ori, g.id_d, self.np_init_prev, self.np_init_next, self.np_init_ori,
                                  self.np_init_orientable, counted, self.n_frags_4_dist)
+
+    def _dist_counted(self):
+        if self._dist_counted_mask is None:
+            counted = ~np.asarray(self.is_repeat, dtype=bool)       # cuda_lib_gl.py:485
+            if len(self.id_frags_blacklisted):
+                counted[np.asarray(self.id_frags_blacklisted, dtype=np.int64)] = False
+            self._dist_counted_mask = counted
+        return self._dist_counted_mask
 
     def temperature(self, t, n_step):
         return 1.0  # cuda_lib_gl.py:2602
@@ -577,7 +642,7 @@ class sampler(object):
         delta = min(self.n_neighbors, delta0)
         distri = self.distri_frags["pk"][ori_id]
         n_max_candidates = min(delta, np.nonzero(distri != 0)[0].shape[0])
-        init_id = self.rng.choice(self.distri_frags["xk"][ori_id], n_max_candidates, p=distri, replace=False)
+        init_id = legacy_choice_without_replacement(self.rng, self.distri_frags["xk"][ori_id], n_max_candidates, distri)
         out = []
         if int(ori_id) in self._dup_set:      # the other copies of a repeated fragment are candidates too (:2314-2318)
             d = self.frag_dispatcher[ori_id]

@@ -141,6 +141,15 @@ int graal_set_finisher(graal_ctx* h, int32_t enabled);
  * commit (the count is then reported by the next graal_begin_step).  The geometry index is stale until then. */
 int graal_apply_move(graal_ctx* h, int32_t fA, int32_t fB, int32_t op, int32_t max_id, int32_t* n_stale);
 
+/* Genome distance to the initial genome, dist_inter_genome (cuda_lib_gl.py:475-541: a Python loop over all fragments after
+ * a full device->host copy, every step).  graal_upload_distance_ref takes the initial prev / next / ori (np_init_prev,
+ * np_init_next, np_init_ori), the orientable flags and which fragments count (not repeated, not blacklisted), n entries each,
+ * after graal_upload_frags; graal_genome_distance evaluates the CURRENT layout on the device and returns twice the sum of
+ * the terms the reference subtracts (an integer): distance = (3 * n_counted - half_units / 2) / (3 * n_counted). */
+int graal_upload_distance_ref(graal_ctx* h, const int32_t* init_prev, const int32_t* init_next, const int32_t* init_ori,
+                              const int32_t* orientable, const uint8_t* counted, int32_t n);
+int graal_genome_distance(graal_ctx* h, int64_t* half_units);
+
 /* HIP event pairs around the streaming kernel of graal_eval_candidates*: enabled = n > 0 records a pair on every n-th
  * call (default 8; each pair costs a few microseconds of command-processor gaps on the step's critical path), 0 = off */
 int graal_set_timing(graal_ctx* h, int32_t enabled);

@@ -66,12 +66,46 @@ def test_select_move_matches_literal_reference_logic():
         if trial % 7 == 0:
             score[:] = score[0]                      # all equal -> nothing is > 0 after the shift -> argmax
         seed = int(rng.randint(1 << 30))
-        got = S.select_move(score, 13, np.random.RandomState(seed))
+        if trial % 11 == 3:
+            score[rng.randint(len(score))] += 500.0  # one candidate far ahead: everything else is cut off -> argmax
+        if trial % 13 == 5:
+            score[:] = np.round(score)               # ties
+        seed = int(rng.randint(1 << 30))
+        mine = np.random.RandomState(seed)
+        got = S.select_move(score, 13, mine)
         # literal copy of cuda_lib_gl.py:1898-1947 as restated in the oracle
         ora.rng = np.random.RandomState(seed)
         ora.score = np.copy(score)
         want = _oracle_select(ora)
         assert got[0] == want[0] and got[1] == want[1]
+        # ... and the generator is left in the same state (the next draw of the run depends on it)
+        assert mine.random_sample() == ora.rng.random_sample()
+
+
+def test_neighbour_draw_is_numpys_legacy_choice_without_replacement():
+    """legacy_choice_without_replacement == RandomState.choice(a, size, replace=False, p=p): values, order and stream."""
+    rng = np.random.RandomState(11)
+    for trial in range(2000):
+        n = int(rng.randint(2, 11))
+        p = rng.random_sample(n) ** rng.choice([1.0, 3.0, 8.0])
+        if trial % 3 == 0:
+            p[rng.random_sample(n) < 0.4] = 0.0              # padded rows: zero entries
+        if not p.any():
+            p[rng.randint(n)] = 1.0
+        p = (p / p.sum()).astype(np.float32) if trial % 2 else p / p.sum()   # pk rows are float32
+        a = rng.permutation(200)[:n].astype(np.int64)
+        size = int(min(rng.randint(1, 11), np.count_nonzero(p)))
+        seed = int(rng.randint(1 << 30))
+        r1, r2 = np.random.RandomState(seed), np.random.RandomState(seed)
+        want = r1.choice(a, size, p=p, replace=False)
+        got = S.legacy_choice_without_replacement(r2, a, size, p)
+        assert np.array_equal(got, want) and got.dtype == want.dtype, trial
+        assert r1.random_sample() == r2.random_sample(), trial
+    # numpy's own errors stay numpy's
+    with pytest.raises(ValueError):
+        S.legacy_choice_without_replacement(np.random.RandomState(0), np.arange(4), 2, np.array([0.5, 0.2, 0.2, 0.2]))
+    with pytest.raises(ValueError):
+        S.legacy_choice_without_replacement(np.random.RandomState(0), np.arange(4), 3, np.array([0.5, 0.5, 0.0, 0.0]))
 
 
 def _oracle_select(ora):

@@ -199,3 +199,35 @@ def test_headless_run_from_a_dataset_folder(tmp_path):
     tr2 = run.main(["--dataset", base, "--size-pyramid", "3", "--level", "1", "--cycles", "3", "--neighbours", "3", "--seed", "5",
                     "--out", str(tmp_path / "out2")])
     assert np.array_equal(tr2.mutations(), tr.mutations())
+
+
+@pytest.mark.parametrize("n_sub,black", [(1, False), (3, False), (3, True)])
+def test_genome_distance_kernel_equals_the_host_loop(n_sub, black):
+    """k_dist (graal_genome_distance) against the vectorised host restatement of dist_inter_genome and the oracle's literal
+    loop (cuda_lib_gl.py:475-541) on random layouts: reversed fragments, circular contigs, singletons, blacklisted bins."""
+    from graal_amd import sampler as S
+    from tests import util
+    P = problem(n_sub, 77, 64, 900)
+    if black:
+        P["id_frags_blacklisted"] = [3, 17, 40]
+        P["mean_value_trans"] = 0.05
+    g = make_gpu_sampler(P, np.random.RandomState(1))
+    ora = O.OracleSampler(P, np.random.RandomState(1))
+    n = P["n_frags"]
+    rng = np.random.RandomState(8)
+    assert g.dist_inter_genome() == 0.0 == ora.dist_inter_genome(ora.gpu_vect_frags)   # the initial genome itself
+    for trial in range(12):
+        s = util.random_layout(rng, n, p_circ=0.3)
+        if trial % 3 == 0:      # near the initial genome: most neighbours still right, some orientations flipped
+            s = O.copy_state(ora.gpu_vect_frags)
+            flip = rng.random_sample(n) < 0.2
+            s["ori"][flip] *= -1
+        for k in O.FIELDS:
+            getattr(g.gpu_vect_frags, k)[:] = s[k]
+        g.gpu_vect_frags.copy_to_gpu()
+        got = g.dist_inter_genome()
+        host = S.dist_inter_genome(s["prev"], s["next"], s["ori"], s["id_d"], g.np_init_prev, g.np_init_next, g.np_init_ori,
+                                   g.np_init_orientable, g._dist_counted(), g.n_frags_4_dist)
+        assert got == host == ora.dist_inter_genome(s), trial
+        assert 0.0 <= got <= 1.0
+    g.free_gpu()
