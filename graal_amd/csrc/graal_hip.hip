@@ -204,9 +204,11 @@ __global__ void k_refresh_geo(SoaPtr s, Geo* __restrict__ geo, Link* __restrict_
 
 // mates rows (see N_MATES); runs after the position index is complete
 __global__ void k_mates(int n, const int* __restrict__ perm, const int* __restrict__ cbase, const Link* __restrict__ link,
-                        int* __restrict__ mates)
+                        int* __restrict__ mates, int* __restrict__ chg_words, int chg_n)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    // last kernel of every relabel: the record of the commit it consumed is cleared for the next commit (no memset launch)
+    if (f < chg_n) chg_words[f] = 0;
     if (f >= n) return;
     const int base = cbase[f], lc = link[f].l_cont;
     int m[N_MATES];
@@ -219,28 +221,31 @@ __global__ void k_mates(int n, const int* __restrict__ perm, const int* __restri
 
 // out: [0] #heads (pos==0) [1] sum l_cont [2] #(start_bp==0) [3] sum l_cont_bp over start_bp==0 [4] max l_cont
 //      [5] min l_cont [6] #(rep != 0 or activ != 1 or id_d != f)  [7] max label  [14] #(circ == 1)
-// With `host` the LAST block (ticket) also does k_stats_fin's job -- publish to pinned host memory, re-arm the accumulators
-// -- so that the host has the statistics while the kernels queued behind this one (the relabel) still run.
-__global__ __launch_bounds__(256) void k_stats(SoaPtr s, int n, long long* __restrict__ out, volatile long long* host = nullptr,
-                                               long long seq = 0, int reset_stale = 0)
+struct StatAcc { long long v[9]; }; // heads, sum l_cont, #start0, sum lbp, max, min, bad, max label, #circ
+__device__ __forceinline__ StatAcc stat_zero() { StatAcc a = {{0, 0, 0, 0, 0, 0x7fffffff, 0, -1, 0}}; return a; }
+__device__ __forceinline__ void stat_add(StatAcc& a, int f, int pos, int lc, int start_bp, int lbp, int rep, int activ, int id_d, int c, int circ)
 {
-    long long v[9] = {0, 0, 0, 0, 0, 0x7fffffff, 0, -1, 0}; // heads, sum l_cont, #start0, sum lbp, max, min, bad, max label, #circ
-    for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < n; f += gridDim.x * blockDim.x) {
-        const int lc = s.p[F_LCONT][f];
-        v[0] += s.p[F_POS][f] == 0;
-        v[1] += lc;
-        if (s.p[F_START][f] == 0) { v[2] += 1; v[3] += s.p[F_LCONTBP][f]; }
-        v[4] = lc > v[4] ? lc : v[4];
-        v[5] = lc < v[5] ? lc : v[5];
-        v[6] += (s.p[F_REP][f] != 0) || (s.p[F_ACTIV][f] != 1) || (s.p[F_IDD][f] != f);
-        const int c = s.p[F_IDC][f];
-        v[7] = c > v[7] ? c : v[7];
-        v[8] += s.p[F_CIRC][f] == 1;
-    }
+    a.v[0] += pos == 0;
+    a.v[1] += lc;
+    if (start_bp == 0) { a.v[2] += 1; a.v[3] += lbp; }
+    a.v[4] = lc > a.v[4] ? lc : a.v[4];
+    a.v[5] = lc < a.v[5] ? lc : a.v[5];
+    a.v[6] += (rep != 0) || (activ != 1) || (id_d != f);
+    a.v[7] = c > a.v[7] ? c : a.v[7];
+    a.v[8] += circ == 1;
+}
+
+// block reduction of the per-thread statistics (256 threads) + one atomic per statistic per block.  With `host` the LAST
+// block (ticket in out[21]) also does k_stats_fin's job -- publish the 16 words to pinned host memory followed by the
+// sequence number, re-arm the accumulators -- so that the host has the statistics while the kernels queued behind this one
+// still run.  Every thread of the block must call it.
+__device__ __forceinline__ void stat_reduce_publish(const StatAcc& a, long long* __restrict__ out, volatile long long* host, long long seq,
+                                                    int reset_stale)
+{
     __shared__ long long sh[4][9];
 #pragma unroll
     for (int i = 0; i < 9; i++) {
-        long long x = v[i];
+        long long x = a.v[i];
         for (int o = 32; o > 0; o >>= 1) {
             const long long y = __shfl_down(x, o, 64);
             x = (i == 4 || i == 7) ? (y > x ? y : x) : (i == 5 ? (y < x ? y : x) : x + y);
@@ -279,6 +284,16 @@ __global__ __launch_bounds__(256) void k_stats(SoaPtr s, int n, long long* __res
     __threadfence_system();
     __syncthreads();
     if (t == 0) { host[0] = seq; __threadfence_system(); }
+}
+
+__global__ __launch_bounds__(256) void k_stats(SoaPtr s, int n, long long* __restrict__ out, volatile long long* host = nullptr,
+                                               long long seq = 0, int reset_stale = 0)
+{
+    StatAcc a = stat_zero();
+    for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < n; f += gridDim.x * blockDim.x)
+        stat_add(a, f, s.p[F_POS][f], s.p[F_LCONT][f], s.p[F_START][f], s.p[F_LCONTBP][f], s.p[F_REP][f], s.p[F_ACTIV][f],
+                 s.p[F_IDD][f], s.p[F_IDC][f], s.p[F_CIRC][f]);
+    stat_reduce_publish(a, out, host, seq, reset_stale);
 }
 
 // last kernel of graal_begin_step / graal_layout_stats: publishes the 16 statistics words to pinned host memory (followed by
@@ -400,24 +415,30 @@ struct Changed {
 };
 
 // commit one candidate (test_copy_struct, cuda_lib_gl.py:1156): out = apply_move(in); also records which contigs exist
-// afterwards among the <= 4 labels the move can touch (for the incremental relabel of the next graal_begin_step)
-__global__ void k_apply(SoaPtr in, SoaPtr out, int n, int op, int fA, int fB, int max_id, int* __restrict__ n_stale,
-                        Changed* __restrict__ chg)
+// afterwards among the <= 4 labels the move can touch (for the incremental relabel of the next graal_begin_step), and -- it
+// has every new record in registers anyway -- the statistics of the NEW layout, which its last block publishes to pinned host
+// memory: the next graal_begin_step finds them there and needs no statistics kernel.
+__global__ __launch_bounds__(256) void k_apply(SoaPtr in, SoaPtr out, int n, int op, int fA, int fB, int max_id, int* __restrict__ n_stale,
+                                               Changed* __restrict__ chg, long long* __restrict__ stats, volatile long long* host, long long seq)
 {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= n) return;
+    StatAcc a = stat_zero();
     const Rec A0 = ld_rec(in, fA), B0 = ld_rec(in, fB);
     const Move m = make_move(op, fA, fB, max_id, A0, B0);
-    bool stale;
-    const Rec r = apply_move(m, f, ld_rec(in, f), &stale);
-    st_rec(out, f, r);
-    if (stale) atomicAdd(n_stale, 1);
-    if (f == 0) { chg->cA = A0.id_c; chg->cB = B0.id_c; chg->lab[0] = A0.id_c; chg->lab[1] = B0.id_c; chg->lab[2] = max_id + 1; chg->lab[3] = max_id + 2; }
-    if (r.pos == 0) {
-        const int c = r.id_c;
-        const int j = c == A0.id_c ? 0 : (c == B0.id_c ? 1 : (c == max_id + 1 ? 2 : (c == max_id + 2 ? 3 : -1)));
-        if (j >= 0) { chg->len[j] = r.l_cont; chg->exists[j] = 1; }
+    // (grid-stride with a small grid: the statistics cost 10 same-address atomics per BLOCK)
+    for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < n; f += gridDim.x * blockDim.x) {
+        bool stale;
+        const Rec r = apply_move(m, f, ld_rec(in, f), &stale);
+        st_rec(out, f, r);
+        if (stale) atomicAdd(n_stale, 1);
+        if (f == 0) { chg->cA = A0.id_c; chg->cB = B0.id_c; chg->lab[0] = A0.id_c; chg->lab[1] = B0.id_c; chg->lab[2] = max_id + 1; chg->lab[3] = max_id + 2; }
+        if (r.pos == 0) {
+            const int c = r.id_c;
+            const int j = c == A0.id_c ? 0 : (c == B0.id_c ? 1 : (c == max_id + 1 ? 2 : (c == max_id + 2 ? 3 : -1)));
+            if (j >= 0) { chg->len[j] = r.l_cont; chg->exists[j] = 1; }
+        }
+        stat_add(a, f, r.pos, r.l_cont, r.start_bp, r.l_cont_bp, r.rep, r.activ, r.id_d, r.id_c, r.circ);
     }
+    stat_reduce_publish(a, stats, host, seq, 0); // (the stale count is reset by the begin_step that reports it)
 }
 
 // ---- incremental relabel.  Invariant after every graal_begin_step: labels ARE ranks (contigs sorted by (l_cont, label)),
@@ -432,55 +453,60 @@ struct IncrPlan {
 
 __device__ __forceinline__ bool key_less(int l1, int c1, int l2, int c2) { return l1 < l2 || (l1 == l2 && c1 < c2); }
 
-__global__ void k_incr_plan(const Changed* __restrict__ chg, const int* __restrict__ len_old, const int* __restrict__ off_old,
-                            int nc_old, int n, IncrPlan* __restrict__ plan)
+// One kernel: every block derives the plan (a dozen loads; the binary searches of the <= 4 new contigs run on 8 lanes side
+// by side), then the elementwise pass: new label of every fragment, sorted-length / offset arrays (contig heads write
+// them), position index and geometry records.  Also re-arms the stale-paste counter the commit's statistics reported.
+__global__ __launch_bounds__(256) void k_incr(SoaPtr s, int n, const Changed* __restrict__ chg, const int* __restrict__ len_old,
+                                              const int* __restrict__ off_old, int nc_old, int* __restrict__ len_new,
+                                              int* __restrict__ off_new, int* __restrict__ perm, int* __restrict__ cbase,
+                                              Geo* __restrict__ geo, Link* __restrict__ link, long long* __restrict__ stats)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    IncrPlan p;
-    p.n_removed = 0;
-    const int cand[2] = {chg->cA, chg->cB};
-    for (int i = 0; i < 2; i++) {
-        if (i == 1 && cand[1] == cand[0]) continue;
-        p.removed[p.n_removed] = cand[i]; p.removed_len[p.n_removed] = len_old[cand[i]]; p.n_removed++;
+    __shared__ IncrPlan sp;
+    __shared__ int s_lb[4], s_ub[4];
+    const int t = threadIdx.x;
+    if (t == 0) {
+        IncrPlan p;
+        p.n_removed = 0;
+        const int cand[2] = {chg->cA, chg->cB};
+        for (int i = 0; i < 2; i++) {
+            if (i == 1 && cand[1] == cand[0]) continue;
+            p.removed[p.n_removed] = cand[i]; p.removed_len[p.n_removed] = len_old[cand[i]]; p.n_removed++;
+        }
+        for (int i = p.n_removed; i < 2; i++) { p.removed[i] = -1; p.removed_len[i] = 0; }
+        p.n_new = 0;
+        for (int j = 0; j < 4; j++) {
+            if (!chg->exists[j]) continue;
+            if (j == 1 && chg->lab[1] == chg->lab[0]) continue;
+            p.new_lab[p.n_new] = chg->lab[j]; p.new_len[p.n_new] = chg->len[j]; p.n_new++;
+        }
+        for (int i = p.n_new; i < 4; i++) { p.new_lab[i] = -1; p.new_len[i] = 0; }
+        for (int i = 0; i < 4; i++) { p.new_rank[i] = -1; p.new_off[i] = 0; }
+        p.nc_new = nc_old - p.n_removed + p.n_new;
+        sp = p;
+        if (blockIdx.x == 0) stats[13] = 0;
     }
-    for (int i = p.n_removed; i < 2; i++) { p.removed[i] = -1; p.removed_len[i] = 0; }
-    p.n_new = 0;
-    for (int j = 0; j < 4; j++) {
-        if (!chg->exists[j]) continue;
-        if (j == 1 && chg->lab[1] == chg->lab[0]) continue;
-        p.new_lab[p.n_new] = chg->lab[j]; p.new_len[p.n_new] = chg->len[j]; p.n_new++;
-    }
-    for (int i = p.n_new; i < 4; i++) { p.new_lab[i] = -1; p.new_len[i] = 0; p.new_rank[i] = -1; p.new_off[i] = 0; }
-    for (int i = 0; i < p.n_new; i++) {
-        const int l = p.new_len[i], c = p.new_lab[i];
-        // old contigs with key < (l, c): binary searches in the sorted length array
+    __syncthreads();
+    if (t < 8 && (t >> 1) < sp.n_new) { // old contigs with key < (l, c): lower / upper bound of l in the sorted length array
+        const int l = sp.new_len[t >> 1];
         int lo = 0, hi = nc_old;
-        while (lo < hi) { const int m = (lo + hi) >> 1; if (len_old[m] < l) lo = m + 1; else hi = m; }
-        const int lb = lo;
-        hi = nc_old;
-        while (lo < hi) { const int m = (lo + hi) >> 1; if (len_old[m] <= l) lo = m + 1; else hi = m; }
-        const int ub = lo;
+        if (t & 1) { while (lo < hi) { const int m = (lo + hi) >> 1; if (len_old[m] <= l) lo = m + 1; else hi = m; } s_ub[t >> 1] = lo; }
+        else { while (lo < hi) { const int m = (lo + hi) >> 1; if (len_old[m] < l) lo = m + 1; else hi = m; } s_lb[t >> 1] = lo; }
+    }
+    __syncthreads();
+    if (t < sp.n_new) {
+        const int i = t, l = sp.new_len[i], c = sp.new_lab[i], lb = s_lb[i], ub = s_ub[i];
         int within = c - lb; within = within < 0 ? 0 : (within > ub - lb ? ub - lb : within);
         const int pcount = lb + within;                    // number of old contigs with a smaller key
         int rank = pcount, off = pcount < nc_old ? off_old[pcount] : n;
-        for (int r = 0; r < p.n_removed; r++)
-            if (key_less(p.removed_len[r], p.removed[r], l, c)) { rank -= 1; off -= p.removed_len[r]; }
-        for (int j = 0; j < p.n_new; j++)
-            if (j != i && key_less(p.new_len[j], p.new_lab[j], l, c)) { rank += 1; off += p.new_len[j]; }
-        p.new_rank[i] = rank; p.new_off[i] = off;
+        for (int r = 0; r < sp.n_removed; r++)
+            if (key_less(sp.removed_len[r], sp.removed[r], l, c)) { rank -= 1; off -= sp.removed_len[r]; }
+        for (int j = 0; j < sp.n_new; j++)
+            if (j != i && key_less(sp.new_len[j], sp.new_lab[j], l, c)) { rank += 1; off += sp.new_len[j]; }
+        sp.new_rank[i] = rank; sp.new_off[i] = off;
     }
-    p.nc_new = nc_old - p.n_removed + p.n_new;
-    *plan = p;
-}
-
-// one elementwise pass: new label of every fragment, sorted-length / offset arrays (contig heads write them), position
-// index and geometry records
-__global__ void k_incr_apply(SoaPtr s, int n, const IncrPlan* __restrict__ planp, const int* __restrict__ len_old,
-                             const int* __restrict__ off_old, int* __restrict__ len_new, int* __restrict__ off_new,
-                             int* __restrict__ perm, int* __restrict__ cbase, Geo* __restrict__ geo, Link* __restrict__ link)
-{
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    const IncrPlan p = *planp;
+    __syncthreads();
+    const int f = blockIdx.x * blockDim.x + t;
+    const IncrPlan p = sp;
     if (f == 0) off_new[p.nc_new] = n;
     if (f >= p.nc_new && f < n) len_new[f] = 0; // keep the tail of the length array zero
     if (f >= n) return;
@@ -1810,6 +1836,7 @@ struct Ctx {
     hipEvent_t ev_fin = nullptr;  // end of the last asynchronous evaluation (orders the next k_tm after it)
     hipEvent_t ev_relabel = nullptr; // end of the relabel kernels graal_begin_step left running (orders the next k_tm, on aux)
     bool relabel_pending = false;
+    bool stats_from_apply = false; // the last commit published the statistics of the layout it produced (sequence stats_seq)
     bool fin_pending = false;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> ring; // pairs of events around k_scan, one pair per call (graal_scan_times)
@@ -1857,9 +1884,8 @@ struct Ctx {
     int* d_sub_ids = nullptr;     // [n_bins][4], only when some bin has more than one sub-fragment
     unsigned long long *keys = nullptr, *keys_sorted = nullptr;
     int *o2n = nullptr, *perm = nullptr, *cbase = nullptr;
-    int *len_of2[2] = {nullptr, nullptr}, *contig_off2[2] = {nullptr, nullptr}; // per layout buffer (see k_incr_apply)
+    int *len_of2[2] = {nullptr, nullptr}, *contig_off2[2] = {nullptr, nullptr}; // per layout buffer (see k_incr)
     Changed* d_chg = nullptr;
-    IncrPlan* d_plan = nullptr;
     bool ranks_valid = false;     // labels of buffer `cur` are ranks and its len/offset arrays are current
     int pending_commits = 0;      // commits since the last graal_begin_step
     bool incr_ok = false;         // the single pending commit started from a ranked layout with the right max_id
@@ -2130,7 +2156,7 @@ int graal_create(int device, graal_ctx** out)
     CK(hipMemset(h->step_hdr, 0, 2 * MAXK * sizeof(int)));
     CK(hipMalloc(&h->d_args, 2 * sizeof(DevArgs)));
     CK(hipMalloc(&h->d_chg, sizeof(Changed)));
-    CK(hipMalloc(&h->d_plan, sizeof(IncrPlan)));
+    CK(hipMemset(h->d_chg, 0, sizeof(Changed)));
     CK(hipHostMalloc((void**)&h->h_res, (1 + MAXK * N_OPS) * sizeof(long long), hipHostMallocDefault));
     memset(h->h_res, 0, (1 + MAXK * N_OPS) * sizeof(long long));
     h->res_host = h->res_dev = h->h_res;
@@ -2156,7 +2182,7 @@ void graal_destroy(graal_ctx* h)
         if (h->aux) (void)hipStreamSynchronize(h->aux);
         void* ptrs[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->stat, h->sub2bin, h->row, h->col, h->cnt, h->queue, h->d_sub_ids, h->d_acc, h->tm_done, h->d_sync, h->d_flags, h->stat_frag, h->d_dup_bins, h->d_dup_index,
                         h->d_dispatcher, h->d_collector, h->d_sub_ids_all, h->d_rep_obs,
-                        h->keys, h->keys_sorted, h->o2n, h->len_of2[0], h->len_of2[1], h->contig_off2[0], h->contig_off2[1], h->perm, h->cbase, h->link, h->mates, h->cub_tmp, h->tabs, h->step_hdr, h->d_args, h->d_chg, h->d_plan,
+                        h->keys, h->keys_sorted, h->o2n, h->len_of2[0], h->len_of2[1], h->contig_off2[0], h->contig_off2[1], h->perm, h->cbase, h->link, h->mates, h->cub_tmp, h->tabs, h->step_hdr, h->d_args, h->d_chg,
                         h->d_scalars, h->d_qout, h->d_dref, h->d_dist};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (h->x_host) (void)hipHostUnregister(h->x_host);
@@ -2447,24 +2473,28 @@ int graal_begin_step(graal_ctx* h, int64_t stats[8], int32_t* max_id)
     const int cur = h->cur;
     SoaPtr s = h->soa[cur];
     static const bool no_incr = getenv("GRAAL_NO_INCREMENTAL_RELABEL") != nullptr;
-    // the statistics do not depend on the relabel.  When the relabel does not need them on the device (the counting paths),
-    // the statistics kernel publishes them itself: the host reads them -- and goes on to draw the step's proposal -- while
-    // the relabel kernels behind it still run (everything the host launches next is ordered after them by the stream)
-    const bool early = h->ranks_valid && (h->pending_commits == 0 || (h->pending_commits == 1 && h->incr_ok && !no_incr));
-    if (early) {
+    // The statistics do not depend on the relabel.  After exactly one commit they are in pinned host memory already (the
+    // commit kernel published them); when nothing changed, the statistics kernel publishes them itself.  Either way the host
+    // reads them -- and goes on to draw the step's proposal -- while the relabel kernels launched here still run (everything
+    // the host launches next is ordered after them: same stream, or the event recorded below).
+    const bool incr = h->ranks_valid && h->pending_commits == 1 && h->incr_ok && !no_incr;
+    const bool early = h->ranks_valid && (h->pending_commits == 0 || incr);
+    if (incr && h->stats_from_apply) {
+        // nothing to launch for the statistics
+    } else if (early) {
         h->stats_seq += 1;
-        k_stats<<<std::min(nb, 64), bs, 0, h->stream>>>(s, n, h->d_scalars, h->h_stats, h->stats_seq, 1);
+        k_stats<<<std::min(nb, 64), bs, 0, h->stream>>>(s, n, h->d_scalars, h->h_stats, h->stats_seq, incr ? 0 : 1);
     } else k_stats<<<std::min(nb, 64), bs, 0, h->stream>>>(s, n, h->d_scalars);
+    h->stats_from_apply = false;
     if (h->ranks_valid && h->pending_commits == 0) {
         // nothing changed since the last call: labels are ranks already
-    } else if (h->ranks_valid && h->pending_commits == 1 && h->incr_ok && !no_incr) {
+    } else if (incr) {
         // exactly one commit since the last ranking: count instead of sort (rank arrays of buffer 1-cur -> buffer cur)
-        k_incr_plan<<<1, 64, 0, h->stream>>>(h->d_chg, h->len_of2[1 - cur], h->contig_off2[1 - cur], h->n_contigs, n, h->d_plan);
-        k_incr_apply<<<blocks_for(n + 1, bs), bs, 0, h->stream>>>(s, n, h->d_plan, h->len_of2[1 - cur], h->contig_off2[1 - cur],
-                                                                 h->len_of2[cur], h->contig_off2[cur], h->perm, h->cbase, h->geo, h->link);
-        k_mates<<<nb, bs, 0, h->stream>>>(n, h->perm, h->cbase, h->link, h->mates);
+        k_incr<<<blocks_for(n + 1, bs), bs, 0, h->stream>>>(s, n, h->d_chg, h->len_of2[1 - cur], h->contig_off2[1 - cur], h->n_contigs,
+                                                           h->len_of2[cur], h->contig_off2[cur], h->perm, h->cbase, h->geo, h->link, h->d_scalars);
+        k_mates<<<nb, bs, 0, h->stream>>>(n, h->perm, h->cbase, h->link, h->mates, (int*)h->d_chg, (int)(sizeof(Changed) / sizeof(int)));
         CK(hipGetLastError());
-        // the host does not wait for these three: whatever runs on the OTHER stream next (k_tm) must
+        // the host does not wait for these two: whatever runs on the OTHER stream next (k_tm) must
         CK(hipEventRecord(h->ev_relabel, h->stream));
         h->relabel_pending = true;
     } else {
@@ -2481,7 +2511,7 @@ int graal_begin_step(graal_ctx* h, int64_t stats[8], int32_t* max_id)
         CK(hipGetLastError());
         int rc = refresh(h);
         if (rc) return rc;
-        k_mates<<<nb, bs, 0, h->stream>>>(n, h->perm, h->cbase, h->link, h->mates);
+        k_mates<<<nb, bs, 0, h->stream>>>(n, h->perm, h->cbase, h->link, h->mates, (int*)h->d_chg, (int)(sizeof(Changed) / sizeof(int)));
         CK(hipGetLastError());
     }
     long long res[16];
@@ -2778,9 +2808,13 @@ int graal_apply_move(graal_ctx* h, int32_t fA, int32_t fB, int32_t op, int32_t m
     if (fA < 0 || fA >= h->n || fB < 0 || fB >= h->n) return fail(h, GRAAL_E_ARG, "fragment index out of range");
     CK(hipSetDevice(h->device));
     int* d_stale = (int*)(h->d_scalars + 13);
-    CK(hipMemsetAsync(h->d_chg, 0, sizeof(Changed), h->stream));
-    k_apply<<<blocks_for(h->n, 256), 256, 0, h->stream>>>(h->soa[h->cur], h->soa[1 - h->cur], h->n, op, fA, fB, max_id, d_stale, h->d_chg);
+    // (the commit record d_chg is clear: the last kernel of every relabel clears it; a second commit without a relabel in
+    // between finds the first one's entries, and the relabel then sorts instead of counting)
+    h->stats_seq += 1;
+    k_apply<<<std::min(blocks_for(h->n, 256), 64), 256, 0, h->stream>>>(h->soa[h->cur], h->soa[1 - h->cur], h->n, op, fA, fB, max_id, d_stale, h->d_chg,
+                                                           h->d_scalars, h->h_stats, h->stats_seq);
     CK(hipGetLastError());
+    h->stats_from_apply = true; // statistics of the new layout are on their way to pinned host memory (sequence stats_seq)
     h->incr_ok = h->ranks_valid && h->pending_commits == 0 && max_id == h->n_contigs - 1;
     h->pending_commits += 1;
     h->cur = 1 - h->cur;
