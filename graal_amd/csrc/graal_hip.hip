@@ -235,14 +235,14 @@ __device__ __forceinline__ void stat_add(StatAcc& a, int f, int pos, int lc, int
     a.v[8] += circ == 1;
 }
 
-// block reduction of the per-thread statistics (256 threads) + one atomic per statistic per block.  With `host` the LAST
+// block reduction of the per-thread statistics (a multiple of 64 threads, <= 1024) + one atomic per statistic per block.  With `host` the LAST
 // block (ticket in out[21]) also does k_stats_fin's job -- publish the 16 words to pinned host memory followed by the
 // sequence number, re-arm the accumulators -- so that the host has the statistics while the kernels queued behind this one
 // still run.  Every thread of the block must call it.
 __device__ __forceinline__ void stat_reduce_publish(const StatAcc& a, long long* __restrict__ out, volatile long long* host, long long seq,
                                                     int reset_stale)
 {
-    __shared__ long long sh[4][9];
+    __shared__ long long sh[16][9]; // up to 1024 threads
 #pragma unroll
     for (int i = 0; i < 9; i++) {
         long long x = a.v[i];
@@ -256,7 +256,7 @@ __device__ __forceinline__ void stat_reduce_publish(const StatAcc& a, long long*
     if (threadIdx.x < 9) { // one atomic per statistic per block
         const int i = threadIdx.x;
         long long x = sh[0][i];
-        for (int w = 1; w < 4; w++) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); w++) {
             const long long y = sh[w][i];
             x = (i == 4 || i == 7) ? (y > x ? y : x) : (i == 5 ? (y < x ? y : x) : x + y);
         }
@@ -424,7 +424,8 @@ __global__ __launch_bounds__(256) void k_apply(SoaPtr in, SoaPtr out, int n, int
     StatAcc a = stat_zero();
     const Rec A0 = ld_rec(in, fA), B0 = ld_rec(in, fB);
     const Move m = make_move(op, fA, fB, max_id, A0, B0);
-    // (grid-stride with a small grid: the statistics cost 10 same-address atomics per BLOCK)
+    // (grid-stride with a small grid: the statistics cost 10 same-address atomics per BLOCK.  Measured on 50k fragments:
+    // 64 x 256 threads 15 us; 49 blocks x 1024 threads ~28 us; 196 x 256 ~25 us)
     for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < n; f += gridDim.x * blockDim.x) {
         bool stale;
         const Rec r = apply_move(m, f, ld_rec(in, f), &stale);
@@ -453,13 +454,15 @@ struct IncrPlan {
 
 __device__ __forceinline__ bool key_less(int l1, int c1, int l2, int c2) { return l1 < l2 || (l1 == l2 && c1 < c2); }
 
-// One kernel: every block derives the plan (a dozen loads; the binary searches of the <= 4 new contigs run on 8 lanes side
-// by side), then the elementwise pass: new label of every fragment, sorted-length / offset arrays (contig heads write
-// them), position index and geometry records.  Also re-arms the stale-paste counter the commit's statistics reported.
+// One kernel: every block derives the plan (a dozen loads; the searches of the <= 4 new contigs in the sorted length array
+// run side by side, 32 probes per round), then the elementwise pass: new label of every fragment, sorted-length / offset
+// arrays (contig heads write them), position index, geometry records and the mates rows of the touched contigs.  Also
+// re-arms the stale-paste counter the commit's statistics reported and clears the commit record the NEXT commit fills.
 __global__ __launch_bounds__(256) void k_incr(SoaPtr s, int n, const Changed* __restrict__ chg, const int* __restrict__ len_old,
                                               const int* __restrict__ off_old, int nc_old, int* __restrict__ len_new,
                                               int* __restrict__ off_new, int* __restrict__ perm, int* __restrict__ cbase,
-                                              Geo* __restrict__ geo, Link* __restrict__ link, long long* __restrict__ stats)
+                                              Geo* __restrict__ geo, Link* __restrict__ link, long long* __restrict__ stats,
+                                              int* __restrict__ mates, int* __restrict__ chg_clear, int chg_n)
 {
     __shared__ IncrPlan sp;
     __shared__ int s_lb[4], s_ub[4];
@@ -486,11 +489,29 @@ __global__ __launch_bounds__(256) void k_incr(SoaPtr s, int n, const Changed* __
         if (blockIdx.x == 0) stats[13] = 0;
     }
     __syncthreads();
-    if (t < 8 && (t >> 1) < sp.n_new) { // old contigs with key < (l, c): lower / upper bound of l in the sorted length array
-        const int l = sp.new_len[t >> 1];
+    {   // old contigs with key < (l, c): lower / upper bound of l in the sorted length array, for each of the <= 4 new contigs.
+        // Eight searches side by side, 32 lanes each (the two halves of a wave share the contig): 32 probes per round, so
+        // 50k contigs take 4 rounds of one load instead of 16 dependent ones.
+        const int g = t >> 5, j = t & 31, i = g >> 1;
+        const bool upper = g & 1, act = i < sp.n_new;
+        const int l = act ? sp.new_len[i] : 0;
         int lo = 0, hi = nc_old;
-        if (t & 1) { while (lo < hi) { const int m = (lo + hi) >> 1; if (len_old[m] <= l) lo = m + 1; else hi = m; } s_ub[t >> 1] = lo; }
-        else { while (lo < hi) { const int m = (lo + hi) >> 1; if (len_old[m] < l) lo = m + 1; else hi = m; } s_lb[t >> 1] = lo; }
+        for (;;) {
+            const bool go = act && lo < hi;
+            if (__ballot(go) == 0) break;
+            const int span = hi - lo;
+            const int m = lo + (int)(((long long)(j + 1) * span) / 33);
+            const int v = go ? len_old[m] : 0;
+            const bool pred = go && (upper ? v <= l : v < l);
+            const unsigned long long bal = __ballot(pred);
+            const int cnt = __popc((unsigned)(bal >> (32 * (g & 1))));   // probes of this search that lie below the bound
+            if (go) {
+                const int nlo = cnt > 0 ? lo + (int)(((long long)cnt * span) / 33) + 1 : lo;
+                const int nhi = cnt < 32 ? lo + (int)(((long long)(cnt + 1) * span) / 33) : hi;
+                lo = nlo; hi = nhi;
+            }
+        }
+        if (act && j == 0) { if (upper) s_ub[i] = lo; else s_lb[i] = lo; }
     }
     __syncthreads();
     if (t < sp.n_new) {
@@ -507,6 +528,7 @@ __global__ __launch_bounds__(256) void k_incr(SoaPtr s, int n, const Changed* __
     __syncthreads();
     const int f = blockIdx.x * blockDim.x + t;
     const IncrPlan p = sp;
+    if (f < chg_n) chg_clear[f] = 0; // the OTHER commit record (consumed by the previous relabel): clear for the next commit
     if (f == 0) off_new[p.nc_new] = n;
     if (f >= p.nc_new && f < n) len_new[f] = 0; // keep the tail of the length array zero
     if (f >= n) return;
@@ -514,6 +536,7 @@ __global__ __launch_bounds__(256) void k_incr(SoaPtr s, int n, const Changed* __
     int rank = -1, off = 0, lenc = 0;
     for (int i = 0; i < 4; i++)
         if (i < p.n_new && c == p.new_lab[i]) { rank = p.new_rank[i]; off = p.new_off[i]; lenc = p.new_len[i]; }
+    const bool touched = rank >= 0;
     if (rank < 0) { // untouched contig: c is its old rank
         lenc = len_old[c]; rank = c; off = off_old[c];
         for (int r = 0; r < 2; r++)
@@ -531,6 +554,22 @@ __global__ __launch_bounds__(256) void k_incr(SoaPtr s, int n, const Changed* __
     geo[f] = g;
     Link l; l.l_cont = s.p[F_LCONT][f]; l.l_cont_bp = s.p[F_LCONTBP][f]; l.prev = s.p[F_PREV][f]; l.next = s.p[F_NEXT][f];
     link[f] = l;
+    // mates row (first N_MATES fragments of the fragment's contig, read only for contigs that short): members and order of
+    // an untouched contig did not change, so only the fragments of the <= 4 touched contigs rewrite theirs -- by walking
+    // the links of the committed layout (complete before this kernel started; the position index is being written by it)
+    if (touched && lenc <= N_MATES) {
+        int head = f;
+        for (int i = 0; i < pos && i < N_MATES; i++) { const int h2 = s.p[F_PREV][head]; if ((unsigned)h2 >= (unsigned)n) break; head = h2; }
+        int m[N_MATES], cur = head;
+#pragma unroll
+        for (int i = 0; i < N_MATES; i++) {
+            m[i] = (i < lenc && cur >= 0) ? cur : -1;
+            if (i + 1 < lenc && cur >= 0) { const int nx = s.p[F_NEXT][cur]; cur = (unsigned)nx < (unsigned)n ? nx : -1; }
+        }
+        int4* out = reinterpret_cast<int4*>(mates + (size_t)f * N_MATES);
+        out[0] = make_int4(m[0], m[1], m[2], m[3]);
+        out[1] = make_int4(m[4], m[5], m[6], m[7]);
+    }
 }
 
 // ------------------------------------------------------------------ full likelihood
@@ -1885,7 +1924,8 @@ struct Ctx {
     unsigned long long *keys = nullptr, *keys_sorted = nullptr;
     int *o2n = nullptr, *perm = nullptr, *cbase = nullptr;
     int *len_of2[2] = {nullptr, nullptr}, *contig_off2[2] = {nullptr, nullptr}; // per layout buffer (see k_incr)
-    Changed* d_chg = nullptr;
+    Changed* d_chg = nullptr;     // [2] commit records: a commit fills one, the relabel that consumes it clears the other
+    int chg_w = 0, chg_last = 0;
     bool ranks_valid = false;     // labels of buffer `cur` are ranks and its len/offset arrays are current
     int pending_commits = 0;      // commits since the last graal_begin_step
     bool incr_ok = false;         // the single pending commit started from a ranked layout with the right max_id
@@ -2155,8 +2195,8 @@ int graal_create(int device, graal_ctx** out)
     CK(hipMalloc(&h->step_hdr, 2 * MAXK * sizeof(int)));
     CK(hipMemset(h->step_hdr, 0, 2 * MAXK * sizeof(int)));
     CK(hipMalloc(&h->d_args, 2 * sizeof(DevArgs)));
-    CK(hipMalloc(&h->d_chg, sizeof(Changed)));
-    CK(hipMemset(h->d_chg, 0, sizeof(Changed)));
+    CK(hipMalloc(&h->d_chg, 2 * sizeof(Changed)));
+    CK(hipMemset(h->d_chg, 0, 2 * sizeof(Changed)));
     CK(hipHostMalloc((void**)&h->h_res, (1 + MAXK * N_OPS) * sizeof(long long), hipHostMallocDefault));
     memset(h->h_res, 0, (1 + MAXK * N_OPS) * sizeof(long long));
     h->res_host = h->res_dev = h->h_res;
@@ -2490,11 +2530,11 @@ int graal_begin_step(graal_ctx* h, int64_t stats[8], int32_t* max_id)
         // nothing changed since the last call: labels are ranks already
     } else if (incr) {
         // exactly one commit since the last ranking: count instead of sort (rank arrays of buffer 1-cur -> buffer cur)
-        k_incr<<<blocks_for(n + 1, bs), bs, 0, h->stream>>>(s, n, h->d_chg, h->len_of2[1 - cur], h->contig_off2[1 - cur], h->n_contigs,
-                                                           h->len_of2[cur], h->contig_off2[cur], h->perm, h->cbase, h->geo, h->link, h->d_scalars);
-        k_mates<<<nb, bs, 0, h->stream>>>(n, h->perm, h->cbase, h->link, h->mates, (int*)h->d_chg, (int)(sizeof(Changed) / sizeof(int)));
+        k_incr<<<blocks_for(n + 1, bs), bs, 0, h->stream>>>(s, n, h->d_chg + h->chg_last, h->len_of2[1 - cur], h->contig_off2[1 - cur], h->n_contigs,
+                                                           h->len_of2[cur], h->contig_off2[cur], h->perm, h->cbase, h->geo, h->link, h->d_scalars,
+                                                           h->mates, (int*)(h->d_chg + (1 - h->chg_last)), (int)(sizeof(Changed) / sizeof(int)));
         CK(hipGetLastError());
-        // the host does not wait for these two: whatever runs on the OTHER stream next (k_tm) must
+        // the host does not wait for this kernel: whatever runs on the OTHER stream next (k_tm) must
         CK(hipEventRecord(h->ev_relabel, h->stream));
         h->relabel_pending = true;
     } else {
@@ -2511,7 +2551,7 @@ int graal_begin_step(graal_ctx* h, int64_t stats[8], int32_t* max_id)
         CK(hipGetLastError());
         int rc = refresh(h);
         if (rc) return rc;
-        k_mates<<<nb, bs, 0, h->stream>>>(n, h->perm, h->cbase, h->link, h->mates, (int*)h->d_chg, (int)(sizeof(Changed) / sizeof(int)));
+        k_mates<<<nb, bs, 0, h->stream>>>(n, h->perm, h->cbase, h->link, h->mates, (int*)h->d_chg, (int)(2 * sizeof(Changed) / sizeof(int)));
         CK(hipGetLastError());
     }
     long long res[16];
@@ -2811,8 +2851,9 @@ int graal_apply_move(graal_ctx* h, int32_t fA, int32_t fB, int32_t op, int32_t m
     // (the commit record d_chg is clear: the last kernel of every relabel clears it; a second commit without a relabel in
     // between finds the first one's entries, and the relabel then sorts instead of counting)
     h->stats_seq += 1;
-    k_apply<<<std::min(blocks_for(h->n, 256), 64), 256, 0, h->stream>>>(h->soa[h->cur], h->soa[1 - h->cur], h->n, op, fA, fB, max_id, d_stale, h->d_chg,
+    k_apply<<<std::min(blocks_for(h->n, 256), 64), 256, 0, h->stream>>>(h->soa[h->cur], h->soa[1 - h->cur], h->n, op, fA, fB, max_id, d_stale, h->d_chg + h->chg_w,
                                                            h->d_scalars, h->h_stats, h->stats_seq);
+    h->chg_last = h->chg_w; h->chg_w ^= 1;
     CK(hipGetLastError());
     h->stats_from_apply = true; // statistics of the new layout are on their way to pinned host memory (sequence stats_seq)
     h->incr_ok = h->ranks_valid && h->pending_commits == 0 && max_id == h->n_contigs - 1;
