@@ -1875,6 +1875,7 @@ struct Ctx {
     hipEvent_t ev_fin = nullptr;  // end of the last asynchronous evaluation (orders the next k_tm after it)
     hipEvent_t ev_relabel = nullptr; // end of the relabel kernels graal_begin_step left running (orders the next k_tm, on aux)
     bool relabel_pending = false;
+    bool begin_launched = false;  // graal_begin_step_launch ran for the current layout; graal_begin_step only has to wait
     bool stats_from_apply = false; // the last commit published the statistics of the layout it produced (sequence stats_seq)
     bool fin_pending = false;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -2456,7 +2457,7 @@ int graal_upload_frags(graal_ctx* h, const int32_t* const soa[GRAAL_N_FIELDS], i
         CK(hipMalloc(&h->cub_tmp, h->cub_tmp_bytes));
         h->n = n;
     }
-    h->cur = 0; h->ranks_valid = false; h->pending_commits = 0;
+    h->cur = 0; h->ranks_valid = false; h->pending_commits = 0; h->begin_launched = false; h->stats_from_apply = false;
     for (int k = 0; k < GRAAL_N_FIELDS; k++)
         CK(hipMemcpy(h->soa[0].p[k], soa[k], sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
     {   // statistics per fragment: those of its bin; copies of repeated bins (original included) carry no sub-fragments in
@@ -2504,10 +2505,9 @@ int graal_layout_stats(graal_ctx* h, int64_t out[8])
     return GRAAL_OK;
 }
 
-int graal_begin_step(graal_ctx* h, int64_t stats[8], int32_t* max_id)
+// first half of graal_begin_step: everything it launches; the statistics are on their way to pinned host memory afterwards
+static int begin_step_launch(graal_ctx* h)
 {
-    if (!h) return GRAAL_E_ARG;
-    if (!h->have_frags) return fail(h, GRAAL_E_STATE, "no fragments uploaded");
     CK(hipSetDevice(h->device));
     const int n = h->n, bs = 256, nb = blocks_for(n, bs);
     const int cur = h->cur;
@@ -2554,8 +2554,31 @@ int graal_begin_step(graal_ctx* h, int64_t stats[8], int32_t* max_id)
         k_mates<<<nb, bs, 0, h->stream>>>(n, h->perm, h->cbase, h->link, h->mates, (int*)h->d_chg, (int)(2 * sizeof(Changed) / sizeof(int)));
         CK(hipGetLastError());
     }
+    if (!early) { // the sorting path reads the statistics on the device, so they are published (and re-armed) behind it
+        h->stats_seq += 1;
+        k_stats_fin<<<1, 64, 0, h->stream>>>(h->d_scalars, h->h_stats, h->stats_seq, 1);
+        CK(hipGetLastError());
+    }
+    h->begin_launched = true;
+    return GRAAL_OK;
+}
+
+int graal_begin_step_launch(graal_ctx* h)
+{
+    if (!h) return GRAAL_E_ARG;
+    if (!h->have_frags) return fail(h, GRAAL_E_STATE, "no fragments uploaded");
+    return h->begin_launched ? GRAAL_OK : begin_step_launch(h);
+}
+
+int graal_begin_step(graal_ctx* h, int64_t stats[8], int32_t* max_id)
+{
+    if (!h) return GRAAL_E_ARG;
+    if (!h->have_frags) return fail(h, GRAAL_E_STATE, "no fragments uploaded");
+    if (!h->begin_launched) { int rc = begin_step_launch(h); if (rc) return rc; }
+    h->begin_launched = false;
+    const int n = h->n;
     long long res[16];
-    { int rc = early ? wait_stats(h, res) : fetch_stats(h, res, true); if (rc) return rc; }
+    { int rc = wait_stats(h, res); if (rc) return rc; }
     const int nc = (int)res[0];
     // (a corrupt layout could have made the kernels above index out of range; the uploads validate labels and the
     // mutations keep them in [0, n_contigs + 2], so this is a consistency check, not a guard)
@@ -2855,6 +2878,7 @@ int graal_apply_move(graal_ctx* h, int32_t fA, int32_t fB, int32_t op, int32_t m
                                                            h->d_scalars, h->h_stats, h->stats_seq);
     h->chg_last = h->chg_w; h->chg_w ^= 1;
     CK(hipGetLastError());
+    h->begin_launched = false;
     h->stats_from_apply = true; // statistics of the new layout are on their way to pinned host memory (sequence stats_seq)
     h->incr_ok = h->ranks_valid && h->pending_commits == 0 && max_id == h->n_contigs - 1;
     h->pending_commits += 1;

@@ -23,7 +23,7 @@ _f64p = ctypes.POINTER(ctypes.c_double)
 
 SYMBOLS = ("graal_abi_version", "graal_create", "graal_destroy", "graal_last_error", "graal_set_params",
            "graal_upload_subfrags", "graal_upload_repeats", "graal_upload_contacts", "graal_upload_contacts_f32", "graal_upload_frags", "graal_download_frags",
-           "graal_relabel_contigs", "graal_begin_step", "graal_layout_stats", "graal_eval_full_q", "graal_eval_candidates_q",
+           "graal_relabel_contigs", "graal_begin_step", "graal_begin_step_launch", "graal_layout_stats", "graal_eval_full_q", "graal_eval_candidates_q",
            "graal_eval_candidates", "graal_exchange_bytes", "graal_attach_exchange", "graal_eval_candidates_x", "graal_upload_distance_ref", "graal_genome_distance", "graal_apply_move", "graal_set_finisher", "graal_set_timing", "graal_last_timing", "graal_scan_times", "graal_time_scan", "graal_last_counters")
 
 _lib = None
@@ -58,6 +58,7 @@ def load():
         L.graal_relabel_contigs.argtypes = [ctypes.c_void_p, _i32p]
         L.graal_layout_stats.argtypes = [ctypes.c_void_p, _i64p]
         L.graal_begin_step.argtypes = [ctypes.c_void_p, _i64p, _i32p]
+        L.graal_begin_step_launch.argtypes = [ctypes.c_void_p]
         L.graal_eval_full_q.argtypes = [ctypes.c_void_p, _i64p]
         L.graal_eval_candidates_q.argtypes = [ctypes.c_void_p, ctypes.c_int32, _i32p, ctypes.c_int32, ctypes.c_int32,
                                               ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
@@ -188,6 +189,10 @@ class Engine:
         m = ctypes.c_int32(0)
         self._ck(self._L.graal_relabel_contigs(self._h, ctypes.byref(m)), "graal_relabel_contigs")
         return int(m.value)
+
+    def begin_step_launch(self):
+        """Launch what begin_step launches and return at once (optional; begin_step then only waits)."""
+        self._ck(self._L.graal_begin_step_launch(self._h), "graal_begin_step_launch")
 
     def begin_step(self):
         """(stats[8], max_id): layout statistics + contig relabel + index rebuild with one synchronisation."""

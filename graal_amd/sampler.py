@@ -658,7 +658,11 @@ class sampler(object):
         """``cuda_lib_gl.py:1793-1980``.  Returns (o, n_contigs, min_len, mean_len_bp, max_len, op_sampled,
         id_f_sampled, dist, F_t)."""
         id_fA = int(id_fA)
-        st, max_id = self.engine.begin_step()   # statistics + relabel + index, one synchronisation
+        # relabel + index are launched; the proposal is drawn while they run (nothing between here and the reference's
+        # return_neighbours call draws from the generator, so the stream is the reference's); then the statistics are read
+        self.engine.begin_step_launch()
+        id_neighbours = None if id_fA in self._black_set else self.return_neighbours(id_fA, delta)
+        st, max_id = self.engine.begin_step()   # statistics (published by the commit kernel), one wait
         max_id = np.int32(max_id)
         n_circ = int(st[6])
         self.n_stale_paste += int(st[7])
@@ -683,7 +687,6 @@ class sampler(object):
             self.likelihood_t = self._full_likelihood()
         self._n_circ_prev = n_circ
         likelihood_t = self.likelihood_t
-        id_neighbours = self.return_neighbours(id_fA, delta)
         n_neighbours = len(id_neighbours)
         id_neighbours.sort()
         self.last_neighbours = list(id_neighbours)

@@ -87,6 +87,9 @@ int graal_relabel_contigs(graal_ctx* h, int32_t* max_id);
  * before the relabel, which does not change them) + stats[7] = fragments that hit the unwritten paste branch in the
  * commits since the previous call, then the relabel of graal_relabel_contigs.  stats may be NULL. */
 int graal_begin_step(graal_ctx* h, int64_t stats[8], int32_t* max_id);
+/* The launching half of graal_begin_step alone: returns at once.  A caller with host work that does not need the statistics
+ * (drawing the proposal) calls this, does that work, then calls graal_begin_step, which only waits.  Optional. */
+int graal_begin_step_launch(graal_ctx* h);
 
 /* layout statistics step_max_likelihood returns (cuda_lib_gl.py:1809-1816):
  * out[0]=n_contigs out[1]=sum(l_cont) out[2]=#(start_bp==0) out[3]=sum(l_cont_bp | start_bp==0)
