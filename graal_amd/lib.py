@@ -106,6 +106,17 @@ class Engine:
         self.device = int(device)
         self.n = 0
         self._x_map = self._x_view = None
+        # buffers of the per-step calls, allocated once (numpy's .ctypes accessor costs more than the call itself)
+        self._fb_buf = np.zeros(MAX_NEIGHBOURS, dtype=np.int32)
+        self._fb_ptr = self._fb_buf.ctypes.data_as(_i32p)
+        self._delta_buf = np.zeros(MAX_NEIGHBOURS * N_OPS, dtype=np.float64)
+        self._delta_ptr = self._delta_buf.ctypes.data_as(_f64p)
+        self._q_buf = np.zeros(MAX_NEIGHBOURS * N_OPS, dtype=np.int64)
+        self._q_ptr = self._q_buf.ctypes.data_as(_i64p)
+        self._st_buf = np.zeros(8, dtype=np.int64)
+        self._st_ptr = self._st_buf.ctypes.data_as(_i64p)
+        self._max_id = ctypes.c_int32(0)
+        self._max_id_ref = ctypes.byref(self._max_id)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -196,10 +207,10 @@ class Engine:
 
     def begin_step(self):
         """(stats[8], max_id): layout statistics + contig relabel + index rebuild with one synchronisation."""
-        out = np.zeros(8, dtype=np.int64)
-        m = ctypes.c_int32(0)
-        self._ck(self._L.graal_begin_step(self._h, out.ctypes.data_as(_i64p), ctypes.byref(m)), "graal_begin_step")
-        return out, int(m.value)
+        rc = self._L.graal_begin_step(self._h, self._st_ptr, self._max_id_ref)
+        if rc != 0:
+            self._ck(rc, "graal_begin_step")
+        return self._st_buf.copy(), int(self._max_id.value)
 
     def layout_stats(self):
         out = np.zeros(8, dtype=np.int64)
@@ -225,14 +236,17 @@ class Engine:
 
     def eval_candidates(self, fA, fB, max_id):
         """Delta logL of the 13 candidates of every neighbour: float64 [K, 13].  Single GPU, synchronous."""
+        K = len(fB)
+        if 1 <= K <= MAX_NEIGHBOURS:   # the per-step path: preallocated buffers, cached pointers (this call is ~10 % of a step)
+            self._fb_buf[:K] = fB
+            rc = self._L.graal_eval_candidates(self._h, int(fA), self._fb_ptr, K, int(max_id), self._delta_ptr)
+            if rc != 0:
+                self._ck(rc, "graal_eval_candidates")
+            return self._delta_buf[:K * N_OPS].reshape(K, N_OPS).copy()
         fb = _c(fB, np.int32)
         out = np.zeros((len(fb), N_OPS), dtype=np.float64)
         for k0 in range(0, len(fb), MAX_NEIGHBOURS):  # > 8 neighbours: one scan pass per group of 8
-            part = fb[k0:k0 + MAX_NEIGHBOURS]
-            buf = np.zeros(len(part) * N_OPS, dtype=np.float64)
-            self._ck(self._L.graal_eval_candidates(self._h, int(fA), part.ctypes.data_as(_i32p), len(part), int(max_id),
-                                                   buf.ctypes.data_as(_f64p)), "graal_eval_candidates")
-            out[k0:k0 + len(part)] = buf.reshape(len(part), N_OPS)
+            out[k0:k0 + MAX_NEIGHBOURS] = self.eval_candidates(fA, fb[k0:k0 + MAX_NEIGHBOURS], max_id)
         return out
 
     # -- genome distance ------------------------------------------------------------------------
@@ -273,14 +287,17 @@ class Engine:
 
     def eval_candidates_x(self, fA, fB, max_id):
         """Sharded, synchronous: float64 [K, 13] = (sum over ALL ranks of the int64 sums) / 2^30; every rank calls it."""
+        K = len(fB)
+        if 1 <= K <= MAX_NEIGHBOURS:
+            self._fb_buf[:K] = fB
+            rc = self._L.graal_eval_candidates_x(self._h, int(fA), self._fb_ptr, K, int(max_id), self._q_ptr)
+            if rc != 0:
+                self._ck(rc, "graal_eval_candidates_x")
+            return (self._q_buf[:K * N_OPS].astype(np.float64) / Q_SCALE).reshape(K, N_OPS)
         fb = _c(fB, np.int32)
         out = np.zeros((len(fb), N_OPS), dtype=np.float64)
         for k0 in range(0, len(fb), MAX_NEIGHBOURS):
-            part = fb[k0:k0 + MAX_NEIGHBOURS]
-            q = np.zeros(len(part) * N_OPS, dtype=np.int64)
-            self._ck(self._L.graal_eval_candidates_x(self._h, int(fA), part.ctypes.data_as(_i32p), len(part), int(max_id),
-                                                     q.ctypes.data_as(_i64p)), "graal_eval_candidates_x")
-            out[k0:k0 + len(part)] = (q.astype(np.float64) / Q_SCALE).reshape(len(part), N_OPS)
+            out[k0:k0 + MAX_NEIGHBOURS] = self.eval_candidates_x(fA, fb[k0:k0 + MAX_NEIGHBOURS], max_id)
         return out
 
     def eval_candidates_q_async(self, fA, fB, max_id, d_out_ptr, stream_ptr, rank=0, world=1):
