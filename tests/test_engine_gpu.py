@@ -337,7 +337,7 @@ def test_short_contigs_finished_by_the_table_kernel(n_sub, seed, p_circ):
 
 @pytest.mark.parametrize("n_sub,seed,p_circ", [(1, 31, 0.0), (1, 32, 0.5), (3, 33, 0.3)])
 def test_incremental_relabel_matches_the_sort(n_sub, seed, p_circ):
-    """graal_begin_step after one commit derives the new ranking by counting (k_incr_plan / k_incr_apply); it must give
+    """graal_begin_step after one commit derives the new ranking by counting (k_incr); it must give
     the labels of the stable sort (cuda_lib_gl.py:1697-1722) and the same position index as a fresh upload."""
     P = make(n_sub, seed, n_bins=60, nnz=800)
     rng = np.random.RandomState(seed)

@@ -4,7 +4,9 @@ need the dense oracle (which cannot run at this size).
 * the reference's implied invariant (cuda_lib_gl.py:2196-2220): candidate delta == full likelihood after the move - before;
 * the step finished inside k_tm == the step finished by k_fin, bit for bit;
 * determinism: the same seed gives the same accepted-move trace and the same final layout twice;
-* structural invariants of the layout after 1,500 real MCMC steps (cuda_lib_gl.py:1530-1537)."""
+* structural invariants of the layout after 1,500 real MCMC steps (cuda_lib_gl.py:1530-1537);
+* 1,500 incremental relabels (k_incr: counting, link-walked mates rows) == one full relabel (sort) of the same layout in a
+  fresh engine: labels, statistics, candidate deltas and the full likelihood bit for bit."""
 import numpy as np
 import pytest
 
@@ -62,6 +64,28 @@ def test_c5_properties(c5):
         o = m[np.argsort(g.pos[m])]
         assert np.array_equal(g.pos[o], np.arange(len(o))) and (g.l_cont[o] == len(o)).all()
         assert np.array_equal(g.start_bp[o], np.cumsum(g.len_bp[o]) - g.len_bp[o]) and (g.l_cont_bp[o] == g.len_bp[o].sum()).all()
+    # ---- the incrementally maintained labels / index / geometry / mates == a fresh engine's full relabel of this layout
+    from graal_amd.lib import Engine
+    state = {k: np.copy(getattr(g, k)) for k in ("pos", "id_c", "start_bp", "len_bp", "circ", "id", "prev", "next", "l_cont",
+                                                 "l_cont_bp", "ori", "rep", "activ", "id_d")}
+    e2 = Engine(0)
+    e2.upload_subfrags(c5["np_sub_frags_id"], c5["np_sub_frags_len_bp"], c5["np_sub_frags_accu"], c5["init_n_sub_frags"],
+                       c5["mean_squared_frags_per_bin"])
+    e2.upload_contacts(c5["coo_row"], c5["coo_col"], c5["coo_val"])
+    e2.set_params(c5["param_simu"])
+    e2.upload_frags(state)
+    st2, max2 = e2.begin_step()
+    st1, max1 = smp.engine.begin_step()
+    assert max1 == max2 and list(st1[:7]) == list(st2[:7])
+    got2 = e2.download_frags()
+    for k in state:
+        assert np.array_equal(got2[k], state[k]), k          # already ranked: the sort leaves the labels alone
+    rng = np.random.RandomState(3)
+    for fA in rng.randint(0, n, size=6):
+        nb = smp.return_neighbours(int(fA), 5); nb.sort()
+        assert np.array_equal(smp.engine.eval_candidates(int(fA), nb, max1), e2.eval_candidates(int(fA), nb, max2))
+    assert np.array_equal(smp.engine.eval_full_q(), e2.eval_full_q())
+    e2.close()
     # ---- determinism and finisher == k_fin at full size
     smp2, trace2 = run(c5, 7, 300, finisher=False)
     assert trace2 == trace[:300]

@@ -24,9 +24,16 @@ def main():
     ap.add_argument("--n-bins", type=int, default=50000)
     ap.add_argument("--nnz", type=int, default=20_000_000)
     ap.add_argument("--dist", action="store_true", help="with the genome distance every step (compute_dist=True)")
+    ap.add_argument("--n-sub", type=int, default=1)
+    ap.add_argument("--original", action="store_true", help="start from the 7 reference contigs (late-stage regime), no explode")
     a = ap.parse_args()
-    P = synth.make_problem(n_bins=a.n_bins, nnz=a.nnz, n_sub=1, seed=20141217)
-    P["S_o_A_frags"] = bench.exploded_layout(P)
+    if a.n_sub > 1:   # the shapes of tools/run_configs.py (C2 / C3)
+        P = synth.make_problem(n_bins=a.n_bins, nnz=a.nnz, n_sub=a.n_sub, seed=2014, contig_weights=(6.8, 6.2, 5.3, 4.6, 4.0, 3.4, 2.7),
+                               mean_len_bp=660.0 * 27 / a.n_sub, accu=9)
+    else:
+        P = synth.make_problem(n_bins=a.n_bins, nnz=a.nnz, n_sub=1, seed=20141217)
+    if not a.original:
+        P["S_o_A_frags"] = bench.exploded_layout(P)
     rng = np.random.RandomState(20141217)
     smp = bench.build_sampler(P, rng, gdist.Group(0, 1), 0)
     smp.compute_dist = a.dist
@@ -34,6 +41,7 @@ def main():
     n = int(smp.n_new_frags)
     order = np.arange(n, dtype=np.int32)
     rng.shuffle(order)
+    order = np.concatenate([order] * (1 + (2000 + a.steps) // n))
     for i in order[:2000]:
         smp.step_max_likelihood(int(i), 5)
     acc = {}
@@ -55,6 +63,7 @@ def main():
     wrap(S, "select_move", "select_move (host)")
     wrap(smp, "test_copy_struct", "commit launch (k_apply)")
     wrap(smp, "dist_inter_genome", "genome distance (k_dist, wait)")
+    wrap(smp, "_full_likelihood", "full re-evaluation (circular contigs around / every 512 steps)")
     t0 = time.perf_counter()
     for i in order[2000:2000 + a.steps]:
         smp.step_max_likelihood(int(i), 5)
