@@ -1587,7 +1587,12 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
             item_base[k + 1] = item_base[k] + own;
         }
         const int total_all = item_base[MAXK];
-        for (int W = wave; W < total_all; W += n_waves) {
+        // Few items (mid-size genomes: a few hundred items of a few hundred y each) would leave most of the chip idle behind
+        // one long sequential walk per wave -- the step then lasts as long as ONE item.  The walk of an item is therefore cut
+        // into YS segments, each a work unit of its own (sums are integers: any partition gives the same result).
+        const int YS = total_all > 0 ? min(32, max(1, (8 * n_waves) / total_all)) : 1;
+        for (int WW = wave; WW < total_all * YS; WW += n_waves) {
+            const int W = WW / YS, seg = WW - W * YS;
             int k = 0;
 #pragma unroll
             for (int j = 1; j < MAXK; j++) k += (W >= item_base[j]) ? 1 : 0;
@@ -1602,7 +1607,7 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
             }
             const Task tk = T.task[ti];
             const int np = tk.np, nq = tk.nq, base_p = tk.base_p, base_q = tk.base_q;
-            items++;
+            items += seg == 0;
             // lane = one fragment x of the chunk.  The fragments y it is paired with are walked AWAY from the chunk, 64 at a
             // time: the wave stages their transformed geometry and statistics in LDS once (one dependent-load chain per 64
             // y instead of one per pair -- the loop used to be bound by that latency), then every lane runs over the tile
@@ -1622,11 +1627,15 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
                 x_below = __shfl((int)(X.start_bp < Q0.start_bp), 0, 64) != 0;
                 asc = (tk.xq.sigma > 0) == x_below; // walk q by increasing old position?
             }
-            const int ny = same ? np : nq;                 // length of the walk
+            const int ny_all = same ? np : nq;             // length of the walk
+            const int walk_lo = same ? chunk * 64 + 1 : 0;
+            const int seg_len = (max(ny_all - walk_lo, 0) + YS - 1) / YS;
+            const int seg_lo = walk_lo + seg * seg_len;
+            const int ny = min(ny_all, seg_lo + seg_len);  // this unit walks [seg_lo, ny)
             YTile* tile = s_tile[threadIdx.x >> 6];
             bool done = !has_x;
             long long accq = 0;
-            for (int tb = same ? chunk * 64 + 1 : 0; tb < ny; tb += 64) {
+            for (int tb = seg_lo; tb < ny; tb += 64) {
                 const int st = tb + lane;
                 if (st < ny) {
                     const int iy = same ? st : (asc ? st : nq - 1 - st);

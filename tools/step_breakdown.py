@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--nnz", type=int, default=20_000_000)
     ap.add_argument("--dist", action="store_true", help="with the genome distance every step (compute_dist=True)")
     ap.add_argument("--n-sub", type=int, default=1)
+    ap.add_argument("--counters", action="store_true", help="also average the engine's per-step counters (adds a copy per step)")
     ap.add_argument("--original", action="store_true", help="start from the 7 reference contigs (late-stage regime), no explode")
     a = ap.parse_args()
     if a.n_sub > 1:   # the shapes of tools/run_configs.py (C2 / C3)
@@ -64,10 +65,23 @@ def main():
     wrap(smp, "test_copy_struct", "commit launch (k_apply)")
     wrap(smp, "dist_inter_genome", "genome distance (k_dist, wait)")
     wrap(smp, "_full_likelihood", "full re-evaluation (circular contigs around / every 512 steps)")
+    cnt = np.zeros(4)
+    orig = smp._candidate_deltas
+
+    def counted(*args, **kw):
+        r = orig(*args, **kw)
+        cnt[:] += smp.engine.last_counters()
+        return r
+    if a.counters:
+        smp._candidate_deltas = counted
     t0 = time.perf_counter()
     for i in order[2000:2000 + a.steps]:
         smp.step_max_likelihood(int(i), 5)
     total = time.perf_counter() - t0
+    if a.counters:
+        print("per step: relevant (contact, neighbour) pairs %.0f, queued contacts %.0f, mass work items %.0f" % tuple(cnt[1:4] / a.steps))
+    st = smp.engine.layout_stats()
+    print("layout: %d contigs, longest %d fragments" % (st[0], st[4]))
     print("full MCMC step: %.1f us  (n=%d, nnz=%d, %d steps, compute_dist=%s)" % (1e6 * total / a.steps, n, a.nnz, a.steps, a.dist))
     for k, v in sorted(acc.items(), key=lambda kv: -kv[1]):
         print("  %-75s %7.1f us" % (k, 1e6 * v / a.steps))
