@@ -594,36 +594,52 @@ __global__ __launch_bounds__(256) void k_full_nnz(const int* __restrict__ row, c
 
 // cis correction of the expected mass for the current layout: one thread per fragment x (in contig order),
 // pairs (x, y later in the same contig) while the gap is below d_max, plus x's own sub-fragment pairs.
-__global__ __launch_bounds__(64) void k_full_mass(int n, const int* __restrict__ perm, const int* __restrict__ contig_off,
-                                                   const Geo* __restrict__ geo, const Stat* __restrict__ stat,
-                                                   const int* __restrict__ lcont, const int* __restrict__ lcontbp,
-                                                   const int* __restrict__ pos, float nfpb, Par par, int reach_bp,
-                                                   long long* __restrict__ out)
+__device__ __forceinline__ long long pair_mass_q(const End& X, const Stat& sx, const End& Y, const Stat& sy, float nfpb, const Par& par);
+
+// One WAVE per fragment x (position-index slot i): its lanes take the fragments y behind it in the contig, 64 at a time,
+// until all of them are beyond the window.  (One THREAD per fragment left a 1,000-bin genome with 1,000 threads walking
+// ~200 x 9 slot pairs each: 1.3 ms per full evaluation, which the nuisance-parameter step pays every MCMC step.)
+// Like the candidate tasks, every fragment PAIR is rounded to Q once, so the sum does not depend on how it is partitioned.
+__global__ __launch_bounds__(256) void k_full_mass(int n, const int* __restrict__ perm, const int* __restrict__ contig_off,
+                                                    const Geo* __restrict__ geo, const Stat* __restrict__ stat,
+                                                    const int* __restrict__ lcont, const int* __restrict__ lcontbp,
+                                                    const int* __restrict__ pos, float nfpb, Par par, int reach_bp,
+                                                    long long* __restrict__ out)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    double acc = 0.0;
-    if (i < n) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    long long accq = 0;
+    if (i < n) { // (wave-uniform)
         const int fx = perm[i];
         const Geo gx = geo[fx];
         const Stat sx = stat[fx];
         const End X = end_cur(gx, lcontbp, fx);
-        for (int a = 0; a < sx.n; a++)
-            for (int b = a + 1; b < sx.n; b++) acc += (double)ex_pair(X, sx, a, X, sx, b, nfpb, par);
-        const int remaining = lcont[fx] - 1 - pos[fx];
-        for (int k = 1; k <= remaining; k++) {
-            const int fy = perm[i + k];
-            const Geo gy = geo[fy];
-            if (gy.start_bp - (gx.start_bp + gx.len_bp) > reach_bp) break;
-            const Stat sy = stat[fy];
-            const End Y = end_cur(gy, lcontbp, fy);
+        if (lane == 0) {
+            double acc = 0.0;
             for (int a = 0; a < sx.n; a++)
-                for (int b = 0; b < sy.n; b++)
-                    acc += (double)ex_pair(X, sx, a, Y, sy, b, nfpb, par) - (double)ex_trans(stat_accu(sx, a), stat_accu(sy, b), nfpb, par);
+                for (int b = a + 1; b < sx.n; b++) acc += (double)ex_pair(X, sx, a, X, sx, b, nfpb, par);
+            accq += to_q(acc);
+        }
+        const int remaining = lcont[fx] - 1 - pos[fx];
+        for (int k0 = 1; k0 <= remaining; k0 += 64) {
+            const int k = k0 + lane;
+            bool beyond = true;
+            if (k <= remaining) {
+                const int fy = perm[i + k];
+                const Geo gy = geo[fy];
+                beyond = gy.start_bp - (gx.start_bp + gx.len_bp) > reach_bp;
+                if (!beyond) {
+                    const Stat sy = stat[fy];
+                    const End Y = end_cur(gy, lcontbp, fy);
+                    accq += pair_mass_q(X, sx, Y, sy, nfpb, par);
+                }
+            }
+            if (__ballot(!beyond) == 0) break; // (start_bp grows along the contig: nothing further is inside the window)
         }
     }
     (void)contig_off;
-    const long long q = wave_sum_ll(to_q(acc)); // one Q rounding per fragment: fixed partition
-    if ((threadIdx.x & 63) == 0 && q != 0) atomicAdd((unsigned long long*)out, (unsigned long long)q);
+    const long long q = wave_sum_ll(accq);
+    if (lane == 0 && q != 0) atomicAdd((unsigned long long*)out, (unsigned long long)q);
 }
 
 // ------------------------------------------------------------------ candidate tables
@@ -2641,7 +2657,7 @@ int graal_eval_full_q(graal_ctx* h, int64_t q_out[2])
         k_full_nnz<<<nb, 256, 0, h->stream>>>(h->row, h->col, h->cnt, h->nnz, h->sub2bin, h->geo, h->stat_frag, s.p[F_LCONTBP],
                                                h->nfpb, h->par, h->d_scalars + 8);
     }
-    k_full_mass<<<blocks_for(h->n, 64), 64, 0, h->stream>>>(h->n, h->perm, h->contig_off2[h->cur], h->geo, h->stat_frag, s.p[F_LCONT],
+    k_full_mass<<<blocks_for(h->n, 4), 256, 0, h->stream>>>(h->n, h->perm, h->contig_off2[h->cur], h->geo, h->stat_frag, s.p[F_LCONT],
                                                              s.p[F_LCONTBP], s.p[F_POS], h->nfpb, h->par, reach_bp(h),
                                                              h->d_scalars + 9);
     if (h->has_rep) { // every pixel of a repeated bin, densely (identical on every rank: it goes with the mass part)
