@@ -312,6 +312,12 @@ __global__ void k_stats_fin(long long* __restrict__ sc, volatile long long* host
     if (t == 0) { host[0] = seq; __threadfence_system(); }
 }
 
+// exchange self-test: this rank's GPU writes a tag into the spare last word of its two slots (graal_exchange_selftest)
+__global__ void k_exchange_tag(volatile long long* slot0, volatile long long* slot1, int word, long long tag)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) { slot0[word] = tag; slot1[word] = tag; __threadfence_system(); }
+}
+
 // Genome distance of dist_inter_genome (cuda_lib_gl.py:475-541) in HALF units: the reference subtracts, per fragment, terms
 // that are multiples of 0.5 from 3 * (fragments counted); this kernel returns twice the sum of those terms (an integer, so
 // the host's float64 result is exactly the reference loop's).  ref[f] = (initial prev, initial next, initial ori,
@@ -2874,6 +2880,46 @@ int graal_attach_exchange(graal_ctx* h, void* segment, int64_t bytes, int32_t ra
     // the published word is the step's sequence number: all ranks continue from the same one
     if (seq_floor > h->seq) h->seq = seq_floor;
     if (seq_now) *seq_now = h->seq;
+    return GRAAL_OK;
+}
+
+int graal_exchange_selftest(graal_ctx* h, int64_t tag, int32_t phase)
+{
+    if (!h) return GRAAL_E_ARG;
+    if (!h->x_host) return fail(h, GRAAL_E_STATE, "graal_attach_exchange first");
+    const size_t w = (size_t)h->x_world;
+    if (phase == 0) { // write: this rank's GPU tags its two slots
+        CK(hipSetDevice(h->device));
+        k_exchange_tag<<<1, 64, 0, h->stream>>>(h->x_dev + (size_t)h->x_rank * X_SLOT_WORDS, h->x_dev + (w + (size_t)h->x_rank) * X_SLOT_WORDS,
+                                                 X_SLOT_WORDS - 1, (long long)tag + h->x_rank);
+        CK(hipGetLastError());
+        CK(hipStreamSynchronize(h->stream));
+        return GRAAL_OK;
+    }
+    // check (after a barrier of the ranks): every rank's tag must be visible to this host in both slots
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        bool all = true;
+        for (size_t r = 0; r < w; r++)
+            for (size_t par = 0; par < 2; par++)
+                all = all && ((volatile long long*)h->x_host)[(par * w + r) * X_SLOT_WORDS + (X_SLOT_WORDS - 1)] == (long long)tag + (long long)r;
+        if (all) return GRAAL_OK;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2))
+            return fail(h, GRAAL_E_STATE, "exchange self-test: another rank's GPU write is not visible in the shared segment");
+        __builtin_ia32_pause();
+    }
+}
+
+int graal_detach_exchange(graal_ctx* h)
+{
+    if (!h) return GRAAL_E_ARG;
+    if (!h->x_host) return GRAAL_OK;
+    CK(hipSetDevice(h->device));
+    CK(hipStreamSynchronize(h->stream));
+    CK(hipStreamSynchronize(h->aux));
+    CK(hipHostUnregister(h->x_host));
+    h->x_host = nullptr; h->x_dev = nullptr; h->x_bytes = 0; h->x_rank = 0; h->x_world = 1;
+    h->res_host = h->res_dev = h->h_res;
     return GRAAL_OK;
 }
 

@@ -24,7 +24,7 @@ _f64p = ctypes.POINTER(ctypes.c_double)
 SYMBOLS = ("graal_abi_version", "graal_create", "graal_destroy", "graal_last_error", "graal_set_params",
            "graal_upload_subfrags", "graal_upload_repeats", "graal_upload_contacts", "graal_upload_contacts_f32", "graal_upload_frags", "graal_download_frags",
            "graal_relabel_contigs", "graal_begin_step", "graal_begin_step_launch", "graal_layout_stats", "graal_eval_full_q", "graal_eval_candidates_q",
-           "graal_eval_candidates", "graal_exchange_bytes", "graal_attach_exchange", "graal_eval_candidates_x", "graal_upload_distance_ref", "graal_genome_distance", "graal_apply_move", "graal_set_finisher", "graal_set_timing", "graal_last_timing", "graal_scan_times", "graal_time_scan", "graal_last_counters")
+           "graal_eval_candidates", "graal_exchange_bytes", "graal_attach_exchange", "graal_eval_candidates_x", "graal_exchange_selftest", "graal_detach_exchange", "graal_upload_distance_ref", "graal_genome_distance", "graal_apply_move", "graal_set_finisher", "graal_set_timing", "graal_last_timing", "graal_scan_times", "graal_time_scan", "graal_last_counters")
 
 _lib = None
 
@@ -66,6 +66,8 @@ def load():
         L.graal_exchange_bytes.argtypes = [ctypes.c_int32, _i64p]
         L.graal_attach_exchange.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
                                             ctypes.c_int64, _i64p]
+        L.graal_exchange_selftest.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32]
+        L.graal_detach_exchange.argtypes = [ctypes.c_void_p]
         L.graal_eval_candidates_x.argtypes = [ctypes.c_void_p, ctypes.c_int32, _i32p, ctypes.c_int32, ctypes.c_int32, _i64p]
         L.graal_upload_distance_ref.argtypes = [ctypes.c_void_p, _i32p, _i32p, _i32p, _i32p, ctypes.POINTER(ctypes.c_uint8),
                                                 ctypes.c_int32]
@@ -284,6 +286,23 @@ class Engine:
                                                int(world), int(seq_floor), ctypes.byref(s)), "graal_attach_exchange")
         self._x_map, self._x_view = shared_map, view
         return int(s.value)
+
+    def exchange_selftest(self, tag, phase):
+        """phase 0: this rank's GPU tags its slots; (barrier); phase 1: True if this host sees every rank's tag."""
+        rc = self._L.graal_exchange_selftest(self._h, int(tag), int(phase))
+        if phase == 0:
+            self._ck(rc, "graal_exchange_selftest")
+        return rc == 0
+
+    def detach_exchange(self):
+        self._ck(self._L.graal_detach_exchange(self._h), "graal_detach_exchange")
+        if self._x_view is not None:
+            self._x_view = None
+            try:
+                self._x_map.close()
+            except (BufferError, ValueError):
+                pass
+            self._x_map = None
 
     def eval_candidates_x(self, fA, fB, max_id):
         """Sharded, synchronous: float64 [K, 13] = (sum over ALL ranks of the int64 sums) / 2^30; every rank calls it."""

@@ -548,6 +548,19 @@ class sampler(object):
         seg = self.group.shared_host_segment(self.engine.exchange_bytes(self.group.world))
         floor = self.group.all_reduce_max_int(self.engine.step_seq())
         self.engine.attach_exchange(seg, self.group.rank, self.group.world, floor)
+        # collective self-test before relying on it: every rank's GPU tags its slots, every host must see every tag
+        tag = 0x47524141 + (floor << 8)
+        self.engine.exchange_selftest(tag, 0)
+        self.group.barrier()
+        ok = self.engine.exchange_selftest(tag, 1)
+        if self.group.all_reduce_max_int(0 if ok else 1) != 0:
+            self.engine.detach_exchange()
+            if mode == "host":
+                raise RuntimeError("exchange='host': the shared-segment self-test failed on some rank")
+            import warnings
+            warnings.warn("graal_amd: the shared-host-memory exchange failed its self-test; using the RCCL all-reduce")
+            self.group.barrier()
+            return "rccl"
         self.group.barrier()
         return "host"
 

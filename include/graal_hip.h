@@ -130,6 +130,12 @@ int graal_eval_candidates(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K
 int graal_exchange_bytes(int32_t world, int64_t* bytes);
 int graal_attach_exchange(graal_ctx* h, void* segment, int64_t bytes, int32_t rank, int32_t world, int64_t seq_floor,
                           int64_t* seq_now);
+/* Self-test of an attached exchange, collective: every rank calls phase 0 (its GPU writes `tag + rank` into a spare word of
+ * its two slots), the ranks synchronise (any barrier), every rank calls phase 1 (its HOST must see every rank's tag; gives up
+ * after 2 s with GRAAL_E_STATE).  graal_detach_exchange unregisters the segment (the caller then falls back to the RCCL
+ * all-reduce of graal_eval_candidates_q). */
+int graal_exchange_selftest(graal_ctx* h, int64_t tag, int32_t phase);
+int graal_detach_exchange(graal_ctx* h);
 /* synchronous, sharded: K*13 int64 Q sums over ALL ranks into a host buffer (every rank must make the same call) */
 int graal_eval_candidates_x(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int32_t max_id, int64_t* q_sum);
 
