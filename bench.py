@@ -69,7 +69,8 @@ def cpu_baseline(P, state, budget_s=24.0):
     max_id = int(state["id_c"].max())
     pop, ids = O.new_state(n), np.zeros(n, np.int32)
     cands = []
-    for fA, fB in ((1234 % n, 4321 % n), (777 % n, 31337 % n), (20141 % n, 217 % n), (4242 % n, 12345 % n)):
+    for fA, fB in ((1234 % n, 4321 % n), (777 % n, 31337 % n), (20141 % n, 217 % n), (4242 % n, 12345 % n), (9001 % n, 40404 % n),
+                   (27182 % n, 31415 % n)):
         O.DenseOracle.pop_out(pop, state, ids, fA, max_id)
         cands.append(O.copy_state(pop))                                    # op 0: eject
         for which, ori in ((3, 1), (1, -1), (2, 1)):                       # ops 6, 3, 4
@@ -77,7 +78,7 @@ def cpu_baseline(P, state, budget_s=24.0):
             O.DenseOracle.pop_in(which, out, pop, fA, fB, int(ids.max()), ori)
             cands.append(out)
     done, t0 = 0, time.perf_counter()
-    for c in cands:                                                        # ~0.7 s each: 16 candidates, ~11 s of CPU work
+    for c in cands:                                                        # ~0.7 s each: 24 candidates, ~17 s of CPU work (>= 20)
         sc.full(c, same_bin=False)
         done += 1
         if time.perf_counter() - t0 > budget_s:
