@@ -66,12 +66,32 @@ __device__ __forceinline__ void st_rec(const SoaPtr& s, int f, const Rec& r)
 // rounded powf returns, e.g. glibc's in the oracle); the general powf costs ~100 instructions more
 __device__ __forceinline__ float sq(float x) { return x * x; }
 
+// powf(x, y) for x > 0: the device library's own algorithm -- extended-precision ln x (__ocmlpriv_epln_f32), y * ln x in
+// two floats, extended-precision exp (__ocmlpriv_expep_f32) -- WITHOUT the ~35 instructions of powf's special cases (x <= 0,
+// infinities, NaN, integer y and the sign of the result), none of which a distance in (0, d_max) can reach.  Bit-identical
+// to powf there: tools/powf_pos_check.hip compares them over all 260 M floats between 2^-15 and 2^16 for eight exponents
+// (tests/test_engine_gpu.py runs it).  The contact model is ~200 instructions per evaluation, 130 of them powf.
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+extern "C" __device__ v2f_t __ocmlpriv_epln_f32(float);
+extern "C" __device__ float __ocmlpriv_expep_f32(v2f_t);
+__device__ __forceinline__ float powf_pos(float x, float y)
+{
+    const v2f_t ln = __ocmlpriv_epln_f32(x); // (.y high part, .x low part)
+    const float yh = y * ln.y;
+    const float err = fmaf(y, ln.y, -yh);
+    const float t = fmaf(y, ln.x, err);
+    const float hi = yh + t;
+    const float lo = t - (hi - yh);
+    v2f_t a; a.x = lo; a.y = hi;
+    return __ocmlpriv_expep_f32(a);
+}
+
 // rippe_contacts kernels3.cu:120
 __device__ __forceinline__ float rippe(float s, const Par& p)
 {
     float result = 0.0f;
     if ((s > 0.0f) && (s < p.d_max))
-        result = (p.c1 * powf(s, p.slope) * expf((p.d - 2) / (sq(s * p.lm / p.kuhn) + p.d))) * p.fact;
+        result = (p.c1 * powf_pos(s, p.slope) * expf((p.d - 2) / (sq(s * p.lm / p.kuhn) + p.d))) * p.fact;
     return fmaxf(result, p.v_inter);
 }
 
@@ -1595,6 +1615,11 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
     __shared__ YTile s_tile[4][64];
+    // the block's K*13 sums: every mass unit and every (queued contact, candidate) adds here, the block flushes once.  Straight
+    // to the global accumulators, a step with millions of queued contacts issued ~10^8 atomics on 65 addresses -- the VALUs
+    // sat idle 91 % of a 12 ms step behind them (rocprofv3: SQ_INSTS_VALU against the kernel's duration).
+    __shared__ long long s_accb[MAXK * N_OPS];
+    for (int i = threadIdx.x; i < MAXK * N_OPS; i += blockDim.x) s_accb[i] = 0;
     STAMP(16, blockIdx.x == 0 && threadIdx.x == 0);
     const unsigned long long nq_total = counters[2]; // written by k_scan, the previous kernel on the stream
     // ---- wait for the tables (bounded spin: every wave reaches the exit even if k_tm never ran).  The word k_tm
@@ -1615,9 +1640,6 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
     }
     __syncthreads();
     STAMP(17, blockIdx.x == 0 && threadIdx.x == 0);
-    int n_items_k[MAXK], done_k[MAXK];
-#pragma unroll
-    for (int k = 0; k < MAXK; k++) { const unsigned w = s_hdr[k]; n_items_k[k] = (int)(w & 0x7fffffffu); done_k[k] = (int)(w >> 31); }
     const int* __restrict__ perm = A->perm;
     const int* __restrict__ lcontbp = A->soa.p[F_LCONTBP];
     const float nfpb = A->nfpb;
@@ -1625,37 +1647,44 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
     const int reach_bp = A->reach_bp;
     if (s_ok) {
         unsigned long long items = 0;
-        // one flat, fixed-order list of the work items this rank owns (local item w of a neighbour belongs to rank w % world),
-        // over the neighbours k_tm did not price itself
-        int item_base[MAXK + 1];
-        item_base[0] = 0;
-#pragma unroll
-        for (int k = 0; k < MAXK; k++) {
-            int own = 0;
-            if (k < K && done_k[k] == 0) { const int ni = n_items_k[k]; own = ni > rank ? (ni - rank + world - 1) / world : 0; }
-            item_base[k + 1] = item_base[k] + own;
-        }
-        const int total_all = item_base[MAXK];
-        // Few items (mid-size genomes: a few hundred items of a few hundred y each) would leave most of the chip idle behind
-        // one long sequential walk per wave -- the step then lasts as long as ONE item.  The walk of an item is therefore cut
-        // into YS segments, each a work unit of its own (sums are integers: any partition gives the same result).
-        const int YS = total_all > 0 ? min(32, max(1, (8 * n_waves) / total_all)) : 1;
-        for (int WW = wave; WW < total_all * YS; WW += n_waves) {
-            const int W = WW / YS, seg = WW - W * YS;
-            int k = 0;
-#pragma unroll
-            for (int j = 1; j < MAXK; j++) k += (W >= item_base[j]) ? 1 : 0;
-            const int w = rank + world * (W - sel_base(item_base, k));
+        // ---- work units.  An ITEM is (task, chunk of 64 fragments x of its larger piece); its walk over the other piece is cut
+        // into segments of SEG fragments y, and (item, segment) is the unit a wave takes.  One wave per item, as it used to be,
+        // made a step last as long as its longest item: with pieces of thousands of fragments next to pieces of one, rocprofv3
+        // showed the VALUs busy 9 % of the time (C5 with its 7 contigs: 12 ms per step).  Every block derives the same unit
+        // list -- per neighbour the exclusive prefix of units per task -- in LDS; unit U of the flat list belongs to rank
+        // U % world.  (Sums are integers: any partition of the pairs gives the same result.)
+        __shared__ int s_ustart[MAXK][MAX_TASKS + 1]; // s_ustart[k][ti] = first unit of task ti among neighbour k's units
+        __shared__ int s_units[MAX_TASKS];
+        __shared__ int s_ubase[MAXK + 1];
+        const int SEG = A->sub2bin_multi == nullptr ? 128 : 16; // (up to 9 slot pairs per fragment pair with sub-fragments)
+        if (threadIdx.x == 0) s_ubase[0] = 0;
+        for (int k = 0; k < K; k++) { // (block-uniform trip count)
             const NbTables& T = tabs[k];
-            int ti, chunk;
-            if (T.n_items <= ITEM_CAP) { const unsigned tc = T.item_tc[w]; ti = (int)(tc & 0xffffu); chunk = (int)(tc >> 16); }
-            else { // task of item w: last task with item_start <= w
-                int lo_t = 0, hi_t = T.n_tasks - 1;
-                while (lo_t < hi_t) { const int mid = (lo_t + hi_t + 1) >> 1; if (T.item_start[mid] <= w) lo_t = mid; else hi_t = mid - 1; }
-                ti = lo_t; chunk = w - T.item_start[ti];
+            const int nt = (s_hdr[k] >> 31) ? 0 : T.n_tasks; // (priced by k_tm already)
+            for (int ti = threadIdx.x; ti < nt; ti += blockDim.x) {
+                const Task& tk = T.task[ti];
+                const int chunks = (tk.np + 63) >> 6, walk = tk.p == tk.q ? tk.np : tk.nq;
+                s_units[ti] = chunks * max(1, (walk + SEG - 1) / SEG);
             }
+            __syncthreads();
+            if (threadIdx.x < 64) wave_excl_scan(s_units, s_ustart[k], nt);
+            __syncthreads();
+            if (threadIdx.x == 0) s_ubase[k + 1] = s_ubase[k] + s_ustart[k][nt];
+        }
+        __syncthreads();
+        const int total_units = s_ubase[K];
+        for (int U = rank + world * wave; U < total_units; U += world * n_waves) {
+            int k = 0;
+            for (int j = 1; j < K; j++) k += (U >= s_ubase[j]) ? 1 : 0;
+            const int u = U - s_ubase[k];
+            const NbTables& T = tabs[k];
+            int lo_t = 0, hi_t = T.n_tasks - 1; // task of unit u: last task with s_ustart <= u
+            while (lo_t < hi_t) { const int mid = (lo_t + hi_t + 1) >> 1; if (s_ustart[k][mid] <= u) lo_t = mid; else hi_t = mid - 1; }
+            const int ti = lo_t;
             const Task tk = T.task[ti];
             const int np = tk.np, nq = tk.nq, base_p = tk.base_p, base_q = tk.base_q;
+            const int n_seg = max(1, ((tk.p == tk.q ? np : nq) + SEG - 1) / SEG);
+            const int within = u - s_ustart[k][ti], chunk = within / n_seg, seg = within - chunk * n_seg;
             items += seg == 0;
             // lane = one fragment x of the chunk.  The fragments y it is paired with are walked AWAY from the chunk, 64 at a
             // time: the wave stages their transformed geometry and statistics in LDS once (one dependent-load chain per 64
@@ -1678,9 +1707,8 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
             }
             const int ny_all = same ? np : nq;             // length of the walk
             const int walk_lo = same ? chunk * 64 + 1 : 0;
-            const int seg_len = (max(ny_all - walk_lo, 0) + YS - 1) / YS;
-            const int seg_lo = walk_lo + seg * seg_len;
-            const int ny = min(ny_all, seg_lo + seg_len);  // this unit walks [seg_lo, ny)
+            const int seg_lo = max(walk_lo, seg * SEG);
+            const int ny = min(ny_all, (seg + 1) * SEG);   // this unit walks [seg_lo, ny)
             YTile* tile = s_tile[threadIdx.x >> 6];
             bool done = !has_x;
             long long accq = 0;
@@ -1717,7 +1745,7 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
                 // logL = contacts - mass: the NEW layout's mass counts negative, the OLD one positive
                 for (int op = 0; op < N_OPS; op++) {
                     const long long sgn = (long long)((tk.minus >> op) & 1u) - (long long)((tk.plus >> op) & 1u);
-                    if (sgn != 0) atomicAdd((unsigned long long*)&out[k * N_OPS + op], (unsigned long long)(sgn * qv));
+                    if (sgn != 0) atomicAdd((unsigned long long*)&s_accb[k * N_OPS + op], (unsigned long long)(sgn * qv));
                 }
             }
         }
@@ -1725,8 +1753,13 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
         // ---- queued contacts, taken from the far end of the grid so that they do not queue up behind the mass items of
         // the low-numbered blocks ----
         PriceArgs pa;
-        pa.queue = queue; pa.tabs = tabs; pa.geo = geo; pa.stat = stat; pa.lcontbp = lcontbp; pa.out = out; pa.nfpb = nfpb; pa.par = par;
+        pa.queue = queue; pa.tabs = tabs; pa.geo = geo; pa.stat = stat; pa.lcontbp = lcontbp; pa.out = s_accb; pa.nfpb = nfpb; pa.par = par;
         price_contacts(pa, nq_total, n_waves - 1 - wave, n_waves, lane);
+        __syncthreads();
+        for (int i = threadIdx.x; i < K * N_OPS; i += blockDim.x) {
+            const long long v = s_accb[i];
+            if (v != 0) atomicAdd((unsigned long long*)&out[i], (unsigned long long)v);
+        }
     }
     // ---- completion ticket: every block releases its atomics, the last one hands the sums out ----
     __shared__ int s_last;

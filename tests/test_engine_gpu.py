@@ -2,6 +2,8 @@
 
 Run on the MI355X box with ``pytest -m gpu``.  Everything goes through libgraal_hip.so; the oracle is only the checker.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -390,3 +392,21 @@ def test_two_commits_between_begin_steps_fall_back_to_the_sort():
     for k in O.FIELDS:
         assert np.array_equal(got[k], ref[k]), k
     e.close()
+
+
+def test_powf_pos_is_the_device_librarys_powf_bit_for_bit(tmp_path):
+    """The contact model calls powf_pos (graal_hip.hip: the device library's powf algorithm without its special cases) for
+    distances in (0, d_max).  tools/powf_pos_check.hip compares it with powf over every float between 2^-15 and 2^16 for eight
+    exponents on the GPU."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    exe = str(tmp_path / "powf_pos_check")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value", "-o", exe,
+                           os.path.join(root, "tools", "powf_pos_check.hip")])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300, check=True).stdout
+    lines = [l for l in out.splitlines() if l.startswith("y=")]
+    assert len(lines) == 8 and all("mismatches 0 " in l for l in lines), out
