@@ -1654,25 +1654,31 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
         // list -- per neighbour the exclusive prefix of units per task -- in LDS; unit U of the flat list belongs to rank
         // U % world.  (Sums are integers: any partition of the pairs gives the same result.)
         __shared__ int s_ustart[MAXK][MAX_TASKS + 1]; // s_ustart[k][ti] = first unit of task ti among neighbour k's units
-        __shared__ int s_units[MAX_TASKS];
-        __shared__ int s_ubase[MAXK + 1];
+        __shared__ int s_ubase[MAXK + 1], s_nt[MAXK];
         const int SEG = A->sub2bin_multi == nullptr ? 128 : 16; // (up to 9 slot pairs per fragment pair with sub-fragments)
-        if (threadIdx.x == 0) s_ubase[0] = 0;
-        for (int k = 0; k < K; k++) { // (block-uniform trip count)
+        for (int k = threadIdx.x >> 6; k < K; k += (int)(blockDim.x >> 6)) { // one wave per neighbour, side by side
             const NbTables& T = tabs[k];
-            const int nt = (s_hdr[k] >> 31) ? 0 : T.n_tasks; // (priced by k_tm already)
-            for (int ti = threadIdx.x; ti < nt; ti += blockDim.x) {
+            const int nt = (s_hdr[k] >> 31) ? 0 : T.n_tasks; // (bit 31: priced by k_tm already)
+            for (int ti = lane; ti < nt; ti += 64) {
                 const Task& tk = T.task[ti];
                 const int chunks = (tk.np + 63) >> 6, walk = tk.p == tk.q ? tk.np : tk.nq;
-                s_units[ti] = chunks * max(1, (walk + SEG - 1) / SEG);
+                s_ustart[k][ti] = chunks * max(1, (walk + SEG - 1) / SEG);
             }
-            __syncthreads();
-            if (threadIdx.x < 64) wave_excl_scan(s_units, s_ustart[k], nt);
-            __syncthreads();
-            if (threadIdx.x == 0) s_ubase[k + 1] = s_ubase[k] + s_ustart[k][nt];
+            WAVE_LDS_SYNC();
+            wave_excl_scan(s_ustart[k], s_ustart[k], nt); // (in place: a lane reads its entry before it writes it)
+            if (lane == 0) s_nt[k] = nt;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            s_ubase[0] = 0;
+            for (int k = 0; k < K; k++) s_ubase[k + 1] = s_ubase[k] + s_ustart[k][s_nt[k]];
         }
         __syncthreads();
         const int total_units = s_ubase[K];
+        STAMP(11, blockIdx.x == 0 && threadIdx.x == 0);
+        // (static deal.  Handing the units out through one global counter -- they differ by orders of magnitude, and the slowest
+        // block of a C2 step ends 100 us after the typical one -- was measured: 2,048 waves queueing on one address cost more
+        // than the imbalance, 175 -> 201 us per step.)
         for (int U = rank + world * wave; U < total_units; U += world * n_waves) {
             int k = 0;
             for (int j = 1; j < K; j++) k += (U >= s_ubase[j]) ? 1 : 0;
@@ -1750,12 +1756,15 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
             }
         }
         if (lane == 0 && items) atomicAdd(&counters[1], items);
+        STAMP(12, blockIdx.x == 0 && threadIdx.x == 0);
         // ---- queued contacts, taken from the far end of the grid so that they do not queue up behind the mass items of
         // the low-numbered blocks ----
         PriceArgs pa;
         pa.queue = queue; pa.tabs = tabs; pa.geo = geo; pa.stat = stat; pa.lcontbp = lcontbp; pa.out = s_accb; pa.nfpb = nfpb; pa.par = par;
         price_contacts(pa, nq_total, n_waves - 1 - wave, n_waves, lane);
+        STAMP(13, blockIdx.x == 0 && threadIdx.x == 0);
         __syncthreads();
+        STAMP(14, blockIdx.x == 0 && threadIdx.x == 0);
         for (int i = threadIdx.x; i < K * N_OPS; i += blockDim.x) {
             const long long v = s_accb[i];
             if (v != 0) atomicAdd((unsigned long long*)&out[i], (unsigned long long)v);
@@ -2220,7 +2229,10 @@ int launch_scan(Ctx* h, int fA, const Neigh& nb, int K, int max_id, int dry, hip
 int launch_fin(Ctx* h, int K, int rank, int world, long long* d_q_out, bool publish, hipStream_t st)
 {
     static const int fin_blocks_env = getenv("GRAAL_FIN_BLOCKS") ? atoi(getenv("GRAAL_FIN_BLOCKS")) : 0;
-    const int fin_blocks = fin_blocks_env > 0 ? fin_blocks_env : (h->max_lcont > 0 && h->max_lcont <= 16 ? 32 : 512);
+    // (contigs of thousands of fragments: the mass units are long dependent chains, 8 waves per SIMD keep the VALUs ~60 % busy
+    // where 2 waves reach ~50 % -- 2.8 -> 2.2 ms per step on C5's 7 contigs; with contigs of a few hundred fragments the larger
+    // grid only adds per-block set-up)
+    const int fin_blocks = fin_blocks_env > 0 ? fin_blocks_env : (h->max_lcont > 0 && h->max_lcont <= 16 ? 32 : (h->max_lcont > 1024 ? 2048 : 512));
     FinArgs fa;
     fa.tm_done = h->tm_done; fa.step_hdr = h->step_hdr; fa.counters = (unsigned long long*)(h->d_scalars + 10); fa.queue = h->queue;
     fa.tabs = h->tabs; fa.geo = h->geo; fa.stat = h->stat_frag; fa.acc = h->d_acc; fa.sync = h->d_sync;
