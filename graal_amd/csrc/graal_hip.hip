@@ -735,9 +735,11 @@ __device__ unsigned long long g_stamps[32];
 #define STAMP(i, cond) do { if (cond) g_stamps[i] = wall_clock64(); } while (0)
 __device__ unsigned long long g_blk[4096 * 4]; // per block of k_scan: start, past prologue, loop done
 #define STAMP_BLK(j, cond) do { if (cond) g_blk[4 * blockIdx.x + (j)] = wall_clock64(); } while (0)
+#define STAMP_FBLK(j, cond) do { if ((cond) && blockIdx.x < 2048) g_blk[4 * (2048 + blockIdx.x) + (j)] = wall_clock64(); } while (0) // k_fin's blocks
 #else
 #define STAMP(i, cond) do { } while (0)
 #define STAMP_BLK(j, cond) do { } while (0)
+#define STAMP_FBLK(j, cond) do { } while (0)
 #endif
 
 // exclusive prefix sum of vals[0..n) into out[0..n) and the total into out[n]; vals / out in LDS.  Executed by ONE wave
@@ -1621,6 +1623,7 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
     __shared__ long long s_accb[MAXK * N_OPS];
     for (int i = threadIdx.x; i < MAXK * N_OPS; i += blockDim.x) s_accb[i] = 0;
     STAMP(16, blockIdx.x == 0 && threadIdx.x == 0);
+    STAMP_FBLK(0, threadIdx.x == 0);
     const unsigned long long nq_total = counters[2]; // written by k_scan, the previous kernel on the stream
     // ---- wait for the tables (bounded spin: every wave reaches the exit even if k_tm never ran).  The word k_tm
     // releases carries the neighbour's work list header with the sequence number: seq << 32 | priced << 31 | n_items ----
@@ -1676,6 +1679,7 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
         __syncthreads();
         const int total_units = s_ubase[K];
         STAMP(11, blockIdx.x == 0 && threadIdx.x == 0);
+        STAMP_FBLK(1, threadIdx.x == 0);
         // (static deal.  Handing the units out through one global counter -- they differ by orders of magnitude, and the slowest
         // block of a C2 step ends 100 us after the typical one -- was measured: 2,048 waves queueing on one address cost more
         // than the imbalance, 175 -> 201 us per step.)
@@ -1763,8 +1767,10 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
         pa.queue = queue; pa.tabs = tabs; pa.geo = geo; pa.stat = stat; pa.lcontbp = lcontbp; pa.out = s_accb; pa.nfpb = nfpb; pa.par = par;
         price_contacts(pa, nq_total, n_waves - 1 - wave, n_waves, lane);
         STAMP(13, blockIdx.x == 0 && threadIdx.x == 0);
+        STAMP_FBLK(2, threadIdx.x == 0);
         __syncthreads();
         STAMP(14, blockIdx.x == 0 && threadIdx.x == 0);
+        STAMP_FBLK(3, threadIdx.x == 0);
         for (int i = threadIdx.x; i < K * N_OPS; i += blockDim.x) {
             const long long v = s_accb[i];
             if (v != 0) atomicAdd((unsigned long long*)&out[i], (unsigned long long)v);
@@ -2790,7 +2796,10 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     ta.flags = h->d_flags;
     ta.sync = h->d_sync; ta.n_scan_blocks = scan_grid(h);
     ta.done = scan_done_counter() ? h->d_sync + 8 : nullptr; ta.done_target = h->scan_done_total + (unsigned long long)scan_grid(h);
-    ta.host_res = (h->publish && (world == 1 || h->x_host) && !no_finisher && h->finisher_ok && !h->has_rep) ? h->res_dev : nullptr;
+    // (late stage -- a few long contigs hold nearly every fragment: nearly every step needs k_fin anyway, so it is launched
+    // right behind the scan instead of after k_tm's verdict has made the round trip through the host, ~10 us per step)
+    const bool late_stage = h->max_lcont > 128 && (long long)h->n_contigs * 64 < (long long)h->n;
+    ta.host_res = (h->publish && (world == 1 || h->x_host) && !no_finisher && h->finisher_ok && !h->has_rep && !late_stage) ? h->res_dev : nullptr;
     // a generous multiple of the time the streaming pass needs at 2 TB/s, plus launch slack
     ta.wait_ticks = (int)std::min<long long>(100ll * 50 + (long long)(4.0 * 4.0 * (double)h->nnz / 2.0e12 * 1.0e8), 1ll << 30);
     ta.counters = (unsigned long long*)(h->d_scalars + 10); ta.queue = h->queue; ta.stat = h->stat_frag;

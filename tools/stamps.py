@@ -44,6 +44,14 @@ for f in rng.randint(0, NB, size=300):
     bs = np.zeros(4096 * 4, dtype=np.uint64)
     assert L.graal_debug_block_stamps(smp.engine._h, bs.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))) == 0
     nblk = int(os.environ.get("GRAAL_SCAN_BLOCKS", 512))
+    fb = bs.reshape(4096, 4)[2048:2048 + 512].astype(np.float64)
+    if C2 and n == 250 and fb[:, 0].max() > 0:   # k_fin's blocks: start, unit list built, wave 0 done, whole block done
+        fb = (fb - t0) * 0.01
+        for j, name in enumerate(("start", "unit list built", "wave 0: units + contacts done", "block done")):
+            v = np.sort(fb[:, j])
+            print("k_fin blocks, %-30s min %7.1f  median %7.1f  p90 %7.1f  max %7.1f us" % (name, v[0], v[len(v) // 2], v[int(0.9 * len(v))], v[-1]))
+        late = np.argsort(fb[:, 3])[-8:]
+        print("the 8 latest blocks:", late.tolist(), "done at", np.round(fb[late, 3], 1).tolist(), "their wave 0 at", np.round(fb[late, 2], 1).tolist())
     bs = bs.reshape(4096, 4)[:nblk].astype(np.float64)
     if n == 250:
         st0 = np.sort((bs[:, 0] - t0) * 0.01)
