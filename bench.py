@@ -14,6 +14,10 @@ the ranks of the node and every host adds them up; the same region is then timed
 buffer instead, reported as `exchange_alt`).  Inputs are resident in HBM; proposals are drawn beforehand.  With N GPUs the SAME
 contact list is sharded N ways (strong scaling).
 
+Extra fields: `full_mcmc_step_ms` (scoring + sampling + commit + relabel + statistics), `late_stage` (the scoring phase on the
+same map with its 7 original contigs -- thousands of mass work items and millions of queued contacts per step, sharded over
+the ranks), `exchange_alt` (N > 1).
+
 Output: one JSON line on rank 0 (contract in the task statement) with `roofline` (fused scan kernel: algorithmic bytes
 = 4 B x contacts (row words) + n/8 B (bitmap) + 64 B x queued contacts per launch; duration = HIP event pairs around
 every 8th launch of the timed region, on the engine's stream) and `cpu_baseline`
@@ -99,6 +103,7 @@ def main():
     ap.add_argument("--mcmc-warmup", type=int, default=int(os.environ.get("GRAAL_BENCH_MCMC_WARMUP", 2000)))
     ap.add_argument("--neighbours", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-late-stage", action="store_true", help="skip the extra measurement on the map's 7 original contigs")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                                                       "the multi-rank code path with several ranks on ONE GPU)")
     ap.add_argument("--layout", choices=("exploded", "original"), default="exploded",
@@ -125,6 +130,7 @@ def main():
 
     t_gen = time.perf_counter()
     P = synth.make_problem(n_bins=args.n_bins, nnz=args.nnz, n_sub=1, seed=20141217)
+    soa_original = P["S_o_A_frags"]
     if args.layout == "exploded":
         P["S_o_A_frags"] = exploded_layout(P)
     t_gen = time.perf_counter() - t_gen
@@ -208,6 +214,43 @@ def main():
     torch.cuda.synchronize()
     full_step_s = (time.perf_counter() - t1) / n_full
 
+    # ---- extra: the same map in its LATE stage (the 7 original contigs of 2.7-6.8k fragments; every step prices thousands of
+    # expected-mass work items and millions of queued contacts, all of it sharded over the ranks) -- reported next to the
+    # headline, which is the short-contig regime SURVEY 8d defines ----------------------------------------------------
+    late = None
+    if args.layout == "exploded" and not args.no_late_stage:
+        P2 = dict(P)
+        P2["S_o_A_frags"] = soa_original
+        rng2 = np.random.RandomState(20141217)
+        smp2 = build_sampler(P2, rng2, group, local if world > 1 else 0)
+        smp2.init_likelihood()
+        max_id2 = smp2.modify_gl_cuda_buffer(0)
+        props2 = []
+        for f in rng2.randint(0, n, size=3 + 12):
+            nb = smp2.return_neighbours(int(f), K)
+            nb.sort()
+            props2.append((int(f), nb))
+        for f, nb in props2[:3]:
+            smp2._candidate_deltas(f, nb, max_id2)
+        sync_all()
+        tl = time.perf_counter()
+        n_cand2 = 0
+        for f, nb in props2[3:]:
+            smp2._candidate_deltas(f, nb, max_id2)
+            n_cand2 += 13 * len(nb)
+        sync_all()
+        tl = time.perf_counter() - tl
+        if world > 1:
+            t = torch.tensor([tl], dtype=torch.float64, device="cuda")
+            td.all_reduce(t, op=td.ReduceOp.MAX)
+            tl = float(t.cpu()[0])
+        c2 = smp2.engine.last_counters()
+        st2 = smp2.engine.layout_stats()
+        late = {"workload": "same map, its %d original contigs (longest %d fragments)" % (int(st2[0]), int(st2[4])),
+                "value": n_cand2 / tl, "unit": "candidate logL evals/s", "ms_per_step": 1e3 * tl / len(props2[3:]), "steps": len(props2[3:]),
+                "queued_contacts_last_step_this_rank": int(c2[2]), "mass_items_last_step_this_rank": int(c2[3])}
+        smp2.free_gpu()
+
     if rank == 0:
         nnz_local = smp.engine.nnz
         # what the streaming pass must read: the row word of every contact (4 B), the affected-fragment bitmap
@@ -259,6 +302,8 @@ def main():
         }
         if alt is not None:
             out["exchange_alt"] = alt
+        if late is not None:
+            out["late_stage"] = late
         if world == 1 and not args.no_cpu_baseline:
             smp.gpu_vect_frags.copy_from_gpu()
             out["cpu_baseline"] = cpu_baseline(P, smp.gpu_vect_frags.as_dict())

@@ -26,6 +26,20 @@ def shard_range(nnz, rank, world):
     return (nnz * rank) // world, (nnz * (rank + 1)) // world
 
 
+def shard_take(nnz, rank, world, block=4096):
+    """Indices of the (row, col)-sorted contact list owned by `rank`: blocks of `block` consecutive contacts dealt round robin.
+    (A contiguous slice per rank -- shard_range -- is balanced in bytes but not in work: the contacts a step has to PRICE are
+    those of the one or two affected contigs, a contiguous row range, i.e. one rank's slice.)  The order inside a shard is
+    still (row, col), which is all the streaming pass wants."""
+    nnz, rank, world, block = int(nnz), int(rank), int(world), int(block)
+    assert world >= 1 and 0 <= rank < world and block >= 1
+    if world == 1:
+        return slice(0, nnz)
+    b = np.arange(rank, (nnz + block - 1) // block, world, dtype=np.int64)
+    idx = (b[:, None] * block + np.arange(block, dtype=np.int64)[None, :]).ravel()
+    return idx[idx < nnz]
+
+
 class Group:
     """Thin wrapper over torch.distributed (RCCL for CUDA tensors, gloo for CPU tensors); world == 1 needs no
     process group at all."""

@@ -344,13 +344,13 @@ class sampler(object):
             self.sub_coo, obs_rows = split_repeat_observations(self.sub_coo, self.np_sub_frags_id, self.id_frag_duplicated,
                                                                int(self.init_n_sub_frags))
             self.engine.upload_repeats(self.id_frag_duplicated, self.frag_dispatcher, self.collector_id_repeats, obs_rows)
-        lo, hi = gdist.shard_range(len(self.sub_coo[0]), group.rank, group.world)
+        take = gdist.shard_take(len(self.sub_coo[0]), group.rank, group.world)
         counts = np.asarray(self.sub_coo[2])
         if np.all(counts == np.round(counts)) and (len(counts) == 0 or counts.max() < 2 ** 24):
             counts = counts.astype(np.int32)
         else:
             counts = counts.astype(np.float32)   # the reference's observation type (blacklist fill: non-integer)
-        self.engine.upload_contacts(self.sub_coo[0][lo:hi], self.sub_coo[1][lo:hi], counts[lo:hi])
+        self.engine.upload_contacts(self.sub_coo[0][take], self.sub_coo[1][take], counts[take])
         n = int(self.n_new_frags)
         soa = {k: np.array(S_o_A_frags[k], dtype=np.int32, copy=True) for k in FIELDS if k != "ori"}
         soa["ori"] = np.ones((n,), dtype=np.int32)  # cuda_lib_gl.py:244,259

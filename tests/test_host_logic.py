@@ -165,6 +165,20 @@ def test_shard_ranges_partition_the_contact_list():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_shard_take_deals_blocks_round_robin():
+    for nnz in (0, 1, 4095, 4096, 4097, 100_003):
+        for world in (1, 2, 3, 8):
+            parts = [np.arange(nnz)[gdist.shard_take(nnz, r, world)] for r in range(world)]
+            allidx = np.concatenate(parts) if parts else np.zeros(0, int)
+            assert len(allidx) == nnz and len(np.unique(allidx)) == nnz          # a partition
+            for p in parts:
+                assert np.all(np.diff(p) > 0)                                    # each shard keeps the list's order
+            sizes = [len(p) for p in parts]
+            assert max(sizes) - min(sizes) <= 4096
+            if world > 1 and nnz > 8 * 4096:
+                assert parts[1][0] == 4096 and parts[0][4096] == world * 4096    # blocks of 4096, dealt round robin
+
+
 def test_blacklist_fill_equals_the_dense_fill():
     """blacklist_fill on COO lists == the reference's dense overwrite (cuda_lib_gl.py:161-172)."""
     from graal_amd.sampler import as_coo_upper, blacklist_fill
