@@ -1027,6 +1027,7 @@ __device__ __forceinline__ void price_contacts(const PriceArgs& pa, unsigned lon
         const unsigned long long e = e0 + (lane >> 4);
         if (e >= nq_total || op >= N_OPS) continue;
         const QEntry qe = pa.queue[e];
+        if (qe.rel == 0) continue; // (a reserved slot whose contact failed the scan's third test)
         const int fx = qe.fx, fy = qe.fy, slx = qe.slots & 3, sly = (qe.slots >> 2) & 3;
         // speculative: geometry, statistics and the transforms of the first neighbour are needed by (nearly) every queued
         // contact -- requested together with the relation masks instead of one dependent load after the other
@@ -1495,12 +1496,27 @@ __global__ __launch_bounds__(1024, (G == 4 ? 8 : 4)) void k_scan(ScanArgs sa, in
             }
             hit &= hit2;
         }
+        // Queue slots for ALL doubly-affected contacts of this wave iteration are reserved with one atomic (the few that the
+        // third test rejects leave entries with an empty neighbour mask behind, which the pricing skips).  One reservation per
+        // PASS of the loop below -- up to 16 per iteration, 10^5 per step when two long contigs are affected -- made the tail
+        // of the queue the bottleneck of the late stage: same-address atomics with return, ~0.7 ms of a 0.8 ms scan.
+        unsigned slot = 0;
+        if (!dry && __ballot(hit != 0) != 0) {
+            const unsigned mine = (unsigned)__popc(hit);
+            unsigned incl = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const unsigned y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
+            unsigned long long base = 0;
+            if (lane == 63) base = atomicAdd(&counters[2], (unsigned long long)incl);
+            slot = (unsigned)__shfl(base, 63, 64) + incl - mine;
+        }
         // third test: one doubly-affected contact per lane and pass (a loop, not a 16-fold unrolled body: rare when contigs
         // are short)
         while (__ballot(hit != 0) != 0) {
             unsigned rel = 0, q_ci = 0, q_cj = 0;
             int j = 0, q_fx = 0, q_fy = 0, q_slots = 0;
             long long cidx = 0;
+            const bool cidx_valid = hit != 0; // this lane examines a contact in this pass
             if (hit) {
                 j = __ffs((int)hit) - 1;
                 hit &= hit - 1;
@@ -1526,20 +1542,14 @@ __global__ __launch_bounds__(1024, (G == 4 ? 8 : 4)) void k_scan(ScanArgs sa, in
                 }
             }
             if (dry) { n_rel += __popc(rel); continue; }
-            const unsigned long long bal = __ballot(rel != 0);
-            if (bal) {
-                const int leader = __ffsll((long long)bal) - 1;
-                unsigned long long base = 0;
-                if (lane == leader) base = atomicAdd(&counters[2], (unsigned long long)__popcll(bal));
-                base = __shfl(base, leader, 64);
+            if (cidx_valid) {
+                // device-scope (write-through) stores: the entry must reach the reader -- possibly a block of k_tm on
+                // another XCD -- without an L2 write-back fence, which costs this kernel several microseconds
+                unsigned long long* qw = reinterpret_cast<unsigned long long*>(queue + slot);
+                slot += 1;
+                __hip_atomic_store(qw + 0, (unsigned long long)(unsigned)cidx | ((unsigned long long)rel << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (rel) {
-                    // device-scope (write-through) stores: the entry must reach the reader -- possibly a block of k_tm on
-                    // another XCD -- without an L2 write-back fence, which costs this kernel several microseconds
-                    // (rank among the set lanes below this one: mbcnt, no loop-invariant lane mask to keep in registers)
-                    const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-                    unsigned long long* qw = reinterpret_cast<unsigned long long*>(queue + base + below);
                     const unsigned cnt_w = (unsigned)sa.cnt[cidx];
-                    __hip_atomic_store(qw + 0, (unsigned long long)(unsigned)cidx | ((unsigned long long)rel << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(qw + 1, (unsigned long long)q_ci | ((unsigned long long)q_cj << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(qw + 2, (unsigned long long)(unsigned)q_fx | ((unsigned long long)(unsigned)q_fy << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(qw + 3, (unsigned long long)cnt_w | ((unsigned long long)(unsigned)q_slots << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -17,14 +17,16 @@ if C2:
                            mean_len_bp=660.0 * 27 / 3, accu=9)
 else:
     P = synth.make_problem(n_bins=50000, nnz=20_000_000, n_sub=1, seed=20141217)
-    P["S_o_A_frags"] = bench.exploded_layout(P)
+    if os.environ.get("STAMPS_SHAPE") != "c5late":   # c5late: the 7 original contigs
+        P["S_o_A_frags"] = bench.exploded_layout(P)
 NB = P["n_frags"]
 rng = np.random.RandomState(20141217)
 smp = bench.build_sampler(P, rng, None, 0)
 smp.init_likelihood()
 order = np.arange(NB, dtype=np.int32); rng.shuffle(order)
 order = np.concatenate([order] * (1 + 2000 // NB))
-for i in order[:2000]:
+LATE = os.environ.get("STAMPS_SHAPE") == "c5late"
+for i in order[:(20 if LATE else 2000)]:
     smp.step_max_likelihood(int(i), 5)
 max_id = smp.modify_gl_cuda_buffer(0)
 L = lib.load()
@@ -32,7 +34,7 @@ L.graal_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64
 L.graal_debug_block_stamps.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
 blk_acc = np.zeros(6)
 acc = np.zeros(32); n = 0; cnt32 = np.zeros(32)
-for f in rng.randint(0, NB, size=300):
+for f in rng.randint(0, NB, size=(40 if LATE else 300)):
     nb = smp.return_neighbours(int(f), 5); nb.sort()
     smp._candidate_deltas(int(f), nb, max_id)
     st = np.zeros(32, dtype=np.uint64)
@@ -44,8 +46,8 @@ for f in rng.randint(0, NB, size=300):
     bs = np.zeros(4096 * 4, dtype=np.uint64)
     assert L.graal_debug_block_stamps(smp.engine._h, bs.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))) == 0
     nblk = int(os.environ.get("GRAAL_SCAN_BLOCKS", 512))
-    fb = bs.reshape(4096, 4)[2048:2048 + 512].astype(np.float64)
-    if C2 and n == 250 and fb[:, 0].max() > 0:   # k_fin's blocks: start, unit list built, wave 0 done, whole block done
+    fb = bs.reshape(4096, 4)[2048:2048 + (2048 if LATE else 512)].astype(np.float64)
+    if (C2 or LATE) and n == (30 if LATE else 250) and fb[:, 0].max() > 0:   # k_fin's blocks: start, unit list built, wave 0 done, whole block done
         fb = (fb - t0) * 0.01
         for j, name in enumerate(("start", "unit list built", "wave 0: units + contacts done", "block done")):
             v = np.sort(fb[:, j])
