@@ -6,7 +6,7 @@ TAG=${1:-r01}
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
-ARGS="bench.py --steps 100 --warmup 10 --no-cpu-baseline"
+ARGS="bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-late-stage"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
 echo "trace rc=$?"
 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 $ARGS > $OUT/fetch.log 2>&1
