@@ -203,13 +203,13 @@ def legacy_choice_one(rng, p):
     return int(cdf.searchsorted(rng.random_sample(1), side='right')[0])
 
 
-def legacy_choice_without_replacement(rng, a, size, p):
+def legacy_choice_without_replacement(rng, a, size, p, p_list=None):
     """``RandomState.choice(a, size, replace=False, p=p)`` for a handful of entries (the neighbour proposal draws <= 10 of
     10): numpy's legacy algorithm -- draw ``size - found`` uniforms, inverse CDF of p with the found entries zeroed, keep
     the first occurrences, repeat -- on Python floats (the float32 -> float64 conversion, the running sum and the division
     are the same IEEE operations as numpy's ``cumsum`` / ``/=``).  Anything unusual (size 0, p not summing to 1) is left
     to numpy, so its errors and corner cases stay its own."""
-    pl = [float(v) for v in p]
+    pl = [float(v) for v in p] if p_list is None else list(p_list)
     if size < 1 or size > len(pl) or not (abs(sum(pl) - 1.0) < 1e-4) or min(pl) < 0.0 or sum(1 for v in pl if v > 0) < size:
         return rng.choice(a, size, p=p, replace=False)
     found = []
@@ -648,21 +648,29 @@ class sampler(object):
         xk, pk = neighbour_distributions(self.bin_coo[0], self.bin_coo[1], self.bin_coo[2], int(self.n_frags),
                                          self.n_neighbors)
         self.distri_frags = {"xk": xk, "pk": pk}
+        self._row_cache, self._copies_cache = {}, {}
 
     def return_neighbours(self, id_fA, delta0):
         """``cuda_lib_gl.py:2295-2331`` (no repeats, no blacklist: the expansion loops are identities)."""
-        ori_id = self.id_d[id_fA]
+        ori_id = int(self.id_d[id_fA])
         delta = min(self.n_neighbors, delta0)
         distri = self.distri_frags["pk"][ori_id]
-        n_max_candidates = min(delta, np.nonzero(distri != 0)[0].shape[0])
-        init_id = legacy_choice_without_replacement(self.rng, self.distri_frags["xk"][ori_id], n_max_candidates, distri)
+        row = self._row_cache.get(ori_id)     # per bin, built on first use: (#non-zero entries, the row as Python floats)
+        if row is None:
+            row = self._row_cache[ori_id] = (int(np.nonzero(distri != 0)[0].shape[0]), [float(v) for v in distri])
+        n_max_candidates = min(delta, row[0])
+        init_id = legacy_choice_without_replacement(self.rng, self.distri_frags["xk"][ori_id], n_max_candidates, distri, row[1])
         out = []
-        if int(ori_id) in self._dup_set:      # the other copies of a repeated fragment are candidates too (:2314-2318)
+        if ori_id in self._dup_set:           # the other copies of a repeated fragment are candidates too (:2314-2318)
             d = self.frag_dispatcher[ori_id]
             out.extend(int(x) for x in np.setdiff1d(self.collector_id_repeats[d[0]:d[1]], id_fA))
-        for id_fB in init_id:                 # every copy of a proposed bin (:2320-2322)
-            d = self.frag_dispatcher[id_fB]
-            out.extend(int(x) for x in self.collector_id_repeats[d[0]:d[1]])
+        copies = self._copies_cache
+        for id_fB in init_id.tolist():        # every copy of a proposed bin (:2320-2322)
+            c = copies.get(id_fB)
+            if c is None:
+                d = self.frag_dispatcher[id_fB]
+                c = copies[id_fB] = tuple(int(x) for x in self.collector_id_repeats[d[0]:d[1]])
+            out.extend(c)
         black = self._black_set
         return [x for x in out if x not in black]   # cuda_lib_gl.py:2326-2329
 
