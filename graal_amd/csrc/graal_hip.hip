@@ -2180,10 +2180,13 @@ int refresh(Ctx* h)
 constexpr int MAX_SCAN_BLOCKS = 4096;
 constexpr int SCAN_LDS_MAX = 48 * 1024; // affected bitmap of k_scan: 1 bit per contact-list id -> <= 393,216 ids
 
-int scan_threads_cfg()
+// threads per block of the streaming pass: 1024 (two blocks per CU) for the lists it is built for; a list of a few hundred
+// thousand contacts (a yeast-sized genome at 3 sub-fragments per bin) would fill only a handful of such blocks, each marking
+// the whole affected set in its prologue: 256-thread blocks there (C2 stand-in: 177 -> 165 us per step)
+int scan_threads_cfg(const Ctx* h)
 {
-    static const int v = getenv("GRAAL_SCAN_THREADS") ? atoi(getenv("GRAAL_SCAN_THREADS")) : 1024;
-    return v;
+    static const int v = getenv("GRAAL_SCAN_THREADS") ? atoi(getenv("GRAAL_SCAN_THREADS")) : 0;
+    return v > 0 ? v : (h->nnz < 2000000 ? 256 : 1024);
 }
 
 int scan_groups_cfg()
@@ -2209,14 +2212,14 @@ int scan_grid(const Ctx* h)
     static const int scan_blocks = getenv("GRAAL_SCAN_BLOCKS") ? atoi(getenv("GRAAL_SCAN_BLOCKS"))
                                                                : (scan_groups_cfg() == 8 ? 256 - 8 : 256 * 2 - 16);
     const long long groups = (h->nnz >> 2) + 1;
-    const long long per_block = (long long)scan_groups_cfg() * scan_threads_cfg(); // groups one block takes per iteration
+    const long long per_block = (long long)scan_groups_cfg() * scan_threads_cfg(h); // groups one block takes per iteration
     return (int)std::max<long long>(1, std::min<long long>((groups + per_block - 1) / per_block, scan_blocks));
 }
 
 // the streaming pass (see k_scan); dry = timing replay that counts relevant contacts but queues nothing
 int launch_scan(Ctx* h, int fA, const Neigh& nb, int K, int max_id, int dry, hipStream_t st)
 {
-    const int nbk = scan_grid(h), scan_threads = scan_threads_cfg();
+    const int nbk = scan_grid(h), scan_threads = scan_threads_cfg(h);
     const size_t shm = (size_t)((h->n_sub_total + 31) / 32 + 2) * 4;
     if (shm > (size_t)SCAN_LDS_MAX) return fail(h, GRAAL_E_UNSUPPORTED, "more than 393,216 sub-fragments: the affected bitmap does not fit the scan's LDS budget");
     ScanArgs sa;
