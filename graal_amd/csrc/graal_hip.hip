@@ -633,8 +633,16 @@ __global__ __launch_bounds__(256) void k_full_nnz(const int* __restrict__ row, c
         }
         acc += to_q((double)__int_as_float(cnt[i]) * ln_ex); // counts are stored as float32 (the reference's obs type)
     }
+    // one atomic per BLOCK: 16,384 waves adding to the one accumulator were ~165 us of this kernel's 270 (same-address atomics
+    // go through at ~10 ns each; found by an ablation that kept nothing but the three streaming loads and still took 210 us)
+    __shared__ long long s_part[4];
     acc = wave_sum_ll(acc);
-    if ((threadIdx.x & 63) == 0 && acc != 0) atomicAdd((unsigned long long*)out, (unsigned long long)acc);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const long long v = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        if (v != 0) atomicAdd((unsigned long long*)out, (unsigned long long)v);
+    }
 }
 
 // cis correction of the expected mass for the current layout: one thread per fragment x (in contig order),
@@ -2756,7 +2764,7 @@ int graal_eval_full_q(graal_ctx* h, int64_t q_out[2])
     if (h->has_rep) CK(hipMemsetAsync(h->d_scalars + 17, 0, sizeof(long long), h->stream));
     SoaPtr s = h->soa[h->cur];
     if (h->nnz) {
-        const int nb = (int)std::min<long long>((h->nnz + 255) / 256, 256 * 16);
+        const int nb = (int)std::min<long long>((h->nnz + 255) / 256, 256 * 8);
         k_full_nnz<<<nb, 256, 0, h->stream>>>(h->row, h->col, h->cnt, h->nnz, h->sub2bin, h->geo, h->stat_frag, s.p[F_LCONTBP],
                                                h->nfpb, h->par, h->ln_lut_n, h->d_scalars + 8);
     }
