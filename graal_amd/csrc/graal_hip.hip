@@ -699,8 +699,14 @@ __global__ __launch_bounds__(256) void k_full_mass(int n, const int* __restrict_
         live = live && any != 0 && k0 + 16 <= remaining;
     }
     (void)contig_off;
+    __shared__ long long s_part[4]; // (one atomic per block, as in k_full_nnz)
     const long long q = wave_sum_ll(accq);
-    if (lane == 0 && q != 0) atomicAdd((unsigned long long*)out, (unsigned long long)q);
+    if (lane == 0) s_part[threadIdx.x >> 6] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const long long v = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        if (v != 0) atomicAdd((unsigned long long*)out, (unsigned long long)v);
+    }
 }
 
 // ------------------------------------------------------------------ candidate tables
@@ -1364,6 +1370,7 @@ __global__ __launch_bounds__(1024, (G == 4 ? 8 : 4)) void k_scan(ScanArgs sa, in
     __shared__ Rec s_rec[MAXK + 1];
     __shared__ int s_cbase[MAXK + 1], s_clen[MAXK + 1], s_pref[MAXK + 2], s_fB[MAXK], s_mates[MAXK + 1][N_MATES];
     __shared__ int s_waves_done;
+    __shared__ unsigned long long s_nrel;
     const int t = threadIdx.x;
     const int lane = t & 63;
     STAMP(8, blockIdx.x == 0 && t == 0 && !dry);
@@ -1407,7 +1414,7 @@ __global__ __launch_bounds__(1024, (G == 4 ? 8 : 4)) void k_scan(ScanArgs sa, in
 #define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
     constexpr int SMALL_TOTAL = 256; // affected fragments wave 0 marks itself; above that the whole block helps
     if (t < 64) {
-        if (t == 0) { S.live = 0; S.intra = 0; s_waves_done = 0; }
+        if (t == 0) { S.live = 0; S.intra = 0; s_waves_done = 0; s_nrel = 0; }
         for (int i = t; i < sa.bitmap_words; i += 64) s_bm[i] = 0;
         if (t <= K) s_cbase[t] = my_cbase;
         if (t < MAXK) s_fB[t] = my_fB;
@@ -1580,7 +1587,9 @@ __global__ __launch_bounds__(1024, (G == 4 ? 8 : 4)) void k_scan(ScanArgs sa, in
     STAMP(10, blockIdx.x == 0 && t == 0 && !dry);
     STAMP_BLK(2, t == 0 && !dry);
     n_rel = (unsigned long long)wave_sum_ll((long long)n_rel);
-    if (lane == 0 && n_rel && !dry) atomicAdd(&counters[0], n_rel);
+    // (the count of relevant pairs is a statistic: it goes through LDS and the block's last wave adds it once -- one global
+    // atomic per WAVE on that one word was ~80 us of a late-stage scan)
+    if (lane == 0 && n_rel && !dry) atomicAdd(&s_nrel, n_rel);
     if (dry == 0) {
         // completion flag for k_tm's finishing block: one word (on its own cache line) per block holding the step's
         // sequence number -- a shared counter would serialise 512 device-scope atomics at the memory side.  No block
@@ -1590,6 +1599,8 @@ __global__ __launch_bounds__(1024, (G == 4 ? 8 : 4)) void k_scan(ScanArgs sa, in
         int last = 0;
         if (lane == 0) last = (atomicAdd(&s_waves_done, 1) == (int)(blockDim.x >> 6) - 1);
         if (last) {
+            const unsigned long long nr = atomicAdd(&s_nrel, 0ull);
+            if (nr) atomicAdd(&counters[0], nr);
             if (sa.done) __hip_atomic_fetch_add(sa.done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (result unused: no-return atomic)
             else __hip_atomic_store(sa.flags + FLAG_STRIDE * blockIdx.x, sa.seq32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -1639,7 +1650,9 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
     // to the global accumulators, a step with millions of queued contacts issued ~10^8 atomics on 65 addresses -- the VALUs
     // sat idle 91 % of a 12 ms step behind them (rocprofv3: SQ_INSTS_VALU against the kernel's duration).
     __shared__ long long s_accb[MAXK * N_OPS];
+    __shared__ long long s_items;
     for (int i = threadIdx.x; i < MAXK * N_OPS; i += blockDim.x) s_accb[i] = 0;
+    if (threadIdx.x == 0) s_items = 0;
     STAMP(16, blockIdx.x == 0 && threadIdx.x == 0);
     STAMP_FBLK(0, threadIdx.x == 0);
     const unsigned long long nq_total = counters[2]; // written by k_scan, the previous kernel on the stream
@@ -1777,7 +1790,7 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
                 }
             }
         }
-        if (lane == 0 && items) atomicAdd(&counters[1], items);
+        if (lane == 0 && items) atomicAdd((unsigned long long*)&s_items, items); // (a statistic: one global atomic per block, below)
         STAMP(12, blockIdx.x == 0 && threadIdx.x == 0);
         // ---- queued contacts, taken from the far end of the grid so that they do not queue up behind the mass items of
         // the low-numbered blocks ----
@@ -1793,6 +1806,7 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
             const long long v = s_accb[i];
             if (v != 0) atomicAdd((unsigned long long*)&out[i], (unsigned long long)v);
         }
+        if (threadIdx.x == 255 && s_items) atomicAdd(&counters[1], (unsigned long long)s_items);
     }
     // ---- completion ticket: every block releases its atomics, the last one hands the sums out ----
     __shared__ int s_last;
