@@ -147,7 +147,8 @@ int graal_set_finisher(graal_ctx* h, int32_t enabled);
 
 /* commit candidate `op` of (fA, fB); replaces test_copy_struct (cuda_lib_gl.py:1156-1180).
  * *n_stale = fragments that hit the reference's unwritten paste branch (expected 0); NULL = do not wait for the
- * commit (the count is then reported by the next graal_begin_step).  The geometry index is stale until then. */
+ * commit (the count is then reported by the next graal_begin_step).  The geometry index is stale until then.  The commit
+ * kernel also publishes the statistics of the layout it writes, so the next graal_begin_step launches no statistics kernel. */
 int graal_apply_move(graal_ctx* h, int32_t fA, int32_t fB, int32_t op, int32_t max_id, int32_t* n_stale);
 
 /* Genome distance to the initial genome, dist_inter_genome (cuda_lib_gl.py:475-541: a Python loop over all fragments after
@@ -172,7 +173,8 @@ int graal_scan_times(graal_ctx* h, int32_t n, float* out_ms);
  * event overhead of graal_last_timing is amortised away. */
 int graal_time_scan(graal_ctx* h, int32_t K, int32_t reps, float* avg_ms);
 /* counters of the last call: out[0]=contacts scanned out[1]=relevant (contact, neighbour) pairs
- * out[2]=queued (relevant) contacts out[3]=mass work items */
+ * out[2]=queue slots (contacts with both ends in an affected contig; the few the third test rejects leave empty entries)
+ * out[3]=mass work items (task x 64-fragment chunk) */
 int graal_last_counters(graal_ctx* h, int64_t out[4]);
 
 #ifdef __cplusplus
