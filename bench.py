@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- candidate logL evaluations per second of the per-move likelihood scan (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W
+
+N = 1 runs in this process.  N > 1 with WORLD_SIZE unset starts the N ranks itself: a child
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`
+is spawned BEFORE anything here touches the GPU, its output is relayed and its exit code returned; under an external
+torchrun (WORLD_SIZE set) the process is one of the ranks.
 
 Workload (BASELINE.json configs[4], SURVEY.md section 8d "C5"): synthetic 50,000-fragment / 20,000,000-contact map,
 generator seed 20141217; layout = exploded genome + 2,000 real MCMC warm-up steps (K = 5 neighbours).  One timed
@@ -14,18 +17,22 @@ the ranks of the node and every host adds them up; the same region is then timed
 buffer instead, reported as `exchange_alt`).  Inputs are resident in HBM; proposals are drawn beforehand.  With N GPUs the SAME
 contact list is sharded N ways (strong scaling).
 
-Extra fields: `full_mcmc_step_ms` (scoring + sampling + commit + relabel + statistics), `late_stage` (the scoring phase on the
-same map with its 7 original contigs -- thousands of mass work items and millions of queued contacts per step, sharded over
-the ranks), `exchange_alt` (N > 1).
+Extra fields: `full_mcmc_step_ms` (scoring + sampling + commit + relabel + statistics), `full_eval_ms` (one full likelihood
+evaluation: what a nuisance-parameter step adds to every MCMC step), `full_mcmc_step_sample_param_ms`, `late_stage` (the scoring
+phase on the same map with its 7 original contigs -- thousands of mass work items and millions of queued contacts per step,
+sharded over the ranks), `exchange_alt` (N > 1).
 
 Output: one JSON line on rank 0 (contract in the task statement) with `roofline` (fused scan kernel: algorithmic bytes
-= 4 B x contacts (row words) + n/8 B (bitmap) + 64 B x queued contacts per launch; duration = HIP event pairs around
-every 8th launch of the timed region, on the engine's stream) and `cpu_baseline`
-(numpy re-score of the same sparse likelihood on the host, N = 1 only).
+= 4 B x contacts (row words) + n/8 B (bitmap) + 64 B x queued contacts per launch; duration = HIP event pairs around the
+launches of the timed region, on the engine's stream -- every launch when --steps <= 64, else every 8th; plus
+`roofline.hbm_control`: the same kernel, same layout, same proposals over a list whose row array (480 MB) cannot stay in the
+256 MiB Infinity Cache, so HBM-vs-cache is settled by measurement) and `cpu_baseline` (numpy re-score of the same sparse
+likelihood on the host, N = 1 only).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -93,6 +100,60 @@ def cpu_baseline(P, state, budget_s=24.0):
                 done, len(P["coo_row"]), dt)}
 
 
+def hbm_control(P, smp, props, max_id, n, repeat):
+    """The Infinity-Cache control of the roofline figure: the SAME kernel, layout and proposals over the contact list with every
+    contact listed `repeat` times (row-sorted still; 6 x 20 M contacts = a 480 MB row array, which cannot stay in the 256 MiB
+    cache between two launches).  Returns the in-step (event pair per launch) and back-to-back durations."""
+    from graal_amd.lib import Engine
+    e = Engine(smp.engine.device)
+    try:
+        e.upload_subfrags(P["np_sub_frags_id"], P["np_sub_frags_len_bp"], P["np_sub_frags_accu"], P["init_n_sub_frags"],
+                          P["mean_squared_frags_per_bin"])
+        e.upload_contacts(np.repeat(P["coo_row"], repeat), np.repeat(P["coo_col"], repeat), np.repeat(P["coo_val"], repeat))
+        e.set_params(P["param_simu"])
+        smp.gpu_vect_frags.copy_from_gpu()
+        e.upload_frags(smp.gpu_vect_frags.as_dict())
+        _, mid = e.begin_step()
+        assert mid == int(max_id)
+        e.set_timing(1)
+        for f, nb in props[:4]:
+            e.eval_candidates(f, nb, mid)
+        use = props[4:4 + 24]
+        t0 = time.perf_counter()
+        for f, nb in use:
+            e.eval_candidates(f, nb, mid)
+        wall = (time.perf_counter() - t0) / max(1, len(use))
+        ms = e.scan_times(len(use))
+        c = e.last_counters()
+        replay_ms = e.time_scan(len(use[-1][1]), reps=20)
+        nnz = int(e.nnz)
+        bytes_per_launch = 4.0 * nnz + n / 8.0 + 64.0 * float(c[2])
+        scan_s = float(np.mean(ms)) * 1e-3
+        return {"contacts": nnz, "row_array_MB": 4.0 * nnz / 1e6, "how": "every contact of the C5 list listed %d times" % repeat,
+                "bytes_per_launch": bytes_per_launch, "avg_launch_ms": scan_s * 1e3, "launches_timed": int(len(ms)),
+                "achieved": bytes_per_launch / scan_s / 1e9, "frac": bytes_per_launch / scan_s / 1e9 / HBM_PEAK_GBS,
+                "back_to_back_replay_ms": replay_ms, "frac_back_to_back_replays": bytes_per_launch / (replay_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "host_wall_per_step_ms": wall * 1e3}
+    finally:
+        e.close()
+
+
+def launch_ranks(args, argv):
+    """--gpus N without a torchrun environment: start the N ranks as a child (this process has not touched the GPU)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "2")
+    p = subprocess.run(cmd, env=env)
+    return p.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,28 +165,55 @@ def main():
     ap.add_argument("--neighbours", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-late-stage", action="store_true", help="skip the extra measurement on the map's 7 original contigs")
+    ap.add_argument("--no-hbm-control", action="store_true", help="skip the Infinity-Cache control of the roofline figure")
+    ap.add_argument("--control-repeat", type=int, default=6, help="hbm_control: list every contact this many times")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                                                       "the multi-rank code path with several ranks on ONE GPU)")
     ap.add_argument("--layout", choices=("exploded", "original"), default="exploded",
                     help="exploded (+ MCMC warm-up) is the BASELINE workload; original = the 7 reference contigs (late-stage regime)")
+    ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / sharding check without a GPU (CPU test-suite)")
     args = ap.parse_args()
 
     from graal_amd import dist as gdist
-    from graal_amd import synth
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args, sys.argv[1:]))
     rank, world, local = gdist.env_world()
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-    import torch
-    if world > 1:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
+
+    if args.dry_run:   # no GPU, no engine: only what the launcher, the rendezvous and the sharding do
+        import torch
         import torch.distributed as td
+        if world > 1:
+            td.init_process_group("gloo")
+        take = gdist.shard_take(args.nnz, rank, world)
+        mine = (take.stop - take.start) if isinstance(take, slice) else len(take)
+        t = torch.tensor([mine], dtype=torch.int64)
+        if world > 1:
+            td.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "contacts": int(t[0]), "contacts_rank0": int(mine)}), flush=True)
+        if world > 1:
+            td.barrier()
+            td.destroy_process_group()
+        return
+
+    from graal_amd import synth
+    import torch
+    td = None
+    if world > 1:
+        import datetime
+        import torch.distributed as td
+        # (a collective that one rank never enters -- e.g. it failed inside the optional late-stage extra -- must not hang
+        # the others for ever: they time out, record the error and still let rank 0 print the headline)
+        tmo = datetime.timedelta(seconds=300)
         if args.backend == "nccl":
             torch.cuda.set_device(local)
-            td.init_process_group("nccl", device_id=torch.device("cuda", local))
+            td.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=tmo)
         else:
             local = 0
             torch.cuda.set_device(0)
-            td.init_process_group(args.backend)
+            td.init_process_group(args.backend, timeout=tmo)
     group = gdist.Group(rank, world)
 
     t_gen = time.perf_counter()
@@ -166,7 +254,16 @@ def main():
         group.barrier()
         torch.cuda.synchronize()
 
-    EVENT_EVERY = 8   # a HIP event pair around k_scan on every 8th step of the timed region (each pair adds gaps)
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        return float(t.cpu()[0])
+
+    # a HIP event pair around k_scan on every step of a short timed region (the driver's 20 steps give 20 samples), on every
+    # 8th step of a long one (each pair adds command-processor marker gaps to that step)
+    EVENT_EVERY = 1 if args.steps <= 64 else 8
     smp.engine.set_timing(EVENT_EVERY)
     for f, nb in props[:args.warmup]:
         smp._candidate_deltas(f, nb, max_id)
@@ -174,15 +271,12 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     for f, nb in props[args.warmup:]:
-        smp._candidate_deltas(f, nb, max_id)   # records one HIP event pair around k_scan on the stream it runs on
+        smp._candidate_deltas(f, nb, max_id)   # records a HIP event pair around k_scan on the stream it runs on
         n_cand += 13 * len(nb)
     sync_all()
     elapsed = time.perf_counter() - t0
     scan_ms = smp.engine.scan_times(max(1, min(args.steps // EVENT_EVERY, 1024)))   # the event pairs of the timed region, read afterwards
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        td.all_reduce(t, op=td.ReduceOp.MAX)
-        elapsed = float(t.cpu()[0])
+    elapsed = max_over_ranks(elapsed)
     counters = smp.engine.last_counters()
     # N > 1: the same timed region once more with the OTHER way of summing the ranks' 13*K int64 values (one all-reduce of a
     # device buffer per step through torch.distributed -- RCCL with the nccl backend), reported next to the default
@@ -196,15 +290,29 @@ def main():
         for f, nb in props[args.warmup:]:
             smp._candidate_deltas(f, nb, max_id)
         sync_all()
-        ta = time.perf_counter() - ta
+        ta = max_over_ranks(time.perf_counter() - ta)
         smp.exchange = "host"
-        t = torch.tensor([ta], dtype=torch.float64, device="cuda")
-        td.all_reduce(t, op=td.ReduceOp.MAX)
-        ta = float(t.cpu()[0])
         alt = {"exchange": "%s all-reduce of a device buffer (graal_eval_candidates_q + torch.distributed)" % args.backend,
                "value": n_cand / ta, "ms_per_step": 1e3 * ta / args.steps}
     # for reference: back-to-back replays of the last step's scan between two events (per-launch event overhead amortised)
     scan_replay_ms = smp.engine.time_scan(len(props[-1][1]), reps=100)
+
+    # ---- Infinity-Cache control of the roofline figure (rank 0's GPU, N = 1) ---------------------------------------
+    control = None
+    if world == 1 and not args.no_hbm_control and args.control_repeat > 1:
+        try:
+            control = hbm_control(P, smp, props, max_id, n, args.control_repeat)
+        except Exception as e:   # an extra: never costs the headline
+            control = {"error": repr(e)}
+
+    # ---- one full likelihood evaluation (every nuisance-parameter step pays one: cuda_lib_gl.py:1986-2017) ---------
+    smp.engine.eval_full_q()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    n_fe = 20
+    for _ in range(n_fe):
+        smp.engine.eval_full_q()
+    full_eval_s = (time.perf_counter() - t1) / n_fe
 
     # ---- full MCMC steps (scoring + sampling + commit + relabel), reported as an extra ----------------------------
     t1 = time.perf_counter()
@@ -213,6 +321,16 @@ def main():
         smp.step_max_likelihood(int(i), K)
     torch.cuda.synchronize()
     full_step_s = (time.perf_counter() - t1) / n_full
+    # the same with the reference GUI's default "sample parameters" (main_gl.py:258-262): one nuisance-parameter Metropolis
+    # step -- one full evaluation under test parameters, plus a scipy fsolve for d_max on the host -- after every MCMC step
+    smp.bins = np.arange(1.0, 41.0, 1.0)
+    t1 = time.perf_counter()
+    n_sp = min(50, max(1, args.steps))
+    for i in order[args.mcmc_warmup + n_full:args.mcmc_warmup + n_full + n_sp]:
+        smp.step_max_likelihood(int(i), K)
+        smp.step_nuisance_parameters(0, 0, 1)
+    torch.cuda.synchronize()
+    full_step_sp_s = (time.perf_counter() - t1) / n_sp
 
     # ---- extra: the same map in its LATE stage (the 7 original contigs of 2.7-6.8k fragments; every step prices thousands of
     # expected-mass work items and millions of queued contacts, all of it sharded over the ranks) -- reported next to the
@@ -240,19 +358,15 @@ def main():
                 smp2._candidate_deltas(f, nb, max_id2)
                 n_cand2 += 13 * len(nb)
             sync_all()
-            tl = time.perf_counter() - tl
-            if world > 1:
-                t = torch.tensor([tl], dtype=torch.float64, device="cuda")
-                td.all_reduce(t, op=td.ReduceOp.MAX)
-                tl = float(t.cpu()[0])
+            tl = max_over_ranks(time.perf_counter() - tl)
             c2 = smp2.engine.last_counters()
             st2 = smp2.engine.layout_stats()
             late = {"workload": "same map, its %d original contigs (longest %d fragments)" % (int(st2[0]), int(st2[4])),
                     "value": n_cand2 / tl, "unit": "candidate logL evals/s", "ms_per_step": 1e3 * tl / len(props2[3:]), "steps": len(props2[3:]),
                     "queued_contacts_last_step_this_rank": int(c2[2]), "mass_items_last_step_this_rank": int(c2[3])}
             smp2.free_gpu()
-        except Exception as e:   # (an extra must not cost the headline line; a failure here is the same on every rank)
-            late = {"error": repr(e)}
+        except Exception as e:   # an extra must not cost the headline line (a rank that fails alone makes the others' next
+            late = {"error": repr(e)}   # collective time out after 300 s: they land here too)
 
     if rank == 0:
         nnz_local = smp.engine.nnz
@@ -260,12 +374,12 @@ def main():
         # (n/8 B) and, for the queued contacts only, col + count + two code words (SURVEY 8d priced a naive pass
         # at 12 B per contact; col words of affected rows that fail the second test are not counted -> conservative)
         bytes_per_launch = 4.0 * nnz_local + n / 8.0 + 64.0 * float(counters[2])
-        # kernel duration: HIP events on the stream the kernel runs on.  (a) an event pair around every 8th launch of the
-        # timed region (each pair adds command-processor marker gaps to that step, hence the sampling): the duration of a
-        # launch as the sampler experiences it -- block launch ramp, the prologue that builds the affected-fragment bitmap,
-        # the stream, the drain.  This prices the roofline; rocprofv3's kernel-trace average (profiles/) agrees with it.
-        # (b) 100 back-to-back replays of the last step's scan between two events, reported next to it: there the ramp and
-        # the prologue of one launch overlap the tail of the previous one, so it measures the streaming phase alone.
+        # kernel duration: HIP events on the stream the kernel runs on.  (a) an event pair around the launches of the timed
+        # region: the duration of a launch as the sampler experiences it -- block launch ramp, the prologue that builds the
+        # affected-fragment bitmap, the stream, the drain.  This prices the roofline; rocprofv3's kernel-trace average
+        # (profiles/) agrees with it.  (b) 100 back-to-back replays of the last step's scan between two events, reported next
+        # to it: there the ramp and the prologue of one launch overlap the tail of the previous one, so it measures the
+        # streaming phase alone.
         scan_s = float(np.mean(scan_ms)) * 1e-3
         achieved = bytes_per_launch / scan_s / 1e9
         replay_s = scan_replay_ms * 1e-3
@@ -296,13 +410,17 @@ def main():
                          "bytes_per_launch": bytes_per_launch, "avg_launch_ms": scan_s * 1e3,
                          "launches_timed": int(len(scan_ms)),
                          "back_to_back_replay_ms": replay_s * 1e3,
-                         "frac_back_to_back_replays": bytes_per_launch / replay_s / 1e9 / HBM_PEAK_GBS},
+                         "frac_back_to_back_replays": bytes_per_launch / replay_s / 1e9 / HBM_PEAK_GBS,
+                         "hbm_control": control},
             "phase_ms": {"k_scan": float(np.mean(scan_ms)), "host_wall_per_step": 1e3 * elapsed / args.steps},
             "relevant_pairs_last_step": int(counters[1]), "queued_contacts_last_step": int(counters[2]),
             "mass_items_last_step": int(counters[3]),
-            "full_mcmc_step_ms": 1e3 * full_step_s,
+            "full_mcmc_step_ms": 1e3 * full_step_s, "full_eval_ms": 1e3 * full_eval_s,
+            "full_mcmc_step_sample_param_ms": 1e3 * full_step_sp_s,
             "setup_s": {"generate": t_gen, "sampler": t_setup, "mcmc_warmup": t_mcmc},
         }
+        if world > 1:
+            out["distributed"] = {"backend": args.backend, "ranks": int(td.get_world_size()), "exchange": smp.exchange}
         if alt is not None:
             out["exchange_alt"] = alt
         if late is not None:
@@ -314,8 +432,11 @@ def main():
         print(json.dumps(out), flush=True)
     smp.free_gpu()
     if world > 1:
-        td.barrier()
-        td.destroy_process_group()
+        try:
+            td.barrier()
+            td.destroy_process_group()
+        except Exception:
+            pass
 
 
 if __name__ == "__main__":

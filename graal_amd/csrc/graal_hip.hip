@@ -35,6 +35,9 @@ namespace {
 constexpr double Q_SCALE = 1073741824.0; // 2^GRAAL_Q_BITS
 constexpr int MAXK = GRAAL_MAX_NEIGHBOURS;
 constexpr int NP = MAX_PIECES + 1;       // piece ids 0..6
+constexpr int CODE_BITS = 3;             // a fragment's piece id (0..6) per neighbour, packed into one word
+constexpr unsigned CODE_LSB = 0x09249249u; // bit 0 of each of the 10 fields
+static_assert(MAXK * CODE_BITS <= 32, "piece codes of all neighbours must fit one word");
 constexpr int MAX_TASKS = 21 * (N_OPS + 1); // per neighbour: 21 piece pairs x (old + 13 candidate layouts), before dedupe
 constexpr int LABEL_BITS = 20;           // relabel sort key = l_cont << 20 | label
 
@@ -184,7 +187,23 @@ __device__ __forceinline__ float ex_pair(const End& X, const Stat& sx, int slx, 
     return rippe(s, p) * norm;
 }
 
-__device__ __forceinline__ long long to_q(double v) { return __double2ll_rn(v * Q_SCALE); }
+// One term in Q.  A term that is not finite (ln of an overflowed / zero expected value) or does not fit (|v| >= 2^31; the
+// running int64 sums hold +-8.6e9 log-likelihood units) gives Q_BAD: the caller flags the candidate (nf_flag) and the host
+// reports NaN for it -- the reference's evaluate_likelihood_double would have produced -inf / NaN there (kernels3.cu:191-210).
+constexpr long long Q_BAD = (long long)0x8000000000000000ull;
+constexpr long long Q_NAN = 1ll << 58;   // handed out instead of a flagged sum; |q| >= 2^57 on the host means NaN (sums of
+                                         // <= 8 ranks' values stay below 2^62)
+constexpr int NF_OFF = 14;               // counters[NF_OFF .. NF_OFF + 2]: bit (k * 13 + op) = that candidate met a bad term
+__device__ __forceinline__ long long to_q(double v) { return fabs(v) < 2147483648.0 ? __double2ll_rn(v * Q_SCALE) : Q_BAD; }
+__device__ __forceinline__ void nf_flag(unsigned long long* nf, int k, int op)
+{
+    const int i = k * N_OPS + op;
+    atomicOr(&nf[i >> 6], 1ull << (i & 63));
+}
+__device__ __forceinline__ void nf_flag_ops(unsigned long long* nf, int k, unsigned ops)
+{
+    while (ops) { nf_flag(nf, k, __ffs((int)ops) - 1); ops &= ops - 1; }
+}
 
 __device__ __forceinline__ long long wave_sum_ll(long long v)
 {
@@ -208,6 +227,14 @@ __device__ __forceinline__ Rec rec_gl(const Geo& g, const Link& l, int f)
     r.prev = l.prev; r.next = l.next; r.l_cont = l.l_cont; r.l_cont_bp = l.l_cont_bp; r.ori = (g.flags & 1) ? 1 : -1;
     r.rep = (g.flags >> 3) & 1; r.activ = geo_active(g.flags) ? 1 : 0; r.id_d = f; // (id_d is not used by any mutation)
     return r;
+}
+
+// 16-byte streaming (nontemporal) load
+__device__ __forceinline__ int4 ld_stream(const int4* p)
+{
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    const v4i v = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(p));
+    return make_int4(v.x, v.y, v.z, v.w);
 }
 
 // ------------------------------------------------------------------ small maintenance kernels
@@ -599,42 +626,103 @@ __global__ __launch_bounds__(256) void k_incr(SoaPtr s, int n, const Changed* __
 }
 
 // ------------------------------------------------------------------ full likelihood
-// contacts part: sum ob * log(ex) in Q (the log-factorial constant is added on the host)
+// contacts part: sum ob * log(ex) in Q (the log-factorial constant is added on the host)  [evaluate_likelihood,
+// kernels3.cu:2802-3222, as called by cuda_lib_gl.py:1986-2017 -- restricted to the pixels that hold a contact]
+//
+// Everything a contact needs of one of its two sub-fragments fits 16 bytes: contig label, centre coordinate (kb, float32,
+// computed by centre_kb exactly as the pricing kernels do), RF count, and the contig length when the contig is circular.
+// k_subrec rebuilds that table from the geometry records before every full evaluation (50k fragments: a few microseconds),
+// and the contact kernel below is a pure stream: three 16-byte nontemporal loads per group of 4 contacts (row, col, count),
+// two groups in flight per lane, two 16-byte gathers per contact from a table that stays in L2.  Round 1's kernel loaded
+// the three words of ONE contact per lane and iteration and gathered a 16-byte + a 32-byte record per end: 234 us for
+// 20 M contacts (13 % of the 240 MB / 8 TB/s bound).
+struct SubRec { int label; float centre; int accu; int lbp /* l_cont_bp of a circular contig, else 0 */; };
+
+__global__ __launch_bounds__(256) void k_subrec(int n, const Geo* __restrict__ geo, const Stat* __restrict__ stat,
+                                                 const int* __restrict__ lcontbp, const int* __restrict__ sub_ids /* nullptr: id = f */,
+                                                 SubRec* __restrict__ rec)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n) return;
+    const Stat st = stat[f];
+    if (st.n == 0) return; // a copy of a repeated bin: no sub-fragments in the sparse path
+    const Geo g = geo[f];
+    const bool fwd = g.flags & 1;
+    const int lbp = ((g.flags >> 1) & 1) ? lcontbp[f] : 0;
+    int4 ids = make_int4(f, 0, 0, 1);
+    if (sub_ids) ids = reinterpret_cast<const int4*>(sub_ids)[f];
+    for (int slot = 0; slot < st.n; slot++) {
+        SubRec r; r.label = g.id_c; r.centre = centre_kb(g.start_bp, fwd, st, slot); r.accu = stat_accu(st, slot); r.lbp = lbp;
+        rec[sel3(ids.x, ids.y, ids.z, slot)] = r;
+    }
+}
+
 // A contact between two contigs has the expected value v_inter * (float(a_x * a_y) / nfpb): it depends on the product of the
 // two RF counts only, so every block first tabulates its ln (same expressions, same device functions as the general path:
-// bit-identical) for the products that can occur, and such contacts skip the float64 logarithm.  (Measured on 20 M contacts,
-// 99 % of them between contigs: 277 -> 228 us.  Also tried: a compact (label, RF count) table per sub-fragment instead of
-// the three gathers per end, four contacts per thread, and a per-wave queue that defers the general-path contacts so that
-// they are priced with all lanes busy -- 210 us in that state but 375 instead of 298 us when 85 % of the contacts are
-// within contigs; not kept.)
+// bit-identical) for the products that can occur, and such contacts skip the float64 logarithm.
 constexpr int LN_TRANS_LUT = 1024;
-__global__ __launch_bounds__(256) void k_full_nnz(const int* __restrict__ row, const int* __restrict__ col,
-                                                   const int* __restrict__ cnt, long long nnz,
-                                                   const int* __restrict__ sub2bin, const Geo* __restrict__ geo,
-                                                   const Stat* __restrict__ stat, const int* __restrict__ lcontbp,
+constexpr int FULL_G = 2; // groups of 4 contacts per lane and iteration
+__device__ __forceinline__ int w4(const int4& q, int j) { return j == 0 ? q.x : (j == 1 ? q.y : (j == 2 ? q.z : q.w)); }
+
+__global__ __launch_bounds__(256) void k_full_nnz(const int4* __restrict__ row4, const int4* __restrict__ col4,
+                                                   const int4* __restrict__ cnt4, long long nnz, const SubRec* __restrict__ rec,
                                                    float nfpb, Par par, int lut_n /* <= LN_TRANS_LUT: products that occur */,
-                                                   long long* __restrict__ out)
+                                                   long long* __restrict__ out, long long* __restrict__ bad_flag)
 {
     __shared__ double s_ln_trans[LN_TRANS_LUT];
     for (int p = threadIdx.x; p < lut_n; p += blockDim.x) s_ln_trans[p] = log((double)(par.v_inter * ((float)p / nfpb)));
     __syncthreads();
     long long acc = 0;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (long long)gridDim.x * blockDim.x) {
-        const int a = sub2bin[row[i]], b = sub2bin[col[i]];
-        const int fx = a >> 2, fy = b >> 2;
-        const Geo gx = geo[fx], gy = geo[fy];
-        const Stat sx = stat[fx], sy = stat[fy];
-        double ln_ex;
-        const int prod = stat_accu(sx, a & 3) * stat_accu(sy, b & 3);
-        if (gx.id_c != gy.id_c && (unsigned)prod < (unsigned)lut_n) ln_ex = s_ln_trans[prod];
-        else {
-            const End X = end_cur(gx, lcontbp, fx), Y = end_cur(gy, lcontbp, fy);
-            ln_ex = log((double)ex_pair(X, sx, a & 3, Y, sy, b & 3, nfpb, par));
+    bool bad = false;
+    const int n4 = (int)(nnz >> 2);   // full groups; group n4 is the partial tail (the arrays are padded: in bounds)
+    const int stride = (int)(gridDim.x * blockDim.x);
+    for (int g0 = (int)(blockIdx.x * blockDim.x + threadIdx.x); g0 <= n4; g0 += FULL_G * stride) {
+        int4 r[FULL_G], c[FULL_G], w[FULL_G];
+#pragma unroll
+        for (int i = 0; i < FULL_G; i++) {
+            const int g = g0 + i * stride;
+            const int gc = g <= n4 ? g : n4;
+            r[i] = ld_stream(row4 + gc); c[i] = ld_stream(col4 + gc); w[i] = ld_stream(cnt4 + gc);
         }
-        acc += to_q((double)__int_as_float(cnt[i]) * ln_ex); // counts are stored as float32 (the reference's obs type)
+        SubRec a[4 * FULL_G], b[4 * FULL_G];
+        bool valid[4 * FULL_G];
+#pragma unroll
+        for (int i = 0; i < FULL_G; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const long long idx = ((long long)(g0 + i * stride) << 2) + j;
+                const bool v = (g0 + i * stride) <= n4 && idx < nnz;
+                valid[4 * i + j] = v;
+                // (padding words are zero: row/col 0 are valid table indices, the result is discarded)
+                a[4 * i + j] = rec[v ? w4(r[i], j) : 0];
+                b[4 * i + j] = rec[v ? w4(c[i], j) : 0];
+            }
+#pragma unroll
+        for (int i = 0; i < FULL_G; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (!valid[4 * i + j]) continue;
+                const SubRec A = a[4 * i + j], B = b[4 * i + j];
+                const int prod = A.accu * B.accu;
+                double ln_ex;
+                if (A.label != B.label && (unsigned)prod < (unsigned)lut_n) ln_ex = s_ln_trans[prod];
+                else {
+                    // ex_pair (kernels3.cu:3062-3078 / 3184-3195) on the precomputed centres
+                    const float norm = (float)prod / nfpb;
+                    float ex;
+                    if (A.label != B.label) ex = par.v_inter * norm;
+                    else {
+                        const float sd = fabsf(B.centre - A.centre);
+                        ex = (A.lbp != 0 ? rippe_circ(sd, (float)A.lbp / 1000.0f, par) : rippe(sd, par)) * norm;
+                    }
+                    ln_ex = log((double)ex);
+                }
+                const long long q = to_q((double)__int_as_float(w4(w[i], j)) * ln_ex); // counts are float32 (the reference's obs type)
+                if (q == Q_BAD) bad = true; else acc += q;
+            }
     }
-    // one atomic per BLOCK: 16,384 waves adding to the one accumulator were ~165 us of this kernel's 270 (same-address atomics
-    // go through at ~10 ns each; found by an ablation that kept nothing but the three streaming loads and still took 210 us)
+    if (bad) atomicOr((unsigned long long*)bad_flag, 1ull);
+    // one atomic per BLOCK (same-address atomics go through at ~10 ns each)
     __shared__ long long s_part[4];
     acc = wave_sum_ll(acc);
     if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
@@ -658,11 +746,12 @@ __global__ __launch_bounds__(256) void k_full_mass(int n, const int* __restrict_
                                                     const Geo* __restrict__ geo, const Stat* __restrict__ stat,
                                                     const int* __restrict__ lcont, const int* __restrict__ lcontbp,
                                                     const int* __restrict__ pos, float nfpb, Par par, int reach_bp,
-                                                    long long* __restrict__ out)
+                                                    long long* __restrict__ out, long long* __restrict__ bad_flag)
 {
     const int lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4;
     const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     long long accq = 0;
+    bool bad = false;
     int remaining = 0;
     Geo gx = {0, 0, 0, 0};
     Stat sx = {0.0f, 0.0f, 0.0f, 0, 0, 0, 0, 0};
@@ -676,7 +765,8 @@ __global__ __launch_bounds__(256) void k_full_mass(int n, const int* __restrict_
             double acc = 0.0;
             for (int a = 0; a < sx.n; a++)
                 for (int b = a + 1; b < sx.n; b++) acc += (double)ex_pair(X, sx, a, X, sx, b, nfpb, par);
-            accq += to_q(acc);
+            const long long q = to_q(acc);
+            if (q == Q_BAD) bad = true; else accq += q;
         }
         remaining = lcont[fx] - 1 - pos[fx];
     }
@@ -691,7 +781,8 @@ __global__ __launch_bounds__(256) void k_full_mass(int n, const int* __restrict_
             if (inside) {
                 const Stat sy = stat[fy];
                 const End Y = end_cur(gy, lcontbp, fy);
-                accq += pair_mass_q(X, sx, Y, sy, nfpb, par);
+                const long long q = pair_mass_q(X, sx, Y, sy, nfpb, par);
+                if (q == Q_BAD) bad = true; else accq += q;
             }
         }
         // start_bp grows along the contig: once none of a fragment's 16 lanes found a y inside the window, nothing further is
@@ -699,6 +790,7 @@ __global__ __launch_bounds__(256) void k_full_mass(int n, const int* __restrict_
         live = live && any != 0 && k0 + 16 <= remaining;
     }
     (void)contig_off;
+    if (bad) atomicOr((unsigned long long*)bad_flag, 1ull);
     __shared__ long long s_part[4]; // (one atomic per block, as in k_full_nnz)
     const long long q = wave_sum_ll(accq);
     if (lane == 0) s_part[threadIdx.x >> 6] = q;
@@ -731,8 +823,6 @@ struct NbTables {        // everything the finishing kernel needs about one neig
     unsigned item_tc[ITEM_CAP];        // task | chunk << 16 of item w (valid when n_items <= ITEM_CAP)
     Task task[MAX_TASKS];
 };
-
-struct Neigh { int fB[MAXK]; };
 
 // LDS hand-over between the lanes of ONE wave: LDS operations of a wave execute in program order, so no hardware barrier is
 // needed -- only the compiler must not move them across lanes' dependencies
@@ -978,8 +1068,8 @@ __device__ int tables_block(const Geo* __restrict__ geo, const Link* __restrict_
 // takes this pointer plus a handful of per-step scalars.
 // one relevant contact, everything k_fin needs to price it without further index loads (32 bytes)
 struct QEntry {
-    unsigned idx, rel;   // contact index in this shard; nibble mask of the neighbours it matters to
-    unsigned ci, cj;     // relevance codes of its two fragments: 4 bits per neighbour = piece id
+    unsigned idx, rel;   // contact index in this shard; mask (bit CODE_BITS*k) of the neighbours it matters to
+    unsigned ci, cj;     // relevance codes of its two fragments: CODE_BITS bits per neighbour = piece id
     int fx, fy, cnt;     // fragments (bins) and observed count (float32 bits)
     int slots;           // sub-fragment slots: slx | sly << 2
 };
@@ -1031,6 +1121,7 @@ struct PriceArgs {
     const Stat* stat;
     const int* lcontbp;
     long long* out;
+    unsigned long long* nf;
     float nfpb;
     Par par;
 };
@@ -1047,14 +1138,14 @@ __device__ __forceinline__ void price_contacts(const PriceArgs& pa, unsigned lon
         // contact -- requested together with the relation masks instead of one dependent load after the other
         const Geo gx = pa.geo[fx], gy = pa.geo[fy];
         const Stat sx = pa.stat[fx], sy = pa.stat[fy];
-        const int k0 = (__ffs((int)qe.rel) - 1) >> 2;
-        const Xf xp0 = pa.tabs[k0].xf[op][(qe.ci >> (4 * k0)) & 7], xq0 = pa.tabs[k0].xf[op][(qe.cj >> (4 * k0)) & 7];
+        const int k0 = (__ffs((int)qe.rel) - 1) / CODE_BITS;
+        const Xf xp0 = pa.tabs[k0].xf[op][(qe.ci >> (CODE_BITS * k0)) & 7], xq0 = pa.tabs[k0].xf[op][(qe.cj >> (CODE_BITS * k0)) & 7];
         // candidates of this lane's op that change the relation of the two fragments (piece ids from the codes)
         unsigned rel = qe.rel, todo = 0;
         while (rel) {
-            const int k = (__ffs((int)rel) - 1) >> 2;
+            const int k = (__ffs((int)rel) - 1) / CODE_BITS;
             rel &= rel - 1;
-            const int p = (qe.ci >> (4 * k)) & 7, q = (qe.cj >> (4 * k)) & 7;
+            const int p = (qe.ci >> (CODE_BITS * k)) & 7, q = (qe.cj >> (CODE_BITS * k)) & 7;
             if ((pa.tabs[k].changed[op] >> (p * 8 + q)) & 1ull) todo |= 1u << k;
         }
         if (!todo) continue;
@@ -1065,11 +1156,12 @@ __device__ __forceinline__ void price_contacts(const PriceArgs& pa, unsigned lon
             const int k = __ffs((int)todo) - 1;
             todo &= todo - 1;
             const NbTables& T = pa.tabs[k];
-            const int p = (qe.ci >> (4 * k)) & 7, q = (qe.cj >> (4 * k)) & 7;
+            const int p = (qe.ci >> (CODE_BITS * k)) & 7, q = (qe.cj >> (CODE_BITS * k)) & 7;
             const End X = end_xf(gx, k == k0 ? xp0 : T.xf[op][p]), Y = end_xf(gy, k == k0 ? xq0 : T.xf[op][q]);
             const double ln_new = log((double)ex_pair(X, sx, slx, Y, sy, sly, pa.nfpb, pa.par));
             const long long qv = to_q(ob * (ln_new - ln_old));
-            if (qv != 0) atomicAdd((unsigned long long*)&pa.out[k * N_OPS + op], (unsigned long long)qv);
+            if (qv == Q_BAD) nf_flag(pa.nf, k, op);
+            else if (qv != 0) atomicAdd((unsigned long long*)&pa.out[k * N_OPS + op], (unsigned long long)qv);
         }
     }
 }
@@ -1083,9 +1175,12 @@ __device__ __forceinline__ void hand_out(long long* out, unsigned long long* cou
 {
     const bool failed = atomicAdd(&counters[6], 0ull) != 0ull;
     for (int i = threadIdx.x; i < K * N_OPS; i += blockDim.x) {
-        const long long v = (long long)atomicExch((unsigned long long*)&out[i], 0ull); // read the final sum, reset for the next step
+        long long v = (long long)atomicExch((unsigned long long*)&out[i], 0ull); // read the final sum, reset for the next step
+        if ((atomicAdd(&counters[NF_OFF + (i >> 6)], 0ull) >> (i & 63)) & 1ull) v = Q_NAN; // a term was not finite / out of range
         if (host_res) host_res[1 + i] = v; else d_q_out[i] = v;
     }
+    __syncthreads();
+    if (threadIdx.x >= 4 && threadIdx.x < 7) counters[NF_OFF + threadIdx.x - 4] = 0;
     if (threadIdx.x < 3) counters[8 + threadIdx.x] = atomicExch(&counters[threadIdx.x], 0ull);
     if (threadIdx.x == 3) { counters[5] = 0; counters[6] = 0; sync[0] = 0; }
     __threadfence_system();
@@ -1095,7 +1190,7 @@ __device__ __forceinline__ void hand_out(long long* out, unsigned long long* cou
 
 constexpr long long NEED_FIN = 1ll << 62; // published instead of the sums: k_tm left work for k_fin, launch it
 constexpr long long GAVE_UP = 1ll << 61;  // (with NEED_FIN) k_tm's last block stopped waiting for k_scan
-constexpr int X_SLOT_WORDS = 128;         // exchange slot: sequence word + MAXK*13 sums, padded to 1 KB
+constexpr int X_SLOT_WORDS = 256;         // exchange slot: sequence word + MAXK*13 sums, padded to 2 KB
 static_assert(1 + MAXK * N_OPS <= X_SLOT_WORDS, "exchange slot too small");
 constexpr int FIN_INLINE_Q = 64;          // queued contacts the finishing block of k_tm prices itself
 
@@ -1103,12 +1198,13 @@ constexpr int FIN_INLINE_Q = 64;          // queued contacts the finishing block
 // k_tm (K blocks, launched on the auxiliary stream so that it overlaps k_scan): block k builds the tables of neighbour k
 // and, when the expected-mass work of that neighbour is small (<= INLINE_PAIRS fragment pairs: the regime of short
 // contigs), prices it on the spot -- one thread per fragment pair -- instead of leaving it to k_fin.
-// element j of 8 values held in registers (a select chain: an indexed private array would live in scratch memory)
-__device__ __forceinline__ int sel8(int x0, int x1, int x2, int x3, int x4, int x5, int x6, int x7, int j)
+struct Neigh { int fB[MAXK]; };
+// fB[j] of a kernel-argument Neigh (a select chain: a dynamically indexed kernel argument is fetched from memory)
+__device__ __forceinline__ int sel_nb(const Neigh& nb, int j)
 {
-    int v = x0;
-    v = j == 1 ? x1 : v; v = j == 2 ? x2 : v; v = j == 3 ? x3 : v; v = j == 4 ? x4 : v;
-    v = j == 5 ? x5 : v; v = j == 6 ? x6 : v; v = j == 7 ? x7 : v;
+    int v = nb.fB[0];
+#pragma unroll
+    for (int i = 1; i < MAXK; i++) v = j == i ? nb.fB[i] : v;
     return v;
 }
 
@@ -1148,7 +1244,7 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
     if (k >= K) return;
     STAMP(0, k == 0 && t == 0);
     NbTables& T = ta.tabs[k];
-    const int my_fB = sel8(nb.fB[0], nb.fB[1], nb.fB[2], nb.fB[3], nb.fB[4], nb.fB[5], nb.fB[6], nb.fB[7], k);
+    const int my_fB = sel_nb(nb, k);
     __shared__ SmallCtx sc;
     __shared__ long long s_acc[N_OPS];
     if (t < N_OPS) s_acc[t] = 0;
@@ -1188,6 +1284,7 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
             if (gap_bp(X, gx.len_bp, Y, gy.len_bp) > reach_bp) continue;
             const long long qv = pair_mass_q(X, sx, Y, sy, nfpb, par);
             if (qv == 0) continue;
+            if (qv == Q_BAD) { nf_flag_ops(ta.counters + NF_OFF, k, tk.minus ^ tk.plus); continue; }
             // logL = contacts - mass: the NEW layout's mass counts negative, the OLD one positive
             unsigned ops = tk.minus | tk.plus;
             while (ops) {
@@ -1264,7 +1361,7 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
     {
         PriceArgs pa;
         pa.queue = ta.queue; pa.tabs = ta.tabs; pa.geo = ta.geo; pa.stat = ta.stat; pa.lcontbp = ta.lcontbp;
-        pa.out = ta.acc; pa.nfpb = ta.nfpb; pa.par = ta.par;
+        pa.out = ta.acc; pa.nf = ta.counters + NF_OFF; pa.nfpb = ta.nfpb; pa.par = ta.par;
         price_contacts(pa, s_nq, t >> 6, (int)(blockDim.x >> 6), t & 63);
     }
     __syncthreads(); // (waits for this block's atomics: they are complete, at the memory side, before hand_out reads the sums)
@@ -1273,26 +1370,19 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
     STAMP(6, t == 0);
 }
 
-// 16-byte streaming (nontemporal) load
-__device__ __forceinline__ int4 ld_stream(const int4* p)
-{
-    typedef int v4i __attribute__((ext_vector_type(4)));
-    const v4i v = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(p));
-    return make_int4(v.x, v.y, v.z, v.w);
-}
-
 struct StepKeys {
     PieceKey key[MAXK];
     unsigned live;   // bit k: neighbour k is a real pair (fB != fA)
-    unsigned intra;  // bit 4k: some candidate of neighbour k may change the geometry INSIDE a piece (circular model)
+    unsigned intra;  // bit CODE_BITS*k: some candidate of neighbour k may change the geometry INSIDE a piece (circular model)
 };
 
-// relevance code of a fragment: 4 bits per neighbour = piece id, 0 = not in contig(fA) u contig(fB_k)
+// relevance code of a fragment: CODE_BITS bits per neighbour = piece id (0..6), 0 = not in contig(fA) u contig(fB_k)
+
 __device__ __forceinline__ unsigned code_of(const StepKeys& S, int K, int id_c, int pos)
 {
     unsigned code = 0;
     for (int k = 0; k < K; k++)
-        if ((S.live >> k) & 1u) code |= (unsigned)piece_of(S.key[k], id_c, pos) << (4 * k);
+        if ((S.live >> k) & 1u) code |= (unsigned)piece_of(S.key[k], id_c, pos) << (CODE_BITS * k);
     return code;
 }
 
@@ -1379,11 +1469,10 @@ __global__ __launch_bounds__(1024, (G == 4 ? 8 : 4)) void k_scan(ScanArgs sa, in
     // index) go out first; the first row words are requested right behind them, so the stream is already running while
     // the bitmap is built ----
     // (select chains, not nb.fB[t]: a dynamically indexed kernel argument is fetched from memory)
-    const int my_fB = sel8(nb.fB[0], nb.fB[1], nb.fB[2], nb.fB[3], nb.fB[4], nb.fB[5], nb.fB[6], nb.fB[7], t & 7);
-    const int my_fPrev = sel8(fA, nb.fB[0], nb.fB[1], nb.fB[2], nb.fB[3], nb.fB[4], nb.fB[5], nb.fB[6], t & 7);
+    const int my_fB = sel_nb(nb, t < MAXK ? t : 0);
     int my_cbase = 0;
     if (t <= K) {
-        const int f = t == 8 ? nb.fB[7] : my_fPrev; // t == 0: fA, t >= 1: fB[t - 1]
+        const int f = t == 0 ? fA : sel_nb(nb, t - 1);
         const Geo g = sa.geo[f];
         const Link l = sa.link[f];
         const int4 m0 = reinterpret_cast<const int4*>(sa.mates)[2 * f], m1 = reinterpret_cast<const int4*>(sa.mates)[2 * f + 1];
@@ -1428,7 +1517,7 @@ __global__ __launch_bounds__(1024, (G == 4 ? 8 : 4)) void k_scan(ScanArgs sa, in
             bool dup = (fB == fA) || (B0.id_c == A0.id_c);
             if (fB != fA) {
                 atomicOr(&S.live, 1u << t);
-                if (circ_may_change(fA, fB, max_id, A0, B0)) atomicOr(&S.intra, 1u << (4 * t));
+                if (circ_may_change(fA, fB, max_id, A0, B0)) atomicOr(&S.intra, 1u << (CODE_BITS * t));
                 for (int j = 0; j < t; j++) if (s_fB[j] != fA && s_rec[j + 1].id_c == B0.id_c) dup = true;
             }
             s_clen[t + 1] = dup ? 0 : B0.l_cont;
@@ -1544,10 +1633,10 @@ __global__ __launch_bounds__(1024, (G == 4 ? 8 : 4)) void k_scan(ScanArgs sa, in
                     q_fx = fx; q_fy = fy;
                     const int2 gi = geo2[2 * fx], gj = geo2[2 * fy];
                     const unsigned ci = code_of(S, K, gi.x, geo_pos(gi.y)), cj = code_of(S, K, gj.x, geo_pos(gj.y));
-                    const unsigned nzi = (ci | (ci >> 1) | (ci >> 2)) & 0x11111111u;
-                    const unsigned nzj = (cj | (cj >> 1) | (cj >> 2)) & 0x11111111u;
+                    const unsigned nzi = (ci | (ci >> 1) | (ci >> 2)) & CODE_LSB;
+                    const unsigned nzj = (cj | (cj >> 1) | (cj >> 2)) & CODE_LSB;
                     const unsigned df = ci ^ cj;
-                    const unsigned dnz = (df | (df >> 1) | (df >> 2)) & 0x11111111u;
+                    const unsigned dnz = (df | (df >> 1) | (df >> 2)) & CODE_LSB;
                     const unsigned both = nzi & nzj;
                     // different pieces, or the same piece of a neighbour whose circular model may change (k_fin filters
                     // by the exact per-candidate relation masks)
@@ -1594,7 +1683,12 @@ __global__ __launch_bounds__(1024, (G == 4 ? 8 : 4)) void k_scan(ScanArgs sa, in
         // completion flag for k_tm's finishing block: one word (on its own cache line) per block holding the step's
         // sequence number -- a shared counter would serialise 512 device-scope atomics at the memory side.  No block
         // barrier here (a trailing __syncthreads measurably costs this kernel 5 us): each wave waits for its own
-        // (write-through) queue stores and counts itself in LDS; the last wave of the block writes the flag.
+        // (write-through) queue stores -- explicitly, below -- and counts itself in LDS; the last wave of the block signals.
+        // The queue entries are agent-scope (write-through) stores: "released" means this wave's stores have been
+        // acknowledged, i.e. its vector-memory counter is back to zero (gfx9 counts stores in vmcnt) -- an agent-scope release
+        // fence would add an L2 write-back, which costs the kernel several microseconds and which write-through stores do not
+        // need.  The workgroup fence only orders the LDS count behind it for the compiler.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         int last = 0;
         if (lane == 0) last = (atomicAdd(&s_waves_done, 1) == (int)(blockDim.x >> 6) - 1);
@@ -1751,7 +1845,7 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
             const int seg_lo = max(walk_lo, seg * SEG);
             const int ny = min(ny_all, (seg + 1) * SEG);   // this unit walks [seg_lo, ny)
             YTile* tile = s_tile[threadIdx.x >> 6];
-            bool done = !has_x;
+            bool done = !has_x, bad = false;
             long long accq = 0;
             for (int tb = seg_lo; tb < ny; tb += 64) {
                 const int st = tb + lane;
@@ -1776,12 +1870,14 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
                     const int gap = same ? gap_bp(X, gx.len_bp, Y, y.len_bp)
                                          : (x_below ? Y.start_bp - (X.start_bp + gx.len_bp) : X.start_bp - (Y.start_bp + y.len_bp));
                     if (gap > reach_bp) { done = true; continue; }
-                    accq += pair_mass_q(X, sx, Y, y.st, nfpb, par);
+                    const long long q1 = pair_mass_q(X, sx, Y, y.st, nfpb, par);
+                    if (q1 == Q_BAD) bad = true; else accq += q1;
                 }
                 if (__ballot(!done) == 0) break;
                 WAVE_LDS_SYNC();
             }
             const long long qv = wave_sum_ll(accq);
+            if (__ballot(bad) != 0 && lane == 0) nf_flag_ops(counters + NF_OFF, k, tk.minus ^ tk.plus);
             if (lane == 0 && qv != 0) {
                 // logL = contacts - mass: the NEW layout's mass counts negative, the OLD one positive
                 for (int op = 0; op < N_OPS; op++) {
@@ -1795,7 +1891,7 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
         // ---- queued contacts, taken from the far end of the grid so that they do not queue up behind the mass items of
         // the low-numbered blocks ----
         PriceArgs pa;
-        pa.queue = queue; pa.tabs = tabs; pa.geo = geo; pa.stat = stat; pa.lcontbp = lcontbp; pa.out = s_accb; pa.nfpb = nfpb; pa.par = par;
+        pa.queue = queue; pa.tabs = tabs; pa.geo = geo; pa.stat = stat; pa.lcontbp = lcontbp; pa.out = s_accb; pa.nf = counters + NF_OFF; pa.nfpb = nfpb; pa.par = par;
         price_contacts(pa, nq_total, n_waves - 1 - wave, n_waves, lane);
         STAMP(13, blockIdx.x == 0 && threadIdx.x == 0);
         STAMP_FBLK(2, threadIdx.x == 0);
@@ -1935,7 +2031,7 @@ __device__ __forceinline__ bool rep_pixel(const RepArgs& R, int ui, int v, int& 
 }
 
 // full likelihood of the repeated bins' pixels in the current layout (Q sum)
-__global__ __launch_bounds__(256) void k_rep_full(RepArgs R, long long* __restrict__ out)
+__global__ __launch_bounds__(256) void k_rep_full(RepArgs R, long long* __restrict__ out, long long* __restrict__ bad_flag)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     long long q = 0;
@@ -1943,6 +2039,7 @@ __global__ __launch_bounds__(256) void k_rep_full(RepArgs R, long long* __restri
         int lo, hi;
         CandCtx C; C.T = nullptr; C.op = 0; C.fA = -1;
         if (rep_pixel(R, (int)(i / R.n_bins), (int)(i % R.n_bins), lo, hi)) q = to_q(pixel_lik<0>(R, lo, hi, C));
+        if (q == Q_BAD) { q = 0; atomicOr((unsigned long long*)bad_flag, 1ull); }
     }
     q = wave_sum_ll(q);
     if ((threadIdx.x & 63) == 0 && q != 0) atomicAdd((unsigned long long*)out, (unsigned long long)q);
@@ -2001,7 +2098,9 @@ __global__ __launch_bounds__(256) void k_rep_delta(RepArgs R, const NbTables* __
                 const long long q_old = to_q(pixel_lik<0>(R, lo, hi, C));
                 for (int op = 0; op < N_OPS; op++) {
                     C.op = op;
-                    const long long dq = to_q(pixel_lik<1>(R, lo, hi, C)) - q_old;
+                    const long long q_new = to_q(pixel_lik<1>(R, lo, hi, C));
+                    if (q_new == Q_BAD || q_old == Q_BAD) { nf_flag(counters + NF_OFF, k, op); continue; }
+                    const long long dq = q_new - q_old;
                     if (dq != 0) atomicAdd((unsigned long long*)&s_acc[k * N_OPS + op], (unsigned long long)dq);
                 }
             }
@@ -2062,11 +2161,12 @@ struct Ctx {
     Link* link = nullptr;
     int* mates = nullptr;
     Stat* stat = nullptr;
+    SubRec* sub_rec = nullptr;    // [n_sub_total] per sub-fragment record of the full evaluation (k_subrec)
     int* sub2bin = nullptr;
     int *row = nullptr, *col = nullptr, *cnt = nullptr;
     QEntry* queue = nullptr;
     int last_fA = 0, last_K = 0, last_max_id = 0; // proposal of the last evaluation (timing replays of the scan)
-    int last_fB[MAXK] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int last_fB[MAXK] = {};
     int max_lcont = 0;            // longest contig at the last graal_begin_step (sizes k_fin's grid)
     int* d_sub_ids = nullptr;     // [n_bins][4], only when some bin has more than one sub-fragment
     unsigned long long *keys = nullptr, *keys_sorted = nullptr;
@@ -2200,6 +2300,7 @@ int refresh(Ctx* h)
 }
 
 constexpr int MAX_SCAN_BLOCKS = 4096;
+constexpr int FULL_BAD = 27; // d_scalars[FULL_BAD]: a term of the last full evaluation was not finite / out of range
 constexpr int SCAN_LDS_MAX = 48 * 1024; // affected bitmap of k_scan: 1 bit per contact-list id -> <= 393,216 ids
 
 // threads per block of the streaming pass: 1024 (two blocks per CU) for the lists it is built for; a list of a few hundred
@@ -2364,8 +2465,8 @@ int graal_create(int device, graal_ctx** out)
     CK(hipMalloc(&h->d_args, 2 * sizeof(DevArgs)));
     CK(hipMalloc(&h->d_chg, 2 * sizeof(Changed)));
     CK(hipMemset(h->d_chg, 0, 2 * sizeof(Changed)));
-    CK(hipHostMalloc((void**)&h->h_res, (1 + MAXK * N_OPS) * sizeof(long long), hipHostMallocDefault));
-    memset(h->h_res, 0, (1 + MAXK * N_OPS) * sizeof(long long));
+    CK(hipHostMalloc((void**)&h->h_res, X_SLOT_WORDS * sizeof(long long), hipHostMallocDefault));
+    memset(h->h_res, 0, X_SLOT_WORDS * sizeof(long long));
     h->res_host = h->res_dev = h->h_res;
     CK(hipHostMalloc((void**)&h->h_dist, 2 * sizeof(long long), hipHostMallocDefault));
     memset(h->h_dist, 0, 2 * sizeof(long long));
@@ -2387,7 +2488,7 @@ void graal_destroy(graal_ctx* h)
         (void)hipSetDevice(h->device);
         (void)hipStreamSynchronize(h->stream);
         if (h->aux) (void)hipStreamSynchronize(h->aux);
-        void* ptrs[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->stat, h->sub2bin, h->row, h->col, h->cnt, h->queue, h->d_sub_ids, h->d_acc, h->tm_done, h->d_sync, h->d_flags, h->stat_frag, h->d_dup_bins, h->d_dup_index,
+        void* ptrs[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->stat, h->sub_rec, h->sub2bin, h->row, h->col, h->cnt, h->queue, h->d_sub_ids, h->d_acc, h->tm_done, h->d_sync, h->d_flags, h->stat_frag, h->d_dup_bins, h->d_dup_index,
                         h->d_dispatcher, h->d_collector, h->d_sub_ids_all, h->d_rep_obs,
                         h->keys, h->keys_sorted, h->o2n, h->len_of2[0], h->len_of2[1], h->contig_off2[0], h->contig_off2[1], h->perm, h->cbase, h->link, h->mates, h->cub_tmp, h->tabs, h->step_hdr, h->d_args, h->d_chg,
                         h->d_scalars, h->d_qout, h->d_dref, h->d_dist};
@@ -2461,13 +2562,15 @@ int graal_upload_subfrags(graal_ctx* h, const int32_t* sub_id, const float* sub_
     h->has_rep = false; h->n_dup = 0; h->h_dup_index.assign((size_t)n_bins, -1); // (graal_upload_repeats comes after)
     // single_sub additionally needs sub id == bin id so that the scan can skip the sub2bin gather
     for (int b = 0; single && b < n_bins; b++) single = (sub_id[4 * b] == b);
-    if (h->stat) { (void)hipFree(h->stat); (void)hipFree(h->sub2bin); (void)hipFree(h->d_sub_ids); h->d_sub_ids = nullptr; }
+    if (h->stat) { (void)hipFree(h->stat); (void)hipFree(h->sub2bin); (void)hipFree(h->d_sub_ids); (void)hipFree(h->sub_rec); h->d_sub_ids = nullptr; h->sub_rec = nullptr; }
     if (!single) {
         CK(hipMalloc(&h->d_sub_ids, sizeof(int) * 4 * (size_t)n_bins));
         CK(hipMemcpy(h->d_sub_ids, sub_id, sizeof(int) * 4 * (size_t)n_bins, hipMemcpyHostToDevice));
     }
     CK(hipMalloc(&h->stat, sizeof(Stat) * (size_t)n_bins));
     CK(hipMalloc(&h->sub2bin, sizeof(int) * (size_t)n_sub_total));
+    CK(hipMalloc(&h->sub_rec, sizeof(SubRec) * (size_t)n_sub_total));
+    CK(hipMemset(h->sub_rec, 0, sizeof(SubRec) * (size_t)n_sub_total));
     CK(hipMemcpy(h->stat, st.data(), sizeof(Stat) * (size_t)n_bins, hipMemcpyHostToDevice));
     CK(hipMemcpy(h->sub2bin, s2b.data(), sizeof(int) * (size_t)n_sub_total, hipMemcpyHostToDevice));
     h->n_bins = n_bins; h->n_sub_total = n_sub_total; h->nfpb = nfpb; h->single_sub = single; h->have_sub = true;
@@ -2775,28 +2878,35 @@ int graal_eval_full_q(graal_ctx* h, int64_t q_out[2])
     if (!h->order_valid) return fail(h, GRAAL_E_STATE, "call graal_relabel_contigs after changing the layout");
     CK(hipSetDevice(h->device));
     CK(hipMemsetAsync(h->d_scalars + 8, 0, 2 * sizeof(long long), h->stream));
+    CK(hipMemsetAsync(h->d_scalars + FULL_BAD, 0, sizeof(long long), h->stream));
     if (h->has_rep) CK(hipMemsetAsync(h->d_scalars + 17, 0, sizeof(long long), h->stream));
     SoaPtr s = h->soa[h->cur];
     if (h->nnz) {
-        const int nb = (int)std::min<long long>((h->nnz + 255) / 256, 256 * 8);
-        k_full_nnz<<<nb, 256, 0, h->stream>>>(h->row, h->col, h->cnt, h->nnz, h->sub2bin, h->geo, h->stat_frag, s.p[F_LCONTBP],
-                                               h->nfpb, h->par, h->ln_lut_n, h->d_scalars + 8);
+        k_subrec<<<blocks_for(h->n, 256), 256, 0, h->stream>>>(h->n, h->geo, h->stat_frag, s.p[F_LCONTBP], h->d_sub_ids, h->sub_rec);
+        // 8 blocks of 256 threads per CU; every lane takes FULL_G groups of 4 contacts per iteration
+        const long long groups = (h->nnz >> 2) + 1;
+        const int nb = (int)std::max<long long>(1, std::min<long long>((groups + 256 * FULL_G - 1) / (256 * FULL_G), 256 * 8));
+        k_full_nnz<<<nb, 256, 0, h->stream>>>(reinterpret_cast<const int4*>(h->row), reinterpret_cast<const int4*>(h->col),
+                                               reinterpret_cast<const int4*>(h->cnt), h->nnz, h->sub_rec, h->nfpb, h->par, h->ln_lut_n,
+                                               h->d_scalars + 8, h->d_scalars + FULL_BAD);
     }
     k_full_mass<<<blocks_for(h->n, 16), 256, 0, h->stream>>>(h->n, h->perm, h->contig_off2[h->cur], h->geo, h->stat_frag, s.p[F_LCONT],
                                                              s.p[F_LCONTBP], s.p[F_POS], h->nfpb, h->par, reach_bp(h),
-                                                             h->d_scalars + 9);
+                                                             h->d_scalars + 9, h->d_scalars + FULL_BAD);
     if (h->has_rep) { // every pixel of a repeated bin, densely (identical on every rank: it goes with the mass part)
         const RepArgs R = rep_args(h);
-        k_rep_full<<<blocks_for((long long)h->n_dup * h->n_bins, 256), 256, 0, h->stream>>>(R, h->d_scalars + 17);
+        k_rep_full<<<blocks_for((long long)h->n_dup * h->n_bins, 256), 256, 0, h->stream>>>(R, h->d_scalars + 17, h->d_scalars + FULL_BAD);
     }
     CK(hipGetLastError());
     long long res[2];
-    long long rep_q = 0;
+    long long rep_q = 0, bad = 0;
     if (h->has_rep) CK(hipMemcpyAsync(&rep_q, h->d_scalars + 17, sizeof rep_q, hipMemcpyDeviceToHost, h->stream));
+    CK(hipMemcpyAsync(&bad, h->d_scalars + FULL_BAD, sizeof bad, hipMemcpyDeviceToHost, h->stream));
     CK(hipMemcpyAsync(res, h->d_scalars + 8, sizeof res, hipMemcpyDeviceToHost, h->stream));
     CK(hipStreamSynchronize(h->stream));
     q_out[0] = res[0] - (int64_t)llrint(h->c_lf * Q_SCALE);
     q_out[1] = -(res[1] + (int64_t)llrint(h->t_all * Q_SCALE)) + rep_q;
+    if (bad) { q_out[0] = Q_NAN; q_out[1] = 0; } // a term was not finite / out of range: the host reports NaN
     return GRAAL_OK;
 }
 
@@ -2939,7 +3049,7 @@ int graal_eval_candidates(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K
     long long q[MAXK * N_OPS];
     const int rc = eval_sync(h, fA, fB, K, max_id, 0, 1, q);
     if (rc) return rc;
-    for (int i = 0; i < K * N_OPS; i++) delta[i] = (double)q[i] / Q_SCALE;
+    for (int i = 0; i < K * N_OPS; i++) delta[i] = llabs(q[i]) >= (Q_NAN >> 1) ? (double)NAN : (double)q[i] / Q_SCALE;
     return GRAAL_OK;
 }
 

@@ -122,5 +122,13 @@ class Group:
         return m
 
 
+Q_NAN_LIMIT = 1 << 57   # |q| at or above this: a term of that sum was not finite / out of range (graal_hip.hip: Q_NAN)
+
+
 def q_to_float(q):
-    return np.asarray(q, dtype=np.int64).astype(np.float64) / float(1 << 30)
+    q = np.asarray(q, dtype=np.int64)
+    out = q.astype(np.float64) / float(1 << 30)
+    bad = np.abs(q) >= Q_NAN_LIMIT
+    if bad.any():
+        out = np.where(bad, np.nan, out)
+    return out

@@ -27,6 +27,8 @@ class Trace(object):
 
 
 def run_em(sampler, n_cycles, n_neighbours, rng=None, sample_param=False, scrambled=True, dt=0, on_step=None):
+    if rng is None and getattr(getattr(sampler, "group", None), "world", 1) > 1:
+        raise ValueError("run_em over a sharded sampler needs the sampler's (identically seeded) rng: every rank shuffles itself")
     rng = np.random if rng is None else rng
     trace = Trace()
     sampler.init_likelihood()

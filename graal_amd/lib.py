@@ -11,8 +11,9 @@ import numpy as np
 from . import build as _build
 
 N_OPS = 13
-MAX_NEIGHBOURS = 8
+MAX_NEIGHBOURS = 10
 Q_SCALE = float(1 << 30)
+Q_NAN_LIMIT = 1 << 57   # |Q| at or above this stands for NaN: a term was not finite / did not fit (graal_hip.hip: Q_NAN)
 FIELDS = ("pos", "id_c", "start_bp", "len_bp", "circ", "id", "prev", "next", "l_cont", "l_cont_bp", "ori", "rep",
           "activ", "id_d")  # struct frag, kernels3.cu:9-24
 
@@ -234,6 +235,8 @@ class Engine:
 
     def eval_full(self):
         q = self.eval_full_q()
+        if abs(int(q[0])) >= Q_NAN_LIMIT:   # a term was not finite / out of range (the reference would return -inf / NaN)
+            return float("nan")
         return float(int(q[0]) + int(q[1])) / Q_SCALE
 
     def eval_candidates(self, fA, fB, max_id):
@@ -247,7 +250,7 @@ class Engine:
             return self._delta_buf[:K * N_OPS].reshape(K, N_OPS).copy()
         fb = _c(fB, np.int32)
         out = np.zeros((len(fb), N_OPS), dtype=np.float64)
-        for k0 in range(0, len(fb), MAX_NEIGHBOURS):  # > 8 neighbours: one scan pass per group of 8
+        for k0 in range(0, len(fb), MAX_NEIGHBOURS):  # > 10 neighbours (copies of repeated bins): one scan pass per group of 10
             out[k0:k0 + MAX_NEIGHBOURS] = self.eval_candidates(fA, fb[k0:k0 + MAX_NEIGHBOURS], max_id)
         return out
 
@@ -312,7 +315,11 @@ class Engine:
             rc = self._L.graal_eval_candidates_x(self._h, int(fA), self._fb_ptr, K, int(max_id), self._q_ptr)
             if rc != 0:
                 self._ck(rc, "graal_eval_candidates_x")
-            return (self._q_buf[:K * N_OPS].astype(np.float64) / Q_SCALE).reshape(K, N_OPS)
+            q = self._q_buf[:K * N_OPS]
+            out = q.astype(np.float64) / Q_SCALE
+            if (np.abs(q) >= Q_NAN_LIMIT).any():
+                out[np.abs(q) >= Q_NAN_LIMIT] = np.nan
+            return out.reshape(K, N_OPS)
         fb = _c(fB, np.int32)
         out = np.zeros((len(fb), N_OPS), dtype=np.float64)
         for k0 in range(0, len(fb), MAX_NEIGHBOURS):

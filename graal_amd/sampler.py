@@ -289,6 +289,7 @@ class sampler(object):
         self.n_iterations = n_iterations
         self.is_simu = is_simu
         self.rng = np.random if rng is None else rng
+        self._rng_given = rng is not None
         self.compute_dist = compute_dist
         self.id_frags_blacklisted = list(id_frags_blacklisted) if id_frags_blacklisted is not None else []
         self.id_frag_duplicated = list(id_frag_duplicated) if id_frag_duplicated is not None else []
@@ -336,6 +337,10 @@ class sampler(object):
             if device is None:
                 device = local if world > 1 else 0
         self.group = group
+        if group.world > 1 and not self._rng_given:
+            # every rank draws the proposal and the move itself: without identically seeded generators the ranks would
+            # sum Q vectors of different proposals and their layouts would diverge silently
+            raise ValueError("a sharded sampler (world > 1) needs an explicit, identically seeded rng= on every rank")
         self.engine = Engine(0 if device is None else int(device))  # raises if the HIP library / GPU is missing
         self.engine.upload_subfrags(self.np_sub_frags_id, self.np_sub_frags_len_bp, self.np_sub_frags_accu,
                                     int(self.init_n_sub_frags), float(self.mean_squared_frags_per_bin))
@@ -372,6 +377,7 @@ class sampler(object):
         # (always a full evaluation, cuda_lib_gl.py:1828-1848) is not the previous score
         self.resync_every = 1 if len(self.id_frag_duplicated) else 512
         self._steps_since_full = 0
+        self._force_full = False   # the carried-over total is not a likelihood of the current layout / parameters
         # ---- proposal ----------------------------------------------------------------------------------------
         self.n_neighbors = 10  # cuda_lib_gl.py:444
         self.setup_distri_frags()
@@ -480,6 +486,7 @@ class sampler(object):
             success = 1
             self.set_param_simu(out_test_param)
             self.likelihood_t = test_likelihood
+            self._force_full = False   # a full evaluation of the current layout under the parameters now in force
         kuhn, lm, c1, slope, d, d_max, fact, d_nuc = self.param_simu[0]
         y_rippe = self.return_rippe_vals([kuhn, lm, slope, d, fact])
         return fact, d, d_max, d_nuc, slope, self.likelihood_t, success, y_rippe
@@ -520,7 +527,10 @@ class sampler(object):
     # ------------------------------------------------------------------ likelihood
     def _full_likelihood(self):
         q = self.engine.eval_full_q()
-        return float(self.group.all_reduce_sum_int(int(q[0])) + int(q[1])) / Q_SCALE
+        q0 = self.group.all_reduce_sum_int(int(q[0]))
+        if abs(q0) >= gdist.Q_NAN_LIMIT:       # some term was not finite (the reference's double sum would be -inf / NaN)
+            return float("nan")
+        return float(q0 + int(q[1])) / Q_SCALE
 
     def eval_likelihood(self):
         self.modify_gl_cuda_buffer(0)
@@ -528,6 +538,7 @@ class sampler(object):
 
     def init_likelihood(self):
         self.likelihood_t = self.eval_likelihood()
+        self._force_full = False
 
     def _setup_exchange(self, mode):
         """How the ranks' per-step Q vectors (13*K int64) are summed.  ``"host"``: through pinned host memory shared by the
@@ -694,14 +705,20 @@ class sampler(object):
         if id_fA in self._black_set:            # cuda_lib_gl.py:1962-1978: nothing is proposed for a blacklisted fragment
             o = self.o
             dist = self.dist_inter_genome() if self.compute_dist else 0.0
+            # The reference sets likelihood_t = o here (the score of the last sampled move, possibly under parameters a
+            # nuisance step has replaced since) and loses at most this one step, because its next step re-evaluates the full
+            # likelihood.  Here the total is CARRIED from step to step: keep the reference's value for a nuisance step that
+            # may follow, but make the next scored step start from a full evaluation instead of this stale number.
             self.likelihood_t = o
+            self._force_full = True
             return o, n_contigs, min_len, mean_len_bp, max_len, -1, id_fA, dist, self.temperature(t, n_step)
         self._steps_since_full += 1
-        if self.likelihood_t is None or self._steps_since_full >= self.resync_every:
+        if self.likelihood_t is None or self._force_full or self._steps_since_full >= self.resync_every:
             # the carried-over total drifts by ~1e-10 |logL| per step against a full evaluation (deviation 1):
             # re-evaluate now and then (the reference does it every step, cuda_lib_gl.py:1828-1848)
             self.likelihood_t = self._full_likelihood()
             self._steps_since_full = 0
+            self._force_full = False
         elif (n_circ or self._n_circ_prev) and not self._single_sub:
             # candidate deltas never include a bin's own pixel (as in the reference); those pixels only change with
             # the circular model, so resynchronise the carried-over total whenever circular contigs are around

@@ -26,7 +26,7 @@ extern "C" {
 
 #define GRAAL_ABI_VERSION 1
 #define GRAAL_N_OPS 13        /* candidates per (fA, fB): cuda_lib_gl.py:112 n_tmp_struct */
-#define GRAAL_MAX_NEIGHBOURS 8 /* neighbours scored by one scan pass */
+#define GRAAL_MAX_NEIGHBOURS 10 /* neighbours scored by one scan pass (the reference proposes at most n_neighbors = 10, cuda_lib_gl.py:444) */
 #define GRAAL_Q_BITS 30
 #define GRAAL_N_FIELDS 14     /* struct frag, kernels3.cu:9-24 */
 

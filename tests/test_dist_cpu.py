@@ -116,3 +116,27 @@ def test_env_world_defaults(monkeypatch):
     assert gdist.env_world() == (0, 1, 0)
     monkeypatch.setenv("RANK", "3"); monkeypatch.setenv("WORLD_SIZE", "8"); monkeypatch.setenv("LOCAL_RANK", "3")
     assert gdist.env_world() == (3, 8, 3)
+
+
+@pytest.mark.timeout(300)
+def test_bench_launcher_starts_the_ranks_itself():
+    """`python bench.py --gpus N` with no torchrun environment spawns the N ranks (torch.distributed.run, 127.0.0.1) itself,
+    relays rank 0's JSON line and the exit code.  --dry-run: rendezvous + sharding only (no GPU in the CPU suite, and the
+    engine has no CPU fallback); the GPU suite runs the same command for real (tests/test_multirank_gpu.py)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--nnz", "100000"],
+                         env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d == {"dry_run": True, "n_gpus": 2, "contacts": 100000, "contacts_rank0": d["contacts_rank0"]}
+    assert 0 < d["contacts_rank0"] < 100000
+    # a launcher that started the wrong number of ranks is an error, not a silent single-rank run
+    env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env2,
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "started 1 ranks" in (bad.stderr + bad.stdout)

@@ -90,3 +90,109 @@ def test_c5_properties(c5):
     smp2, trace2 = run(c5, 7, 300, finisher=False)
     assert trace2 == trace[:300]
     smp.free_gpu(); smp2.free_gpu()
+
+
+# ------------------------------------------------------------------------------------------------ late-stage regime
+# C5 on its 7 ORIGINAL contigs (2.7-6.8k fragments each): what bench.py reports as `late_stage`.  Every step queues millions of
+# contacts and thousands of mass work items; the dense oracle cannot run at this size, so the checks are the reference's implied
+# invariant (delta == full after - full before, cuda_lib_gl.py:2196-2220), finisher setting irrelevant, and 2 ranks == 1 rank.
+def _original_sampler(P, group=None, seed=11):
+    import bench
+    rng = np.random.RandomState(seed)
+    smp = bench.build_sampler(P, rng, group, 0)
+    smp.init_likelihood()
+    return smp
+
+
+def _late_proposals(smp, n_props, seed=12):
+    rng = np.random.RandomState(seed)
+    props = []
+    for f in rng.randint(0, int(smp.n_new_frags), size=n_props):
+        nb = smp.return_neighbours(int(f), 5)
+        nb.sort()
+        props.append((int(f), nb))
+    return props
+
+
+@pytest.fixture(scope="module")
+def c5_original():
+    from graal_amd import synth
+    return synth.make_problem(n_bins=50000, nnz=20_000_000, n_sub=1, seed=20141217)
+
+
+def test_c5_original_layout_delta_is_full_after_minus_before(c5_original):
+    smp = _original_sampler(c5_original)
+    st = smp.engine.layout_stats()
+    assert int(st[0]) == 7 and int(st[4]) > 5000
+    worst = 0.0
+    for fA, nb in _late_proposals(smp, 6):
+        max_id = smp.modify_gl_cuda_buffer(0)
+        before = smp._full_likelihood()
+        d = smp._candidate_deltas(fA, nb, max_id)
+        c = smp.engine.last_counters()
+        assert c[2] > 100000 and c[3] > 100            # the late-stage work: queued contacts and mass items for k_fin
+        smp.engine.set_finisher(False)
+        assert np.array_equal(d, smp._candidate_deltas(fA, nb, max_id))   # finisher setting: same sums, bit for bit
+        smp.engine.set_finisher(True)
+        # the move with the largest |delta| among the non-degenerate ones, and the best one
+        for k, op in (np.unravel_index(np.argmax(np.abs(d)), d.shape), np.unravel_index(np.argmax(d), d.shape)):
+            smp.test_copy_struct(fA, nb[k], int(op), max_id)
+            after = smp.eval_likelihood()
+            # float32 kb coordinates of megabase contigs: a full evaluation of the moved layout re-rounds every centre
+            # (deviation 1), so the two sides agree to ~1e-6 x |logL|, far inside north_star's 1e-5
+            err = abs(d[k, op] - (after - before)) / abs(before)
+            worst = max(worst, err)
+            assert err < 1e-5, (fA, nb[k], op, d[k, op], after - before)
+            # undo is not defined for every op: continue from the moved layout
+            max_id = smp.modify_gl_cuda_buffer(0)
+            before = after
+            d = smp._candidate_deltas(fA, nb, max_id)
+    print("C5 original layout: worst |delta - (after - before)| / |logL| = %.3e" % worst)
+    smp.free_gpu()
+
+
+def _late_worker(rank, world, port, q):
+    import os
+    import torch.distributed as td
+    from graal_amd import dist as gdist
+    from graal_amd import synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        P = synth.make_problem(n_bins=50000, nnz=20_000_000, n_sub=1, seed=20141217)
+        smp = _original_sampler(P, gdist.Group(rank, world))
+        max_id = smp.modify_gl_cuda_buffer(0)
+        out = [smp._candidate_deltas(fA, nb, max_id) for fA, nb in _late_proposals(smp, 3)]
+        full = smp._full_likelihood()
+        q.put((rank, out, full, smp.exchange))
+        smp.free_gpu()
+    finally:
+        td.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_c5_original_layout_two_ranks_equal_one_rank(c5_original):
+    import socket
+    import torch.multiprocessing as mp
+    smp = _original_sampler(c5_original)
+    max_id = smp.modify_gl_cuda_buffer(0)
+    want = [smp._candidate_deltas(fA, nb, max_id) for fA, nb in _late_proposals(smp, 3)]
+    want_full = smp._full_likelihood()
+    smp.free_gpu()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 2
+    procs = [ctx.Process(target=_late_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=800) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, out, full, exchange in res:
+        assert exchange == "host"
+        for a, b in zip(out, want):
+            assert np.array_equal(a, b), rank          # sharded contacts + sharded mass units: the same int64 sums
+        assert full == want_full

@@ -93,3 +93,22 @@ def test_ranks_reproduce_the_single_rank_run_bit_for_bit(world, exchange):
         for k in ref_soa:
             assert np.array_equal(soa[k], ref_soa[k]), (rank, k)
         assert full == ref_full
+
+
+@pytest.mark.timeout(900)
+def test_bench_runs_two_ranks_from_one_command():
+    """`python bench.py --gpus 2` (no torchrun around it) on a small map: the launcher starts both ranks (here both on this one
+    GPU, gloo instead of RCCL), rank 0 prints the one JSON line with both exchanges and the late-stage extra."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--n-bins", "2000",
+                          "--nnz", "100000", "--steps", "6", "--warmup", "2", "--mcmc-warmup", "300"],
+                         env=env, capture_output=True, text=True, timeout=850)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["distributed"]["ranks"] == 2
+    assert d["exchange_alt"]["value"] > 0 and "error" not in d["late_stage"]
+    assert d["roofline"]["launches_timed"] == 6

@@ -60,3 +60,61 @@ def test_fit_runs_and_is_sane():
     d_max = rippe_fit.estimate_max_dist_intra(p, 0.05)
     assert rippe_fit.peval(d_max, [p[0], p[1], p[2], p[4]]) == np.float64(0.05) or abs(
         rippe_fit.peval(d_max, [p[0], p[1], p[2], p[4]]) - 0.05) < 1e-6 or d_max == 500
+
+
+# ---- pinned by the reference itself: tests/golden/rippe_fit.json holds inputs and outputs of the REFERENCE's
+# optim_rippe_curve_update.py (peval, estimate_max_dist_intra, estimate_param_rippe), generated in the build container by
+# tests/golden/make_rippe_fixtures.py from a lib2to3 copy of /root/reference/optim_rippe_curve_update.py.
+def _golden():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rippe_fit.json")) as f:
+        return json.load(f)
+
+
+def _same_stack(fx):
+    import scipy
+    return fx["numpy"] == np.__version__ and fx["scipy"] == scipy.__version__
+
+
+def _close(got, want, fx):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    if _same_stack(fx):      # same numpy / scipy (MINPACK) as the generating run: the very same numbers
+        return np.array_equal(got, want, equal_nan=True)
+    return np.allclose(got, want, rtol=1e-6, atol=0, equal_nan=True)
+
+
+def test_peval_matches_the_reference_module():
+    from oracle import optim_ref
+    fx = _golden()
+    assert fx["d_module_constant"] == rippe_fit.D_RIPPE == optim_ref.d
+    for c in fx["peval"]:
+        x = np.asarray(c["x"], dtype=np.float64) if isinstance(c["x"], list) else np.float32(c["x"])
+        for mod in (rippe_fit, optim_ref):
+            assert _close(mod.peval(x, c["param"]), c["y"], fx), c["param"]
+
+
+def test_estimate_max_dist_intra_matches_the_reference_module():
+    from oracle import optim_ref
+    fx = _golden()
+    xs = [c["x"] for c in fx["estimate_max_dist_intra"]]
+    assert any(abs(x - 500.0) < 1e-6 for x in xs)          # MINPACK gives the start value back: kept as is
+    assert any(0 < x < 400 for x in xs)
+    for c in fx["estimate_max_dist_intra"]:
+        p, v = c["p"], c["val_inter"]
+        if c.get("float32_inputs"):
+            p, v = [np.float32(a) for a in p], np.float32(v)
+        for mod in (rippe_fit, optim_ref):
+            assert _close(mod.estimate_max_dist_intra(p, v), c["x"], fx), c
+
+
+def test_estimate_param_rippe_matches_the_reference_module():
+    fx = _golden()
+    kinds = set()
+    for c in fx["estimate_param_rippe"]:
+        y = np.asarray(c["y_meas"], dtype=np.float32 if c["y_is_float32"] else np.float64)
+        p, y_est = rippe_fit.estimate_param_rippe(y, np.asarray(c["x_bins"]))
+        assert _close(p, c["p"], fx), c["kind"]
+        assert _close(y_est, c["y_estim"], fx), c["kind"]
+        kinds.add(c["kind"])
+    assert len(kinds) == 3

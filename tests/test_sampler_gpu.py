@@ -231,3 +231,30 @@ def test_genome_distance_kernel_equals_the_host_loop(n_sub, black):
         assert got == host == ora.dist_inter_genome(s), trial
         assert 0.0 <= got <= 1.0
     g.free_gpu()
+
+
+def test_blacklisted_fragments_with_parameter_sampling_match_oracle():
+    """Blacklisted fragments AND "sample parameters": the step of a blacklisted fragment proposes nothing and hands the
+    reference's stale `self.o` to the nuisance step that follows it (cuda_lib_gl.py:1962-1978, 2076) -- reproduced -- but the
+    carried-over total must not keep that stale value: the next scored step starts from a full evaluation (the reference
+    re-evaluates every step, cuda_lib_gl.py:1828).  Accepted moves, accepted parameter moves and parameters are bit-exact."""
+    P = problem(3, 49, 45, 900)
+    P["id_frags_blacklisted"] = [2, 9, 10, 30]
+    P["bins"] = np.arange(2.0, 60.0, 2.0)
+    ora = O.OracleSampler(P, np.random.RandomState(49), fix_trans_accu=True)
+    t_ref = em.run_em(ora, 2, 3, rng=ora.rng, sample_param=True)
+    gpu_rng = np.random.RandomState(49)
+    g = make_gpu_sampler(P, gpu_rng)
+    g.bins = P["bins"]
+    t_gpu = em.run_em(g, 2, 3, rng=gpu_rng, sample_param=True)
+    assert np.array_equal(t_gpu.mutations(), t_ref.mutations())
+    assert (np.asarray(t_ref.mutations())[:, 2] == -1).sum() == 2 * len(P["id_frags_blacklisted"])
+    assert t_gpu.success == t_ref.success and 0 < sum(t_ref.success) < len(t_ref.success)
+    for a, b in ((t_gpu.fact, t_ref.fact), (t_gpu.slope, t_ref.slope), (t_gpu.d_max, t_ref.d_max), (t_gpu.d_nuc, t_ref.d_nuc)):
+        assert np.array_equal(np.asarray(a, np.float32), np.asarray(b, np.float32))
+    assert np.allclose(t_gpu.likelihood, t_ref.likelihood, rtol=1e-6, atol=0)
+    assert np.allclose(t_gpu.likelihood_nuisance, t_ref.likelihood_nuisance, rtol=1e-6, atol=0)
+    g.gpu_vect_frags.copy_from_gpu()
+    for k in O.FIELDS:
+        assert np.array_equal(getattr(g.gpu_vect_frags, k), ora.gpu_vect_frags[k]), k
+    g.free_gpu()
