@@ -125,7 +125,9 @@ __device__ __forceinline__ int geo_pos(int flags) { return (int)((unsigned)flags
 __device__ __forceinline__ bool geo_active(int flags) { return (flags & 4) == 0; }
 // the rest of a fragment's layout record, 16 bytes: with Geo it replaces 13 scattered SoA words by two 16-byte loads
 struct Link { int l_cont, l_cont_bp, prev, next; };
-constexpr int N_MATES = 8; // mates[f][0..8): the first fragments of f's contig in position order (-1 padded)
+constexpr int N_MATES = 8; // mates[f][0..8): the fragments of f's contig in position order (-1 padded) when it holds <= 8 of them,
+                           // else a row that starts with MATES_LONG
+constexpr int MATES_LONG = -2;
 
 // static data of one bin: sub-fragment lengths (kb) and RF counts (simulation_loader.py:673-704)
 struct Stat { float l0, l1, l2; int n; int a0, a1, a2; int pad; };
@@ -191,8 +193,10 @@ __device__ __forceinline__ float ex_pair(const End& X, const Stat& sx, int slx, 
 // running int64 sums hold +-8.6e9 log-likelihood units) gives Q_BAD: the caller flags the candidate (nf_flag) and the host
 // reports NaN for it -- the reference's evaluate_likelihood_double would have produced -inf / NaN there (kernels3.cu:191-210).
 constexpr long long Q_BAD = (long long)0x8000000000000000ull;
-constexpr long long Q_NAN = 1ll << 58;   // handed out instead of a flagged sum; |q| >= 2^57 on the host means NaN (sums of
-                                         // <= 8 ranks' values stay below 2^62)
+constexpr long long Q_NAN = 1ll << 59;   // handed out instead of a flagged candidate sum; |q| >= 2^58 on the host means NaN
+                                         // (a legitimate candidate delta is far below 2^58 / 2^30 = 2.7e8 log-likelihood units;
+                                         // the sum of <= 8 ranks' values stays below 2^63).  The full likelihood (whose Q value
+                                         // may legitimately exceed 2^58) is flagged by the exact value INT64_MIN instead
 constexpr int NF_OFF = 14;               // counters[NF_OFF .. NF_OFF + 2]: bit (k * 13 + op) = that candidate met a bad term
 __device__ __forceinline__ long long to_q(double v) { return fabs(v) < 2147483648.0 ? __double2ll_rn(v * Q_SCALE) : Q_BAD; }
 __device__ __forceinline__ void nf_flag(unsigned long long* nf, int k, int op)
@@ -203,6 +207,24 @@ __device__ __forceinline__ void nf_flag(unsigned long long* nf, int k, int op)
 __device__ __forceinline__ void nf_flag_ops(unsigned long long* nf, int k, unsigned ops)
 {
     while (ops) { nf_flag(nf, k, __ffs((int)ops) - 1); ops &= ops - 1; }
+}
+
+// The same with the reference's own accu indexing in the TRANS branch (kernels3.cu:3155 / 3638): when the bin with the LOWER
+// id of the pixel ("fi" = min, kernels3.cu:2884-2888 / 3364-3365) is reversed, every one of its slots is priced with the RF count
+// of its LAST sub-fragment (list_accu_data_i[i] = accu_sub_fi[limit_fi] instead of [limit_fi - i]).  Only bins whose
+// sub-fragments carry different RF counts see a difference.  `quirk` = GRAAL_MODE_REF_TRANS_ACCU.
+__device__ __forceinline__ float ex_pair_ref(const End& X, const Stat& sx, int slx, int bin_x, const End& Y, const Stat& sy, int sly,
+                                             int bin_y, float nfpb, const Par& p, bool quirk)
+{
+    if (X.label != Y.label) {
+        int ax = stat_accu(sx, slx), ay = stat_accu(sy, sly);
+        if (quirk) {
+            if (bin_x < bin_y) { if (!X.fwd) ax = stat_accu(sx, sx.n - 1); }
+            else if (!Y.fwd) ay = stat_accu(sy, sy.n - 1);
+        }
+        return p.v_inter * ((float)(ax * ay) / nfpb);
+    }
+    return ex_pair(X, sx, slx, Y, sy, sly, nfpb, p);
 }
 
 __device__ __forceinline__ long long wave_sum_ll(long long v)
@@ -260,7 +282,7 @@ __global__ void k_mates(int n, const int* __restrict__ perm, const int* __restri
     const int base = cbase[f], lc = link[f].l_cont;
     int m[N_MATES];
 #pragma unroll
-    for (int i = 0; i < N_MATES; i++) m[i] = i < lc ? perm[base + i] : -1;
+    for (int i = 0; i < N_MATES; i++) m[i] = lc > N_MATES ? MATES_LONG : (i < lc ? perm[base + i] : -1);
     int4* out = reinterpret_cast<int4*>(mates + (size_t)f * N_MATES);
     out[0] = make_int4(m[0], m[1], m[2], m[3]);
     out[1] = make_int4(m[4], m[5], m[6], m[7]);
@@ -622,6 +644,10 @@ __global__ __launch_bounds__(256) void k_incr(SoaPtr s, int n, const Changed* __
         int4* out = reinterpret_cast<int4*>(mates + (size_t)f * N_MATES);
         out[0] = make_int4(m[0], m[1], m[2], m[3]);
         out[1] = make_int4(m[4], m[5], m[6], m[7]);
+    } else if (touched) { // a longer contig: marker row (k_scan then walks the position index instead)
+        int4* out = reinterpret_cast<int4*>(mates + (size_t)f * N_MATES);
+        out[0] = make_int4(MATES_LONG, MATES_LONG, MATES_LONG, MATES_LONG);
+        out[1] = out[0];
     }
 }
 
@@ -636,11 +662,14 @@ __global__ __launch_bounds__(256) void k_incr(SoaPtr s, int n, const Changed* __
 // two groups in flight per lane, two 16-byte gathers per contact from a table that stays in L2.  Round 1's kernel loaded
 // the three words of ONE contact per lane and iteration and gathered a 16-byte + a 32-byte record per end: 234 us for
 // 20 M contacts (13 % of the 240 MB / 8 TB/s bound).
-struct SubRec { int label; float centre; int accu; int lbp /* l_cont_bp of a circular contig, else 0 */; };
+struct SubRec {
+    int label; float centre;
+    int accu;   // RF count | RF count under the reference's trans-branch indexing (ex_pair_ref) << 16
+    int bin;    // fragment (= bin) id | contig is circular << 31
+};
 
 __global__ __launch_bounds__(256) void k_subrec(int n, const Geo* __restrict__ geo, const Stat* __restrict__ stat,
-                                                 const int* __restrict__ lcontbp, const int* __restrict__ sub_ids /* nullptr: id = f */,
-                                                 SubRec* __restrict__ rec)
+                                                 const int* __restrict__ sub_ids /* nullptr: id = f */, SubRec* __restrict__ rec)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n) return;
@@ -648,11 +677,12 @@ __global__ __launch_bounds__(256) void k_subrec(int n, const Geo* __restrict__ g
     if (st.n == 0) return; // a copy of a repeated bin: no sub-fragments in the sparse path
     const Geo g = geo[f];
     const bool fwd = g.flags & 1;
-    const int lbp = ((g.flags >> 1) & 1) ? lcontbp[f] : 0;
     int4 ids = make_int4(f, 0, 0, 1);
     if (sub_ids) ids = reinterpret_cast<const int4*>(sub_ids)[f];
     for (int slot = 0; slot < st.n; slot++) {
-        SubRec r; r.label = g.id_c; r.centre = centre_kb(g.start_bp, fwd, st, slot); r.accu = stat_accu(st, slot); r.lbp = lbp;
+        SubRec r; r.label = g.id_c; r.centre = centre_kb(g.start_bp, fwd, st, slot);
+        r.accu = stat_accu(st, slot) | ((fwd ? stat_accu(st, slot) : stat_accu(st, st.n - 1)) << 16);   // (RF counts are <= 30000)
+        r.bin = f | (((g.flags >> 1) & 1) << 31);
         rec[sel3(ids.x, ids.y, ids.z, slot)] = r;
     }
 }
@@ -666,7 +696,8 @@ __device__ __forceinline__ int w4(const int4& q, int j) { return j == 0 ? q.x : 
 
 __global__ __launch_bounds__(256) void k_full_nnz(const int4* __restrict__ row4, const int4* __restrict__ col4,
                                                    const int4* __restrict__ cnt4, long long nnz, const SubRec* __restrict__ rec,
-                                                   float nfpb, Par par, int lut_n /* <= LN_TRANS_LUT: products that occur */,
+                                                   const int* __restrict__ lcontbp, float nfpb, Par par,
+                                                   int lut_n /* <= LN_TRANS_LUT: products that occur */, int quirk /* ex_pair_ref */,
                                                    long long* __restrict__ out, long long* __restrict__ bad_flag)
 {
     __shared__ double s_ln_trans[LN_TRANS_LUT];
@@ -703,7 +734,9 @@ __global__ __launch_bounds__(256) void k_full_nnz(const int4* __restrict__ row4,
             for (int j = 0; j < 4; j++) {
                 if (!valid[4 * i + j]) continue;
                 const SubRec A = a[4 * i + j], B = b[4 * i + j];
-                const int prod = A.accu * B.accu;
+                const int bin_a = A.bin & 0x7fffffff, bin_b = B.bin & 0x7fffffff;
+                int prod = (A.accu & 0xffff) * (B.accu & 0xffff);
+                if (quirk && A.label != B.label) prod = bin_a < bin_b ? (A.accu >> 16) * (B.accu & 0xffff) : (A.accu & 0xffff) * (B.accu >> 16);
                 double ln_ex;
                 if (A.label != B.label && (unsigned)prod < (unsigned)lut_n) ln_ex = s_ln_trans[prod];
                 else {
@@ -713,7 +746,7 @@ __global__ __launch_bounds__(256) void k_full_nnz(const int4* __restrict__ row4,
                     if (A.label != B.label) ex = par.v_inter * norm;
                     else {
                         const float sd = fabsf(B.centre - A.centre);
-                        ex = (A.lbp != 0 ? rippe_circ(sd, (float)A.lbp / 1000.0f, par) : rippe(sd, par)) * norm;
+                        ex = (A.bin < 0 ? rippe_circ(sd, (float)lcontbp[bin_a] / 1000.0f, par) : rippe(sd, par)) * norm;
                     }
                     ln_ex = log((double)ex);
                 }
@@ -1221,6 +1254,7 @@ struct TmArgs { // first-needed pointers by value (see ScanArgs)
     const unsigned long long* done; // non-null: k_scan's blocks count themselves here; the step's scan is complete at done_target
     unsigned long long done_target;
     int wait_ticks;                // how long that block waits for k_scan (100 MHz ticks)
+    int strict;                    // GRAAL_MODE_STRICT: tables only (k_strict prices everything)
     // the finishing block's pointers, by value too
     unsigned long long* counters;
     const QEntry* queue;
@@ -1250,7 +1284,7 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
     if (t < N_OPS) s_acc[t] = 0;
     const int n_tasks = tables_block(ta.geo, ta.link, ta.cbase, ta.mates, ta.stat, fA, my_fB, max_id, T, k, ta.step_hdr, s_task, s_pp, sc);
     const int total = s_pp[n_tasks];
-    const bool inl = total <= INLINE_PAIRS;
+    const bool inl = total <= INLINE_PAIRS && !ta.strict;
     STAMP(1, k == 0 && t == 0);
     if (inl && total > 0) {
         const int* __restrict__ perm = A->perm;
@@ -1415,9 +1449,8 @@ __device__ bool circ_may_change(int fA, int fB, int max_id, const Rec& A0, const
 #ifndef GRAAL_SCAN_PRE
 #define GRAAL_SCAN_PRE 4
 #endif
-// groups of row words (of the first four) requested ABOVE the prologue.  All of them would flood the memory system with
-// 32 MB at once and the prologue's second dependent load would come back behind that burst; none would leave HBM idle
-// during the prologue.
+// groups of row words requested ABOVE the prologue: 4 = the first batch, 8 = the first two, 0 = none (HBM idle during the
+// prologue).
 constexpr int SCAN_PRE = GRAAL_SCAN_PRE;
 
 struct ScanArgs { // by value: kernel-argument pointers are known to be GLOBAL (pointers read from a struct in memory are
@@ -1434,6 +1467,7 @@ struct ScanArgs { // by value: kernel-argument pointers are known to be GLOBAL (
     unsigned long long* done;     // non-null: completion = one fire-and-forget atomic per block on this counter instead of a flag
     long long nnz;
     int bitmap_words;
+    int strict;                   // GRAAL_MODE_STRICT: queue every contact with both ends in a neighbour's affected set
 };
 
 // word j (0 .. 4G-1) of G groups held in registers (select chain over constant indices: stays in registers)
@@ -1458,28 +1492,30 @@ __global__ __launch_bounds__(1024, (G == 4 ? 8 : 4)) void k_scan(ScanArgs sa, in
     extern __shared__ unsigned s_bm[];
     __shared__ StepKeys S;
     __shared__ Rec s_rec[MAXK + 1];
-    __shared__ int s_cbase[MAXK + 1], s_clen[MAXK + 1], s_pref[MAXK + 2], s_fB[MAXK], s_mates[MAXK + 1][N_MATES];
-    __shared__ int s_waves_done;
+    __shared__ int s_cbase[MAXK + 1], s_clen[MAXK + 1], s_pref[MAXK + 2], s_fB[MAXK];
+    __shared__ int s_waves_done, s_keys_ready, s_long;
     __shared__ unsigned long long s_nrel;
     const int t = threadIdx.x;
     const int lane = t & 63;
     STAMP(8, blockIdx.x == 0 && t == 0 && !dry);
     STAMP_BLK(0, t == 0 && !dry);
-    // ---- prologue: keys of the K neighbours and the affected bitmap.  Its dependent loads (fragment records -> position
-    // index) go out first; the first row words are requested right behind them, so the stream is already running while
-    // the bitmap is built ----
-    // (select chains, not nb.fB[t]: a dynamically indexed kernel argument is fetched from memory)
-    const int my_fB = sel_nb(nb, t < MAXK ? t : 0);
-    int my_cbase = 0;
-    if (t <= K) {
+    // ---- prologue.  Only the affected BITMAP stands between a block and its stream, so wave 0 builds nothing else: one
+    // 32-byte load per fragment (fA and the K neighbours: their mates rows = the fragments of their contigs when those hold
+    // <= N_MATES fragments, a marker row otherwise), LDS bit sets, the block's one barrier.  Everything the rare later tests
+    // need (piece keys, circular-model flags, the long contigs' index ranges) is derived by WAVE 1 from its own loads, off the
+    // critical path; a wave that finds an affected row waits for s_keys_ready first.
+    // (round 1 built keys, flags and prefix sums in wave 0 before the barrier: 3.5-4 us of a 20 us launch)
+    int4 row0 = make_int4(-1, -1, -1, -1), row1 = row0;
+    if (t <= K) {   // (select chains, not nb.fB[t]: a dynamically indexed kernel argument is fetched from memory)
         const int f = t == 0 ? fA : sel_nb(nb, t - 1);
-        const Geo g = sa.geo[f];
-        const Link l = sa.link[f];
-        const int4 m0 = reinterpret_cast<const int4*>(sa.mates)[2 * f], m1 = reinterpret_cast<const int4*>(sa.mates)[2 * f + 1];
-        my_cbase = sa.cbase[f];
-        s_rec[t] = rec_gl(g, l, f);
-        s_mates[t][0] = m0.x; s_mates[t][1] = m0.y; s_mates[t][2] = m0.z; s_mates[t][3] = m0.w;
-        s_mates[t][4] = m1.x; s_mates[t][5] = m1.y; s_mates[t][6] = m1.z; s_mates[t][7] = m1.w;
+        row0 = reinterpret_cast<const int4*>(sa.mates)[2 * f]; row1 = reinterpret_cast<const int4*>(sa.mates)[2 * f + 1];
+    }
+    Geo my_geo = {0, 0, 0, 0};
+    Link my_link = {0, 0, 0, 0};
+    int my_cbase = 0, my_f = 0;
+    if (t >= 64 && t - 64 <= K) {
+        my_f = t == 64 ? fA : sel_nb(nb, t - 65);
+        my_geo = sa.geo[my_f]; my_link = sa.link[my_f]; my_cbase = sa.cbase[my_f];
     }
     const long long nnz = sa.nnz;
     const int n4 = (int)(nnz >> 2);           // groups of 4 contacts: 0 .. n4 (the last one partial or empty; nnz < 2^33)
@@ -1487,69 +1523,87 @@ __global__ __launch_bounds__(1024, (G == 4 ? 8 : 4)) void k_scan(ScanArgs sa, in
     const int stride = (int)(gridDim.x * blockDim.x);
     int g0 = (int)(blockIdx.x * blockDim.x) + t;
     // unconditional loads with a clamped group index (group n4 is in bounds: the arrays are padded): branch-free, so the
-    // compiler keeps all four in flight together.  The first iteration's loads are issued here, ABOVE the prologue: 40 % of
-    // the list is on its way while the bitmap is built -- except by wave 0, which builds it: vector-memory results return in
-    // order, so its dependent prologue loads would queue up behind its own stream loads.
+    // compiler keeps all of them in flight together.  The first batch is requested here, ABOVE the barrier: 40 % of the list is
+    // on its way while the bitmap is built -- except by waves 0 and 1: vector-memory results return in order, so their prologue
+    // loads would queue up behind their own stream loads.
     auto ldg = [&](int g) { return ld_stream(row4 + (g < n4 ? g : n4)); }; // (group indices fit 32 bits: nnz < 2^32)
     int4 f[G];
     static_assert(SCAN_PRE == 0 || SCAN_PRE == 4, "");
-    if (t >= 64 && SCAN_PRE) {
+    if (t >= 128 && SCAN_PRE) {
 #pragma unroll
         for (int i = 0; i < G; i++) f[i] = ldg(g0 + i * stride);
     }
-    // Wave 0 alone builds the bitmap (the other waves go straight to the one barrier below: a block-wide barrier this early
-    // waits for the block's last wave to be LAUNCHED, and there were four of them).  Inside one wave, LDS operations
-    // execute in program order; WSYNC only keeps the compiler from reordering them across lanes' dependencies.
 #define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
-    constexpr int SMALL_TOTAL = 256; // affected fragments wave 0 marks itself; above that the whole block helps
-    if (t < 64) {
-        if (t == 0) { S.live = 0; S.intra = 0; s_waves_done = 0; s_nrel = 0; }
-        for (int i = t; i < sa.bitmap_words; i += 64) s_bm[i] = 0;
-        if (t <= K) s_cbase[t] = my_cbase;
-        if (t < MAXK) s_fB[t] = my_fB;
-        WSYNC();
-        if (t < K) {
-            const Rec& A0 = s_rec[0];
-            const Rec& B0 = s_rec[t + 1];
-            const int fB = my_fB;
-            PieceKey key; key.cA = A0.id_c; key.a = A0.pos; key.cB = B0.id_c; key.b = B0.pos;
-            S.key[t] = key;
-            bool dup = (fB == fA) || (B0.id_c == A0.id_c);
-            if (fB != fA) {
-                atomicOr(&S.live, 1u << t);
-                if (circ_may_change(fA, fB, max_id, A0, B0)) atomicOr(&S.intra, 1u << (CODE_BITS * t));
-                for (int j = 0; j < t; j++) if (s_fB[j] != fA && s_rec[j + 1].id_c == B0.id_c) dup = true;
-            }
-            s_clen[t + 1] = dup ? 0 : B0.l_cont;
-        }
-        if (t == 0) s_clen[0] = s_rec[0].l_cont;
-        WSYNC();
-        if (t == 0) { int acc = 0; for (int j = 0; j <= K; j++) { s_pref[j] = acc; acc += s_clen[j]; } s_pref[K + 1] = acc; }
-        WSYNC();
-    }
-    auto mark = [&](int e0, int step) {
-        const int total = s_pref[K + 1];
-        const int* __restrict__ perm = sa.perm;
-        for (int e = e0; e < total; e += step) {
-            int j = 0;
-            while (j < K && e >= s_pref[j + 1]) j++;
-            // short contigs come with the fragment's own record (mates row): no second dependent load
-            const int i = e - s_pref[j];
-            const int f = s_clen[j] <= N_MATES ? s_mates[j][i] : perm[s_cbase[j] + i];
-            if (SINGLE_SUB) atomicOr(&s_bm[f >> 5], 1u << (f & 31));
-            else {
-                const int4 ids = reinterpret_cast<const int4*>(sa.sub_ids)[f];
-                atomicOr(&s_bm[ids.x >> 5], 1u << (ids.x & 31));
-                if (ids.w > 1) atomicOr(&s_bm[ids.y >> 5], 1u << (ids.y & 31));
-                if (ids.w > 2) atomicOr(&s_bm[ids.z >> 5], 1u << (ids.z & 31));
-            }
+    auto set_bits = [&](int fr) {   // mark fragment fr: its id, or the ids of its sub-fragments
+        if (SINGLE_SUB) atomicOr(&s_bm[fr >> 5], 1u << (fr & 31));
+        else {
+            const int4 ids = reinterpret_cast<const int4*>(sa.sub_ids)[fr];
+            atomicOr(&s_bm[ids.x >> 5], 1u << (ids.x & 31));
+            if (ids.w > 1) atomicOr(&s_bm[ids.y >> 5], 1u << (ids.y & 31));
+            if (ids.w > 2) atomicOr(&s_bm[ids.z >> 5], 1u << (ids.z & 31));
         }
     };
-    if (t < 64 && s_pref[K + 1] <= SMALL_TOTAL) mark(t, 64);
+    if (t < 64) {
+        if (t == 0) { s_waves_done = 0; s_nrel = 0; s_keys_ready = 0; }
+        for (int i = t; i < sa.bitmap_words; i += 64) s_bm[i] = 0;
+        WSYNC();
+        const bool is_long = t <= K && row0.x == MATES_LONG;
+        if (t <= K && !is_long) {
+            if (row0.x >= 0) set_bits(row0.x);
+            if (row0.y >= 0) set_bits(row0.y);
+            if (row0.z >= 0) set_bits(row0.z);
+            if (row0.w >= 0) set_bits(row0.w);
+            if (row1.x >= 0) set_bits(row1.x);
+            if (row1.y >= 0) set_bits(row1.y);
+            if (row1.z >= 0) set_bits(row1.z);
+            if (row1.w >= 0) set_bits(row1.w);
+        }
+        const unsigned long long lm = __ballot(is_long);
+        if (t == 0) s_long = lm != 0 ? 1 : 0;
+    } else if (t < 128) {
+        const int u = t - 64;
+        if (u == 0) { S.live = 0; S.intra = 0; }
+        if (u <= K) { s_rec[u] = rec_gl(my_geo, my_link, my_f); s_cbase[u] = my_cbase; }
+        if (u < MAXK) s_fB[u] = sel_nb(nb, u);
+        WSYNC();
+        if (u < K) {
+            const Rec& A0 = s_rec[0];
+            const Rec& B0 = s_rec[u + 1];
+            const int fB = s_fB[u];
+            PieceKey key; key.cA = A0.id_c; key.a = A0.pos; key.cB = B0.id_c; key.b = B0.pos;
+            S.key[u] = key;
+            bool dup = (fB == fA) || (B0.id_c == A0.id_c);
+            if (fB != fA) {
+                atomicOr(&S.live, 1u << u);
+                if (circ_may_change(fA, fB, max_id, A0, B0)) atomicOr(&S.intra, 1u << (CODE_BITS * u));
+                for (int j = 0; j < u; j++) if (s_fB[j] != fA && s_rec[j + 1].id_c == B0.id_c) dup = true;
+            }
+            s_clen[u + 1] = (dup || B0.l_cont <= N_MATES) ? 0 : B0.l_cont;    // long contigs only: the short ones are marked from their rows
+        }
+        if (u == 0) s_clen[0] = s_rec[0].l_cont <= N_MATES ? 0 : s_rec[0].l_cont;
+        WSYNC();
+        if (u == 0) {
+            int acc = 0;
+            for (int j = 0; j <= K; j++) { s_pref[j] = acc; acc += s_clen[j]; }
+            s_pref[K + 1] = acc;
+            __hip_atomic_store(&s_keys_ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    auto wait_keys = [&]() {
+        while (__hip_atomic_load(&s_keys_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+    };
 #undef WSYNC
     __syncthreads();
-    if (s_pref[K + 1] > SMALL_TOTAL) { // long contigs: everybody marks (the extra barrier is nothing next to that regime's work)
-        mark(t, (int)blockDim.x);
+    if (s_long) { // some affected contig holds more than N_MATES fragments: everybody marks it from the position index (two
+                  // more barriers are nothing next to that regime's work)
+        wait_keys();
+        const int total = s_pref[K + 1];
+        const int* __restrict__ perm = sa.perm;
+        for (int e = t; e < total; e += (int)blockDim.x) {
+            int j = 0;
+            while (j < K && e >= s_pref[j + 1]) j++;
+            set_bits(perm[s_cbase[j] + (e - s_pref[j])]);
+        }
         __syncthreads();
     }
     const int4* __restrict__ col4 = sa.col4;
@@ -1557,12 +1611,12 @@ __global__ __launch_bounds__(1024, (G == 4 ? 8 : 4)) void k_scan(ScanArgs sa, in
     const int2* __restrict__ geo2 = sa.geo2;
     QEntry* __restrict__ queue = sa.queue;
     unsigned long long* __restrict__ counters = sa.counters;
-    const unsigned intra = S.intra;
     unsigned long long n_rel = 0;
     STAMP_BLK(1, t == 0 && !dry);
     STAMP(9, blockIdx.x == 0 && t == 0 && !dry);
-    // one iteration: G groups of 4 contacts (ga + i * stride)
-    auto process = [&](const int4 (&rr)[G], const int ga) {
+    // first test of one batch = G groups of 4 contacts (ga + i * stride): bit j of the result = contact j of this lane is valid
+    // and has an affected row.  No memory operations other than LDS reads: the main loop's fast path stays a pure stream.
+    auto test_rows = [&](const int4 (&rr)[G], const int ga) -> unsigned {
         unsigned vmask = 0xffffffffu >> (32 - 4 * G); // valid contacts of the G groups: all of them, except at the very end
         if (ga + (G - 1) * stride >= n4) {
             vmask = 0;
@@ -1580,8 +1634,12 @@ __global__ __launch_bounds__(1024, (G == 4 ? 8 : 4)) void k_scan(ScanArgs sa, in
             hit |= (((s_bm[q.x >> 5] >> (q.x & 31)) & 1u) | (((s_bm[q.y >> 5] >> (q.y & 31)) & 1u) << 1)
                     | (((s_bm[q.z >> 5] >> (q.z & 31)) & 1u) << 2) | (((s_bm[q.w >> 5] >> (q.w & 31)) & 1u) << 3)) << (4 * i);
         }
-        hit &= vmask;
-        if (__ballot(hit != 0) == 0) return; // the common case: nobody in this wave needs its col words
+        return hit & vmask;
+    };
+    // the rest of a batch in which some lane of the wave found an affected row (rare while contigs are short)
+    auto process_hits = [&](const int4 (&rr)[G], const int ga, unsigned hit) {
+        wait_keys();   // (wave 1's keys: long there by the time a block has streamed its first batch)
+        const unsigned intra = S.intra;
         // second test, still wide: the col words of the groups with an affected row (up to G 16-byte loads in flight
         // together), all bitmap tests at once
         int4 cc[G];
@@ -1640,7 +1698,7 @@ __global__ __launch_bounds__(1024, (G == 4 ? 8 : 4)) void k_scan(ScanArgs sa, in
                     const unsigned both = nzi & nzj;
                     // different pieces, or the same piece of a neighbour whose circular model may change (k_fin filters
                     // by the exact per-candidate relation masks)
-                    rel = both & (dnz | intra);
+                    rel = sa.strict ? both : both & (dnz | intra);
                     if (!SINGLE_SUB && fx == fy) rel = 0; // a bin's own pixel is never revisited (kernels3.cu:3356-3380)
                     q_ci = ci; q_cj = cj;
                 }
@@ -1662,16 +1720,23 @@ __global__ __launch_bounds__(1024, (G == 4 ? 8 : 4)) void k_scan(ScanArgs sa, in
             }
         }
     };
-    if (t < 64 || !SCAN_PRE) {
+    // ---- main loop: G loads in flight, first test, (rarely) the rest.  (A two-buffer software pipeline of this loop was
+    // measured in tools/scan_micro.hip: 15.4 -> 14.6 us per isolated launch with 2 x 2 groups through raw buffer loads, slower
+    // with 2 x 4; in this kernel two buffers of 4 groups do not fit next to process_hits in 64 VGPRs.)
+    if (t < 128 || !SCAN_PRE) {
 #pragma unroll
         for (int i = 0; i < G; i++) f[i] = ldg(g0 + i * stride);
     }
-    process(f, g0);
+    {
+        const unsigned hit = test_rows(f, g0);
+        if (__ballot(hit != 0) != 0) process_hits(f, g0, hit);
+    }
     for (int g = g0 + G * stride; g <= n4; g += G * stride) {
         int4 q[G];
 #pragma unroll
         for (int i = 0; i < G; i++) q[i] = ldg(g + i * stride);
-        process(q, g);
+        const unsigned hit = test_rows(q, g);
+        if (__ballot(hit != 0) != 0) process_hits(q, g, hit);
     }
     STAMP(10, blockIdx.x == 0 && t == 0 && !dry);
     STAMP_BLK(2, t == 0 && !dry);
@@ -1921,6 +1986,248 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
     STAMP(21, threadIdx.x == 0);
 }
 
+// ------------------------------------------------------------------ reference-arithmetic validation mode
+// GRAAL_MODE_STRICT: a candidate's delta is computed the way the reference's sub_compute_likelihood defines it
+// (kernels3.cu:3259-3718): EVERY pixel between two different bins of contig(fA) u contig(fB) is priced again from the float32 kb
+// coordinates of the candidate layout and compared with its value in the current layout -- also the pairs whose geometry the
+// move leaves mathematically unchanged (their float32 coordinates shift, so their values move by rounding noise: DESIGN.md
+// section 2, deviation 1) and, with GRAAL_MODE_REF_TRANS_ACCU, with the reference's RF-count indexing in the trans branch.
+//   delta = sum_{contacts inside the set} ob (ln ex_new - ln ex_old)  -  sum_{ALL slot pairs inside the set} (ex_new - ex_old)
+// No window, no piece relations, no deduplication: O(m^2) per candidate for m affected bins, like the reference.  It exists for
+// parity (tests/test_strict_gpu.py: bit-exact traces against the reference-arithmetic oracle on generic coordinates and
+// non-uniform RF counts), not for speed.
+struct STile { Geo g; int lbp, piece, frag, pad; Stat st; };   // one staged fragment of the strict mass walk, 64 bytes
+struct StrictArgs {
+    const int *perm, *cbase, *lcontbp;
+    const Link* link;
+    float nfpb;
+    Par par;
+    int quirk;
+};
+
+__device__ __forceinline__ End end_old(const Geo& g, int lbp)
+{
+    End e; e.label = g.id_c; e.start_bp = g.start_bp; e.fwd = g.flags & 1; e.circ = (g.flags >> 1) & 1; e.lbp = lbp;
+    return e;
+}
+
+// correction of the layout independent all-trans mass T_all for the reference's trans-branch RF-count indexing: pairs of
+// different contigs whose lower-id bin is reversed and has non-uniform RF counts (ubins lists the bins with non-uniform counts)
+__global__ __launch_bounds__(256) void k_quirk_mass(int n_u, const int* __restrict__ ubins, int n_bins, const Geo* __restrict__ geo,
+                                                     const Stat* __restrict__ stat, float nfpb, Par par, long long* __restrict__ out,
+                                                     long long* __restrict__ bad_flag)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long q = 0;
+    if (i < (long long)n_u * n_bins) {
+        const int x = ubins[i / n_bins], y = (int)(i % n_bins);
+        if (y > x) {
+            const Geo gx = geo[x], gy = geo[y];
+            const Stat sx = stat[x], sy = stat[y];
+            if ((gx.flags & 1) == 0 && gx.id_c != gy.id_c && sx.n > 0 && sy.n > 0) {
+                const int alast = stat_accu(sx, sx.n - 1);
+                double acc = 0.0;
+                for (int a = 0; a < sx.n; a++)
+                    for (int b = 0; b < sy.n; b++)
+                        acc += (double)ex_trans(alast, stat_accu(sy, b), nfpb, par) - (double)ex_trans(stat_accu(sx, a), stat_accu(sy, b), nfpb, par);
+                q = to_q(acc);
+                if (q == Q_BAD) { q = 0; atomicOr((unsigned long long*)bad_flag, 1ull); }
+            }
+        }
+    }
+    q = wave_sum_ll(q);
+    if ((threadIdx.x & 63) == 0 && q != 0) atomicAdd((unsigned long long*)out, (unsigned long long)q);
+}
+
+__global__ __launch_bounds__(256) void k_strict(FinArgs fa, StrictArgs sa, int fA, int K, int rank, int world,
+                                                 long long* __restrict__ d_q_out, volatile long long* host_res, long long seq)
+{
+    const NbTables* __restrict__ tabs = fa.tabs;
+    const Geo* __restrict__ geo = fa.geo;
+    const Stat* __restrict__ stat = fa.stat;
+    unsigned long long* __restrict__ counters = fa.counters;
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + wib, n_waves = gridDim.x * (blockDim.x >> 6);
+    __shared__ STile s_tile[4][64];
+    __shared__ long long s_accb[MAXK * N_OPS];
+    __shared__ Xf s_xf[MAXK][N_OPS][NP];
+    __shared__ unsigned s_ident[MAXK][N_OPS];      // bit p: candidate op leaves piece p exactly where it is
+    __shared__ int s_m[MAXK], s_lenA[MAXK], s_baseA[MAXK], s_baseB[MAXK], s_ubase[MAXK + 1];
+    __shared__ int s_ok;
+    for (int i = threadIdx.x; i < MAXK * N_OPS; i += blockDim.x) s_accb[i] = 0;
+    if (threadIdx.x == 0) s_ok = 1;
+    __syncthreads();
+    if ((int)threadIdx.x < K) { // the tables come from k_tm on another stream (bounded spin, as in k_fin)
+        bool ok = false;
+        for (int spin = 0; spin < (1 << 22); spin++) {
+            const unsigned long long w = (unsigned long long)__hip_atomic_load(&fa.tm_done[threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(w >> 32) == (unsigned)seq) { ok = true; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (!ok) { s_ok = 0; atomicOr((unsigned long long*)&counters[6], 1ull); }
+    }
+    __syncthreads();
+    const unsigned long long nq_total = counters[2];
+    if (s_ok) {
+        for (int i = threadIdx.x; i < K * N_OPS * NP; i += blockDim.x) {
+            const int k = i / (N_OPS * NP), op = (i / NP) % N_OPS, p = i % NP;
+            s_xf[k][op][p] = tabs[k].xf[op][p];
+        }
+        if ((int)threadIdx.x < K) {
+            const int k = threadIdx.x, fB = tabs[k].fB;
+            const Geo gA = geo[fA], gB = geo[fB];
+            const int lenA = sa.link[fA].l_cont, lenB = (fB == fA || gB.id_c == gA.id_c) ? 0 : sa.link[fB].l_cont;
+            s_lenA[k] = lenA; s_baseA[k] = sa.cbase[fA]; s_baseB[k] = sa.cbase[fB];
+            s_m[k] = fB == fA ? 0 : lenA + lenB;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < K * N_OPS; i += blockDim.x) {
+            const int k = i / N_OPS, op = i % N_OPS;
+            unsigned m = 0;
+            for (int p = 1; p < NP; p++) {
+                const Xf x = s_xf[k][op][p];
+                const int c = tabs[k].contig[p];      // the piece's contig in the current layout (-1: empty piece)
+                // identity: same label, no mirror, no shift, same circular model (xf_identity of any of its fragments)
+                if (c >= 0 && x.label == c && x.sigma == 1 && x.off == 0) {
+                    const int rep_f = c == geo[fA].id_c ? fA : tabs[k].fB;
+                    const Geo gr = geo[rep_f];
+                    const int circ_old = (gr.flags >> 1) & 1;
+                    if (x.circ == circ_old && (circ_old == 0 || x.lbp == sa.lcontbp[rep_f])) m |= 1u << p;
+                }
+            }
+            s_ident[k][op] = m;
+        }
+        if (threadIdx.x == 0) {
+            s_ubase[0] = 0;
+            for (int k = 0; k < K; k++) { const int nt = (s_m[k] + 63) >> 6; s_ubase[k + 1] = s_ubase[k] + nt * (nt + 1) / 2; }
+        }
+        __syncthreads();
+        // ---- (1) every slot pair between two different bins of the affected set: unit = (neighbour, tile of 64 x, tile of 64 y)
+        const int total_units = s_ubase[K];
+        STile* tile = s_tile[wib];
+        for (int U = rank + world * wave; U < total_units; U += world * n_waves) {
+            int k = 0;
+            for (int j = 1; j < K; j++) k += (U >= s_ubase[j]) ? 1 : 0;
+            int u = U - s_ubase[k];
+            const int m = s_m[k], nt = (m + 63) >> 6;
+            int ti = 0;
+            while (u >= nt - ti) { u -= nt - ti; ti++; }
+            const int tj = ti + u;
+            const NbTables& T = tabs[k];
+            auto frag_at = [&](int i) { return sa.perm[i < s_lenA[k] ? s_baseA[k] + i : s_baseB[k] + (i - s_lenA[k])]; };
+            const int ix = ti * 64 + lane;
+            const bool has_x = ix < m;
+            Geo gx = {0, 0, 0, 0};
+            Stat sx = {0.0f, 0.0f, 0.0f, 0, 0, 0, 0, 0};
+            int fx = 0, px = 0, lbpx = 0;
+            if (has_x) {
+                fx = frag_at(ix); gx = geo[fx]; sx = stat[fx];
+                px = piece_of(T.key, gx.id_c, geo_pos(gx.flags));
+                lbpx = ((gx.flags >> 1) & 1) ? sa.lcontbp[fx] : 0;
+            }
+            {
+                const int iy = tj * 64 + lane;
+                if (iy < m) {
+                    STile y; y.frag = frag_at(iy); y.g = geo[y.frag]; y.st = stat[y.frag];
+                    y.piece = piece_of(T.key, y.g.id_c, geo_pos(y.g.flags));
+                    y.lbp = ((y.g.flags >> 1) & 1) ? sa.lcontbp[y.frag] : 0; y.pad = 0;
+                    tile[lane] = y;
+                }
+            }
+            WAVE_LDS_SYNC();
+            const End X0 = end_old(gx, lbpx);
+            long long accq[N_OPS];
+#pragma unroll
+            for (int op = 0; op < N_OPS; op++) accq[op] = 0;
+            unsigned bad = 0;
+            const int cnt = m - tj * 64 < 64 ? m - tj * 64 : 64;
+            for (int j = 0; j < cnt; j++) {
+                if (!has_x || ix >= tj * 64 + j) continue;       // every unordered pair once; never a bin with itself
+                const STile& y = tile[j];
+                const Stat sy = y.st;
+                const End Y0 = end_old(y.g, y.lbp);
+                float exo[3][3];
+#pragma unroll
+                for (int a = 0; a < 3; a++)
+#pragma unroll
+                    for (int b = 0; b < 3; b++)
+                        exo[a][b] = (a < sx.n && b < sy.n) ? ex_pair_ref(X0, sx, a, fx, Y0, sy, b, y.frag, sa.nfpb, sa.par, sa.quirk) : 0.0f;
+#pragma unroll
+                for (int op = 0; op < N_OPS; op++) {
+                    const unsigned idm = s_ident[k][op];
+                    if (((idm >> px) & 1u) && ((idm >> y.piece) & 1u)) continue;   // both pieces stay where they are: same inputs, same values
+                    const End X = end_xf(gx, s_xf[k][op][px]), Y = end_xf(y.g, s_xf[k][op][y.piece]);
+                    double acc = 0.0;
+#pragma unroll
+                    for (int a = 0; a < 3; a++)
+#pragma unroll
+                        for (int b = 0; b < 3; b++)
+                            if (a < sx.n && b < sy.n)
+                                acc += (double)exo[a][b] - (double)ex_pair_ref(X, sx, a, fx, Y, sy, b, y.frag, sa.nfpb, sa.par, sa.quirk);
+                    const long long q1 = to_q(acc);
+                    if (q1 == Q_BAD) bad |= 1u << op; else accq[op] += q1;
+                }
+            }
+#pragma unroll
+            for (int op = 0; op < N_OPS; op++) {
+                const long long qv = wave_sum_ll(accq[op]);
+                if (lane == 0 && qv != 0) atomicAdd((unsigned long long*)&s_accb[k * N_OPS + op], (unsigned long long)qv);
+            }
+            for (int o = 32; o > 0; o >>= 1) bad |= __shfl_down(bad, o, 64);
+            if (lane == 0 && bad) nf_flag_ops(counters + NF_OFF, k, bad);
+            WAVE_LDS_SYNC();
+        }
+        // ---- (2) the queued contacts (k_scan queued every contact with both ends in some neighbour's affected set): 16 lanes per
+        // contact, lane = candidate; every candidate of every such neighbour is priced again
+        {
+            const int op = lane & 15;
+            for (unsigned long long e0 = (unsigned long long)(n_waves - 1 - wave) * 4; e0 < nq_total; e0 += (unsigned long long)n_waves * 4) {
+                const unsigned long long e = e0 + (lane >> 4);
+                if (e >= nq_total || op >= N_OPS) continue;
+                const QEntry qe = fa.queue[e];
+                if (qe.rel == 0) continue;
+                const int fx = qe.fx, fy = qe.fy, slx = qe.slots & 3, sly = (qe.slots >> 2) & 3;
+                const Geo gx = geo[fx], gy = geo[fy];
+                const Stat sx = stat[fx], sy = stat[fy];
+                const End X0 = end_old(gx, ((gx.flags >> 1) & 1) ? sa.lcontbp[fx] : 0), Y0 = end_old(gy, ((gy.flags >> 1) & 1) ? sa.lcontbp[fy] : 0);
+                const float ex_old = ex_pair_ref(X0, sx, slx, fx, Y0, sy, sly, fy, sa.nfpb, sa.par, sa.quirk);
+                const double ln_old = log((double)ex_old), ob = (double)__int_as_float(qe.cnt);
+                unsigned rel = qe.rel;
+                while (rel) {
+                    const int k = (__ffs((int)rel) - 1) / CODE_BITS;
+                    rel &= rel - 1;
+                    const int p = (qe.ci >> (CODE_BITS * k)) & 7, q = (qe.cj >> (CODE_BITS * k)) & 7;
+                    const unsigned idm = s_ident[k][op];
+                    if (((idm >> p) & 1u) && ((idm >> q) & 1u)) continue;
+                    const End X = end_xf(gx, s_xf[k][op][p]), Y = end_xf(gy, s_xf[k][op][q]);
+                    const float ex_new = ex_pair_ref(X, sx, slx, fx, Y, sy, sly, fy, sa.nfpb, sa.par, sa.quirk);
+                    if (ex_new == ex_old) continue;
+                    const long long qv = to_q(ob * (log((double)ex_new) - ln_old));
+                    if (qv == Q_BAD) nf_flag(counters + NF_OFF, k, op);
+                    else if (qv != 0) atomicAdd((unsigned long long*)&s_accb[k * N_OPS + op], (unsigned long long)qv);
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < K * N_OPS; i += blockDim.x) {
+            const long long v = s_accb[i];
+            if (v != 0) atomicAdd((unsigned long long*)&fa.acc[i], (unsigned long long)v);
+        }
+        if (threadIdx.x == 255 && blockIdx.x == 0 && rank == 0) atomicAdd(&counters[1], (unsigned long long)total_units);
+    }
+    __shared__ int s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned long long ticket = atomicAdd(&counters[5], 1ull);
+        s_last = (ticket == (unsigned long long)gridDim.x - 1ull);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    hand_out(fa.acc, counters, fa.sync, K, d_q_out, host_res, seq);
+}
+
 // ------------------------------------------------------------------ repeated bins (allow_repeats)
 // A repeated ("duplicated") bin has several fragment copies (frag_dispatcher / collector_id_repeats,
 // simulation_loader.py:258-277); the expected value of a pixel is the float32 sum over the ACTIVE copy pairs of its two
@@ -2139,7 +2446,8 @@ struct Ctx {
     bool have_par = false, have_sub = false, have_frags = false, have_contacts = false, order_valid = false;
     int n_contigs = 0;
     double t_all = 0.0;         // layout independent all-trans expected mass
-    double c_lf = 0.0;          // sum of log-factorial terms of this shard's contacts
+    long long c_lf_q = 0;       // sum of the log-factorial terms of this shard's contacts, each rounded to Q: an integer sum, so
+                                // the full likelihood is bit-identical for any sharding of the list (a double sum depends on the order)
     std::vector<int> h_accu;    // [n_bins][3]
     int ln_lut_n = 0;           // entries of k_full_nnz's ln(trans) table (0: none)
     std::vector<int> h_nsub;
@@ -2186,6 +2494,9 @@ struct Ctx {
     unsigned long long* d_sync = nullptr; // [0] k_tm ticket
     unsigned* d_flags = nullptr;          // k_scan's per-block completion flags
     unsigned long long scan_done_total = 0; // blocks of all non-dry scans launched so far (completion counter mode)
+    int mode = 0;                 // GRAAL_MODE_* flags (graal_set_mode)
+    int* d_ubins = nullptr;       // bins whose sub-fragments carry different RF counts (k_quirk_mass)
+    int n_ubins = 0;
     bool finisher_ok = true;      // k_tm's last block may finish short-contig steps (switched off when the kernels turn
                                   // out not to run concurrently, e.g. under a profiler that serialises dispatches)
     int gave_up = 0;
@@ -2352,6 +2663,7 @@ int launch_scan(Ctx* h, int fA, const Neigh& nb, int K, int max_id, int dry, hip
     sa.col4 = reinterpret_cast<const int4*>(h->col); sa.geo2 = reinterpret_cast<const int2*>(h->geo); sa.sub2bin = h->sub2bin;
     sa.queue = h->queue; sa.counters = (unsigned long long*)(h->d_scalars + 10);
     sa.flags = h->d_flags; sa.seq32 = (unsigned)h->seq;
+    sa.strict = (h->mode & GRAAL_MODE_STRICT) ? 1 : 0;
     sa.done = (scan_done_counter() && !dry) ? h->d_sync + 8 : nullptr;
     if (sa.done) h->scan_done_total += (unsigned long long)nbk;
     if (nbk > MAX_SCAN_BLOCKS) return fail(h, GRAAL_E_ARG, "GRAAL_SCAN_BLOCKS too large");
@@ -2488,7 +2800,7 @@ void graal_destroy(graal_ctx* h)
         (void)hipSetDevice(h->device);
         (void)hipStreamSynchronize(h->stream);
         if (h->aux) (void)hipStreamSynchronize(h->aux);
-        void* ptrs[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->stat, h->sub_rec, h->sub2bin, h->row, h->col, h->cnt, h->queue, h->d_sub_ids, h->d_acc, h->tm_done, h->d_sync, h->d_flags, h->stat_frag, h->d_dup_bins, h->d_dup_index,
+        void* ptrs[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->stat, h->sub_rec, h->d_ubins, h->sub2bin, h->row, h->col, h->cnt, h->queue, h->d_sub_ids, h->d_acc, h->tm_done, h->d_sync, h->d_flags, h->stat_frag, h->d_dup_bins, h->d_dup_index,
                         h->d_dispatcher, h->d_collector, h->d_sub_ids_all, h->d_rep_obs,
                         h->keys, h->keys_sorted, h->o2n, h->len_of2[0], h->len_of2[1], h->contig_off2[0], h->contig_off2[1], h->perm, h->cbase, h->link, h->mates, h->cub_tmp, h->tabs, h->step_hdr, h->d_args, h->d_chg,
                         h->d_scalars, h->d_qout, h->d_dref, h->d_dist};
@@ -2571,6 +2883,21 @@ int graal_upload_subfrags(graal_ctx* h, const int32_t* sub_id, const float* sub_
     CK(hipMalloc(&h->sub2bin, sizeof(int) * (size_t)n_sub_total));
     CK(hipMalloc(&h->sub_rec, sizeof(SubRec) * (size_t)n_sub_total));
     CK(hipMemset(h->sub_rec, 0, sizeof(SubRec) * (size_t)n_sub_total));
+    {   // bins with non-uniform RF counts: the only ones the reference's trans-branch indexing prices differently
+        std::vector<int> ub;
+        for (int b = 0; b < n_bins; b++) {
+            const int ns = sub_id[4 * b + 3];
+            bool uni = true;
+            for (int k = 1; k < ns; k++) uni = uni && sub_accu[3 * b + k] == sub_accu[3 * b];
+            if (!uni) ub.push_back(b);
+        }
+        if (h->d_ubins) { (void)hipFree(h->d_ubins); h->d_ubins = nullptr; }
+        h->n_ubins = (int)ub.size();
+        if (h->n_ubins) {
+            CK(hipMalloc(&h->d_ubins, sizeof(int) * ub.size()));
+            CK(hipMemcpy(h->d_ubins, ub.data(), sizeof(int) * ub.size(), hipMemcpyHostToDevice));
+        }
+    }
     CK(hipMemcpy(h->stat, st.data(), sizeof(Stat) * (size_t)n_bins, hipMemcpyHostToDevice));
     CK(hipMemcpy(h->sub2bin, s2b.data(), sizeof(int) * (size_t)n_sub_total, hipMemcpyHostToDevice));
     h->n_bins = n_bins; h->n_sub_total = n_sub_total; h->nfpb = nfpb; h->single_sub = single; h->have_sub = true;
@@ -2642,9 +2969,9 @@ static int upload_contacts_impl(graal_ctx* h, const int32_t* row, const int32_t*
     if (!h->have_sub) return fail(h, GRAAL_E_STATE, "upload_subfrags first");
     if (nnz >= (1ll << 32)) return fail(h, GRAAL_E_ARG, "at most 2^32 - 1 contacts per shard");
     CK(hipSetDevice(h->device));
-    double c_lf = 0.0;
-    double lf_small[16];
-    for (int i = 0; i < 16; i++) lf_small[i] = lf_term((double)i);
+    long long c_lf_q = 0;
+    long long lf_small[16];
+    for (int i = 0; i < 16; i++) lf_small[i] = llrint(lf_term((double)i) * Q_SCALE);
     for (int64_t i = 0; i < nnz; i++) {
         if (row[i] < 0 || col[i] >= h->n_sub_total || row[i] >= col[i]) return fail(h, GRAAL_E_ARG, "contacts need 0 <= row < col < n_sub_total");
         const float c = count[i];
@@ -2652,7 +2979,7 @@ static int upload_contacts_impl(graal_ctx* h, const int32_t* row, const int32_t*
         if (h->has_rep && (h->h_dup_index[s2b_host(h, row[i])] >= 0 || h->h_dup_index[s2b_host(h, col[i])] >= 0))
             return fail(h, GRAAL_E_ARG, "contacts of repeated bins belong to graal_upload_repeats (observation rows), not to the contact list");
         const int ci = (int)c;
-        c_lf += (c < 16.0f && (float)ci == c) ? lf_small[ci] : lf_term((double)c);
+        c_lf_q += (c < 16.0f && (float)ci == c) ? lf_small[ci] : llrint(lf_term((double)c) * Q_SCALE);
     }
     if (h->row) { (void)hipFree(h->row); (void)hipFree(h->col); (void)hipFree(h->cnt); (void)hipFree(h->queue); h->row = h->col = h->cnt = nullptr; h->queue = nullptr; }
     const size_t bytes = sizeof(int) * (size_t)(nnz + 8); // +8: int4 tail reads stay in bounds
@@ -2664,7 +2991,7 @@ static int upload_contacts_impl(graal_ctx* h, const int32_t* row, const int32_t*
         CK(hipMemcpy(h->col, col, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
         CK(hipMemcpy(h->cnt, count, sizeof(float) * (size_t)nnz, hipMemcpyHostToDevice));
     }
-    h->nnz = nnz; h->c_lf = c_lf; h->have_contacts = true;
+    h->nnz = nnz; h->c_lf_q = c_lf_q; h->have_contacts = true;
     return sync_args(h);
 }
 
@@ -2881,15 +3208,20 @@ int graal_eval_full_q(graal_ctx* h, int64_t q_out[2])
     CK(hipMemsetAsync(h->d_scalars + FULL_BAD, 0, sizeof(long long), h->stream));
     if (h->has_rep) CK(hipMemsetAsync(h->d_scalars + 17, 0, sizeof(long long), h->stream));
     SoaPtr s = h->soa[h->cur];
+    const bool quirk = (h->mode & GRAAL_MODE_REF_TRANS_ACCU) != 0;
+    if (quirk && h->has_rep) return fail(h, GRAAL_E_UNSUPPORTED, "GRAAL_MODE_REF_TRANS_ACCU with repeated bins is not implemented");
     if (h->nnz) {
-        k_subrec<<<blocks_for(h->n, 256), 256, 0, h->stream>>>(h->n, h->geo, h->stat_frag, s.p[F_LCONTBP], h->d_sub_ids, h->sub_rec);
+        k_subrec<<<blocks_for(h->n, 256), 256, 0, h->stream>>>(h->n, h->geo, h->stat_frag, h->d_sub_ids, h->sub_rec);
         // 8 blocks of 256 threads per CU; every lane takes FULL_G groups of 4 contacts per iteration
         const long long groups = (h->nnz >> 2) + 1;
         const int nb = (int)std::max<long long>(1, std::min<long long>((groups + 256 * FULL_G - 1) / (256 * FULL_G), 256 * 8));
         k_full_nnz<<<nb, 256, 0, h->stream>>>(reinterpret_cast<const int4*>(h->row), reinterpret_cast<const int4*>(h->col),
-                                               reinterpret_cast<const int4*>(h->cnt), h->nnz, h->sub_rec, h->nfpb, h->par, h->ln_lut_n,
-                                               h->d_scalars + 8, h->d_scalars + FULL_BAD);
+                                               reinterpret_cast<const int4*>(h->cnt), h->nnz, h->sub_rec, s.p[F_LCONTBP], h->nfpb, h->par,
+                                               h->ln_lut_n, quirk ? 1 : 0, h->d_scalars + 8, h->d_scalars + FULL_BAD);
     }
+    if (quirk && h->n_ubins) // T_all prices every pair of different bins with the plain trans value: add the indexing's difference
+        k_quirk_mass<<<blocks_for((long long)h->n_ubins * h->n_bins, 256), 256, 0, h->stream>>>(h->n_ubins, h->d_ubins, h->n_bins, h->geo, h->stat_frag,
+                                                                                             h->nfpb, h->par, h->d_scalars + 9, h->d_scalars + FULL_BAD);
     k_full_mass<<<blocks_for(h->n, 16), 256, 0, h->stream>>>(h->n, h->perm, h->contig_off2[h->cur], h->geo, h->stat_frag, s.p[F_LCONT],
                                                              s.p[F_LCONTBP], s.p[F_POS], h->nfpb, h->par, reach_bp(h),
                                                              h->d_scalars + 9, h->d_scalars + FULL_BAD);
@@ -2904,9 +3236,9 @@ int graal_eval_full_q(graal_ctx* h, int64_t q_out[2])
     CK(hipMemcpyAsync(&bad, h->d_scalars + FULL_BAD, sizeof bad, hipMemcpyDeviceToHost, h->stream));
     CK(hipMemcpyAsync(res, h->d_scalars + 8, sizeof res, hipMemcpyDeviceToHost, h->stream));
     CK(hipStreamSynchronize(h->stream));
-    q_out[0] = res[0] - (int64_t)llrint(h->c_lf * Q_SCALE);
+    q_out[0] = res[0] - (int64_t)h->c_lf_q;
     q_out[1] = -(res[1] + (int64_t)llrint(h->t_all * Q_SCALE)) + rep_q;
-    if (bad) { q_out[0] = Q_NAN; q_out[1] = 0; } // a term was not finite / out of range: the host reports NaN
+    if (bad) { q_out[0] = Q_BAD; q_out[1] = 0; } // a term was not finite / out of range: INT64_MIN exactly, the host reports NaN
     return GRAAL_OK;
 }
 
@@ -2935,7 +3267,10 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
         if (st != h->stream) CK(hipStreamWaitEvent(st, h->ev_relabel, 0));
         h->relabel_pending = false;
     }
+    const bool strict = (h->mode & GRAAL_MODE_STRICT) != 0;
+    if (strict && h->has_rep) return fail(h, GRAAL_E_UNSUPPORTED, "GRAAL_MODE_STRICT with repeated bins is not implemented");
     TmArgs ta;
+    ta.strict = strict ? 1 : 0;
     ta.geo = h->geo; ta.link = h->link; ta.cbase = h->cbase; ta.mates = h->mates; ta.tabs = h->tabs; ta.step_hdr = h->step_hdr;
     static const bool no_finisher = getenv("GRAAL_NO_FINISHER") != nullptr; // always finish with k_fin (diagnostics)
     ta.flags = h->d_flags;
@@ -2944,7 +3279,7 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     // (late stage -- a few long contigs hold nearly every fragment: nearly every step needs k_fin anyway, so it is launched
     // right behind the scan instead of after k_tm's verdict has made the round trip through the host, ~10 us per step)
     const bool late_stage = h->max_lcont > 128 && (long long)h->n_contigs * 64 < (long long)h->n;
-    ta.host_res = (h->publish && (world == 1 || h->x_host) && !no_finisher && h->finisher_ok && !h->has_rep && !late_stage) ? h->res_dev : nullptr;
+    ta.host_res = (h->publish && (world == 1 || h->x_host) && !no_finisher && h->finisher_ok && !h->has_rep && !late_stage && !strict) ? h->res_dev : nullptr;
     // a generous multiple of the time the streaming pass needs at 2 TB/s, plus launch slack
     ta.wait_ticks = (int)std::min<long long>(100ll * 50 + (long long)(4.0 * 4.0 * (double)h->nnz / 2.0e12 * 1.0e8), 1ll << 30);
     ta.counters = (unsigned long long*)(h->d_scalars + 10); ta.queue = h->queue; ta.stat = h->stat_frag;
@@ -2965,7 +3300,17 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
                                                                                          h->d_acc, (unsigned long long*)(h->d_scalars + 10));
         CK(hipGetLastError());
     }
-    if (ta.host_res == nullptr) {
+    if (strict) {
+        FinArgs fa;
+        fa.tm_done = h->tm_done; fa.step_hdr = h->step_hdr; fa.counters = (unsigned long long*)(h->d_scalars + 10); fa.queue = h->queue;
+        fa.tabs = h->tabs; fa.geo = h->geo; fa.stat = h->stat_frag; fa.acc = h->d_acc; fa.sync = h->d_sync;
+        StrictArgs sx;
+        sx.perm = h->perm; sx.cbase = h->cbase; sx.lcontbp = h->soa[h->cur].p[F_LCONTBP]; sx.link = h->link; sx.nfpb = h->nfpb; sx.par = h->par;
+        sx.quirk = (h->mode & GRAAL_MODE_REF_TRANS_ACCU) ? 1 : 0;
+        k_strict<<<1024, 256, 0, st>>>(fa, sx, fA, K, rank, world, (long long*)d_q_out, h->publish ? h->res_dev : nullptr, h->seq);
+        CK(hipGetLastError());
+        if (!h->publish) { CK(hipEventRecord(h->ev_fin, st)); h->fin_pending = true; }
+    } else if (ta.host_res == nullptr) {
         int rc_ = launch_fin(h, K, rank, world, (long long*)d_q_out, h->publish, st);
         if (rc_) return rc_;
         if (!h->publish) { CK(hipEventRecord(h->ev_fin, st)); h->fin_pending = true; }
@@ -3168,6 +3513,14 @@ int graal_genome_distance(graal_ctx* h, int64_t* half_units)
     }
     __sync_synchronize();
     *half_units = p[1];
+    return GRAAL_OK;
+}
+
+int graal_set_mode(graal_ctx* h, int32_t flags)
+{
+    if (!h || (flags & ~(GRAAL_MODE_REF_TRANS_ACCU | GRAAL_MODE_STRICT))) return GRAAL_E_ARG;
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    h->mode = flags;
     return GRAAL_OK;
 }
 

@@ -122,7 +122,7 @@ class Group:
         return m
 
 
-Q_NAN_LIMIT = 1 << 57   # |q| at or above this: a term of that sum was not finite / out of range (graal_hip.hip: Q_NAN)
+Q_NAN_LIMIT = 1 << 58   # a candidate's |q| at or above this: a term of that sum was not finite / out of range (graal_hip.hip: Q_NAN)
 
 
 def q_to_float(q):

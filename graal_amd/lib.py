@@ -11,9 +11,12 @@ import numpy as np
 from . import build as _build
 
 N_OPS = 13
+ABI_VERSION = 2
+MODE_REF_TRANS_ACCU, MODE_STRICT = 1, 2
 MAX_NEIGHBOURS = 10
 Q_SCALE = float(1 << 30)
-Q_NAN_LIMIT = 1 << 57   # |Q| at or above this stands for NaN: a term was not finite / did not fit (graal_hip.hip: Q_NAN)
+Q_NAN_LIMIT = 1 << 58   # a candidate's |Q| at or above this stands for NaN: a term was not finite / did not fit (graal_hip.hip: Q_NAN)
+Q_FULL_BAD = -(1 << 63)  # graal_eval_full_q: q[0] == INT64_MIN exactly flags a non-finite / out-of-range term
 FIELDS = ("pos", "id_c", "start_bp", "len_bp", "circ", "id", "prev", "next", "l_cont", "l_cont_bp", "ori", "rep",
           "activ", "id_d")  # struct frag, kernels3.cu:9-24
 
@@ -25,7 +28,7 @@ _f64p = ctypes.POINTER(ctypes.c_double)
 SYMBOLS = ("graal_abi_version", "graal_create", "graal_destroy", "graal_last_error", "graal_set_params",
            "graal_upload_subfrags", "graal_upload_repeats", "graal_upload_contacts", "graal_upload_contacts_f32", "graal_upload_frags", "graal_download_frags",
            "graal_relabel_contigs", "graal_begin_step", "graal_begin_step_launch", "graal_layout_stats", "graal_eval_full_q", "graal_eval_candidates_q",
-           "graal_eval_candidates", "graal_exchange_bytes", "graal_attach_exchange", "graal_eval_candidates_x", "graal_exchange_selftest", "graal_detach_exchange", "graal_upload_distance_ref", "graal_genome_distance", "graal_apply_move", "graal_set_finisher", "graal_set_timing", "graal_last_timing", "graal_scan_times", "graal_time_scan", "graal_last_counters")
+           "graal_eval_candidates", "graal_exchange_bytes", "graal_attach_exchange", "graal_eval_candidates_x", "graal_exchange_selftest", "graal_detach_exchange", "graal_upload_distance_ref", "graal_genome_distance", "graal_apply_move", "graal_set_finisher", "graal_set_mode", "graal_set_timing", "graal_last_timing", "graal_scan_times", "graal_time_scan", "graal_last_counters")
 
 _lib = None
 
@@ -78,6 +81,7 @@ def load():
         L.graal_last_counters.argtypes = [ctypes.c_void_p, _i64p]
         L.graal_set_timing.argtypes = [ctypes.c_void_p, ctypes.c_int32]
         L.graal_set_finisher.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+        L.graal_set_mode.argtypes = [ctypes.c_void_p, ctypes.c_int32]
         L.graal_scan_times.argtypes = [ctypes.c_void_p, ctypes.c_int32, _f32p]
         L.graal_time_scan.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, _f32p]
         _lib = L
@@ -235,7 +239,7 @@ class Engine:
 
     def eval_full(self):
         q = self.eval_full_q()
-        if abs(int(q[0])) >= Q_NAN_LIMIT:   # a term was not finite / out of range (the reference would return -inf / NaN)
+        if int(q[0]) == Q_FULL_BAD:         # a term was not finite / out of range (the reference would return -inf / NaN)
             return float("nan")
         return float(int(q[0]) + int(q[1])) / Q_SCALE
 
@@ -338,6 +342,11 @@ class Engine:
     def set_finisher(self, enabled):
         """Let the table kernel's last block finish short-contig steps (default) or always use the finishing kernel."""
         self._ck(self._L.graal_set_finisher(self._h, 1 if enabled else 0), "graal_set_finisher")
+
+    def set_mode(self, ref_trans_accu=False, strict=False):
+        """Reference-arithmetic switches (include/graal_hip.h: GRAAL_MODE_REF_TRANS_ACCU = 1, GRAAL_MODE_STRICT = 2)."""
+        self._ck(self._L.graal_set_mode(self._h, (MODE_REF_TRANS_ACCU if ref_trans_accu else 0) | (MODE_STRICT if strict else 0)),
+                 "graal_set_mode")
 
     def set_timing(self, enabled):
         self._ck(self._L.graal_set_timing(self._h, int(enabled)), "graal_set_timing")

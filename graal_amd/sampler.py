@@ -26,7 +26,7 @@ import numpy as np
 
 from . import dist as gdist
 from .gpustruct import GPUStruct
-from .lib import FIELDS, MAX_NEIGHBOURS, N_OPS, Q_SCALE, Engine
+from .lib import FIELDS, MAX_NEIGHBOURS, N_OPS, Q_FULL_BAD, Q_SCALE, Engine
 
 N_TMP_STRUCT = N_OPS  # cuda_lib_gl.py:112
 MODIFICATION_STR = ['eject frag', 'flip frag',
@@ -281,7 +281,8 @@ class sampler(object):
                  S_o_A_sub_frags,
                  hic_matrix, mean_value_trans, n_iterations, is_simu, gl_window=None, pos_vbo=None, col_vbo=None,
                  vel=None, pos=None, raw_im_init=None, pbo_im_buffer=None, sub_sample_factor=0,
-                 device=None, rng=None, group=None, param_simu=None, compute_dist=True, exchange=None):
+                 device=None, rng=None, group=None, param_simu=None, compute_dist=True, exchange=None,
+                 reference_arithmetic=None):
         self.o = 0
         self.use_rippe = use_rippe
         self.gl_window = gl_window
@@ -342,6 +343,14 @@ class sampler(object):
             # sum Q vectors of different proposals and their layouts would diverge silently
             raise ValueError("a sharded sampler (world > 1) needs an explicit, identically seeded rng= on every rank")
         self.engine = Engine(0 if device is None else int(device))  # raises if the HIP library / GPU is missing
+        # reference-arithmetic switches (include/graal_hip.h): None = the fast default; "trans_accu" = the
+        # reference's RF-count indexing in the trans branch (kernels3.cu:3155); "strict" = that plus candidate deltas that
+        # re-price every pixel of contig(A) u contig(B) from float32 coordinates like sub_compute_likelihood (validation mode)
+        if reference_arithmetic not in (None, "trans_accu", "strict"):
+            raise ValueError("reference_arithmetic must be None, 'trans_accu' or 'strict'")
+        self.reference_arithmetic = reference_arithmetic
+        if reference_arithmetic:
+            self.engine.set_mode(ref_trans_accu=True, strict=reference_arithmetic == "strict")
         self.engine.upload_subfrags(self.np_sub_frags_id, self.np_sub_frags_len_bp, self.np_sub_frags_accu,
                                     int(self.init_n_sub_frags), float(self.mean_squared_frags_per_bin))
         self.sub_coo_full = self.sub_coo   # (what estimate_parameters fits: the whole observation matrix, cuda_lib_gl.py:1244)
@@ -375,7 +384,7 @@ class sampler(object):
         # MCMC steps between full re-evaluations of the carried-over likelihood.  With repeats every step: the reference's
         # candidate pixel ranges miss some pixels an activity swap changes (kernels3.cu:3368-3373), so its per-step total
         # (always a full evaluation, cuda_lib_gl.py:1828-1848) is not the previous score
-        self.resync_every = 1 if len(self.id_frag_duplicated) else 512
+        self.resync_every = 1 if (len(self.id_frag_duplicated) or self.reference_arithmetic == "strict") else 512
         self._steps_since_full = 0
         self._force_full = False   # the carried-over total is not a likelihood of the current layout / parameters
         # ---- proposal ----------------------------------------------------------------------------------------
@@ -527,8 +536,11 @@ class sampler(object):
     # ------------------------------------------------------------------ likelihood
     def _full_likelihood(self):
         q = self.engine.eval_full_q()
-        q0 = self.group.all_reduce_sum_int(int(q[0]))
-        if abs(q0) >= gdist.Q_NAN_LIMIT:       # some term was not finite (the reference's double sum would be -inf / NaN)
+        bad = int(q[0]) == Q_FULL_BAD          # some term was not finite (the reference's double sum would be -inf / NaN)
+        if self.group.world > 1:
+            bad = self.group.all_reduce_max_int(1 if bad else 0) != 0
+        q0 = self.group.all_reduce_sum_int(0 if bad else int(q[0]))
+        if bad:
             return float("nan")
         return float(q0 + int(q[1])) / Q_SCALE
 

@@ -101,12 +101,18 @@ def make_problem(n_bins=50000, nnz=20_000_000, n_sub=1, seed=20141217, contig_we
     sub_len = np.zeros((n_bins, 3), dtype=np.float32)
     sub_accu = np.zeros((n_bins, 3), dtype=np.int32)
     sub_id[:, 3] = sub_per_bin
+    # accu = an int (uniform RF counts) or ("random", lo, hi): every sub-fragment draws its own count in [lo, hi]
+    if isinstance(accu, (tuple, list)):
+        accu_of_sub = rng.randint(int(accu[1]), int(accu[2]) + 1, size=n_sub_total).astype(np.int32)
+        accu = float(accu_of_sub.mean())
+    else:
+        accu_of_sub = np.full(n_sub_total, accu, dtype=np.int32)
     for k in range(3):
         m = sub_per_bin > k
         sub_id[m, k] = sub_first[m] + k
         sub_len[m, k] = np.float32(sub_len_bp[sub_first[m] + k]) / np.float32(1000.0)
-        sub_accu[m, k] = accu
-    accu_all = np.full(n_sub_total, accu, dtype=np.float32)
+        sub_accu[m, k] = accu_of_sub[sub_first[m] + k]
+    accu_all = accu_of_sub.astype(np.float32)
     nfpb = np.float32(accu_all.mean() ** 2)  # simulation_loader.py:73
     if param is None:
         param = make_param_simu()

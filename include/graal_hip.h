@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GRAAL_ABI_VERSION 1
+#define GRAAL_ABI_VERSION 2
 #define GRAAL_N_OPS 13        /* candidates per (fA, fB): cuda_lib_gl.py:112 n_tmp_struct */
 #define GRAAL_MAX_NEIGHBOURS 10 /* neighbours scored by one scan pass (the reference proposes at most n_neighbors = 10, cuda_lib_gl.py:444) */
 #define GRAAL_Q_BITS 30
@@ -138,6 +138,19 @@ int graal_exchange_selftest(graal_ctx* h, int64_t tag, int32_t phase);
 int graal_detach_exchange(graal_ctx* h);
 /* synchronous, sharded: K*13 int64 Q sums over ALL ranks into a host buffer (every rank must make the same call) */
 int graal_eval_candidates_x(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int32_t max_id, int64_t* q_sum);
+
+/* Reference-arithmetic switches (default 0 = neither).
+ * GRAAL_MODE_REF_TRANS_ACCU: trans pixels are priced with the reference's RF-count indexing of reversed bins
+ *   (kernels3.cu:3155 / 3638: list_accu_data_i[i] = accu_sub_fi[limit_fi]) in the full evaluation and in strict deltas; only bins
+ *   whose sub-fragments carry different RF counts see a difference.  The oracle's fix_trans_accu=False.
+ * GRAAL_MODE_STRICT: graal_eval_candidates* price every candidate the way sub_compute_likelihood defines it
+ *   (kernels3.cu:3259-3718): every pixel between two different bins of contig(fA) u contig(fB) again, from the float32 kb
+ *   coordinates of the candidate layout -- including the pairs whose geometry the move does not change (the default path treats
+ *   those as exactly unchanged; the reference's values for them move by float32 rounding noise, which on megabase contigs reaches
+ *   ~1e-4 of logL).  O(m^2) per candidate: a validation mode.  Not available with repeated bins. */
+#define GRAAL_MODE_REF_TRANS_ACCU 1
+#define GRAAL_MODE_STRICT 2
+int graal_set_mode(graal_ctx* h, int32_t flags);
 
 /* In the synchronous single-GPU call, a step that leaves little work (short contigs) is finished by the last block of the
  * table kernel, which runs concurrently with the streaming kernel and waits for it; otherwise a third kernel finishes it.

@@ -26,7 +26,8 @@ def test_library_exports_every_declared_symbol():
     for sym in declared_symbols():
         assert hasattr(L, sym), sym
     L.graal_abi_version.restype = ctypes.c_int
-    assert L.graal_abi_version() == 1
+    from graal_amd import lib
+    assert L.graal_abi_version() == lib.ABI_VERSION == 2
 
 
 def test_no_gpu_means_a_loud_error_not_a_fallback():

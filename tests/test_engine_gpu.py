@@ -64,7 +64,7 @@ def random_state_for(P, rng, **kw):
 
 def test_library_loads_on_gpu():
     from graal_amd import lib
-    assert lib.load().graal_abi_version() == 1
+    assert lib.load().graal_abi_version() == lib.ABI_VERSION
 
 
 @pytest.mark.parametrize("n_sub,seed", [(1, 1), (3, 2)])
@@ -410,3 +410,53 @@ def test_powf_pos_is_the_device_librarys_powf_bit_for_bit(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300, check=True).stdout
     lines = [l for l in out.splitlines() if l.startswith("y=")]
     assert len(lines) == 8 and all("mismatches 0 " in l for l in lines), out
+
+
+def test_non_finite_terms_surface_as_nan_not_as_arbitrary_numbers():
+    """An expected value that overflows float32 makes the reference's evaluate_likelihood_double return +-inf / NaN
+    (kernels3.cu:191-210).  The engine's int64 sums cannot hold that: such a term flags its candidate (or the full
+    evaluation) and the host reports NaN -- never a saturated, finite-looking number."""
+    P = make(1, 58, n_bins=40, nnz=500, grid_bp=2000)
+    s = random_state_for(P, np.random.RandomState(58), n_contigs=3, p_circ=0.0)
+    max_id = relabel_ref(s)
+    e = engine_for(P, s)
+    e.relabel_contigs()
+    ok = e.eval_candidates(3, [4, 20, 33], max_id)
+    assert np.isfinite(ok).all() and np.isfinite(e.eval_full())
+    par = np.array(P["param_simu"], dtype=np.float32)
+    par[6] = 3.0e38                      # fact: every cis expected value inside the window overflows to +inf
+    e.set_params(par)
+    assert np.isnan(e.eval_full())
+    got = e.eval_candidates(3, [4, 20, 33], max_id)
+    assert np.isnan(got).any()
+    e.set_params(P["param_simu"])        # and the flags do not stick
+    assert np.array_equal(e.eval_candidates(3, [4, 20, 33], max_id), ok) and np.isfinite(e.eval_full())
+    e.close()
+
+
+@pytest.mark.parametrize("n_sub,n_bins,K", [(1, 1500, 3), (1, 1500, 5), (3, 700, 3)])
+def test_window_of_hundreds_of_fragments_long_pieces(n_sub, n_bins, K):
+    """A contact model whose window (d_max) spans hundreds of fragments on contigs of ~500-750 bins: mass tasks between pieces
+    of several hundred fragments, walks of several 64-fragment tiles and several segments per work item (128 fragments per
+    segment with one sub-fragment per bin) -- the shape of C5 on its original contigs, at a size the dense oracle handles."""
+    par = synth.make_param_simu(fact=1.0e4, v_inter=1.0e-3)          # d_max ~ 3,166 kb: the window is the whole contig
+    P = synth.with_dense(synth.make_problem(n_bins=n_bins, nnz=40000, n_sub=n_sub, seed=71, contig_weights=(1, 1), mean_len_bp=1500.0,
+                                            accu=1 if n_sub == 1 else 9, param=par, grid_bp=2000))
+    dense = dense_for(P)
+    s = O.copy_state(P["S_o_A_frags"]); s["id_c"][:] -= 1
+    max_id = relabel_ref(s)
+    e = engine_for(P, s)
+    assert e.relabel_contigs() == max_id
+    rng = np.random.RandomState(72)
+    n = P["n_frags"]
+    for trial in range(3):
+        fA = int(rng.randint(n))
+        if trial == 0:   # neighbours next to fA in its own contig (what the proposal usually draws)
+            fBs = sorted(set(int(v) for v in np.clip(fA + np.array([-2, -1, 1, 2, 3, 5, 8][:K]), 0, n - 1)) - {fA})
+        else:
+            fBs = sorted(int(v) for v in rng.choice(np.setdiff1d(np.arange(n), [fA]), K, replace=False))
+        base, want = oracle_deltas(P, dense, s, fA, fBs, max_id)
+        got = e.eval_candidates(fA, fBs, max_id)
+        err = np.abs(got - want).max()
+        assert err <= 1e-7 * abs(base), (trial, fA, fBs, err / abs(base), got[0], want[0])
+    e.close()

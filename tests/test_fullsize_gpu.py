@@ -96,6 +96,14 @@ def test_c5_properties(c5):
 # C5 on its 7 ORIGINAL contigs (2.7-6.8k fragments each): what bench.py reports as `late_stage`.  Every step queues millions of
 # contacts and thousands of mass work items; the dense oracle cannot run at this size, so the checks are the reference's implied
 # invariant (delta == full after - full before, cuda_lib_gl.py:2196-2220), finisher setting irrelevant, and 2 ranks == 1 rank.
+#
+# The invariant is checked on a GRID variant of the map (every fragment a multiple of 1,000 bp: float32 kb coordinates are exact,
+# so shifting a piece does not re-round anybody's coordinates).  On C5's own fragments (1 + Exp(660) bp, some of a few bp, at
+# coordinates of several thousand kb where one float32 ulp is 0.5 bp) a FULL evaluation of the moved layout re-rounds the
+# centres of every downstream fragment, and the expected values of neighbouring few-bp fragments -- ~1e6 contacts at the C5
+# parameters -- jump by that rounding: full(after) - full(before) then differs from the geometric delta by ~1e-4 of logL
+# (measured with the numpy re-score, which agrees with the engine's full evaluation to 1e-9: tools/diag_late.py).  The
+# reference's own candidate scores carry that noise; GRAAL_MODE_STRICT reproduces it, the default path is free of it.
 def _original_sampler(P, group=None, seed=11):
     import bench
     rng = np.random.RandomState(seed)
@@ -120,8 +128,14 @@ def c5_original():
     return synth.make_problem(n_bins=50000, nnz=20_000_000, n_sub=1, seed=20141217)
 
 
-def test_c5_original_layout_delta_is_full_after_minus_before(c5_original):
-    smp = _original_sampler(c5_original)
+@pytest.fixture(scope="module")
+def c5_grid():
+    from graal_amd import synth
+    return synth.make_problem(n_bins=50000, nnz=20_000_000, n_sub=1, seed=20141217, grid_bp=1000)
+
+
+def test_c5_original_layout_delta_is_full_after_minus_before(c5_grid):
+    smp = _original_sampler(c5_grid)
     st = smp.engine.layout_stats()
     assert int(st[0]) == 7 and int(st[4]) > 5000
     worst = 0.0
@@ -138,11 +152,9 @@ def test_c5_original_layout_delta_is_full_after_minus_before(c5_original):
         for k, op in (np.unravel_index(np.argmax(np.abs(d)), d.shape), np.unravel_index(np.argmax(d), d.shape)):
             smp.test_copy_struct(fA, nb[k], int(op), max_id)
             after = smp.eval_likelihood()
-            # float32 kb coordinates of megabase contigs: a full evaluation of the moved layout re-rounds every centre
-            # (deviation 1), so the two sides agree to ~1e-6 x |logL|, far inside north_star's 1e-5
             err = abs(d[k, op] - (after - before)) / abs(before)
             worst = max(worst, err)
-            assert err < 1e-5, (fA, nb[k], op, d[k, op], after - before)
+            assert err < 1e-8, (fA, nb[k], op, d[k, op], after - before)   # (grid coordinates: exact geometry; Q30 rounding only)
             # undo is not defined for every op: continue from the moved layout
             max_id = smp.modify_gl_cuda_buffer(0)
             before = after

@@ -9,8 +9,10 @@ import pytest
 from graal_amd import pyramid as pyr
 
 
-def make_dataset(tmp, rng, contig_sizes=(11, 7, 5), n_pairs=6000, empty=(4, 15)):
-    """info_contigs.txt / fragments_list.txt / abs_fragments_contacts_weighted.txt (README.md:111-113)."""
+def make_dataset(tmp, rng, contig_sizes=(11, 7, 5), n_pairs=6000, empty=(4, 15), polymer_like=False):
+    """info_contigs.txt / fragments_list.txt / abs_fragments_contacts_weighted.txt (README.md:111-113).
+    polymer_like: index offsets of the contact pairs follow a power law (~ k^-1.3) plus a uniform background instead of a
+    geometric law, so that the Rippe fit of the dataset lands on polymer-like parameters."""
     frag_rows, contig_rows, seqs = [], [], {}
     cum = 0
     for ci, nf in enumerate(contig_sizes):
@@ -29,7 +31,14 @@ def make_dataset(tmp, rng, contig_sizes=(11, 7, 5), n_pairs=6000, empty=(4, 15))
     pyr._write_table(os.path.join(tmp, "fragments_list.txt"), ["id", "chrom", "start_pos", "end_pos", "size", "gc_content"], frag_rows)
     ok = np.setdiff1d(np.arange(n), empty)
     a = rng.choice(ok, size=n_pairs)
-    b = np.clip(a + rng.geometric(0.35, size=n_pairs) * rng.choice([-1, 1], size=n_pairs), 0, n - 1)
+    if polymer_like:
+        ks = np.arange(1, max(2, n // 2))
+        pk = ks ** -1.3
+        off = rng.choice(ks, size=n_pairs, p=pk / pk.sum())
+        off = np.where(rng.random_sample(n_pairs) < 0.12, rng.randint(1, n, size=n_pairs), off)   # uniform background
+    else:
+        off = rng.geometric(0.35, size=n_pairs)
+    b = np.clip(a + off * rng.choice([-1, 1], size=n_pairs), 0, n - 1)
     b = np.where(np.isin(b, empty), a, b)
     extra = [(e, e + 1) for e in empty]           # the "empty" fragments get one contact each: very sparse rows
     pairs = np.concatenate([np.stack([a, b], 1), np.array(extra)]) + 1

@@ -184,12 +184,13 @@ def test_headless_run_from_a_dataset_folder(tmp_path):
     from graal_amd import run
     from tests.test_pyramid import make_dataset
     base = str(tmp_path / "ds")
-    make_dataset(base, np.random.RandomState(21), contig_sizes=(40, 30, 20), n_pairs=40000, empty=(4, 45))
+    make_dataset(base, np.random.RandomState(21), contig_sizes=(40, 30, 20), n_pairs=40000, empty=(4, 45), polymer_like=True)
     out = str(tmp_path / "out")
     tr = run.main(["--dataset", base, "--fasta", os.path.join(base, "genome.fa"), "--size-pyramid", "3", "--level", "1",
                    "--cycles", "3", "--neighbours", "3", "--seed", "5", "--out", out])
     n = len(tr.likelihood)
-    assert n == 3 * 27 and np.isfinite(tr.likelihood).all()   # (toy contacts are not polymer-like: no claim on the assembly)
+    n_frags = len(set(tr.id_fA))
+    assert n == 3 * n_frags and 20 <= n_frags <= 30 and np.isfinite(tr.likelihood).all()   # (a toy: no claim on the assembly)
     muts = em.load_mutations(os.path.join(out, "list_mutations.txt"))
     assert muts.shape == (n, 3) and np.array_equal(muts, tr.mutations())
     fa = open(os.path.join(out, "genome.fasta")).read()
@@ -256,5 +257,9 @@ def test_blacklisted_fragments_with_parameter_sampling_match_oracle():
     assert np.allclose(t_gpu.likelihood_nuisance, t_ref.likelihood_nuisance, rtol=1e-6, atol=0)
     g.gpu_vect_frags.copy_from_gpu()
     for k in O.FIELDS:
-        assert np.array_equal(getattr(g.gpu_vect_frags, k), ora.gpu_vect_frags[k]), k
+        if k != "id_c":
+            assert np.array_equal(getattr(g.gpu_vect_frags, k), ora.gpu_vect_frags[k]), k
+    # (the last nuisance step's full evaluation relabels the contigs on the GPU side: labels are compared as a partition)
+    a, b = g.gpu_vect_frags.id_c, ora.gpu_vect_frags["id_c"]
+    assert np.array_equal(a[:, None] == a[None, :], b[:, None] == b[None, :])
     g.free_gpu()
