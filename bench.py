@@ -261,9 +261,11 @@ def main():
         td.all_reduce(t, op=td.ReduceOp.MAX)
         return float(t.cpu()[0])
 
-    # a HIP event pair around k_scan on every step of a short timed region (the driver's 20 steps give 20 samples), on every
-    # 8th step of a long one (each pair adds command-processor marker gaps to that step)
-    EVENT_EVERY = 1 if args.steps <= 64 else 8
+    # a HIP event pair around k_scan on every 4th step of a short timed region (the driver's 20 steps give 5 samples), on every
+    # 8th step of a long one.  Not on every step: each pair adds command-processor marker gaps -- measured with a pair on EVERY
+    # step: 72 instead of 40 us per step and 35 instead of 24 us between the two events of a pair (r02, gpurun_out/bench_r02a.log)
+    # -- so a densely instrumented region measures its own instrumentation
+    EVENT_EVERY = int(os.environ.get("GRAAL_BENCH_EVENT_EVERY", 4 if args.steps <= 64 else 8))
     smp.engine.set_timing(EVENT_EVERY)
     for f, nb in props[:args.warmup]:
         smp._candidate_deltas(f, nb, max_id)
@@ -296,6 +298,7 @@ def main():
                "value": n_cand / ta, "ms_per_step": 1e3 * ta / args.steps}
     # for reference: back-to-back replays of the last step's scan between two events (per-launch event overhead amortised)
     scan_replay_ms = smp.engine.time_scan(len(props[-1][1]), reps=100)
+    scan_isolated_ms = smp.engine.time_scan(len(props[-1][1]), reps=-40)   # median of isolated replays (device idle in between)
 
     # ---- Infinity-Cache control of the roofline figure (rank 0's GPU, N = 1) ---------------------------------------
     control = None
@@ -411,6 +414,7 @@ def main():
                          "launches_timed": int(len(scan_ms)),
                          "back_to_back_replay_ms": replay_s * 1e3,
                          "frac_back_to_back_replays": bytes_per_launch / replay_s / 1e9 / HBM_PEAK_GBS,
+                         "isolated_replay_ms": scan_isolated_ms,
                          "hbm_control": control},
             "phase_ms": {"k_scan": float(np.mean(scan_ms)), "host_wall_per_step": 1e3 * elapsed / args.steps},
             "relevant_pairs_last_step": int(counters[1]), "queued_contacts_last_step": int(counters[2]),

@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-HIP_LIB = os.path.join(HERE, "libgraal_hip.so")
+HIP_LIB = os.environ.get("GRAAL_HIP_LIB") or os.path.join(HERE, "libgraal_hip.so")   # (override: experiments with variant builds)
 HOSTCHECK_LIB = os.path.join(HERE, "libgraal_hostcheck.so")
 
 

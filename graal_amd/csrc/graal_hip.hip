@@ -21,6 +21,7 @@
 #include <string.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <chrono>
 #include <string>
 #include <vector>
@@ -1199,6 +1200,95 @@ __device__ __forceinline__ void price_contacts(const PriceArgs& pa, unsigned lon
     }
 }
 
+// The same for MANY queued contacts (k_fin; long contigs queue millions per step and this pricing is most of the step).  Three
+// things the small routine above does not bother with:
+//  * the OLD expected value's logarithm is computed once per contact -- a wave takes 64 entries, lane = entry, and hands the
+//    value to the (contact, candidate) passes by shuffle -- instead of once per (contact, candidate) lane;
+//  * a NEW relation that is trans needs no logarithm: ln(v_inter * norm) comes from the table k_ln_tab built with the very
+//    same expression (the table k_full_nnz's blocks build for themselves);
+//  * neighbours that lead to the SAME candidate geometry of the two fragments (ejecting fA does not depend on the neighbour
+//    at all; cuts at nearby fragments leave a far pair in the same relative position) are priced once: the lane remembers the
+//    inputs of its last evaluation.  Same inputs, same float32 / float64 operations: the sums are bit-identical to the small routine's.
+__device__ __forceinline__ void price_contacts_bulk(const PriceArgs& pa, const double* __restrict__ ln_tab, int lut_n,
+                                                    unsigned long long nq_total, int first, int n_waves, int lane)
+{
+    const int op = lane & 15, c4 = lane >> 4;
+    auto ln_of = [&](const End& X, const Stat& sx, int slx, const End& Y, const Stat& sy, int sly) -> double {
+        if (X.label != Y.label) {
+            const int prod = stat_accu(sx, slx) * stat_accu(sy, sly);
+            if ((unsigned)prod < (unsigned)lut_n) return ln_tab[prod];
+        }
+        return log((double)ex_pair(X, sx, slx, Y, sy, sly, pa.nfpb, pa.par));
+    };
+    for (unsigned long long b0 = (unsigned long long)first * 64; b0 < nq_total; b0 += (unsigned long long)n_waves * 64) {
+        double ln_old_a = 0.0;
+        int live_a = 0;
+        {
+            const unsigned long long ea = b0 + lane;
+            if (ea < nq_total) {
+                const QEntry qe = pa.queue[ea];
+                if (qe.rel != 0) {
+                    const int fx = qe.fx, fy = qe.fy;
+                    const Geo gx = pa.geo[fx], gy = pa.geo[fy];
+                    const Stat sx = pa.stat[fx], sy = pa.stat[fy];
+                    const End X0 = end_cur(gx, pa.lcontbp, fx), Y0 = end_cur(gy, pa.lcontbp, fy);
+                    ln_old_a = ln_of(X0, sx, qe.slots & 3, Y0, sy, (qe.slots >> 2) & 3);
+                    live_a = 1;
+                }
+            }
+        }
+        const int n_here = nq_total - b0 < 64ull ? (int)(nq_total - b0) : 64;
+        for (int pass = 0; pass * 4 < n_here; pass++) {
+            const int src = pass * 4 + c4;
+            const double ln_old = __shfl(ln_old_a, src, 64);
+            const int live = __shfl(live_a, src, 64);
+            if (!live || op >= N_OPS) continue;
+            const QEntry qe = pa.queue[b0 + src];
+            const int fx = qe.fx, fy = qe.fy, slx = qe.slots & 3, sly = (qe.slots >> 2) & 3;
+            unsigned rel = qe.rel, todo = 0;
+            while (rel) {
+                const int k = (__ffs((int)rel) - 1) / CODE_BITS;
+                rel &= rel - 1;
+                const int p = (qe.ci >> (CODE_BITS * k)) & 7, q = (qe.cj >> (CODE_BITS * k)) & 7;
+                if ((pa.tabs[k].changed[op] >> (p * 8 + q)) & 1ull) todo |= 1u << k;
+            }
+            if (!todo) continue;
+            const Geo gx = pa.geo[fx], gy = pa.geo[fy];
+            const Stat sx = pa.stat[fx], sy = pa.stat[fy];
+            const double ob = (double)__int_as_float(qe.cnt);
+            int m_xs = 0, m_ys = 0, m_fl = -1, m_lbp = 0;   // inputs of the lane's last cis evaluation
+            double m_ln = 0.0;
+            while (todo) {
+                const int k = __ffs((int)todo) - 1;
+                todo &= todo - 1;
+                const NbTables& T = pa.tabs[k];
+                const int p = (qe.ci >> (CODE_BITS * k)) & 7, q = (qe.cj >> (CODE_BITS * k)) & 7;
+                const End X = end_xf(gx, T.xf[op][p]), Y = end_xf(gy, T.xf[op][q]);
+                double ln_new;
+                if (X.label != Y.label) ln_new = ln_of(X, sx, slx, Y, sy, sly);
+                else {
+                    const int fl = (X.fwd ? 1 : 0) | (Y.fwd ? 2 : 0) | (X.circ << 2);
+                    if (fl == m_fl && X.start_bp == m_xs && Y.start_bp == m_ys && (X.circ == 0 || X.lbp == m_lbp)) ln_new = m_ln;
+                    else {
+                        ln_new = log((double)ex_pair(X, sx, slx, Y, sy, sly, pa.nfpb, pa.par));
+                        m_fl = fl; m_xs = X.start_bp; m_ys = Y.start_bp; m_lbp = X.lbp; m_ln = ln_new;
+                    }
+                }
+                const long long qv = to_q(ob * (ln_new - ln_old));
+                if (qv == Q_BAD) nf_flag(pa.nf, k, op);
+                else if (qv != 0) atomicAdd((unsigned long long*)&pa.out[k * N_OPS + op], (unsigned long long)qv);
+            }
+        }
+    }
+}
+
+// ln(v_inter * (float(p) / nfpb)) for every product p of two RF counts that can occur (see k_full_nnz)
+__global__ void k_ln_tab(double* __restrict__ tab, int n, float nfpb, Par par)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) tab[p] = log((double)(par.v_inter * ((float)p / nfpb)));
+}
+
 // the last block of a step: read the K*13 sums, reset the accumulators and counters for the next step, hand the sums
 // out -- to d_q_out (device; the caller all-reduces them) or to PINNED HOST memory followed by the step's sequence
 // number (the host spins on that word instead of paying for a device->host copy and a stream-synchronise wake-up).
@@ -1468,6 +1558,8 @@ struct ScanArgs { // by value: kernel-argument pointers are known to be GLOBAL (
     long long nnz;
     int bitmap_words;
     int strict;                   // GRAAL_MODE_STRICT: queue every contact with both ends in a neighbour's affected set
+    int wt_queue;                 // queue entries are read by k_tm's finishing block (concurrent kernel): write-through stores
+    unsigned token;               // unique per launch: "wave 1's keys of THIS launch are in LDS"
 };
 
 // word j (0 .. 4G-1) of G groups held in registers (select chain over constant indices: stays in registers)
@@ -1486,14 +1578,15 @@ template <int G> __device__ __forceinline__ int sel_words(const int4 (&a)[G], in
 // G = groups of 4 contacts per thread and iteration.  G = 4 with two 1024-thread blocks per CU (8 waves/SIMD, <= 64 VGPRs);
 // G = 8 with one block per CU (half the waves to launch, the same bytes in flight).
 template <bool SINGLE_SUB, int G>
-__global__ __launch_bounds__(1024, (G == 4 ? 8 : 4)) void k_scan(ScanArgs sa, int fA, Neigh nb, int K, int max_id,
+__global__ __launch_bounds__(1024, (G <= 4 ? 8 : 4)) void k_scan(ScanArgs sa, int fA, Neigh nb, int K, int max_id,
                                                 int dry /* timing replays: count, do not queue */)
 {
     extern __shared__ unsigned s_bm[];
     __shared__ StepKeys S;
     __shared__ Rec s_rec[MAXK + 1];
     __shared__ int s_cbase[MAXK + 1], s_clen[MAXK + 1], s_pref[MAXK + 2], s_fB[MAXK];
-    __shared__ int s_waves_done, s_keys_ready, s_long;
+    __shared__ int s_waves_done, s_long;
+    __shared__ unsigned s_keys_ready;
     __shared__ unsigned long long s_nrel;
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -1524,12 +1617,13 @@ __global__ __launch_bounds__(1024, (G == 4 ? 8 : 4)) void k_scan(ScanArgs sa, in
     int g0 = (int)(blockIdx.x * blockDim.x) + t;
     // unconditional loads with a clamped group index (group n4 is in bounds: the arrays are padded): branch-free, so the
     // compiler keeps all of them in flight together.  The first batch is requested here, ABOVE the barrier: 40 % of the list is
-    // on its way while the bitmap is built -- except by waves 0 and 1: vector-memory results return in order, so their prologue
-    // loads would queue up behind their own stream loads.
+    // on its way while the bitmap is built.  Waves 0 and 1 too: their prologue loads were issued first (just above), so they
+    // come back first (vector-memory results return in issue order) and the two waves hold their first batch like everybody else
+    // instead of starting their stream a round trip late -- which made them the tail of every block.
     auto ldg = [&](int g) { return ld_stream(row4 + (g < n4 ? g : n4)); }; // (group indices fit 32 bits: nnz < 2^32)
     int4 f[G];
     static_assert(SCAN_PRE == 0 || SCAN_PRE == 4, "");
-    if (t >= 128 && SCAN_PRE) {
+    if (SCAN_PRE) {
 #pragma unroll
         for (int i = 0; i < G; i++) f[i] = ldg(g0 + i * stride);
     }
@@ -1544,7 +1638,7 @@ __global__ __launch_bounds__(1024, (G == 4 ? 8 : 4)) void k_scan(ScanArgs sa, in
         }
     };
     if (t < 64) {
-        if (t == 0) { s_waves_done = 0; s_nrel = 0; s_keys_ready = 0; }
+        if (t == 0) { s_waves_done = 0; s_nrel = 0; }   // (both are first used behind the block's barrier)
         for (int i = t; i < sa.bitmap_words; i += 64) s_bm[i] = 0;
         WSYNC();
         const bool is_long = t <= K && row0.x == MATES_LONG;
@@ -1560,7 +1654,16 @@ __global__ __launch_bounds__(1024, (G == 4 ? 8 : 4)) void k_scan(ScanArgs sa, in
         }
         const unsigned long long lm = __ballot(is_long);
         if (t == 0) s_long = lm != 0 ? 1 : 0;
-    } else if (t < 128) {
+    }
+    auto wait_keys = [&]() {   // bounded: a wave always gets out (the step is then flagged as failed)
+        for (int spin = 0; spin < (1 << 24); spin++) {
+            if (__hip_atomic_load(&s_keys_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == sa.token) return;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        atomicOr(&sa.counters[6], 1ull);
+    };
+    __syncthreads();
+    if (t >= 64 && t < 128) {   // wave 1, BEHIND the barrier (in front of it, the whole block would wait for this work)
         const int u = t - 64;
         if (u == 0) { S.live = 0; S.intra = 0; }
         if (u <= K) { s_rec[u] = rec_gl(my_geo, my_link, my_f); s_cbase[u] = my_cbase; }
@@ -1586,14 +1689,11 @@ __global__ __launch_bounds__(1024, (G == 4 ? 8 : 4)) void k_scan(ScanArgs sa, in
             int acc = 0;
             for (int j = 0; j <= K; j++) { s_pref[j] = acc; acc += s_clen[j]; }
             s_pref[K + 1] = acc;
-            __hip_atomic_store(&s_keys_ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // (a per-launch token, not a flag that somebody would have to clear first: nothing orders wave 0 before this store)
+            __hip_atomic_store(&s_keys_ready, sa.token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
-    auto wait_keys = [&]() {
-        while (__hip_atomic_load(&s_keys_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
-    };
 #undef WSYNC
-    __syncthreads();
     if (s_long) { // some affected contig holds more than N_MATES fragments: everybody marks it from the position index (two
                   // more barriers are nothing next to that regime's work)
         wait_keys();
@@ -1709,35 +1809,56 @@ __global__ __launch_bounds__(1024, (G == 4 ? 8 : 4)) void k_scan(ScanArgs sa, in
                 // another XCD -- without an L2 write-back fence, which costs this kernel several microseconds
                 unsigned long long* qw = reinterpret_cast<unsigned long long*>(queue + slot);
                 slot += 1;
-                __hip_atomic_store(qw + 0, (unsigned long long)(unsigned)cidx | ((unsigned long long)rel << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (rel) {
-                    const unsigned cnt_w = (unsigned)sa.cnt[cidx];
-                    __hip_atomic_store(qw + 1, (unsigned long long)q_ci | ((unsigned long long)q_cj << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(qw + 2, (unsigned long long)(unsigned)q_fx | ((unsigned long long)(unsigned)q_fy << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(qw + 3, (unsigned long long)cnt_w | ((unsigned long long)(unsigned)q_slots << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    n_rel += __popc(rel);
-                }
+                // (entries read by k_tm's finishing block while this kernel may still run are written through, 8 bytes at a
+                // time; entries for the NEXT kernel on the stream (k_fin / k_strict) as two plain 16-byte stores -- four 8-byte
+                // write-through stores per entry made a scan that queues 2 M contacts run at 8 % of the HBM rate)
+                const int cnt_w = rel ? sa.cnt[cidx] : 0;
+                const unsigned long long w0 = (unsigned long long)(unsigned)cidx | ((unsigned long long)rel << 32);
+                const unsigned long long w1 = (unsigned long long)q_ci | ((unsigned long long)q_cj << 32);
+                const unsigned long long w2 = (unsigned long long)(unsigned)q_fx | ((unsigned long long)(unsigned)q_fy << 32);
+                const unsigned long long w3 = (unsigned long long)(unsigned)cnt_w | ((unsigned long long)(unsigned)q_slots << 32);
+                if (sa.wt_queue) {
+                    __hip_atomic_store(qw + 0, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (rel) {
+                        __hip_atomic_store(qw + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(qw + 2, w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(qw + 3, w3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                } else if (rel) {
+                    typedef unsigned long long v2u __attribute__((ext_vector_type(2)));
+                    v2u a; a.x = w0; a.y = w1;
+                    v2u b; b.x = w2; b.y = w3;
+                    reinterpret_cast<v2u*>(qw)[0] = a;
+                    reinterpret_cast<v2u*>(qw)[1] = b;
+                } else qw[0] = w0;
+                n_rel += __popc(rel);
             }
         }
     };
     // ---- main loop: G loads in flight, first test, (rarely) the rest.  (A two-buffer software pipeline of this loop was
     // measured in tools/scan_micro.hip: 15.4 -> 14.6 us per isolated launch with 2 x 2 groups through raw buffer loads, slower
     // with 2 x 4; in this kernel two buffers of 4 groups do not fit next to process_hits in 64 VGPRs.)
-    if (t < 128 || !SCAN_PRE) {
+    if (!SCAN_PRE) {
 #pragma unroll
         for (int i = 0; i < G; i++) f[i] = ldg(g0 + i * stride);
     }
+#ifdef GRAAL_EXP_NOHITS   // (bisecting build, tools/ab_scan2.sh: the stream and the first test only -- wrong results)
+#define PROCESS_HITS(a, b, c) do { n_rel += __popc(c); } while (0)
+#else
+#define PROCESS_HITS(a, b, c) process_hits(a, b, c)
+#endif
     {
         const unsigned hit = test_rows(f, g0);
-        if (__ballot(hit != 0) != 0) process_hits(f, g0, hit);
+        if (__ballot(hit != 0) != 0) PROCESS_HITS(f, g0, hit);
     }
     for (int g = g0 + G * stride; g <= n4; g += G * stride) {
         int4 q[G];
 #pragma unroll
         for (int i = 0; i < G; i++) q[i] = ldg(g + i * stride);
         const unsigned hit = test_rows(q, g);
-        if (__ballot(hit != 0) != 0) process_hits(q, g, hit);
+        if (__ballot(hit != 0) != 0) PROCESS_HITS(q, g, hit);
     }
+#undef PROCESS_HITS
     STAMP(10, blockIdx.x == 0 && t == 0 && !dry);
     STAMP_BLK(2, t == 0 && !dry);
     n_rel = (unsigned long long)wave_sum_ll((long long)n_rel);
@@ -1791,6 +1912,9 @@ struct FinArgs { // first-needed pointers by value (see ScanArgs)
     const Stat* stat;
     long long* acc;
     unsigned long long* sync;
+    const double* ln_tab;          // ln of the trans value by RF-count product (k_ln_tab), lut_n entries
+    int lut_n;
+    int skip;                      // diagnostics (GRAAL_FIN_SKIP): 1 = no mass units, 2 = no queued contacts
 };
 
 __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinArgs fa, int K, int rank, int world,
@@ -1873,7 +1997,7 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
         // (static deal.  Handing the units out through one global counter -- they differ by orders of magnitude, and the slowest
         // block of a C2 step ends 100 us after the typical one -- was measured: 2,048 waves queueing on one address cost more
         // than the imbalance, 175 -> 201 us per step.)
-        for (int U = rank + world * wave; U < total_units; U += world * n_waves) {
+        for (int U = rank + world * wave; U < ((fa.skip & 1) ? 0 : total_units); U += world * n_waves) {
             int k = 0;
             for (int j = 1; j < K; j++) k += (U >= s_ubase[j]) ? 1 : 0;
             const int u = U - s_ubase[k];
@@ -1957,7 +2081,7 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
         // the low-numbered blocks ----
         PriceArgs pa;
         pa.queue = queue; pa.tabs = tabs; pa.geo = geo; pa.stat = stat; pa.lcontbp = lcontbp; pa.out = s_accb; pa.nf = counters + NF_OFF; pa.nfpb = nfpb; pa.par = par;
-        price_contacts(pa, nq_total, n_waves - 1 - wave, n_waves, lane);
+        if (!(fa.skip & 2)) price_contacts_bulk(pa, fa.ln_tab, fa.lut_n, nq_total, n_waves - 1 - wave, n_waves, lane);
         STAMP(13, blockIdx.x == 0 && threadIdx.x == 0);
         STAMP_FBLK(2, threadIdx.x == 0);
         __syncthreads();
@@ -2495,6 +2619,8 @@ struct Ctx {
     unsigned* d_flags = nullptr;          // k_scan's per-block completion flags
     unsigned long long scan_done_total = 0; // blocks of all non-dry scans launched so far (completion counter mode)
     int mode = 0;                 // GRAAL_MODE_* flags (graal_set_mode)
+    unsigned scan_token = 0x5ca90000u; // k_scan launches so far (ScanArgs.token)
+    double* d_ln_tab = nullptr;   // [LN_TRANS_LUT] ln of the trans value by RF-count product (k_ln_tab; rebuilt by sync_args)
     int* d_ubins = nullptr;       // bins whose sub-fragments carry different RF counts (k_quirk_mass)
     int n_ubins = 0;
     bool finisher_ok = true;      // k_tm's last block may finish short-contig steps (switched off when the kernels turn
@@ -2600,6 +2726,12 @@ int sync_args(Ctx* h)
         a[b].nfpb = h->nfpb; a[b].par = h->par;
     }
     CK(hipMemcpy(h->d_args, a, sizeof a, hipMemcpyHostToDevice));
+    if (h->have_par && h->have_sub && h->ln_lut_n > 0) {
+        if (!h->d_ln_tab) CK(hipMalloc(&h->d_ln_tab, sizeof(double) * LN_TRANS_LUT));
+        k_ln_tab<<<blocks_for(h->ln_lut_n, 256), 256, 0, h->stream>>>(h->d_ln_tab, h->ln_lut_n, h->nfpb, h->par);
+        CK(hipGetLastError());
+        CK(hipStreamSynchronize(h->stream));
+    }
     return GRAAL_OK;
 }
 
@@ -2625,7 +2757,8 @@ int scan_threads_cfg(const Ctx* h)
 
 int scan_groups_cfg()
 {
-    static const int v = (getenv("GRAAL_SCAN_G") && atoi(getenv("GRAAL_SCAN_G")) == 8) ? 8 : 4;
+    static const int e = getenv("GRAAL_SCAN_G") ? atoi(getenv("GRAAL_SCAN_G")) : 4;
+    static const int v = (e == 8 || e == 2) ? e : 4;
     return v;
 }
 
@@ -2651,7 +2784,7 @@ int scan_grid(const Ctx* h)
 }
 
 // the streaming pass (see k_scan); dry = timing replay that counts relevant contacts but queues nothing
-int launch_scan(Ctx* h, int fA, const Neigh& nb, int K, int max_id, int dry, hipStream_t st)
+int launch_scan(Ctx* h, int fA, const Neigh& nb, int K, int max_id, int dry, hipStream_t st, bool finisher_reads = true)
 {
     const int nbk = scan_grid(h), scan_threads = scan_threads_cfg(h);
     const size_t shm = (size_t)((h->n_sub_total + 31) / 32 + 2) * 4;
@@ -2664,12 +2797,16 @@ int launch_scan(Ctx* h, int fA, const Neigh& nb, int K, int max_id, int dry, hip
     sa.queue = h->queue; sa.counters = (unsigned long long*)(h->d_scalars + 10);
     sa.flags = h->d_flags; sa.seq32 = (unsigned)h->seq;
     sa.strict = (h->mode & GRAAL_MODE_STRICT) ? 1 : 0;
-    sa.done = (scan_done_counter() && !dry) ? h->d_sync + 8 : nullptr;
+    sa.wt_queue = finisher_reads ? 1 : 0;
+    sa.token = ++h->scan_token;
     if (sa.done) h->scan_done_total += (unsigned long long)nbk;
     if (nbk > MAX_SCAN_BLOCKS) return fail(h, GRAAL_E_ARG, "GRAAL_SCAN_BLOCKS too large");
     if (scan_groups_cfg() == 8) {
         if (h->single_sub) k_scan<true, 8><<<nbk, scan_threads, shm, st>>>(sa, fA, nb, K, max_id, dry);
         else k_scan<false, 8><<<nbk, scan_threads, shm, st>>>(sa, fA, nb, K, max_id, dry);
+    } else if (scan_groups_cfg() == 2) {
+        if (h->single_sub) k_scan<true, 2><<<nbk, scan_threads, shm, st>>>(sa, fA, nb, K, max_id, dry);
+        else k_scan<false, 2><<<nbk, scan_threads, shm, st>>>(sa, fA, nb, K, max_id, dry);
     } else {
         if (h->single_sub) k_scan<true, 4><<<nbk, scan_threads, shm, st>>>(sa, fA, nb, K, max_id, dry);
         else k_scan<false, 4><<<nbk, scan_threads, shm, st>>>(sa, fA, nb, K, max_id, dry);
@@ -2687,9 +2824,11 @@ int launch_fin(Ctx* h, int K, int rank, int world, long long* d_q_out, bool publ
     // where 2 waves reach ~50 % -- 2.8 -> 2.2 ms per step on C5's 7 contigs; with contigs of a few hundred fragments the larger
     // grid only adds per-block set-up)
     const int fin_blocks = fin_blocks_env > 0 ? fin_blocks_env : (h->max_lcont > 0 && h->max_lcont <= 16 ? 32 : (h->max_lcont > 1024 ? 2048 : 512));
+    static const int fin_skip = getenv("GRAAL_FIN_SKIP") ? atoi(getenv("GRAAL_FIN_SKIP")) : 0;   // (diagnostics: wrong sums)
     FinArgs fa;
     fa.tm_done = h->tm_done; fa.step_hdr = h->step_hdr; fa.counters = (unsigned long long*)(h->d_scalars + 10); fa.queue = h->queue;
     fa.tabs = h->tabs; fa.geo = h->geo; fa.stat = h->stat_frag; fa.acc = h->d_acc; fa.sync = h->d_sync;
+    fa.ln_tab = h->d_ln_tab; fa.lut_n = h->d_ln_tab ? h->ln_lut_n : 0; fa.skip = fin_skip;
     k_fin<<<fin_blocks, 256, 0, st>>>(h->d_args + h->cur, fa, K, rank, world, d_q_out, publish ? h->res_dev : nullptr, h->seq);
     CK(hipGetLastError());
     return GRAAL_OK;
@@ -2800,7 +2939,7 @@ void graal_destroy(graal_ctx* h)
         (void)hipSetDevice(h->device);
         (void)hipStreamSynchronize(h->stream);
         if (h->aux) (void)hipStreamSynchronize(h->aux);
-        void* ptrs[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->stat, h->sub_rec, h->d_ubins, h->sub2bin, h->row, h->col, h->cnt, h->queue, h->d_sub_ids, h->d_acc, h->tm_done, h->d_sync, h->d_flags, h->stat_frag, h->d_dup_bins, h->d_dup_index,
+        void* ptrs[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->stat, h->sub_rec, h->d_ubins, h->d_ln_tab, h->sub2bin, h->row, h->col, h->cnt, h->queue, h->d_sub_ids, h->d_acc, h->tm_done, h->d_sync, h->d_flags, h->stat_frag, h->d_dup_bins, h->d_dup_index,
                         h->d_dispatcher, h->d_collector, h->d_sub_ids_all, h->d_rep_obs,
                         h->keys, h->keys_sorted, h->o2n, h->len_of2[0], h->len_of2[1], h->contig_off2[0], h->contig_off2[1], h->perm, h->cbase, h->link, h->mates, h->cub_tmp, h->tabs, h->step_hdr, h->d_args, h->d_chg,
                         h->d_scalars, h->d_qout, h->d_dref, h->d_dist};
@@ -3291,7 +3430,7 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     h->eval_calls += 1;
     const size_t slot = (size_t)(h->ring_calls % (long long)(h->ring.size() / 2));
     if (ev) CK(hipEventRecord(h->ring[2 * slot], st));
-    { int rc_ = launch_scan(h, fA, nb, K, max_id, 0, st); if (rc_) return rc_; }
+    { int rc_ = launch_scan(h, fA, nb, K, max_id, 0, st, ta.host_res != nullptr); if (rc_) return rc_; }
     if (ev) { CK(hipEventRecord(h->ring[2 * slot + 1], st)); h->ring_calls += 1; }
     // (3) finishing kernel -- unless k_tm's last block does that job (it asks for k_fin through the result word if not)
     if (h->has_rep) { // the repeated bins' pixels, densely, for all 13 K candidates (waits for k_tm's tables itself)
@@ -3304,6 +3443,7 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
         FinArgs fa;
         fa.tm_done = h->tm_done; fa.step_hdr = h->step_hdr; fa.counters = (unsigned long long*)(h->d_scalars + 10); fa.queue = h->queue;
         fa.tabs = h->tabs; fa.geo = h->geo; fa.stat = h->stat_frag; fa.acc = h->d_acc; fa.sync = h->d_sync;
+        fa.ln_tab = nullptr; fa.lut_n = 0; fa.skip = 0;
         StrictArgs sx;
         sx.perm = h->perm; sx.cbase = h->cbase; sx.lcontbp = h->soa[h->cur].p[F_LCONTBP]; sx.link = h->link; sx.nfpb = h->nfpb; sx.par = h->par;
         sx.quirk = (h->mode & GRAAL_MODE_REF_TRANS_ACCU) ? 1 : 0;
@@ -3594,6 +3734,28 @@ int graal_scan_times(graal_ctx* h, int32_t n, float* out_ms)
 
 int graal_time_scan(graal_ctx* h, int32_t K, int32_t reps, float* avg_ms)
 {
+    if (h && avg_ms && reps < 0 && K >= 1 && K <= MAXK) {   // ISOLATED replays: an event pair around each launch, the device idle in between
+        if (!h->scan_ready) return fail(h, GRAAL_E_STATE, "run graal_eval_candidates first (the replays reuse its tables)");
+        CK(hipSetDevice(h->device));
+        Neigh nb;
+        for (int k = 0; k < MAXK; k++) nb.fB[k] = h->last_fB[k];
+        std::vector<float> t;
+        for (int i = 0; i < -reps + 3; i++) {
+            CK(hipStreamSynchronize(h->stream));
+            const auto t0 = std::chrono::steady_clock::now();
+            while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(50)) { }
+            CK(hipEventRecord(h->ev[0], h->stream));
+            { int rc = launch_scan(h, h->last_fA, nb, K, h->last_max_id, 1, h->stream); if (rc) return rc; }
+            CK(hipEventRecord(h->ev[4], h->stream));
+            CK(hipEventSynchronize(h->ev[4]));
+            float ms = 0.0f;
+            CK(hipEventElapsedTime(&ms, h->ev[0], h->ev[4]));
+            if (i >= 3) t.push_back(ms);
+        }
+        std::sort(t.begin(), t.end());
+        *avg_ms = t[t.size() / 2];   // median
+        return GRAAL_OK;
+    }
     if (!h || !avg_ms || reps < 1 || K < 1 || K > MAXK) return GRAAL_E_ARG;
     if (!h->scan_ready) return fail(h, GRAAL_E_STATE, "run graal_eval_candidates first (the replays reuse its tables)");
     CK(hipSetDevice(h->device));

@@ -181,7 +181,9 @@ int graal_set_timing(graal_ctx* h, int32_t enabled);
  * from rocprofv3).  graal_scan_times returns the last n calls (a ring of 1024 event pairs). */
 int graal_last_timing(graal_ctx* h, float out[4]);
 int graal_scan_times(graal_ctx* h, int32_t n, float* out_ms);
-/* average duration (ms) of the streaming scan kernel over `reps` back-to-back replays of the last call's scan between
+/* reps < 0: MEDIAN duration of -reps ISOLATED replays (an event pair around each launch, the device idle in between: what a launch
+ * costs on its own, without the other kernels of a step).  reps > 0:
+ * average duration (ms) of the streaming scan kernel over `reps` back-to-back replays of the last call's scan between
  * two HIP events on the engine's stream (the replays count relevant contacts but queue nothing): the per-launch
  * event overhead of graal_last_timing is amortised away. */
 int graal_time_scan(graal_ctx* h, int32_t K, int32_t reps, float* avg_ms);

@@ -337,13 +337,13 @@ def test_short_contigs_finished_by_the_table_kernel(n_sub, seed, p_circ):
     e1.close(); e2.close()
 
 
-@pytest.mark.parametrize("n_sub,seed,p_circ", [(1, 31, 0.0), (1, 32, 0.5), (3, 33, 0.3)])
-def test_incremental_relabel_matches_the_sort(n_sub, seed, p_circ):
+@pytest.mark.parametrize("n_sub,seed,p_circ,n_bins", [(1, 31, 0.0, 60), (1, 32, 0.5, 60), (3, 33, 0.3, 60), (1, 34, 0.1, 1300)])
+def test_incremental_relabel_matches_the_sort(n_sub, seed, p_circ, n_bins):
     """graal_begin_step after one commit derives the new ranking by counting (k_incr); it must give
     the labels of the stable sort (cuda_lib_gl.py:1697-1722) and the same position index as a fresh upload."""
-    P = make(n_sub, seed, n_bins=60, nnz=800)
+    P = make(n_sub, seed, n_bins=n_bins, nnz=800)
     rng = np.random.RandomState(seed)
-    s = random_state_for(P, rng, p_circ=p_circ)
+    s = random_state_for(P, rng, p_circ=p_circ, n_contigs=None if n_bins < 1000 else 1150)   # (> 1,024 contigs: mostly singletons)
     n = P["n_frags"]
     e = engine_for(P, s)
     ref = O.copy_state(s)
