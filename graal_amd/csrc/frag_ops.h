@@ -279,7 +279,9 @@ struct Move {
     Rec A1, B1;      // after pop_out (ops 0, 2-8) or after the first split (ops 9-12)
     Rec A2, B2;      // after the second split (ops 9-12)
     int max_id1, max_id2;
-    bool identity;   // fA == fB: the reference's behaviour is undefined; we score and apply a no-op
+    bool identity;   // fA == fB and an op that involves fB (2-7, 9-12): the reference's behaviour is undefined; we score and
+                     // apply a no-op.  Ops 0, 1 and 8 (eject, flip, swap activity) never look at fB and are applied as they
+                     // are -- explode_genome commits (i, 0, op 0) for every fragment, fragment 0 included (cuda_lib_gl.py:1539-1544)
 };
 
 GR_HD Move make_move(int op, int fA, int fB, int max_id, const Rec& A0, const Rec& B0)
@@ -287,7 +289,7 @@ GR_HD Move make_move(int op, int fA, int fB, int max_id, const Rec& A0, const Re
     Move m;
     m.op = op; m.fA = fA; m.fB = fB; m.max_id = max_id; m.A0 = A0; m.B0 = B0;
     m.A1 = A0; m.B1 = B0; m.A2 = A0; m.B2 = B0; m.max_id1 = max_id; m.max_id2 = max_id;
-    m.identity = (fA == fB);
+    m.identity = (fA == fB) && !(op == 0 || op == 1 || op == 8);
     if (m.identity) return m;
     if (op <= 8) {
         m.A1 = m_pop_out(A0, fA, A0, fA, max_id);

@@ -692,9 +692,10 @@ __global__ __launch_bounds__(256) void k_subrec(int n, const Geo* __restrict__ g
 // two RF counts only, so every block first tabulates its ln (same expressions, same device functions as the general path:
 // bit-identical) for the products that can occur, and such contacts skip the float64 logarithm.
 constexpr int LN_TRANS_LUT = 1024;
-constexpr int FULL_G = 2; // groups of 4 contacts per lane and iteration
+// FULL_G = groups of 4 contacts per lane and iteration (template parameter; GRAAL_FULL_G picks 1, 2 or 4 for experiments)
 __device__ __forceinline__ int w4(const int4& q, int j) { return j == 0 ? q.x : (j == 1 ? q.y : (j == 2 ? q.z : q.w)); }
 
+template <int FULL_G>
 __global__ __launch_bounds__(256) void k_full_nnz(const int4* __restrict__ row4, const int4* __restrict__ col4,
                                                    const int4* __restrict__ cnt4, long long nnz, const SubRec* __restrict__ rec,
                                                    const int* __restrict__ lcontbp, float nfpb, Par par,
@@ -770,6 +771,30 @@ __global__ __launch_bounds__(256) void k_full_nnz(const int4* __restrict__ row4,
 // cis correction of the expected mass for the current layout: one thread per fragment x (in contig order),
 // pairs (x, y later in the same contig) while the gap is below d_max, plus x's own sub-fragment pairs.
 __device__ __forceinline__ long long pair_mass_q(const End& X, const Stat& sx, const End& Y, const Stat& sy, float nfpb, const Par& par);
+// pair_mass_q from centre coordinates computed once per fragment (centre_kb's float32 values, cached: every pair of a walk would
+// otherwise redo two int->float conversions, four divisions and the running sums of BOTH fragments).  Both fragments lie in
+// one contig of the layout in question (mass tasks exist for cis relations only).
+struct Ctr { float c0, c1, c2; };
+__device__ __forceinline__ Ctr centres_of(int start_bp, bool fwd, const Stat& st)
+{
+    Ctr c; c.c0 = centre_kb(start_bp, fwd, st, 0); c.c1 = st.n > 1 ? centre_kb(start_bp, fwd, st, 1) : 0.0f;
+    c.c2 = st.n > 2 ? centre_kb(start_bp, fwd, st, 2) : 0.0f;
+    return c;
+}
+__device__ __forceinline__ long long pair_mass_q_c(const Ctr& cx, const Stat& sx, const Ctr& cy, const Stat& sy, int circ, int lbp,
+                                                   float nfpb, const Par& par)
+{
+    double acc = 0.0;
+    for (int a = 0; a < sx.n; a++)
+        for (int b = 0; b < sy.n; b++) {
+            const float norm = (float)(stat_accu(sx, a) * stat_accu(sy, b)) / nfpb;
+            const float sd = fabsf(sel3(cy.c0, cy.c1, cy.c2, b) - sel3(cx.c0, cx.c1, cx.c2, a));
+            const float ex = (circ == 1 ? rippe_circ(sd, (float)lbp / 1000.0f, par) : rippe(sd, par)) * norm;
+            acc += (double)ex - (double)(par.v_inter * norm);
+        }
+    return to_q(acc);
+}
+
 
 // SIXTEEN LANES per fragment x (position-index slot i): they take the fragments y behind it in the contig, 16 at a time,
 // until all of them are beyond the window.  (One THREAD per fragment left a 1,000-bin genome with 1,000 threads walking
@@ -790,11 +815,13 @@ __global__ __launch_bounds__(256) void k_full_mass(int n, const int* __restrict_
     Geo gx = {0, 0, 0, 0};
     Stat sx = {0.0f, 0.0f, 0.0f, 0, 0, 0, 0, 0};
     End X = {0, 0, true, 0, 0};
+    Ctr cx = {0.0f, 0.0f, 0.0f};
     if (i < n) {
         const int fx = perm[i];
         gx = geo[fx];
         sx = stat[fx];
         X = end_cur(gx, lcontbp, fx);
+        cx = centres_of(X.start_bp, X.fwd, sx);
         if (sub == 0) {
             double acc = 0.0;
             for (int a = 0; a < sx.n; a++)
@@ -814,8 +841,8 @@ __global__ __launch_bounds__(256) void k_full_mass(int n, const int* __restrict_
             inside = gy.start_bp - (gx.start_bp + gx.len_bp) <= reach_bp;
             if (inside) {
                 const Stat sy = stat[fy];
-                const End Y = end_cur(gy, lcontbp, fy);
-                const long long q = pair_mass_q(X, sx, Y, sy, nfpb, par);
+                const Ctr cy = centres_of(gy.start_bp, (gy.flags & 1) != 0, sy);
+                const long long q = pair_mass_q_c(cx, sx, cy, sy, X.circ, X.lbp, nfpb, par);   // (same contig: same circular model)
                 if (q == Q_BAD) bad = true; else accq += q;
             }
         }
@@ -863,7 +890,7 @@ struct NbTables {        // everything the finishing kernel needs about one neig
 #define WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
 // one staged fragment y of the mass walk (k_fin): transformed geometry + statistics, 64 bytes
-struct YTile { int start_bp, len_bp, flags, label, lbp, pad0, pad1, pad2; Stat st; };
+struct YTile { int start_bp, len_bp, flags, label, lbp; float c0, c1, c2; Stat st; };   // (c*: centres of its sub-fragments, kb)
 constexpr int FLAG_STRIDE = 32; // words between two blocks' completion flags: one 128-byte line each (partial writes to one
                                 // line from many XCDs serialise at the memory side)
 
@@ -1638,7 +1665,10 @@ __global__ __launch_bounds__(1024, (G <= 4 ? 8 : 4)) void k_scan(ScanArgs sa, in
         }
     };
     if (t < 64) {
-        if (t == 0) { s_waves_done = 0; s_nrel = 0; }   // (both are first used behind the block's barrier)
+        // (all three are first touched by anybody else BEHIND the block's barrier -- wave 1 sets s_keys_ready there -- so this
+        // clear is ordered before every use.  LDS keeps what earlier launches left: another engine of this process, or another
+        // process on the same GPU, may have left the very same token value behind)
+        if (t == 0) { s_waves_done = 0; s_nrel = 0; s_keys_ready = 0; }
         for (int i = t; i < sa.bitmap_words; i += 64) s_bm[i] = 0;
         WSYNC();
         const bool is_long = t <= K && row0.x == MATES_LONG;
@@ -1689,7 +1719,6 @@ __global__ __launch_bounds__(1024, (G <= 4 ? 8 : 4)) void k_scan(ScanArgs sa, in
             int acc = 0;
             for (int j = 0; j <= K; j++) { s_pref[j] = acc; acc += s_clen[j]; }
             s_pref[K + 1] = acc;
-            // (a per-launch token, not a flag that somebody would have to clear first: nothing orders wave 0 before this store)
             __hip_atomic_store(&s_keys_ready, sa.token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
@@ -2021,6 +2050,7 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
             Stat sx = {0.0f, 0.0f, 0.0f, 0, 0, 0, 0, 0};
             if (has_x) { const int fx = perm[base_p + ix]; gx = geo[fx]; sx = stat[fx]; }
             const End X = end_xf(gx, tk.xp);
+            const Ctr cx = centres_of(X.start_bp, X.fwd, sx);
             bool x_below = true, asc = true;
             if (!same) {
                 // q's fragment nearest to x in this layout: pieces map to disjoint intervals, so the side is fixed by
@@ -2046,6 +2076,8 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
                     YTile y;
                     y.start_bp = Y.start_bp; y.len_bp = gy.len_bp; y.flags = (Y.fwd ? 1 : 0) | (Y.circ << 1); y.label = Y.label;
                     y.lbp = Y.lbp; y.st = stat[fy];
+                    const Ctr cy = centres_of(Y.start_bp, Y.fwd, y.st);
+                    y.c0 = cy.c0; y.c1 = cy.c1; y.c2 = cy.c2;
                     tile[lane] = y;
                 }
                 WAVE_LDS_SYNC();
@@ -2059,7 +2091,8 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
                     const int gap = same ? gap_bp(X, gx.len_bp, Y, y.len_bp)
                                          : (x_below ? Y.start_bp - (X.start_bp + gx.len_bp) : X.start_bp - (Y.start_bp + y.len_bp));
                     if (gap > reach_bp) { done = true; continue; }
-                    const long long q1 = pair_mass_q(X, sx, Y, y.st, nfpb, par);
+                    Ctr cy; cy.c0 = y.c0; cy.c1 = y.c1; cy.c2 = y.c2;
+                    const long long q1 = pair_mass_q_c(cx, sx, cy, y.st, X.circ, X.lbp, nfpb, par);
                     if (q1 == Q_BAD) bad = true; else accq += q1;
                 }
                 if (__ballot(!done) == 0) break;
@@ -2799,6 +2832,7 @@ int launch_scan(Ctx* h, int fA, const Neigh& nb, int K, int max_id, int dry, hip
     sa.strict = (h->mode & GRAAL_MODE_STRICT) ? 1 : 0;
     sa.wt_queue = finisher_reads ? 1 : 0;
     sa.token = ++h->scan_token;
+    sa.done = (scan_done_counter() && !dry) ? h->d_sync + 8 : nullptr;
     if (sa.done) h->scan_done_total += (unsigned long long)nbk;
     if (nbk > MAX_SCAN_BLOCKS) return fail(h, GRAAL_E_ARG, "GRAAL_SCAN_BLOCKS too large");
     if (scan_groups_cfg() == 8) {
@@ -3352,11 +3386,17 @@ int graal_eval_full_q(graal_ctx* h, int64_t q_out[2])
     if (h->nnz) {
         k_subrec<<<blocks_for(h->n, 256), 256, 0, h->stream>>>(h->n, h->geo, h->stat_frag, h->d_sub_ids, h->sub_rec);
         // 8 blocks of 256 threads per CU; every lane takes FULL_G groups of 4 contacts per iteration
+        static const int full_g = getenv("GRAAL_FULL_G") ? atoi(getenv("GRAAL_FULL_G")) : 2;
+        static const int full_bpc = getenv("GRAAL_FULL_BPC") ? atoi(getenv("GRAAL_FULL_BPC")) : 8;   // blocks per CU
+        const int FG = full_g == 1 ? 1 : (full_g == 4 ? 4 : 2);
         const long long groups = (h->nnz >> 2) + 1;
-        const int nb = (int)std::max<long long>(1, std::min<long long>((groups + 256 * FULL_G - 1) / (256 * FULL_G), 256 * 8));
-        k_full_nnz<<<nb, 256, 0, h->stream>>>(reinterpret_cast<const int4*>(h->row), reinterpret_cast<const int4*>(h->col),
-                                               reinterpret_cast<const int4*>(h->cnt), h->nnz, h->sub_rec, s.p[F_LCONTBP], h->nfpb, h->par,
-                                               h->ln_lut_n, quirk ? 1 : 0, h->d_scalars + 8, h->d_scalars + FULL_BAD);
+        const int nb = (int)std::max<long long>(1, std::min<long long>((groups + 256 * FG - 1) / (256 * FG), 256 * full_bpc));
+#define FULL_NNZ_ARGS reinterpret_cast<const int4*>(h->row), reinterpret_cast<const int4*>(h->col), reinterpret_cast<const int4*>(h->cnt), \
+                      h->nnz, h->sub_rec, s.p[F_LCONTBP], h->nfpb, h->par, h->ln_lut_n, quirk ? 1 : 0, h->d_scalars + 8, h->d_scalars + FULL_BAD
+        if (FG == 1) k_full_nnz<1><<<nb, 256, 0, h->stream>>>(FULL_NNZ_ARGS);
+        else if (FG == 4) k_full_nnz<4><<<nb, 256, 0, h->stream>>>(FULL_NNZ_ARGS);
+        else k_full_nnz<2><<<nb, 256, 0, h->stream>>>(FULL_NNZ_ARGS);
+#undef FULL_NNZ_ARGS
     }
     if (quirk && h->n_ubins) // T_all prices every pair of different bins with the plain trans value: add the indexing's difference
         k_quirk_mass<<<blocks_for((long long)h->n_ubins * h->n_bins, 256), 256, 0, h->stream>>>(h->n_ubins, h->d_ubins, h->n_bins, h->geo, h->stat_frag,

@@ -460,3 +460,21 @@ def test_window_of_hundreds_of_fragments_long_pieces(n_sub, n_bins, K):
         err = np.abs(got - want).max()
         assert err <= 1e-7 * abs(base), (trial, fA, fBs, err / abs(base), got[0], want[0])
     e.close()
+
+
+@pytest.mark.parametrize("op", [0, 1, 8])
+def test_ops_that_ignore_the_neighbour_are_applied_with_identical_fragments(op):
+    """explode_genome commits (i, 0, op 0) for every fragment -- also (0, 0, 0) (cuda_lib_gl.py:1539-1544): eject, flip and swap
+    activity never look at fB, so fA == fB is no reason to skip them (ops that do involve fB stay a no-op there)."""
+    P = make(1, 59, n_bins=30, nnz=200, grid_bp=2000)
+    s = random_state_for(P, np.random.RandomState(59), n_contigs=3)
+    max_id = relabel_ref(s)
+    f = int(np.nonzero(s["l_cont"] > 2)[0][0])
+    e = engine_for(P, s)
+    e.relabel_contigs()
+    assert e.apply_move(f, f, op, max_id) == 0
+    got = e.download_frags()
+    want, _ = util.oracle_candidate(s, f, f, op, max_id)
+    for k in O.FIELDS:
+        assert np.array_equal(got[k], want[k]), k
+    e.close()
