@@ -14,7 +14,9 @@ What it mirrors in the reference (``pyramid_sparse.py``), function by function:
 The same text files are written in the same folder layout (``pyramids/pyramid_<n>_thresh_auto/level_<k>/<k>_*.txt``), so a
 pyramid built here can be read by the reference and vice versa -- except for the contact matrices, which the reference
 keeps in ``pyramid.hdf5`` (h5py is not available here): they go to ``pyramid.npz`` with the same logical layout, one
-``(3, nnz)`` int32 array ``<level>/data`` (rows: id_a, id_b, count) plus ``<level>/nfrags``.  Nothing is ever densified
+``(3, nnz)`` int32 array ``<level>/data`` (rows: id_a, id_b, count) plus ``<level>/nfrags``.  READING goes both ways: a folder
+that holds the reference's ``pyramid.hdf5`` instead is loaded through h5py when it can be imported and through
+``graal_amd/hdf5_min.py`` (a pure-Python reader of that file's HDF5 subset) when not; ``write_hdf5`` exports with h5py.  Nothing is ever densified
 (``simulation_loader.py:81-82`` is what is NOT reproduced): the COO arrays go straight to the engine.
 
 Reference quirks kept on purpose (switchable), because they change the numbers a reference run would produce:
@@ -244,13 +246,37 @@ def build_and_filter(base_folder, size_pyramid, factor, drop_first_contact=True)
     return Pyramid(root, size_pyramid)
 
 
+def write_hdf5(pyramid_folder, n_levels):
+    """Export ``pyramid.npz`` as the reference's ``pyramid.hdf5`` (``pyramid_sparse.py:83-126, 313-322``); needs h5py."""
+    import h5py
+    data = dict(np.load(os.path.join(pyramid_folder, "pyramid.npz")))
+    with h5py.File(os.path.join(pyramid_folder, "pyramid.hdf5"), "w") as f:
+        for level in range(n_levels):
+            d = np.asarray(data["%d/data" % level], dtype=np.int32)
+            g = f.create_group(str(level))
+            ds = g.create_dataset("data", d.shape, "i")
+            ds[...] = d
+            nf = g.create_dataset("nfrags", (1, 1), "i")
+            nf[:] = int(data["%d/nfrags" % level])
+            f.attrs[str(level)] = "done"
+
+
 # ----------------------------------------------------------------------------------------- reading a pyramid
 class Pyramid:
     """``pyramid`` (``pyramid_sparse.py:896-1034``): per level the fragment table and the sub <-> super bin indices."""
 
     def __init__(self, pyramid_folder, n_levels):
         self.pyramid_folder, self.n_levels = pyramid_folder, n_levels
-        self.data = dict(np.load(os.path.join(pyramid_folder, "pyramid.npz")))
+        npz, h5 = os.path.join(pyramid_folder, "pyramid.npz"), os.path.join(pyramid_folder, "pyramid.hdf5")
+        if os.path.exists(npz):
+            self.data = dict(np.load(npz))
+        elif os.path.exists(h5):   # a pyramid built by the reference (pyramid_sparse.py:904): h5py if present, else graal_amd/hdf5_min.py
+            from . import hdf5_min
+            self.data = {}
+            for lev, (d, nf) in hdf5_min.read_pyramid_levels(h5).items():
+                self.data["%d/data" % lev], self.data["%d/nfrags" % lev] = d, np.int32(nf)
+        else:
+            raise FileNotFoundError("neither pyramid.npz nor pyramid.hdf5 in %s" % pyramid_folder)
         self.resol_F_s_kb = 3
         self.dist_max_kb = 30 * 2 * self.resol_F_s_kb
         self.spec_level = {}

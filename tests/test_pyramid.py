@@ -211,3 +211,64 @@ def test_repeated_fragments_are_selected_by_coverage(tmp_path):
     d = inp["frag_dispatcher"][hot[0]]
     assert sorted(inp["collector_id_repeats"][d[0]:d[1]].tolist()) == [int(hot[0])] + new.tolist()
     assert pyr.simulation_inputs(P, 1, allow_repeats=False)["id_frag_duplicated"] == []
+
+
+# ---- the reference's pyramid.hdf5 (pyramid_sparse.py:83-126, 313-322, 904) without h5py -----------------------------------
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CONDA_H5PY = "/opt/conda/bin/python3.9"     # this image carries a second interpreter that has h5py (the main one does not)
+
+
+def test_pure_python_reader_reads_a_file_written_by_h5py():
+    """tests/golden/pyramid_fixture.hdf5 was written by real h5py 3.3 / libhdf5 1.10.6 with the reference's own calls
+    (generator: tests/golden/make_hdf5_fixture.py); graal_amd/hdf5_min.py must return the numbers stored beside it."""
+    import json
+    from graal_amd import hdf5_min as H
+    f = H.File(os.path.join(GOLDEN, "pyramid_fixture.hdf5"))
+    e = json.load(open(os.path.join(GOLDEN, "pyramid_fixture.json")))
+    assert [k for k in f.keys() if k.isdigit()] == ["0", "1", "2"]
+    assert all(f.attrs[str(k)] == "done" for k in range(3)) and f.attrs["thresh"] == 0.125
+    for lev, d in e["levels"].items():
+        got = f[lev]["data"].read()
+        assert got.dtype == np.int32 and np.array_equal(got, np.array(d["data"]))
+        assert int(f[lev + "/nfrags"].read()[0, 0]) == d["nfrags"]
+    many = f["many"]                              # 40 links: more than one symbol-table node under the group's B-tree
+    assert len(many.keys()) == 40
+    for i in range(40):
+        assert np.array_equal(many["d%02d" % i].read(), np.arange(i + 1) * (i + 1))
+    assert np.array_equal(f["chunked_gzip_shuffle"].read(), np.array(e["chunked_gzip_shuffle"]))   # chunk B-tree, deflate, shuffle
+    assert np.array_equal(f["big_endian"].read(), np.array(e["big_endian"]))
+    assert np.allclose(f["float64"].read(), e["float64"]) and np.array_equal(f["never_written"].read(), np.zeros((4, 2)))
+    lev = H.read_pyramid_levels(os.path.join(GOLDEN, "pyramid_fixture.hdf5"))
+    assert sorted(lev) == [0, 1, 2] and lev[1][1] == e["levels"]["1"]["nfrags"]
+    with pytest.raises(H.Hdf5Error):
+        H.File(os.path.join(GOLDEN, "appendix_e.json"))      # not an HDF5 file: a loud error, not garbage
+
+
+def test_pyramid_folder_with_the_references_hdf5_file(tmp_path):
+    """A pyramid folder that holds pyramid.hdf5 (what the reference writes) instead of pyramid.npz loads to the same levels."""
+    import shutil
+    import subprocess
+    if not os.path.exists(CONDA_H5PY) or subprocess.run([CONDA_H5PY, "-c", "import h5py"], capture_output=True).returncode != 0:
+        pytest.skip("no interpreter with h5py on this box to write the file with")
+    base = str(tmp_path / "ds")
+    make_dataset(base, np.random.RandomState(5))
+    P = pyr.build_and_filter(base, 3, 3)
+    root = P.pyramid_folder
+    script = ("import sys, numpy as np, h5py\\n"
+              "root = sys.argv[1]; d = dict(np.load(root + '/pyramid.npz'))\\n"
+              "f = h5py.File(root + '/pyramid.hdf5', 'w')\\n"
+              "for level in range(3):\\n"
+              "    g = f.create_group(str(level)); a = d['%d/data' % level]\\n"
+              "    ds = g.create_dataset('data', a.shape, 'i'); ds[0, :] = a[0]; ds[1, :] = a[1]; ds[2, :] = a[2]\\n"
+              "    nf = g.create_dataset('nfrags', (1, 1), 'i'); nf[:] = int(d['%d/nfrags' % level]); f.attrs[str(level)] = 'done'\\n"
+              "f.close()\\n")
+    subprocess.check_call([CONDA_H5PY, "-c", script.replace("\\n", "\n"), root], env={"PATH": "/usr/bin:/bin"})
+    want = [P.level_coo(k) for k in range(3)]
+    os.remove(os.path.join(root, "pyramid.npz"))
+    P2 = pyr.Pyramid(root, 3)
+    for k in range(3):
+        for a, b in zip(P2.level_coo(k), want[k]):
+            assert np.array_equal(a, b)
+        assert int(P2.data["%d/nfrags" % k]) == int(P.data["%d/nfrags" % k])
+    inp = pyr.simulation_inputs(P2, 1)
+    assert inp["n_frags"] == int(P.data["1/nfrags"])
