@@ -272,3 +272,33 @@ def test_pyramid_folder_with_the_references_hdf5_file(tmp_path):
         assert int(P2.data["%d/nfrags" % k]) == int(P.data["%d/nfrags" % k])
     inp = pyr.simulation_inputs(P2, 1)
     assert inp["n_frags"] == int(P.data["1/nfrags"])
+
+
+def test_pyramid_matches_the_reference_run(tmp_path):
+    """tests/golden/pyramid_ref.json holds what the REFERENCE's pyramid_sparse.py produced for the toy dataset below (its functions
+    run by tests/golden/make_pyramid_fixture.py under an interpreter with h5py: filtered level 0, two sub-sampled levels, the HDF5
+    contact lists, every text file, and the level loader's S_o_A_frags / mean_value_trans).  graal_amd/pyramid.py must reproduce
+    all of it from the same three files: contact lists and tables byte for byte."""
+    import json
+    e = json.load(open(os.path.join(GOLDEN, "pyramid_ref.json")))
+    ds = e["dataset"]
+    base = str(tmp_path / "ds")
+    make_dataset(base, np.random.RandomState(ds["seed"]), contig_sizes=tuple(ds["contig_sizes"]), n_pairs=ds["n_pairs"],
+                 empty=tuple(ds["empty"]))
+    P = pyr.build_and_filter(base, e["size_pyramid"], e["factor"])
+    assert float(P.data["thresh"]) == pytest.approx(e["thresh"], rel=1e-6)
+    for lev in range(e["size_pyramid"]):
+        r = e["levels"][str(lev)]
+        assert int(P.data["%d/nfrags" % lev]) == r["nfrags"]
+        assert np.array_equal(np.stack(P.level_coo(lev)), np.array(r["data"]))          # the (3, nnz) dataset of pyramid.hdf5
+        folder = os.path.join(P.pyramid_folder, "level_%d" % lev)
+        for key, name in (("fragments_list", "%d_fragments_list.txt"), ("contig_info", "%d_contig_info.txt"),
+                          ("sub_2_super", "%d_sub_2_super_index_frag.txt")):
+            if key in r:
+                assert open(os.path.join(folder, name % lev)).read() == r[key], (lev, key)
+        if "S_o_A_frags" in r:                                                            # level loader, pyramid_sparse.py:1206-1380
+            L = P.get_level(lev)
+            assert sorted(L.S_o_A_frags) == sorted(r["S_o_A_frags"])
+            for k, v in r["S_o_A_frags"].items():
+                assert np.array_equal(np.asarray(L.S_o_A_frags[k]).astype(int), np.array(v)), (lev, k)
+            assert float(L.mean_value_trans) == pytest.approx(r["mean_value_trans"], rel=1e-12)
