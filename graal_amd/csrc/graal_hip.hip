@@ -663,6 +663,7 @@ __global__ __launch_bounds__(256) void k_incr(SoaPtr s, int n, const Changed* __
 // two groups in flight per lane, two 16-byte gathers per contact from a table that stays in L2.  Round 1's kernel loaded
 // the three words of ONE contact per lane and iteration and gathered a 16-byte + a 32-byte record per end: 234 us for
 // 20 M contacts (13 % of the 240 MB / 8 TB/s bound).
+struct SubRec8 { int label; float centre; };   // compact form for uniform RF counts (k_full_nnz_u): label | circular << 31
 struct SubRec {
     int label; float centre;
     int accu;   // RF count | RF count under the reference's trans-branch indexing (ex_pair_ref) << 16
@@ -670,7 +671,8 @@ struct SubRec {
 };
 
 __global__ __launch_bounds__(256) void k_subrec(int n, const Geo* __restrict__ geo, const Stat* __restrict__ stat,
-                                                 const int* __restrict__ sub_ids /* nullptr: id = f */, SubRec* __restrict__ rec)
+                                                 const int* __restrict__ sub_ids /* nullptr: id = f */, SubRec* __restrict__ rec,
+                                                 SubRec8* __restrict__ rec8 /* nullptr: RF counts are not uniform */)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n) return;
@@ -685,6 +687,7 @@ __global__ __launch_bounds__(256) void k_subrec(int n, const Geo* __restrict__ g
         r.accu = stat_accu(st, slot) | ((fwd ? stat_accu(st, slot) : stat_accu(st, st.n - 1)) << 16);   // (RF counts are <= 30000)
         r.bin = f | (((g.flags >> 1) & 1) << 31);
         rec[sel3(ids.x, ids.y, ids.z, slot)] = r;
+        if (rec8) { SubRec8 r8; r8.label = g.id_c | (((g.flags >> 1) & 1) << 31); r8.centre = r.centre; rec8[sel3(ids.x, ids.y, ids.z, slot)] = r8; }
     }
 }
 
@@ -694,6 +697,74 @@ __global__ __launch_bounds__(256) void k_subrec(int n, const Geo* __restrict__ g
 constexpr int LN_TRANS_LUT = 1024;
 // FULL_G = groups of 4 contacts per lane and iteration (template parameter; GRAAL_FULL_G picks 1, 2 or 4 for experiments)
 __device__ __forceinline__ int w4(const int4& q, int j) { return j == 0 ? q.x : (j == 1 ? q.y : (j == 2 ? q.z : q.w)); }
+
+// The same when every sub-fragment carries the SAME RF count (level 0: one restriction fragment per bin; any level of a map whose
+// bins are complete): the record shrinks to 8 bytes {label | circular << 31, centre} -- twice as many records per cache line for
+// the column-side gather, which is what bounds this kernel (random 16-byte reads of an L2-resident table pull a whole line into
+// the CU's L1 each) -- and the trans logarithm is one constant.  Bit-identical sums (same expressions on the same values).
+template <int FULL_G>
+__global__ __launch_bounds__(256) void k_full_nnz_u(const int4* __restrict__ row4, const int4* __restrict__ col4,
+                                                     const int4* __restrict__ cnt4, long long nnz, const SubRec8* __restrict__ rec,
+                                                     const SubRec* __restrict__ rec_full /* circular contigs only */,
+                                                     const int* __restrict__ lcontbp, float nfpb, Par par, int accu,
+                                                     long long* __restrict__ out, long long* __restrict__ bad_flag)
+{
+    const float norm = (float)(accu * accu) / nfpb;
+    const double ln_trans = log((double)(par.v_inter * norm));
+    long long acc = 0;
+    bool bad = false;
+    const int n4 = (int)(nnz >> 2);
+    const int stride = (int)(gridDim.x * blockDim.x);
+    for (int g0 = (int)(blockIdx.x * blockDim.x + threadIdx.x); g0 <= n4; g0 += FULL_G * stride) {
+        int4 r[FULL_G], c[FULL_G], w[FULL_G];
+#pragma unroll
+        for (int i = 0; i < FULL_G; i++) {
+            const int g = g0 + i * stride;
+            const int gc = g <= n4 ? g : n4;
+            r[i] = ld_stream(row4 + gc); c[i] = ld_stream(col4 + gc); w[i] = ld_stream(cnt4 + gc);
+        }
+        SubRec8 a[4 * FULL_G], b[4 * FULL_G];
+        bool valid[4 * FULL_G];
+#pragma unroll
+        for (int i = 0; i < FULL_G; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const long long idx = ((long long)(g0 + i * stride) << 2) + j;
+                const bool v = (g0 + i * stride) <= n4 && idx < nnz;
+                valid[4 * i + j] = v;
+                a[4 * i + j] = rec[v ? w4(r[i], j) : 0];
+                b[4 * i + j] = rec[v ? w4(c[i], j) : 0];
+            }
+#pragma unroll
+        for (int i = 0; i < FULL_G; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (!valid[4 * i + j]) continue;
+                const SubRec8 A = a[4 * i + j], B = b[4 * i + j];
+                double ln_ex = ln_trans;
+                if (((A.label ^ B.label) & 0x7fffffff) == 0) {
+                    const float sd = fabsf(B.centre - A.centre);
+                    float ex;
+                    if (A.label < 0) {   // circular contig (rare): its length sits in the full record's fragment
+                        const int bin_a = rec_full[w4(r[i], j)].bin & 0x7fffffff;
+                        ex = rippe_circ(sd, (float)lcontbp[bin_a] / 1000.0f, par) * norm;
+                    } else ex = rippe(sd, par) * norm;
+                    ln_ex = log((double)ex);
+                }
+                const long long q = to_q((double)__int_as_float(w4(w[i], j)) * ln_ex);
+                if (q == Q_BAD) bad = true; else acc += q;
+            }
+    }
+    if (bad) atomicOr((unsigned long long*)bad_flag, 1ull);
+    __shared__ long long s_part[4];
+    acc = wave_sum_ll(acc);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const long long v = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        if (v != 0) atomicAdd((unsigned long long*)out, (unsigned long long)v);
+    }
+}
 
 template <int FULL_G>
 __global__ __launch_bounds__(256) void k_full_nnz(const int4* __restrict__ row4, const int4* __restrict__ col4,
@@ -2627,6 +2698,8 @@ struct Ctx {
     int* mates = nullptr;
     Stat* stat = nullptr;
     SubRec* sub_rec = nullptr;    // [n_sub_total] per sub-fragment record of the full evaluation (k_subrec)
+    SubRec8* sub_rec8 = nullptr;  // the compact form, used when every sub-fragment has the same RF count (uniform_accu > 0)
+    int uniform_accu = 0;
     int* sub2bin = nullptr;
     int *row = nullptr, *col = nullptr, *cnt = nullptr;
     QEntry* queue = nullptr;
@@ -2973,7 +3046,7 @@ void graal_destroy(graal_ctx* h)
         (void)hipSetDevice(h->device);
         (void)hipStreamSynchronize(h->stream);
         if (h->aux) (void)hipStreamSynchronize(h->aux);
-        void* ptrs[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->stat, h->sub_rec, h->d_ubins, h->d_ln_tab, h->sub2bin, h->row, h->col, h->cnt, h->queue, h->d_sub_ids, h->d_acc, h->tm_done, h->d_sync, h->d_flags, h->stat_frag, h->d_dup_bins, h->d_dup_index,
+        void* ptrs[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->stat, h->sub_rec, h->sub_rec8, h->d_ubins, h->d_ln_tab, h->sub2bin, h->row, h->col, h->cnt, h->queue, h->d_sub_ids, h->d_acc, h->tm_done, h->d_sync, h->d_flags, h->stat_frag, h->d_dup_bins, h->d_dup_index,
                         h->d_dispatcher, h->d_collector, h->d_sub_ids_all, h->d_rep_obs,
                         h->keys, h->keys_sorted, h->o2n, h->len_of2[0], h->len_of2[1], h->contig_off2[0], h->contig_off2[1], h->perm, h->cbase, h->link, h->mates, h->cub_tmp, h->tabs, h->step_hdr, h->d_args, h->d_chg,
                         h->d_scalars, h->d_qout, h->d_dref, h->d_dist};
@@ -3047,7 +3120,7 @@ int graal_upload_subfrags(graal_ctx* h, const int32_t* sub_id, const float* sub_
     h->has_rep = false; h->n_dup = 0; h->h_dup_index.assign((size_t)n_bins, -1); // (graal_upload_repeats comes after)
     // single_sub additionally needs sub id == bin id so that the scan can skip the sub2bin gather
     for (int b = 0; single && b < n_bins; b++) single = (sub_id[4 * b] == b);
-    if (h->stat) { (void)hipFree(h->stat); (void)hipFree(h->sub2bin); (void)hipFree(h->d_sub_ids); (void)hipFree(h->sub_rec); h->d_sub_ids = nullptr; h->sub_rec = nullptr; }
+    if (h->stat) { (void)hipFree(h->stat); (void)hipFree(h->sub2bin); (void)hipFree(h->d_sub_ids); (void)hipFree(h->sub_rec); (void)hipFree(h->sub_rec8); h->d_sub_ids = nullptr; h->sub_rec = nullptr; h->sub_rec8 = nullptr; }
     if (!single) {
         CK(hipMalloc(&h->d_sub_ids, sizeof(int) * 4 * (size_t)n_bins));
         CK(hipMemcpy(h->d_sub_ids, sub_id, sizeof(int) * 4 * (size_t)n_bins, hipMemcpyHostToDevice));
@@ -3056,6 +3129,14 @@ int graal_upload_subfrags(graal_ctx* h, const int32_t* sub_id, const float* sub_
     CK(hipMalloc(&h->sub2bin, sizeof(int) * (size_t)n_sub_total));
     CK(hipMalloc(&h->sub_rec, sizeof(SubRec) * (size_t)n_sub_total));
     CK(hipMemset(h->sub_rec, 0, sizeof(SubRec) * (size_t)n_sub_total));
+    CK(hipMalloc(&h->sub_rec8, sizeof(SubRec8) * (size_t)n_sub_total));
+    CK(hipMemset(h->sub_rec8, 0, sizeof(SubRec8) * (size_t)n_sub_total));
+    {
+        h->uniform_accu = sub_accu[0];
+        for (int b = 0; b < n_bins && h->uniform_accu; b++)
+            for (int k = 0; k < sub_id[4 * b + 3]; k++) if (sub_accu[3 * b + k] != h->uniform_accu) { h->uniform_accu = 0; break; }
+        if (h->uniform_accu > 30000) h->uniform_accu = 0;
+    }
     {   // bins with non-uniform RF counts: the only ones the reference's trans-branch indexing prices differently
         std::vector<int> ub;
         for (int b = 0; b < n_bins; b++) {
@@ -3384,7 +3465,9 @@ int graal_eval_full_q(graal_ctx* h, int64_t q_out[2])
     const bool quirk = (h->mode & GRAAL_MODE_REF_TRANS_ACCU) != 0;
     if (quirk && h->has_rep) return fail(h, GRAAL_E_UNSUPPORTED, "GRAAL_MODE_REF_TRANS_ACCU with repeated bins is not implemented");
     if (h->nnz) {
-        k_subrec<<<blocks_for(h->n, 256), 256, 0, h->stream>>>(h->n, h->geo, h->stat_frag, h->d_sub_ids, h->sub_rec);
+        static const bool no_compact = getenv("GRAAL_FULL_NO_COMPACT") != nullptr;
+        const bool compact = h->uniform_accu > 0 && !quirk && !no_compact;
+        k_subrec<<<blocks_for(h->n, 256), 256, 0, h->stream>>>(h->n, h->geo, h->stat_frag, h->d_sub_ids, h->sub_rec, compact ? h->sub_rec8 : nullptr);
         // 8 blocks of 256 threads per CU; every lane takes FULL_G groups of 4 contacts per iteration
         static const int full_g = getenv("GRAAL_FULL_G") ? atoi(getenv("GRAAL_FULL_G")) : 2;
         static const int full_bpc = getenv("GRAAL_FULL_BPC") ? atoi(getenv("GRAAL_FULL_BPC")) : 8;   // blocks per CU
@@ -3393,7 +3476,15 @@ int graal_eval_full_q(graal_ctx* h, int64_t q_out[2])
         const int nb = (int)std::max<long long>(1, std::min<long long>((groups + 256 * FG - 1) / (256 * FG), 256 * full_bpc));
 #define FULL_NNZ_ARGS reinterpret_cast<const int4*>(h->row), reinterpret_cast<const int4*>(h->col), reinterpret_cast<const int4*>(h->cnt), \
                       h->nnz, h->sub_rec, s.p[F_LCONTBP], h->nfpb, h->par, h->ln_lut_n, quirk ? 1 : 0, h->d_scalars + 8, h->d_scalars + FULL_BAD
-        if (FG == 1) k_full_nnz<1><<<nb, 256, 0, h->stream>>>(FULL_NNZ_ARGS);
+        if (compact) {
+#define FULL_NNZ_U_ARGS reinterpret_cast<const int4*>(h->row), reinterpret_cast<const int4*>(h->col), reinterpret_cast<const int4*>(h->cnt), \
+                        h->nnz, h->sub_rec8, h->sub_rec, s.p[F_LCONTBP], h->nfpb, h->par, h->uniform_accu, h->d_scalars + 8, h->d_scalars + FULL_BAD
+            if (FG == 1) k_full_nnz_u<1><<<nb, 256, 0, h->stream>>>(FULL_NNZ_U_ARGS);
+            else if (FG == 4) k_full_nnz_u<4><<<nb, 256, 0, h->stream>>>(FULL_NNZ_U_ARGS);
+            else k_full_nnz_u<2><<<nb, 256, 0, h->stream>>>(FULL_NNZ_U_ARGS);
+#undef FULL_NNZ_U_ARGS
+        }
+        else if (FG == 1) k_full_nnz<1><<<nb, 256, 0, h->stream>>>(FULL_NNZ_ARGS);
         else if (FG == 4) k_full_nnz<4><<<nb, 256, 0, h->stream>>>(FULL_NNZ_ARGS);
         else k_full_nnz<2><<<nb, 256, 0, h->stream>>>(FULL_NNZ_ARGS);
 #undef FULL_NNZ_ARGS

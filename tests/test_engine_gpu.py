@@ -478,3 +478,39 @@ def test_ops_that_ignore_the_neighbour_are_applied_with_identical_fragments(op):
     for k in O.FIELDS:
         assert np.array_equal(got[k], want[k]), k
     e.close()
+
+
+def _full_q_of_fixture(n_sub, seed):
+    P = make(n_sub, seed, n_bins=300, nnz=20000)
+    rng = np.random.RandomState(seed)
+    out = []
+    for _ in range(3):
+        s = random_state_for(P, rng, n_contigs=12, p_circ=0.4)
+        e = engine_for(P, s)
+        e.relabel_contigs()
+        out.append([int(v) for v in e.eval_full_q()])
+        e.close()
+    return out
+
+
+def _print_full_q():   # body of the child process below
+    import json
+    print("FULLQ " + json.dumps([_full_q_of_fixture(1, 91), _full_q_of_fixture(3, 92)]))
+
+
+@pytest.mark.timeout(600)
+def test_compact_records_of_the_full_evaluation_are_bit_identical():
+    """k_full_nnz_u (8-byte records, used when every sub-fragment has the same RF count) against k_full_nnz (16-byte records;
+    GRAAL_FULL_NO_COMPACT=1 in a child process -- the switch is read once per process): the same int64 sums, circular contigs
+    included."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GRAAL_FULL_NO_COMPACT="1", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    out = subprocess.run([sys.executable, "-c", "import tests.test_engine_gpu as t; t._print_full_q()"], cwd=root, env=env,
+                         capture_output=True, text=True, timeout=500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    want = json.loads([l for l in out.stdout.splitlines() if l.startswith("FULLQ ")][-1][6:])
+    got = [_full_q_of_fixture(1, 91), _full_q_of_fixture(3, 92)]
+    assert got == want

@@ -77,10 +77,16 @@ def main():
     ks = find(os.path.join(d, "trace"), "*kernel_stats.csv")
     if ks:
         res["kernel_stats_csv"] = open(ks).read()
-    for name in ("fetch", "write"):
+    for name in ("fetch", "write", "sq"):
         c = find(os.path.join(d, name), "*counter_collection.csv")
         if c:
             res["pmc_" + name] = counter_stats(c)
+    # HBM bytes per launch of every kernel that has both TCC counters: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 correction)
+    hbm = {}
+    for k, cs in res.get("pmc_fetch", {}).items():
+        if k in res.get("pmc_write", {}) and "FETCH_SIZE" in cs and "WRITE_SIZE" in res["pmc_write"][k]:
+            hbm[k] = (2.0 * cs["FETCH_SIZE"]["mean_last_100"] + res["pmc_write"][k]["WRITE_SIZE"]["mean_last_100"]) * 1024.0
+    res["hbm_bytes_per_launch"] = hbm
     scan = [k for k in res.get("pmc_fetch", {}) if k.startswith("k_scan")]
     if scan and scan[0] in res.get("pmc_write", {}):
         k = scan[0]
@@ -98,12 +104,16 @@ def main():
         for k, v in sorted(res.get("kernel_trace", {}).items(), key=lambda kv: -kv[1]["total_ms"]):
             f.write("| %s | %d | %.3f | %.2f | %.2f | %.2f | %.2f |\n" % (k[:70], v["calls"], v["total_ms"], v["avg_us"], v["min_us"],
                                                                   v["max_us"], v["avg_us_last_100"]))
-        for name in ("fetch", "write"):
+        for name in ("fetch", "write", "sq"):
             if "pmc_" + name in res:
-                f.write("\n## PMC pass: %s (KiB per dispatch)\n\n| kernel | counter | n | mean | mean last 100 | min | max |\n|---|---|---|---|---|---|---|\n" % name)
+                f.write("\n## PMC pass: %s (KiB per dispatch for the TCC counters)\n\n| kernel | counter | n | mean | mean last 100 | min | max |\n|---|---|---|---|---|---|---|\n" % name)
                 for k, cs in res["pmc_" + name].items():
                     for c, v in cs.items():
                         f.write("| %s | %s | %d | %.1f | %.1f | %.1f | %.1f |\n" % (k[:70], c, v["n"], v["mean"], v["mean_last_100"], v["min"], v["max"]))
+        if res.get("hbm_bytes_per_launch"):
+            f.write("\n## HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (mean of the last 100 launches)\n\n| kernel | MB |\n|---|---|\n")
+            for k, v in sorted(res["hbm_bytes_per_launch"].items(), key=lambda kv: -kv[1]):
+                f.write("| %s | %.3f |\n" % (k[:70], v / 1e6))
         if "k_scan_hbm_bytes_per_launch" in res:
             f.write("\nk_scan HBM bytes / launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 = %.0f\n" % res["k_scan_hbm_bytes_per_launch"])
         if "kernel_stats_csv" in res:
