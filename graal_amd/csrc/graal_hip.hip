@@ -1318,12 +1318,15 @@ __device__ __forceinline__ void price_contacts_bulk(const PriceArgs& pa, const d
         }
         return log((double)ex_pair(X, sx, slx, Y, sy, sly, pa.nfpb, pa.par));
     };
-    for (unsigned long long b0 = (unsigned long long)first * 64; b0 < nq_total; b0 += (unsigned long long)n_waves * 64) {
+    // entries per wave and round: 64 when there are enough of them to keep every wave busy that way, else 16 or 4 (a queue of a
+    // few hundred contacts priced 64 per wave would leave most of the grid idle while a few waves run 16 passes each)
+    const int B = nq_total >= 64ull * (unsigned long long)n_waves ? 64 : (nq_total >= 16ull * (unsigned long long)n_waves ? 16 : 4);
+    for (unsigned long long b0 = (unsigned long long)first * B; b0 < nq_total; b0 += (unsigned long long)n_waves * B) {
         double ln_old_a = 0.0;
         int live_a = 0;
         {
             const unsigned long long ea = b0 + lane;
-            if (ea < nq_total) {
+            if (lane < B && ea < nq_total) {
                 const QEntry qe = pa.queue[ea];
                 if (qe.rel != 0) {
                     const int fx = qe.fx, fy = qe.fy;
@@ -1335,7 +1338,7 @@ __device__ __forceinline__ void price_contacts_bulk(const PriceArgs& pa, const d
                 }
             }
         }
-        const int n_here = nq_total - b0 < 64ull ? (int)(nq_total - b0) : 64;
+        const int n_here = nq_total - b0 < (unsigned long long)B ? (int)(nq_total - b0) : B;
         for (int pass = 0; pass * 4 < n_here; pass++) {
             const int src = pass * 4 + c4;
             const double ln_old = __shfl(ln_old_a, src, 64);
