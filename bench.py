@@ -24,7 +24,7 @@ sharded over the ranks), `exchange_alt` (N > 1).
 
 Output: one JSON line on rank 0 (contract in the task statement) with `roofline` (fused scan kernel: algorithmic bytes
 = 4 B x contacts (row words) + n/8 B (bitmap) + 64 B x queued contacts per launch; duration = HIP event pairs around the
-launches of the timed region, on the engine's stream -- every launch when --steps <= 64, else every 8th; plus
+launches of the timed region (every 8th step) and of an untimed repeat of the same steps with a pair on every step; plus
 `roofline.hbm_control`: the same kernel, same layout, same proposals over a list whose row array (480 MB) cannot stay in the
 256 MiB Infinity Cache, so HBM-vs-cache is settled by measurement) and `cpu_baseline` (numpy re-score of the same sparse
 likelihood on the host, N = 1 only).
@@ -261,11 +261,11 @@ def main():
         td.all_reduce(t, op=td.ReduceOp.MAX)
         return float(t.cpu()[0])
 
-    # a HIP event pair around k_scan on every 4th step of a short timed region (the driver's 20 steps give 5 samples), on every
-    # 8th step of a long one.  Not on every step: each pair adds command-processor marker gaps -- measured with a pair on EVERY
-    # step: 72 instead of 40 us per step and 35 instead of 24 us between the two events of a pair (r02, gpurun_out/bench_r02a.log)
-    # -- so a densely instrumented region measures its own instrumentation
-    EVENT_EVERY = int(os.environ.get("GRAAL_BENCH_EVENT_EVERY", 4 if args.steps <= 64 else 8))
+    # The timed region carries a HIP event pair around k_scan on every 8th step only (a pair costs the step ~10-25 us of
+    # command-processor marker gaps: 64 us per step with a pair on every step against 40 without, profiles/r02_event_sampling.log);
+    # right behind it the same steps run once more, untimed, with a pair on EVERY step (at most 64): those samples -- in-step
+    # launches of the same proposals -- price the roofline, so that a 20-step run has 20 of them rather than 2.
+    EVENT_EVERY = int(os.environ.get("GRAAL_BENCH_EVENT_EVERY", 8))
     smp.engine.set_timing(EVENT_EVERY)
     for f, nb in props[:args.warmup]:
         smp._candidate_deltas(f, nb, max_id)
@@ -277,8 +277,16 @@ def main():
         n_cand += 13 * len(nb)
     sync_all()
     elapsed = time.perf_counter() - t0
-    scan_ms = smp.engine.scan_times(max(1, min(args.steps // EVENT_EVERY, 1024)))   # the event pairs of the timed region, read afterwards
+    n_timed_pairs = min(args.steps // EVENT_EVERY, 1024)
+    scan_ms_timed = smp.engine.scan_times(n_timed_pairs) if n_timed_pairs else np.zeros(0, np.float32)   # pairs of the timed region
     elapsed = max_over_ranks(elapsed)
+    n2 = min(args.steps, 64)
+    smp.engine.set_timing(1)
+    for f, nb in props[args.warmup:args.warmup + n2]:
+        smp._candidate_deltas(f, nb, max_id)
+    sync_all()
+    scan_ms = np.concatenate([smp.engine.scan_times(n2), scan_ms_timed])
+    smp.engine.set_timing(EVENT_EVERY)
     counters = smp.engine.last_counters()
     # N > 1: the same timed region once more with the OTHER way of summing the ranks' 13*K int64 values (one all-reduce of a
     # device buffer per step through torch.distributed -- RCCL with the nccl backend), reported next to the default
@@ -383,7 +391,13 @@ def main():
         # (profiles/) agrees with it.  (b) 100 back-to-back replays of the last step's scan between two events, reported next
         # to it: there the ramp and the prologue of one launch overlap the tail of the previous one, so it measures the
         # streaming phase alone.
-        scan_s = float(np.mean(scan_ms)) * 1e-3
+        # (an event pair also spans whatever the HOST does between recording the first event and submitting the kernel: now and
+        # then a sample is ten times the others -- 250 us instead of 23, always among the first pairs after a synchronisation.
+        # Those are host stalls, not kernel time (rocprofv3's per-kernel durations never show them): samples above twice the
+        # median are left out of the mean, and counted.)
+        med = float(np.median(scan_ms))
+        kept = scan_ms[scan_ms <= 2.0 * med]
+        scan_s = float(np.mean(kept)) * 1e-3
         achieved = bytes_per_launch / scan_s / 1e9
         replay_s = scan_replay_ms * 1e-3
         traffic = None
@@ -411,12 +425,13 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_scan",
                          "bytes_per_launch": bytes_per_launch, "avg_launch_ms": scan_s * 1e3,
-                         "launches_timed": int(len(scan_ms)),
+                         "launches_timed": int(len(kept)), "host_stall_samples_left_out": int(len(scan_ms) - len(kept)),
+                         "launch_ms_samples": [round(float(x), 5) for x in scan_ms[:96]],
                          "back_to_back_replay_ms": replay_s * 1e3,
                          "frac_back_to_back_replays": bytes_per_launch / replay_s / 1e9 / HBM_PEAK_GBS,
                          "isolated_replay_ms": scan_isolated_ms,
                          "hbm_control": control},
-            "phase_ms": {"k_scan": float(np.mean(scan_ms)), "host_wall_per_step": 1e3 * elapsed / args.steps},
+            "phase_ms": {"k_scan": scan_s * 1e3, "host_wall_per_step": 1e3 * elapsed / args.steps},
             "relevant_pairs_last_step": int(counters[1]), "queued_contacts_last_step": int(counters[2]),
             "mass_items_last_step": int(counters[3]),
             "full_mcmc_step_ms": 1e3 * full_step_s, "full_eval_ms": 1e3 * full_eval_s,
