@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -2677,6 +2678,8 @@ struct Ctx {
     bool have_par = false, have_sub = false, have_frags = false, have_contacts = false, order_valid = false;
     int n_contigs = 0;
     double t_all = 0.0;         // layout independent all-trans expected mass
+    std::vector<long long> t_hist;          // its inputs: number of sub-fragments per RF count,
+    std::map<long long, long long> t_self;  // and of slot pairs inside one bin per product of RF counts
     long long c_lf_q = 0;       // sum of the log-factorial terms of this shard's contacts, each rounded to Q: an integer sum, so
                                 // the full likelihood is bit-identical for any sharding of the list (a double sum depends on the order)
     std::vector<int> h_accu;    // [n_bins][3]
@@ -2789,18 +2792,28 @@ double lf_term(double ob)
     return 0.0;
 }
 
-void compute_t_all(Ctx* h)
+// histograms behind T_all (they depend on the RF counts and on which bins are repeats, not on the parameters)
+void build_t_hist(Ctx* h)
 {
-    // T_all = sum over pairs of DIFFERENT bins, all slot pairs, of float32(v * float32(float32(ax*ay)/nfpb))
-    if (!h->have_par || !h->have_sub) return;
-    std::vector<long long> hist;
+    h->t_hist.clear(); h->t_self.clear();
+    if (!h->have_sub) return;
     auto nsub = [&](int b) { return (h->has_rep && h->h_dup_index[b] >= 0) ? 0 : h->h_nsub[b]; }; // repeated bins: priced densely
     for (int b = 0; b < h->n_bins; b++)
         for (int s = 0; s < nsub(b); s++) {
             const int a = h->h_accu[3 * b + s];
-            if ((size_t)a >= hist.size()) hist.resize(a + 1, 0);
-            hist[a]++;
+            if ((size_t)a >= h->t_hist.size()) h->t_hist.resize(a + 1, 0);
+            h->t_hist[a]++;
+            for (int t = 0; t < nsub(b); t++) h->t_self[(long long)a * h->h_accu[3 * b + t]]++;
         }
+}
+
+void compute_t_all(Ctx* h, bool rebuild = true)
+{
+    // T_all = sum over pairs of DIFFERENT bins, all slot pairs, of float32(v * float32(float32(ax*ay)/nfpb)); a nuisance-
+    // parameter step changes v_inter only: the histograms are kept (the per-bin loops were 0.2 ms of each graal_set_params at C5)
+    if (rebuild) build_t_hist(h);
+    if (!h->have_par || !h->have_sub) return;
+    const std::vector<long long>& hist = h->t_hist;
     auto c = [&](long long m) { return (double)(h->par.v_inter * ((float)(int)m / h->nfpb)); };
     double all = 0.0;
     for (size_t u = 0; u < hist.size(); u++)
@@ -2808,9 +2821,7 @@ void compute_t_all(Ctx* h)
             for (size_t w = 0; w < hist.size(); w++)
                 if (hist[w]) all += (double)hist[u] * (double)hist[w] * c((long long)u * (long long)w);
     double self = 0.0;
-    for (int b = 0; b < h->n_bins; b++)
-        for (int s = 0; s < nsub(b); s++)
-            for (int t = 0; t < nsub(b); t++) self += c((long long)h->h_accu[3 * b + s] * h->h_accu[3 * b + t]);
+    for (const auto& kv : h->t_self) self += (double)kv.second * c(kv.first);
     h->t_all = 0.5 * (all - self);
 }
 
@@ -3074,11 +3085,12 @@ int graal_set_params(graal_ctx* h, const float* p)
 {
     if (h && h->stream) (void)hipStreamSynchronize(h->stream); // (graal_begin_step may have left its relabel kernels running)
     if (!h || !p) return GRAAL_E_ARG;
+    if (h->have_par && memcmp(&h->par, p, sizeof(Par)) == 0) return GRAAL_OK;   // (re-sending the parameters in force)
     memcpy(&h->par, p, sizeof(Par));
     if (!(h->par.v_inter > 0.0f)) return fail(h, GRAAL_E_ARG, "v_inter must be > 0 (the sparse form prices every pixel at >= v_inter)");
     if (!(h->par.d_max > 0.0f) || !(h->par.d_max < 2.0e6f)) return fail(h, GRAAL_E_ARG, "d_max out of range");
     h->have_par = true;
-    compute_t_all(h);
+    compute_t_all(h, h->t_hist.empty());
     CK(hipSetDevice(h->device));
     return sync_args(h);
 }

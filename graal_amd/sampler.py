@@ -434,14 +434,19 @@ class sampler(object):
         from . import rippe_fit
         return rippe_fit.peval(self.bins, p0)  # cuda_lib_gl.py:1982-1984 (5-list: p0[3] = d is the amplitude, kept)
 
-    def compute_likelihood_4_nuisance(self, test_param):
-        """Full likelihood of the current layout under TEST parameters (``cuda_lib_gl.py:1986-2017``)."""
+    def compute_likelihood_4_nuisance(self, test_param, restore=True):
+        """Full likelihood of the current layout under TEST parameters (``cuda_lib_gl.py:1986-2017``).  ``restore=False`` leaves
+        the test parameters in force on the device (the caller accepts them or puts ``_param_flat`` back itself)."""
         keep = np.copy(self._param_flat)
         self.engine.set_params(test_param)
         try:
             return self.eval_likelihood()
+        except BaseException:
+            restore = True
+            raise
         finally:
-            self.engine.set_params(keep)
+            if restore:
+                self.engine.set_params(keep)
 
     def step_nuisance_parameters(self, dt=0, t=0, n_step=1):
         """Random-walk Metropolis step on (fact, slope, d_max, v_inter): ``cuda_lib_gl.py:2022-2107`` with its quirks kept
@@ -485,7 +490,7 @@ class sampler(object):
         if self.likelihood_t is None:
             self.likelihood_t = self.eval_likelihood()
         valid = bool(np.isfinite(flat).all() and flat[7] > 0 and 0 < flat[5] < 2.0e6)
-        test_likelihood = self.compute_likelihood_4_nuisance(flat) if valid else -np.inf
+        test_likelihood = self.compute_likelihood_4_nuisance(flat, restore=False) if valid else -np.inf
         F_t = self.temperature(t, n_step)
         with np.errstate(over="ignore"):
             ratio = np.exp((test_likelihood - self.likelihood_t) / F_t)
@@ -496,6 +501,8 @@ class sampler(object):
             self.set_param_simu(out_test_param)
             self.likelihood_t = test_likelihood
             self._force_full = False   # a full evaluation of the current layout under the parameters now in force
+        elif valid:
+            self.engine.set_params(self._param_flat)   # rejected: back to the parameters in force
         kuhn, lm, c1, slope, d, d_max, fact, d_nuc = self.param_simu[0]
         y_rippe = self.return_rippe_vals([kuhn, lm, slope, d, fact])
         return fact, d, d_max, d_nuc, slope, self.likelihood_t, success, y_rippe
