@@ -2019,6 +2019,7 @@ struct FinArgs { // first-needed pointers by value (see ScanArgs)
     const double* ln_tab;          // ln of the trans value by RF-count product (k_ln_tab), lut_n entries
     int lut_n;
     int skip;                      // diagnostics (GRAAL_FIN_SKIP): 1 = no mass units, 2 = no queued contacts
+    int seg;                       // fragments y per mass unit (0: 128, or 16 with sub-fragments)
 };
 
 __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinArgs fa, int K, int rank, int world,
@@ -2076,7 +2077,33 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
         // U % world.  (Sums are integers: any partition of the pairs gives the same result.)
         __shared__ int s_ustart[MAXK][MAX_TASKS + 1]; // s_ustart[k][ti] = first unit of task ti among neighbour k's units
         __shared__ int s_ubase[MAXK + 1], s_nt[MAXK];
-        const int SEG = A->sub2bin_multi == nullptr ? 128 : 16; // (up to 9 slot pairs per fragment pair with sub-fragments)
+        // SEG: fragments y per unit.  At most 128 (16 with sub-fragments: up to 9 slot pairs per fragment pair), and small enough
+        // for the step to have ~4 units per wave of the grid: a unit is one long dependent chain of float32 powf / expf, ~25 us
+        // for 16 y with sub-fragments, and a step of the C2 stand-in has only ~1,500 such units for 2,048 waves -- its k_fin lasted
+        // 140 us for 12 us worth of VALU work, the few waves that got two or three units carried it (tools/fin_seg_ab.sh:
+        // SEG 16 -> 2 takes the scoring phase from 138 to 79 us there, from 178 to 126 us at the C3 shape).
+        __shared__ int s_walk[MAXK];
+        const bool multi_sub = A->sub2bin_multi != nullptr;
+        for (int k = threadIdx.x >> 6; k < K; k += (int)(blockDim.x >> 6)) {
+            const NbTables& T = tabs[k];
+            const int nt = (s_hdr[k] >> 31) ? 0 : T.n_tasks;
+            int w = 0;
+            for (int ti = lane; ti < nt; ti += 64) {
+                const Task& tk = T.task[ti];
+                w += ((tk.np + 63) >> 6) * (tk.p == tk.q ? tk.np : tk.nq);
+            }
+            w = (int)wave_sum_ll((long long)w);
+            if (lane == 0) s_walk[k] = w;
+        }
+        __syncthreads();
+        int SEG = fa.seg;
+        if (SEG <= 0) {
+            long long w_all = 0;
+            for (int k = 0; k < K; k++) w_all += s_walk[k];
+            const long long per_unit = w_all / (4ll * n_waves * world);
+            SEG = multi_sub ? 2 : 16;
+            while (SEG < (multi_sub ? 16 : 128) && SEG < per_unit) SEG <<= 1;
+        }
         for (int k = threadIdx.x >> 6; k < K; k += (int)(blockDim.x >> 6)) { // one wave per neighbour, side by side
             const NbTables& T = tabs[k];
             const int nt = (s_hdr[k] >> 31) ? 0 : T.n_tasks; // (bit 31: priced by k_tm already)
@@ -2658,6 +2685,7 @@ struct Ctx {
     hipStream_t aux = nullptr;    // k_tm runs here, concurrently with k_scan on the main stream
     hipEvent_t ev_fin = nullptr;  // end of the last asynchronous evaluation (orders the next k_tm after it)
     hipEvent_t ev_relabel = nullptr; // end of the relabel kernels graal_begin_step left running (orders the next k_tm, on aux)
+    hipEvent_t ev_tm = nullptr;   // end of the step's k_tm (orders a chip-filling k_fin behind it, see launch_fin)
     bool relabel_pending = false;
     bool begin_launched = false;  // graal_begin_step_launch ran for the current layout; graal_begin_step only has to wait
     bool stats_from_apply = false; // the last commit published the statistics of the layout it produced (sequence stats_seq)
@@ -2936,20 +2964,35 @@ int launch_scan(Ctx* h, int fA, const Neigh& nb, int K, int max_id, int dry, hip
     return GRAAL_OK;
 }
 
-// left-over mass items, queued contacts, hand-out.  Short contigs leave it a handful of contacts: a small grid keeps its
-// launch and completion ticket cheap; long contigs get the whole chip.
-int launch_fin(Ctx* h, int K, int rank, int world, long long* d_q_out, bool publish, hipStream_t st)
+constexpr int FIN_BLOCKS_NO_WAIT = 3 * 256;   // largest k_fin grid that cannot keep k_tm off the chip (see launch_fin)
+
+int fin_blocks_cfg(const Ctx* h)
 {
     static const int fin_blocks_env = getenv("GRAAL_FIN_BLOCKS") ? atoi(getenv("GRAAL_FIN_BLOCKS")) : 0;
     // (contigs of thousands of fragments: the mass units are long dependent chains, 8 waves per SIMD keep the VALUs ~60 % busy
     // where 2 waves reach ~50 % -- 2.8 -> 2.2 ms per step on C5's 7 contigs; with contigs of a few hundred fragments the larger
     // grid only adds per-block set-up)
-    const int fin_blocks = fin_blocks_env > 0 ? fin_blocks_env : (h->max_lcont > 0 && h->max_lcont <= 16 ? 32 : (h->max_lcont > 1024 ? 2048 : 512));
+    // (768 = 3 blocks per CU: the largest grid that may spin for k_tm's tables, see launch_fin)
+    return fin_blocks_env > 0 ? fin_blocks_env : (h->max_lcont > 0 && h->max_lcont <= 16 ? 32 : (h->max_lcont > 1024 ? 2048 : FIN_BLOCKS_NO_WAIT));
+}
+
+// left-over mass items, queued contacts, hand-out.  Short contigs leave it a handful of contacts: a small grid keeps its
+// launch and completion ticket cheap; long contigs get the whole chip.
+int launch_fin(Ctx* h, int K, int rank, int world, long long* d_q_out, bool publish, hipStream_t st)
+{
+    const int fin_blocks = fin_blocks_cfg(h);
+    // k_fin's blocks spin until k_tm has released the tables.  k_tm is launched first, on the other stream, but nothing
+    // guarantees that its blocks are PLACED first: k_fin holds 116 VGPRs, four of its blocks fill a CU's register files, and a
+    // grid of more than 3 x 256 blocks that gets there first (a short scan) leaves no SIMD with the 96 VGPRs a wave of k_tm needs
+    // -- every block then spins to its bound and the step fails (seen with 2,048 blocks on the C2 stand-in).  Such a grid is
+    // ordered behind k_tm by an event instead (the regime where it is used has steps of hundreds of microseconds).
+    if (fin_blocks > FIN_BLOCKS_NO_WAIT) CK(hipStreamWaitEvent(st, h->ev_tm, 0));
     static const int fin_skip = getenv("GRAAL_FIN_SKIP") ? atoi(getenv("GRAAL_FIN_SKIP")) : 0;   // (diagnostics: wrong sums)
     FinArgs fa;
     fa.tm_done = h->tm_done; fa.step_hdr = h->step_hdr; fa.counters = (unsigned long long*)(h->d_scalars + 10); fa.queue = h->queue;
     fa.tabs = h->tabs; fa.geo = h->geo; fa.stat = h->stat_frag; fa.acc = h->d_acc; fa.sync = h->d_sync;
-    fa.ln_tab = h->d_ln_tab; fa.lut_n = h->d_ln_tab ? h->ln_lut_n : 0; fa.skip = fin_skip;
+    static const int fin_seg = getenv("GRAAL_FIN_SEG") ? atoi(getenv("GRAAL_FIN_SEG")) : 0;
+    fa.ln_tab = h->d_ln_tab; fa.lut_n = h->d_ln_tab ? h->ln_lut_n : 0; fa.skip = fin_skip; fa.seg = fin_seg;
     k_fin<<<fin_blocks, 256, 0, st>>>(h->d_args + h->cur, fa, K, rank, world, d_q_out, publish ? h->res_dev : nullptr, h->seq);
     CK(hipGetLastError());
     return GRAAL_OK;
@@ -3016,6 +3059,7 @@ int graal_create(int device, graal_ctx** out)
     }
     CK(hipEventCreateWithFlags(&h->ev_fin, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&h->ev_relabel, hipEventDisableTiming));
+    CK(hipEventCreateWithFlags(&h->ev_tm, hipEventDisableTiming));
     for (auto& ev : h->ev) CK(hipEventCreate(&ev));
     h->ring.resize(2 * 1024, nullptr);
     for (auto& ev : h->ring) CK(hipEventCreate(&ev));
@@ -3073,6 +3117,7 @@ void graal_destroy(graal_ctx* h)
         for (auto& ev : h->ring) if (ev) (void)hipEventDestroy(ev);
         if (h->ev_fin) (void)hipEventDestroy(h->ev_fin);
         if (h->ev_relabel) (void)hipEventDestroy(h->ev_relabel);
+        if (h->ev_tm) (void)hipEventDestroy(h->ev_tm);
         if (h->aux) (void)hipStreamDestroy(h->aux);
         (void)hipStreamDestroy(h->stream);
     }
@@ -3571,6 +3616,7 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     ta.lcontbp = h->soa[h->cur].p[F_LCONTBP]; ta.acc = h->d_acc; ta.nfpb = h->nfpb; ta.par = h->par;
     k_tm<<<K, 256, 0, h->aux>>>(A, ta, fA, nb, K, max_id, rank, world, h->seq);
     CK(hipGetLastError());
+    if (ta.host_res == nullptr && !strict && fin_blocks_cfg(h) > FIN_BLOCKS_NO_WAIT) CK(hipEventRecord(h->ev_tm, h->aux));
     // (2) the streaming pass, with a HIP event pair around it on every event_every-th call
     const bool ev = h->want_events && (h->eval_calls % h->event_every == 0);
     h->eval_calls += 1;
@@ -3589,7 +3635,7 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
         FinArgs fa;
         fa.tm_done = h->tm_done; fa.step_hdr = h->step_hdr; fa.counters = (unsigned long long*)(h->d_scalars + 10); fa.queue = h->queue;
         fa.tabs = h->tabs; fa.geo = h->geo; fa.stat = h->stat_frag; fa.acc = h->d_acc; fa.sync = h->d_sync;
-        fa.ln_tab = nullptr; fa.lut_n = 0; fa.skip = 0;
+        fa.ln_tab = nullptr; fa.lut_n = 0; fa.skip = 0; fa.seg = 0;
         StrictArgs sx;
         sx.perm = h->perm; sx.cbase = h->cbase; sx.lcontbp = h->soa[h->cur].p[F_LCONTBP]; sx.link = h->link; sx.nfpb = h->nfpb; sx.par = h->par;
         sx.quirk = (h->mode & GRAAL_MODE_REF_TRANS_ACCU) ? 1 : 0;
