@@ -229,6 +229,14 @@ __device__ __forceinline__ float ex_pair_ref(const End& X, const Stat& sx, int s
     return ex_pair(X, sx, slx, Y, sy, sly, nfpb, p);
 }
 
+// "This thread's device-scope atomics have been performed."  They execute at the memory side, and on gfx9 the vector-memory
+// counter also counts stores and atomics without return and is decremented when they are acknowledged: waiting for it is all
+// a block needs before it takes its completion ticket.  __threadfence() -- a release fence at agent scope -- adds a write-back
+// of the XCD's L2 (buffer_wbl2), which the atomics do not need and which takes a microsecond or more per block: the 768 blocks
+// of k_fin doing it one after the other were a 15 us tail of that kernel (in-kernel stamps, C2 stand-in: last block at the
+// ticket -> last block past it).
+#define ATOMICS_DONE() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
 __device__ __forceinline__ long long wave_sum_ll(long long v)
 {
 #pragma unroll
@@ -338,7 +346,7 @@ __device__ __forceinline__ void stat_reduce_publish(const StatAcc& a, long long*
     }
     if (host == nullptr) return;
     __shared__ int s_last;
-    __threadfence();
+    ATOMICS_DONE();
     __syncthreads();
     if (threadIdx.x == 0) s_last = atomicAdd((unsigned long long*)&out[21], 1ull) == (unsigned long long)gridDim.x - 1ull;
     __syncthreads();
@@ -430,7 +438,7 @@ __global__ __launch_bounds__(256) void k_dist(SoaPtr s, int n, const int4* __res
     __syncthreads();
     if (threadIdx.x == 0) {
         atomicAdd(&acc[0], (unsigned long long)(s_h[0] + s_h[1] + s_h[2] + s_h[3]));
-        __threadfence();
+        ATOMICS_DONE();
         if (atomicAdd(&acc[1], 1ull) == (unsigned long long)gridDim.x - 1ull) { // last block: publish to pinned host memory
             __threadfence();
             host[1] = (long long)atomicExch(&acc[0], 0ull);
@@ -953,6 +961,8 @@ struct NbTables {        // everything the finishing kernel needs about one neig
     unsigned intra_any;                // bit p: some op changes piece p internally
     int n_tasks, n_items;
     int item_start[MAX_TASKS + 1];     // prefix sum of 64-fragment chunks per task: the mass work list, in a fixed order
+    int cw[MAX_TASKS];                 // chunks << 19 | walk; walk = fragments y a chunk of the task is paired with (np inside a piece, else nq)
+    long long w_total;                 // sum over tasks of chunks x walk: k_fin sizes its work units by it
     unsigned item_tc[ITEM_CAP];        // task | chunk << 16 of item w (valid when n_items <= ITEM_CAP)
     Task task[MAX_TASKS];
 };
@@ -1188,6 +1198,13 @@ __device__ int tables_block(const Geo* __restrict__ geo, const Link* __restrict_
     if (s_pp[n_tasks] > INLINE_PAIRS) { // k_fin will price this neighbour: it needs the tasks and the work list in memory
         for (int i = t; i < n_tasks; i += blockDim.x) T.task[i] = s_task[i];
         for (int i = t; i <= n_tasks; i += blockDim.x) T.item_start[i] = s_start[i];
+        for (int i = t; i < n_tasks; i += blockDim.x) T.cw[i] = (s_chunks[i] << 19) | (s_task[i].p == s_task[i].q ? s_task[i].np : s_task[i].nq);
+        if (t >= 128 && t < 192) {
+            long long w = 0;
+            for (int i = t - 128; i < n_tasks; i += 64) w += (long long)s_chunks[i] * (long long)(s_task[i].p == s_task[i].q ? s_task[i].np : s_task[i].nq);
+            w = wave_sum_ll(w);
+            if (t == 128) T.w_total = w;
+        }
         if (n_items <= ITEM_CAP)
             for (int i = t; i < n_tasks; i += blockDim.x)
                 for (int w = s_start[i]; w < s_start[i + 1]; w++) T.item_tc[w] = (unsigned)i | ((unsigned)(w - s_start[i]) << 16);
@@ -2019,7 +2036,7 @@ struct FinArgs { // first-needed pointers by value (see ScanArgs)
     const double* ln_tab;          // ln of the trans value by RF-count product (k_ln_tab), lut_n entries
     int lut_n;
     int skip;                      // diagnostics (GRAAL_FIN_SKIP): 1 = no mass units, 2 = no queued contacts
-    int seg;                       // fragments y per mass unit (0: 128, or 16 with sub-fragments)
+    int seg;                       // fragments y per mass unit (0: chosen per step)
 };
 
 __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinArgs fa, int K, int rank, int world,
@@ -2048,9 +2065,23 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
     // releases carries the neighbour's work list header with the sequence number: seq << 32 | priced << 31 | n_items ----
     __shared__ int s_ok;
     __shared__ unsigned s_hdr[MAXK];
+    __shared__ int s_nt[MAXK];
+    __shared__ long long s_wt[MAXK];
     if (threadIdx.x == 0) s_ok = 1;
-    if (threadIdx.x < MAXK) s_hdr[threadIdx.x] = 0x80000000u;
+    if (threadIdx.x < MAXK) { s_hdr[threadIdx.x] = 0x80000000u; s_nt[threadIdx.x] = 0; s_wt[threadIdx.x] = 0; }
     __syncthreads();
+    // k_tm's compact per-task list (chunks << 19 | walk), every thread a few (neighbour, task) entries -- requested together
+    // with the task counts (entries beyond them are leftovers of earlier steps and ignored): one memory round trip less
+    constexpr int NE = (MAXK * MAX_TASKS + 255) / 256;
+    int cw[NE];
+    auto load_cw = [&]() {
+#pragma unroll
+        for (int j = 0; j < NE; j++) {
+            const int e = (int)threadIdx.x + j * 256;
+            cw[j] = 0;
+            if (e < K * MAX_TASKS) { const int k = e / MAX_TASKS; cw[j] = tabs[k].cw[e - k * MAX_TASKS]; }
+        }
+    };
     if ((int)threadIdx.x < K) {
         bool ok = false;
         for (int spin = 0; spin < (1 << 22); spin++) {
@@ -2059,8 +2090,13 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
             __builtin_amdgcn_s_sleep(2);
         }
         if (!ok) { s_ok = 0; atomicOr((unsigned long long*)&counters[6], 1ull); }
+        else if (!(s_hdr[threadIdx.x] >> 31)) { // (bit 31: priced by k_tm already, nothing written for k_fin)
+            s_nt[threadIdx.x] = tabs[threadIdx.x].n_tasks;
+            s_wt[threadIdx.x] = tabs[threadIdx.x].w_total;
+        }
     }
     __syncthreads();
+    load_cw();
     STAMP(17, blockIdx.x == 0 && threadIdx.x == 0);
     const int* __restrict__ perm = A->perm;
     const int* __restrict__ lcontbp = A->soa.p[F_LCONTBP];
@@ -2076,46 +2112,32 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
         // list -- per neighbour the exclusive prefix of units per task -- in LDS; unit U of the flat list belongs to rank
         // U % world.  (Sums are integers: any partition of the pairs gives the same result.)
         __shared__ int s_ustart[MAXK][MAX_TASKS + 1]; // s_ustart[k][ti] = first unit of task ti among neighbour k's units
-        __shared__ int s_ubase[MAXK + 1], s_nt[MAXK];
+        __shared__ int s_ubase[MAXK + 1];
         // SEG: fragments y per unit.  At most 128 (16 with sub-fragments: up to 9 slot pairs per fragment pair), and small enough
         // for the step to have ~4 units per wave of the grid: a unit is one long dependent chain of float32 powf / expf, ~25 us
         // for 16 y with sub-fragments, and a step of the C2 stand-in has only ~1,500 such units for 2,048 waves -- its k_fin lasted
         // 140 us for 12 us worth of VALU work, the few waves that got two or three units carried it (tools/fin_seg_ab.sh:
         // SEG 16 -> 2 takes the scoring phase from 138 to 79 us there, from 178 to 126 us at the C3 shape).
-        __shared__ int s_walk[MAXK];
         const bool multi_sub = A->sub2bin_multi != nullptr;
-        for (int k = threadIdx.x >> 6; k < K; k += (int)(blockDim.x >> 6)) {
-            const NbTables& T = tabs[k];
-            const int nt = (s_hdr[k] >> 31) ? 0 : T.n_tasks;
-            int w = 0;
-            for (int ti = lane; ti < nt; ti += 64) {
-                const Task& tk = T.task[ti];
-                w += ((tk.np + 63) >> 6) * (tk.p == tk.q ? tk.np : tk.nq);
-            }
-            w = (int)wave_sum_ll((long long)w);
-            if (lane == 0) s_walk[k] = w;
-        }
-        __syncthreads();
         int SEG = fa.seg;
         if (SEG <= 0) {
             long long w_all = 0;
-            for (int k = 0; k < K; k++) w_all += s_walk[k];
+            for (int k = 0; k < K; k++) w_all += s_wt[k];
             const long long per_unit = w_all / (4ll * n_waves * world);
             SEG = multi_sub ? 2 : 16;
             while (SEG < (multi_sub ? 16 : 128) && SEG < per_unit) SEG <<= 1;
         }
-        for (int k = threadIdx.x >> 6; k < K; k += (int)(blockDim.x >> 6)) { // one wave per neighbour, side by side
-            const NbTables& T = tabs[k];
-            const int nt = (s_hdr[k] >> 31) ? 0 : T.n_tasks; // (bit 31: priced by k_tm already)
-            for (int ti = lane; ti < nt; ti += 64) {
-                const Task& tk = T.task[ti];
-                const int chunks = (tk.np + 63) >> 6, walk = tk.p == tk.q ? tk.np : tk.nq;
-                s_ustart[k][ti] = chunks * max(1, (walk + SEG - 1) / SEG);
+#pragma unroll
+        for (int j = 0; j < NE; j++) {
+            const int e = (int)threadIdx.x + j * 256;
+            if (e < K * MAX_TASKS) {
+                const int k = e / MAX_TASKS, ti = e - k * MAX_TASKS;
+                if (ti < s_nt[k]) s_ustart[k][ti] = (int)((unsigned)cw[j] >> 19) * max(1, ((cw[j] & 0x7ffff) + SEG - 1) / SEG);
             }
-            WAVE_LDS_SYNC();
-            wave_excl_scan(s_ustart[k], s_ustart[k], nt); // (in place: a lane reads its entry before it writes it)
-            if (lane == 0) s_nt[k] = nt;
         }
+        __syncthreads();
+        for (int k = threadIdx.x >> 6; k < K; k += (int)(blockDim.x >> 6)) // one wave per neighbour, side by side
+            wave_excl_scan(s_ustart[k], s_ustart[k], s_nt[k]); // (in place: a lane reads its entry before it writes it)
         __syncthreads();
         if (threadIdx.x == 0) {
             s_ubase[0] = 0;
@@ -2133,7 +2155,7 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
             for (int j = 1; j < K; j++) k += (U >= s_ubase[j]) ? 1 : 0;
             const int u = U - s_ubase[k];
             const NbTables& T = tabs[k];
-            int lo_t = 0, hi_t = T.n_tasks - 1; // task of unit u: last task with s_ustart <= u
+            int lo_t = 0, hi_t = s_nt[k] - 1; // task of unit u: last task with s_ustart <= u
             while (lo_t < hi_t) { const int mid = (lo_t + hi_t + 1) >> 1; if (s_ustart[k][mid] <= u) lo_t = mid; else hi_t = mid - 1; }
             const int ti = lo_t;
             const Task tk = T.task[ti];
@@ -2200,23 +2222,22 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
                 if (__ballot(!done) == 0) break;
                 WAVE_LDS_SYNC();
             }
-            const long long qv = wave_sum_ll(accq);
+            const long long qv = __shfl(wave_sum_ll(accq), 0, 64);
             if (__ballot(bad) != 0 && lane == 0) nf_flag_ops(counters + NF_OFF, k, tk.minus ^ tk.plus);
-            if (lane == 0 && qv != 0) {
-                // logL = contacts - mass: the NEW layout's mass counts negative, the OLD one positive
-                for (int op = 0; op < N_OPS; op++) {
-                    const long long sgn = (long long)((tk.minus >> op) & 1u) - (long long)((tk.plus >> op) & 1u);
-                    if (sgn != 0) atomicAdd((unsigned long long*)&s_accb[k * N_OPS + op], (unsigned long long)(sgn * qv));
-                }
+            if (lane < N_OPS && qv != 0) {
+                // logL = contacts - mass: the NEW layout's mass counts negative, the OLD one positive (lane = candidate)
+                const long long sgn = (long long)((tk.minus >> lane) & 1u) - (long long)((tk.plus >> lane) & 1u);
+                if (sgn != 0) atomicAdd((unsigned long long*)&s_accb[k * N_OPS + lane], (unsigned long long)(sgn * qv));
             }
         }
         if (lane == 0 && items) atomicAdd((unsigned long long*)&s_items, items); // (a statistic: one global atomic per block, below)
         STAMP(12, blockIdx.x == 0 && threadIdx.x == 0);
-        // ---- queued contacts, taken from the far end of the grid so that they do not queue up behind the mass items of
-        // the low-numbered blocks ----
+        // ---- queued contacts ----
         PriceArgs pa;
         pa.queue = queue; pa.tabs = tabs; pa.geo = geo; pa.stat = stat; pa.lcontbp = lcontbp; pa.out = s_accb; pa.nf = counters + NF_OFF; pa.nfpb = nfpb; pa.par = par;
-        if (!(fa.skip & 2)) price_contacts_bulk(pa, fa.ln_tab, fa.lut_n, nq_total, n_waves - 1 - wave, n_waves, lane);
+        // (batches of queued contacts continue the round robin where this rank's mass units ended)
+        const int mass_slots = (int)(((long long)total_units - rank + world - 1) / world % n_waves);
+        if (!(fa.skip & 2)) price_contacts_bulk(pa, fa.ln_tab, fa.lut_n, nq_total, (wave - mass_slots + n_waves) % n_waves, n_waves, lane);
         STAMP(13, blockIdx.x == 0 && threadIdx.x == 0);
         STAMP_FBLK(2, threadIdx.x == 0);
         __syncthreads();
@@ -2232,8 +2253,9 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
     __shared__ int s_last;
     __syncthreads();
     STAMP(18, blockIdx.x == gridDim.x - 1 && threadIdx.x == 0);
+    ATOMICS_DONE();
+    __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();
         const unsigned long long ticket = atomicAdd(&counters[5], 1ull);
         s_last = (ticket == (unsigned long long)gridDim.x - 1ull);
     }
@@ -2475,9 +2497,9 @@ __global__ __launch_bounds__(256) void k_strict(FinArgs fa, StrictArgs sa, int f
         if (threadIdx.x == 255 && blockIdx.x == 0 && rank == 0) atomicAdd(&counters[1], (unsigned long long)total_units);
     }
     __shared__ int s_last;
+    ATOMICS_DONE();
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();
         const unsigned long long ticket = atomicAdd(&counters[5], 1ull);
         s_last = (ticket == (unsigned long long)gridDim.x - 1ull);
     }
@@ -2755,7 +2777,7 @@ struct Ctx {
     int* step_hdr = nullptr;      // [MAXK] mass work items per neighbour of the current step, [MAXK..] priced by k_tm
     long long* tm_done = nullptr; // [MAXK] sequence number of the step whose tables are complete
     long long* d_acc = nullptr;   // K*13 running sums (self-cleaning: the step's last block zeroes them after reading)
-    unsigned long long* d_sync = nullptr; // [0] k_tm ticket
+    unsigned long long* d_sync = nullptr; // [0] k_tm ticket [8] finished blocks of k_scan
     unsigned* d_flags = nullptr;          // k_scan's per-block completion flags
     unsigned long long scan_done_total = 0; // blocks of all non-dry scans launched so far (completion counter mode)
     int mode = 0;                 // GRAAL_MODE_* flags (graal_set_mode)
@@ -2964,6 +2986,9 @@ int launch_scan(Ctx* h, int fA, const Neigh& nb, int K, int max_id, int dry, hip
     return GRAAL_OK;
 }
 
+// how long a kernel waits for the scan's completion: a generous multiple of the time the streaming pass needs at 2 TB/s, plus launch slack
+int fin_wait_ticks(const Ctx* h) { return (int)std::min<long long>(100ll * 50 + (long long)(4.0 * 4.0 * (double)h->nnz / 2.0e12 * 1.0e8), 1ll << 30); }
+
 constexpr int FIN_BLOCKS_NO_WAIT = 3 * 256;   // largest k_fin grid that cannot keep k_tm off the chip (see launch_fin)
 
 int fin_blocks_cfg(const Ctx* h)
@@ -3069,8 +3094,8 @@ int graal_create(int device, graal_ctx** out)
     CK(hipMemset(h->d_acc, 0, MAXK * N_OPS * sizeof(long long)));
     CK(hipMalloc(&h->tm_done, MAXK * sizeof(long long)));
     CK(hipMemset(h->tm_done, 0, MAXK * sizeof(long long)));
-    CK(hipMalloc(&h->d_sync, 16 * sizeof(unsigned long long)));
-    CK(hipMemset(h->d_sync, 0, 16 * sizeof(unsigned long long)));
+    CK(hipMalloc(&h->d_sync, 32 * sizeof(unsigned long long)));
+    CK(hipMemset(h->d_sync, 0, 32 * sizeof(unsigned long long)));
     CK(hipMalloc(&h->d_flags, (size_t)MAX_SCAN_BLOCKS * FLAG_STRIDE * sizeof(unsigned)));
     CK(hipMemset(h->d_flags, 0, (size_t)MAX_SCAN_BLOCKS * FLAG_STRIDE * sizeof(unsigned)));
     if (getenv("GRAAL_EVENT_EVERY")) h->event_every = std::max(1, atoi(getenv("GRAAL_EVENT_EVERY")));
@@ -3610,8 +3635,7 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     // right behind the scan instead of after k_tm's verdict has made the round trip through the host, ~10 us per step)
     const bool late_stage = h->max_lcont > 128 && (long long)h->n_contigs * 64 < (long long)h->n;
     ta.host_res = (h->publish && (world == 1 || h->x_host) && !no_finisher && h->finisher_ok && !h->has_rep && !late_stage && !strict) ? h->res_dev : nullptr;
-    // a generous multiple of the time the streaming pass needs at 2 TB/s, plus launch slack
-    ta.wait_ticks = (int)std::min<long long>(100ll * 50 + (long long)(4.0 * 4.0 * (double)h->nnz / 2.0e12 * 1.0e8), 1ll << 30);
+    ta.wait_ticks = fin_wait_ticks(h);
     ta.counters = (unsigned long long*)(h->d_scalars + 10); ta.queue = h->queue; ta.stat = h->stat_frag;
     ta.lcontbp = h->soa[h->cur].p[F_LCONTBP]; ta.acc = h->d_acc; ta.nfpb = h->nfpb; ta.par = h->par;
     k_tm<<<K, 256, 0, h->aux>>>(A, ta, fA, nb, K, max_id, rank, world, h->seq);

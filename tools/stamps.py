@@ -46,7 +46,7 @@ for f in rng.randint(0, NB, size=(40 if LATE else 300)):
     bs = np.zeros(4096 * 4, dtype=np.uint64)
     assert L.graal_debug_block_stamps(smp.engine._h, bs.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))) == 0
     nblk = int(os.environ.get("GRAAL_SCAN_BLOCKS", 512))
-    fb = bs.reshape(4096, 4)[2048:2048 + (2048 if LATE else 512)].astype(np.float64)
+    fb = bs.reshape(4096, 4)[2048:2048 + (2048 if LATE else 768)].astype(np.float64)
     if (C2 or LATE) and n == (30 if LATE else 250) and fb[:, 0].max() > 0:   # k_fin's blocks: start, unit list built, wave 0 done, whole block done
         fb = (fb - t0) * 0.01
         for j, name in enumerate(("start", "unit list built", "wave 0: units + contacts done", "block done")):
