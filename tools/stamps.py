@@ -11,9 +11,10 @@ from graal_amd import build
 build.HIP_LIB = so
 from graal_amd import lib, synth
 import bench
-C2 = os.environ.get("STAMPS_SHAPE") == "c2"   # the C2 stand-in with its 7 contigs (k_fin finishes every step) instead of C5 exploded
+C3 = os.environ.get("STAMPS_SHAPE") == "c3"
+C2 = os.environ.get("STAMPS_SHAPE") == "c2" or C3   # the C2 / C3 stand-ins with their 7 contigs (k_fin finishes every step) instead of C5 exploded
 if C2:
-    P = synth.make_problem(n_bins=1086, nnz=120000, n_sub=3, seed=2014, contig_weights=(6.8, 6.2, 5.3, 4.6, 4.0, 3.4, 2.7),
+    P = synth.make_problem(n_bins=3500 if C3 else 1086, nnz=600000 if C3 else 120000, n_sub=3, seed=2014, contig_weights=(6.8, 6.2, 5.3, 4.6, 4.0, 3.4, 2.7),
                            mean_len_bp=660.0 * 27 / 3, accu=9)
 else:
     P = synth.make_problem(n_bins=50000, nnz=20_000_000, n_sub=1, seed=20141217)
