@@ -681,7 +681,8 @@ struct SubRec {
 
 __global__ __launch_bounds__(256) void k_subrec(int n, const Geo* __restrict__ geo, const Stat* __restrict__ stat,
                                                  const int* __restrict__ sub_ids /* nullptr: id = f */, SubRec* __restrict__ rec,
-                                                 SubRec8* __restrict__ rec8 /* nullptr: RF counts are not uniform */)
+                                                 SubRec8* __restrict__ rec8 /* nullptr: RF counts are not uniform */,
+                                                 unsigned short* __restrict__ lab16 /* with rec8: low 16 bits of the label */)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n) return;
@@ -696,7 +697,10 @@ __global__ __launch_bounds__(256) void k_subrec(int n, const Geo* __restrict__ g
         r.accu = stat_accu(st, slot) | ((fwd ? stat_accu(st, slot) : stat_accu(st, st.n - 1)) << 16);   // (RF counts are <= 30000)
         r.bin = f | (((g.flags >> 1) & 1) << 31);
         rec[sel3(ids.x, ids.y, ids.z, slot)] = r;
-        if (rec8) { SubRec8 r8; r8.label = g.id_c | (((g.flags >> 1) & 1) << 31); r8.centre = r.centre; rec8[sel3(ids.x, ids.y, ids.z, slot)] = r8; }
+        if (rec8) {
+            SubRec8 r8; r8.label = g.id_c | (((g.flags >> 1) & 1) << 31); r8.centre = r.centre; rec8[sel3(ids.x, ids.y, ids.z, slot)] = r8;
+            lab16[sel3(ids.x, ids.y, ids.z, slot)] = (unsigned short)(g.id_c & 0xffff);
+        }
     }
 }
 
@@ -771,6 +775,78 @@ __global__ __launch_bounds__(256) void k_full_nnz_u(const int4* __restrict__ row
     __syncthreads();
     if (threadIdx.x == 0) {
         const long long v = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        if (v != 0) atomicAdd((unsigned long long*)out, (unsigned long long)v);
+    }
+}
+
+// The same again with the labels in LDS.  What bounds k_full_nnz_u is the column-side gather: 20 M random 8-byte reads of an
+// L2-resident table, each one a 128-byte line fill of the CU's L1 (~75 % of the L1 fill bandwidth at 85 us).  But most
+// contacts join two DIFFERENT contigs -- all but a few while contigs are short -- and for those the record is only needed to
+// find that out.  Every block therefore keeps the low 16 bits of every sub-fragment's label in LDS (2 bytes x n_sub: 100 KB for
+// C5, one 1024-thread block per CU): different 16-bit labels = different contigs = the constant trans logarithm, no gather;
+// equal ones (the same contig, or a collision above 65,536 contigs) take the path of k_full_nnz_u.  Same expressions on the same
+// values, integer sums: bit-identical.
+template <int FULL_G>
+__global__ __launch_bounds__(1024) void k_full_nnz_l(const int4* __restrict__ row4, const int4* __restrict__ col4,
+                                                      const int4* __restrict__ cnt4, long long nnz, const unsigned short* __restrict__ lab16,
+                                                      int n_sub, const SubRec8* __restrict__ rec, const SubRec* __restrict__ rec_full,
+                                                      const int* __restrict__ lcontbp, float nfpb, Par par, int accu,
+                                                      long long* __restrict__ out, long long* __restrict__ bad_flag)
+{
+    extern __shared__ unsigned s_lab[];   // two labels per word
+    {
+        const int nq = (n_sub + 7) >> 3;  // (the device array is padded to a multiple of 16 bytes)
+        const uint4* src = reinterpret_cast<const uint4*>(lab16);
+        for (int i = threadIdx.x; i < nq; i += blockDim.x) reinterpret_cast<uint4*>(s_lab)[i] = src[i];
+    }
+    __syncthreads();
+    auto lab = [&](int id) -> unsigned { return (s_lab[id >> 1] >> ((id & 1) << 4)) & 0xffffu; };
+    const float norm = (float)(accu * accu) / nfpb;
+    const double ln_trans = log((double)(par.v_inter * norm));
+    long long acc = 0;
+    bool bad = false;
+    const int n4 = (int)(nnz >> 2);
+    const int stride = (int)(gridDim.x * blockDim.x);
+    for (int g0 = (int)(blockIdx.x * blockDim.x + threadIdx.x); g0 <= n4; g0 += FULL_G * stride) {
+        int4 r[FULL_G], c[FULL_G], w[FULL_G];
+#pragma unroll
+        for (int i = 0; i < FULL_G; i++) {
+            const int g = g0 + i * stride;
+            const int gc = g <= n4 ? g : n4;
+            r[i] = ld_stream(row4 + gc); c[i] = ld_stream(col4 + gc); w[i] = ld_stream(cnt4 + gc);
+        }
+#pragma unroll
+        for (int i = 0; i < FULL_G; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const long long idx = ((long long)(g0 + i * stride) << 2) + j;
+                if (!((g0 + i * stride) <= n4 && idx < nnz)) continue;
+                const int ia = w4(r[i], j), ib = w4(c[i], j);
+                double ln_ex = ln_trans;
+                if (lab(ia) == lab(ib)) {
+                    const SubRec8 A = rec[ia], B = rec[ib];
+                    if (((A.label ^ B.label) & 0x7fffffff) == 0) {
+                        const float sd = fabsf(B.centre - A.centre);
+                        float ex;
+                        if (A.label < 0) {   // circular contig (rare): its length sits in the full record's fragment
+                            const int bin_a = rec_full[ia].bin & 0x7fffffff;
+                            ex = rippe_circ(sd, (float)lcontbp[bin_a] / 1000.0f, par) * norm;
+                        } else ex = rippe(sd, par) * norm;
+                        ln_ex = log((double)ex);
+                    }
+                }
+                const long long q = to_q((double)__int_as_float(w4(w[i], j)) * ln_ex);
+                if (q == Q_BAD) bad = true; else acc += q;
+            }
+    }
+    if (bad) atomicOr((unsigned long long*)bad_flag, 1ull);
+    __shared__ long long s_part[16];
+    acc = wave_sum_ll(acc);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long v = 0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); i++) v += s_part[i];
         if (v != 0) atomicAdd((unsigned long long*)out, (unsigned long long)v);
     }
 }
@@ -2755,6 +2831,7 @@ struct Ctx {
     Stat* stat = nullptr;
     SubRec* sub_rec = nullptr;    // [n_sub_total] per sub-fragment record of the full evaluation (k_subrec)
     SubRec8* sub_rec8 = nullptr;  // the compact form, used when every sub-fragment has the same RF count (uniform_accu > 0)
+    unsigned short* sub_lab16 = nullptr; // low 16 bits of every sub-fragment's label (k_full_nnz_l keeps them in LDS)
     int uniform_accu = 0;
     int* sub2bin = nullptr;
     int *row = nullptr, *col = nullptr, *cnt = nullptr;
@@ -3129,7 +3206,7 @@ void graal_destroy(graal_ctx* h)
         (void)hipSetDevice(h->device);
         (void)hipStreamSynchronize(h->stream);
         if (h->aux) (void)hipStreamSynchronize(h->aux);
-        void* ptrs[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->stat, h->sub_rec, h->sub_rec8, h->d_ubins, h->d_ln_tab, h->sub2bin, h->row, h->col, h->cnt, h->queue, h->d_sub_ids, h->d_acc, h->tm_done, h->d_sync, h->d_flags, h->stat_frag, h->d_dup_bins, h->d_dup_index,
+        void* ptrs[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->stat, h->sub_rec, h->sub_rec8, h->sub_lab16, h->d_ubins, h->d_ln_tab, h->sub2bin, h->row, h->col, h->cnt, h->queue, h->d_sub_ids, h->d_acc, h->tm_done, h->d_sync, h->d_flags, h->stat_frag, h->d_dup_bins, h->d_dup_index,
                         h->d_dispatcher, h->d_collector, h->d_sub_ids_all, h->d_rep_obs,
                         h->keys, h->keys_sorted, h->o2n, h->len_of2[0], h->len_of2[1], h->contig_off2[0], h->contig_off2[1], h->perm, h->cbase, h->link, h->mates, h->cub_tmp, h->tabs, h->step_hdr, h->d_args, h->d_chg,
                         h->d_scalars, h->d_qout, h->d_dref, h->d_dist};
@@ -3205,7 +3282,7 @@ int graal_upload_subfrags(graal_ctx* h, const int32_t* sub_id, const float* sub_
     h->has_rep = false; h->n_dup = 0; h->h_dup_index.assign((size_t)n_bins, -1); // (graal_upload_repeats comes after)
     // single_sub additionally needs sub id == bin id so that the scan can skip the sub2bin gather
     for (int b = 0; single && b < n_bins; b++) single = (sub_id[4 * b] == b);
-    if (h->stat) { (void)hipFree(h->stat); (void)hipFree(h->sub2bin); (void)hipFree(h->d_sub_ids); (void)hipFree(h->sub_rec); (void)hipFree(h->sub_rec8); h->d_sub_ids = nullptr; h->sub_rec = nullptr; h->sub_rec8 = nullptr; }
+    if (h->stat) { (void)hipFree(h->stat); (void)hipFree(h->sub2bin); (void)hipFree(h->d_sub_ids); (void)hipFree(h->sub_rec); (void)hipFree(h->sub_rec8); (void)hipFree(h->sub_lab16); h->d_sub_ids = nullptr; h->sub_rec = nullptr; h->sub_rec8 = nullptr; h->sub_lab16 = nullptr; }
     if (!single) {
         CK(hipMalloc(&h->d_sub_ids, sizeof(int) * 4 * (size_t)n_bins));
         CK(hipMemcpy(h->d_sub_ids, sub_id, sizeof(int) * 4 * (size_t)n_bins, hipMemcpyHostToDevice));
@@ -3216,6 +3293,8 @@ int graal_upload_subfrags(graal_ctx* h, const int32_t* sub_id, const float* sub_
     CK(hipMemset(h->sub_rec, 0, sizeof(SubRec) * (size_t)n_sub_total));
     CK(hipMalloc(&h->sub_rec8, sizeof(SubRec8) * (size_t)n_sub_total));
     CK(hipMemset(h->sub_rec8, 0, sizeof(SubRec8) * (size_t)n_sub_total));
+    CK(hipMalloc(&h->sub_lab16, 2 * (size_t)(((size_t)n_sub_total + 7) & ~(size_t)7)));
+    CK(hipMemset(h->sub_lab16, 0, 2 * (size_t)(((size_t)n_sub_total + 7) & ~(size_t)7)));
     {
         h->uniform_accu = sub_accu[0];
         for (int b = 0; b < n_bins && h->uniform_accu; b++)
@@ -3552,7 +3631,7 @@ int graal_eval_full_q(graal_ctx* h, int64_t q_out[2])
     if (h->nnz) {
         static const bool no_compact = getenv("GRAAL_FULL_NO_COMPACT") != nullptr;
         const bool compact = h->uniform_accu > 0 && !quirk && !no_compact;
-        k_subrec<<<blocks_for(h->n, 256), 256, 0, h->stream>>>(h->n, h->geo, h->stat_frag, h->d_sub_ids, h->sub_rec, compact ? h->sub_rec8 : nullptr);
+        k_subrec<<<blocks_for(h->n, 256), 256, 0, h->stream>>>(h->n, h->geo, h->stat_frag, h->d_sub_ids, h->sub_rec, compact ? h->sub_rec8 : nullptr, h->sub_lab16);
         // 8 blocks of 256 threads per CU; every lane takes FULL_G groups of 4 contacts per iteration
         static const int full_g = getenv("GRAAL_FULL_G") ? atoi(getenv("GRAAL_FULL_G")) : 2;
         static const int full_bpc = getenv("GRAAL_FULL_BPC") ? atoi(getenv("GRAAL_FULL_BPC")) : 8;   // blocks per CU
@@ -3561,7 +3640,25 @@ int graal_eval_full_q(graal_ctx* h, int64_t q_out[2])
         const int nb = (int)std::max<long long>(1, std::min<long long>((groups + 256 * FG - 1) / (256 * FG), 256 * full_bpc));
 #define FULL_NNZ_ARGS reinterpret_cast<const int4*>(h->row), reinterpret_cast<const int4*>(h->col), reinterpret_cast<const int4*>(h->cnt), \
                       h->nnz, h->sub_rec, s.p[F_LCONTBP], h->nfpb, h->par, h->ln_lut_n, quirk ? 1 : 0, h->d_scalars + 8, h->d_scalars + FULL_BAD
-        if (compact) {
+        // labels in LDS (k_full_nnz_l): uniform RF counts, a list worth it, and 2 bytes per sub-fragment within 150 KB of LDS
+        static const bool no_lds = getenv("GRAAL_FULL_NO_LDS") != nullptr;
+        const size_t lab_bytes = 2 * (((size_t)h->n_sub_total + 7) & ~(size_t)7);
+        if (compact && !no_lds && h->nnz >= 2000000 && lab_bytes <= 150 * 1024) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_full_nnz_l<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+                CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_full_nnz_l<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+                attr_set = true;
+            }
+            const int nbl = (int)std::max<long long>(1, std::min<long long>((groups + 1024 * FG - 1) / (1024 * FG), 256));
+#define FULL_NNZ_L_ARGS reinterpret_cast<const int4*>(h->row), reinterpret_cast<const int4*>(h->col), reinterpret_cast<const int4*>(h->cnt), \
+                        h->nnz, h->sub_lab16, h->n_sub_total, h->sub_rec8, h->sub_rec, s.p[F_LCONTBP], h->nfpb, h->par, h->uniform_accu,        \
+                        h->d_scalars + 8, h->d_scalars + FULL_BAD
+            if (FG == 2) k_full_nnz_l<2><<<nbl, 1024, lab_bytes, h->stream>>>(FULL_NNZ_L_ARGS);
+            else k_full_nnz_l<4><<<nbl, 1024, lab_bytes, h->stream>>>(FULL_NNZ_L_ARGS);
+#undef FULL_NNZ_L_ARGS
+        }
+        else if (compact) {
 #define FULL_NNZ_U_ARGS reinterpret_cast<const int4*>(h->row), reinterpret_cast<const int4*>(h->col), reinterpret_cast<const int4*>(h->cnt), \
                         h->nnz, h->sub_rec8, h->sub_rec, s.p[F_LCONTBP], h->nfpb, h->par, h->uniform_accu, h->d_scalars + 8, h->d_scalars + FULL_BAD
             if (FG == 1) k_full_nnz_u<1><<<nb, 256, 0, h->stream>>>(FULL_NNZ_U_ARGS);

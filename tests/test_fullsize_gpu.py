@@ -6,7 +6,8 @@ need the dense oracle (which cannot run at this size).
 * determinism: the same seed gives the same accepted-move trace and the same final layout twice;
 * structural invariants of the layout after 1,500 real MCMC steps (cuda_lib_gl.py:1530-1537);
 * 1,500 incremental relabels (k_incr: counting, link-walked mates rows) == one full relabel (sort) of the same layout in a
-  fresh engine: labels, statistics, candidate deltas and the full likelihood bit for bit."""
+  fresh engine: labels, statistics, candidate deltas and the full likelihood bit for bit;
+* the full evaluation with the labels in LDS (k_full_nnz_l) == the one with 8-byte record gathers (k_full_nnz_u), bit for bit."""
 import numpy as np
 import pytest
 
@@ -208,3 +209,18 @@ def test_c5_original_layout_two_ranks_equal_one_rank(c5_original):
         for a, b in zip(out, want):
             assert np.array_equal(a, b), rank          # sharded contacts + sharded mass units: the same int64 sums
         assert full == want_full
+
+
+@pytest.mark.timeout(1200)
+def test_full_evaluation_with_labels_in_lds_is_bit_identical():
+    """k_full_nnz_l (lists of >= 2 M contacts with uniform RF counts: 16-bit labels in LDS, record gathers only for contacts
+    inside one contig) against k_full_nnz_u (GRAAL_FULL_NO_LDS=1; the switch is read once per process, hence child processes):
+    both int64 sums of graal_eval_full_q, on the exploded layout after 600 MCMC steps (nearly every contact joins two
+    contigs) and on the 7 original contigs (nearly every contact inside one).  tools/full_l_check.py asserts the equality."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "full_l_check.py")], cwd=root, capture_output=True, text=True, timeout=1100)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    assert "bit-identical sums" in out.stdout
