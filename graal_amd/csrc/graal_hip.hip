@@ -2870,6 +2870,8 @@ struct Ctx {
     DevArgs* d_args = nullptr;    // [2]: one argument block per layout buffer
     long long* h_res = nullptr;   // pinned host: [0] sequence number of the published step, [1..] K*13 sums
     long long* h_stats = nullptr; // pinned host: [0] sequence number, [1..16] the statistics words of k_stats_fin
+    long long* h_full = nullptr;  // pinned host: [0] sequence number, [1..4] the sums / flags of the last full evaluation (k_full_pub)
+    long long full_seq = 0;
     // where the step's last block publishes: h_res, or -- with an exchange attached -- this rank's slot of the step's
     // parity in a host segment shared by the ranks of the node (host and device views of the same memory)
     long long* res_host = nullptr;
@@ -3129,6 +3131,19 @@ static int fetch_stats(Ctx* h, long long res[16], bool reset_stale)
     return wait_stats(h, res);
 }
 
+// end of a full evaluation: the two sums, the not-finite flag and the repeats' sum go to pinned host memory followed by the
+// evaluation's sequence number (the host spins on it: no device->host copies, no stream synchronise), and the accumulators
+// are zero again for the next one (they are zero at rest: no memsets in front of an evaluation either)
+__global__ void k_full_pub(long long* __restrict__ sc, volatile long long* host, long long seq)
+{
+    const int t = threadIdx.x;
+    const int src = t == 0 ? 8 : (t == 1 ? 9 : (t == 2 ? FULL_BAD : 17));
+    if (t < 4) { host[1 + t] = sc[src]; sc[src] = 0; }
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) { host[0] = seq; __threadfence_system(); }
+}
+
 struct graal_ctx : Ctx {};
 
 extern "C" {
@@ -3190,6 +3205,8 @@ int graal_create(int device, graal_ctx** out)
     memset(h->h_dist, 0, 2 * sizeof(long long));
     CK(hipMalloc(&h->d_dist, 2 * sizeof(unsigned long long)));
     CK(hipMemset(h->d_dist, 0, 2 * sizeof(unsigned long long)));
+    CK(hipHostMalloc((void**)&h->h_full, 8 * sizeof(long long), hipHostMallocDefault));
+    memset(h->h_full, 0, 8 * sizeof(long long));
     CK(hipHostMalloc((void**)&h->h_stats, 17 * sizeof(long long), hipHostMallocDefault));
     memset(h->h_stats, 0, 17 * sizeof(long long));
     {
@@ -3214,6 +3231,7 @@ void graal_destroy(graal_ctx* h)
         if (h->x_host) (void)hipHostUnregister(h->x_host);
         if (h->h_res) (void)hipHostFree(h->h_res);
         if (h->h_stats) (void)hipHostFree(h->h_stats);
+        if (h->h_full) (void)hipHostFree(h->h_full);
         if (h->h_dist) (void)hipHostFree(h->h_dist);
         for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
         for (auto& ev : h->ring) if (ev) (void)hipEventDestroy(ev);
@@ -3622,9 +3640,6 @@ int graal_eval_full_q(graal_ctx* h, int64_t q_out[2])
     if (!(h->have_frags && h->have_contacts && h->have_par)) return fail(h, GRAAL_E_STATE, "upload fragments, contacts and parameters first");
     if (!h->order_valid) return fail(h, GRAAL_E_STATE, "call graal_relabel_contigs after changing the layout");
     CK(hipSetDevice(h->device));
-    CK(hipMemsetAsync(h->d_scalars + 8, 0, 2 * sizeof(long long), h->stream));
-    CK(hipMemsetAsync(h->d_scalars + FULL_BAD, 0, sizeof(long long), h->stream));
-    if (h->has_rep) CK(hipMemsetAsync(h->d_scalars + 17, 0, sizeof(long long), h->stream));
     SoaPtr s = h->soa[h->cur];
     const bool quirk = (h->mode & GRAAL_MODE_REF_TRANS_ACCU) != 0;
     if (quirk && h->has_rep) return fail(h, GRAAL_E_UNSUPPORTED, "GRAAL_MODE_REF_TRANS_ACCU with repeated bins is not implemented");
@@ -3681,13 +3696,25 @@ int graal_eval_full_q(graal_ctx* h, int64_t q_out[2])
         const RepArgs R = rep_args(h);
         k_rep_full<<<blocks_for((long long)h->n_dup * h->n_bins, 256), 256, 0, h->stream>>>(R, h->d_scalars + 17, h->d_scalars + FULL_BAD);
     }
+    h->full_seq += 1;
+    k_full_pub<<<1, 64, 0, h->stream>>>(h->d_scalars, h->h_full, h->full_seq);
     CK(hipGetLastError());
-    long long res[2];
-    long long rep_q = 0, bad = 0;
-    if (h->has_rep) CK(hipMemcpyAsync(&rep_q, h->d_scalars + 17, sizeof rep_q, hipMemcpyDeviceToHost, h->stream));
-    CK(hipMemcpyAsync(&bad, h->d_scalars + FULL_BAD, sizeof bad, hipMemcpyDeviceToHost, h->stream));
-    CK(hipMemcpyAsync(res, h->d_scalars + 8, sizeof res, hipMemcpyDeviceToHost, h->stream));
-    CK(hipStreamSynchronize(h->stream));
+    {
+        volatile long long* p = h->h_full;
+        bool seen = false;
+        for (long long spin = 0; spin < 400000000ll; spin++) {
+            if (p[0] == h->full_seq) { seen = true; break; }
+            if ((spin & 0xfffff) == 0xfffff && hipStreamQuery(h->stream) != hipErrorNotReady) { seen = (p[0] == h->full_seq); break; }
+            __builtin_ia32_pause();
+        }
+        if (!seen) {
+            CK(hipStreamSynchronize(h->stream));
+            if (p[0] != h->full_seq) return fail(h, GRAAL_E_HIP, "the full evaluation did not publish its sums");
+        }
+        __sync_synchronize();
+    }
+    const long long res[2] = {h->h_full[1], h->h_full[2]};
+    const long long bad = h->h_full[3], rep_q = h->has_rep ? h->h_full[4] : 0;
     q_out[0] = res[0] - (int64_t)h->c_lf_q;
     q_out[1] = -(res[1] + (int64_t)llrint(h->t_all * Q_SCALE)) + rep_q;
     if (bad) { q_out[0] = Q_BAD; q_out[1] = 0; } // a term was not finite / out of range: INT64_MIN exactly, the host reports NaN
