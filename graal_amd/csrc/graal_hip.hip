@@ -40,7 +40,8 @@ constexpr int NP = MAX_PIECES + 1;       // piece ids 0..6
 constexpr int CODE_BITS = 3;             // a fragment's piece id (0..6) per neighbour, packed into one word
 constexpr unsigned CODE_LSB = 0x09249249u; // bit 0 of each of the 10 fields
 static_assert(MAXK * CODE_BITS <= 32, "piece codes of all neighbours must fit one word");
-constexpr int MAX_TASKS = 21 * (N_OPS + 1); // per neighbour: 21 piece pairs x (old + 13 candidate layouts), before dedupe
+constexpr int N_PAIRS = 21;                 // unordered pairs (p <= q) of the 6 pieces
+constexpr int MAX_TASKS = N_PAIRS * (N_OPS + 1); // per neighbour: 21 piece pairs x (old + 13 candidate layouts), before dedupe
 constexpr int LABEL_BITS = 20;           // relabel sort key = l_cont << 20 | label
 
 struct Par { float kuhn, lm, c1, slope, d, d_max, fact, v_inter; };
@@ -1039,6 +1040,14 @@ struct NbTables {        // everything the finishing kernel needs about one neig
     int item_start[MAX_TASKS + 1];     // prefix sum of 64-fragment chunks per task: the mass work list, in a fixed order
     int cw[MAX_TASKS];                 // chunks << 19 | walk; walk = fragments y a chunk of the task is paired with (np inside a piece, else nq)
     long long w_total;                 // sum over tasks of chunks x walk: k_fin sizes its work units by it
+    // per piece pair (pair_index): how a CONTACT between the two pieces is priced -- the tasks (distinct cis relations: the old
+    // one and the deduplicated new ones) it has to be evaluated under, and the candidates under which the relation changes and
+    // is trans afterwards (tplus) / was trans before (tminus)
+    unsigned short tplus[N_PAIRS], tminus[N_PAIRS];
+    unsigned short pair_old[N_PAIRS];               // the task of the pair's OLD relation (0xffff: it is trans)
+    unsigned short pair_n[N_PAIRS];                 // the tasks of its distinct NEW cis relations
+    unsigned short pair_task[N_PAIRS][N_OPS];
+    unsigned short pair_owner[N_PAIRS][N_OPS];      // per candidate: the task of the pair's new cis relation under it (0xffff: trans, or unchanged)
     unsigned item_tc[ITEM_CAP];        // task | chunk << 16 of item w (valid when n_items <= ITEM_CAP)
     Task task[MAX_TASKS];
 };
@@ -1090,6 +1099,12 @@ __device__ __forceinline__ void pair_of_index(int idx, int& p, int& q)
     for (p = 1; p <= MAX_PIECES; p++) { const int row = MAX_PIECES - p + 1; if (idx < row) { q = p + idx; break; } idx -= row; }
 }
 
+__device__ __forceinline__ int pair_index(int p, int q) // inverse of pair_of_index, any order of 1 <= p, q <= MAX_PIECES
+{
+    const int a = p < q ? p : q, b = p < q ? q : p;
+    return (a - 1) * (2 * MAX_PIECES + 2 - a) / 2 + (b - a);
+}
+
 // short contigs (<= N_MATES fragments each): the geometry and statistics of every fragment of contig(fA) and contig(fB)
 // are fetched into LDS while the tables are being built, so the block's own mass pricing needs no global loads
 struct SmallCtx {
@@ -1115,8 +1130,11 @@ __device__ int tables_block(const Geo* __restrict__ geo, const Link* __restrict_
     __shared__ unsigned long long changed[N_OPS];
     __shared__ unsigned intra_any;
     // dedupe table: entries 0..20 = old relation of (p<=q); then 13*21 new relations
-    constexpr int NPAIR = 21, NENT = NPAIR * (N_OPS + 1);
+    constexpr int NPAIR = N_PAIRS, NENT = NPAIR * (N_OPS + 1);
     __shared__ int e_valid[NENT], e_owner[NENT], e_slot[NENT], e_flag[NENT];
+    __shared__ unsigned t_plus[NPAIR], t_minus[NPAIR];
+    __shared__ int p_cnt[NPAIR], p_old[NPAIR];
+    __shared__ unsigned short p_list[NPAIR][N_OPS];
     __shared__ unsigned e_plus[NENT], e_minus[NENT];
     __shared__ int s_lo[NP], s_hi[NP], s_contig[NP], s_cbase[NP], s_chunks[NENT], s_start[NENT + 1], s_pairs[NENT];
     const int t = threadIdx.x;
@@ -1155,6 +1173,7 @@ __device__ int tables_block(const Geo* __restrict__ geo, const Link* __restrict_
     STAMP(24, k == 0 && t == 0); // A0 / B0 loaded
     if (t < N_OPS) changed[t] = 0;
     for (int e = t; e < NENT; e += blockDim.x) { e_valid[e] = 0; e_plus[e] = 0; e_minus[e] = 0; e_owner[e] = e; e_slot[e] = -1; }
+    if (t < NPAIR) { t_plus[t] = 0; t_minus[t] = 0; p_cnt[t] = 0; p_old[t] = 0xffff; }
     __syncthreads();
     if (t < NP) {
         if (rep[t] >= 0) { rep_old[t] = rec_gl(geo[rep[t]], link[rep[t]], rep[t]); xf_old[t] = xf_identity(rep_old[t]); }
@@ -1196,7 +1215,9 @@ __device__ int tables_block(const Geo* __restrict__ geo, const Link* __restrict_
         const int pair = e % NPAIR;
         // old relation entry (shared by all ops) and new relation entry
         if (xf_old[p].label == xf_old[q].label) { e_valid[pair] = 1; atomicOr(&e_minus[pair], 1u << op); }
+        else atomicOr(&t_minus[pair], 1u << op);
         if (xf[op][p].label == xf[op][q].label) { e_valid[NPAIR + e] = 1; atomicOr(&e_plus[NPAIR + e], 1u << op); }
+        else atomicOr(&t_plus[pair], 1u << op);
     }
     __syncthreads();
     STAMP(27, k == 0 && t == 0); // relations
@@ -1257,6 +1278,7 @@ __device__ int tables_block(const Geo* __restrict__ geo, const Link* __restrict_
         tk.base_p = s_cbase[tk.p] + s_lo[tk.p];
         tk.base_q = s_cbase[tk.q] + s_lo[tk.q];
         const int slot = e_slot[e];
+        if (e < NPAIR) p_old[pair] = slot; else p_list[pair][atomicAdd(&p_cnt[pair], 1)] = (unsigned short)slot;
         s_task[slot] = tk;
         s_chunks[slot] = (tk.np + 63) / 64;
         const long long pr = (long long)tk.np * (long long)(tk.p == tk.q ? tk.np : tk.nq);
@@ -1271,8 +1293,18 @@ __device__ int tables_block(const Geo* __restrict__ geo, const Link* __restrict_
     __syncthreads();
     const int n_items = s_start[n_tasks];
     if (t == 0) { T.n_items = n_items; step_hdr[k] = n_items; }
-    if (s_pp[n_tasks] > INLINE_PAIRS) { // k_fin will price this neighbour: it needs the tasks and the work list in memory
-        for (int i = t; i < n_tasks; i += blockDim.x) T.task[i] = s_task[i];
+    // (the tasks and the per-pair lists are needed by whoever prices the queued contacts, always)
+    for (int i = t; i < n_tasks; i += blockDim.x) T.task[i] = s_task[i];
+    if (t < NPAIR) {
+        T.tplus[t] = (unsigned short)t_plus[t]; T.tminus[t] = (unsigned short)t_minus[t]; T.pair_n[t] = (unsigned short)p_cnt[t];
+        T.pair_old[t] = (unsigned short)p_old[t];
+        for (int op = 0; op < N_OPS; op++) {
+            const int e = NPAIR + op * NPAIR + t;
+            T.pair_owner[t][op] = (unsigned short)((e_valid[e] && e_slot[e_owner[e]] >= 0) ? e_slot[e_owner[e]] : 0xffff);
+        }
+        for (int i = 0; i < p_cnt[t]; i++) T.pair_task[t][i] = p_list[t][i];
+    }
+    if (s_pp[n_tasks] > INLINE_PAIRS) { // k_fin will price this neighbour's mass: it needs the work list in memory
         for (int i = t; i <= n_tasks; i += blockDim.x) T.item_start[i] = s_start[i];
         for (int i = t; i < n_tasks; i += blockDim.x) T.cw[i] = (s_chunks[i] << 19) | (s_task[i].p == s_task[i].q ? s_task[i].np : s_task[i].nq);
         if (t >= 128 && t < 192) {
@@ -1340,7 +1372,15 @@ __device__ __forceinline__ int gap_bp(const End& X, int len_x, const End& Y, int
 // the queued contacts: 16 lanes per contact (lane & 15 = candidate op), 4 contacts per wave pass.  Everything a contact
 // needs is addressable from its queue entry, so the loads below go out together: entry -> {relation masks, geometry,
 // statistics, transforms} -> arithmetic.
+// what the pricing of a contact needs of a task, and of a piece pair's list: the finishing block of k_tm copies them into LDS
+// while it waits for the scan (price_contacts then has no dependent loads behind the queue entry and the two fragment records)
+struct PTask { int p; unsigned plus, minus; Xf xp, xq; };
+constexpr int PT_CAP = 32;                      // tasks per neighbour held in LDS (more: read from the tables in memory)
+constexpr int PR_WORDS = 3 + N_OPS;             // tplus, tminus, old task, the new relation's task per candidate
 struct PriceArgs {
+    const unsigned short* pr_lds;  // [K][N_PAIRS][PR_WORDS] or nullptr
+    const PTask* pt_lds;           // [K][PT_CAP]
+    const int* nt_lds;             // [K] number of tasks of neighbour k
     const QEntry* queue;
     const NbTables* tabs;
     const Geo* geo;
@@ -1351,6 +1391,54 @@ struct PriceArgs {
     float nfpb;
     Par par;
 };
+// What a queued contact contributes to candidate `op` of neighbour k, in Q30:
+//     sum over the cis relations t of its piece pair (the tasks of k_tm's per-pair list: the old one and the distinct new ones)
+//         of  ([op in plus_t] - [op in minus_t]) * Q(ob * ln ex_t)
+//     + ([op in tplus] - [op in tminus]) * Q(ob * ln ex_trans)
+// i.e. every DISTINCT relation is evaluated once per contact -- with the transforms of the task that owns it -- and rounded once;
+// candidates that lead to the same relation share the value.  The old relation (the current layout) and the trans value do not
+// depend on the neighbour: evaluated once per contact; a new relation that two neighbours share (ejecting fA does not depend on
+// the neighbour at all) is recognised by its inputs.  Both routines below compute exactly these terms from the same inputs, so
+// their sums are bit-identical (tests/test_engine_gpu.py::test_short_contigs_finished_by_the_table_kernel).
+__device__ __forceinline__ double ln_trans_of(const Stat& sx, int slx, const Stat& sy, int sly, const double* __restrict__ ln_tab, int lut_n,
+                                              float nfpb, const Par& par)
+{
+    const int prod = stat_accu(sx, slx) * stat_accu(sy, sly);
+    if ((unsigned)prod < (unsigned)lut_n) return ln_tab[prod];   // (k_ln_tab: the same expression)
+    return log((double)(par.v_inter * ((float)prod / nfpb)));
+}
+
+// one contact's values: Q(ob ln ex) of the current layout, of the trans relation, and of the last new relation evaluated
+struct ContactVals {
+    const Geo gx, gy;
+    const Stat sx, sy;
+    const int slx, sly;
+    const double ob;
+    long long q_old, q_tr, q_memo;
+    int have;             // bit 0: q_old, bit 1: q_tr, bit 2: q_memo valid
+    int m_xs, m_ys, m_fl, m_lbp;
+    __device__ __forceinline__ long long q_cis(const Xf& xa, const Xf& xb, float nfpb, const Par& par)
+    {
+        const End X = end_xf(gx, xa), Y = end_xf(gy, xb);
+        const int fl = (X.fwd ? 1 : 0) | (Y.fwd ? 2 : 0) | (X.circ << 2);
+        if ((have & 4) && X.start_bp == m_xs && Y.start_bp == m_ys && fl == m_fl && X.lbp == m_lbp) return q_memo;
+        q_memo = to_q(ob * log((double)ex_pair(X, sx, slx, Y, sy, sly, nfpb, par)));
+        m_xs = X.start_bp; m_ys = Y.start_bp; m_fl = fl; m_lbp = X.lbp; have |= 4;
+        return q_memo;
+    }
+};
+
+template <typename PA>
+__device__ __forceinline__ PTask ptask_of(const PA& pa, const NbTables& T, bool in_lds, int k, int ti)
+{
+    if (in_lds) return pa.pt_lds[k * PT_CAP + ti];
+    const Task& g = T.task[ti];
+    PTask tk; tk.p = g.p; tk.plus = g.plus; tk.minus = g.minus; tk.xp = g.xp; tk.xq = g.xq;
+    return tk;
+}
+
+// A few queued contacts (the finishing block of k_tm): 16 lanes per contact, lane = candidate; a lane evaluates the (at most two
+// or three) relations its candidate takes part in.
 __device__ __forceinline__ void price_contacts(const PriceArgs& pa, unsigned long long nq_total, int first, int n_waves, int lane)
 {
     const int op = lane & 15;
@@ -1359,125 +1447,131 @@ __device__ __forceinline__ void price_contacts(const PriceArgs& pa, unsigned lon
         if (e >= nq_total || op >= N_OPS) continue;
         const QEntry qe = pa.queue[e];
         if (qe.rel == 0) continue; // (a reserved slot whose contact failed the scan's third test)
-        const int fx = qe.fx, fy = qe.fy, slx = qe.slots & 3, sly = (qe.slots >> 2) & 3;
-        // speculative: geometry, statistics and the transforms of the first neighbour are needed by (nearly) every queued
-        // contact -- requested together with the relation masks instead of one dependent load after the other
-        const Geo gx = pa.geo[fx], gy = pa.geo[fy];
-        const Stat sx = pa.stat[fx], sy = pa.stat[fy];
-        const int k0 = (__ffs((int)qe.rel) - 1) / CODE_BITS;
-        const Xf xp0 = pa.tabs[k0].xf[op][(qe.ci >> (CODE_BITS * k0)) & 7], xq0 = pa.tabs[k0].xf[op][(qe.cj >> (CODE_BITS * k0)) & 7];
-        // candidates of this lane's op that change the relation of the two fragments (piece ids from the codes)
-        unsigned rel = qe.rel, todo = 0;
+        const int fx = qe.fx, fy = qe.fy;
+        ContactVals cv = {pa.geo[fx], pa.geo[fy], pa.stat[fx], pa.stat[fy], qe.slots & 3, (qe.slots >> 2) & 3,
+                          (double)__int_as_float(qe.cnt), 0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned rel = qe.rel;
         while (rel) {
             const int k = (__ffs((int)rel) - 1) / CODE_BITS;
             rel &= rel - 1;
             const int p = (qe.ci >> (CODE_BITS * k)) & 7, q = (qe.cj >> (CODE_BITS * k)) & 7;
-            if ((pa.tabs[k].changed[op] >> (p * 8 + q)) & 1ull) todo |= 1u << k;
-        }
-        if (!todo) continue;
-        const End X0 = end_cur(gx, pa.lcontbp, fx), Y0 = end_cur(gy, pa.lcontbp, fy);
-        const double ln_old = log((double)ex_pair(X0, sx, slx, Y0, sy, sly, pa.nfpb, pa.par));
-        const double ob = (double)__int_as_float(qe.cnt);
-        while (todo) {
-            const int k = __ffs((int)todo) - 1;
-            todo &= todo - 1;
             const NbTables& T = pa.tabs[k];
-            const int p = (qe.ci >> (CODE_BITS * k)) & 7, q = (qe.cj >> (CODE_BITS * k)) & 7;
-            const End X = end_xf(gx, k == k0 ? xp0 : T.xf[op][p]), Y = end_xf(gy, k == k0 ? xq0 : T.xf[op][q]);
-            const double ln_new = log((double)ex_pair(X, sx, slx, Y, sy, sly, pa.nfpb, pa.par));
-            const long long qv = to_q(ob * (ln_new - ln_old));
-            if (qv == Q_BAD) nf_flag(pa.nf, k, op);
-            else if (qv != 0) atomicAdd((unsigned long long*)&pa.out[k * N_OPS + op], (unsigned long long)qv);
+            const int pr = pair_index(p, q);
+            const unsigned short* P = pa.pr_lds ? pa.pr_lds + (k * N_PAIRS + pr) * PR_WORDS : nullptr;
+            const unsigned tplus = P ? P[0] : T.tplus[pr], tminus = P ? P[1] : T.tminus[pr];
+            const int t_old = P ? P[2] : T.pair_old[pr], t_new = P ? P[3 + op] : T.pair_owner[pr][op];
+            const bool in_lds = P != nullptr && pa.nt_lds[k] <= PT_CAP;
+            long long acc = 0;
+            bool bad = false;
+            const int sg_tr = (int)((tplus >> op) & 1u) - (int)((tminus >> op) & 1u);
+            if (sg_tr != 0) {
+                if (!(cv.have & 2)) { cv.q_tr = to_q(cv.ob * ln_trans_of(cv.sx, cv.slx, cv.sy, cv.sly, nullptr, 0, pa.nfpb, pa.par)); cv.have |= 2; }
+                if (cv.q_tr == Q_BAD) bad = true; else acc += sg_tr * cv.q_tr;
+            }
+            if (t_old != 0xffff) {
+                const PTask tk = ptask_of(pa, T, in_lds, k, t_old);
+                const int sg = (int)((tk.plus >> op) & 1u) - (int)((tk.minus >> op) & 1u);
+                if (sg != 0) {
+                    if (!(cv.have & 1)) {   // (the current layout: the same value whatever the neighbour)
+                        const bool straight = p == tk.p;
+                        const End X = end_xf(cv.gx, straight ? tk.xp : tk.xq), Y = end_xf(cv.gy, straight ? tk.xq : tk.xp);
+                        cv.q_old = to_q(cv.ob * log((double)ex_pair(X, cv.sx, cv.slx, Y, cv.sy, cv.sly, pa.nfpb, pa.par)));
+                        cv.have |= 1;
+                    }
+                    if (cv.q_old == Q_BAD) bad = true; else acc += sg * cv.q_old;
+                }
+            }
+            if (t_new != 0xffff && t_new != t_old) {   // (a new relation merged into the old one carries both signs: nothing)
+                const PTask tk = ptask_of(pa, T, in_lds, k, t_new);
+                const int sg = (int)((tk.plus >> op) & 1u) - (int)((tk.minus >> op) & 1u);
+                if (sg != 0) {
+                    const bool straight = p == tk.p;   // (the task lists its pieces larger first)
+                    const long long qv = cv.q_cis(straight ? tk.xp : tk.xq, straight ? tk.xq : tk.xp, pa.nfpb, pa.par);
+                    if (qv == Q_BAD) bad = true; else acc += sg * qv;
+                }
+            }
+            if (bad) nf_flag(pa.nf, k, op);
+            else if (acc != 0) atomicAdd((unsigned long long*)&pa.out[k * N_OPS + op], (unsigned long long)acc);
         }
     }
 }
 
-// The same for MANY queued contacts (k_fin; long contigs queue millions per step and this pricing is most of the step).  Three
-// things the small routine above does not bother with:
-//  * the OLD expected value's logarithm is computed once per contact -- a wave takes 64 entries, lane = entry, and hands the
-//    value to the (contact, candidate) passes by shuffle -- instead of once per (contact, candidate) lane;
-//  * a NEW relation that is trans needs no logarithm: ln(v_inter * norm) comes from the table k_ln_tab built with the very
-//    same expression (the table k_full_nnz's blocks build for themselves);
-//  * neighbours that lead to the SAME candidate geometry of the two fragments (ejecting fA does not depend on the neighbour
-//    at all; cuts at nearby fragments leave a far pair in the same relative position) are priced once: the lane remembers the
-//    inputs of its last evaluation.  Same inputs, same float32 / float64 operations: the sums are bit-identical to the small routine's.
-__device__ __forceinline__ void price_contacts_bulk(const PriceArgs& pa, const double* __restrict__ ln_tab, int lut_n,
+// MANY queued contacts (k_fin; long contigs queue millions per step and this pricing was a third of the step): lane = contact,
+// and a contact is evaluated once per distinct relation, not once per candidate -- the 13 candidates of a neighbour lead to a
+// handful of distinct relations of a piece pair.  The values are added per (neighbour, task) / (neighbour, pair) in LDS (`S`:
+// K x (MAX_TASKS + N_PAIRS) words) and folded into the per-candidate sums with the tasks' masks once per block
+// (fold_contact_sums).  Short queues: B < 64 contacts per wave and 64 / B lanes per contact, which share its relations.
+constexpr int S_PER_K = MAX_TASKS + N_PAIRS;
+__device__ __forceinline__ void price_contacts_bulk(const PriceArgs& pa, long long* __restrict__ S, const double* __restrict__ ln_tab, int lut_n,
                                                     unsigned long long nq_total, int first, int n_waves, int lane)
 {
-    const int op = lane & 15, c4 = lane >> 4;
-    auto ln_of = [&](const End& X, const Stat& sx, int slx, const End& Y, const Stat& sy, int sly) -> double {
-        if (X.label != Y.label) {
-            const int prod = stat_accu(sx, slx) * stat_accu(sy, sly);
-            if ((unsigned)prod < (unsigned)lut_n) return ln_tab[prod];
-        }
-        return log((double)ex_pair(X, sx, slx, Y, sy, sly, pa.nfpb, pa.par));
-    };
-    // entries per wave and round: 64 when there are enough of them to keep every wave busy that way, else 16 or 4 (a queue of a
-    // few hundred contacts priced 64 per wave would leave most of the grid idle while a few waves run 16 passes each)
     const int B = nq_total >= 64ull * (unsigned long long)n_waves ? 64 : (nq_total >= 16ull * (unsigned long long)n_waves ? 16 : 4);
+    const int ent = lane % B, slice = lane / B, n_slices = 64 / B;
     for (unsigned long long b0 = (unsigned long long)first * B; b0 < nq_total; b0 += (unsigned long long)n_waves * B) {
-        double ln_old_a = 0.0;
-        int live_a = 0;
-        {
-            const unsigned long long ea = b0 + lane;
-            if (lane < B && ea < nq_total) {
-                const QEntry qe = pa.queue[ea];
-                if (qe.rel != 0) {
-                    const int fx = qe.fx, fy = qe.fy;
-                    const Geo gx = pa.geo[fx], gy = pa.geo[fy];
-                    const Stat sx = pa.stat[fx], sy = pa.stat[fy];
-                    const End X0 = end_cur(gx, pa.lcontbp, fx), Y0 = end_cur(gy, pa.lcontbp, fy);
-                    ln_old_a = ln_of(X0, sx, qe.slots & 3, Y0, sy, (qe.slots >> 2) & 3);
-                    live_a = 1;
+        const unsigned long long e = b0 + ent;
+        if (e >= nq_total) continue;
+        const QEntry qe = pa.queue[e];
+        if (qe.rel == 0) continue; // (a reserved slot whose contact failed the scan's third test)
+        const int fx = qe.fx, fy = qe.fy;
+        ContactVals cv = {pa.geo[fx], pa.geo[fy], pa.stat[fx], pa.stat[fy], qe.slots & 3, (qe.slots >> 2) & 3,
+                          (double)__int_as_float(qe.cnt), 0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned rel = qe.rel;
+        while (rel) {
+            const int k = (__ffs((int)rel) - 1) / CODE_BITS;
+            rel &= rel - 1;
+            const int p = (qe.ci >> (CODE_BITS * k)) & 7, q = (qe.cj >> (CODE_BITS * k)) & 7;
+            const NbTables& T = pa.tabs[k];
+            const int pr = pair_index(p, q);
+            if (slice == 0) {   // the two values that do not depend on the neighbour
+                const unsigned tmask = (unsigned)(T.tplus[pr] | T.tminus[pr]);
+                if (tmask != 0) {
+                    if (!(cv.have & 2)) { cv.q_tr = to_q(cv.ob * ln_trans_of(cv.sx, cv.slx, cv.sy, cv.sly, ln_tab, lut_n, pa.nfpb, pa.par)); cv.have |= 2; }
+                    if (cv.q_tr == Q_BAD) nf_flag_ops(pa.nf, k, tmask);
+                    else if (cv.q_tr != 0) atomicAdd((unsigned long long*)&S[k * S_PER_K + MAX_TASKS + pr], (unsigned long long)cv.q_tr);
                 }
-            }
-        }
-        const int n_here = nq_total - b0 < (unsigned long long)B ? (int)(nq_total - b0) : B;
-        for (int pass = 0; pass * 4 < n_here; pass++) {
-            const int src = pass * 4 + c4;
-            const double ln_old = __shfl(ln_old_a, src, 64);
-            const int live = __shfl(live_a, src, 64);
-            if (!live || op >= N_OPS) continue;
-            const QEntry qe = pa.queue[b0 + src];
-            const int fx = qe.fx, fy = qe.fy, slx = qe.slots & 3, sly = (qe.slots >> 2) & 3;
-            unsigned rel = qe.rel, todo = 0;
-            while (rel) {
-                const int k = (__ffs((int)rel) - 1) / CODE_BITS;
-                rel &= rel - 1;
-                const int p = (qe.ci >> (CODE_BITS * k)) & 7, q = (qe.cj >> (CODE_BITS * k)) & 7;
-                if ((pa.tabs[k].changed[op] >> (p * 8 + q)) & 1ull) todo |= 1u << k;
-            }
-            if (!todo) continue;
-            const Geo gx = pa.geo[fx], gy = pa.geo[fy];
-            const Stat sx = pa.stat[fx], sy = pa.stat[fy];
-            const double ob = (double)__int_as_float(qe.cnt);
-            int m_xs = 0, m_ys = 0, m_fl = -1, m_lbp = 0;   // inputs of the lane's last cis evaluation
-            double m_ln = 0.0;
-            while (todo) {
-                const int k = __ffs((int)todo) - 1;
-                todo &= todo - 1;
-                const NbTables& T = pa.tabs[k];
-                const int p = (qe.ci >> (CODE_BITS * k)) & 7, q = (qe.cj >> (CODE_BITS * k)) & 7;
-                const End X = end_xf(gx, T.xf[op][p]), Y = end_xf(gy, T.xf[op][q]);
-                double ln_new;
-                if (X.label != Y.label) ln_new = ln_of(X, sx, slx, Y, sy, sly);
-                else {
-                    const int fl = (X.fwd ? 1 : 0) | (Y.fwd ? 2 : 0) | (X.circ << 2);
-                    if (fl == m_fl && X.start_bp == m_xs && Y.start_bp == m_ys && (X.circ == 0 || X.lbp == m_lbp)) ln_new = m_ln;
-                    else {
-                        ln_new = log((double)ex_pair(X, sx, slx, Y, sy, sly, pa.nfpb, pa.par));
-                        m_fl = fl; m_xs = X.start_bp; m_ys = Y.start_bp; m_lbp = X.lbp; m_ln = ln_new;
+                const int t_old = T.pair_old[pr];
+                if (t_old != 0xffff) {
+                    const Task& tk = T.task[t_old];
+                    if (!(cv.have & 1)) {
+                        const bool straight = p == tk.p;
+                        const End X = end_xf(cv.gx, straight ? tk.xp : tk.xq), Y = end_xf(cv.gy, straight ? tk.xq : tk.xp);
+                        cv.q_old = to_q(cv.ob * log((double)ex_pair(X, cv.sx, cv.slx, Y, cv.sy, cv.sly, pa.nfpb, pa.par)));
+                        cv.have |= 1;
                     }
+                    if (cv.q_old == Q_BAD) nf_flag_ops(pa.nf, k, tk.plus | tk.minus);
+                    else if (cv.q_old != 0) atomicAdd((unsigned long long*)&S[k * S_PER_K + t_old], (unsigned long long)cv.q_old);
                 }
-                const long long qv = to_q(ob * (ln_new - ln_old));
-                if (qv == Q_BAD) nf_flag(pa.nf, k, op);
-                else if (qv != 0) atomicAdd((unsigned long long*)&pa.out[k * N_OPS + op], (unsigned long long)qv);
+            }
+            const int n = T.pair_n[pr];
+            for (int i = slice; i < n; i += n_slices) {
+                const int t = T.pair_task[pr][i];
+                const Task& tk = T.task[t];
+                const bool straight = p == tk.p;   // (the task lists its pieces larger first)
+                const long long qv = cv.q_cis(straight ? tk.xp : tk.xq, straight ? tk.xq : tk.xp, pa.nfpb, pa.par);
+                if (qv == Q_BAD) nf_flag_ops(pa.nf, k, tk.plus | tk.minus);
+                else if (qv != 0) atomicAdd((unsigned long long*)&S[k * S_PER_K + t], (unsigned long long)qv);
             }
         }
     }
 }
 
-// ln(v_inter * (float(p) / nfpb)) for every product p of two RF counts that can occur (see k_full_nnz)
+// the block's per-relation sums of price_contacts_bulk -> its per-candidate sums (acc: K * N_OPS words in LDS)
+__device__ __forceinline__ void fold_contact_sums(const NbTables* __restrict__ tabs, const long long* __restrict__ S, long long* __restrict__ acc, int K)
+{
+    for (int e = threadIdx.x; e < K * S_PER_K; e += blockDim.x) {
+        const long long v = S[e];
+        if (v == 0) continue;
+        const int k = e / S_PER_K, j = e - k * S_PER_K;
+        unsigned plus, minus;
+        if (j < MAX_TASKS) { plus = tabs[k].task[j].plus; minus = tabs[k].task[j].minus; }
+        else { plus = tabs[k].tplus[j - MAX_TASKS]; minus = tabs[k].tminus[j - MAX_TASKS]; }
+        for (int op = 0; op < N_OPS; op++) {
+            const long long sg = (long long)((plus >> op) & 1u) - (long long)((minus >> op) & 1u);   // (a contact counts with the NEW layout's sign)
+            if (sg != 0) atomicAdd((unsigned long long*)&acc[k * N_OPS + op], (unsigned long long)(sg * v));
+        }
+    }
+}
+
 __global__ void k_ln_tab(double* __restrict__ tab, int n, float nfpb, Par par)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1630,6 +1724,9 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
     // ---- finisher: the last table block ----
     __shared__ int s_fin; // 0 = not the last block, 1 = finish here, 2 = leave it to k_fin
     __shared__ unsigned long long s_nq;
+    __shared__ unsigned short s_prl[MAXK * N_PAIRS * PR_WORDS];
+    __shared__ PTask s_ptl[MAXK * PT_CAP];
+    __shared__ int s_ntl[MAXK];
     if (t == 0) {
         int mode = 0;
         __threadfence();
@@ -1648,6 +1745,25 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
         // (only wave 0 polls -- all its flag loads of a round are in flight together, no block barrier inside the loop; the
         // other waves wait at the barrier below)
         __shared__ int s_seen;
+        // the other waves meanwhile copy what the pricing needs of all K tables into LDS (the other blocks released their
+        // tables before they took their tickets)
+        if (t >= 64 && s_fin == 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const int u = t - 64, nu = (int)blockDim.x - 64;
+            for (int e = u; e < K * N_PAIRS; e += nu) {
+                const int k = e / N_PAIRS, pr = e - k * N_PAIRS;
+                const NbTables& T = ta.tabs[k];
+                unsigned short* P = s_prl + e * PR_WORDS;
+                P[0] = T.tplus[pr]; P[1] = T.tminus[pr]; P[2] = T.pair_old[pr];
+                for (int op = 0; op < N_OPS; op++) P[3 + op] = T.pair_owner[pr][op];
+            }
+            for (int e = u; e < K * PT_CAP; e += nu) {
+                const int k = e / PT_CAP, i = e - k * PT_CAP;
+                const NbTables& T = ta.tabs[k];
+                if (i < T.n_tasks) { const Task& g = T.task[i]; PTask tk; tk.p = g.p; tk.plus = g.plus; tk.minus = g.minus; tk.xp = g.xp; tk.xq = g.xq; s_ptl[e] = tk; }
+            }
+            if (u < K) s_ntl[u] = ta.tabs[u].n_tasks;
+        }
         if (t < 64) {
             bool ok0 = false;
             const unsigned long long t_end = wall_clock64() + (unsigned long long)ta.wait_ticks;
@@ -1679,6 +1795,7 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
     }
     {
         PriceArgs pa;
+        pa.pr_lds = s_prl; pa.pt_lds = s_ptl; pa.nt_lds = s_ntl;
         pa.queue = ta.queue; pa.tabs = ta.tabs; pa.geo = ta.geo; pa.stat = ta.stat; pa.lcontbp = ta.lcontbp;
         pa.out = ta.acc; pa.nf = ta.counters + NF_OFF; pa.nfpb = ta.nfpb; pa.par = ta.par;
         price_contacts(pa, s_nq, t >> 6, (int)(blockDim.x >> 6), t & 63);
@@ -2132,7 +2249,13 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
     // sat idle 91 % of a 12 ms step behind them (rocprofv3: SQ_INSTS_VALU against the kernel's duration).
     __shared__ long long s_accb[MAXK * N_OPS];
     __shared__ long long s_items;
+    // dynamic LDS, sized by K (fin_dyn_lds): the per-relation sums of the queued contacts, then the unit list's prefix sums
+    extern __shared__ long long s_dyn[];
+    long long* const S = s_dyn;
+    int* const s_ust = reinterpret_cast<int*>(s_dyn + K * S_PER_K);
+#define USTART(k_, ti_) s_ust[(k_) * (MAX_TASKS + 1) + (ti_)]
     for (int i = threadIdx.x; i < MAXK * N_OPS; i += blockDim.x) s_accb[i] = 0;
+    for (int i = threadIdx.x; i < K * S_PER_K; i += blockDim.x) S[i] = 0;
     if (threadIdx.x == 0) s_items = 0;
     STAMP(16, blockIdx.x == 0 && threadIdx.x == 0);
     STAMP_FBLK(0, threadIdx.x == 0);
@@ -2187,7 +2310,7 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
         // showed the VALUs busy 9 % of the time (C5 with its 7 contigs: 12 ms per step).  Every block derives the same unit
         // list -- per neighbour the exclusive prefix of units per task -- in LDS; unit U of the flat list belongs to rank
         // U % world.  (Sums are integers: any partition of the pairs gives the same result.)
-        __shared__ int s_ustart[MAXK][MAX_TASKS + 1]; // s_ustart[k][ti] = first unit of task ti among neighbour k's units
+        // (USTART(k, ti) = first unit of task ti among neighbour k's units: dynamic LDS, sized by K like the contact sums S)
         __shared__ int s_ubase[MAXK + 1];
         // SEG: fragments y per unit.  At most 128 (16 with sub-fragments: up to 9 slot pairs per fragment pair), and small enough
         // for the step to have ~4 units per wave of the grid: a unit is one long dependent chain of float32 powf / expf, ~25 us
@@ -2208,16 +2331,16 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
             const int e = (int)threadIdx.x + j * 256;
             if (e < K * MAX_TASKS) {
                 const int k = e / MAX_TASKS, ti = e - k * MAX_TASKS;
-                if (ti < s_nt[k]) s_ustart[k][ti] = (int)((unsigned)cw[j] >> 19) * max(1, ((cw[j] & 0x7ffff) + SEG - 1) / SEG);
+                if (ti < s_nt[k]) USTART(k, ti) = (int)((unsigned)cw[j] >> 19) * max(1, ((cw[j] & 0x7ffff) + SEG - 1) / SEG);
             }
         }
         __syncthreads();
         for (int k = threadIdx.x >> 6; k < K; k += (int)(blockDim.x >> 6)) // one wave per neighbour, side by side
-            wave_excl_scan(s_ustart[k], s_ustart[k], s_nt[k]); // (in place: a lane reads its entry before it writes it)
+            wave_excl_scan(&USTART(k, 0), &USTART(k, 0), s_nt[k]); // (in place: a lane reads its entry before it writes it)
         __syncthreads();
         if (threadIdx.x == 0) {
             s_ubase[0] = 0;
-            for (int k = 0; k < K; k++) s_ubase[k + 1] = s_ubase[k] + s_ustart[k][s_nt[k]];
+            for (int k = 0; k < K; k++) s_ubase[k + 1] = s_ubase[k] + USTART(k, s_nt[k]);
         }
         __syncthreads();
         const int total_units = s_ubase[K];
@@ -2232,12 +2355,12 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
             const int u = U - s_ubase[k];
             const NbTables& T = tabs[k];
             int lo_t = 0, hi_t = s_nt[k] - 1; // task of unit u: last task with s_ustart <= u
-            while (lo_t < hi_t) { const int mid = (lo_t + hi_t + 1) >> 1; if (s_ustart[k][mid] <= u) lo_t = mid; else hi_t = mid - 1; }
+            while (lo_t < hi_t) { const int mid = (lo_t + hi_t + 1) >> 1; if (USTART(k, mid) <= u) lo_t = mid; else hi_t = mid - 1; }
             const int ti = lo_t;
             const Task tk = T.task[ti];
             const int np = tk.np, nq = tk.nq, base_p = tk.base_p, base_q = tk.base_q;
             const int n_seg = max(1, ((tk.p == tk.q ? np : nq) + SEG - 1) / SEG);
-            const int within = u - s_ustart[k][ti], chunk = within / n_seg, seg = within - chunk * n_seg;
+            const int within = u - USTART(k, ti), chunk = within / n_seg, seg = within - chunk * n_seg;
             items += seg == 0;
             // lane = one fragment x of the chunk.  The fragments y it is paired with are walked AWAY from the chunk, 64 at a
             // time: the wave stages their transformed geometry and statistics in LDS once (one dependent-load chain per 64
@@ -2310,12 +2433,15 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
         STAMP(12, blockIdx.x == 0 && threadIdx.x == 0);
         // ---- queued contacts ----
         PriceArgs pa;
+        pa.pr_lds = nullptr; pa.pt_lds = nullptr; pa.nt_lds = nullptr;
         pa.queue = queue; pa.tabs = tabs; pa.geo = geo; pa.stat = stat; pa.lcontbp = lcontbp; pa.out = s_accb; pa.nf = counters + NF_OFF; pa.nfpb = nfpb; pa.par = par;
         // (batches of queued contacts continue the round robin where this rank's mass units ended)
         const int mass_slots = (int)(((long long)total_units - rank + world - 1) / world % n_waves);
-        if (!(fa.skip & 2)) price_contacts_bulk(pa, fa.ln_tab, fa.lut_n, nq_total, (wave - mass_slots + n_waves) % n_waves, n_waves, lane);
+        if (!(fa.skip & 2)) price_contacts_bulk(pa, S, fa.ln_tab, fa.lut_n, nq_total, (wave - mass_slots + n_waves) % n_waves, n_waves, lane);
         STAMP(13, blockIdx.x == 0 && threadIdx.x == 0);
         STAMP_FBLK(2, threadIdx.x == 0);
+        __syncthreads();
+        fold_contact_sums(tabs, S, s_accb, K);
         __syncthreads();
         STAMP(14, blockIdx.x == 0 && threadIdx.x == 0);
         STAMP_FBLK(3, threadIdx.x == 0);
@@ -2341,6 +2467,7 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
     __threadfence();
     hand_out(out, counters, fa.sync, K, d_q_out, host_res, seq);
     STAMP(21, threadIdx.x == 0);
+#undef USTART
 }
 
 // ------------------------------------------------------------------ reference-arithmetic validation mode
@@ -3097,7 +3224,8 @@ int launch_fin(Ctx* h, int K, int rank, int world, long long* d_q_out, bool publ
     fa.tabs = h->tabs; fa.geo = h->geo; fa.stat = h->stat_frag; fa.acc = h->d_acc; fa.sync = h->d_sync;
     static const int fin_seg = getenv("GRAAL_FIN_SEG") ? atoi(getenv("GRAAL_FIN_SEG")) : 0;
     fa.ln_tab = h->d_ln_tab; fa.lut_n = h->d_ln_tab ? h->ln_lut_n : 0; fa.skip = fin_skip; fa.seg = fin_seg;
-    k_fin<<<fin_blocks, 256, 0, st>>>(h->d_args + h->cur, fa, K, rank, world, d_q_out, publish ? h->res_dev : nullptr, h->seq);
+    const size_t fin_dyn_lds = (size_t)K * (S_PER_K * sizeof(long long) + (MAX_TASKS + 1) * sizeof(int));   // K = 10: 37 KB
+    k_fin<<<fin_blocks, 256, fin_dyn_lds, st>>>(h->d_args + h->cur, fa, K, rank, world, d_q_out, publish ? h->res_dev : nullptr, h->seq);
     CK(hipGetLastError());
     return GRAAL_OK;
 }
