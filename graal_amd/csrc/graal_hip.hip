@@ -1542,8 +1542,9 @@ __device__ __forceinline__ void price_contacts_bulk(const PriceArgs& pa, long lo
                     else if (cv.q_old != 0) atomicAdd((unsigned long long*)&S[k * S_PER_K + t_old], (unsigned long long)cv.q_old);
                 }
             }
+            // (several lanes per contact: lane 0 of them has the two shared values above, the others share the new relations)
             const int n = T.pair_n[pr];
-            for (int i = slice; i < n; i += n_slices) {
+            for (int i = n_slices > 1 ? slice - 1 : 0; i >= 0 && i < n; i += n_slices > 1 ? n_slices - 1 : 1) {
                 const int t = T.pair_task[pr][i];
                 const Task& tk = T.task[t];
                 const bool straight = p == tk.p;   // (the task lists its pieces larger first)
