@@ -2231,6 +2231,7 @@ struct FinArgs { // first-needed pointers by value (see ScanArgs)
     int lut_n;
     int skip;                      // diagnostics (GRAAL_FIN_SKIP): 1 = no mass units, 2 = no queued contacts
     int seg;                       // fragments y per mass unit (0: chosen per step)
+    float norm_u;                  // >= 0: every sub-fragment has the same RF count a, and this is float(a * a) / nfpb
 };
 
 __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinArgs fa, int K, int rank, int world,
@@ -2415,8 +2416,16 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
                     const int gap = same ? gap_bp(X, gx.len_bp, Y, y.len_bp)
                                          : (x_below ? Y.start_bp - (X.start_bp + gx.len_bp) : X.start_bp - (Y.start_bp + y.len_bp));
                     if (gap > reach_bp) { done = true; continue; }
-                    Ctr cy; cy.c0 = y.c0; cy.c1 = y.c1; cy.c2 = y.c2;
-                    const long long q1 = pair_mass_q_c(cx, sx, cy, y.st, X.circ, X.lbp, nfpb, par);
+                    long long q1;
+                    if (!multi_sub) {   // one sub-fragment per bin: pair_mass_q_c without its slot loops (the same operations on the same values)
+                        const float norm = fa.norm_u >= 0.0f ? fa.norm_u : (float)(sx.a0 * y.st.a0) / nfpb;
+                        const float sd = fabsf(y.c0 - cx.c0);
+                        const float ex = (X.circ == 1 ? rippe_circ(sd, (float)X.lbp / 1000.0f, par) : rippe(sd, par)) * norm;
+                        q1 = to_q((double)ex - (double)(par.v_inter * norm));
+                    } else {
+                        Ctr cy; cy.c0 = y.c0; cy.c1 = y.c1; cy.c2 = y.c2;
+                        q1 = pair_mass_q_c(cx, sx, cy, y.st, X.circ, X.lbp, nfpb, par);
+                    }
                     if (q1 == Q_BAD) bad = true; else accq += q1;
                 }
                 if (__ballot(!done) == 0) break;
@@ -3225,6 +3234,7 @@ int launch_fin(Ctx* h, int K, int rank, int world, long long* d_q_out, bool publ
     fa.tabs = h->tabs; fa.geo = h->geo; fa.stat = h->stat_frag; fa.acc = h->d_acc; fa.sync = h->d_sync;
     static const int fin_seg = getenv("GRAAL_FIN_SEG") ? atoi(getenv("GRAAL_FIN_SEG")) : 0;
     fa.ln_tab = h->d_ln_tab; fa.lut_n = h->d_ln_tab ? h->ln_lut_n : 0; fa.skip = fin_skip; fa.seg = fin_seg;
+    fa.norm_u = h->uniform_accu > 0 ? (float)(h->uniform_accu * h->uniform_accu) / h->nfpb : -1.0f;
     const size_t fin_dyn_lds = (size_t)K * (S_PER_K * sizeof(long long) + (MAX_TASKS + 1) * sizeof(int));   // K = 10: 37 KB
     k_fin<<<fin_blocks, 256, fin_dyn_lds, st>>>(h->d_args + h->cur, fa, K, rank, world, d_q_out, publish ? h->res_dev : nullptr, h->seq);
     CK(hipGetLastError());
@@ -3912,7 +3922,7 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
         FinArgs fa;
         fa.tm_done = h->tm_done; fa.step_hdr = h->step_hdr; fa.counters = (unsigned long long*)(h->d_scalars + 10); fa.queue = h->queue;
         fa.tabs = h->tabs; fa.geo = h->geo; fa.stat = h->stat_frag; fa.acc = h->d_acc; fa.sync = h->d_sync;
-        fa.ln_tab = nullptr; fa.lut_n = 0; fa.skip = 0; fa.seg = 0;
+        fa.ln_tab = nullptr; fa.lut_n = 0; fa.skip = 0; fa.seg = 0; fa.norm_u = -1.0f;
         StrictArgs sx;
         sx.perm = h->perm; sx.cbase = h->cbase; sx.lcontbp = h->soa[h->cur].p[F_LCONTBP]; sx.link = h->link; sx.nfpb = h->nfpb; sx.par = h->par;
         sx.quirk = (h->mode & GRAAL_MODE_REF_TRANS_ACCU) ? 1 : 0;
