@@ -1375,7 +1375,7 @@ __device__ __forceinline__ int gap_bp(const End& X, int len_x, const End& Y, int
 // what the pricing of a contact needs of a task, and of a piece pair's list: the finishing block of k_tm copies them into LDS
 // while it waits for the scan (price_contacts then has no dependent loads behind the queue entry and the two fragment records)
 struct PTask { int p; unsigned plus, minus; Xf xp, xq; };
-constexpr int PT_CAP = 32;                      // tasks per neighbour held in LDS (more: read from the tables in memory)
+constexpr int PT_CAP = 64;                      // tasks per neighbour held in LDS (more: read from the tables in memory)
 constexpr int PR_WORDS = 3 + N_OPS;             // tplus, tminus, old task, the new relation's task per candidate
 struct PriceArgs {
     const unsigned short* pr_lds;  // [K][N_PAIRS][PR_WORDS] or nullptr
