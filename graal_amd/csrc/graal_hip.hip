@@ -1058,6 +1058,9 @@ struct NbTables {        // everything the finishing kernel needs about one neig
 
 // one staged fragment y of the mass walk (k_fin): transformed geometry + statistics, 64 bytes
 struct YTile { int start_bp, len_bp, flags, label, lbp; float c0, c1, c2; Stat st; };   // (c*: centres of its sub-fragments, kb)
+// completion counters of k_scan: N_DONE words on lines of their own take the blocks in turn, so that 496 device-scope atomics
+// do not queue on one address (measured: 0.3-0.5 us per step against the single counter, GRAAL_SCAN_DONE_N=1; tools/done_ab.sh)
+constexpr int N_DONE = 16, DONE_STRIDE = 16;
 constexpr int FLAG_STRIDE = 32; // words between two blocks' completion flags: one 128-byte line each (partial writes to one
                                 // line from many XCDs serialise at the memory side)
 
@@ -1631,8 +1634,10 @@ struct TmArgs { // first-needed pointers by value (see ScanArgs)
     const unsigned* flags;         // k_scan's per-block completion flags
     volatile long long* host_res;  // non-null: the last block of k_tm finishes the step itself when the work is small
     int n_scan_blocks;
-    const unsigned long long* done; // non-null: k_scan's blocks count themselves here; the step's scan is complete at done_target
-    unsigned long long done_target;
+    const unsigned long long* done; // non-null: k_scan's blocks count themselves here (block b in counter b % n_done, one 128-byte line
+                                    // each); the step's scan is complete when every counter has reached its target
+    int n_done;
+    unsigned long long done_target[N_DONE];
     int wait_ticks;                // how long that block waits for k_scan (100 MHz ticks)
     int strict;                    // GRAAL_MODE_STRICT: tables only (k_strict prices everything)
     // the finishing block's pointers, by value too
@@ -1770,7 +1775,7 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
             const unsigned long long t_end = wall_clock64() + (unsigned long long)ta.wait_ticks;
             for (;;) {
                 unsigned missing = 0; // (no short-circuit: the loads of a round must not wait for each other)
-                if (ta.done) missing = __hip_atomic_load(ta.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ta.done_target;
+                if (ta.done) { if (t < ta.n_done) missing = __hip_atomic_load(ta.done + DONE_STRIDE * t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ta.done_target[t]; }
                 else
                     for (int b = t; b < ta.n_scan_blocks; b += 64)
                         missing |= __hip_atomic_load(&ta.flags[FLAG_STRIDE * b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ^ (unsigned)seq;
@@ -1867,7 +1872,8 @@ struct ScanArgs { // by value: kernel-argument pointers are known to be GLOBAL (
     unsigned long long* counters;
     unsigned* flags;              // [block] sequence number of the last step this block finished
     unsigned seq32;
-    unsigned long long* done;     // non-null: completion = one fire-and-forget atomic per block on this counter instead of a flag
+    unsigned long long* done;     // non-null: completion = one fire-and-forget atomic per block on one of n_done counters instead of a flag
+    int n_done;
     long long nnz;
     int bitmap_words;
     int strict;                   // GRAAL_MODE_STRICT: queue every contact with both ends in a neighbour's affected set
@@ -2196,7 +2202,7 @@ __global__ __launch_bounds__(1024, (G <= 4 ? 8 : 4)) void k_scan(ScanArgs sa, in
         if (last) {
             const unsigned long long nr = atomicAdd(&s_nrel, 0ull);
             if (nr) atomicAdd(&counters[0], nr);
-            if (sa.done) __hip_atomic_fetch_add(sa.done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (result unused: no-return atomic)
+            if (sa.done) __hip_atomic_fetch_add(sa.done + DONE_STRIDE * (blockIdx.x % sa.n_done), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (result unused: no-return atomic)
             else __hip_atomic_store(sa.flags + FLAG_STRIDE * blockIdx.x, sa.seq32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -2993,7 +2999,8 @@ struct Ctx {
     long long* d_acc = nullptr;   // K*13 running sums (self-cleaning: the step's last block zeroes them after reading)
     unsigned long long* d_sync = nullptr; // [0] k_tm ticket [8] finished blocks of k_scan
     unsigned* d_flags = nullptr;          // k_scan's per-block completion flags
-    unsigned long long scan_done_total = 0; // blocks of all non-dry scans launched so far (completion counter mode)
+    unsigned long long scan_done_total[N_DONE] = {}; // per completion counter: blocks of all non-dry scans launched so far
+    unsigned long long* d_done = nullptr;    // the N_DONE completion counters of k_scan, DONE_STRIDE words apart
     int mode = 0;                 // GRAAL_MODE_* flags (graal_set_mode)
     unsigned scan_token = 0x5ca90000u; // k_scan launches so far (ScanArgs.token)
     double* d_ln_tab = nullptr;   // [LN_TRANS_LUT] ln of the trans value by RF-count product (k_ln_tab; rebuilt by sync_args)
@@ -3158,6 +3165,12 @@ bool scan_done_counter()
     return v;
 }
 
+int scan_done_n()
+{
+    static const int e = getenv("GRAAL_SCAN_DONE_N") ? atoi(getenv("GRAAL_SCAN_DONE_N")) : N_DONE;
+    return e >= 1 && e <= N_DONE ? e : N_DONE;
+}
+
 int scan_grid(const Ctx* h)
 {
     // two 1024-thread blocks per CU fill the 256 CUs; 16 fewer leave room for k_tm's blocks, which run at the same time (a
@@ -3185,8 +3198,9 @@ int launch_scan(Ctx* h, int fA, const Neigh& nb, int K, int max_id, int dry, hip
     sa.strict = (h->mode & GRAAL_MODE_STRICT) ? 1 : 0;
     sa.wt_queue = finisher_reads ? 1 : 0;
     sa.token = ++h->scan_token;
-    sa.done = (scan_done_counter() && !dry) ? h->d_sync + 8 : nullptr;
-    if (sa.done) h->scan_done_total += (unsigned long long)nbk;
+    sa.done = (scan_done_counter() && !dry) ? h->d_done : nullptr;
+    sa.n_done = scan_done_n();
+    if (sa.done) for (int c = 0; c < sa.n_done; c++) h->scan_done_total[c] += (unsigned long long)((nbk - c + sa.n_done - 1) / sa.n_done);
     if (nbk > MAX_SCAN_BLOCKS) return fail(h, GRAAL_E_ARG, "GRAAL_SCAN_BLOCKS too large");
     if (scan_groups_cfg() == 8) {
         if (h->single_sub) k_scan<true, 8><<<nbk, scan_threads, shm, st>>>(sa, fA, nb, K, max_id, dry);
@@ -3325,6 +3339,8 @@ int graal_create(int device, graal_ctx** out)
     CK(hipMemset(h->d_acc, 0, MAXK * N_OPS * sizeof(long long)));
     CK(hipMalloc(&h->tm_done, MAXK * sizeof(long long)));
     CK(hipMemset(h->tm_done, 0, MAXK * sizeof(long long)));
+    CK(hipMalloc(&h->d_done, N_DONE * DONE_STRIDE * sizeof(unsigned long long)));
+    CK(hipMemset(h->d_done, 0, N_DONE * DONE_STRIDE * sizeof(unsigned long long)));
     CK(hipMalloc(&h->d_sync, 32 * sizeof(unsigned long long)));
     CK(hipMemset(h->d_sync, 0, 32 * sizeof(unsigned long long)));
     CK(hipMalloc(&h->d_flags, (size_t)MAX_SCAN_BLOCKS * FLAG_STRIDE * sizeof(unsigned)));
@@ -3362,7 +3378,7 @@ void graal_destroy(graal_ctx* h)
         (void)hipSetDevice(h->device);
         (void)hipStreamSynchronize(h->stream);
         if (h->aux) (void)hipStreamSynchronize(h->aux);
-        void* ptrs[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->stat, h->sub_rec, h->sub_rec8, h->sub_lab16, h->d_ubins, h->d_ln_tab, h->sub2bin, h->row, h->col, h->cnt, h->queue, h->d_sub_ids, h->d_acc, h->tm_done, h->d_sync, h->d_flags, h->stat_frag, h->d_dup_bins, h->d_dup_index,
+        void* ptrs[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->stat, h->sub_rec, h->sub_rec8, h->sub_lab16, h->d_ubins, h->d_ln_tab, h->sub2bin, h->row, h->col, h->cnt, h->queue, h->d_sub_ids, h->d_acc, h->tm_done, h->d_sync, h->d_done, h->d_flags, h->stat_frag, h->d_dup_bins, h->d_dup_index,
                         h->d_dispatcher, h->d_collector, h->d_sub_ids_all, h->d_rep_obs,
                         h->keys, h->keys_sorted, h->o2n, h->len_of2[0], h->len_of2[1], h->contig_off2[0], h->contig_off2[1], h->perm, h->cbase, h->link, h->mates, h->cub_tmp, h->tabs, h->step_hdr, h->d_args, h->d_chg,
                         h->d_scalars, h->d_qout, h->d_dref, h->d_dist};
@@ -3893,7 +3909,8 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     static const bool no_finisher = getenv("GRAAL_NO_FINISHER") != nullptr; // always finish with k_fin (diagnostics)
     ta.flags = h->d_flags;
     ta.sync = h->d_sync; ta.n_scan_blocks = scan_grid(h);
-    ta.done = scan_done_counter() ? h->d_sync + 8 : nullptr; ta.done_target = h->scan_done_total + (unsigned long long)scan_grid(h);
+    ta.done = scan_done_counter() ? h->d_done : nullptr; ta.n_done = scan_done_n();
+    for (int c = 0; c < N_DONE; c++) ta.done_target[c] = c < ta.n_done ? h->scan_done_total[c] + (unsigned long long)((scan_grid(h) - c + ta.n_done - 1) / ta.n_done) : 0ull;
     // (late stage -- a few long contigs hold nearly every fragment: nearly every step needs k_fin anyway, so it is launched
     // right behind the scan instead of after k_tm's verdict has made the round trip through the host, ~10 us per step)
     const bool late_stage = h->max_lcont > 128 && (long long)h->n_contigs * 64 < (long long)h->n;
