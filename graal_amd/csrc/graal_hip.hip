@@ -2097,7 +2097,7 @@ __global__ __launch_bounds__(1024, (G <= 4 ? 8 : 4)) void k_scan(ScanArgs sa, in
         // are short)
         while (__ballot(hit != 0) != 0) {
             unsigned rel = 0, q_ci = 0, q_cj = 0;
-            int j = 0, q_fx = 0, q_fy = 0, q_slots = 0;
+            int j = 0, q_fx = 0, q_fy = 0, q_slots = 0, cnt_w = 0;
             long long cidx = 0;
             const bool cidx_valid = hit != 0; // this lane examines a contact in this pass
             if (hit) {
@@ -2105,6 +2105,9 @@ __global__ __launch_bounds__(1024, (G <= 4 ? 8 : 4)) void k_scan(ScanArgs sa, in
                 hit &= hit - 1;
                 const int rj = sel_words<G>(rr, j), cj_ = sel_words<G>(cc, j);
                 cidx = ((long long)(ga + (j >> 2) * stride) << 2) + (j & 3);
+                // (the count is requested together with the two fragment records below, not after the third test: one
+                // dependent round trip less in a chain that ends the kernel when the contact turns up in a late iteration)
+                if (!dry) cnt_w = sa.cnt[cidx];
                 {
                     int fx, fy;
                     if (SINGLE_SUB) { fx = rj; fy = cj_; }
@@ -2133,7 +2136,6 @@ __global__ __launch_bounds__(1024, (G <= 4 ? 8 : 4)) void k_scan(ScanArgs sa, in
                 // (entries read by k_tm's finishing block while this kernel may still run are written through, 8 bytes at a
                 // time; entries for the NEXT kernel on the stream (k_fin / k_strict) as two plain 16-byte stores -- four 8-byte
                 // write-through stores per entry made a scan that queues 2 M contacts run at 8 % of the HBM rate)
-                const int cnt_w = rel ? sa.cnt[cidx] : 0;
                 const unsigned long long w0 = (unsigned long long)(unsigned)cidx | ((unsigned long long)rel << 32);
                 const unsigned long long w1 = (unsigned long long)q_ci | ((unsigned long long)q_cj << 32);
                 const unsigned long long w2 = (unsigned long long)(unsigned)q_fx | ((unsigned long long)(unsigned)q_fy << 32);
