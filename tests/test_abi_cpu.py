@@ -47,3 +47,21 @@ def test_product_package_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "libgraal_oracle" not in src, f
+
+
+def test_environment_switches_are_documented():
+    """Every GRAAL_* environment variable the library, the host package or bench.py reads is listed in INTEGRATION.md section 5
+    (tuning knobs in the product library must not drift undocumented)."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    used = set()
+    for f in glob.glob(os.path.join(root, "graal_amd", "csrc", "*")) + glob.glob(os.path.join(root, "graal_amd", "*.py")) + [os.path.join(root, "bench.py")]:
+        if os.path.isfile(f) and not f.endswith(".so"):
+            txt = open(f, errors="ignore").read()
+            used |= set(re.findall(r'getenv\("(GRAAL_[A-Z0-9_]+)"\)', txt))
+            used |= set(re.findall(r'environ(?:\.get)?[\[(]\s*"(GRAAL_[A-Z0-9_]+)"', txt))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    documented = set(re.findall(r"`(GRAAL_[A-Z0-9_]+)`", doc))
+    assert used, "no switches found: the patterns of this test are out of date"
+    assert used <= documented, sorted(used - documented)
