@@ -1730,9 +1730,12 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
     // ---- finisher: the last table block ----
     __shared__ int s_fin; // 0 = not the last block, 1 = finish here, 2 = leave it to k_fin
     __shared__ unsigned long long s_nq;
-    __shared__ unsigned short s_prl[MAXK * N_PAIRS * PR_WORDS];
-    __shared__ PTask s_ptl[MAXK * PT_CAP];
-    __shared__ int s_ntl[MAXK];
+    // (dynamic LDS, requested only when a finisher can exist: a k_tm block that k_fin's resident blocks wait for must stay small
+    // enough to be placed next to them -- tm_fin_dyn_lds / fin_blocks_no_wait)
+    extern __shared__ long long s_tm_dyn[];
+    PTask* const s_ptl = reinterpret_cast<PTask*>(s_tm_dyn);
+    unsigned short* const s_prl = reinterpret_cast<unsigned short*>(s_ptl + MAXK * PT_CAP);
+    int* const s_ntl = reinterpret_cast<int*>(s_prl + MAXK * N_PAIRS * PR_WORDS);
     if (t == 0) {
         int mode = 0;
         __threadfence();
@@ -2240,6 +2243,7 @@ struct FinArgs { // first-needed pointers by value (see ScanArgs)
     int skip;                      // diagnostics (GRAAL_FIN_SKIP): 1 = no mass units, 2 = no queued contacts
     int seg;                       // fragments y per mass unit (0: chosen per step)
     float norm_u;                  // >= 0: every sub-fragment has the same RF count a, and this is float(a * a) / nfpb
+    int upw;                       // mass units per wave of the grid the unit size aims at
 };
 
 __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinArgs fa, int K, int rank, int world,
@@ -2328,20 +2332,26 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
         // 140 us for 12 us worth of VALU work, the few waves that got two or three units carried it (tools/fin_seg_ab.sh:
         // SEG 16 -> 2 takes the scoring phase from 138 to 79 us there, from 178 to 126 us at the C3 shape).
         const bool multi_sub = A->sub2bin_multi != nullptr;
-        int SEG = fa.seg;
+        // ... and a unit is a RUN of segments: run r of a (task, chunk) takes the segments r, r + R, r + 2R, ... of the walk (R
+        // runs per chunk).  The segments near the chunk are the expensive ones and those beyond the window cost nothing, so
+        // contiguous runs would be a lottery; strided ones cost about the same, end at the window (a lane that has left the
+        // window stays out: distances only grow along the walk), and load x once per run.  LRUN = segments per run.
+        int SEG = fa.seg, LRUN = 1;
         if (SEG <= 0) {
             long long w_all = 0;
             for (int k = 0; k < K; k++) w_all += s_wt[k];
-            const long long per_unit = w_all / (4ll * n_waves * world);
+            const long long per_unit = w_all / ((long long)fa.upw * n_waves * world);   // fragments y a unit should walk
             SEG = multi_sub ? 2 : 16;
-            while (SEG < (multi_sub ? 16 : 128) && SEG < per_unit) SEG <<= 1;
+            while (SEG < (multi_sub ? 16 : 64) && 2 * SEG <= per_unit / 2) SEG <<= 1;
+            LRUN = (int)(per_unit / SEG > 1 ? (per_unit / SEG > 4096 ? 4096 : per_unit / SEG) : 1);
         }
+        auto runs_of = [&](int walk) { const int n_seg = max(1, (walk + SEG - 1) / SEG); return min(n_seg, (n_seg + LRUN - 1) / LRUN); };
 #pragma unroll
         for (int j = 0; j < NE; j++) {
             const int e = (int)threadIdx.x + j * 256;
             if (e < K * MAX_TASKS) {
                 const int k = e / MAX_TASKS, ti = e - k * MAX_TASKS;
-                if (ti < s_nt[k]) USTART(k, ti) = (int)((unsigned)cw[j] >> 19) * max(1, ((cw[j] & 0x7ffff) + SEG - 1) / SEG);
+                if (ti < s_nt[k]) USTART(k, ti) = (int)((unsigned)cw[j] >> 19) * runs_of(cw[j] & 0x7ffff);
             }
         }
         __syncthreads();
@@ -2369,9 +2379,9 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
             const int ti = lo_t;
             const Task tk = T.task[ti];
             const int np = tk.np, nq = tk.nq, base_p = tk.base_p, base_q = tk.base_q;
-            const int n_seg = max(1, ((tk.p == tk.q ? np : nq) + SEG - 1) / SEG);
-            const int within = u - USTART(k, ti), chunk = within / n_seg, seg = within - chunk * n_seg;
-            items += seg == 0;
+            const int n_seg = max(1, ((tk.p == tk.q ? np : nq) + SEG - 1) / SEG), n_runs = runs_of(tk.p == tk.q ? np : nq);
+            const int within = u - USTART(k, ti), chunk = within / n_runs, run = within - chunk * n_runs;
+            items += run == 0;
             // lane = one fragment x of the chunk.  The fragments y it is paired with are walked AWAY from the chunk, 64 at a
             // time: the wave stages their transformed geometry and statistics in LDS once (one dependent-load chain per 64
             // y instead of one per pair -- the loop used to be bound by that latency), then every lane runs over the tile
@@ -2394,11 +2404,12 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
             }
             const int ny_all = same ? np : nq;             // length of the walk
             const int walk_lo = same ? chunk * 64 + 1 : 0;
-            const int seg_lo = max(walk_lo, seg * SEG);
-            const int ny = min(ny_all, (seg + 1) * SEG);   // this unit walks [seg_lo, ny)
             YTile* tile = s_tile[threadIdx.x >> 6];
             bool done = !has_x, bad = false;
             long long accq = 0;
+            for (int seg = run; seg < n_seg && __ballot(!done) != 0; seg += n_runs) {
+            const int seg_lo = max(walk_lo, seg * SEG);
+            const int ny = min(ny_all, (seg + 1) * SEG);   // this segment is [seg_lo, ny) of the walk
             for (int tb = seg_lo; tb < ny; tb += 64) {
                 const int st = tb + lane;
                 if (st < ny) {
@@ -2438,6 +2449,8 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
                 }
                 if (__ballot(!done) == 0) break;
                 WAVE_LDS_SYNC();
+            }
+            WAVE_LDS_SYNC();   // (the next segment stages its tile over this one)
             }
             const long long qv = __shfl(wave_sum_ll(accq), 0, 64);
             if (__ballot(bad) != 0 && lane == 0) nf_flag_ops(counters + NF_OFF, k, tk.minus ^ tk.plus);
@@ -3221,29 +3234,58 @@ int launch_scan(Ctx* h, int fA, const Neigh& nb, int K, int max_id, int dry, hip
 // how long a kernel waits for the scan's completion: a generous multiple of the time the streaming pass needs at 2 TB/s, plus launch slack
 int fin_wait_ticks(const Ctx* h) { return (int)std::min<long long>(100ll * 50 + (long long)(4.0 * 4.0 * (double)h->nnz / 2.0e12 * 1.0e8), 1ll << 30); }
 
-constexpr int FIN_BLOCKS_NO_WAIT = 3 * 256;   // largest k_fin grid that cannot keep k_tm off the chip (see launch_fin)
+// dynamic LDS of k_tm's finishing block: the pricing records of all K tables (see k_tm)
+constexpr size_t tm_fin_dyn_lds()
+{
+    return sizeof(PTask) * MAXK * PT_CAP + sizeof(unsigned short) * MAXK * N_PAIRS * PR_WORDS + sizeof(int) * MAXK + 16;
+}
+size_t fin_dyn_lds(int K) { return (size_t)K * (S_PER_K * sizeof(long long) + (MAX_TASKS + 1) * sizeof(int)); }   // K = 10: 37 KB
 
-int fin_blocks_cfg(const Ctx* h)
+// k_fin's blocks spin until k_tm has released the tables.  k_tm is launched first, on the other stream, but nothing guarantees
+// that its blocks are PLACED first: if k_fin's grid gets there first (a short scan) and fills every CU, k_tm's blocks have
+// nowhere to go, every block of k_fin spins to its bound and the step fails (seen: 2,048 blocks on the C2 stand-in -- registers;
+// and once in ~100 runs with 768 blocks after k_tm's LDS had grown -- LDS).  So the largest grid that may spin is the one that
+// leaves room for a block of k_tm on every CU, in registers AND in LDS, computed from the kernels' own attributes; a larger
+// grid is ordered behind k_tm by an event instead (launch_fin).
+int fin_blocks_no_wait(int K)
+{
+    static size_t lds_tm = 0, lds_fin = 0;
+    static int regs_tm = 0, regs_fin = 0;
+    if (lds_tm == 0) {
+        hipFuncAttributes a;
+        if (hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_tm)) == hipSuccess) { lds_tm = a.sharedSizeBytes; regs_tm = a.numRegs; }
+        if (hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_fin)) == hipSuccess) { lds_fin = a.sharedSizeBytes; regs_fin = a.numRegs; }
+        if (lds_tm == 0) lds_tm = 64 * 1024;
+        if (lds_fin == 0) lds_fin = 32 * 1024;
+        if (regs_tm <= 0) regs_tm = 128;
+        if (regs_fin <= 0) regs_fin = 128;
+    }
+    const size_t lds_cu = 160 * 1024;   // gfx950
+    const int regs_simd = 512;          // VGPRs per lane and SIMD; a 256-thread block puts one wave on each SIMD
+    const auto up8 = [](int r) { return (r + 7) & ~7; };
+    const int by_lds = (int)((lds_cu - std::min(lds_cu, lds_tm)) / (lds_fin + fin_dyn_lds(K)));
+    const int by_regs = (regs_simd - up8(regs_tm)) / up8(regs_fin);
+    return 256 * std::max(1, std::min(by_lds, by_regs));
+}
+
+int fin_blocks_cfg(const Ctx* h, int K)
 {
     static const int fin_blocks_env = getenv("GRAAL_FIN_BLOCKS") ? atoi(getenv("GRAAL_FIN_BLOCKS")) : 0;
-    // (contigs of thousands of fragments: the mass units are long dependent chains, 8 waves per SIMD keep the VALUs ~60 % busy
-    // where 2 waves reach ~50 % -- 2.8 -> 2.2 ms per step on C5's 7 contigs; with contigs of a few hundred fragments the larger
-    // grid only adds per-block set-up)
-    // (768 = 3 blocks per CU: the largest grid that may spin for k_tm's tables, see launch_fin)
-    return fin_blocks_env > 0 ? fin_blocks_env : (h->max_lcont > 0 && h->max_lcont <= 16 ? 32 : (h->max_lcont > 1024 ? 2048 : FIN_BLOCKS_NO_WAIT));
+    // short contigs leave k_fin a handful of contacts: a small grid keeps its launch and completion ticket cheap.  Contigs of a
+    // few hundred fragments: the largest grid that may spin for k_tm's tables (3 blocks per CU unless LDS allows fewer).
+    // Contigs of thousands of fragments: long dependent chains, 4 resident blocks per CU and fresh ones as they retire keep the
+    // VALUs busiest (2.8 -> 2.2 ms per step on C5's 7 contigs in round 1) -- that grid waits for k_tm through an event.
+    if (fin_blocks_env > 0) return fin_blocks_env;
+    if (h->max_lcont > 0 && h->max_lcont <= 16) return 32;
+    return h->max_lcont > 1024 ? 2048 : std::min(768, fin_blocks_no_wait(K));
 }
 
 // left-over mass items, queued contacts, hand-out.  Short contigs leave it a handful of contacts: a small grid keeps its
 // launch and completion ticket cheap; long contigs get the whole chip.
 int launch_fin(Ctx* h, int K, int rank, int world, long long* d_q_out, bool publish, hipStream_t st)
 {
-    const int fin_blocks = fin_blocks_cfg(h);
-    // k_fin's blocks spin until k_tm has released the tables.  k_tm is launched first, on the other stream, but nothing
-    // guarantees that its blocks are PLACED first: k_fin holds 116 VGPRs, four of its blocks fill a CU's register files, and a
-    // grid of more than 3 x 256 blocks that gets there first (a short scan) leaves no SIMD with the 96 VGPRs a wave of k_tm needs
-    // -- every block then spins to its bound and the step fails (seen with 2,048 blocks on the C2 stand-in).  Such a grid is
-    // ordered behind k_tm by an event instead (the regime where it is used has steps of hundreds of microseconds).
-    if (fin_blocks > FIN_BLOCKS_NO_WAIT) CK(hipStreamWaitEvent(st, h->ev_tm, 0));
+    const int fin_blocks = fin_blocks_cfg(h, K);
+    if (fin_blocks > fin_blocks_no_wait(K)) CK(hipStreamWaitEvent(st, h->ev_tm, 0));   // (see fin_blocks_no_wait)
     static const int fin_skip = getenv("GRAAL_FIN_SKIP") ? atoi(getenv("GRAAL_FIN_SKIP")) : 0;   // (diagnostics: wrong sums)
     FinArgs fa;
     fa.tm_done = h->tm_done; fa.step_hdr = h->step_hdr; fa.counters = (unsigned long long*)(h->d_scalars + 10); fa.queue = h->queue;
@@ -3251,8 +3293,9 @@ int launch_fin(Ctx* h, int K, int rank, int world, long long* d_q_out, bool publ
     static const int fin_seg = getenv("GRAAL_FIN_SEG") ? atoi(getenv("GRAAL_FIN_SEG")) : 0;
     fa.ln_tab = h->d_ln_tab; fa.lut_n = h->d_ln_tab ? h->ln_lut_n : 0; fa.skip = fin_skip; fa.seg = fin_seg;
     fa.norm_u = h->uniform_accu > 0 ? (float)(h->uniform_accu * h->uniform_accu) / h->nfpb : -1.0f;
-    const size_t fin_dyn_lds = (size_t)K * (S_PER_K * sizeof(long long) + (MAX_TASKS + 1) * sizeof(int));   // K = 10: 37 KB
-    k_fin<<<fin_blocks, 256, fin_dyn_lds, st>>>(h->d_args + h->cur, fa, K, rank, world, d_q_out, publish ? h->res_dev : nullptr, h->seq);
+    static const int fin_upw = getenv("GRAAL_FIN_UPW") ? std::max(1, atoi(getenv("GRAAL_FIN_UPW"))) : 4;
+    fa.upw = fin_upw;
+    k_fin<<<fin_blocks, 256, fin_dyn_lds(K), st>>>(h->d_args + h->cur, fa, K, rank, world, d_q_out, publish ? h->res_dev : nullptr, h->seq);
     CK(hipGetLastError());
     return GRAAL_OK;
 }
@@ -3920,9 +3963,9 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     ta.wait_ticks = fin_wait_ticks(h);
     ta.counters = (unsigned long long*)(h->d_scalars + 10); ta.queue = h->queue; ta.stat = h->stat_frag;
     ta.lcontbp = h->soa[h->cur].p[F_LCONTBP]; ta.acc = h->d_acc; ta.nfpb = h->nfpb; ta.par = h->par;
-    k_tm<<<K, 256, 0, h->aux>>>(A, ta, fA, nb, K, max_id, rank, world, h->seq);
+    k_tm<<<K, 256, ta.host_res ? tm_fin_dyn_lds() : 0, h->aux>>>(A, ta, fA, nb, K, max_id, rank, world, h->seq);
     CK(hipGetLastError());
-    if (ta.host_res == nullptr && !strict && fin_blocks_cfg(h) > FIN_BLOCKS_NO_WAIT) CK(hipEventRecord(h->ev_tm, h->aux));
+    if (ta.host_res == nullptr && !strict && fin_blocks_cfg(h, K) > fin_blocks_no_wait(K)) CK(hipEventRecord(h->ev_tm, h->aux));
     // (2) the streaming pass, with a HIP event pair around it on every event_every-th call
     const bool ev = h->want_events && (h->eval_calls % h->event_every == 0);
     h->eval_calls += 1;
@@ -3931,7 +3974,11 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     { int rc_ = launch_scan(h, fA, nb, K, max_id, 0, st, ta.host_res != nullptr); if (rc_) return rc_; }
     if (ev) { CK(hipEventRecord(h->ring[2 * slot + 1], st)); h->ring_calls += 1; }
     // (3) finishing kernel -- unless k_tm's last block does that job (it asks for k_fin through the result word if not)
-    if (h->has_rep) { // the repeated bins' pixels, densely, for all 13 K candidates (waits for k_tm's tables itself)
+    if (h->has_rep) { // the repeated bins' pixels, densely, for all 13 K candidates
+        // (its blocks wait for k_tm's tables too, and with 167 VGPRs three of them fill a CU's register files: ordered behind
+        // k_tm by the event rather than trusted to be placed after it -- see fin_blocks_no_wait)
+        CK(hipEventRecord(h->ev_tm, h->aux));
+        CK(hipStreamWaitEvent(st, h->ev_tm, 0));
         const RepArgs R = rep_args(h);
         k_rep_delta<<<blocks_for((long long)h->n_dup * h->n_bins * K, 256), 256, 0, st>>>(R, h->tabs, h->tm_done, h->seq, fA, K, rank, world,
                                                                                          h->d_acc, (unsigned long long*)(h->d_scalars + 10));
@@ -3941,7 +3988,7 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
         FinArgs fa;
         fa.tm_done = h->tm_done; fa.step_hdr = h->step_hdr; fa.counters = (unsigned long long*)(h->d_scalars + 10); fa.queue = h->queue;
         fa.tabs = h->tabs; fa.geo = h->geo; fa.stat = h->stat_frag; fa.acc = h->d_acc; fa.sync = h->d_sync;
-        fa.ln_tab = nullptr; fa.lut_n = 0; fa.skip = 0; fa.seg = 0; fa.norm_u = -1.0f;
+        fa.ln_tab = nullptr; fa.lut_n = 0; fa.skip = 0; fa.seg = 0; fa.norm_u = -1.0f; fa.upw = 4;
         StrictArgs sx;
         sx.perm = h->perm; sx.cbase = h->cbase; sx.lcontbp = h->soa[h->cur].p[F_LCONTBP]; sx.link = h->link; sx.nfpb = h->nfpb; sx.par = h->par;
         sx.quirk = (h->mode & GRAAL_MODE_REF_TRANS_ACCU) ? 1 : 0;
