@@ -1372,9 +1372,8 @@ __device__ __forceinline__ int gap_bp(const End& X, int len_x, const End& Y, int
 }
 
 
-// the queued contacts: 16 lanes per contact (lane & 15 = candidate op), 4 contacts per wave pass.  Everything a contact
-// needs is addressable from its queue entry, so the loads below go out together: entry -> {relation masks, geometry,
-// statistics, transforms} -> arithmetic.
+// ---- the queued contacts.  Everything a contact needs is addressable from its queue entry: entry -> {geometry, statistics,
+// the piece pair's task list} -> arithmetic.
 // what the pricing of a contact needs of a task, and of a piece pair's list: the finishing block of k_tm copies them into LDS
 // while it waits for the scan (price_contacts then has no dependent loads behind the queue entry and the two fragment records)
 struct PTask { int p; unsigned plus, minus; Xf xp, xq; };
@@ -2222,8 +2221,8 @@ __device__ __forceinline__ int sel_base(const int (&a)[MAXK + 1], int i)
 }
 
 // k_fin: (0) waits for k_tm's tables (normally long complete: k_tm was launched before k_scan); (1) the mass tasks k_tm
-// left over -- work item = (neighbour, task, chunk of 64 fragments of the task's first piece), one wave per item;
-// (2) the queued contacts -- 16 lanes per contact, lane = candidate op.
+// left over -- unit = (neighbour, task, chunk of 64 fragments of the task's larger piece, strided run of segments of the
+// other piece), one wave per unit; (2) the queued contacts -- lane = contact, one evaluation per distinct relation.
 // Completion: the last block to finish (ticket counter) reads the K*13 sums, zeroes the accumulators for the next step,
 // and hands the sums out: to d_q_out (device; the caller all-reduces them) or, if host_res is given, to PINNED HOST
 // memory followed by the step's sequence number -- the host spins on that word instead of paying for a device->host
