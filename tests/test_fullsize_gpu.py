@@ -224,3 +224,48 @@ def test_full_evaluation_with_labels_in_lds_is_bit_identical():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "full_l_check.py")], cwd=root, capture_output=True, text=True, timeout=1100)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
     assert "bit-identical sums" in out.stdout
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE config 4 shape, mid-run
+# 40,000 bins x 1 sub-fragment, 8,000,000 contacts (tools/run_configs.py C4), on grid coordinates, after one full cycle from
+# the exploded genome: ~3,000 contigs of a few to ~100 bins.  Here most steps leave k_tm's thresholds and are finished by
+# k_fin after its verdict (tools/c4_trace.sh: 69 % of the steps) -- the path neither the exploded C5 state (finisher) nor its 7
+# original contigs (k_fin launched unconditionally) take.  The dense oracle cannot run at this size: properties.
+@pytest.mark.timeout(900)
+def test_c4_shape_mid_run_properties():
+    import bench
+    from graal_amd import synth
+    P = synth.make_problem(n_bins=40000, nnz=8_000_000, n_sub=1, seed=2014, contig_weights=(6.8, 6.2, 5.3, 4.6, 4.0, 3.4, 2.7),
+                           grid_bp=1000)
+    P["S_o_A_frags"] = bench.exploded_layout(P)
+    rng = np.random.RandomState(41)
+    smp = bench.build_sampler(P, rng, None, 0)
+    smp.init_likelihood()
+    n = int(smp.n_new_frags)
+    order = np.arange(n, dtype=np.int32)
+    rng.shuffle(order)
+    for i in order:                                   # one cycle: 40,000 MCMC steps
+        smp.step_max_likelihood(int(i), 5)
+    st = smp.engine.layout_stats()
+    assert 500 < int(st[0]) < 20000 and int(st[4]) > 16          # contigs have grown, the longest beyond the finisher's regime
+    carried = smp.likelihood_t
+    full = smp.eval_likelihood()
+    assert carried == pytest.approx(full, rel=1e-8)              # 40,000 accumulated deltas vs one full evaluation
+    needed_fin = 0
+    for fA in rng.randint(0, n, size=40):
+        fA = int(fA)
+        max_id = smp.modify_gl_cuda_buffer(0)
+        before = smp._full_likelihood()
+        nb = smp.return_neighbours(fA, 5); nb.sort()
+        d = smp._candidate_deltas(fA, nb, max_id)
+        c = smp.engine.last_counters()
+        needed_fin += (c[2] > 64) or (c[3] > 0)
+        smp.engine.set_finisher(False)
+        assert np.array_equal(d, smp._candidate_deltas(fA, nb, max_id))      # k_tm's finisher == k_fin, bit for bit
+        smp.engine.set_finisher(True)
+        k, op = np.unravel_index(np.argmax(np.abs(d)), d.shape)
+        smp.test_copy_struct(fA, nb[k], int(op), max_id)
+        after = smp.eval_likelihood()
+        assert abs(d[k, op] - (after - before)) / abs(before) < 1e-8, (fA, nb[k], op, d[k, op], after - before)
+    assert needed_fin >= 10                                       # the regime this test is about did occur
+    smp.free_gpu()
