@@ -1504,16 +1504,21 @@ __device__ __forceinline__ void price_contacts(const PriceArgs& pa, unsigned lon
 // K x (MAX_TASKS + N_PAIRS) words) and folded into the per-candidate sums with the tasks' masks once per block
 // (fold_contact_sums).  Short queues: B < 64 contacts per wave and 64 / B lanes per contact, which share its relations.
 constexpr int S_PER_K = MAX_TASKS + N_PAIRS;
-__device__ __forceinline__ void price_contacts_bulk(const PriceArgs& pa, long long* __restrict__ S, const double* __restrict__ ln_tab, int lut_n,
-                                                    unsigned long long nq_total, int first, int n_waves, int lane)
+constexpr int N_WQ = 8, WQ_STRIDE = 16;   // k_fin's work queues: classes of units (U % N_WQ), one counter (on its own line) each
+__device__ __forceinline__ int contact_batch_size(unsigned long long nq_total, int n_waves)
 {
-    const int B = nq_total >= 64ull * (unsigned long long)n_waves ? 64 : (nq_total >= 16ull * (unsigned long long)n_waves ? 16 : 4);
+    return nq_total >= 64ull * (unsigned long long)n_waves ? 64 : (nq_total >= 16ull * (unsigned long long)n_waves ? 16 : 4);
+}
+// one batch: the B queue entries from b0 on
+__device__ __forceinline__ void price_contact_batch(const PriceArgs& pa, long long* __restrict__ S, const double* __restrict__ ln_tab, int lut_n,
+                                                    unsigned long long nq_total, unsigned long long b0, int B, int lane)
+{
     const int ent = lane % B, slice = lane / B, n_slices = 64 / B;
-    for (unsigned long long b0 = (unsigned long long)first * B; b0 < nq_total; b0 += (unsigned long long)n_waves * B) {
+    {
         const unsigned long long e = b0 + ent;
-        if (e >= nq_total) continue;
+        if (e >= nq_total) return;
         const QEntry qe = pa.queue[e];
-        if (qe.rel == 0) continue; // (a reserved slot whose contact failed the scan's third test)
+        if (qe.rel == 0) return; // (a reserved slot whose contact failed the scan's third test)
         const int fx = qe.fx, fy = qe.fy;
         ContactVals cv = {pa.geo[fx], pa.geo[fy], pa.stat[fx], pa.stat[fy], qe.slots & 3, (qe.slots >> 2) & 3,
                           (double)__int_as_float(qe.cnt), 0, 0, 0, 0, 0, 0, 0, 0};
@@ -2243,6 +2248,7 @@ struct FinArgs { // first-needed pointers by value (see ScanArgs)
     int seg;                       // fragments y per mass unit (0: chosen per step)
     float norm_u;                  // >= 0: every sub-fragment has the same RF count a, and this is float(a * a) / nfpb
     int upw;                       // mass units per wave of the grid the unit size aims at
+    unsigned long long* wq;        // work-queue counters: N_WQ for the mass units, N_WQ for the contact batches, WQ_STRIDE words apart (nullptr: static deal)
 };
 
 __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinArgs fa, int K, int rank, int world,
@@ -2336,6 +2342,7 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
         // contiguous runs would be a lottery; strided ones cost about the same, end at the window (a lane that has left the
         // window stays out: distances only grow along the walk), and load x once per run.  LRUN = segments per run.
         int SEG = fa.seg, LRUN = 1;
+        bool long_units = false;   // units of hundreds of fragments y each: worth a draw from a work queue
         if (SEG <= 0) {
             long long w_all = 0;
             for (int k = 0; k < K; k++) w_all += s_wt[k];
@@ -2343,6 +2350,7 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
             SEG = multi_sub ? 2 : 16;
             while (SEG < (multi_sub ? 16 : 64) && 2 * SEG <= per_unit / 2) SEG <<= 1;
             LRUN = (int)(per_unit / SEG > 1 ? (per_unit / SEG > 4096 ? 4096 : per_unit / SEG) : 1);
+            long_units = per_unit >= 512;
         }
         auto runs_of = [&](int walk) { const int n_seg = max(1, (walk + SEG - 1) / SEG); return min(n_seg, (n_seg + LRUN - 1) / LRUN); };
 #pragma unroll
@@ -2368,7 +2376,37 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
         // (static deal.  Handing the units out through one global counter -- they differ by orders of magnitude, and the slowest
         // block of a C2 step ends 100 us after the typical one -- was measured: 2,048 waves queueing on one address cost more
         // than the imbalance, 175 -> 201 us per step.)
-        for (int U = rank + world * wave; U < ((fa.skip & 1) ? 0 : total_units); U += world * n_waves) {
+        // Hand-out.  Units differ in cost by an order of magnitude (beyond the window: nothing; circular contig, nine slot pairs: a
+        // long chain) and a wave gets only ~4 of them: dealt statically, the slowest block of a C2 step worked five times as long as
+        // the median one.  So the units of this rank (v = 0, 1, ...: U = rank + world v) form N_WQ classes v % N_WQ, each with a
+        // counter of its own; a wave draws from its class, then from the others.  The next draw is in flight while a unit is
+        // priced.  Only when units are long (the late stage: 0.95 -> 0.90 ms per step): a draw is a device-scope atomic with
+        // return, 2-3 us, and with units of a few microseconds the queue costs far more than the imbalance (C2 stand-in 88 -> 140
+        // us, C4 122 -> 165 us per step with every unit drawn; one counter for everything, round 1: 175 -> 201 us).  Otherwise the
+        // static deal: wave w takes v = w, w + n_waves, ...
+        const long long n_virtual = (fa.skip & 1) ? 0 : ((long long)total_units - rank + world - 1) / world;
+        int cls = wave % N_WQ, tried = 0;
+        unsigned long long* const wq = long_units ? fa.wq : nullptr;
+        long long pend = wq ? 0 : wave;
+        if (wq && lane == 0) pend = (long long)atomicAdd(&fa.wq[cls * WQ_STRIDE], 1ull);
+        for (;;) {
+            long long v;
+            if (wq) {
+                const long long j = __shfl(pend, 0, 64);
+                v = cls + (long long)N_WQ * j;
+                if (v >= n_virtual) {   // this class is used up: on to the next one
+                    if (++tried == N_WQ) break;
+                    cls = (cls + 1) % N_WQ;
+                    if (lane == 0) pend = (long long)atomicAdd(&wq[cls * WQ_STRIDE], 1ull);
+                    continue;
+                }
+                if (lane == 0) pend = (long long)atomicAdd(&wq[cls * WQ_STRIDE], 1ull);
+            } else {
+                v = pend;
+                if (v >= n_virtual) break;
+                pend += n_waves;
+            }
+            const int U = (int)(rank + world * v);
             int k = 0;
             for (int j = 1; j < K; j++) k += (U >= s_ubase[j]) ? 1 : 0;
             const int u = U - s_ubase[k];
@@ -2467,7 +2505,27 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
         pa.queue = queue; pa.tabs = tabs; pa.geo = geo; pa.stat = stat; pa.lcontbp = lcontbp; pa.out = s_accb; pa.nf = counters + NF_OFF; pa.nfpb = nfpb; pa.par = par;
         // (batches of queued contacts continue the round robin where this rank's mass units ended)
         const int mass_slots = (int)(((long long)total_units - rank + world - 1) / world % n_waves);
-        if (!(fa.skip & 2)) price_contacts_bulk(pa, S, fa.ln_tab, fa.lut_n, nq_total, (wave - mass_slots + n_waves) % n_waves, n_waves, lane);
+        const int B = contact_batch_size(nq_total, n_waves);
+        const long long n_batches = (fa.skip & 2) ? 0 : (long long)((nq_total + (unsigned long long)B - 1ull) / (unsigned long long)B);
+        if (fa.wq && B == 64) {   // (millions of queued contacts: drawn like the units, from the second set of counters)
+            int cls2 = wave % N_WQ, tried2 = 0;
+            long long pend2 = 0;
+            if (lane == 0) pend2 = (long long)atomicAdd(&fa.wq[(N_WQ + cls2) * WQ_STRIDE], 1ull);
+            for (;;) {
+                const long long b = cls2 + (long long)N_WQ * __shfl(pend2, 0, 64);
+                if (b >= n_batches) {
+                    if (++tried2 == N_WQ) break;
+                    cls2 = (cls2 + 1) % N_WQ;
+                    if (lane == 0) pend2 = (long long)atomicAdd(&fa.wq[(N_WQ + cls2) * WQ_STRIDE], 1ull);
+                    continue;
+                }
+                if (lane == 0) pend2 = (long long)atomicAdd(&fa.wq[(N_WQ + cls2) * WQ_STRIDE], 1ull);
+                price_contact_batch(pa, S, fa.ln_tab, fa.lut_n, nq_total, (unsigned long long)b * (unsigned long long)B, B, lane);
+            }
+        } else {
+            for (long long b = (wave - mass_slots + n_waves) % n_waves; b < n_batches; b += n_waves)
+                price_contact_batch(pa, S, fa.ln_tab, fa.lut_n, nq_total, (unsigned long long)b * (unsigned long long)B, B, lane);
+        }
         STAMP(13, blockIdx.x == 0 && threadIdx.x == 0);
         STAMP_FBLK(2, threadIdx.x == 0);
         __syncthreads();
@@ -2495,6 +2553,7 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
     if (!s_last) return;
     STAMP(19, threadIdx.x == 0);
     __threadfence();
+    if (fa.wq && threadIdx.x < 2 * N_WQ) atomicExch(&fa.wq[threadIdx.x * WQ_STRIDE], 0ull);   // (every wave has made its last draw)
     hand_out(out, counters, fa.sync, K, d_q_out, host_res, seq);
     STAMP(21, threadIdx.x == 0);
 #undef USTART
@@ -3015,6 +3074,7 @@ struct Ctx {
     unsigned* d_flags = nullptr;          // k_scan's per-block completion flags
     unsigned long long scan_done_total[N_DONE] = {}; // per completion counter: blocks of all non-dry scans launched so far
     unsigned long long* d_done = nullptr;    // the N_DONE completion counters of k_scan, DONE_STRIDE words apart
+    unsigned long long* d_wq = nullptr;      // k_fin's work-queue counters (2 x N_WQ, WQ_STRIDE words apart), zero at rest
     int mode = 0;                 // GRAAL_MODE_* flags (graal_set_mode)
     unsigned scan_token = 0x5ca90000u; // k_scan launches so far (ScanArgs.token)
     double* d_ln_tab = nullptr;   // [LN_TRANS_LUT] ln of the trans value by RF-count product (k_ln_tab; rebuilt by sync_args)
@@ -3294,6 +3354,8 @@ int launch_fin(Ctx* h, int K, int rank, int world, long long* d_q_out, bool publ
     fa.norm_u = h->uniform_accu > 0 ? (float)(h->uniform_accu * h->uniform_accu) / h->nfpb : -1.0f;
     static const int fin_upw = getenv("GRAAL_FIN_UPW") ? std::max(1, atoi(getenv("GRAAL_FIN_UPW"))) : 4;
     fa.upw = fin_upw;
+    static const bool fin_static = getenv("GRAAL_FIN_STATIC") != nullptr;   // (units and contact batches dealt statically)
+    fa.wq = fin_static ? nullptr : h->d_wq;
     k_fin<<<fin_blocks, 256, fin_dyn_lds(K), st>>>(h->d_args + h->cur, fa, K, rank, world, d_q_out, publish ? h->res_dev : nullptr, h->seq);
     CK(hipGetLastError());
     return GRAAL_OK;
@@ -3383,6 +3445,8 @@ int graal_create(int device, graal_ctx** out)
     CK(hipMemset(h->d_acc, 0, MAXK * N_OPS * sizeof(long long)));
     CK(hipMalloc(&h->tm_done, MAXK * sizeof(long long)));
     CK(hipMemset(h->tm_done, 0, MAXK * sizeof(long long)));
+    CK(hipMalloc(&h->d_wq, 2 * N_WQ * WQ_STRIDE * sizeof(unsigned long long)));
+    CK(hipMemset(h->d_wq, 0, 2 * N_WQ * WQ_STRIDE * sizeof(unsigned long long)));
     CK(hipMalloc(&h->d_done, N_DONE * DONE_STRIDE * sizeof(unsigned long long)));
     CK(hipMemset(h->d_done, 0, N_DONE * DONE_STRIDE * sizeof(unsigned long long)));
     CK(hipMalloc(&h->d_sync, 32 * sizeof(unsigned long long)));
@@ -3422,7 +3486,7 @@ void graal_destroy(graal_ctx* h)
         (void)hipSetDevice(h->device);
         (void)hipStreamSynchronize(h->stream);
         if (h->aux) (void)hipStreamSynchronize(h->aux);
-        void* ptrs[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->stat, h->sub_rec, h->sub_rec8, h->sub_lab16, h->d_ubins, h->d_ln_tab, h->sub2bin, h->row, h->col, h->cnt, h->queue, h->d_sub_ids, h->d_acc, h->tm_done, h->d_sync, h->d_done, h->d_flags, h->stat_frag, h->d_dup_bins, h->d_dup_index,
+        void* ptrs[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->stat, h->sub_rec, h->sub_rec8, h->sub_lab16, h->d_ubins, h->d_ln_tab, h->sub2bin, h->row, h->col, h->cnt, h->queue, h->d_sub_ids, h->d_acc, h->tm_done, h->d_sync, h->d_done, h->d_wq, h->d_flags, h->stat_frag, h->d_dup_bins, h->d_dup_index,
                         h->d_dispatcher, h->d_collector, h->d_sub_ids_all, h->d_rep_obs,
                         h->keys, h->keys_sorted, h->o2n, h->len_of2[0], h->len_of2[1], h->contig_off2[0], h->contig_off2[1], h->perm, h->cbase, h->link, h->mates, h->cub_tmp, h->tabs, h->step_hdr, h->d_args, h->d_chg,
                         h->d_scalars, h->d_qout, h->d_dref, h->d_dist};
@@ -3987,7 +4051,7 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
         FinArgs fa;
         fa.tm_done = h->tm_done; fa.step_hdr = h->step_hdr; fa.counters = (unsigned long long*)(h->d_scalars + 10); fa.queue = h->queue;
         fa.tabs = h->tabs; fa.geo = h->geo; fa.stat = h->stat_frag; fa.acc = h->d_acc; fa.sync = h->d_sync;
-        fa.ln_tab = nullptr; fa.lut_n = 0; fa.skip = 0; fa.seg = 0; fa.norm_u = -1.0f; fa.upw = 4;
+        fa.ln_tab = nullptr; fa.lut_n = 0; fa.skip = 0; fa.seg = 0; fa.norm_u = -1.0f; fa.upw = 4; fa.wq = nullptr;
         StrictArgs sx;
         sx.perm = h->perm; sx.cbase = h->cbase; sx.lcontbp = h->soa[h->cur].p[F_LCONTBP]; sx.link = h->link; sx.nfpb = h->nfpb; sx.par = h->par;
         sx.quirk = (h->mode & GRAAL_MODE_REF_TRANS_ACCU) ? 1 : 0;
