@@ -417,6 +417,21 @@ GR_HD bool rel_changed(const Xf& p_old, const Xf& q_old, const Xf& p_new, const 
     return rho_old != rho_new || d_old != d_new;
 }
 
+// Reference arithmetic (GRAAL_MODE_STRICT): do two layouts hand the contact model the SAME INPUTS for every fragment pair of
+// pieces (p, q)?  The dense reference prices a pixel from the float32 kb coordinates of its two fragments, so -- unlike
+// rel_changed -- the absolute offsets matter, not only the relative map (kernels3.cu:2997-3078).  Equal inputs = bit-equal
+// values; anything else is priced again.  A trans pair has no geometry; with the reference's RF-count indexing in the trans
+// branch (`quirk`, kernels3.cu:3155) its value depends on the orientation of the lower-id bin, i.e. on the two mirrors.
+GR_HD bool same_inputs(const Xf& p1, const Xf& q1, const Xf& p2, const Xf& q2, bool quirk)
+{
+    const bool cis1 = p1.label == q1.label, cis2 = p2.label == q2.label;
+    if (cis1 != cis2) return false;
+    if (!cis1) return !quirk || (p1.sigma == p2.sigma && q1.sigma == q2.sigma);
+    if (p1.sigma != p2.sigma || q1.sigma != q2.sigma || p1.off != p2.off || q1.off != q2.off) return false;
+    if (p1.circ != p2.circ) return false;
+    return p1.circ != 1 || p1.lbp == p2.lbp;
+}
+
 // geometry inside ONE piece changes only through the circular model (or if the piece is torn, which
 // cannot happen: pieces are the tear units)
 GR_HD bool intra_changed(const Xf& p_old, const Xf& p_new)

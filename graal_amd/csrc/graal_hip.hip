@@ -139,6 +139,7 @@ __device__ __forceinline__ float sel3(float x0, float x1, float x2, int i) { ret
 __device__ __forceinline__ int sel3(int x0, int x1, int x2, int i) { return i == 0 ? x0 : (i == 1 ? x1 : x2); }
 __device__ __forceinline__ float stat_len(const Stat& s, int i) { return sel3(s.l0, s.l1, s.l2, i); }
 __device__ __forceinline__ int stat_accu(const Stat& s, int i) { return sel3(s.a0, s.a1, s.a2, i); }
+__device__ __forceinline__ bool stat_uniform(const Stat& s) { return (s.n < 2 || s.a1 == s.a0) && (s.n < 3 || s.a2 == s.a0); } // equal RF counts
 
 // centre (kb) of the sub-fragment stored in data slot `slot`, walking the bin in its orientation with
 // the reference's float32 operation order (kernels3.cu:2997-3060)
@@ -165,6 +166,13 @@ __device__ __forceinline__ End end_cur(const Geo& g, const int* __restrict__ lco
 {
     End e; e.label = g.id_c; e.start_bp = g.start_bp; e.fwd = g.flags & 1; e.circ = (g.flags >> 1) & 1;
     e.lbp = e.circ ? lcontbp[f] : 0;
+    return e;
+}
+
+// the same with the contig length handed in (0 unless the contig is circular)
+__device__ __forceinline__ End end_old(const Geo& g, int lbp)
+{
+    End e; e.label = g.id_c; e.start_bp = g.start_bp; e.fwd = g.flags & 1; e.circ = (g.flags >> 1) & 1; e.lbp = lbp;
     return e;
 }
 
@@ -228,6 +236,22 @@ __device__ __forceinline__ float ex_pair_ref(const End& X, const Stat& sx, int s
         return p.v_inter * ((float)(ax * ay) / nfpb);
     }
     return ex_pair(X, sx, slx, Y, sy, sly, nfpb, p);
+}
+
+// Reference arithmetic, one fragment pair under one candidate class: sum over its slot pairs of (old value - new value), both
+// priced from the float32 coordinates of their layout (kernels3.cu:3383-3697 against the stored evaluate_likelihood value),
+// rounded to Q once per fragment pair.  X0 / Y0: the two fragments in the current layout, X / Y: under the candidate.
+__device__ __forceinline__ long long strict_pair_q(const End& X0, const End& Y0, const End& X, const End& Y, const Stat& sx, int fx,
+                                                   const Stat& sy, int fy, float nfpb, const Par& par, bool quirk)
+{
+    double acc = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++)
+            if (a < sx.n && b < sy.n)
+                acc += (double)ex_pair_ref(X0, sx, a, fx, Y0, sy, b, fy, nfpb, par, quirk) - (double)ex_pair_ref(X, sx, a, fx, Y, sy, b, fy, nfpb, par, quirk);
+    return to_q(acc);
 }
 
 // "This thread's device-scope atomics have been performed."  They execute at the memory side, and on gfx9 the vector-memory
@@ -1028,6 +1052,7 @@ struct Task {            // windowed cis sum between piece p and piece q in one 
 };
 constexpr int ITEM_CAP = 2048;     // work items per neighbour with a direct item -> task table (else: binary search)
 constexpr int INLINE_PAIRS = 1024; // fragment pairs per neighbour that the table block prices itself (k_tm)
+constexpr int STRICT_INLINE_M = 20;  // reference arithmetic: affected sets up to this many fragments are priced by the table block (190 pairs x 13)
 
 struct NbTables {        // everything the finishing kernel needs about one neighbour
     PieceKey key;
@@ -1049,8 +1074,16 @@ struct NbTables {        // everything the finishing kernel needs about one neig
     unsigned short pair_task[N_PAIRS][N_OPS];
     unsigned short pair_owner[N_PAIRS][N_OPS];      // per candidate: the task of the pair's new cis relation under it (0xffff: trans, or unchanged)
     unsigned item_tc[ITEM_CAP];        // task | chunk << 16 of item w (valid when n_items <= ITEM_CAP)
+    // reference arithmetic (GRAAL_MODE_STRICT): the 13 candidates in classes of equal contact-model inputs per piece pair
+    // (same_inputs).  crep[pair][op] = the first candidate with the same inputs as `op` (its class representative: the class is
+    // priced once, under it), CREP_OLD = the same inputs as the current layout (nothing to price); cmask[pair][rep] = the
+    // candidates of that class
+    unsigned char crep[N_PAIRS][N_OPS];
+    unsigned short cmask[N_PAIRS][N_OPS];
+    int set_m;                         // strict: fragments of contig(fA) u contig(fB) that are left to k_strict (0: priced by k_tm, or fB == fA)
     Task task[MAX_TASKS];
 };
+constexpr unsigned char CREP_OLD = 0xff;
 
 // LDS hand-over between the lanes of ONE wave: LDS operations of a wave execute in program order, so no hardware barrier is
 // needed -- only the compiler must not move them across lanes' dependencies
@@ -1120,9 +1153,16 @@ struct SmallCtx {
 
 // one block builds everything about one neighbour; tasks are left in s_task (LDS) too, with the exclusive prefix of
 // their fragment-pair counts in s_pp.  Returns the number of tasks.
+struct TabViews {   // what the strict pricing of k_tm reads of the block's tables (LDS)
+    const Xf* xf;                  // [N_OPS][NP]
+    const Xf* xf_old;              // [NP]
+    const unsigned char* crep;     // [N_PAIRS][N_OPS]
+    const unsigned* cmask;         // [N_PAIRS][N_OPS]
+    const Rec *A0, *B0;
+};
 __device__ int tables_block(const Geo* __restrict__ geo, const Link* __restrict__ link, const int* __restrict__ cbase,
                             const int* __restrict__ mates, const Stat* __restrict__ stat, int fA, int fB, int max_id, NbTables& T,
-                            int k, int* __restrict__ step_hdr, Task* s_task, int* s_pp, SmallCtx& sc)
+                            int k, int* __restrict__ step_hdr, Task* s_task, int* s_pp, SmallCtx& sc, int strict, int quirk, TabViews& tv)
 {
     __shared__ Rec A0, B0;
     __shared__ int s_baseA, s_baseB;
@@ -1205,6 +1245,28 @@ __device__ int tables_block(const Geo* __restrict__ geo, const Link* __restrict_
     }
     __syncthreads();
     STAMP(26, k == 0 && t == 0); // transforms
+    __shared__ unsigned char s_crep[N_PAIRS][N_OPS];
+    __shared__ unsigned s_cmask[N_PAIRS][N_OPS];
+    tv.xf = &xf[0][0]; tv.xf_old = xf_old; tv.crep = &s_crep[0][0]; tv.cmask = &s_cmask[0][0]; tv.A0 = &A0; tv.B0 = &B0;
+    if (strict) {   // classes of equal contact-model inputs (see NbTables::crep): one thread per (piece pair, candidate)
+        for (int e = t; e < N_PAIRS * N_OPS; e += blockDim.x) s_cmask[e / N_OPS][e % N_OPS] = 0;
+        __syncthreads();
+        for (int e = t; e < N_PAIRS * N_OPS; e += blockDim.x) {
+            const int pair = e / N_OPS, op = e - pair * N_OPS;
+            int p, q;
+            pair_of_index(pair, p, q);
+            int r = op;
+            if (rep[p] < 0 || rep[q] < 0 || same_inputs(xf_old[p], xf_old[q], xf[op][p], xf[op][q], quirk != 0)) r = CREP_OLD;
+            else
+                for (int o = 0; o < op; o++)
+                    if (same_inputs(xf[o][p], xf[o][q], xf[op][p], xf[op][q], quirk != 0)) { r = o; break; }
+            s_crep[pair][op] = (unsigned char)r;
+            T.crep[pair][op] = (unsigned char)r;
+            if (r != CREP_OLD) atomicOr(&s_cmask[pair][r], 1u << op);
+        }
+        __syncthreads();
+        for (int e = t; e < N_PAIRS * N_OPS; e += blockDim.x) T.cmask[e / N_OPS][e % N_OPS] = (unsigned short)s_cmask[e / N_OPS][e % N_OPS];
+    }
     // relations: one thread per (op, p <= q)
     for (int e = t; e < N_OPS * NPAIR; e += blockDim.x) {
         const int op = e / NPAIR;
@@ -1498,6 +1560,43 @@ __device__ __forceinline__ void price_contacts(const PriceArgs& pa, unsigned lon
     }
 }
 
+// Reference arithmetic, a few queued contacts (the finishing block of k_tm): 16 lanes per contact, lane = candidate.  The scan
+// queued every contact with both ends in some neighbour's affected set; each is priced again under every candidate whose
+// inputs differ from the current layout's:  ob (ln ex_new - ln ex_old)  (kernels3.cu:3383-3697).
+__device__ __forceinline__ void price_contacts_strict(const QEntry* __restrict__ queue, const NbTables* __restrict__ tabs, const Geo* __restrict__ geo,
+                                                      const Stat* __restrict__ stat, const int* __restrict__ lcontbp, long long* __restrict__ out,
+                                                      unsigned long long* __restrict__ nf, float nfpb, const Par& par, bool quirk,
+                                                      unsigned long long nq_total, int first, int n_waves, int lane)
+{
+    const int op = lane & 15;
+    for (unsigned long long e0 = (unsigned long long)first * 4; e0 < nq_total; e0 += (unsigned long long)n_waves * 4) {
+        const unsigned long long e = e0 + (lane >> 4);
+        if (e >= nq_total || op >= N_OPS) continue;
+        const QEntry qe = queue[e];
+        if (qe.rel == 0) continue;
+        const int fx = qe.fx, fy = qe.fy, slx = qe.slots & 3, sly = (qe.slots >> 2) & 3;
+        const Geo gx = geo[fx], gy = geo[fy];
+        const Stat sx = stat[fx], sy = stat[fy];
+        const End X0 = end_old(gx, ((gx.flags >> 1) & 1) ? lcontbp[fx] : 0), Y0 = end_old(gy, ((gy.flags >> 1) & 1) ? lcontbp[fy] : 0);
+        const float ex_old = ex_pair_ref(X0, sx, slx, fx, Y0, sy, sly, fy, nfpb, par, quirk);
+        const double ln_old = log((double)ex_old), ob = (double)__int_as_float(qe.cnt);
+        unsigned rel = qe.rel;
+        while (rel) {
+            const int k = (__ffs((int)rel) - 1) / CODE_BITS;
+            rel &= rel - 1;
+            const int p = (qe.ci >> (CODE_BITS * k)) & 7, q = (qe.cj >> (CODE_BITS * k)) & 7;
+            const NbTables& T = tabs[k];
+            if (T.crep[pair_index(p, q)][op] == CREP_OLD) continue;   // the inputs of the current layout: the same value
+            const End X = end_xf(gx, T.xf[op][p]), Y = end_xf(gy, T.xf[op][q]);
+            const float ex_new = ex_pair_ref(X, sx, slx, fx, Y, sy, sly, fy, nfpb, par, quirk);
+            if (ex_new == ex_old) continue;
+            const long long qv = to_q(ob * (log((double)ex_new) - ln_old));
+            if (qv == Q_BAD) nf_flag(nf, k, op);
+            else if (qv != 0) atomicAdd((unsigned long long*)&out[k * N_OPS + op], (unsigned long long)qv);
+        }
+    }
+}
+
 // MANY queued contacts (k_fin; long contigs queue millions per step and this pricing was a third of the step): lane = contact,
 // and a contact is evaluated once per distinct relation, not once per candidate -- the 13 candidates of a neighbour lead to a
 // handful of distinct relations of a piece pair.  The values are added per (neighbour, task) / (neighbour, pair) in LDS (`S`:
@@ -1643,7 +1742,9 @@ struct TmArgs { // first-needed pointers by value (see ScanArgs)
     int n_done;
     unsigned long long done_target[N_DONE];
     int wait_ticks;                // how long that block waits for k_scan (100 MHz ticks)
-    int strict;                    // GRAAL_MODE_STRICT: tables only (k_strict prices everything)
+    int strict;                    // GRAAL_MODE_STRICT: reference arithmetic (same_inputs classes; small sets priced here, the rest by k_strict)
+    int quirk;                     // GRAAL_MODE_REF_TRANS_ACCU
+    int strict_inline_m;           // largest affected set k_tm prices itself in reference arithmetic (-1: none, k_strict_dense validation)
     // the finishing block's pointers, by value too
     unsigned long long* counters;
     const QEntry* queue;
@@ -1671,11 +1772,67 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
     __shared__ SmallCtx sc;
     __shared__ long long s_acc[N_OPS];
     if (t < N_OPS) s_acc[t] = 0;
-    const int n_tasks = tables_block(ta.geo, ta.link, ta.cbase, ta.mates, ta.stat, fA, my_fB, max_id, T, k, ta.step_hdr, s_task, s_pp, sc);
+    TabViews tv;
+    const int n_tasks = tables_block(ta.geo, ta.link, ta.cbase, ta.mates, ta.stat, fA, my_fB, max_id, T, k, ta.step_hdr, s_task, s_pp, sc,
+                                     ta.strict, ta.quirk, tv);
     const int total = s_pp[n_tasks];
-    const bool inl = total <= INLINE_PAIRS && !ta.strict;
+    // reference arithmetic: the set is contig(fA) u contig(fB), every pair of different bins in it is priced under every class
+    const int s_lenA = sc.len[0], s_lenB = (my_fB == fA || tv.B0->id_c == tv.A0->id_c) ? 0 : sc.len[1];
+    const int s_m = my_fB == fA ? 0 : s_lenA + s_lenB;
+    const int s_pairs = s_m * (s_m - 1) / 2;   // (only used when small)
+    const bool inl = ta.strict ? s_m <= ta.strict_inline_m : total <= INLINE_PAIRS;
+    if (ta.strict && t == 0) T.set_m = inl ? 0 : s_m;
     STAMP(1, k == 0 && t == 0);
-    if (inl && total > 0) {
+    if (ta.strict && inl && s_m > 1) {
+        const int* __restrict__ perm = A->perm;
+        const Geo* __restrict__ geo = ta.geo;
+        const Stat* __restrict__ stat = ta.stat;
+        const float nfpb = ta.nfpb;
+        const Par par = ta.par;
+        const int reach_bp = A->reach_bp;
+        const bool quirk = ta.quirk != 0;
+        const Rec A0 = *tv.A0, B0 = *tv.B0;
+        const PieceKey key = T.key;
+        for (int it = rank + world * t; it < s_pairs * N_OPS; it += world * (int)blockDim.x) {
+            const int e = it / N_OPS, op = it - e * N_OPS;
+            int j = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)e)) * 0.5f);   // pair e = (i < j): j (j - 1) / 2 <= e < j (j + 1) / 2
+            while (j * (j - 1) / 2 > e) j--;
+            while (j * (j + 1) / 2 <= e) j++;
+            const int i = e - j * (j - 1) / 2;
+            Geo gx, gy;
+            Stat sx, sy;
+            int fx, fy;
+            if (sc.small) {   // both contigs sit in LDS, in position order
+                const int wx = i < s_lenA ? 0 : 1, wy = j < s_lenA ? 0 : 1;
+                const int ix = i - wx * s_lenA, iy = j - wy * s_lenA;
+                fx = sc.mates[wx][ix]; fy = sc.mates[wy][iy];
+                gx = sc.geo[wx * N_MATES + ix]; gy = sc.geo[wy * N_MATES + iy]; sx = sc.stat[wx * N_MATES + ix]; sy = sc.stat[wy * N_MATES + iy];
+            } else {
+                fx = perm[i < s_lenA ? sc.base[0] + i : sc.base[1] + (i - s_lenA)];
+                fy = perm[j < s_lenA ? sc.base[0] + j : sc.base[1] + (j - s_lenA)];
+                gx = geo[fx]; gy = geo[fy]; sx = stat[fx]; sy = stat[fy];
+            }
+            if (sx.n == 0 || sy.n == 0) continue;   // (copies of repeated bins: priced by k_rep_delta)
+            const int px = piece_of(key, gx.id_c, geo_pos(gx.flags)), py = piece_of(key, gy.id_c, geo_pos(gy.flags));
+            const int pr = pair_index(px, py);
+            if (tv.crep[pr * N_OPS + op] != op) continue;   // not the representative of its class (or: the inputs of the current layout)
+            const End X0 = end_old(gx, ((gx.flags >> 1) & 1) ? (gx.id_c == A0.id_c ? A0.l_cont_bp : B0.l_cont_bp) : 0);
+            const End Y0 = end_old(gy, ((gy.flags >> 1) & 1) ? (gy.id_c == A0.id_c ? A0.l_cont_bp : B0.l_cont_bp) : 0);
+            const End X = end_xf(gx, tv.xf[op * NP + px]), Y = end_xf(gy, tv.xf[op * NP + py]);
+            const unsigned ops = tv.cmask[pr * N_OPS + op];
+            const bool near_old = X0.label == Y0.label && gap_bp(X0, gx.len_bp, Y0, gy.len_bp) <= reach_bp;
+            const bool near_new = X.label == Y.label && gap_bp(X, gx.len_bp, Y, gy.len_bp) <= reach_bp;
+            // beyond the window (or between two contigs) before AND after, every slot pair has the trans value both times: the
+            // difference is exactly zero -- unless the reference's trans-branch RF-count indexing is on and a bin's counts differ
+            if (!near_old && !near_new && !(quirk && (!stat_uniform(sx) || !stat_uniform(sy)))) continue;
+            const long long qv = strict_pair_q(X0, Y0, X, Y, sx, fx, sy, fy, nfpb, par, quirk);
+            if (qv == 0) continue;
+            if (qv == Q_BAD) { nf_flag_ops(ta.counters + NF_OFF, k, ops); continue; }
+            unsigned o2 = ops;
+            while (o2) { const int b = __ffs((int)o2) - 1; o2 &= o2 - 1; atomicAdd((unsigned long long*)&s_acc[b], (unsigned long long)qv); }
+        }
+    }
+    if (!ta.strict && inl && total > 0) {
         const int* __restrict__ perm = A->perm;
         const Geo* __restrict__ geo = ta.geo;
         const Stat* __restrict__ stat = ta.stat;
@@ -1760,7 +1917,7 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
         __shared__ int s_seen;
         // the other waves meanwhile copy what the pricing needs of all K tables into LDS (the other blocks released their
         // tables before they took their tickets)
-        if (t >= 64 && s_fin == 1) {
+        if (t >= 64 && s_fin == 1 && !ta.strict) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             const int u = t - 64, nu = (int)blockDim.x - 64;
             for (int e = u; e < K * N_PAIRS; e += nu) {
@@ -1806,7 +1963,10 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
         if (t == 0) { ta.sync[0] = 0; __threadfence_system(); ta.host_res[0] = seq | NEED_FIN | (s_fin == 3 ? GAVE_UP : 0ll); __threadfence_system(); }
         return;
     }
-    {
+    if (ta.strict)
+        price_contacts_strict(ta.queue, ta.tabs, ta.geo, ta.stat, ta.lcontbp, ta.acc, ta.counters + NF_OFF, ta.nfpb, ta.par, ta.quirk != 0,
+                              s_nq, t >> 6, (int)(blockDim.x >> 6), t & 63);
+    else {
         PriceArgs pa;
         pa.pr_lds = s_prl; pa.pt_lds = s_ptl; pa.nt_lds = s_ntl;
         pa.queue = ta.queue; pa.tabs = ta.tabs; pa.geo = ta.geo; pa.stat = ta.stat; pa.lcontbp = ta.lcontbp;
@@ -2576,13 +2736,9 @@ struct StrictArgs {
     float nfpb;
     Par par;
     int quirk;
+    int reach_bp;
+    unsigned long long list_cap;
 };
-
-__device__ __forceinline__ End end_old(const Geo& g, int lbp)
-{
-    End e; e.label = g.id_c; e.start_bp = g.start_bp; e.fwd = g.flags & 1; e.circ = (g.flags >> 1) & 1; e.lbp = lbp;
-    return e;
-}
 
 // correction of the layout independent all-trans mass T_all for the reference's trans-branch RF-count indexing: pairs of
 // different contigs whose lower-id bin is reversed and has non-uniform RF counts (ubins lists the bins with non-uniform counts)
@@ -2612,8 +2768,8 @@ __global__ __launch_bounds__(256) void k_quirk_mass(int n_u, const int* __restri
     if ((threadIdx.x & 63) == 0 && q != 0) atomicAdd((unsigned long long*)out, (unsigned long long)q);
 }
 
-__global__ __launch_bounds__(256) void k_strict(FinArgs fa, StrictArgs sa, int fA, int K, int rank, int world,
-                                                 long long* __restrict__ d_q_out, volatile long long* host_res, long long seq)
+__global__ __launch_bounds__(256) void k_strict_dense(FinArgs fa, StrictArgs sa, int fA, int K, int rank, int world,
+                                                       long long* __restrict__ d_q_out, volatile long long* host_res, long long seq)
 {
     const NbTables* __restrict__ tabs = fa.tabs;
     const Geo* __restrict__ geo = fa.geo;
@@ -2801,6 +2957,351 @@ __global__ __launch_bounds__(256) void k_strict(FinArgs fa, StrictArgs sa, int f
     hand_out(fa.acc, counters, fa.sync, K, d_q_out, host_res, seq);
 }
 
+// ------------------------------------------------------------------ reference arithmetic, windowed (k_strict_cull + k_strict)
+// The same sums as k_strict_dense -- every term it adds that is not exactly zero -- without its O(m^2) evaluations:
+//   * a fragment pair that is beyond the window (or in two contigs) both before and under a candidate has the trans value both
+//     times, slot by slot: the difference is exactly 0 and the pair is skipped (unless the reference's trans-branch RF-count
+//     indexing is on and RF counts differ inside a bin: then nothing is skipped);
+//   * the 13 candidates of a neighbour fall into classes of equal contact-model inputs per piece pair (same_inputs, built by
+//     k_tm): a class is priced once, under its first candidate, and its value added to every candidate of the class; the class
+//     of the current layout's own inputs is never priced.
+// Work unit = (neighbour, tile of 64 fragments x, tile of 64 fragments y) of the affected set, tiles never straddling the two
+// contigs.  k_strict_cull lists the units that can hold a pair inside the window under some layout (interval arithmetic on
+// the tiles' and pieces' bp extents: one thread per candidate unit); k_strict takes the listed units round robin, one wave
+// each: lane = fragment x, the y tile staged in LDS, every (x, y) rounded to Q once per class.  Then the queued contacts (the
+// scan queued every contact with both ends in a neighbour's set): lane = contact, one evaluation per class.
+struct SetGeo { int m, lenA, lenB, baseA, baseB, tilesA, nt, lbpA, lbpB, cA, cB, pad; };   // one neighbour's affected set
+
+__device__ __forceinline__ SetGeo set_geo(const NbTables& T, const Geo* __restrict__ geo, const Link* __restrict__ link,
+                                          const int* __restrict__ cbase, int fA)
+{
+    SetGeo g;
+    const int fB = T.fB;
+    const Geo gA = geo[fA], gB = geo[fB];
+    const Link lA = link[fA], lB = link[fB];
+    g.cA = gA.id_c; g.cB = gB.id_c;
+    g.lenA = lA.l_cont; g.lenB = (fB == fA || gB.id_c == gA.id_c) ? 0 : lB.l_cont;
+    g.m = T.set_m > 0 ? g.lenA + g.lenB : 0;      // (0: fB == fA, or priced by k_tm already)
+    g.baseA = cbase[fA]; g.baseB = cbase[fB];
+    g.lbpA = lA.l_cont_bp; g.lbpB = lB.l_cont_bp;
+    g.tilesA = (g.lenA + 63) >> 6;
+    g.nt = g.m > 0 ? g.tilesA + ((g.lenB + 63) >> 6) : 0;
+    g.pad = 0;
+    return g;
+}
+
+// old bp interval [lo, hi) of piece p of the neighbour and its contig (0 = contig(fA), 1 = contig(fB)); lo >= hi: empty
+__device__ __forceinline__ void piece_extent(const PieceKey& key, const Geo& gA, const Geo& gB, const SetGeo& sg, int p, int& lo, int& hi, int& side)
+{
+    lo = 0; hi = 0; side = 0;
+    if (key.cA != key.cB) {
+        const Geo& g = p <= 3 ? gA : gB;
+        side = p <= 3 ? 0 : 1;
+        const int lbp = p <= 3 ? sg.lbpA : sg.lbpB, w = p <= 3 ? p : p - 3;
+        if (w == 1) { lo = 0; hi = g.start_bp; } else if (w == 2) { lo = g.start_bp; hi = g.start_bp + g.len_bp; } else { lo = g.start_bp + g.len_bp; hi = lbp; }
+        return;
+    }
+    const bool a_first = key.a < key.b;
+    const Geo& L = a_first ? gA : gB;
+    const Geo& H = a_first ? gB : gA;
+    if (p == 1) { lo = 0; hi = L.start_bp; }
+    else if (p == 2) { lo = L.start_bp; hi = L.start_bp + L.len_bp; }
+    else if (p == 3) { lo = L.start_bp + L.len_bp; hi = H.start_bp; }
+    else if (p == 4) { lo = H.start_bp; hi = H.start_bp + H.len_bp; }
+    else if (p == 5) { lo = H.start_bp + H.len_bp; hi = sg.lbpA; }
+}
+
+
+__global__ __launch_bounds__(256) void k_strict_cull(const NbTables* __restrict__ tabs, const Geo* __restrict__ geo, const Link* __restrict__ link,
+                                                      const int* __restrict__ cbase, const int* __restrict__ perm, int fA, int K, int rank, int world,
+                                                      int reach_bp, int no_window, unsigned long long* __restrict__ list,
+                                                      unsigned long long* __restrict__ list_n, unsigned long long cap,
+                                                      unsigned long long* __restrict__ counters)
+{
+    __shared__ SetGeo s_sg[MAXK];
+    __shared__ int s_plo[MAXK][NP], s_phi[MAXK][NP], s_pside[MAXK][NP];
+    __shared__ Xf s_xf[MAXK][N_OPS][NP];
+    __shared__ unsigned char s_crep[MAXK][N_PAIRS][N_OPS];
+    __shared__ int s_rbase[MAXK + 1];
+    __shared__ int s_row[4];      // the row's x tile: lo, hi (old bp), side
+    const int t = threadIdx.x;
+    if (t < K) {
+        const SetGeo sg = set_geo(tabs[t], geo, link, cbase, fA);
+        s_sg[t] = sg;
+        const Geo gA = geo[fA], gB = geo[tabs[t].fB];
+        for (int p = 0; p < NP; p++) { int lo, hi, side; piece_extent(tabs[t].key, gA, gB, sg, p, lo, hi, side); s_plo[t][p] = p ? lo : 0; s_phi[t][p] = p ? hi : 0; s_pside[t][p] = side; }
+    }
+    for (int i = t; i < K * N_OPS * NP; i += blockDim.x) { const int k = i / (N_OPS * NP), r = i - k * (N_OPS * NP); s_xf[k][r / NP][r % NP] = tabs[k].xf[r / NP][r % NP]; }
+    for (int i = t; i < K * N_PAIRS * N_OPS; i += blockDim.x) { const int k = i / (N_PAIRS * N_OPS), r = i - k * (N_PAIRS * N_OPS); s_crep[k][r / N_OPS][r % N_OPS] = tabs[k].crep[r / N_OPS][r % N_OPS]; }
+    __syncthreads();
+    if (t == 0) { s_rbase[0] = 0; for (int k = 0; k < K; k++) s_rbase[k + 1] = s_rbase[k] + s_sg[k].nt; }
+    __syncthreads();
+    const int n_rows = s_rbase[K];
+    // old bp extent of tile tt of neighbour k
+    auto tile_extent = [&](int k, int tt, int& lo, int& hi, int& side) {
+        const SetGeo& sg = s_sg[k];
+        side = tt < sg.tilesA ? 0 : 1;
+        const int t0 = side ? tt - sg.tilesA : tt, len = side ? sg.lenB : sg.lenA, base = side ? sg.baseB : sg.baseA;
+        const int first = t0 * 64, next = first + 64;
+        lo = geo[perm[base + first]].start_bp;
+        hi = next >= len ? (side ? sg.lbpB : sg.lbpA) : geo[perm[base + next]].start_bp;
+    };
+    for (int row = blockIdx.x; row < n_rows; row += gridDim.x) {
+        int k = 0;
+        for (int j = 1; j < K; j++) k += row >= s_rbase[j] ? 1 : 0;
+        const int ti = row - s_rbase[k];
+        const SetGeo sg = s_sg[k];
+        __syncthreads();
+        if (t == 0) { int lo, hi, side; tile_extent(k, ti, lo, hi, side); s_row[0] = lo; s_row[1] = hi; s_row[2] = side; }
+        __syncthreads();
+        const int xlo = s_row[0], xhi = s_row[1], xside = s_row[2];
+        for (int tj0 = ti; tj0 < sg.nt; tj0 += blockDim.x) {
+            const int tj = tj0 + t;
+            bool alive = false;
+            if (tj < sg.nt && ((ti + tj + k) % world) == rank) {
+                int ylo, yhi, yside;
+                tile_extent(k, tj, ylo, yhi, yside);
+                for (int p = 1; p < NP && !alive; p++) {
+                    if (s_pside[k][p] != xside) continue;
+                    const int xs = max(xlo, s_plo[k][p]), xe = min(xhi, s_phi[k][p]);
+                    if (xs >= xe) continue;
+                    for (int q = 1; q < NP && !alive; q++) {
+                        if (s_pside[k][q] != yside) continue;
+                        const int ys = max(ylo, s_plo[k][q]), ye = min(yhi, s_phi[k][q]);
+                        if (ys >= ye) continue;
+                        const int pr = pair_index(p, q);
+                        // the current layout
+                        const bool near_old = xside == yside && max(ys - xe, xs - ye) <= reach_bp;
+                        for (int op = 0; op < N_OPS && !alive; op++) {
+                            if (s_crep[k][pr][op] != op) continue;   // a class is priced under its first candidate only
+                            if (no_window || near_old) { alive = true; break; }
+                            const Xf a = s_xf[k][op][p], b = s_xf[k][op][q];
+                            if (a.label != b.label) continue;
+                            const int xs2 = a.sigma > 0 ? xs + a.off : a.off - xe, xe2 = a.sigma > 0 ? xe + a.off : a.off - xs;
+                            const int ys2 = b.sigma > 0 ? ys + b.off : b.off - ye, ye2 = b.sigma > 0 ? ye + b.off : b.off - ys;
+                            if (max(ys2 - xe2, xs2 - ye2) <= reach_bp) alive = true;
+                        }
+                    }
+                }
+            }
+            const unsigned long long bal = __ballot(alive);
+            if (bal) {
+                const int lane = t & 63, n_alive = __popcll(bal);
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(list_n, (unsigned long long)n_alive);
+                base = __shfl(base, 0, 64);
+                if (alive) {
+                    const unsigned long long at = base + (unsigned long long)__popcll(bal & ((1ull << lane) - 1ull));
+                    if (at < cap) list[at] = ((unsigned long long)k << 48) | ((unsigned long long)ti << 24) | (unsigned long long)tj;
+                    else atomicOr(&counters[6], 2ull);   // (cannot happen: the host sizes the list for the longest contig)
+                }
+            }
+        }
+    }
+}
+
+struct STileW { Geo g; int lbp, piece, frag, nonuni; Stat st; };   // one staged fragment y, 64 bytes
+constexpr int STRICT_ACC_COPIES = 8;   // copies of the block's K*13 sums (lane & 7 picks one): LDS atomics of a wave spread over them
+
+// dynamic LDS of k_strict for K neighbours: the transforms, the classes and their candidate masks
+__host__ __device__ constexpr size_t strict_dyn_lds(int K) { return (size_t)K * (N_OPS * NP * sizeof(Xf) + N_PAIRS * N_OPS * sizeof(unsigned short) + ((N_PAIRS * N_OPS + 3) & ~3)); }
+
+template <bool MULTI>
+__global__ __launch_bounds__(256) void k_strict(FinArgs fa, StrictArgs sa, int fA, int K, const unsigned long long* __restrict__ list,
+                                                 unsigned long long* __restrict__ list_n, long long* __restrict__ d_q_out,
+                                                 volatile long long* host_res, long long seq)
+{
+    const NbTables* __restrict__ tabs = fa.tabs;
+    const Geo* __restrict__ geo = fa.geo;
+    const Stat* __restrict__ stat = fa.stat;
+    unsigned long long* __restrict__ counters = fa.counters;
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + wib, n_waves = gridDim.x * (blockDim.x >> 6);
+    __shared__ STileW s_tile[4][64];
+    __shared__ long long s_accb[STRICT_ACC_COPIES][MAXK * N_OPS];
+    __shared__ SetGeo s_sg[MAXK];
+    extern __shared__ long long s_dyn_strict[];
+    Xf* const s_xf = reinterpret_cast<Xf*>(s_dyn_strict);                                          // [K][N_OPS][NP]
+    unsigned short* const s_cmask = reinterpret_cast<unsigned short*>(s_xf + K * N_OPS * NP);     // [K][N_PAIRS][N_OPS]
+    unsigned char* const s_crep = reinterpret_cast<unsigned char*>(s_cmask + K * N_PAIRS * N_OPS); // [K][N_PAIRS][N_OPS]
+#define XF_(k_, op_, p_) s_xf[((k_) * N_OPS + (op_)) * NP + (p_)]
+#define CREP_(k_, pr_, op_) s_crep[((k_) * N_PAIRS + (pr_)) * N_OPS + (op_)]
+#define CMASK_(k_, pr_, op_) s_cmask[((k_) * N_PAIRS + (pr_)) * N_OPS + (op_)]
+    for (int i = threadIdx.x; i < STRICT_ACC_COPIES * MAXK * N_OPS; i += blockDim.x) (&s_accb[0][0])[i] = 0;
+    // (the tables are complete: the launch is ordered behind k_tm by an event)
+    for (int i = threadIdx.x; i < K * N_OPS * NP; i += blockDim.x) { const int k = i / (N_OPS * NP), r = i - k * (N_OPS * NP); s_xf[i] = tabs[k].xf[r / NP][r % NP]; }
+    for (int i = threadIdx.x; i < K * N_PAIRS * N_OPS; i += blockDim.x) {
+        const int k = i / (N_PAIRS * N_OPS), r = i - k * (N_PAIRS * N_OPS);
+        s_crep[i] = tabs[k].crep[r / N_OPS][r % N_OPS]; s_cmask[i] = tabs[k].cmask[r / N_OPS][r % N_OPS];
+    }
+    if ((int)threadIdx.x < K) s_sg[threadIdx.x] = set_geo(tabs[threadIdx.x], geo, sa.link, sa.cbase, fA);
+    __syncthreads();
+    const unsigned long long nq_total = counters[2];          // written by k_scan, an earlier kernel on the stream
+    const unsigned long long n_units = min(*list_n, sa.list_cap); // written by k_strict_cull, the previous kernel on the stream
+    const float nfpb = sa.nfpb;
+    const Par par = sa.par;
+    const bool quirk = sa.quirk != 0;
+    const int reach_bp = sa.reach_bp;
+    long long* const my_acc = s_accb[lane & (STRICT_ACC_COPIES - 1)];
+    auto add_ops = [&](int k, unsigned ops, long long v) {
+        while (ops) { const int b = __ffs((int)ops) - 1; ops &= ops - 1; atomicAdd((unsigned long long*)&my_acc[k * N_OPS + b], (unsigned long long)v); }
+    };
+    // ---- (1) the listed units
+    STileW* tile = s_tile[wib];
+    for (unsigned long long u = (unsigned long long)wave; u < n_units; u += (unsigned long long)n_waves) {
+        const unsigned long long ent = list[u];
+        const int k = (int)(ent >> 48), ti = (int)((ent >> 24) & 0xffffffull), tj = (int)(ent & 0xffffffull);
+        const SetGeo sg = s_sg[k];
+        const PieceKey key = tabs[k].key;
+        auto frag_at = [&](int tt, int l, bool& ok) {
+            const int side = tt < sg.tilesA ? 0 : 1, t0 = side ? tt - sg.tilesA : tt, pos = t0 * 64 + l;
+            ok = pos < (side ? sg.lenB : sg.lenA);
+            return ok ? sa.perm[(side ? sg.baseB : sg.baseA) + pos] : 0;
+        };
+        bool has_x;
+        const int fx = frag_at(ti, lane, has_x);
+        Geo gx = {0, 0, 0, 0};
+        Stat sx = {0.0f, 0.0f, 0.0f, 0, 0, 0, 0, 0};
+        int px = 0, lbpx = 0;
+        if (has_x) {
+            gx = geo[fx]; sx = stat[fx];
+            px = piece_of(key, gx.id_c, geo_pos(gx.flags));
+            lbpx = ((gx.flags >> 1) & 1) ? (gx.id_c == sg.cA ? sg.lbpA : sg.lbpB) : 0;
+        }
+        const bool nonuni_x = !stat_uniform(sx);
+        int cnt = 0;
+        {
+            bool has_y;
+            const int fy = frag_at(tj, lane, has_y);
+            if (has_y) {
+                STileW y; y.frag = fy; y.g = geo[fy]; y.st = stat[fy];
+                y.piece = piece_of(key, y.g.id_c, geo_pos(y.g.flags));
+                y.lbp = ((y.g.flags >> 1) & 1) ? (y.g.id_c == sg.cA ? sg.lbpA : sg.lbpB) : 0;
+                y.nonuni = stat_uniform(y.st) ? 0 : 1;
+                tile[lane] = y;
+            }
+            cnt = __popcll(__ballot(has_y));
+        }
+        WAVE_LDS_SYNC();
+        const End X0 = end_old(gx, lbpx);
+        long long accq[N_OPS];
+#pragma unroll
+        for (int op = 0; op < N_OPS; op++) accq[op] = 0;
+        unsigned bad = 0;
+        int cur_pr = -1;
+        auto flush = [&]() {
+            if (cur_pr < 0) return;
+#pragma unroll
+            for (int op = 0; op < N_OPS; op++)
+                if (accq[op] != 0) { add_ops(k, CMASK_(k, cur_pr, op), accq[op]); accq[op] = 0; }
+        };
+        const bool live_x = has_x && sx.n > 0;
+        for (int j = 0; j < cnt; j++) {
+            if (!live_x || (ti == tj && j <= lane)) continue;       // every unordered pair once; never a bin with itself
+            const STileW& y = tile[j];
+            const Stat sy = y.st;
+            if (sy.n == 0) continue;                                  // (a copy of a repeated bin: priced by k_rep_delta)
+            const int py = y.piece, pr = pair_index(px, py);
+            if (pr != cur_pr) { flush(); cur_pr = pr; }
+            const End Y0 = end_old(y.g, y.lbp);
+            const bool near_old = X0.label == Y0.label && gap_bp(X0, gx.len_bp, Y0, y.g.len_bp) <= reach_bp;
+            const bool always = quirk && (nonuni_x || y.nonuni != 0);
+            bool have_old = false;
+            float exo[3][3];
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int b = 0; b < 3; b++) exo[a][b] = 0.0f;
+            for (int op = 0; op < N_OPS; op++) {
+                if (CREP_(k, pr, op) != op) continue;
+                const End X = end_xf(gx, XF_(k, op, px)), Y = end_xf(y.g, XF_(k, op, py));
+                const bool near_new = X.label == Y.label && gap_bp(X, gx.len_bp, Y, y.g.len_bp) <= reach_bp;
+                if (!near_old && !near_new && !always) continue;      // the trans value both times, slot by slot: exactly zero
+                if (!have_old) {
+                    have_old = true;
+                    if (MULTI) {
+#pragma unroll
+                        for (int a = 0; a < 3; a++)
+#pragma unroll
+                            for (int b = 0; b < 3; b++)
+                                if (a < sx.n && b < sy.n) exo[a][b] = ex_pair_ref(X0, sx, a, fx, Y0, sy, b, y.frag, nfpb, par, quirk);
+                    } else exo[0][0] = ex_pair_ref(X0, sx, 0, fx, Y0, sy, 0, y.frag, nfpb, par, quirk);
+                }
+                double acc = 0.0;
+                if (MULTI) {
+#pragma unroll
+                    for (int a = 0; a < 3; a++)
+#pragma unroll
+                        for (int b = 0; b < 3; b++)
+                            if (a < sx.n && b < sy.n) acc += (double)exo[a][b] - (double)ex_pair_ref(X, sx, a, fx, Y, sy, b, y.frag, nfpb, par, quirk);
+                } else acc += (double)exo[0][0] - (double)ex_pair_ref(X, sx, 0, fx, Y, sy, 0, y.frag, nfpb, par, quirk);
+                const long long q1 = to_q(acc);
+                if (q1 == Q_BAD) bad |= (unsigned)CMASK_(k, pr, op) | (1u << 16);
+                else {
+#pragma unroll
+                    for (int i = 0; i < N_OPS; i++) accq[i] += (i == op) ? q1 : 0ll;
+                }
+            }
+        }
+        flush();
+        for (int o = 32; o > 0; o >>= 1) bad |= __shfl_down(bad, o, 64);
+        if (lane == 0 && bad) nf_flag_ops(counters + NF_OFF, k, bad & 0xffffu);
+        WAVE_LDS_SYNC();   // (the next unit stages its tile over this one)
+    }
+    // ---- (2) the queued contacts: lane = contact, one evaluation per class
+    for (unsigned long long b0 = (unsigned long long)(n_waves - 1 - wave) * 64ull; b0 < nq_total; b0 += (unsigned long long)n_waves * 64ull) {
+        const unsigned long long e = b0 + (unsigned long long)lane;
+        if (e >= nq_total) continue;
+        const QEntry qe = fa.queue[e];
+        if (qe.rel == 0) continue;
+        const int fx = qe.fx, fy = qe.fy, slx = qe.slots & 3, sly = (qe.slots >> 2) & 3;
+        const Geo gx = geo[fx], gy = geo[fy];
+        const Stat sx = stat[fx], sy = stat[fy];
+        const End X0 = end_old(gx, ((gx.flags >> 1) & 1) ? sa.lcontbp[fx] : 0), Y0 = end_old(gy, ((gy.flags >> 1) & 1) ? sa.lcontbp[fy] : 0);
+        const float ex_old = ex_pair_ref(X0, sx, slx, fx, Y0, sy, sly, fy, nfpb, par, quirk);
+        const double ln_old = log((double)ex_old), ob = (double)__int_as_float(qe.cnt);
+        unsigned rel = qe.rel;
+        while (rel) {
+            const int k = (__ffs((int)rel) - 1) / CODE_BITS;
+            rel &= rel - 1;
+            const int p = (qe.ci >> (CODE_BITS * k)) & 7, q = (qe.cj >> (CODE_BITS * k)) & 7;
+            const int pr = pair_index(p, q);
+            for (int op = 0; op < N_OPS; op++) {
+                if (CREP_(k, pr, op) != op) continue;
+                const End X = end_xf(gx, XF_(k, op, p)), Y = end_xf(gy, XF_(k, op, q));
+                const float ex_new = ex_pair_ref(X, sx, slx, fx, Y, sy, sly, fy, nfpb, par, quirk);
+                if (ex_new == ex_old) continue;
+                const long long qv = to_q(ob * (log((double)ex_new) - ln_old));
+                if (qv == Q_BAD) nf_flag_ops(counters + NF_OFF, k, CMASK_(k, pr, op));
+                else if (qv != 0) add_ops(k, CMASK_(k, pr, op), qv);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < K * N_OPS; i += blockDim.x) {
+        long long v = 0;
+#pragma unroll
+        for (int c = 0; c < STRICT_ACC_COPIES; c++) v += s_accb[c][i];
+        if (v != 0) atomicAdd((unsigned long long*)&fa.acc[i], (unsigned long long)v);
+    }
+    if (threadIdx.x == 255 && blockIdx.x == 0) atomicAdd(&counters[1], n_units);
+    __shared__ int s_last;
+    ATOMICS_DONE();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long ticket = atomicAdd(&counters[5], 1ull);
+        s_last = (ticket == (unsigned long long)gridDim.x - 1ull);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (threadIdx.x == 0) *list_n = 0;   // (every block has read it: the list is empty again for the next step)
+    hand_out(fa.acc, counters, fa.sync, K, d_q_out, host_res, seq);
+#undef XF_
+#undef CREP_
+#undef CMASK_
+}
+
 // ------------------------------------------------------------------ repeated bins (allow_repeats)
 // A repeated ("duplicated") bin has several fragment copies (frag_dispatcher / collector_id_repeats,
 // simulation_loader.py:258-277); the expected value of a pixel is the float32 sum over the ACTIVE copy pairs of its two
@@ -2821,7 +3322,22 @@ struct RepArgs {
     const int* lcontbp;
     float nfpb;
     Par par;
+    int quirk;                  // GRAAL_MODE_REF_TRANS_ACCU: the reference's RF-count indexing in the trans branch
 };
+
+// ex_pair with the reference's trans-branch RF-count indexing when X is the pixel's FIRST copy (a copy of its lower-id bin;
+// of the bin itself on the diagonal): reversed, every slot of X is priced with the count of its last sub-fragment
+// (kernels3.cu:3155; oracle/graal_oracle.c:walk_trans)
+__device__ __forceinline__ float ex_pair_first(const End& X, const Stat& sx, int slx, const End& Y, const Stat& sy, int sly, float nfpb,
+                                               const Par& p, bool quirk)
+{
+    if (X.label != Y.label) {
+        int ax = stat_accu(sx, slx);
+        if (quirk && !X.fwd) ax = stat_accu(sx, sx.n - 1);
+        return p.v_inter * ((float)(ax * stat_accu(sy, sly)) / nfpb);
+    }
+    return ex_pair(X, sx, slx, Y, sy, sly, nfpb, p);
+}
 
 // float factorial of kernels3.cu:80-93 and evaluate_likelihood_double (kernels3.cu:191-210)
 __device__ __forceinline__ float factorial_f(float n)
@@ -2881,7 +3397,7 @@ __device__ double pixel_lik(const RepArgs& R, int lo, int hi, const CandCtx& C)
             for (int a = 0; a < 3; a++)
 #pragma unroll
                 for (int b = 0; b < 3; b++)
-                    if (a < si.n && b < sj.n) ex[a][b] = ex[a][b] + ex_pair(vi.e, si, a, vj.e, sj, b, R.nfpb, R.par);
+                    if (a < si.n && b < sj.n) ex[a][b] = ex[a][b] + ex_pair_first(vi.e, si, a, vj.e, sj, b, R.nfpb, R.par, R.quirk != 0);
         }
     }
     // observations: symmetric matrix, stored by rows of the repeated bins' sub-fragments
@@ -3076,6 +3592,9 @@ struct Ctx {
     unsigned long long* d_done = nullptr;    // the N_DONE completion counters of k_scan, DONE_STRIDE words apart
     unsigned long long* d_wq = nullptr;      // k_fin's work-queue counters (2 x N_WQ, WQ_STRIDE words apart), zero at rest
     int mode = 0;                 // GRAAL_MODE_* flags (graal_set_mode)
+    unsigned long long* d_slist = nullptr;   // k_strict's unit list (k_strict_cull fills it), slist_cap entries
+    unsigned long long* d_slist_n = nullptr; // its length (zero at rest: k_strict's last block clears it)
+    unsigned long long slist_cap = 0;
     unsigned scan_token = 0x5ca90000u; // k_scan launches so far (ScanArgs.token)
     double* d_ln_tab = nullptr;   // [LN_TRANS_LUT] ln of the trans value by RF-count product (k_ln_tab; rebuilt by sync_args)
     int* d_ubins = nullptr;       // bins whose sub-fragments carry different RF counts (k_quirk_mass)
@@ -3361,6 +3880,61 @@ int launch_fin(Ctx* h, int K, int rank, int world, long long* d_q_out, bool publ
     return GRAAL_OK;
 }
 
+// GRAAL_STRICT_DENSE=1: the O(m^2) validation kernel (k_strict_dense) instead of k_strict_cull + k_strict (tests compare the two)
+bool strict_dense_cfg()
+{
+    static const bool v = getenv("GRAAL_STRICT_DENSE") != nullptr && atoi(getenv("GRAAL_STRICT_DENSE")) != 0;
+    return v;
+}
+
+// reference arithmetic: what k_tm left (sets larger than STRICT_INLINE_M, the queued contacts when there are many), hand-out
+int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out, bool publish, hipStream_t st)
+{
+    CK(hipStreamWaitEvent(st, h->ev_tm, 0));   // the tables are complete before either kernel starts: nobody spins for them
+    FinArgs fa;
+    fa.tm_done = h->tm_done; fa.step_hdr = h->step_hdr; fa.counters = (unsigned long long*)(h->d_scalars + 10); fa.queue = h->queue;
+    fa.tabs = h->tabs; fa.geo = h->geo; fa.stat = h->stat_frag; fa.acc = h->d_acc; fa.sync = h->d_sync;
+    fa.ln_tab = nullptr; fa.lut_n = 0; fa.skip = 0; fa.seg = 0; fa.norm_u = -1.0f; fa.upw = 4; fa.wq = nullptr;
+    StrictArgs sx;
+    sx.perm = h->perm; sx.cbase = h->cbase; sx.lcontbp = h->soa[h->cur].p[F_LCONTBP]; sx.link = h->link; sx.nfpb = h->nfpb; sx.par = h->par;
+    sx.quirk = (h->mode & GRAAL_MODE_REF_TRANS_ACCU) ? 1 : 0;
+    sx.reach_bp = reach_bp(h);
+    sx.list_cap = 0;
+    if (strict_dense_cfg()) {
+        k_strict_dense<<<1024, 256, 0, st>>>(fa, sx, fA, K, rank, world, d_q_out, publish ? h->res_dev : nullptr, h->seq);
+        CK(hipGetLastError());
+        return GRAAL_OK;
+    }
+    // the unit list holds at most K * nt (nt + 1) / 2 entries, nt = tiles of the two longest contigs (grow-only)
+    const unsigned long long nt = 2ull * (unsigned long long)((std::max(h->max_lcont, 1) + 63) / 64);
+    const unsigned long long need = (unsigned long long)K * nt * (nt + 1ull) / 2ull + 64ull;
+    if (need > h->slist_cap) {
+        CK(hipStreamSynchronize(st));
+        if (h->d_slist) CK(hipFree(h->d_slist));
+        h->d_slist = nullptr;
+        const unsigned long long cap = std::max<unsigned long long>(need + need / 2ull, 1ull << 16);
+        CK(hipMalloc(&h->d_slist, cap * sizeof(unsigned long long)));
+        h->slist_cap = cap;
+    }
+    if (!h->d_slist_n) {
+        CK(hipMalloc(&h->d_slist_n, sizeof(unsigned long long)));
+        CK(hipMemset(h->d_slist_n, 0, sizeof(unsigned long long)));
+    }
+    sx.list_cap = h->slist_cap;
+    const int no_window = (sx.quirk && h->n_ubins > 0) ? 1 : 0;
+    // rows of candidate units = tiles of the affected sets: a block per row up to the chip's width
+    const int cull_blocks = (int)std::min<unsigned long long>(1024ull, std::max<unsigned long long>(1ull, (unsigned long long)K * nt));
+    k_strict_cull<<<cull_blocks, 256, 0, st>>>(h->tabs, h->geo, h->link, h->cbase, h->perm, fA, K, rank, world, sx.reach_bp, no_window,
+                                               h->d_slist, h->d_slist_n, h->slist_cap, (unsigned long long*)(h->d_scalars + 10));
+    CK(hipGetLastError());
+    static const int blocks_env = getenv("GRAAL_STRICT_BLOCKS") ? atoi(getenv("GRAAL_STRICT_BLOCKS")) : 0;
+    const int blocks = blocks_env > 0 ? blocks_env : (h->max_lcont > 0 && h->max_lcont <= 64 ? 32 : (h->max_lcont <= 1024 ? 512 : 1024));
+    if (h->single_sub) k_strict<false><<<blocks, 256, strict_dyn_lds(K), st>>>(fa, sx, fA, K, h->d_slist, h->d_slist_n, d_q_out, publish ? h->res_dev : nullptr, h->seq);
+    else k_strict<true><<<blocks, 256, strict_dyn_lds(K), st>>>(fa, sx, fA, K, h->d_slist, h->d_slist_n, d_q_out, publish ? h->res_dev : nullptr, h->seq);
+    CK(hipGetLastError());
+    return GRAAL_OK;
+}
+
 } // namespace
 
 // statistics of the layout (k_stats ran earlier on the stream): publish + wait; res[0..15] on return
@@ -3486,7 +4060,7 @@ void graal_destroy(graal_ctx* h)
         (void)hipSetDevice(h->device);
         (void)hipStreamSynchronize(h->stream);
         if (h->aux) (void)hipStreamSynchronize(h->aux);
-        void* ptrs[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->stat, h->sub_rec, h->sub_rec8, h->sub_lab16, h->d_ubins, h->d_ln_tab, h->sub2bin, h->row, h->col, h->cnt, h->queue, h->d_sub_ids, h->d_acc, h->tm_done, h->d_sync, h->d_done, h->d_wq, h->d_flags, h->stat_frag, h->d_dup_bins, h->d_dup_index,
+        void* ptrs[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->stat, h->sub_rec, h->sub_rec8, h->sub_lab16, h->d_ubins, h->d_ln_tab, h->sub2bin, h->row, h->col, h->cnt, h->queue, h->d_sub_ids, h->d_acc, h->tm_done, h->d_sync, h->d_done, h->d_wq, h->d_flags, h->d_slist, h->d_slist_n, h->stat_frag, h->d_dup_bins, h->d_dup_index,
                         h->d_dispatcher, h->d_collector, h->d_sub_ids_all, h->d_rep_obs,
                         h->keys, h->keys_sorted, h->o2n, h->len_of2[0], h->len_of2[1], h->contig_off2[0], h->contig_off2[1], h->perm, h->cbase, h->link, h->mates, h->cub_tmp, h->tabs, h->step_hdr, h->d_args, h->d_chg,
                         h->d_scalars, h->d_qout, h->d_dref, h->d_dist};
@@ -3618,6 +4192,7 @@ static RepArgs rep_args(const Ctx* h)
     R.dup_bins = h->d_dup_bins; R.dup_index = h->d_dup_index; R.dispatcher = h->d_dispatcher; R.collector = h->d_collector;
     R.obs = h->d_rep_obs; R.sub_ids = h->d_sub_ids_all; R.stat_bin = h->stat; R.geo = h->geo;
     R.lcontbp = h->soa[h->cur].p[F_LCONTBP]; R.nfpb = h->nfpb; R.par = h->par;
+    R.quirk = (h->mode & GRAAL_MODE_REF_TRANS_ACCU) ? 1 : 0;
     return R;
 }
 
@@ -3905,7 +4480,6 @@ int graal_eval_full_q(graal_ctx* h, int64_t q_out[2])
     CK(hipSetDevice(h->device));
     SoaPtr s = h->soa[h->cur];
     const bool quirk = (h->mode & GRAAL_MODE_REF_TRANS_ACCU) != 0;
-    if (quirk && h->has_rep) return fail(h, GRAAL_E_UNSUPPORTED, "GRAAL_MODE_REF_TRANS_ACCU with repeated bins is not implemented");
     if (h->nnz) {
         static const bool no_compact = getenv("GRAAL_FULL_NO_COMPACT") != nullptr;
         const bool compact = h->uniform_accu > 0 && !quirk && !no_compact;
@@ -4010,9 +4584,10 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
         h->relabel_pending = false;
     }
     const bool strict = (h->mode & GRAAL_MODE_STRICT) != 0;
-    if (strict && h->has_rep) return fail(h, GRAAL_E_UNSUPPORTED, "GRAAL_MODE_STRICT with repeated bins is not implemented");
     TmArgs ta;
     ta.strict = strict ? 1 : 0;
+    ta.quirk = (h->mode & GRAAL_MODE_REF_TRANS_ACCU) ? 1 : 0;
+    ta.strict_inline_m = strict_dense_cfg() ? -1 : STRICT_INLINE_M;
     ta.geo = h->geo; ta.link = h->link; ta.cbase = h->cbase; ta.mates = h->mates; ta.tabs = h->tabs; ta.step_hdr = h->step_hdr;
     static const bool no_finisher = getenv("GRAAL_NO_FINISHER") != nullptr; // always finish with k_fin (diagnostics)
     ta.flags = h->d_flags;
@@ -4022,13 +4597,13 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     // (late stage -- a few long contigs hold nearly every fragment: nearly every step needs k_fin anyway, so it is launched
     // right behind the scan instead of after k_tm's verdict has made the round trip through the host, ~10 us per step)
     const bool late_stage = h->max_lcont > 128 && (long long)h->n_contigs * 64 < (long long)h->n;
-    ta.host_res = (h->publish && (world == 1 || h->x_host) && !no_finisher && h->finisher_ok && !h->has_rep && !late_stage && !strict) ? h->res_dev : nullptr;
+    ta.host_res = (h->publish && (world == 1 || h->x_host) && !no_finisher && h->finisher_ok && !h->has_rep && !late_stage && !(strict && strict_dense_cfg())) ? h->res_dev : nullptr;
     ta.wait_ticks = fin_wait_ticks(h);
     ta.counters = (unsigned long long*)(h->d_scalars + 10); ta.queue = h->queue; ta.stat = h->stat_frag;
     ta.lcontbp = h->soa[h->cur].p[F_LCONTBP]; ta.acc = h->d_acc; ta.nfpb = h->nfpb; ta.par = h->par;
     k_tm<<<K, 256, ta.host_res ? tm_fin_dyn_lds() : 0, h->aux>>>(A, ta, fA, nb, K, max_id, rank, world, h->seq);
     CK(hipGetLastError());
-    if (ta.host_res == nullptr && !strict && fin_blocks_cfg(h, K) > fin_blocks_no_wait(K)) CK(hipEventRecord(h->ev_tm, h->aux));
+    if (strict || (ta.host_res == nullptr && fin_blocks_cfg(h, K) > fin_blocks_no_wait(K))) CK(hipEventRecord(h->ev_tm, h->aux));
     // (2) the streaming pass, with a HIP event pair around it on every event_every-th call
     const bool ev = h->want_events && (h->eval_calls % h->event_every == 0);
     h->eval_calls += 1;
@@ -4048,16 +4623,11 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
         CK(hipGetLastError());
     }
     if (strict) {
-        FinArgs fa;
-        fa.tm_done = h->tm_done; fa.step_hdr = h->step_hdr; fa.counters = (unsigned long long*)(h->d_scalars + 10); fa.queue = h->queue;
-        fa.tabs = h->tabs; fa.geo = h->geo; fa.stat = h->stat_frag; fa.acc = h->d_acc; fa.sync = h->d_sync;
-        fa.ln_tab = nullptr; fa.lut_n = 0; fa.skip = 0; fa.seg = 0; fa.norm_u = -1.0f; fa.upw = 4; fa.wq = nullptr;
-        StrictArgs sx;
-        sx.perm = h->perm; sx.cbase = h->cbase; sx.lcontbp = h->soa[h->cur].p[F_LCONTBP]; sx.link = h->link; sx.nfpb = h->nfpb; sx.par = h->par;
-        sx.quirk = (h->mode & GRAAL_MODE_REF_TRANS_ACCU) ? 1 : 0;
-        k_strict<<<1024, 256, 0, st>>>(fa, sx, fA, K, rank, world, (long long*)d_q_out, h->publish ? h->res_dev : nullptr, h->seq);
-        CK(hipGetLastError());
-        if (!h->publish) { CK(hipEventRecord(h->ev_fin, st)); h->fin_pending = true; }
+        if (ta.host_res == nullptr) {
+            int rc_ = launch_strict(h, fA, K, rank, world, (long long*)d_q_out, h->publish, st);
+            if (rc_) return rc_;
+            if (!h->publish) { CK(hipEventRecord(h->ev_fin, st)); h->fin_pending = true; }
+        }
     } else if (ta.host_res == nullptr) {
         int rc_ = launch_fin(h, K, rank, world, (long long*)d_q_out, h->publish, st);
         if (rc_) return rc_;
@@ -4095,7 +4665,8 @@ static int eval_sync(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int
             if ((v & GAVE_UP) && ++h->gave_up >= 3) h->finisher_ok = false;
             res[0] = 0;
             h->publish = true;
-            rc = launch_fin(h, K, rank, world, (long long*)h->d_qout, true, h->stream);
+            rc = (h->mode & GRAAL_MODE_STRICT) ? launch_strict(h, fA, K, rank, world, (long long*)h->d_qout, true, h->stream)
+                                               : launch_fin(h, K, rank, world, (long long*)h->d_qout, true, h->stream);
             h->publish = false;
             if (rc) return rc;
             continue;

@@ -384,7 +384,15 @@ class sampler(object):
         # MCMC steps between full re-evaluations of the carried-over likelihood.  With repeats every step: the reference's
         # candidate pixel ranges miss some pixels an activity swap changes (kernels3.cu:3368-3373), so its per-step total
         # (always a full evaluation, cuda_lib_gl.py:1828-1848) is not the previous score
-        self.resync_every = 1 if (len(self.id_frag_duplicated) or self.reference_arithmetic == "strict") else 512
+        # Reference arithmetic: a strict delta IS full(after) - full(before) pixel by pixel, so that total is carried like the
+        # default one (tests/test_strict_windowed_gpu.py::test_strict_total_carried_over_equals_a_full_evaluation) -- except with
+        # the trans-branch RF-count indexing (kernels3.cu:3155) when a bin's sub-fragments have different counts: mirroring a bin
+        # then changes its trans pixels with bins OUTSIDE contig(A) u contig(B) too, which no candidate delta of the reference
+        # contains; its per-step full evaluation does.
+        # And with several sub-fragments per bin, a bin's OWN pixel (its sub-fragment pairs) is in no candidate delta either
+        # (kernels3.cu:3356-3380) while its float32 value moves with the bin's coordinates: 1e-7 relative per 100 steps, measured.
+        # So the strict total is carried only at one sub-fragment per bin (level 0: the C4 / C5 shapes).
+        self.resync_every = 1 if (len(self.id_frag_duplicated) or (self.reference_arithmetic and not self._single_sub)) else 512
         self._steps_since_full = 0
         self._force_full = False   # the carried-over total is not a likelihood of the current layout / parameters
         # ---- proposal ----------------------------------------------------------------------------------------

@@ -1,0 +1,127 @@
+"""GPU: the windowed reference-arithmetic candidate kernels (k_tm's own pricing of small sets, k_strict_cull + k_strict, the
+finishing block's contacts) -- the path `reference_arithmetic="strict"` runs and bench.py measures.
+
+* equal, BIT FOR BIT, to k_strict_dense -- the O(m^2) kernel that prices every pixel of contig(fA) u contig(fB) under every
+  candidate the way sub_compute_likelihood does (kernels3.cu:3259-3718) -- run in a child process (GRAAL_STRICT_DENSE=1);
+* against the oracle's reference-arithmetic restatement (fix_trans_accu=False) with repeated bins: deltas, full likelihood and
+  full start_EM traces with activity swaps (the modes used to refuse repeats);
+* the total carried from step to step in strict mode == a full evaluation (the reference re-evaluates every step)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from graal_amd import em, synth
+from oracle import oracle as O
+from tests import strict_cases
+from tests.test_engine_gpu import relabel_ref
+from tests.test_repeats_gpu import engine_with_repeats, oracle_deltas_with_repeats, random_state_with_repeats
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.timeout(1500)
+def test_windowed_kernels_equal_the_dense_validation_kernel_bit_for_bit(tmp_path):
+    out = str(tmp_path / "dense.npz")
+    env = dict(os.environ, GRAAL_STRICT_DENSE="1")
+    subprocess.check_call([sys.executable, "-m", "tests.strict_cases", out], cwd=ROOT, env=env, timeout=1200)
+    dense = np.load(out)
+    got = strict_cases.run_cases()
+    assert os.environ.get("GRAAL_STRICT_DENSE") in (None, "0")
+    for i, (name, *_rest) in enumerate(strict_cases.CASES):
+        want = dense["case%d" % i]
+        assert got[name].shape == want.shape
+        assert np.abs(want).max() > 0
+        bad = np.argwhere(got[name] != want)
+        assert len(bad) == 0, (name, len(bad), bad[:5], (got[name] - want)[tuple(bad[0])])
+
+
+def rep_problem_ref(n_sub, seed, n_bins=40, nnz=900, dup=(7, 21), n_copies=2):
+    """Repeated bins on generic coordinates with non-uniform RF counts: what the reference arithmetic is sensitive to."""
+    par = synth.make_param_simu(fact=300.0, v_inter=0.03)
+    P = synth.make_problem(n_bins=n_bins, nnz=nnz, n_sub=n_sub, seed=seed, contig_weights=(5, 3, 2), mean_len_bp=1500.0,
+                           accu=("random", 1, 9) if n_sub > 1 else 1, param=par)
+    return synth.add_repeats(synth.with_dense(P), dup, n_copies)
+
+
+def ref_dense(P):
+    return O.DenseOracle(P["hic_matrix"], P["np_sub_frags_id"], P["np_sub_frags_len_bp"], P["np_sub_frags_accu"],
+                         P["frag_dispatcher"], P["collector_id_repeats"], P["n_frags"], P["mean_squared_frags_per_bin"],
+                         P["param_simu"], fix_trans_accu=False)
+
+
+@pytest.mark.parametrize("n_sub,seed,p_circ", [(1, 181, 0.0), (3, 182, 0.0), (3, 183, 0.3)])
+def test_reference_arithmetic_with_repeats_full_and_deltas(n_sub, seed, p_circ):
+    P = rep_problem_ref(n_sub, seed)
+    dense = ref_dense(P)
+    rng = np.random.RandomState(seed)
+    n = int(P["n_new_frags"])
+    copies = np.nonzero(P["S_o_A_frags"]["rep"] == 1)[0]
+    for trial in range(3):
+        s = random_state_with_repeats(P, rng, n_contigs=int(rng.randint(8, 16)), p_circ=p_circ)
+        max_id = relabel_ref(s)
+        e = engine_with_repeats(P, s)
+        e.set_mode(ref_trans_accu=True, strict=True)
+        assert e.relabel_contigs() == max_id
+        assert e.eval_full() == pytest.approx(dense.evaluate(s), rel=1e-6)
+        for fA in (int(rng.randint(n)), int(copies[trial % len(copies)]), 7):
+            fBs = [int(v) for v in rng.choice(np.setdiff1d(np.arange(n), [fA]), 3, replace=False)]
+            base, want = oracle_deltas_with_repeats(P, dense, s, fA, fBs, max_id)
+            got = e.eval_candidates(fA, fBs, max_id)
+            # (5e-6: every pixel is priced twice from slightly different float32 coordinates, device vs glibc powf / expf ulps
+            # do not cancel -- tests/test_strict_gpu.py)
+            assert np.all(np.abs(got - want) <= 5e-6 * abs(base)), (trial, fA, fBs, np.abs(got - want).max() / abs(base))
+        e.close()
+
+
+@pytest.mark.parametrize("n_sub,seed,dup", [(1, 191, (7, 21)), (3, 192, (5, 18, 30))])
+def test_strict_trace_with_repeats_matches_the_reference_arithmetic_oracle(n_sub, seed, dup):
+    from tests.test_sampler_gpu import make_gpu_sampler
+    par = synth.make_param_simu(fact=200.0, v_inter=0.02)
+    P = synth.make_problem(n_bins=45, nnz=900, n_sub=n_sub, seed=seed, contig_weights=(5, 4, 3), mean_len_bp=2000.0,
+                           accu=("random", 1, 9) if n_sub > 1 else 1, param=par)
+    P = synth.add_repeats(synth.with_dense(P), dup, 2)
+    ora = O.OracleSampler(P, np.random.RandomState(seed), fix_trans_accu=False)
+    t_ref = em.run_em(ora, 2, 3, rng=ora.rng)
+    rng = np.random.RandomState(seed)
+    g = make_gpu_sampler(P, rng, reference_arithmetic="strict")
+    t_gpu = em.run_em(g, 2, 3, rng=rng)
+    m_ref = np.asarray(t_ref.mutations())
+    assert np.array_equal(t_gpu.mutations(), m_ref)
+    assert (m_ref[:, 2] == 8).any()                                     # activity swaps occurred
+    assert t_gpu.n_contigs == t_ref.n_contigs and t_gpu.dist == t_ref.dist
+    assert np.allclose(t_gpu.likelihood, t_ref.likelihood, rtol=1e-6, atol=0)
+    g.gpu_vect_frags.copy_from_gpu()
+    for k in O.FIELDS:
+        assert np.array_equal(getattr(g.gpu_vect_frags, k), ora.gpu_vect_frags[k]), k
+    g.free_gpu()
+
+
+def test_strict_total_carried_over_equals_a_full_evaluation():
+    """In reference arithmetic the candidate delta IS full(after) - full(before) pixel by pixel (pixels outside the set get the
+    same inputs), so at one sub-fragment per bin -- no bin has a pixel of its own -- the carried-over total needs no per-step
+    re-evaluation: after 150 steps on generic coordinates it equals a full pass to summation rounding.  (With sub-fragments the
+    sampler re-evaluates every step, like the reference: sampler.resync_every.)"""
+    from tests.test_sampler_gpu import make_gpu_sampler
+    par = synth.make_param_simu(fact=200.0, v_inter=0.02)
+    P = synth.with_dense(synth.make_problem(n_bins=150, nnz=5000, n_sub=1, seed=77, contig_weights=(5, 4, 3), mean_len_bp=1800.0,
+                                            accu=1, param=par))
+    rng = np.random.RandomState(5)
+    g = make_gpu_sampler(P, rng, reference_arithmetic="strict")
+    assert g.resync_every > 150
+    g.init_likelihood()
+    order = rng.permutation(P["n_frags"])
+    for i in order[:150]:
+        g.step_max_likelihood(int(i), 3)
+    carried = g.likelihood_t
+    full = g.eval_likelihood()
+    assert carried == pytest.approx(full, rel=1e-10), (carried, full)
+    g.free_gpu()
+    P3 = synth.with_dense(synth.make_problem(n_bins=60, nnz=900, n_sub=3, seed=78, contig_weights=(5, 4, 3), mean_len_bp=1800.0, accu=9, param=par))
+    g3 = make_gpu_sampler(P3, np.random.RandomState(5), reference_arithmetic="strict")
+    assert g3.resync_every == 1
+    g3.free_gpu()
