@@ -44,14 +44,15 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 
 
-def build_sampler(P, rng, group, device):
+def build_sampler(P, rng, group, device, arithmetic="strict"):
     from graal_amd.sampler import sampler
     return sampler(True, P["S_o_A_frags"], P["collector_id_repeats"], P["frag_dispatcher"], [], [], P["n_frags"],
                    P["n_new_frags"], P["init_n_sub_frags"], P["n_new_sub_frags"], None,
                    (P["bin_coo_row"], P["bin_coo_col"], P["bin_coo_val"]), P["np_sub_frags_len_bp"],
                    P["np_sub_frags_id"], P["np_sub_frags_accu"], P["mean_squared_frags_per_bin"], None, None,
                    (P["coo_row"], P["coo_col"], P["coo_val"]), P["mean_value_trans"], 1, False, None,
-                   device=device, rng=rng, group=group, param_simu=P["param_simu"], compute_dist=False)
+                   device=device, rng=rng, group=group, param_simu=P["param_simu"], compute_dist=False,
+                   reference_arithmetic=arithmetic)
 
 
 def exploded_layout(P):
@@ -98,6 +99,41 @@ def cpu_baseline(P, state, budget_s=24.0):
     return {"value": done / dt, "unit": "candidate logL evals/s", "cores": 1, "kind": "port",
             "sample": "%d whole-candidate numpy float32/float64 re-scores of the same %d-contact state (%.1f s)" % (
                 done, len(P["coo_row"]), dt)}
+
+
+def cpu_baseline_dense(budget_s=8.0):
+    """SURVEY 8d(i) "reference arithmetic on CPU": the C restatement of the reference's dense kernels (oracle/graal_oracle.c:
+    sub_compute_likelihood over every pixel of contig(A) u contig(B), kernels3.cu:3259-3718) on the C2 stand-in (1,086 bins x 3
+    sub-fragments, its 7 original contigs), one host thread.  The checker, timed -- never shipped."""
+    from graal_amd import synth
+    from oracle import oracle as O
+    from tests import util
+    par = synth.make_param_simu(fact=200.0, v_inter=0.02)
+    P = synth.with_dense(synth.make_problem(n_bins=1086, nnz=120_000, n_sub=3, seed=2016, contig_weights=synth.C5_CONTIG_WEIGHTS,
+                                            mean_len_bp=660.0, accu=("random", 1, 9), param=par))
+    dense = O.DenseOracle(P["hic_matrix"], P["np_sub_frags_id"], P["np_sub_frags_len_bp"], P["np_sub_frags_accu"],
+                          P["frag_dispatcher"], P["collector_id_repeats"], P["n_frags"], P["mean_squared_frags_per_bin"],
+                          P["param_simu"], fix_trans_accu=False)
+    s = O.copy_state(P["S_o_A_frags"])
+    s["id_c"][:] -= 1
+    per_pix = np.zeros(dense.n_pix)
+    dense.evaluate(s, per_pix)
+    n = P["n_frags"]
+    max_id = int(s["id_c"].max())
+    rng = np.random.RandomState(1)
+    done, pixels, t0 = 0, 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        fA, fB = (int(v) for v in rng.choice(n, 2, replace=False))
+        sub = np.sort(np.nonzero((s["id_c"] == s["id_c"][fA]) | (s["id_c"] == s["id_c"][fB]))[0])
+        for op in range(13):
+            cand, _ = util.oracle_candidate(s, fA, fB, op, max_id)
+            dense.sub_compute(cand, sub, [], np.arange(n, dtype=np.int32), per_pix)
+            done += 1
+            pixels += len(sub) * (len(sub) - 1) // 2
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "candidate logL evals/s", "cores": 1, "kind": "port",
+            "workload": "C2 stand-in (1,086 bins x 3 sub-fragments, 120,000 contacts, 7 contigs)",
+            "sample": "%d candidates = %d dense pixels re-priced by the C restatement of sub_compute_likelihood (%.1f s)" % (done, pixels, dt)}
 
 
 def hbm_control(P, smp, props, max_id, n, repeat):
@@ -164,6 +200,10 @@ def main():
     ap.add_argument("--mcmc-warmup", type=int, default=int(os.environ.get("GRAAL_BENCH_MCMC_WARMUP", 2000)))
     ap.add_argument("--neighbours", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--arithmetic", choices=("strict", "exact"), default="strict",
+                    help="arithmetic of the headline `value`: strict = the reference's (kernels3.cu:3259-3718; the sampler's default), "
+                         "exact = mathematically exact deltas; the other one is reported next to it")
+    ap.add_argument("--long-steps", type=int, default=1000, help="steps of the second timed region (`value_1000`, SURVEY 8d); 0 = skip")
     ap.add_argument("--no-late-stage", action="store_true", help="skip the extra measurement on the map's 7 original contigs")
     ap.add_argument("--no-hbm-control", action="store_true", help="skip the Infinity-Cache control of the roofline figure")
     ap.add_argument("--control-repeat", type=int, default=6, help="hbm_control: list every contact this many times")
@@ -224,8 +264,12 @@ def main():
     t_gen = time.perf_counter() - t_gen
     rng = np.random.RandomState(20141217)
     t_setup = time.perf_counter()
-    smp = build_sampler(P, rng, group, local if world > 1 else 0)
+    smp = build_sampler(P, rng, group, local if world > 1 else 0, args.arithmetic)
     t_setup = time.perf_counter() - t_setup
+
+    def set_arithmetic(sm, which):
+        sm.engine.set_mode(ref_trans_accu=which == "strict", strict=which == "strict")
+    other = "exact" if args.arithmetic == "strict" else "strict" 
     n = int(smp.n_new_frags)
     K = args.neighbours
 
@@ -242,7 +286,7 @@ def main():
     max_id = smp.modify_gl_cuda_buffer(0)
 
     # ---- proposals for the timed region, drawn beforehand ---------------------------------------------------------
-    total = args.warmup + args.steps
+    total = args.warmup + max(args.steps, args.long_steps)
     frags = rng.randint(0, n, size=total)
     props = []
     for f in frags:
@@ -272,7 +316,7 @@ def main():
     n_cand = 0
     sync_all()
     t0 = time.perf_counter()
-    for f, nb in props[args.warmup:]:
+    for f, nb in props[args.warmup:args.warmup + args.steps]:
         smp._candidate_deltas(f, nb, max_id)   # records a HIP event pair around k_scan on the stream it runs on
         n_cand += 13 * len(nb)
     sync_all()
@@ -288,6 +332,29 @@ def main():
     scan_ms = np.concatenate([smp.engine.scan_times(n2), scan_ms_timed])
     smp.engine.set_timing(EVENT_EVERY)
     counters = smp.engine.last_counters()
+    def timed_region(sm, pr, mid, n_steps):
+        nc = 0
+        sync_all()
+        tt = time.perf_counter()
+        for f, nb in pr[:n_steps]:
+            sm._candidate_deltas(f, nb, mid)
+            nc += 13 * len(nb)
+        sync_all()
+        return nc, max_over_ranks(time.perf_counter() - tt)
+
+    # SURVEY 8d's region: 1,000 steps (the driver's 20 steps last under a millisecond)
+    long_region = None
+    if args.long_steps > 0:
+        nc, tl_ = timed_region(smp, props[args.warmup:], max_id, args.long_steps)
+        long_region = {"value_1000": nc / tl_, "ms_per_step_1000": 1e3 * tl_ / args.long_steps, "steps_1000": args.long_steps}
+    # the same steps in the OTHER arithmetic (same engine, same proposals)
+    set_arithmetic(smp, other)
+    for f, nb in props[:args.warmup]:
+        smp._candidate_deltas(f, nb, max_id)
+    n_other = max(args.steps, min(args.long_steps, 300))
+    nc, to_ = timed_region(smp, props[args.warmup:], max_id, n_other)
+    other_block = {"arithmetic": other, "value": nc / to_, "unit": "candidate logL evals/s", "ms_per_step": 1e3 * to_ / n_other, "steps": n_other}
+    set_arithmetic(smp, args.arithmetic)
     # N > 1: the same timed region once more with the OTHER way of summing the ranks' 13*K int64 values (one all-reduce of a
     # device buffer per step through torch.distributed -- RCCL with the nccl backend), reported next to the default
     alt = None
@@ -297,7 +364,7 @@ def main():
             smp._candidate_deltas(f, nb, max_id)
         sync_all()
         ta = time.perf_counter()
-        for f, nb in props[args.warmup:]:
+        for f, nb in props[args.warmup:args.warmup + args.steps]:
             smp._candidate_deltas(f, nb, max_id)
         sync_all()
         ta = max_over_ranks(time.perf_counter() - ta)
@@ -354,7 +421,7 @@ def main():
             P2 = dict(P)
             P2["S_o_A_frags"] = soa_original
             rng2 = np.random.RandomState(20141217)
-            smp2 = build_sampler(P2, rng2, group, local if world > 1 else 0)
+            smp2 = build_sampler(P2, rng2, group, local if world > 1 else 0, args.arithmetic)
             smp2.init_likelihood()
             max_id2 = smp2.modify_gl_cuda_buffer(0)
             props2 = []
@@ -362,21 +429,44 @@ def main():
                 nb = smp2.return_neighbours(int(f), K)
                 nb.sort()
                 props2.append((int(f), nb))
-            for f, nb in props2[:3]:
-                smp2._candidate_deltas(f, nb, max_id2)
-            sync_all()
-            tl = time.perf_counter()
-            n_cand2 = 0
-            for f, nb in props2[3:]:
-                smp2._candidate_deltas(f, nb, max_id2)
-                n_cand2 += 13 * len(nb)
-            sync_all()
-            tl = max_over_ranks(time.perf_counter() - tl)
-            c2 = smp2.engine.last_counters()
             st2 = smp2.engine.layout_stats()
-            late = {"workload": "same map, its %d original contigs (longest %d fragments)" % (int(st2[0]), int(st2[4])),
-                    "value": n_cand2 / tl, "unit": "candidate logL evals/s", "ms_per_step": 1e3 * tl / len(props2[3:]), "steps": len(props2[3:]),
-                    "queued_contacts_last_step_this_rank": int(c2[2]), "mass_items_last_step_this_rank": int(c2[3])}
+            late = {"workload": "same map, its %d original contigs (longest %d fragments)" % (int(st2[0]), int(st2[4]))}
+            for which in (args.arithmetic, other):
+                set_arithmetic(smp2, which)
+                for f, nb in props2[:3]:
+                    smp2._candidate_deltas(f, nb, max_id2)
+                n_cand2, tl = timed_region(smp2, props2[3:], max_id2, len(props2[3:]))
+                c2 = smp2.engine.last_counters()
+                blk = {"value": n_cand2 / tl, "unit": "candidate logL evals/s", "ms_per_step": 1e3 * tl / len(props2[3:]), "steps": len(props2[3:]),
+                       "queued_contacts_last_step_this_rank": int(c2[2]), "work_units_last_step_this_rank": int(c2[3])}
+                if which == args.arithmetic:
+                    late.update(blk)
+                    late["arithmetic"] = which
+                else:
+                    late["other_arithmetic"] = dict(blk, arithmetic=which)
+            # a full MCMC step (+ the nuisance-parameter step of the reference GUI's default) in this regime
+            set_arithmetic(smp2, args.arithmetic)
+            smp2.bins = np.arange(1.0, 41.0, 1.0)
+            smp2.step_nuisance_parameters(0, 0, 1)
+            order2 = np.arange(n, dtype=np.int32)
+            rng2.shuffle(order2)
+            torch.cuda.synchronize()
+            tl = time.perf_counter()
+            for i in order2[:8]:
+                smp2.step_max_likelihood(int(i), K)
+            torch.cuda.synchronize()
+            late["full_mcmc_step_ms"] = 1e3 * (time.perf_counter() - tl) / 8
+            tl = time.perf_counter()
+            for i in order2[8:16]:
+                smp2.step_max_likelihood(int(i), K)
+                smp2.step_nuisance_parameters(0, 0, 1)
+            torch.cuda.synchronize()
+            late["full_mcmc_step_sample_param_ms"] = 1e3 * (time.perf_counter() - tl) / 8
+            smp2.engine.eval_full_q()
+            tl = time.perf_counter()
+            for _ in range(5):
+                smp2.engine.eval_full_q()
+            late["full_eval_ms"] = 1e3 * (time.perf_counter() - tl) / 5
             smp2.free_gpu()
         except Exception as e:   # an extra must not cost the headline line (a rank that fails alone makes the others' next
             late = {"error": repr(e)}   # collective time out after 300 s: they land here too)
@@ -399,7 +489,7 @@ def main():
         # median are left out of the mean, and counted.)
         med = float(np.median(scan_ms))
         kept = scan_ms[scan_ms <= 2.0 * med]
-        scan_s = float(np.mean(kept)) * 1e-3
+        scan_s = med * 1e-3                       # the MEDIAN launch prices the roofline (the trimmed and the plain mean are reported)
         achieved = bytes_per_launch / scan_s / 1e9
         replay_s = scan_replay_ms * 1e-3
         traffic = None
@@ -418,21 +508,30 @@ def main():
             "data": "synthetic",
             "config": {"workload": "C5 synthetic %d-fragment / %d-contact map, %s + %d MCMC warm-up steps"
                                    % (n, len(P["coo_row"]), args.layout, args.mcmc_warmup),
+                       "reference_arithmetic": args.arithmetic,
+                       "reference_arithmetic_note": "strict = every pixel of contig(A) u contig(B) re-priced from float32 kb coordinates like "
+                                                    "sub_compute_likelihood (kernels3.cu:3259-3718) + the trans-branch RF-count indexing: the "
+                                                    "sampler's default, traces are the reference's; exact = mathematically exact deltas",
                        "neighbours_per_step": K, "candidates_per_step": 13 * K, "contacts_per_gpu": int(nnz_local),
                        "n_contigs": int(stats[0]), "max_contig_len": int(stats[4]),
                        "parallelism": "contacts sharded x%d, %s" % (world, {
                            "none": "single rank", "rccl": "1 all-reduce(65 x int64)/step (%s)" % args.backend,
                            "host": "65 x int64 per rank and step published to pinned host memory shared by the ranks, summed by every host"
                        }[smp.exchange])},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_scan",
-                         "bytes_per_launch": bytes_per_launch, "avg_launch_ms": scan_s * 1e3,
-                         "launches_timed": int(len(kept)), "host_stall_samples_left_out": int(len(scan_ms) - len(kept)),
+            "roofline": dict({"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "committed rocprofv3 --pmc run of this workload (profiles/traffic.json), not measured in this run",
+                         "kernel": "k_scan", "bytes_per_launch": bytes_per_launch, "avg_launch_ms": scan_s * 1e3,
+                         "launch_ms_median": med, "launch_ms_mean_all_samples": float(np.mean(scan_ms)),
+                         "launch_ms_mean_without_host_stalls": float(np.mean(kept)),
+                         "launches_timed": int(len(scan_ms)), "host_stall_samples": int(len(scan_ms) - len(kept)),
                          "launch_ms_samples": [round(float(x), 5) for x in scan_ms[:96]],
                          "back_to_back_replay_ms": replay_s * 1e3,
                          "frac_back_to_back_replays": bytes_per_launch / replay_s / 1e9 / HBM_PEAK_GBS,
                          "isolated_replay_ms": scan_isolated_ms,
-                         "hbm_control": control},
+                         "working_set_note": "the 80 MB row array is re-read every step and fits the 256 MiB Infinity Cache: "
+                                             "the hbm_control_* fields time the same kernel on a 480 MB row array"},
+                        **({} if not control else {"hbm_control_" + k_: v_ for k_, v_ in control.items()})),
             "phase_ms": {"k_scan": scan_s * 1e3, "host_wall_per_step": 1e3 * elapsed / args.steps},
             "relevant_pairs_last_step": int(counters[1]), "queued_contacts_last_step": int(counters[2]),
             "mass_items_last_step": int(counters[3]),
@@ -440,16 +539,25 @@ def main():
             "full_mcmc_step_sample_param_ms": 1e3 * full_step_sp_s,
             "setup_s": {"generate": t_gen, "sampler": t_setup, "mcmc_warmup": t_mcmc},
         }
+        out["other_arithmetic"] = other_block
+        if long_region:
+            out.update(long_region)
         if world > 1:
-            out["distributed"] = {"backend": args.backend, "ranks": int(td.get_world_size()), "exchange": smp.exchange}
+            out["distributed"] = {"backend": td.get_backend(), "ranks": int(td.get_world_size()), "exchange": smp.exchange,
+                                  "rccl_ranks": int(td.get_world_size()) if td.get_backend() == "nccl" else 0,
+                                  "value_produced_by_exchange": smp.exchange}
         if alt is not None:
             out["exchange_alt"] = alt
         if late is not None:
             out["late_stage"] = late
         if world == 1 and not args.no_cpu_baseline:
             smp.gpu_vect_frags.copy_from_gpu()
-            out["cpu_baseline"] = cpu_baseline(P, smp.gpu_vect_frags.as_dict())
+            out["cpu_baseline"] = cpu_baseline(P, smp.gpu_vect_frags.as_dict(), budget_s=16.0)
             out["cpu_baseline"]["host_cpus"] = os.cpu_count()
+            try:
+                out["cpu_baseline_dense"] = cpu_baseline_dense()
+            except Exception as e:
+                out["cpu_baseline_dense"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     smp.free_gpu()
     if world > 1:

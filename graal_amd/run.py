@@ -32,6 +32,9 @@ def main(argv=None):
     ap.add_argument("--no-explode", action="store_true")
     ap.add_argument("--seed", type=int, default=None, help="seed of the numpy RandomState (the reference never seeds)")
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--arithmetic", choices=("strict", "trans_accu", "exact"), default="strict",
+                    help="strict = the reference's float32 pixel arithmetic (default: traces are the reference's); exact = "
+                         "mathematically exact candidate deltas (faster on long contigs)")
     ap.add_argument("--out", default=None)
     args = ap.parse_args(argv)
     if not 1 <= args.level < args.size_pyramid:
@@ -48,7 +51,8 @@ def main(argv=None):
                   inp["id_frags_blacklisted"], inp["n_frags"], inp["n_new_frags"], inp["init_n_sub_frags"], inp["n_new_sub_frags"],
                   None, inp["hic_matrix_sub_sampled"], inp["np_sub_frags_len_bp"], inp["np_sub_frags_id"], inp["np_sub_frags_accu"],
                   inp["mean_squared_frags_per_bin"], inp["norm_vect_accu"], inp["S_o_A_sub_frags"], inp["hic_matrix"],
-                  inp["mean_value_trans"], args.cycles, False, None, device=args.device, rng=rng)
+                  inp["mean_value_trans"], args.cycles, False, None, device=args.device, rng=rng,
+                  reference_arithmetic=args.arithmetic)
     # simulation_loader.py:109-123: window and bin size of the fit from the initial layout
     g = smp.gpu_vect_frags
     g.copy_from_gpu()

@@ -282,7 +282,7 @@ class sampler(object):
                  hic_matrix, mean_value_trans, n_iterations, is_simu, gl_window=None, pos_vbo=None, col_vbo=None,
                  vel=None, pos=None, raw_im_init=None, pbo_im_buffer=None, sub_sample_factor=0,
                  device=None, rng=None, group=None, param_simu=None, compute_dist=True, exchange=None,
-                 reference_arithmetic=None):
+                 reference_arithmetic="strict"):
         self.o = 0
         self.use_rippe = use_rippe
         self.gl_window = gl_window
@@ -343,11 +343,18 @@ class sampler(object):
             # sum Q vectors of different proposals and their layouts would diverge silently
             raise ValueError("a sharded sampler (world > 1) needs an explicit, identically seeded rng= on every rank")
         self.engine = Engine(0 if device is None else int(device))  # raises if the HIP library / GPU is missing
-        # reference-arithmetic switches (include/graal_hip.h): None = the fast default; "trans_accu" = the
-        # reference's RF-count indexing in the trans branch (kernels3.cu:3155); "strict" = that plus candidate deltas that
-        # re-price every pixel of contig(A) u contig(B) from float32 coordinates like sub_compute_likelihood (validation mode)
+        # Which arithmetic the candidate scores are computed in (include/graal_hip.h):
+        #   "strict" (default) = the reference's: every pixel of contig(A) u contig(B) re-priced from the float32 kb coordinates of
+        #       the candidate layout like sub_compute_likelihood (kernels3.cu:3259-3718), the reference's RF-count indexing in the
+        #       trans branch (kernels3.cu:3155) -- accepted-move traces are the reference's on any coordinates;
+        #   "trans_accu" = that indexing in the full evaluation only, exact deltas;
+        #   "exact" (or None) = mathematically exact deltas: pairs whose geometry a move leaves unchanged contribute exactly
+        #       nothing (the reference re-rounds their float32 coordinates and lets the noise into its scores).  Equal to the
+        #       reference when every kb coordinate is exact in float32, 2-4x faster once contigs hold thousands of fragments.
+        if reference_arithmetic == "exact":
+            reference_arithmetic = None
         if reference_arithmetic not in (None, "trans_accu", "strict"):
-            raise ValueError("reference_arithmetic must be None, 'trans_accu' or 'strict'")
+            raise ValueError("reference_arithmetic must be 'strict', 'trans_accu', 'exact' or None")
         self.reference_arithmetic = reference_arithmetic
         if reference_arithmetic:
             self.engine.set_mode(ref_trans_accu=True, strict=reference_arithmetic == "strict")

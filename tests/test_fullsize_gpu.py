@@ -164,6 +164,59 @@ def test_c5_original_layout_delta_is_full_after_minus_before(c5_grid):
     smp.free_gpu()
 
 
+def test_c5_reference_arithmetic_at_full_size(c5_original, c5):
+    """GRAAL_MODE_STRICT on C5's OWN fragments (generic bp lengths at coordinates of thousands of kb -- where the float32 noise of
+    the reference's geometry is largest, see above).  At one sub-fragment per bin the reference's candidate delta is
+    full(after) - full(before) pixel by pixel, so -- unlike the default mode, which needs the grid variant for this -- the
+    windowed strict kernels (k_strict_cull + k_strict) must reproduce the difference of two FULL evaluations (independent
+    kernels: k_full_nnz / k_full_mass) on the 7 original contigs; and the default mode's distance from the reference arithmetic
+    is recorded for the late stage and for the headline state bench.py measures."""
+    import json
+    import os
+    smp = _original_sampler(c5_original)
+    smp.engine.set_mode(ref_trans_accu=True, strict=True)
+    worst = worst_default = 0.0
+    for fA, nb in _late_proposals(smp, 3):
+        max_id = smp.modify_gl_cuda_buffer(0)
+        before = smp._full_likelihood()
+        d = smp._candidate_deltas(fA, nb, max_id)
+        smp.engine.set_mode()
+        d_def = smp._candidate_deltas(fA, nb, max_id)
+        smp.engine.set_mode(ref_trans_accu=True, strict=True)
+        worst_default = max(worst_default, float(np.nanmax(np.abs(d - d_def))) / abs(before))
+        for k, op in (np.unravel_index(np.nanargmax(np.abs(d)), d.shape), np.unravel_index(np.nanargmax(d), d.shape)):
+            smp.test_copy_struct(fA, nb[k], int(op), max_id)
+            after = smp.eval_likelihood()
+            err = abs(d[k, op] - (after - before)) / abs(before)
+            worst = max(worst, err)
+            assert err < 1e-9, (fA, nb[k], op, d[k, op], after - before)
+            max_id = smp.modify_gl_cuda_buffer(0)
+            before = after
+            d = smp._candidate_deltas(fA, nb, max_id)
+    smp.free_gpu()
+    # the headline state (exploded + MCMC steps): the same proposals in both arithmetics
+    smp, _ = run(c5, 7, 600)
+    max_id = smp.modify_gl_cuda_buffer(0)
+    logl = abs(smp._full_likelihood())
+    rng = np.random.RandomState(5)
+    head = 0.0
+    for fA in rng.randint(0, int(smp.n_new_frags), size=40):
+        nb = smp.return_neighbours(int(fA), 5); nb.sort()
+        d_def = smp._candidate_deltas(int(fA), nb, max_id)
+        smp.engine.set_mode(ref_trans_accu=True, strict=True)
+        d_ref = smp._candidate_deltas(int(fA), nb, max_id)
+        smp.engine.set_mode()
+        head = max(head, float(np.nanmax(np.abs(d_ref - d_def))))
+    smp.free_gpu()
+    rec = {"late_stage_strict_delta_vs_full_difference_rel": worst, "late_stage_default_vs_reference_arithmetic_rel": worst_default,
+           "headline_state_default_vs_reference_arithmetic_abs_logL_units": head, "headline_state_abs_logL": logl}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", "c5_reference_arithmetic.json"), "w") as f:
+        json.dump(rec, f)
+    print("C5 reference arithmetic:", rec)
+
+
 def _late_worker(rank, world, port, q):
     import os
     import torch.distributed as td

@@ -6,7 +6,7 @@ the dense reference re-prices pairs whose geometry a move leaves unchanged with 
 * full likelihood with GRAAL_MODE_REF_TRANS_ACCU == dense evaluate_likelihood restatement, <= 1e-6 relative;
 * strict candidate deltas == the oracle's sub_compute_likelihood restatement, <= 5e-6 x |logL| (libm ulps, see the test);
 * strict accepted-move traces bit-exact, small maps and the C2 shape;
-* the DEFAULT mode on the same inputs: bound on its candidate scores and the step at which its trace departs (recorded)."""
+* the EXACT mode (reference_arithmetic="exact") on the same inputs: bound on its candidate scores and the step at which its trace departs (recorded)."""
 import json
 import os
 
@@ -160,7 +160,7 @@ def test_c2_shape_reference_arithmetic_strict_exact_default_bounded():
     # ---- default mode on the same inputs
     from tests.test_sampler_gpu import make_gpu_sampler
     rng_d = np.random.RandomState(31)
-    d = make_gpu_sampler(P, rng_d)
+    d = make_gpu_sampler(P, rng_d, reference_arithmetic="exact")
     t_def = _run(d, rng_d, 3, n_steps, scrambled=False)
     mut_d, mut_r = t_def.mutations(), t_ref.mutations()
     same = np.all(mut_d == mut_r, axis=1)
