@@ -3593,7 +3593,7 @@ struct Ctx {
     unsigned long long* d_wq = nullptr;      // k_fin's work-queue counters (2 x N_WQ, WQ_STRIDE words apart), zero at rest
     int mode = 0;                 // GRAAL_MODE_* flags (graal_set_mode)
     unsigned long long* d_slist = nullptr;   // k_strict's unit list (k_strict_cull fills it), slist_cap entries
-    unsigned long long* d_slist_n = nullptr; // its length (zero at rest: k_strict's last block clears it)
+    unsigned long long* d_slist_n = nullptr; // its length, a word of d_scalars (zero at rest: k_strict's last block clears it)
     unsigned long long slist_cap = 0;
     unsigned scan_token = 0x5ca90000u; // k_scan launches so far (ScanArgs.token)
     double* d_ln_tab = nullptr;   // [LN_TRANS_LUT] ln of the trans value by RF-count product (k_ln_tab; rebuilt by sync_args)
@@ -3730,6 +3730,7 @@ int refresh(Ctx* h)
 
 constexpr int MAX_SCAN_BLOCKS = 4096;
 constexpr int FULL_BAD = 27; // d_scalars[FULL_BAD]: a term of the last full evaluation was not finite / out of range
+constexpr int SLIST_N = 28;  // d_scalars[SLIST_N]: length of k_strict's unit list (zero at rest)
 constexpr int SCAN_LDS_MAX = 48 * 1024; // affected bitmap of k_scan: 1 bit per contact-list id -> <= 393,216 ids
 
 // threads per block of the streaming pass: 1024 (two blocks per CU) for the lists it is built for; a list of a few hundred
@@ -3916,10 +3917,9 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
         CK(hipMalloc(&h->d_slist, cap * sizeof(unsigned long long)));
         h->slist_cap = cap;
     }
-    if (!h->d_slist_n) {
-        CK(hipMalloc(&h->d_slist_n, sizeof(unsigned long long)));
-        CK(hipMemset(h->d_slist_n, 0, sizeof(unsigned long long)));
-    }
+    // (the list's length lives in the scalars block -- zeroed, synchronously, when the context was created: a hipMemset issued
+    // here could still be in flight when k_strict_cull counts into it)
+    h->d_slist_n = (unsigned long long*)(h->d_scalars + SLIST_N);
     sx.list_cap = h->slist_cap;
     const int no_window = (sx.quirk && h->n_ubins > 0) ? 1 : 0;
     // rows of candidate units = tiles of the affected sets: a block per row up to the chip's width
@@ -4060,7 +4060,7 @@ void graal_destroy(graal_ctx* h)
         (void)hipSetDevice(h->device);
         (void)hipStreamSynchronize(h->stream);
         if (h->aux) (void)hipStreamSynchronize(h->aux);
-        void* ptrs[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->stat, h->sub_rec, h->sub_rec8, h->sub_lab16, h->d_ubins, h->d_ln_tab, h->sub2bin, h->row, h->col, h->cnt, h->queue, h->d_sub_ids, h->d_acc, h->tm_done, h->d_sync, h->d_done, h->d_wq, h->d_flags, h->d_slist, h->d_slist_n, h->stat_frag, h->d_dup_bins, h->d_dup_index,
+        void* ptrs[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->stat, h->sub_rec, h->sub_rec8, h->sub_lab16, h->d_ubins, h->d_ln_tab, h->sub2bin, h->row, h->col, h->cnt, h->queue, h->d_sub_ids, h->d_acc, h->tm_done, h->d_sync, h->d_done, h->d_wq, h->d_flags, h->d_slist, h->stat_frag, h->d_dup_bins, h->d_dup_index,
                         h->d_dispatcher, h->d_collector, h->d_sub_ids_all, h->d_rep_obs,
                         h->keys, h->keys_sorted, h->o2n, h->len_of2[0], h->len_of2[1], h->contig_off2[0], h->contig_off2[1], h->perm, h->cbase, h->link, h->mates, h->cub_tmp, h->tabs, h->step_hdr, h->d_args, h->d_chg,
                         h->d_scalars, h->d_qout, h->d_dref, h->d_dist};
