@@ -160,7 +160,9 @@ def test_dataset_to_trace_through_the_pyramid(tmp_path):
     P["hic_matrix"] = synth.dense_from_coo(sr, sc, sv, S)
     P["hic_matrix_sub_sampled"] = synth.dense_from_coo(br, bc, bv, n)
     seed = 12
-    ora = O.OracleSampler(P, np.random.RandomState(seed), fix_trans_accu=True)
+    # (ragged bins with different RF counts: the sampler's default is the reference's arithmetic, trans-branch RF-count indexing
+    # included -- the oracle runs with it too)
+    ora = O.OracleSampler(P, np.random.RandomState(seed), fix_trans_accu=False)
     t_ref = em.run_em(ora, 2, 4, rng=ora.rng)
     gpu_rng = np.random.RandomState(seed)
     g = sampler(True, inp["S_o_A_frags"], inp["collector_id_repeats"], inp["frag_dispatcher"], inp["id_frag_duplicated"],
