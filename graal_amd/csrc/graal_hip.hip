@@ -3508,8 +3508,12 @@ __global__ __launch_bounds__(256) void k_rep_delta(RepArgs R, const NbTables* __
 }
 
 // ------------------------------------------------------------------ host side
+struct HostStep;                 // host_step.h: the sampler's per-step host logic
+void hs_free(HostStep* p);
+
 struct Ctx {
     int device = 0;
+    HostStep* hs = nullptr;
     std::string err;
     hipStream_t stream = nullptr;
     hipStream_t aux = nullptr;    // k_tm runs here, concurrently with k_scan on the main stream
@@ -4078,6 +4082,7 @@ void graal_destroy(graal_ctx* h)
         if (h->aux) (void)hipStreamDestroy(h->aux);
         (void)hipStreamDestroy(h->stream);
     }
+    hs_free(h->hs);
     delete h;
 }
 
@@ -4989,5 +4994,7 @@ int graal_last_counters(graal_ctx* h, int64_t out[4])
     out[0] = h->nnz; out[1] = res[0]; out[2] = res[2]; out[3] = res[1];
     return GRAAL_OK;
 }
+
+#include "host_step.h"
 
 } // extern "C"

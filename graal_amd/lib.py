@@ -11,7 +11,7 @@ import numpy as np
 from . import build as _build
 
 N_OPS = 13
-ABI_VERSION = 2
+ABI_VERSION = 3
 MODE_REF_TRANS_ACCU, MODE_STRICT = 1, 2
 MAX_NEIGHBOURS = 10
 Q_SCALE = float(1 << 30)
@@ -28,7 +28,19 @@ _f64p = ctypes.POINTER(ctypes.c_double)
 SYMBOLS = ("graal_abi_version", "graal_create", "graal_destroy", "graal_last_error", "graal_set_params",
            "graal_upload_subfrags", "graal_upload_repeats", "graal_upload_contacts", "graal_upload_contacts_f32", "graal_upload_frags", "graal_download_frags",
            "graal_relabel_contigs", "graal_begin_step", "graal_begin_step_launch", "graal_layout_stats", "graal_eval_full_q", "graal_eval_candidates_q",
-           "graal_eval_candidates", "graal_exchange_bytes", "graal_attach_exchange", "graal_eval_candidates_x", "graal_exchange_selftest", "graal_detach_exchange", "graal_upload_distance_ref", "graal_genome_distance", "graal_apply_move", "graal_set_finisher", "graal_set_mode", "graal_set_timing", "graal_last_timing", "graal_scan_times", "graal_time_scan", "graal_last_counters")
+           "graal_eval_candidates", "graal_exchange_bytes", "graal_attach_exchange", "graal_eval_candidates_x", "graal_exchange_selftest", "graal_detach_exchange", "graal_upload_distance_ref", "graal_genome_distance", "graal_apply_move", "graal_set_finisher", "graal_set_mode", "graal_set_timing", "graal_last_timing", "graal_scan_times", "graal_time_scan", "graal_last_counters",
+           "graal_upload_proposal_tables", "graal_step", "graal_step_finish", "graal_host_np_sum", "graal_host_select_move", "graal_host_neighbours")
+
+STEP_DONE, STEP_PAUSED, STEP_FALLBACK = 0, 1, 2
+
+
+class StepOut(ctypes.Structure):
+    """include/graal_hip.h: graal_step_out"""
+    _fields_ = [("stats", ctypes.c_int64 * 8), ("max_id", ctypes.c_int32), ("n_neighbours", ctypes.c_int32),
+                ("neighbours", ctypes.c_int32 * 128), ("sample_out", ctypes.c_int32), ("op_sampled", ctypes.c_int32),
+                ("id_f_sampled", ctypes.c_int32), ("pad", ctypes.c_int32), ("o", ctypes.c_double),
+                ("dist_half_units", ctypes.c_int64), ("scores", ctypes.c_double * (128 * N_OPS))]
+
 
 _lib = None
 
@@ -84,6 +96,16 @@ def load():
         L.graal_set_mode.argtypes = [ctypes.c_void_p, ctypes.c_int32]
         L.graal_scan_times.argtypes = [ctypes.c_void_p, ctypes.c_int32, _f32p]
         L.graal_time_scan.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, _f32p]
+        _u8p = ctypes.POINTER(ctypes.c_uint8)
+        L.graal_upload_proposal_tables.argtypes = [ctypes.c_void_p, _i32p, _f32p, ctypes.c_int32, ctypes.c_int32, _i32p, ctypes.c_int32,
+                                                   _i32p, _i32p, ctypes.c_int32, _u8p, _u8p]
+        L.graal_step.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_double, ctypes.c_int32,
+                                 ctypes.c_int32, ctypes.POINTER(StepOut)]
+        L.graal_step_finish.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_int32, ctypes.POINTER(StepOut)]
+        L.graal_host_np_sum.restype = ctypes.c_double
+        L.graal_host_np_sum.argtypes = [_f64p, ctypes.c_int64]
+        L.graal_host_select_move.argtypes = [ctypes.c_void_p, _f64p, ctypes.c_int32, ctypes.c_int32]
+        L.graal_host_neighbours.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, _i32p, ctypes.c_int32]
         _lib = L
     return _lib
 
@@ -338,6 +360,34 @@ class Engine:
                                                  int(rank), int(world), ctypes.c_void_p(int(d_out_ptr)),
                                                  ctypes.c_void_p(int(stream_ptr) if stream_ptr else 0)),
                  "graal_eval_candidates_q")
+
+    # -- the per-step host logic in C (graal_step) ---------------------------------------------------
+    def upload_proposal_tables(self, xk, pk, id_d, dispatcher, collector, dup_bin_flags, black_frag_flags):
+        xk = _c(xk, np.int32); pk = _c(pk, np.float32)
+        idd = _c(id_d, np.int32); disp = _c(np.asarray(dispatcher).reshape(-1, 2), np.int32); coll = _c(collector, np.int32)
+        dup = _c(dup_bin_flags, np.uint8); blk = _c(black_frag_flags, np.uint8)
+        assert xk.shape == pk.shape and len(dup) == xk.shape[0] == len(disp) and len(blk) == len(idd)
+        u8 = ctypes.POINTER(ctypes.c_uint8)
+        self._ck(self._L.graal_upload_proposal_tables(self._h, xk.ctypes.data_as(_i32p), pk.ctypes.data_as(_f32p), xk.shape[0], xk.shape[1],
+                                                      idd.ctypes.data_as(_i32p), len(idd), disp.ctypes.data_as(_i32p),
+                                                      coll.ctypes.data_as(_i32p), len(coll), dup.ctypes.data_as(u8), blk.ctypes.data_as(u8)),
+                 "graal_upload_proposal_tables")
+        self.step_out = StepOut()
+        self._step_ref = ctypes.byref(self.step_out)
+        self.step_scores = np.frombuffer(self.step_out, dtype=np.float64, count=128 * N_OPS, offset=StepOut.scores.offset)
+
+    def step(self, mt_addr, fA, delta, likelihood_t, flags, prev_circ):
+        """graal_step: STEP_DONE / STEP_PAUSED / STEP_FALLBACK; results in self.step_out"""
+        rc = self._L.graal_step(self._h, mt_addr, fA, delta, likelihood_t, flags, prev_circ, self._step_ref)
+        if rc >= 16:
+            self._ck(rc - 16, "graal_step")
+        return rc
+
+    def step_finish(self, mt_addr, likelihood_t, flags):
+        rc = self._L.graal_step_finish(self._h, mt_addr, likelihood_t, flags, self._step_ref)
+        if rc >= 16:
+            self._ck(rc - 16, "graal_step_finish")
+        return rc
 
     def set_finisher(self, enabled):
         """Let the table kernel's last block finish short-contig steps (default) or always use the finishing kernel."""

@@ -26,7 +26,7 @@ import numpy as np
 
 from . import dist as gdist
 from .gpustruct import GPUStruct
-from .lib import FIELDS, MAX_NEIGHBOURS, N_OPS, Q_FULL_BAD, Q_SCALE, Engine
+from .lib import FIELDS, MAX_NEIGHBOURS, N_OPS, Q_FULL_BAD, Q_SCALE, STEP_DONE, STEP_FALLBACK, STEP_PAUSED, Engine
 
 N_TMP_STRUCT = N_OPS  # cuda_lib_gl.py:112
 MODIFICATION_STR = ['eject frag', 'flip frag',
@@ -406,6 +406,7 @@ class sampler(object):
         self.n_neighbors = 10  # cuda_lib_gl.py:444
         self.setup_distri_frags()
         self.define_repeats()
+        self._setup_c_step()
         self.param_simu = None
         self.bins = np.zeros(0)
         self.likelihood_t = None
@@ -719,11 +720,108 @@ class sampler(object):
         black = self._black_set
         return [x for x in out if x not in black]   # cuda_lib_gl.py:2326-2329
 
+    # ------------------------------------------------------------------ the per-step host logic in C
+    def _mt_state_address(self):
+        """Address of the generator's MT19937 state (uint32 key[624]; int pos) if `rng` is numpy's legacy RandomState (or the
+        module-level np.random), else None: graal_step draws from that very state, so Python and C stay one stream."""
+        rng = self.rng
+        try:
+            if rng is np.random:
+                rng = np.random.mtrand._rand
+            if not isinstance(rng, np.random.RandomState):
+                return None
+            bg = rng._bit_generator
+            if not isinstance(bg, np.random.MT19937):
+                return None
+            self._bitgen_keepalive = bg
+            return int(bg.ctypes.state_address)
+        except Exception:
+            return None
+
+    def _setup_c_step(self):
+        import os
+        self._c_step = False
+        if os.environ.get("GRAAL_PY_STEP"):        # (the Python path, for comparison)
+            return
+        if self.exchange == "rccl":                # the all-reduce is torch's: the Python path drives it
+            return
+        self._mt_addr = self._mt_state_address()
+        if self._mt_addr is None:
+            return
+        n, nb = int(self.n_new_frags), int(self.n_frags)
+        dup = np.zeros(nb, dtype=np.uint8)
+        dup[self.id_frag_duplicated] = 1
+        black = np.zeros(n, dtype=np.uint8)
+        if len(self.id_frags_blacklisted):
+            black[np.asarray(self.id_frags_blacklisted, dtype=np.int64)] = 1
+        self.engine.upload_proposal_tables(self.distri_frags["xk"], self.distri_frags["pk"], self.id_d, self.frag_dispatcher,
+                                           self.collector_id_repeats, dup, black)
+        self._c_step = True
+
+    def _step_c(self, id_fA, delta, t, n_step):
+        """step_max_likelihood through graal_step (include/graal_hip.h): the proposal, the score post-processing, the sampling and
+        the commit run behind the C ABI, on this sampler's own generator state; the rare full re-evaluations stay here.
+        Returns the 9-tuple, or None when the C side hands the step back before drawing anything."""
+        e = self.engine
+        F_t = self.temperature(t, n_step)
+        if F_t != 1.0:
+            return None
+        so = e.step_out
+        flags = (0 if self._single_sub else 1) | (4 if self.compute_dist else 0)
+        resync = self.likelihood_t is None or self._force_full or self._steps_since_full + 1 >= self.resync_every
+        if resync:
+            flags |= 2
+        if self.compute_dist and not self._dist_ref_uploaded:
+            self.dist_inter_genome()                               # (uploads the reference layout of the distance once)
+        rc = e.step(self._mt_addr, id_fA, int(delta), 0.0 if self.likelihood_t is None else float(self.likelihood_t), flags,
+                    self._n_circ_prev)
+        if rc == STEP_FALLBACK:
+            return None
+        st = so.stats
+        n_circ = int(st[6])
+        self.n_stale_paste += int(st[7])
+        self._steps_since_full += 1
+        if rc == STEP_PAUSED:
+            if resync:
+                self.likelihood_t = self._full_likelihood()
+                self._steps_since_full = 0
+                self._force_full = False
+            elif (n_circ or self._n_circ_prev) and not self._single_sub:
+                self.likelihood_t = self._full_likelihood()
+            rc = e.step_finish(self._mt_addr, float(self.likelihood_t), flags)
+        self._n_circ_prev = n_circ
+        K = int(so.n_neighbours)
+        self.last_neighbours = list(so.neighbours[:K])
+        self.score = e.step_scores[:K * self.n_tmp_struct]
+        max_id = np.int32(so.max_id)
+        if rc == STEP_FALLBACK:                                    # an unusual score vector: numpy judges (and raises) itself
+            sample_out, o = select_move(self.score, self.n_tmp_struct, self.rng, F_t)
+            id_f_sampled = self.last_neighbours[sample_out // self.n_tmp_struct]
+            op_sampled = sample_out % self.n_tmp_struct
+            self.test_copy_struct(id_fA, id_f_sampled, op_sampled, max_id)
+            dist = self.dist_inter_genome() if self.compute_dist else 0.0
+        else:
+            o, op_sampled, id_f_sampled = float(so.o), int(so.op_sampled), int(so.id_f_sampled)
+            if self.compute_dist:
+                norm_distance = 3.0 * (len(self.np_init_prev) - self.n_frags_4_dist)
+                dist = (norm_distance - 0.5 * int(so.dist_half_units)) / norm_distance
+            else:
+                dist = 0.0
+        self.o = o
+        self.likelihood_t = o
+        if not np.isfinite(o):
+            self._force_full = True   # (a flagged candidate won: the carried total is not a likelihood; re-evaluate next step)
+        return (o, int(st[0]), np.int32(st[5]), float(st[3]) / float(st[2]), np.int32(st[4]), op_sampled, id_f_sampled, dist, F_t)
+
     # ------------------------------------------------------------------ one MCMC step
     def step_max_likelihood(self, id_fA, delta, size_block=512, dt=0, t=0, n_step=1):
         """``cuda_lib_gl.py:1793-1980``.  Returns (o, n_contigs, min_len, mean_len_bp, max_len, op_sampled,
         id_f_sampled, dist, F_t)."""
         id_fA = int(id_fA)
+        if self._c_step and id_fA not in self._black_set:
+            res = self._step_c(id_fA, delta, t, n_step)
+            if res is not None:
+                return res
         # relabel + index are launched; the proposal is drawn while they run (nothing between here and the reference's
         # return_neighbours call draws from the generator, so the stream is the reference's); then the statistics are read
         self.engine.begin_step_launch()
@@ -772,4 +870,6 @@ class sampler(object):
         self.o = o
         dist = self.dist_inter_genome() if self.compute_dist else 0.0
         self.likelihood_t = o
+        if not np.isfinite(o):
+            self._force_full = True   # (a flagged candidate won: the carried total is not a likelihood; re-evaluate next step)
         return o, n_contigs, min_len, mean_len_bp, max_len, op_sampled, id_f_sampled, dist, F_t

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GRAAL_ABI_VERSION 2
+#define GRAAL_ABI_VERSION 3
 #define GRAAL_N_OPS 13        /* candidates per (fA, fB): cuda_lib_gl.py:112 n_tmp_struct */
 #define GRAAL_MAX_NEIGHBOURS 10 /* neighbours scored by one scan pass (the reference proposes at most n_neighbors = 10, cuda_lib_gl.py:444) */
 #define GRAAL_Q_BITS 30
@@ -191,6 +191,47 @@ int graal_time_scan(graal_ctx* h, int32_t K, int32_t reps, float* avg_ms);
  * out[2]=queue slots (contacts with both ends in an affected contig; the few the third test rejects leave empty entries)
  * out[3]=mass work items (task x 64-fragment chunk) */
 int graal_last_counters(graal_ctx* h, int64_t out[4]);
+
+/* ---- the sampler's per-step HOST logic behind the boundary (graal_amd/csrc/host_step.h) --------------------------------
+ * What cuda_lib_gl.sampler.step_max_likelihood does on the host between its launches: return_neighbours
+ * (cuda_lib_gl.py:2295-2331: RandomState.choice(xk, n, p=pk, replace=False), expansion to the copies of repeated bins,
+ * blacklist filter), the score post-processing and the sampling of the move (cuda_lib_gl.py:1898-1947: duplicate eject / flip
+ * entries zeroed, shift to max - 30, RandomState.choice(ids, 1, p=...)), then the commit (test_copy_struct, :1156).  Same
+ * float64 operations in numpy's order, same draws from the CALLER'S generator: `mt_state` is the address of a numpy MT19937
+ * state (uint32 key[624]; int pos -- RandomState._bit_generator.ctypes.state_address), advanced in place. */
+typedef struct graal_step_out {
+    int64_t stats[8];        /* graal_begin_step's statistics of the layout the step started from */
+    int32_t max_id;
+    int32_t n_neighbours;
+    int32_t neighbours[128]; /* the proposal, sorted */
+    int32_t sample_out;      /* index of the sampled candidate: neighbour * 13 + op */
+    int32_t op_sampled, id_f_sampled;
+    int32_t pad;
+    double o;                /* its score (likelihood_t + delta) */
+    int64_t dist_half_units; /* graal_genome_distance of the new layout (flag bit 2) */
+    double scores[128 * GRAAL_N_OPS];
+} graal_step_out;
+
+enum { GRAAL_STEP_DONE = 0, GRAAL_STEP_PAUSED = 1, GRAAL_STEP_FALLBACK = 2 /* 16 + GRAAL_E_*: error */ };
+
+/* setup_distri_frags' tables (cuda_lib_gl.py:2363-2390): xk[n_bins][k], pk[n_bins][k] (float32); id_d[n_frags] (fragment ->
+ * bin), frag_dispatcher / collector_id_repeats, one flag per bin (repeated) and per fragment (blacklisted) */
+int graal_upload_proposal_tables(graal_ctx* h, const int32_t* xk, const float* pk, int32_t n_bins, int32_t k, const int32_t* id_d,
+                                 int32_t n_frags, const int32_t* dispatcher, const int32_t* collector, int32_t n_collector,
+                                 const uint8_t* dup_bin_flags, const uint8_t* black_frag_flags);
+/* One MCMC step for a fragment that is not blacklisted: relabel + statistics (graal_begin_step), proposal, candidate scores
+ * (graal_eval_candidates / _x), sampling, commit (graal_apply_move), optionally the genome distance.
+ * flags: 1 = pause after the proposal if circular contigs exist now or did at the previous step (`prev_circ`); 2 = pause
+ * always; 4 = genome distance.  Returns GRAAL_STEP_DONE, GRAAL_STEP_PAUSED (the caller refreshes its total and calls
+ * graal_step_finish), GRAAL_STEP_FALLBACK (an unusual case numpy itself has to judge: nothing drawn, nothing committed; after
+ * graal_step_finish: out->scores are valid, the selection is the caller's) or 16 + an error code. */
+int graal_step(graal_ctx* h, void* mt_state, int32_t fA, int32_t delta, double likelihood_t, int32_t flags, int32_t prev_circ,
+               graal_step_out* out);
+int graal_step_finish(graal_ctx* h, void* mt_state, double likelihood_t, int32_t flags, graal_step_out* out);
+/* test hooks of that logic; no device needed (a handle whose graal_create failed for lack of a GPU will do) */
+double graal_host_np_sum(const double* a, int64_t n);
+int graal_host_select_move(void* mt_state, const double* score, int32_t n, int32_t n_tmp);
+int graal_host_neighbours(graal_ctx* h, void* mt_state, int32_t fA, int32_t delta, int32_t* out, int32_t cap);
 
 #ifdef __cplusplus
 }

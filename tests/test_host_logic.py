@@ -205,3 +205,107 @@ def test_blacklist_fill_equals_the_dense_fill():
     assert np.all(r < c) and np.all(np.diff(r.astype(np.int64) * S + c) > 0)      # upper, sorted, no duplicates
     bgot = np.zeros((n_bins, n_bins), dtype=np.float32); bgot[br, bc] = bv; bgot[bc, br] = bv
     assert np.array_equal(bgot, bwant)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The same host logic behind the C ABI (graal_amd/csrc/host_step.h: graal_step): numpy's MT19937 state advanced in place,
+# numpy's pairwise float64 sum, the two legacy `choice` algorithms -- values AND generator state against the Python path above
+# (which tests above hold to numpy itself and to the oracle's literal restatement).  No device call is made.
+def _mt_addr(rs):
+    return int(rs._bit_generator.ctypes.state_address)
+
+
+def test_mt19937_state_layout_is_what_the_c_side_assumes():
+    import ctypes
+    rs = np.random.RandomState(123)
+    rs.random_sample(7)
+    st = rs.get_state(legacy=False)["state"]
+    raw = (ctypes.c_uint32 * 625).from_address(_mt_addr(rs))
+    assert np.array_equal(np.frombuffer(raw, dtype=np.uint32, count=624), st["key"])
+    assert int(np.frombuffer(raw, dtype=np.int32, count=625)[624]) == int(st["pos"])
+
+
+def test_c_np_sum_is_numpys_sum():
+    import ctypes
+    from graal_amd import lib
+    L = lib.load()
+    rng = np.random.RandomState(9)
+    for n in list(range(1, 40)) + [63, 64, 65, 127, 128, 129, 130, 200, 257, 1000]:
+        for scale in (1.0, 1e-8, 1e12):
+            a = np.ascontiguousarray(rng.standard_normal(n) * scale * rng.choice([1.0, 1e-6], size=n))
+            got = L.graal_host_np_sum(a.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), n)
+            assert got == a.sum(), (n, scale)
+
+
+def test_c_select_move_equals_the_python_path_values_and_generator_state():
+    import ctypes
+    from graal_amd import lib
+    L = lib.load()
+    rng = np.random.RandomState(31)
+    n_sampled = 0
+    for trial in range(600):
+        k = int(rng.randint(1, 11))
+        score = -1000.0 + rng.standard_normal(13 * k) * rng.choice([0.1, 5.0, 50.0])
+        if trial % 7 == 0:
+            score[:] = score[0]
+        if trial % 11 == 3:
+            score[rng.randint(len(score))] += 500.0
+        if trial % 13 == 5:
+            score[:] = np.round(score)
+        if trial % 17 == 9:
+            score[rng.randint(len(score))] = np.nan
+        seed = int(rng.randint(1 << 30))
+        a, b = np.random.RandomState(seed), np.random.RandomState(seed)
+        a.random_sample(int(rng.randint(0, 700)) or 1); b.set_state(a.get_state())    # anywhere in the 624-word block
+        want = S.select_move(score, 13, a)
+        sc = np.ascontiguousarray(score)
+        got = L.graal_host_select_move(ctypes.c_void_p(_mt_addr(b)), sc.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), len(sc), 13)
+        assert got == want[0], (trial, got, want)
+        sa, sb = a.get_state(legacy=False)["state"], b.get_state(legacy=False)["state"]
+        assert np.array_equal(sa["key"], sb["key"]) and sa["pos"] == sb["pos"], trial
+        n_sampled += 1
+    assert n_sampled == 600
+
+
+def test_c_neighbour_proposal_equals_the_python_path_values_and_generator_state():
+    import ctypes
+    from graal_amd import lib
+    L = lib.load()
+    P = synth.add_repeats(problem(n_sub=1, seed=8, n_bins=70, nnz=900), (5, 18), 2)
+    n, nb = int(P["n_new_frags"]), int(P["n_frags"])
+    xk, pk = S.neighbour_distributions(P["bin_coo_row"], P["bin_coo_col"], P["bin_coo_val"], nb)
+    # a handle without a device: graal_create fails (no GPU here / or succeeds on the GPU box) but hands the context out either way
+    h = ctypes.c_void_p()
+    L.graal_create(0, ctypes.byref(h))
+    assert h
+    disp = np.ascontiguousarray(np.asarray(P["frag_dispatcher"]).reshape(-1, 2), dtype=np.int32)
+    coll = np.ascontiguousarray(P["collector_id_repeats"], dtype=np.int32)
+    id_d = np.ascontiguousarray(P["S_o_A_frags"]["id_d"], dtype=np.int32)
+    dup = np.zeros(nb, np.uint8); dup[list(P["id_frag_duplicated"])] = 1
+    black = np.zeros(n, np.uint8); black[[3, 40]] = 1
+    i32, u8 = ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_uint8)
+    xk_c, pk_c = np.ascontiguousarray(xk, np.int32), np.ascontiguousarray(pk, np.float32)
+    assert L.graal_upload_proposal_tables(h, xk_c.ctypes.data_as(i32), pk_c.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), nb, xk_c.shape[1],
+                                          id_d.ctypes.data_as(i32), n, disp.ctypes.data_as(i32), coll.ctypes.data_as(i32), len(coll),
+                                          dup.ctypes.data_as(u8), black.ctypes.data_as(u8)) == 0
+
+    class Fake(object):      # the Python path's return_neighbours, without an engine
+        return_neighbours = S.sampler.return_neighbours
+    f = Fake()
+    f.id_d = id_d; f.n_neighbors = 10; f.distri_frags = {"xk": xk, "pk": pk}; f._row_cache, f._copies_cache = {}, {}
+    f._dup_set = set(int(x) for x in P["id_frag_duplicated"]); f.frag_dispatcher = disp; f.collector_id_repeats = coll
+    f._black_set = {3, 40}
+    rng = np.random.RandomState(2)
+    out = np.zeros(128, np.int32)
+    for trial in range(400):
+        fA, delta = int(rng.randint(n)), int(rng.randint(1, 13))
+        seed = int(rng.randint(1 << 30))
+        a, b = np.random.RandomState(seed), np.random.RandomState(seed)
+        a.random_sample(int(rng.randint(1, 700))); b.set_state(a.get_state())
+        f.rng = a
+        want = f.return_neighbours(fA, delta)
+        k = L.graal_host_neighbours(h, ctypes.c_void_p(_mt_addr(b)), fA, delta, out.ctypes.data_as(i32), 128)
+        assert k == len(want) and list(out[:k]) == [int(x) for x in want], (trial, fA, delta)
+        sa, sb = a.get_state(legacy=False)["state"], b.get_state(legacy=False)["state"]
+        assert np.array_equal(sa["key"], sb["key"]) and sa["pos"] == sb["pos"], trial
+    L.graal_destroy(h)
