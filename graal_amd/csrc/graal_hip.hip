@@ -294,6 +294,19 @@ __device__ __forceinline__ int4 ld_stream(const int4* p)
     return make_int4(v.x, v.y, v.z, v.w);
 }
 
+// Debug build (-DGRAAL_STAMPS): selected threads write the 100 MHz wall clock at a few points of the per-step kernels
+#ifdef GRAAL_STAMPS
+__device__ unsigned long long g_stamps[32];
+#define STAMP(i, cond) do { if (cond) g_stamps[i] = wall_clock64(); } while (0)
+__device__ unsigned long long g_blk[4096 * 4]; // per block of k_scan: start, past prologue, loop done
+#define STAMP_BLK(j, cond) do { if (cond) g_blk[4 * blockIdx.x + (j)] = wall_clock64(); } while (0)
+#define STAMP_FBLK(j, cond) do { if ((cond) && blockIdx.x < 2048) g_blk[4 * (2048 + blockIdx.x) + (j)] = wall_clock64(); } while (0) // k_fin's blocks
+#else
+#define STAMP(i, cond) do { } while (0)
+#define STAMP_BLK(j, cond) do { } while (0)
+#define STAMP_FBLK(j, cond) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------ small maintenance kernels
 __global__ void k_refresh_geo(SoaPtr s, Geo* __restrict__ geo, Link* __restrict__ link, int n)
 {
@@ -325,6 +338,9 @@ __global__ void k_mates(int n, const int* __restrict__ perm, const int* __restri
 
 // out: [0] #heads (pos==0) [1] sum l_cont [2] #(start_bp==0) [3] sum l_cont_bp over start_bp==0 [4] max l_cont
 //      [5] min l_cont [6] #(rep != 0 or activ != 1 or id_d != f)  [7] max label  [14] #(circ == 1)
+constexpr int NC_WORD = 29;   // d_scalars[NC_WORD]: number of contigs of the ranked layout (= max_id + 1), kept on the device so that the
+                              // scoring kernels can be launched before the host has read the statistics
+constexpr int N_STAT = 9;
 struct StatAcc { long long v[9]; }; // heads, sum l_cont, #start0, sum lbp, max, min, bad, max label, #circ
 __device__ __forceinline__ StatAcc stat_zero() { StatAcc a = {{0, 0, 0, 0, 0, 0x7fffffff, 0, -1, 0}}; return a; }
 __device__ __forceinline__ void stat_add(StatAcc& a, int f, int pos, int lc, int start_bp, int lbp, int rep, int activ, int id_d, int c, int circ)
@@ -380,6 +396,7 @@ __device__ __forceinline__ void stat_reduce_publish(const StatAcc& a, long long*
     // (device-scope atomic reads: the other blocks' atomics were performed at the memory side, a plain load could hit a
     // stale line of this XCD's L2)
     if (t < 16) host[1 + t] = (long long)atomicAdd((unsigned long long*)&out[t], 0ull);
+    if (t == 16) out[NC_WORD] = (long long)atomicAdd((unsigned long long*)&out[0], 0ull);
     __syncthreads();
     if (t < 8) out[t] = (t == 5) ? 0x7fffffffll : (t == 7 ? -1ll : 0ll);
     if (t == 13 && reset_stale) out[13] = 0;
@@ -388,6 +405,32 @@ __device__ __forceinline__ void stat_reduce_publish(const StatAcc& a, long long*
     __threadfence_system();
     __syncthreads();
     if (t == 0) { host[0] = seq; __threadfence_system(); }
+}
+
+// the block's statistics as one row of partials (no atomics, no ticket): the commit kernel leaves them for the relabel kernel
+// that follows it on the stream, whose first block combines the rows and publishes (k_incr)
+__device__ __forceinline__ void stat_block_partials(const StatAcc& a, long long* __restrict__ part)
+{
+    __shared__ long long sh[16][N_STAT];
+#pragma unroll
+    for (int i = 0; i < N_STAT; i++) {
+        long long x = a.v[i];
+        for (int o = 32; o > 0; o >>= 1) {
+            const long long y = __shfl_down(x, o, 64);
+            x = (i == 4 || i == 7) ? (y > x ? y : x) : (i == 5 ? (y < x ? y : x) : x + y);
+        }
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][i] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < N_STAT) {
+        const int i = threadIdx.x;
+        long long x = sh[0][i];
+        for (int w = 1; w < (int)(blockDim.x >> 6); w++) {
+            const long long y = sh[w][i];
+            x = (i == 4 || i == 7) ? (y > x ? y : x) : (i == 5 ? (y < x ? y : x) : x + y);
+        }
+        part[(size_t)blockIdx.x * N_STAT + i] = x;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_stats(SoaPtr s, int n, long long* __restrict__ out, volatile long long* host = nullptr,
@@ -407,6 +450,7 @@ __global__ void k_stats_fin(long long* __restrict__ sc, volatile long long* host
 {
     const int t = threadIdx.x;
     if (t < 16) host[1 + t] = sc[t];
+    if (t == 16) sc[NC_WORD] = sc[0];
     __syncthreads();
     if (t < 8) sc[t] = (t == 5) ? 0x7fffffffll : (t == 7 ? -1ll : 0ll);
     if (t == 13 && reset_stale) sc[13] = 0;
@@ -529,8 +573,9 @@ struct Changed {
 // has every new record in registers anyway -- the statistics of the NEW layout, which its last block publishes to pinned host
 // memory: the next graal_begin_step finds them there and needs no statistics kernel.
 __global__ __launch_bounds__(256) void k_apply(SoaPtr in, SoaPtr out, int n, int op, int fA, int fB, int max_id, int* __restrict__ n_stale,
-                                               Changed* __restrict__ chg, long long* __restrict__ stats, volatile long long* host, long long seq)
+                                               Changed* __restrict__ chg, long long* __restrict__ part)
 {
+    STAMP(7, blockIdx.x == 0 && threadIdx.x == 0);
     StatAcc a = stat_zero();
     const Rec A0 = ld_rec(in, fA), B0 = ld_rec(in, fB);
     const Move m = make_move(op, fA, fB, max_id, A0, B0);
@@ -549,13 +594,50 @@ __global__ __launch_bounds__(256) void k_apply(SoaPtr in, SoaPtr out, int n, int
         }
         stat_add(a, f, r.pos, r.l_cont, r.start_bp, r.l_cont_bp, r.rep, r.activ, r.id_d, r.id_c, r.circ);
     }
-    stat_reduce_publish(a, stats, host, seq, 0); // (the stale count is reset by the begin_step that reports it)
+    // (round 2 reduced and published here: 10 of this kernel's 16 us were that atomics -> ticket -> publish chain, in front of
+    // the relabel and the whole next step; now the rows go to the relabel kernel, whose block 0 publishes them next to its own work)
+    stat_block_partials(a, part);
+    STAMP(15, blockIdx.x == gridDim.x - 1 && threadIdx.x == 0);
 }
 
 // ---- incremental relabel.  Invariant after every graal_begin_step: labels ARE ranks (contigs sorted by (l_cont, label)),
 // len_of[rank] is sorted and contig_off is its exclusive prefix sum.  One commit changes <= 4 contigs, so the new stable
 // ranking follows from the old one by counting: rank' = rank - #removed before + #inserted before.  Same result as the
 // full sort (cuda_lib_gl.py:1697-1722 with a stable argsort), without sorting 50k keys per step.
+// The statistics of the committed layout: the commit kernel's rows of partials combined and published to pinned host memory,
+// followed by the sequence number; one wave (lane = rows u, u + 64, ...: nine loads in flight per row, then wave reductions).
+__device__ __forceinline__ void publish_partials(const long long* __restrict__ part, int n_part, long long* __restrict__ stats,
+                                                 volatile long long* host, long long seq, int u)
+{
+    if (host != nullptr) {
+        long long v[N_STAT];
+#pragma unroll
+        for (int i = 0; i < N_STAT; i++) v[i] = (i == 5 ? 0x7fffffffll : (i == 7 ? -1ll : 0ll));
+        for (int r = u; r < n_part; r += 64) {
+#pragma unroll
+            for (int i = 0; i < N_STAT; i++) {
+                const long long y = part[(size_t)r * N_STAT + i];
+                v[i] = (i == 4 || i == 7) ? (y > v[i] ? y : v[i]) : (i == 5 ? (y < v[i] ? y : v[i]) : v[i] + y);
+            }
+        }
+        const long long stale = u == 0 ? stats[13] : 0;               // fragments that hit the unwritten paste branch
+#pragma unroll
+        for (int i = 0; i < N_STAT; i++) {
+            long long x = v[i];
+            for (int o = 32; o > 0; o >>= 1) {
+                const long long y = __shfl_down(x, o, 64);
+                x = (i == 4 || i == 7) ? (y > x ? y : x) : (i == 5 ? (y < x ? y : x) : x + y);
+            }
+            if (u == 0) host[1 + (i < 8 ? i : 14)] = x;
+        }
+        if (u == 0) host[1 + 13] = stale;
+        // (words 8..12 and 15 of the host block are not statistics: nobody reads them)
+        __threadfence_system();
+    }
+    if (u == 0) stats[13] = 0;   // (re-armed for the next commit)
+    if (host != nullptr && u == 0) { host[0] = seq; __threadfence_system(); }
+}
+
 struct IncrPlan {
     int n_removed, removed[2], removed_len[2];   // old ranks of contig(fA), contig(fB) and their old lengths
     int n_new, new_lab[4], new_len[4], new_rank[4], new_off[4];
@@ -572,11 +654,20 @@ __global__ __launch_bounds__(256) void k_incr(SoaPtr s, int n, const Changed* __
                                               const int* __restrict__ off_old, int nc_old, int* __restrict__ len_new,
                                               int* __restrict__ off_new, int* __restrict__ perm, int* __restrict__ cbase,
                                               Geo* __restrict__ geo, Link* __restrict__ link, long long* __restrict__ stats,
-                                              int* __restrict__ mates, int* __restrict__ chg_clear, int chg_n)
+                                              int* __restrict__ mates, int* __restrict__ chg_clear, int chg_n,
+                                              const long long* __restrict__ part, int n_part, volatile long long* host, long long seq)
 {
     __shared__ IncrPlan sp;
     __shared__ int s_lb[4], s_ub[4];
     const int t = threadIdx.x;
+    // the LAST block (the grid is one block larger than the fragments need) has one job: the statistics of this layout
+    // (publish_partials) -- next to the other blocks, not in front of them: the two system-scope fences are microseconds
+    STAMP(22, blockIdx.x == 0 && t == 0);
+    if (blockIdx.x == gridDim.x - 1) {
+        if (t < 64 && part != nullptr) publish_partials(part, n_part, stats, host, seq, t);   // (nullptr: k_tm's extra block publishes)
+        STAMP(31, t == 0);
+        return;
+    }
     if (t == 0) {
         IncrPlan p;
         p.n_removed = 0;
@@ -596,7 +687,7 @@ __global__ __launch_bounds__(256) void k_incr(SoaPtr s, int n, const Changed* __
         for (int i = 0; i < 4; i++) { p.new_rank[i] = -1; p.new_off[i] = 0; }
         p.nc_new = nc_old - p.n_removed + p.n_new;
         sp = p;
-        if (blockIdx.x == 0) stats[13] = 0;
+        if (blockIdx.x == 0) stats[NC_WORD] = p.nc_new;
     }
     __syncthreads();
     {   // old contigs with key < (l, c): lower / upper bound of l in the sorted length array, for each of the <= 4 new contigs.
@@ -684,6 +775,7 @@ __global__ __launch_bounds__(256) void k_incr(SoaPtr s, int n, const Changed* __
         out[0] = make_int4(MATES_LONG, MATES_LONG, MATES_LONG, MATES_LONG);
         out[1] = out[0];
     }
+    STAMP(23, blockIdx.x == gridDim.x - 2 && t == 0);
 }
 
 // ------------------------------------------------------------------ full likelihood
@@ -1097,18 +1189,6 @@ constexpr int N_DONE = 16, DONE_STRIDE = 16;
 constexpr int FLAG_STRIDE = 32; // words between two blocks' completion flags: one 128-byte line each (partial writes to one
                                 // line from many XCDs serialise at the memory side)
 
-// Debug build (-DGRAAL_STAMPS): selected threads write the 100 MHz wall clock at a few points of the per-step kernels
-#ifdef GRAAL_STAMPS
-__device__ unsigned long long g_stamps[32];
-#define STAMP(i, cond) do { if (cond) g_stamps[i] = wall_clock64(); } while (0)
-__device__ unsigned long long g_blk[4096 * 4]; // per block of k_scan: start, past prologue, loop done
-#define STAMP_BLK(j, cond) do { if (cond) g_blk[4 * blockIdx.x + (j)] = wall_clock64(); } while (0)
-#define STAMP_FBLK(j, cond) do { if ((cond) && blockIdx.x < 2048) g_blk[4 * (2048 + blockIdx.x) + (j)] = wall_clock64(); } while (0) // k_fin's blocks
-#else
-#define STAMP(i, cond) do { } while (0)
-#define STAMP_BLK(j, cond) do { } while (0)
-#define STAMP_FBLK(j, cond) do { } while (0)
-#endif
 
 // exclusive prefix sum of vals[0..n) into out[0..n) and the total into out[n]; vals / out in LDS.  Executed by ONE wave
 // (all 64 lanes of it), no block barrier inside: a few hundred entries are cheaper to scan in one wave than to
@@ -1744,6 +1824,18 @@ struct TmArgs { // first-needed pointers by value (see ScanArgs)
     int wait_ticks;                // how long that block waits for k_scan (100 MHz ticks)
     int strict;                    // GRAAL_MODE_STRICT: reference arithmetic (same_inputs classes; small sets priced here, the rest by k_strict)
     int quirk;                     // GRAAL_MODE_REF_TRANS_ACCU
+    const long long* nc;           // number of contigs of the ranked layout, on the device (max_id < 0: read it here)
+    // graal_step's deferred flow: the kernel is launched right behind the relabel WITHOUT an event in between (a cross-stream
+    // event wait costs ~10 us of start latency here); its blocks spin until k_scan -- stream-ordered behind the relabel --
+    // announces that it has started (relabel_flag == relabel_seq).  0 = ordered by the host (event / synchronisation).
+    const unsigned long long* relabel_flag;
+    unsigned long long relabel_seq;
+    // ... and one extra block publishes the layout statistics the commit kernel left in rows of partials (see k_incr)
+    const long long* part;
+    int n_part;
+    volatile long long* stats_host;
+    long long stats_seq;
+    long long* stats_dev;
     int strict_inline_m;           // largest affected set k_tm prices itself in reference arithmetic (-1: none, k_strict_dense validation)
     // the finishing block's pointers, by value too
     unsigned long long* counters;
@@ -1765,7 +1857,39 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
     __shared__ Task s_task[MAX_TASKS];
     __shared__ int s_pp[MAX_TASKS + 1];
     const int k = blockIdx.x, t = threadIdx.x;
-    if (k >= K) return;
+    if (k > K || (k == K && ta.part == nullptr)) return;
+    if (ta.relabel_seq != 0ull) {
+        // launched without an event behind the relabel: wait until k_scan (stream-ordered behind it) says it has started.  Bounded:
+        // if the two kernels cannot be resident together (a tool serialising dispatches) the step is flagged as failed and the
+        // host repeats it with an event (eval_sync).
+        __shared__ int s_go;
+        if (t == 0) {
+            int go = 0;
+            const unsigned long long t_end = wall_clock64() + (unsigned long long)ta.wait_ticks;
+            for (;;) {
+                if (__hip_atomic_load(ta.relabel_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == ta.relabel_seq) { go = 1; break; }
+                if (wall_clock64() > t_end) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            s_go = go;
+            if (!go) atomicOr(&ta.counters[6], 4ull);
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (!s_go) {
+            // nothing can be built; take the ticket so that the last block still reports (a failed step: hand_out sees counters[6])
+            if (ta.host_res != nullptr && t == 0 && k < K) {
+                const unsigned long long after = atomicAdd(&ta.sync[0], 1ull) + 1ull;
+                if ((after & 0xffffull) == (unsigned long long)K) { ta.sync[0] = 0; __threadfence_system(); ta.host_res[0] = -seq; __threadfence_system(); }
+            }
+            return;
+        }
+    }
+    if (k == K) {   // the extra block of graal_step's deferred flow: the layout statistics (the commit kernel's rows), off everybody's path
+        if (t < 64) publish_partials(ta.part, ta.n_part, ta.stats_dev, ta.stats_host, ta.stats_seq, t);
+        return;
+    }
+    if (max_id < 0) max_id = (int)ta.nc[0] - 1;   // (launched before the host had the statistics: the relabel left the contig count)
     STAMP(0, k == 0 && t == 0);
     NbTables& T = ta.tabs[k];
     const int my_fB = sel_nb(nb, k);
@@ -2046,6 +2170,9 @@ struct ScanArgs { // by value: kernel-argument pointers are known to be GLOBAL (
     int strict;                   // GRAAL_MODE_STRICT: queue every contact with both ends in a neighbour's affected set
     int wt_queue;                 // queue entries are read by k_tm's finishing block (concurrent kernel): write-through stores
     unsigned token;               // unique per launch: "wave 1's keys of THIS launch are in LDS"
+    const long long* nc;          // number of contigs of the ranked layout (max_id < 0: read it here)
+    unsigned long long* relabel_flag;   // block 0 stores relabel_seq here at once: "the relabel in front of this kernel is complete" (k_tm waits for it)
+    unsigned long long relabel_seq;     // 0: nobody waits
 };
 
 // word j (0 .. 4G-1) of G groups held in registers (select chain over constant indices: stays in registers)
@@ -2076,6 +2203,9 @@ __global__ __launch_bounds__(1024, (G <= 4 ? 8 : 4)) void k_scan(ScanArgs sa, in
     __shared__ unsigned long long s_nrel;
     const int t = threadIdx.x;
     const int lane = t & 63;
+    if (sa.relabel_seq != 0ull && blockIdx.x == 0 && t == 0)
+        __hip_atomic_store(sa.relabel_flag, sa.relabel_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the relabel's writes were released when it ended)
+    if (max_id < 0) max_id = (int)sa.nc[0] - 1;   // (see k_tm; only wave 1 uses it, behind the block's barrier)
     STAMP(8, blockIdx.x == 0 && t == 0 && !dry);
     STAMP_BLK(0, t == 0 && !dry);
     // ---- prologue.  Only the affected BITMAP stands between a block and its stream, so wave 0 builds nothing else: one
@@ -3521,6 +3651,12 @@ struct Ctx {
     hipEvent_t ev_relabel = nullptr; // end of the relabel kernels graal_begin_step left running (orders the next k_tm, on aux)
     hipEvent_t ev_tm = nullptr;   // end of the step's k_tm (orders a chip-filling k_fin behind it, see launch_fin)
     bool relabel_pending = false;
+    // graal_step's deferred flow (begin_step_launch(defer)): the next k_tm is ordered behind the relabel by a device flag that the
+    // next k_scan sets, not by an event; and it publishes the layout statistics in an extra block
+    bool relabel_spin_pending = false, stats_pub_pending = false;
+    bool spin_ok = getenv("GRAAL_NO_TM_SPIN") == nullptr;   // switched off when k_tm and k_scan turn out not to run concurrently
+    unsigned long long relabel_flag_seq = 0, scan_relabel_seq = 0;
+    bool spin_used = false;       // the evaluation in flight relies on the flag (eval_sync repeats it with an event if k_tm gives up)
     bool begin_launched = false;  // graal_begin_step_launch ran for the current layout; graal_begin_step only has to wait
     bool stats_from_apply = false; // the last commit published the statistics of the layout it produced (sequence stats_seq)
     bool fin_pending = false;
@@ -3575,12 +3711,15 @@ struct Ctx {
     int last_fA = 0, last_K = 0, last_max_id = 0; // proposal of the last evaluation (timing replays of the scan)
     int last_fB[MAXK] = {};
     int max_lcont = 0;            // longest contig at the last graal_begin_step (sizes k_fin's grid)
+    int lcont_bound = 0;          // upper bound of the longest contig NOW (graal_step scores before it has the statistics)
     int* d_sub_ids = nullptr;     // [n_bins][4], only when some bin has more than one sub-fragment
     unsigned long long *keys = nullptr, *keys_sorted = nullptr;
     int *o2n = nullptr, *perm = nullptr, *cbase = nullptr;
     int *len_of2[2] = {nullptr, nullptr}, *contig_off2[2] = {nullptr, nullptr}; // per layout buffer (see k_incr)
+    long long* d_part = nullptr;  // [<= 1024][N_STAT] the commit kernel's per-block statistics (published by the next k_incr)
     Changed* d_chg = nullptr;     // [2] commit records: a commit fills one, the relabel that consumes it clears the other
     int chg_w = 0, chg_last = 0;
+    int apply_blocks = 0;         // grid of the last k_apply = rows of d_part
     bool ranks_valid = false;     // labels of buffer `cur` are ranks and its len/offset arrays are current
     int pending_commits = 0;      // commits since the last graal_begin_step
     bool incr_ok = false;         // the single pending commit started from a ranked layout with the right max_id
@@ -3735,6 +3874,7 @@ int refresh(Ctx* h)
 constexpr int MAX_SCAN_BLOCKS = 4096;
 constexpr int FULL_BAD = 27; // d_scalars[FULL_BAD]: a term of the last full evaluation was not finite / out of range
 constexpr int SLIST_N = 28;  // d_scalars[SLIST_N]: length of k_strict's unit list (zero at rest)
+constexpr int RELABEL_FLAG = 30; // d_scalars[RELABEL_FLAG]: sequence number of the last relabel k_scan has announced as complete (k_tm spins on it)
 constexpr int SCAN_LDS_MAX = 48 * 1024; // affected bitmap of k_scan: 1 bit per contact-list id -> <= 393,216 ids
 
 // threads per block of the streaming pass: 1024 (two blocks per CU) for the lists it is built for; a list of a few hundred
@@ -3796,6 +3936,9 @@ int launch_scan(Ctx* h, int fA, const Neigh& nb, int K, int max_id, int dry, hip
     sa.strict = (h->mode & GRAAL_MODE_STRICT) ? 1 : 0;
     sa.wt_queue = finisher_reads ? 1 : 0;
     sa.token = ++h->scan_token;
+    sa.nc = h->d_scalars + NC_WORD;
+    sa.relabel_flag = (unsigned long long*)(h->d_scalars + RELABEL_FLAG);
+    sa.relabel_seq = dry ? 0ull : h->scan_relabel_seq;
     sa.done = (scan_done_counter() && !dry) ? h->d_done : nullptr;
     sa.n_done = scan_done_n();
     if (sa.done) for (int c = 0; c < sa.n_done; c++) h->scan_done_total[c] += (unsigned long long)((nbk - c + sa.n_done - 1) / sa.n_done);
@@ -3868,7 +4011,7 @@ int fin_blocks_cfg(const Ctx* h, int K)
 int launch_fin(Ctx* h, int K, int rank, int world, long long* d_q_out, bool publish, hipStream_t st)
 {
     const int fin_blocks = fin_blocks_cfg(h, K);
-    if (fin_blocks > fin_blocks_no_wait(K)) CK(hipStreamWaitEvent(st, h->ev_tm, 0));   // (see fin_blocks_no_wait)
+    if (fin_blocks > fin_blocks_no_wait(K)) { CK(hipEventRecord(h->ev_tm, h->aux)); CK(hipStreamWaitEvent(st, h->ev_tm, 0)); }   // (see fin_blocks_no_wait)
     static const int fin_skip = getenv("GRAAL_FIN_SKIP") ? atoi(getenv("GRAAL_FIN_SKIP")) : 0;   // (diagnostics: wrong sums)
     FinArgs fa;
     fa.tm_done = h->tm_done; fa.step_hdr = h->step_hdr; fa.counters = (unsigned long long*)(h->d_scalars + 10); fa.queue = h->queue;
@@ -3895,6 +4038,7 @@ bool strict_dense_cfg()
 // reference arithmetic: what k_tm left (sets larger than STRICT_INLINE_M, the queued contacts when there are many), hand-out
 int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out, bool publish, hipStream_t st)
 {
+    CK(hipEventRecord(h->ev_tm, h->aux));      // (k_tm is on the auxiliary stream, done or not: the event completes behind it)
     CK(hipStreamWaitEvent(st, h->ev_tm, 0));   // the tables are complete before either kernel starts: nobody spins for them
     FinArgs fa;
     fa.tm_done = h->tm_done; fa.step_hdr = h->step_hdr; fa.counters = (unsigned long long*)(h->d_scalars + 10); fa.queue = h->queue;
@@ -3911,7 +4055,7 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
         return GRAAL_OK;
     }
     // the unit list holds at most K * nt (nt + 1) / 2 entries, nt = tiles of the two longest contigs (grow-only)
-    const unsigned long long nt = 2ull * (unsigned long long)((std::max(h->max_lcont, 1) + 63) / 64);
+    const unsigned long long nt = 2ull * (unsigned long long)((std::max(std::max(h->max_lcont, h->lcont_bound), 1) + 63) / 64);
     const unsigned long long need = (unsigned long long)K * nt * (nt + 1ull) / 2ull + 64ull;
     if (need > h->slist_cap) {
         CK(hipStreamSynchronize(st));
@@ -4037,6 +4181,8 @@ int graal_create(int device, graal_ctx** out)
     CK(hipMalloc(&h->step_hdr, 2 * MAXK * sizeof(int)));
     CK(hipMemset(h->step_hdr, 0, 2 * MAXK * sizeof(int)));
     CK(hipMalloc(&h->d_args, 2 * sizeof(DevArgs)));
+    CK(hipMalloc(&h->d_part, 1024 * N_STAT * sizeof(long long)));
+    CK(hipMemset(h->d_part, 0, 1024 * N_STAT * sizeof(long long)));
     CK(hipMalloc(&h->d_chg, 2 * sizeof(Changed)));
     CK(hipMemset(h->d_chg, 0, 2 * sizeof(Changed)));
     CK(hipHostMalloc((void**)&h->h_res, X_SLOT_WORDS * sizeof(long long), hipHostMallocDefault));
@@ -4066,7 +4212,7 @@ void graal_destroy(graal_ctx* h)
         if (h->aux) (void)hipStreamSynchronize(h->aux);
         void* ptrs[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->stat, h->sub_rec, h->sub_rec8, h->sub_lab16, h->d_ubins, h->d_ln_tab, h->sub2bin, h->row, h->col, h->cnt, h->queue, h->d_sub_ids, h->d_acc, h->tm_done, h->d_sync, h->d_done, h->d_wq, h->d_flags, h->d_slist, h->stat_frag, h->d_dup_bins, h->d_dup_index,
                         h->d_dispatcher, h->d_collector, h->d_sub_ids_all, h->d_rep_obs,
-                        h->keys, h->keys_sorted, h->o2n, h->len_of2[0], h->len_of2[1], h->contig_off2[0], h->contig_off2[1], h->perm, h->cbase, h->link, h->mates, h->cub_tmp, h->tabs, h->step_hdr, h->d_args, h->d_chg,
+                        h->keys, h->keys_sorted, h->o2n, h->len_of2[0], h->len_of2[1], h->contig_off2[0], h->contig_off2[1], h->perm, h->cbase, h->link, h->mates, h->cub_tmp, h->tabs, h->step_hdr, h->d_args, h->d_chg, h->d_part,
                         h->d_scalars, h->d_qout, h->d_dref, h->d_dist};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (h->x_host) (void)hipHostUnregister(h->x_host);
@@ -4386,7 +4532,7 @@ int graal_layout_stats(graal_ctx* h, int64_t out[8])
 }
 
 // first half of graal_begin_step: everything it launches; the statistics are on their way to pinned host memory afterwards
-static int begin_step_launch(graal_ctx* h)
+static int begin_step_launch(graal_ctx* h, bool defer = false)
 {
     CK(hipSetDevice(h->device));
     const int n = h->n, bs = 256, nb = blocks_for(n, bs);
@@ -4399,8 +4545,10 @@ static int begin_step_launch(graal_ctx* h)
     // the host launches next is ordered after them: same stream, or the event recorded below).
     const bool incr = h->ranks_valid && h->pending_commits == 1 && h->incr_ok && !no_incr;
     const bool early = h->ranks_valid && (h->pending_commits == 0 || incr);
-    if (incr && h->stats_from_apply) {
-        // nothing to launch for the statistics
+    const bool from_apply = incr && h->stats_from_apply;
+    const bool defer_stats = defer && h->spin_ok && from_apply;   // k_tm's extra block publishes them (graal_step reads them with the scores)
+    if (from_apply) {
+        // nothing to launch for the statistics: the commit kernel left its rows, k_incr (below) publishes them
     } else if (early) {
         h->stats_seq += 1;
         k_stats<<<std::min(nb, 64), bs, 0, h->stream>>>(s, n, h->d_scalars, h->h_stats, h->stats_seq, incr ? 0 : 1);
@@ -4410,13 +4558,20 @@ static int begin_step_launch(graal_ctx* h)
         // nothing changed since the last call: labels are ranks already
     } else if (incr) {
         // exactly one commit since the last ranking: count instead of sort (rank arrays of buffer 1-cur -> buffer cur)
-        k_incr<<<blocks_for(n + 1, bs), bs, 0, h->stream>>>(s, n, h->d_chg + h->chg_last, h->len_of2[1 - cur], h->contig_off2[1 - cur], h->n_contigs,
+        k_incr<<<blocks_for(n + 1, bs) + 1, bs, 0, h->stream>>>(s, n, h->d_chg + h->chg_last, h->len_of2[1 - cur], h->contig_off2[1 - cur], h->n_contigs,
                                                            h->len_of2[cur], h->contig_off2[cur], h->perm, h->cbase, h->geo, h->link, h->d_scalars,
-                                                           h->mates, (int*)(h->d_chg + (1 - h->chg_last)), (int)(sizeof(Changed) / sizeof(int)));
+                                                           h->mates, (int*)(h->d_chg + (1 - h->chg_last)), (int)(sizeof(Changed) / sizeof(int)),
+                                                           (defer_stats ? nullptr : h->d_part), h->apply_blocks, from_apply ? h->h_stats : nullptr, h->stats_seq);
         CK(hipGetLastError());
-        // the host does not wait for this kernel: whatever runs on the OTHER stream next (k_tm) must
-        CK(hipEventRecord(h->ev_relabel, h->stream));
-        h->relabel_pending = true;
+        if (defer && h->spin_ok) {
+            // graal_step: k_tm goes out next, without an event: it spins until the step's k_scan (behind this kernel on the stream) starts
+            h->relabel_spin_pending = true;
+            h->stats_pub_pending = defer_stats;
+        } else {
+            // the host does not wait for this kernel: whatever runs on the OTHER stream next (k_tm) must
+            CK(hipEventRecord(h->ev_relabel, h->stream));
+            h->relabel_pending = true;
+        }
     } else {
         k_relabel_keys<<<nb, bs, 0, h->stream>>>(s, n, h->keys);
         CK(hipGetLastError());
@@ -4450,12 +4605,40 @@ int graal_begin_step_launch(graal_ctx* h)
     return h->begin_launched ? GRAAL_OK : begin_step_launch(h);
 }
 
+// second half of graal_begin_step: wait for the statistics, check them, take them over
+static int begin_step_collect(graal_ctx* h, int64_t stats[8], int32_t* max_id);
+
+__global__ void k_stats_pub(const long long* __restrict__ part, int n_part, long long* __restrict__ stats, volatile long long* host, long long seq)
+{
+    publish_partials(part, n_part, stats, host, seq, (int)threadIdx.x);
+}
+
 int graal_begin_step(graal_ctx* h, int64_t stats[8], int32_t* max_id)
 {
     if (!h) return GRAAL_E_ARG;
     if (!h->have_frags) return fail(h, GRAAL_E_STATE, "no fragments uploaded");
     if (!h->begin_launched) { int rc = begin_step_launch(h); if (rc) return rc; }
     h->begin_launched = false;
+    if (h->stats_pub_pending) {   // (graal_step deferred the publication to the scoring kernels and then handed the step back)
+        k_stats_pub<<<1, 64, 0, h->stream>>>(h->d_part, h->apply_blocks, h->d_scalars, h->h_stats, h->stats_seq);
+        CK(hipGetLastError());
+        h->stats_pub_pending = false;
+    }
+    return begin_step_collect(h, stats, max_id);
+}
+
+// graal_step launches the scoring kernels BEFORE it has the statistics (they are stream-ordered behind the relabel and read
+// the contig count on the device) and collects the statistics together with the scores: what graal_begin_step establishes on
+// the host side, without the wait.  The longest contig is then one commit stale: a commit at most joins two contigs.
+static void begin_step_assume(graal_ctx* h)
+{
+    h->begin_launched = false;
+    h->order_valid = true; h->ranks_valid = true; h->pending_commits = 0; h->incr_ok = false;
+    h->lcont_bound = (int)std::min<long long>(h->n, 2ll * h->max_lcont + 2);
+}
+
+static int begin_step_collect(graal_ctx* h, int64_t stats[8], int32_t* max_id)
+{
     const int n = h->n;
     long long res[16];
     { int rc = wait_stats(h, res); if (rc) return rc; }
@@ -4466,6 +4649,7 @@ int graal_begin_step(graal_ctx* h, int64_t stats[8], int32_t* max_id)
     if (res[6] != 0 && !h->has_rep) return fail(h, GRAAL_E_STATE, "corrupt layout: rep / activ / id_d changed without repeats");
     h->n_contigs = nc; h->order_valid = true; h->ranks_valid = true; h->pending_commits = 0; h->incr_ok = false;
     h->max_lcont = (int)res[4];
+    h->lcont_bound = h->max_lcont;
     if (max_id) *max_id = nc - 1;
     if (stats) {
         for (int i = 0; i < 6; i++) stats[i] = res[i];
@@ -4588,10 +4772,15 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
         if (st != h->stream) CK(hipStreamWaitEvent(st, h->ev_relabel, 0));
         h->relabel_pending = false;
     }
+    // graal_step's deferred flow: no event -- k_tm spins until this step's k_scan, behind the relabel on the engine's stream, starts
+    const bool spin = h->relabel_spin_pending && st == h->stream;
+    if (h->relabel_spin_pending && !spin) { CK(hipEventRecord(h->ev_relabel, h->stream)); CK(hipStreamWaitEvent(h->aux, h->ev_relabel, 0)); CK(hipStreamWaitEvent(st, h->ev_relabel, 0)); }
+    h->relabel_spin_pending = false;
     const bool strict = (h->mode & GRAAL_MODE_STRICT) != 0;
     TmArgs ta;
     ta.strict = strict ? 1 : 0;
     ta.quirk = (h->mode & GRAAL_MODE_REF_TRANS_ACCU) ? 1 : 0;
+    ta.nc = h->d_scalars + NC_WORD;
     ta.strict_inline_m = strict_dense_cfg() ? -1 : STRICT_INLINE_M;
     ta.geo = h->geo; ta.link = h->link; ta.cbase = h->cbase; ta.mates = h->mates; ta.tabs = h->tabs; ta.step_hdr = h->step_hdr;
     static const bool no_finisher = getenv("GRAAL_NO_FINISHER") != nullptr; // always finish with k_fin (diagnostics)
@@ -4606,9 +4795,16 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     ta.wait_ticks = fin_wait_ticks(h);
     ta.counters = (unsigned long long*)(h->d_scalars + 10); ta.queue = h->queue; ta.stat = h->stat_frag;
     ta.lcontbp = h->soa[h->cur].p[F_LCONTBP]; ta.acc = h->d_acc; ta.nfpb = h->nfpb; ta.par = h->par;
-    k_tm<<<K, 256, ta.host_res ? tm_fin_dyn_lds() : 0, h->aux>>>(A, ta, fA, nb, K, max_id, rank, world, h->seq);
+    ta.relabel_flag = (const unsigned long long*)(h->d_scalars + RELABEL_FLAG);
+    ta.relabel_seq = spin ? ++h->relabel_flag_seq : 0ull;
+    h->scan_relabel_seq = ta.relabel_seq;
+    h->spin_used = spin;
+    const bool pub = h->stats_pub_pending;
+    h->stats_pub_pending = false;
+    ta.part = pub ? h->d_part : nullptr; ta.n_part = h->apply_blocks; ta.stats_host = h->h_stats; ta.stats_seq = h->stats_seq; ta.stats_dev = h->d_scalars;
+    k_tm<<<K + (pub ? 1 : 0), 256, ta.host_res ? tm_fin_dyn_lds() : 0, h->aux>>>(A, ta, fA, nb, K, max_id, rank, world, h->seq);
     CK(hipGetLastError());
-    if (strict || (ta.host_res == nullptr && fin_blocks_cfg(h, K) > fin_blocks_no_wait(K))) CK(hipEventRecord(h->ev_tm, h->aux));
+    // (the event that orders a chip-filling k_fin / the strict kernels behind k_tm is recorded where they are launched)
     // (2) the streaming pass, with a HIP event pair around it on every event_every-th call
     const bool ev = h->want_events && (h->eval_calls % h->event_every == 0);
     h->eval_calls += 1;
@@ -4687,6 +4883,22 @@ static int eval_sync(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int
         CK(hipStreamSynchronize(h->stream));
         CK(hipStreamSynchronize(h->aux));
         if (res[0] != want && res[0] != -want) return fail(h, GRAAL_E_HIP, "the step's last block did not publish its results");
+    }
+    if (res[0] == -want && h->spin_used) {
+        // k_tm gave up waiting for k_scan's announcement: the two kernels did not run side by side (a tool serialising dispatches).
+        // Everything of the step has ended by now; put the step's accumulators back to rest and repeat it ordered by the host --
+        // and stay with events from here on.
+        h->spin_ok = false; h->spin_used = false;
+        CK(hipStreamSynchronize(h->stream));
+        CK(hipStreamSynchronize(h->aux));
+        CK(hipMemset(h->d_scalars + 10, 0, 8 * sizeof(long long)));
+        CK(hipMemset(h->d_scalars + 10 + NF_OFF, 0, 3 * sizeof(long long)));
+        CK(hipMemset(h->d_scalars + SLIST_N, 0, sizeof(long long)));
+        CK(hipMemset(h->d_acc, 0, MAXK * N_OPS * sizeof(long long)));
+        CK(hipMemset(h->d_sync, 0, 32 * sizeof(unsigned long long)));
+        CK(hipDeviceSynchronize());
+        res[0] = 0;
+        return eval_sync(h, fA, fB, K, max_id, rank, world, q_sum);
     }
     if (res[0] == -want) return fail(h, GRAAL_E_HIP, "timed out waiting for the candidate tables / the scan (a kernel of the step did not run)");
     __sync_synchronize();
@@ -4876,8 +5088,11 @@ int graal_apply_move(graal_ctx* h, int32_t fA, int32_t fB, int32_t op, int32_t m
     // (the commit record d_chg is clear: the last kernel of every relabel clears it; a second commit without a relabel in
     // between finds the first one's entries, and the relabel then sorts instead of counting)
     h->stats_seq += 1;
-    k_apply<<<std::min(blocks_for(h->n, 256), 64), 256, 0, h->stream>>>(h->soa[h->cur], h->soa[1 - h->cur], h->n, op, fA, fB, max_id, d_stale, h->d_chg + h->chg_w,
-                                                           h->d_scalars, h->h_stats, h->stats_seq);
+    // (one fragment per thread up to 256 blocks: the kernel is a dependent chain -- records of fA / fB, the fragment's own 13
+    // words, the stores -- and no longer pays atomics per block, so more, shorter blocks win: 12.4 -> ~6 us at 50k fragments)
+    static const int apply_blocks_env = getenv("GRAAL_APPLY_BLOCKS") ? atoi(getenv("GRAAL_APPLY_BLOCKS")) : 256;
+    h->apply_blocks = std::min(blocks_for(h->n, 256), std::max(1, std::min(apply_blocks_env, 1024)));
+    k_apply<<<h->apply_blocks, 256, 0, h->stream>>>(h->soa[h->cur], h->soa[1 - h->cur], h->n, op, fA, fB, max_id, d_stale, h->d_chg + h->chg_w, h->d_part);
     h->chg_last = h->chg_w; h->chg_w ^= 1;
     CK(hipGetLastError());
     h->begin_launched = false;

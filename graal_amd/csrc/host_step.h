@@ -77,6 +77,10 @@ static double np_sum(const double* a, long n) { return 0.0 + np_pairwise_sum(a, 
 
 struct HostStep {
     bool ready = false;
+    bool timing = getenv("GRAAL_STEP_TIMING") != nullptr;   // debug: mean host time of each phase of graal_step, printed at destroy
+    double t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long t_n = 0;
+    double t_mark = 0.0;
     int n_bins = 0, k = 0, n = 0;
     std::vector<int> xk;             // [n_bins][k]
     std::vector<double> pk;          // [n_bins][k] float32 values as doubles
@@ -89,7 +93,15 @@ struct HostStep {
     long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
-void hs_free(HostStep* p) { delete p; }
+void hs_free(HostStep* p)
+{
+    if (p && p->timing && p->t_n)
+        fprintf(stderr, "graal_step timing over %lld deferred steps (us): relabel launch %.1f | proposal %.1f | scoring launches + wait %.1f | statistics %.1f | "
+                        "selection %.1f | commit launch %.1f\n", p->t_n, p->t_acc[0] / p->t_n, p->t_acc[1] / p->t_n, p->t_acc[2] / p->t_n, p->t_acc[3] / p->t_n,
+                p->t_acc[4] / p->t_n, p->t_acc[5] / p->t_n);
+    delete p;
+}
+inline double hs_now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 } // namespace
 
@@ -221,7 +233,7 @@ static int hs_select(MtState* mt, const double* score, int n, int n_tmp)
 }
 
 // second half of a step: score the candidates of the neighbours drawn by graal_step, sample, commit
-static int hs_finish(graal_ctx* h, MtState* mt, double likelihood_t, int want_dist, graal_step_out* out)
+static int hs_finish(graal_ctx* h, MtState* mt, double likelihood_t, int want_dist, graal_step_out* out, bool deferred = false)
 {
     if (!h->hs) return fail(h, GRAAL_E_STATE, "graal_upload_proposal_tables first");
     HostStep& S = *h->hs;
@@ -237,7 +249,15 @@ static int hs_finish(graal_ctx* h, MtState* mt, double likelihood_t, int want_di
             out->scores[k0 * N_OPS + i] = d + likelihood_t;
         }
     }
+    const double t2 = S.timing ? hs_now() : 0.0;
+    if (deferred) {   // the statistics of the layout this step started from: published long ago, read now
+        const int rc = begin_step_collect(h, out->stats, &out->max_id);
+        if (rc) return rc;
+        S.max_id = out->max_id;
+    }
+    const double t3 = S.timing ? hs_now() : 0.0;
     const int pick = hs_select(mt, out->scores, K * N_OPS, N_OPS);
+    const double t4 = S.timing ? hs_now() : 0.0;
     if (pick < 0) return GRAAL_STEP_FALLBACK;   // (the scores are in out->scores; nothing was drawn for the selection)
     out->sample_out = pick;
     out->id_f_sampled = S.nb[pick / N_OPS];
@@ -245,6 +265,7 @@ static int hs_finish(graal_ctx* h, MtState* mt, double likelihood_t, int want_di
     out->o = out->scores[pick];
     int rc = graal_apply_move(h, S.fA, out->id_f_sampled, out->op_sampled, S.max_id, nullptr);
     if (rc) return rc;
+    if (S.timing && deferred) { S.t_acc[2] += t2 - S.t_mark; S.t_acc[3] += t3 - t2; S.t_acc[4] += t4 - t3; S.t_acc[5] += hs_now() - t4; S.t_n += 1; }
     out->dist_half_units = 0;
     if (want_dist) { rc = graal_genome_distance(h, &out->dist_half_units); if (rc) return rc; }
     S.nb.clear();
@@ -265,20 +286,33 @@ int graal_step(graal_ctx* h, void* mt_state, int32_t fA, int32_t delta, double l
     if (!h || !mt_state || !out) return 16 + GRAAL_E_ARG;
     if (!h->hs || !h->hs->ready) return 16 + fail(h, GRAAL_E_STATE, "graal_upload_proposal_tables first");
     HostStep& S = *h->hs;
+    if (!h->have_frags) return 16 + fail(h, GRAAL_E_STATE, "no fragments uploaded");
     if (fA < 0 || fA >= S.n || S.n != h->n) return 16 + fail(h, GRAAL_E_ARG, "graal_step: fA out of range");
     MtState* mt = (MtState*)mt_state;
     if (mt->pos < 0 || mt->pos > 624) return 16 + fail(h, GRAAL_E_ARG, "graal_step: not an MT19937 state");
-    int rc = graal_begin_step_launch(h);
+    const double t0 = S.timing ? hs_now() : 0.0;
+    const bool defer = (flags & 3) == 0;
+    int rc = h->begin_launched ? GRAAL_OK : begin_step_launch(h, defer);
     if (rc) return 16 + rc;
+    const double t1 = S.timing ? hs_now() : 0.0;
     // the proposal is drawn while the relabel runs
     MtState keep = *mt;
     if (!hs_neighbours(S, mt, fA, delta, S.nb) || S.nb.empty() || S.nb.size() > 128) { *mt = keep; S.nb.clear(); return GRAAL_STEP_FALLBACK; }
     std::sort(S.nb.begin(), S.nb.end());
-    rc = graal_begin_step(h, out->stats, &out->max_id);
-    if (rc) { *mt = keep; S.nb.clear(); return 16 + rc; }
-    S.fA = fA; S.max_id = out->max_id;
+    S.fA = fA;
     out->n_neighbours = (int32_t)S.nb.size();
     for (size_t i = 0; i < S.nb.size(); i++) out->neighbours[i] = S.nb[i];
+    if (defer) {
+        // nobody needs the statistics before the scores: the scoring kernels go out right behind the relabel, the host waits once
+        begin_step_assume(h);
+        S.max_id = -1;
+        if (S.timing) { S.t_mark = hs_now(); S.t_acc[0] += t1 - t0; S.t_acc[1] += S.t_mark - t1; }
+        rc = hs_finish(h, mt, likelihood_t, (flags & 4) != 0, out, true);
+        return rc > GRAAL_STEP_FALLBACK ? 16 + rc : rc;
+    }
+    rc = graal_begin_step(h, out->stats, &out->max_id);
+    if (rc) { *mt = keep; S.nb.clear(); return 16 + rc; }
+    S.max_id = out->max_id;
     if ((flags & 2) || ((flags & 1) && (out->stats[6] != 0 || prev_circ != 0))) return GRAAL_STEP_PAUSED;
     rc = hs_finish(h, mt, likelihood_t, (flags & 4) != 0, out);
     return rc > GRAAL_STEP_FALLBACK ? 16 + rc : rc;
