@@ -1830,6 +1830,7 @@ struct TmArgs { // first-needed pointers by value (see ScanArgs)
     // announces that it has started (relabel_flag == relabel_seq).  0 = ordered by the host (event / synchronisation).
     const unsigned long long* relabel_flag;
     unsigned long long relabel_seq;
+    unsigned long long relabel_wait_ticks;
     // ... and one extra block publishes the layout statistics the commit kernel left in rows of partials (see k_incr)
     const long long* part;
     int n_part;
@@ -1865,7 +1866,9 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
         __shared__ int s_go;
         if (t == 0) {
             int go = 0;
-            const unsigned long long t_end = wall_clock64() + (unsigned long long)ta.wait_ticks;
+            // (a deadlock guard, not a latency budget: 20 ms -- the first launch of a kernel, an allocation or a profiler can hold
+            // the engine's stream for milliseconds)
+            const unsigned long long t_end = wall_clock64() + ta.relabel_wait_ticks;
             for (;;) {
                 if (__hip_atomic_load(ta.relabel_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == ta.relabel_seq) { go = 1; break; }
                 if (wall_clock64() > t_end) break;
@@ -3656,6 +3659,8 @@ struct Ctx {
     bool relabel_spin_pending = false, stats_pub_pending = false;
     bool spin_ok = getenv("GRAAL_NO_TM_SPIN") == nullptr;   // switched off when k_tm and k_scan turn out not to run concurrently
     unsigned long long relabel_flag_seq = 0, scan_relabel_seq = 0;
+    bool pub_in_flight = false;   // ... and its k_tm carries the statistics' publication block (re-armed if the evaluation is repeated)
+    unsigned long long tm_spin_ticks = getenv("GRAAL_TM_SPIN_TICKS") ? strtoull(getenv("GRAAL_TM_SPIN_TICKS"), nullptr, 10) : 2000000ull;   // 100 MHz ticks
     bool spin_used = false;       // the evaluation in flight relies on the flag (eval_sync repeats it with an event if k_tm gives up)
     bool begin_launched = false;  // graal_begin_step_launch ran for the current layout; graal_begin_step only has to wait
     bool stats_from_apply = false; // the last commit published the statistics of the layout it produced (sequence stats_seq)
@@ -4545,6 +4550,7 @@ static int begin_step_launch(graal_ctx* h, bool defer = false)
     // the host launches next is ordered after them: same stream, or the event recorded below).
     const bool incr = h->ranks_valid && h->pending_commits == 1 && h->incr_ok && !no_incr;
     const bool early = h->ranks_valid && (h->pending_commits == 0 || incr);
+    bool full_relabel = false;
     const bool from_apply = incr && h->stats_from_apply;
     const bool defer_stats = defer && h->spin_ok && from_apply;   // k_tm's extra block publishes them (graal_step reads them with the scores)
     if (from_apply) {
@@ -4588,11 +4594,18 @@ static int begin_step_launch(graal_ctx* h, bool defer = false)
         if (rc) return rc;
         k_mates<<<nb, bs, 0, h->stream>>>(n, h->perm, h->cbase, h->link, h->mates, (int*)h->d_chg, (int)(2 * sizeof(Changed) / sizeof(int)));
         CK(hipGetLastError());
+        full_relabel = true;
     }
     if (!early) { // the sorting path reads the statistics on the device, so they are published (and re-armed) behind it
         h->stats_seq += 1;
         k_stats_fin<<<1, 64, 0, h->stream>>>(h->d_scalars, h->h_stats, h->stats_seq, 1);
         CK(hipGetLastError());
+    }
+    if (defer && full_relabel) {
+        // graal_step will not wait for the statistics (which, on this path, are published behind the relabel and so imply it):
+        // whatever it launches on the other stream is ordered behind these kernels by the event
+        CK(hipEventRecord(h->ev_relabel, h->stream));
+        h->relabel_pending = true;
     }
     h->begin_launched = true;
     return GRAAL_OK;
@@ -4797,10 +4810,12 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     ta.lcontbp = h->soa[h->cur].p[F_LCONTBP]; ta.acc = h->d_acc; ta.nfpb = h->nfpb; ta.par = h->par;
     ta.relabel_flag = (const unsigned long long*)(h->d_scalars + RELABEL_FLAG);
     ta.relabel_seq = spin ? ++h->relabel_flag_seq : 0ull;
+    ta.relabel_wait_ticks = h->tm_spin_ticks;
     h->scan_relabel_seq = ta.relabel_seq;
     h->spin_used = spin;
     const bool pub = h->stats_pub_pending;
     h->stats_pub_pending = false;
+    h->pub_in_flight = pub;
     ta.part = pub ? h->d_part : nullptr; ta.n_part = h->apply_blocks; ta.stats_host = h->h_stats; ta.stats_seq = h->stats_seq; ta.stats_dev = h->d_scalars;
     k_tm<<<K + (pub ? 1 : 0), 256, ta.host_res ? tm_fin_dyn_lds() : 0, h->aux>>>(A, ta, fA, nb, K, max_id, rank, world, h->seq);
     CK(hipGetLastError());
@@ -4889,6 +4904,7 @@ static int eval_sync(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int
         // Everything of the step has ended by now; put the step's accumulators back to rest and repeat it ordered by the host --
         // and stay with events from here on.
         h->spin_ok = false; h->spin_used = false;
+        if (h->pub_in_flight) h->stats_pub_pending = true;   // (its publication block gave up with the others)
         CK(hipStreamSynchronize(h->stream));
         CK(hipStreamSynchronize(h->aux));
         CK(hipMemset(h->d_scalars + 10, 0, 8 * sizeof(long long)));

@@ -232,18 +232,19 @@ static int hs_select(MtState* mt, const double* score, int n, int n_tmp)
     return ids[(size_t)idx];
 }
 
-// second half of a step: score the candidates of the neighbours drawn by graal_step, sample, commit
+// second half of a step: score the candidates of the neighbours drawn by graal_step, sample, commit.  Returns GRAAL_STEP_DONE,
+// GRAAL_STEP_FALLBACK or 16 + a GRAAL_E_* code (error codes 1 and 2 must not be taken for PAUSED / FALLBACK)
 static int hs_finish(graal_ctx* h, MtState* mt, double likelihood_t, int want_dist, graal_step_out* out, bool deferred = false)
 {
-    if (!h->hs) return fail(h, GRAAL_E_STATE, "graal_upload_proposal_tables first");
+    if (!h->hs) return 16 + fail(h, GRAAL_E_STATE, "graal_upload_proposal_tables first");
     HostStep& S = *h->hs;
     const int K = (int)S.nb.size();
-    if (K < 1 || K > 128) return fail(h, GRAAL_E_STATE, "graal_step_finish: no step in progress");
+    if (K < 1 || K > 128) return 16 + fail(h, GRAAL_E_STATE, "graal_step_finish: no step in progress");
     long long q[MAXK * N_OPS];
     for (int k0 = 0; k0 < K; k0 += MAXK) {
         const int kk = std::min(MAXK, K - k0);
         const int rc = eval_sync(h, S.fA, S.nb.data() + k0, kk, S.max_id, h->x_host ? h->x_rank : 0, h->x_host ? h->x_world : 1, q);
-        if (rc) return rc;
+        if (rc) return 16 + rc;
         for (int i = 0; i < kk * N_OPS; i++) {
             const double d = llabs(q[i]) >= (Q_NAN >> 1) ? (double)NAN : (double)q[i] / Q_SCALE;
             out->scores[k0 * N_OPS + i] = d + likelihood_t;
@@ -252,11 +253,13 @@ static int hs_finish(graal_ctx* h, MtState* mt, double likelihood_t, int want_di
     const double t2 = S.timing ? hs_now() : 0.0;
     if (deferred) {   // the statistics of the layout this step started from: published long ago, read now
         const int rc = begin_step_collect(h, out->stats, &out->max_id);
-        if (rc) return rc;
+        if (rc) return 16 + rc;
         S.max_id = out->max_id;
     }
     const double t3 = S.timing ? hs_now() : 0.0;
+    const int pos_before = mt->pos;
     const int pick = hs_select(mt, out->scores, K * N_OPS, N_OPS);
+    if (getenv("GRAAL_STEP_TRACE")) fprintf(stderr, "[step] fA %d K %d deferred %d pick %d mt.pos %d -> %d max_id %d seq %lld spin_ok %d\n", S.fA, K, (int)deferred, pick, pos_before, mt->pos, S.max_id, h->seq, (int)h->spin_ok);
     const double t4 = S.timing ? hs_now() : 0.0;
     if (pick < 0) return GRAAL_STEP_FALLBACK;   // (the scores are in out->scores; nothing was drawn for the selection)
     out->sample_out = pick;
@@ -264,10 +267,10 @@ static int hs_finish(graal_ctx* h, MtState* mt, double likelihood_t, int want_di
     out->op_sampled = pick % N_OPS;
     out->o = out->scores[pick];
     int rc = graal_apply_move(h, S.fA, out->id_f_sampled, out->op_sampled, S.max_id, nullptr);
-    if (rc) return rc;
+    if (rc) return 16 + rc;
     if (S.timing && deferred) { S.t_acc[2] += t2 - S.t_mark; S.t_acc[3] += t3 - t2; S.t_acc[4] += t4 - t3; S.t_acc[5] += hs_now() - t4; S.t_n += 1; }
     out->dist_half_units = 0;
-    if (want_dist) { rc = graal_genome_distance(h, &out->dist_half_units); if (rc) return rc; }
+    if (want_dist) { rc = graal_genome_distance(h, &out->dist_half_units); if (rc) return 16 + rc; }
     S.nb.clear();
     return GRAAL_STEP_DONE;
 }
@@ -299,6 +302,7 @@ int graal_step(graal_ctx* h, void* mt_state, int32_t fA, int32_t delta, double l
     MtState keep = *mt;
     if (!hs_neighbours(S, mt, fA, delta, S.nb) || S.nb.empty() || S.nb.size() > 128) { *mt = keep; S.nb.clear(); return GRAAL_STEP_FALLBACK; }
     std::sort(S.nb.begin(), S.nb.end());
+    if (getenv("GRAAL_STEP_TRACE")) fprintf(stderr, "[step] fA %d proposal drawn: mt.pos %d -> %d, %d neighbours, first %d\n", fA, keep.pos, mt->pos, (int)S.nb.size(), S.nb[0]);
     S.fA = fA;
     out->n_neighbours = (int32_t)S.nb.size();
     for (size_t i = 0; i < S.nb.size(); i++) out->neighbours[i] = S.nb[i];
@@ -307,22 +311,19 @@ int graal_step(graal_ctx* h, void* mt_state, int32_t fA, int32_t delta, double l
         begin_step_assume(h);
         S.max_id = -1;
         if (S.timing) { S.t_mark = hs_now(); S.t_acc[0] += t1 - t0; S.t_acc[1] += S.t_mark - t1; }
-        rc = hs_finish(h, mt, likelihood_t, (flags & 4) != 0, out, true);
-        return rc > GRAAL_STEP_FALLBACK ? 16 + rc : rc;
+        return hs_finish(h, mt, likelihood_t, (flags & 4) != 0, out, true);   // (GRAAL_STEP_DONE / _FALLBACK, or 16 + an error code)
     }
     rc = graal_begin_step(h, out->stats, &out->max_id);
     if (rc) { *mt = keep; S.nb.clear(); return 16 + rc; }
     S.max_id = out->max_id;
     if ((flags & 2) || ((flags & 1) && (out->stats[6] != 0 || prev_circ != 0))) return GRAAL_STEP_PAUSED;
-    rc = hs_finish(h, mt, likelihood_t, (flags & 4) != 0, out);
-    return rc > GRAAL_STEP_FALLBACK ? 16 + rc : rc;
+    return hs_finish(h, mt, likelihood_t, (flags & 4) != 0, out);
 }
 
 int graal_step_finish(graal_ctx* h, void* mt_state, double likelihood_t, int32_t flags, graal_step_out* out)
 {
     if (!h || !mt_state || !out) return 16 + GRAAL_E_ARG;
-    const int rc = hs_finish(h, (MtState*)mt_state, likelihood_t, (flags & 4) != 0, out);
-    return rc > GRAAL_STEP_FALLBACK ? 16 + rc : rc;
+    return hs_finish(h, (MtState*)mt_state, likelihood_t, (flags & 4) != 0, out);
 }
 
 /* test hooks of the host logic (CPU-only: no device call): numpy's sum, the neighbour draw and the move sampling */

@@ -265,3 +265,35 @@ def test_blacklisted_fragments_with_parameter_sampling_match_oracle():
     a, b = g.gpu_vect_frags.id_c, ora.gpu_vect_frags["id_c"]
     assert np.array_equal(a[:, None] == a[None, :], b[:, None] == b[None, :])
     g.free_gpu()
+
+
+def test_c_step_equals_python_step_and_survives_its_fallbacks(monkeypatch):
+    """graal_step (the per-step host logic behind the C ABI, scoring kernels launched behind the relabel without an event, statistics
+    collected with the scores) against the Python host logic on the same engine code: the same accepted-move trace, likelihood
+    series, statistics and generator state -- also when k_tm's wait for k_scan's announcement is made to time out at once, so that
+    every engine takes the repeat-with-an-event path once (GRAAL_TM_SPIN_TICKS=1), and with the finishing kernel instead of
+    k_tm's finisher."""
+    P = problem(1, 51, 160, 6000)
+
+    def go(env, finisher=True):
+        for k in ("GRAAL_PY_STEP", "GRAAL_TM_SPIN_TICKS", "GRAAL_NO_TM_SPIN"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        rng = np.random.RandomState(51)
+        g = make_gpu_sampler(P, rng)
+        g.engine.set_finisher(finisher)
+        t = em.run_em(g, 2, 4, rng=rng)
+        st = rng.get_state(legacy=False)["state"]
+        out = (np.asarray(t.mutations()), list(t.likelihood), list(t.n_contigs), list(t.dist), int(st["pos"]), st["key"].copy())
+        used_c = g._c_step
+        g.free_gpu()
+        return out, used_c
+    want, used_c = go({"GRAAL_PY_STEP": "1"})
+    assert not used_c
+    for env, fin in (({}, True), ({"GRAAL_TM_SPIN_TICKS": "1"}, True), ({"GRAAL_NO_TM_SPIN": "1"}, True), ({}, False), ({"GRAAL_TM_SPIN_TICKS": "1"}, False)):
+        got, used_c = go(env, fin)
+        assert used_c
+        assert np.array_equal(got[0], want[0]), (env, fin)
+        assert got[1] == want[1] and got[2] == want[2] and got[3] == want[3], (env, fin)
+        assert got[4] == want[4] and np.array_equal(got[5], want[5]), (env, fin)
