@@ -394,7 +394,7 @@ def main():
 
     # ---- full MCMC steps (scoring + sampling + commit + relabel), reported as an extra ----------------------------
     t1 = time.perf_counter()
-    n_full = min(200, max(1, args.steps))
+    n_full = 500   # (an extra next to the headline: always enough steps for a stable figure, 30 ms)
     for i in order[args.mcmc_warmup:args.mcmc_warmup + n_full]:
         smp.step_max_likelihood(int(i), K)
     torch.cuda.synchronize()

@@ -2871,6 +2871,7 @@ struct StrictArgs {
     int quirk;
     int reach_bp;
     unsigned long long list_cap;
+    int seg;                      // fragments y per work unit (a power of two <= 64: the y tile of a unit is cut into 64 / seg segments)
 };
 
 // correction of the layout independent all-trans mass T_all for the reference's trans-branch RF-count indexing: pairs of
@@ -3147,7 +3148,7 @@ __device__ __forceinline__ void piece_extent(const PieceKey& key, const Geo& gA,
 
 __global__ __launch_bounds__(256) void k_strict_cull(const NbTables* __restrict__ tabs, const Geo* __restrict__ geo, const Link* __restrict__ link,
                                                       const int* __restrict__ cbase, const int* __restrict__ perm, int fA, int K, int rank, int world,
-                                                      int reach_bp, int no_window, unsigned long long* __restrict__ list,
+                                                      int reach_bp, int no_window, int seg, unsigned long long* __restrict__ list,
                                                       unsigned long long* __restrict__ list_n, unsigned long long cap,
                                                       unsigned long long* __restrict__ counters)
 {
@@ -3217,15 +3218,25 @@ __global__ __launch_bounds__(256) void k_strict_cull(const NbTables* __restrict_
                     }
                 }
             }
-            const unsigned long long bal = __ballot(alive);
-            if (bal) {
-                const int lane = t & 63, n_alive = __popcll(bal);
+            // an alive tile pair is listed as ceil(count of its y tile / seg) units: (k, ti, tj, segment)
+            int ne = 0;
+            if (alive) {
+                const int side = tj < sg.tilesA ? 0 : 1, t0 = side ? tj - sg.tilesA : tj;
+                const int cnt_y = min(64, (side ? sg.lenB : sg.lenA) - t0 * 64);
+                ne = (cnt_y + seg - 1) / seg;
+            }
+            if (__ballot(alive)) {
+                const int lane = t & 63;
+                int incl = ne;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
+                const int total = __shfl(incl, 63, 64);
                 unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(list_n, (unsigned long long)n_alive);
+                if (lane == 0) base = atomicAdd(list_n, (unsigned long long)total);
                 base = __shfl(base, 0, 64);
-                if (alive) {
-                    const unsigned long long at = base + (unsigned long long)__popcll(bal & ((1ull << lane) - 1ull));
-                    if (at < cap) list[at] = ((unsigned long long)k << 48) | ((unsigned long long)ti << 24) | (unsigned long long)tj;
+                for (int e = 0; e < ne; e++) {
+                    const unsigned long long at = base + (unsigned long long)(incl - ne + e);
+                    if (at < cap) list[at] = ((unsigned long long)k << 56) | ((unsigned long long)ti << 32) | ((unsigned long long)tj << 8) | (unsigned long long)e;
                     else atomicOr(&counters[6], 2ull);   // (cannot happen: the host sizes the list for the longest contig)
                 }
             }
@@ -3283,12 +3294,12 @@ __global__ __launch_bounds__(256) void k_strict(FinArgs fa, StrictArgs sa, int f
     STileW* tile = s_tile[wib];
     for (unsigned long long u = (unsigned long long)wave; u < n_units; u += (unsigned long long)n_waves) {
         const unsigned long long ent = list[u];
-        const int k = (int)(ent >> 48), ti = (int)((ent >> 24) & 0xffffffull), tj = (int)(ent & 0xffffffull);
+        const int k = (int)(ent >> 56), ti = (int)((ent >> 32) & 0xffffffull), tj = (int)((ent >> 8) & 0xffffffull), j0 = (int)(ent & 0xffull) * sa.seg;
         const SetGeo sg = s_sg[k];
         const PieceKey key = tabs[k].key;
         auto frag_at = [&](int tt, int l, bool& ok) {
             const int side = tt < sg.tilesA ? 0 : 1, t0 = side ? tt - sg.tilesA : tt, pos = t0 * 64 + l;
-            ok = pos < (side ? sg.lenB : sg.lenA);
+            ok = l < 64 && pos < (side ? sg.lenB : sg.lenA);
             return ok ? sa.perm[(side ? sg.baseB : sg.baseA) + pos] : 0;
         };
         bool has_x;
@@ -3303,9 +3314,10 @@ __global__ __launch_bounds__(256) void k_strict(FinArgs fa, StrictArgs sa, int f
         }
         const bool nonuni_x = !stat_uniform(sx);
         int cnt = 0;
-        {
+        {   // the unit's segment of the y tile: fragments j0 .. j0 + seg of it
             bool has_y;
-            const int fy = frag_at(tj, lane, has_y);
+            const int fy = frag_at(tj, j0 + lane, has_y);
+            has_y = has_y && lane < sa.seg;
             if (has_y) {
                 STileW y; y.frag = fy; y.g = geo[fy]; y.st = stat[fy];
                 y.piece = piece_of(key, y.g.id_c, geo_pos(y.g.flags));
@@ -3330,7 +3342,7 @@ __global__ __launch_bounds__(256) void k_strict(FinArgs fa, StrictArgs sa, int f
         };
         const bool live_x = has_x && sx.n > 0;
         for (int j = 0; j < cnt; j++) {
-            if (!live_x || (ti == tj && j <= lane)) continue;       // every unordered pair once; never a bin with itself
+            if (!live_x || (ti == tj && j0 + j <= lane)) continue;  // every unordered pair once; never a bin with itself
             const STileW& y = tile[j];
             const Stat sy = y.st;
             if (sy.n == 0) continue;                                  // (a copy of a repeated bin: priced by k_rep_delta)
@@ -4054,6 +4066,7 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
     sx.quirk = (h->mode & GRAAL_MODE_REF_TRANS_ACCU) ? 1 : 0;
     sx.reach_bp = reach_bp(h);
     sx.list_cap = 0;
+    sx.seg = 64;
     if (strict_dense_cfg()) {
         k_strict_dense<<<1024, 256, 0, st>>>(fa, sx, fA, K, rank, world, d_q_out, publish ? h->res_dev : nullptr, h->seq);
         CK(hipGetLastError());
@@ -4061,7 +4074,23 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
     }
     // the unit list holds at most K * nt (nt + 1) / 2 entries, nt = tiles of the two longest contigs (grow-only)
     const unsigned long long nt = 2ull * (unsigned long long)((std::max(std::max(h->max_lcont, h->lcont_bound), 1) + 63) / 64);
-    const unsigned long long need = (unsigned long long)K * nt * (nt + 1ull) / 2ull + 64ull;
+    static const int blocks_env = getenv("GRAAL_STRICT_BLOCKS") ? atoi(getenv("GRAAL_STRICT_BLOCKS")) : 0;
+    const int lc = std::max(h->max_lcont, h->lcont_bound);
+    const int blocks = blocks_env > 0 ? blocks_env : (lc > 0 && lc <= 64 ? 32 : (lc <= 1024 ? 512 : 1024));
+    // fragments y per unit: a 64 x 64 tile pair under half a dozen classes with nine slot pairs each is a millisecond of dependent
+    // float32 powf / expf in ONE wave -- with contigs of a few hundred bins a step has a few dozen tile pairs, and the C2 stand-in
+    // ran at 3.2 ms per step.  The y tile is cut into segments so that the grid has ~6 units per wave (bounded below: the x tile
+    // is loaded once per unit).
+    static const int seg_env = getenv("GRAAL_STRICT_SEG") ? atoi(getenv("GRAAL_STRICT_SEG")) : 0;
+    int seg = 64;
+    {
+        const unsigned long long est = (unsigned long long)K * nt * (nt + 1ull) / 2ull, target = 6ull * 4ull * (unsigned long long)blocks;
+        const int seg_min = h->single_sub ? 4 : 1;
+        while (seg > seg_min && est * (unsigned long long)(64 / seg) < target) seg >>= 1;
+        if (seg_env == 1 || seg_env == 2 || seg_env == 4 || seg_env == 8 || seg_env == 16 || seg_env == 32 || seg_env == 64) seg = seg_env;
+    }
+    sx.seg = seg;
+    const unsigned long long need = (unsigned long long)K * nt * (nt + 1ull) / 2ull * (unsigned long long)(64 / seg) + 64ull;
     if (need > h->slist_cap) {
         CK(hipStreamSynchronize(st));
         if (h->d_slist) CK(hipFree(h->d_slist));
@@ -4077,11 +4106,9 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
     const int no_window = (sx.quirk && h->n_ubins > 0) ? 1 : 0;
     // rows of candidate units = tiles of the affected sets: a block per row up to the chip's width
     const int cull_blocks = (int)std::min<unsigned long long>(1024ull, std::max<unsigned long long>(1ull, (unsigned long long)K * nt));
-    k_strict_cull<<<cull_blocks, 256, 0, st>>>(h->tabs, h->geo, h->link, h->cbase, h->perm, fA, K, rank, world, sx.reach_bp, no_window,
+    k_strict_cull<<<cull_blocks, 256, 0, st>>>(h->tabs, h->geo, h->link, h->cbase, h->perm, fA, K, rank, world, sx.reach_bp, no_window, seg,
                                                h->d_slist, h->d_slist_n, h->slist_cap, (unsigned long long*)(h->d_scalars + 10));
     CK(hipGetLastError());
-    static const int blocks_env = getenv("GRAAL_STRICT_BLOCKS") ? atoi(getenv("GRAAL_STRICT_BLOCKS")) : 0;
-    const int blocks = blocks_env > 0 ? blocks_env : (h->max_lcont > 0 && h->max_lcont <= 64 ? 32 : (h->max_lcont <= 1024 ? 512 : 1024));
     if (h->single_sub) k_strict<false><<<blocks, 256, strict_dyn_lds(K), st>>>(fa, sx, fA, K, h->d_slist, h->d_slist_n, d_q_out, publish ? h->res_dev : nullptr, h->seq);
     else k_strict<true><<<blocks, 256, strict_dyn_lds(K), st>>>(fa, sx, fA, K, h->d_slist, h->d_slist_n, d_q_out, publish ? h->res_dev : nullptr, h->seq);
     CK(hipGetLastError());

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU box: the BASELINE.json configurations 2-4 on synthetic stand-ins of the documented shapes (the
 S1 / T. reesei tarballs are not in this image): full headless start_EM runs (explode + n cycles) through the drop-in
-sampler, wall time per MCMC step, contigs left, final log-likelihood.  Usage: python tools/run_configs.py [C2 C3 C4]"""
+sampler, wall time per MCMC step, contigs left, final log-likelihood.  Usage: python tools/run_configs.py [C2 C3 C4] [--arithmetic strict|exact] [--cycles N]"""
 import os
 import sys
 import time
@@ -21,23 +21,27 @@ CONFIGS = {  # name: (n_bins, nnz, n_sub, cycles, neighbours, accu)
 
 
 def main():
-    names = sys.argv[1:] or ["C2", "C3", "C4"]
+    args = sys.argv[1:]
+    arith = args[args.index("--arithmetic") + 1] if "--arithmetic" in args else "strict"
+    cyc = int(args[args.index("--cycles") + 1]) if "--cycles" in args else None
+    names = [a for a in args if a in CONFIGS] or ["C2", "C3", "C4"]
     for name in names:
         n_bins, nnz, n_sub, cycles, K, accu = CONFIGS[name]
+        cycles = cyc or cycles
         P = synth.make_problem(n_bins=n_bins, nnz=nnz, n_sub=n_sub, seed=2014, contig_weights=(6.8, 6.2, 5.3, 4.6, 4.0, 3.4, 2.7),
                                mean_len_bp=660.0 * (27 if n_sub > 1 else 1) / max(n_sub, 1), accu=accu)
         rng = np.random.RandomState(1)
         t0 = time.perf_counter()
-        smp = bench.build_sampler(P, rng, None, 0)
+        smp = bench.build_sampler(P, rng, None, 0, arith)
         t_setup = time.perf_counter() - t0
         t0 = time.perf_counter()
         tr = em.run_em(smp, cycles, K, rng=rng)
         dt = time.perf_counter() - t0
         n_steps = len(tr.likelihood)
         full = smp.eval_likelihood()
-        print("%s: %d bins x %d sub, %d contacts, %d cycles x %d neighbours: setup %.1f s, explode + %d MCMC steps in %.1f s = %.0f us/step, "
+        print("%s [%s]: %d bins x %d sub, %d contacts, %d cycles x %d neighbours: setup %.1f s, explode + %d MCMC steps in %.1f s = %.0f us/step, "
               "%d contigs left (started exploded: %d), carried logL %.6e vs full re-evaluation %.6e (rel %.1e)"
-              % (name, n_bins, n_sub, nnz, cycles, K, t_setup, n_steps, dt, 1e6 * dt / n_steps, tr.n_contigs[-1], n_bins,
+              % (name, arith, n_bins, n_sub, nnz, cycles, K, t_setup, n_steps, dt, 1e6 * dt / n_steps, tr.n_contigs[-1], n_bins,
                  tr.likelihood[-1], full, abs(full - tr.likelihood[-1]) / abs(full)), flush=True)
         smp.free_gpu()
 
