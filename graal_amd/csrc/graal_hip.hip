@@ -1074,14 +1074,18 @@ __device__ __forceinline__ long long pair_mass_q_c(const Ctr& cx, const Stat& sx
 // ~200 x 9 slot pairs each: 1.3 ms per full evaluation, which the nuisance-parameter step pays every MCMC step; a whole wave
 // per fragment costs 50,000 nearly empty waves while contigs are short: 58 us against 33.)
 // Like the candidate tasks, every fragment PAIR is rounded to Q once, so the sum does not depend on how it is partitioned.
+template <int LPF>   // lanes per fragment x: 16, or 64 for maps of a few thousand bins (a contig of 200 bins with nine slot pairs per
+                     // fragment pair is a chain of 13 x 9 evaluations per lane at 16 lanes: 80 us per call at the C2 shape, every step
+                     // of a reference-arithmetic run with sub-fragments; 64 lanes: a quarter of the chain)
 __global__ __launch_bounds__(256) void k_full_mass(int n, const int* __restrict__ perm, const int* __restrict__ contig_off,
                                                     const Geo* __restrict__ geo, const Stat* __restrict__ stat,
                                                     const int* __restrict__ lcont, const int* __restrict__ lcontbp,
                                                     const int* __restrict__ pos, float nfpb, Par par, int reach_bp,
                                                     long long* __restrict__ out, long long* __restrict__ bad_flag)
 {
-    const int lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4;
-    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    constexpr int LPF_SHIFT = LPF == 64 ? 6 : 4;
+    const int lane = threadIdx.x & 63, sub = lane & (LPF - 1), grp = LPF == 64 ? 0 : lane >> 4;
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> LPF_SHIFT;
     long long accq = 0;
     bool bad = false;
     int remaining = 0;
@@ -1104,8 +1108,8 @@ __global__ __launch_bounds__(256) void k_full_mass(int n, const int* __restrict_
         }
         remaining = lcont[fx] - 1 - pos[fx];
     }
-    bool live = remaining > 0; // (uniform within the 16 lanes of a fragment)
-    for (int k0 = 1; __ballot(live) != 0; k0 += 16) {
+    bool live = remaining > 0; // (uniform within the LPF lanes of a fragment)
+    for (int k0 = 1; __ballot(live) != 0; k0 += LPF) {
         bool inside = false;
         const int k = k0 + sub;
         if (live && k <= remaining) {
@@ -1120,8 +1124,9 @@ __global__ __launch_bounds__(256) void k_full_mass(int n, const int* __restrict_
             }
         }
         // start_bp grows along the contig: once none of a fragment's 16 lanes found a y inside the window, nothing further is
-        const unsigned any = (unsigned)(__ballot(inside) >> (16 * grp)) & 0xffffu;
-        live = live && any != 0 && k0 + 16 <= remaining;
+        const unsigned long long bal = __ballot(inside);
+        const bool any = LPF == 64 ? bal != 0ull : ((unsigned)(bal >> (16 * grp)) & 0xffffu) != 0u;
+        live = live && any && k0 + LPF <= remaining;
     }
     (void)contig_off;
     if (bad) atomicOr((unsigned long long*)bad_flag, 1ull);
@@ -3383,8 +3388,13 @@ __global__ __launch_bounds__(256) void k_strict(FinArgs fa, StrictArgs sa, int f
                 const long long q1 = to_q(acc);
                 if (q1 == Q_BAD) bad |= (unsigned)CMASK_(k, pr, op) | (1u << 16);
                 else {
-#pragma unroll
-                    for (int i = 0; i < N_OPS; i++) accq[i] += (i == op) ? q1 : 0ll;
+                    // (`op` is wave-uniform -- the loop counter -- so this is a scalar jump to one 64-bit add, not 13 selects)
+                    switch (op) {
+                    case 0: accq[0] += q1; break; case 1: accq[1] += q1; break; case 2: accq[2] += q1; break; case 3: accq[3] += q1; break;
+                    case 4: accq[4] += q1; break; case 5: accq[5] += q1; break; case 6: accq[6] += q1; break; case 7: accq[7] += q1; break;
+                    case 8: accq[8] += q1; break; case 9: accq[9] += q1; break; case 10: accq[10] += q1; break; case 11: accq[11] += q1; break;
+                    default: accq[12] += q1; break;
+                    }
                 }
             }
         }
@@ -4711,7 +4721,9 @@ int graal_eval_full_q(graal_ctx* h, int64_t q_out[2])
     const bool quirk = (h->mode & GRAAL_MODE_REF_TRANS_ACCU) != 0;
     if (h->nnz) {
         static const bool no_compact = getenv("GRAAL_FULL_NO_COMPACT") != nullptr;
-        const bool compact = h->uniform_accu > 0 && !quirk && !no_compact;
+        // (equal RF counts everywhere: the reference's trans-branch indexing picks the same count whatever the orientation, so
+        // the compact records serve that mode too)
+        const bool compact = h->uniform_accu > 0 && !no_compact;
         k_subrec<<<blocks_for(h->n, 256), 256, 0, h->stream>>>(h->n, h->geo, h->stat_frag, h->d_sub_ids, h->sub_rec, compact ? h->sub_rec8 : nullptr, h->sub_lab16);
         // 8 blocks of 256 threads per CU; every lane takes FULL_G groups of 4 contacts per iteration
         static const int full_g = getenv("GRAAL_FULL_G") ? atoi(getenv("GRAAL_FULL_G")) : 2;
@@ -4755,9 +4767,14 @@ int graal_eval_full_q(graal_ctx* h, int64_t q_out[2])
     if (quirk && h->n_ubins) // T_all prices every pair of different bins with the plain trans value: add the indexing's difference
         k_quirk_mass<<<blocks_for((long long)h->n_ubins * h->n_bins, 256), 256, 0, h->stream>>>(h->n_ubins, h->d_ubins, h->n_bins, h->geo, h->stat_frag,
                                                                                              h->nfpb, h->par, h->d_scalars + 9, h->d_scalars + FULL_BAD);
-    k_full_mass<<<blocks_for(h->n, 16), 256, 0, h->stream>>>(h->n, h->perm, h->contig_off2[h->cur], h->geo, h->stat_frag, s.p[F_LCONT],
-                                                             s.p[F_LCONTBP], s.p[F_POS], h->nfpb, h->par, reach_bp(h),
-                                                             h->d_scalars + 9, h->d_scalars + FULL_BAD);
+    if (h->n <= 16384)
+        k_full_mass<64><<<blocks_for(h->n, 4), 256, 0, h->stream>>>(h->n, h->perm, h->contig_off2[h->cur], h->geo, h->stat_frag, s.p[F_LCONT],
+                                                                    s.p[F_LCONTBP], s.p[F_POS], h->nfpb, h->par, reach_bp(h),
+                                                                    h->d_scalars + 9, h->d_scalars + FULL_BAD);
+    else
+        k_full_mass<16><<<blocks_for(h->n, 16), 256, 0, h->stream>>>(h->n, h->perm, h->contig_off2[h->cur], h->geo, h->stat_frag, s.p[F_LCONT],
+                                                                     s.p[F_LCONTBP], s.p[F_POS], h->nfpb, h->par, reach_bp(h),
+                                                                     h->d_scalars + 9, h->d_scalars + FULL_BAD);
     if (h->has_rep) { // every pixel of a repeated bin, densely (identical on every rank: it goes with the mass part)
         const RepArgs R = rep_args(h);
         k_rep_full<<<blocks_for((long long)h->n_dup * h->n_bins, 256), 256, 0, h->stream>>>(R, h->d_scalars + 17, h->d_scalars + FULL_BAD);
