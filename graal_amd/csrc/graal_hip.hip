@@ -297,12 +297,17 @@ __device__ __forceinline__ int4 ld_stream(const int4* p)
 // Debug build (-DGRAAL_STAMPS): selected threads write the 100 MHz wall clock at a few points of the per-step kernels
 #ifdef GRAAL_STAMPS
 __device__ unsigned long long g_stamps[32];
+__device__ unsigned long long g_hitstat[8];   // [0] launches' max third-stage duration (ticks) [1] latest third-stage end [2] count [3] sum of durations [4] max passes
 #define STAMP(i, cond) do { if (cond) g_stamps[i] = wall_clock64(); } while (0)
+#define HITSTAT_BEGIN() const unsigned long long hs_t0 = wall_clock64()
+#define HITSTAT_END() do { if (lane == 0 && !dry) { const unsigned long long hs_t1 = wall_clock64(); atomicMax(&g_hitstat[0], hs_t1 - hs_t0); atomicMax(&g_hitstat[1], hs_t1); atomicAdd(&g_hitstat[2], 1ull); atomicAdd(&g_hitstat[3], hs_t1 - hs_t0); } } while (0)
 __device__ unsigned long long g_blk[4096 * 4]; // per block of k_scan: start, past prologue, loop done
 #define STAMP_BLK(j, cond) do { if (cond) g_blk[4 * blockIdx.x + (j)] = wall_clock64(); } while (0)
 #define STAMP_FBLK(j, cond) do { if ((cond) && blockIdx.x < 2048) g_blk[4 * (2048 + blockIdx.x) + (j)] = wall_clock64(); } while (0) // k_fin's blocks
 #else
 #define STAMP(i, cond) do { } while (0)
+#define HITSTAT_BEGIN() do { } while (0)
+#define HITSTAT_END() do { } while (0)
 #define STAMP_BLK(j, cond) do { } while (0)
 #define STAMP_FBLK(j, cond) do { } while (0)
 #endif
@@ -1481,6 +1486,68 @@ struct QEntry {
     int fx, fy, cnt;     // fragments (bins) and observed count (float32 bits)
     int slots;           // sub-fragment slots: slx | sly << 2
 };
+// What k_scan stores per doubly-affected contact (16 bytes): it neither gathers the fragments' records nor waits for its stores to be
+// acknowledged -- both used to end the kernel one or two memory round trips after the last such contact turned up (6 us per
+// launch: tools/ab.sh, tools/stamps_hits.py).  The consumers load the records anyway; the piece codes and the neighbour mask are
+// derived there (q_fetch, q_codes), and a consumer that may run WHILE the scan's last stores are in flight (k_tm's finishing block)
+// validates the step's sequence tag carried by both words.
+//   w0 = contact index | seq << 32            w1 = fx | fy << 20 | slots << 40 | (seq & 0xfffff) << 44
+struct QRaw { unsigned long long w0, w1; };
+static_assert(LABEL_BITS <= 20, "fragment ids must fit the 20-bit fields of a queue entry");
+struct QSrc {
+    const QRaw* queue;
+    const int2* geo2;          // (id_c, flags) = first half of a Geo record
+    const int* cnt;
+    const PieceKey* keys;      // [K] of the step's neighbours (shared memory of the consumer)
+    unsigned live;             // bit k: neighbour k is a real pair (fB != fA)
+    int K;
+    unsigned seq;              // the step's sequence number (low 32 bits)
+    int concurrent;            // the producer may still be storing: validate the tags (bounded spin)
+    int multi;                 // bins have several sub-fragments: a bin's own pixel is skipped
+};
+// first half: the entry itself (one round trip; fx < 0: nothing to price).  The caller then requests the two fragments' records,
+// their statistics and the contact's count TOGETHER (second round trip) and calls q_codes.
+__device__ __forceinline__ QEntry q_fetch(const QSrc& q, unsigned long long e, unsigned long long* __restrict__ err)
+{
+    QEntry qe;
+    qe.rel = 0; qe.ci = 0; qe.cj = 0; qe.cnt = 0; qe.idx = 0; qe.fx = -1; qe.fy = 0; qe.slots = 0;
+    unsigned long long w0, w1;
+    if (!q.concurrent) {
+        typedef unsigned long long v2u __attribute__((ext_vector_type(2)));
+        const v2u v = *reinterpret_cast<const v2u*>(q.queue + e);
+        w0 = v.x; w1 = v.y;
+    } else {
+        const unsigned long long* p = reinterpret_cast<const unsigned long long*>(q.queue + e);
+        bool ok = false;
+        for (int spin = 0; spin < (1 << 20); spin++) {
+            w0 = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            w1 = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(w0 >> 32) == q.seq && (unsigned)(w1 >> 44) == (q.seq & 0xfffffu)) { ok = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (!ok) { atomicOr(err, 1ull); return qe; }
+    }
+    qe.idx = (unsigned)w0;
+    const int fx = (int)(w1 & 0xfffffull), fy = (int)((w1 >> 20) & 0xfffffull);
+    qe.fy = fy; qe.slots = (int)((w1 >> 40) & 0xfull);
+    if (q.multi && fx == fy) return qe;   // a bin's own pixel is never revisited (kernels3.cu:3356-3380)
+    qe.fx = fx;
+    return qe;
+}
+// second half: piece codes of the two fragments per neighbour and the mask of the neighbours whose two contigs hold both
+__device__ __forceinline__ void q_codes(const QSrc& q, QEntry& qe, const Geo& gx, const Geo& gy, int cnt)
+{
+    unsigned ci = 0, cj = 0;
+    for (int k = 0; k < q.K; k++)
+        if ((q.live >> k) & 1u) {
+            ci |= (unsigned)piece_of(q.keys[k], gx.id_c, geo_pos(gx.flags)) << (CODE_BITS * k);
+            cj |= (unsigned)piece_of(q.keys[k], gy.id_c, geo_pos(gy.flags)) << (CODE_BITS * k);
+        }
+    const unsigned nzi = (ci | (ci >> 1) | (ci >> 2)) & CODE_LSB, nzj = (cj | (cj >> 1) | (cj >> 2)) & CODE_LSB;
+    qe.ci = ci; qe.cj = cj; qe.cnt = cnt;
+    qe.rel = nzi & nzj;   // both ends in the neighbour's two contigs: the consumers' exact per-candidate masks do the rest
+}
+
 struct DevArgs {
     SoaPtr soa;
     long long nnz;
@@ -1494,7 +1561,7 @@ struct DevArgs {
     NbTables* tabs;
     int* step_hdr;                // [k] mass work items of neighbour k, [MAXK + k] 1 = k_tm priced them already
     long long* tm_done;           // [k] sequence number of the step whose tables of neighbour k are complete
-    QEntry* queue;
+    QRaw* queue;
     long long* acc;               // K*13 running sums of the step (zeroed again by k_fin once it has read them)
     unsigned long long* counters; // [0] n_rel [1] n_items [2] queue count [5] ticket [6] error; [8..10] copy of [0..2] of the last step
     float nfpb;
@@ -1530,7 +1597,8 @@ struct PriceArgs {
     const unsigned short* pr_lds;  // [K][N_PAIRS][PR_WORDS] or nullptr
     const PTask* pt_lds;           // [K][PT_CAP]
     const int* nt_lds;             // [K] number of tasks of neighbour k
-    const QEntry* queue;
+    QSrc q;                        // the queue and what expands its entries
+    unsigned long long* err;       // counters[6]
     const NbTables* tabs;
     const Geo* geo;
     const Stat* stat;
@@ -1594,11 +1662,13 @@ __device__ __forceinline__ void price_contacts(const PriceArgs& pa, unsigned lon
     for (unsigned long long e0 = (unsigned long long)first * 4; e0 < nq_total; e0 += (unsigned long long)n_waves * 4) {
         const unsigned long long e = e0 + (lane >> 4);
         if (e >= nq_total || op >= N_OPS) continue;
-        const QEntry qe = pa.queue[e];
-        if (qe.rel == 0) continue; // (a reserved slot whose contact failed the scan's third test)
+        QEntry qe = q_fetch(pa.q, e, pa.err);
+        if (qe.fx < 0) continue;
         const int fx = qe.fx, fy = qe.fy;
         ContactVals cv = {pa.geo[fx], pa.geo[fy], pa.stat[fx], pa.stat[fy], qe.slots & 3, (qe.slots >> 2) & 3,
-                          (double)__int_as_float(qe.cnt), 0, 0, 0, 0, 0, 0, 0, 0};
+                          (double)__int_as_float(pa.q.cnt[qe.idx]), 0, 0, 0, 0, 0, 0, 0, 0};
+        q_codes(pa.q, qe, cv.gx, cv.gy, 0);
+        if (qe.rel == 0) continue; // (both ends affected, but by no common neighbour)
         unsigned rel = qe.rel;
         while (rel) {
             const int k = (__ffs((int)rel) - 1) / CODE_BITS;
@@ -1648,7 +1718,7 @@ __device__ __forceinline__ void price_contacts(const PriceArgs& pa, unsigned lon
 // Reference arithmetic, a few queued contacts (the finishing block of k_tm): 16 lanes per contact, lane = candidate.  The scan
 // queued every contact with both ends in some neighbour's affected set; each is priced again under every candidate whose
 // inputs differ from the current layout's:  ob (ln ex_new - ln ex_old)  (kernels3.cu:3383-3697).
-__device__ __forceinline__ void price_contacts_strict(const QEntry* __restrict__ queue, const NbTables* __restrict__ tabs, const Geo* __restrict__ geo,
+__device__ __forceinline__ void price_contacts_strict(const QSrc& qs, unsigned long long* __restrict__ err, const NbTables* __restrict__ tabs, const Geo* __restrict__ geo,
                                                       const Stat* __restrict__ stat, const int* __restrict__ lcontbp, long long* __restrict__ out,
                                                       unsigned long long* __restrict__ nf, float nfpb, const Par& par, bool quirk,
                                                       unsigned long long nq_total, int first, int n_waves, int lane)
@@ -1657,11 +1727,13 @@ __device__ __forceinline__ void price_contacts_strict(const QEntry* __restrict__
     for (unsigned long long e0 = (unsigned long long)first * 4; e0 < nq_total; e0 += (unsigned long long)n_waves * 4) {
         const unsigned long long e = e0 + (lane >> 4);
         if (e >= nq_total || op >= N_OPS) continue;
-        const QEntry qe = queue[e];
-        if (qe.rel == 0) continue;
+        QEntry qe = q_fetch(qs, e, err);
+        if (qe.fx < 0) continue;
         const int fx = qe.fx, fy = qe.fy, slx = qe.slots & 3, sly = (qe.slots >> 2) & 3;
         const Geo gx = geo[fx], gy = geo[fy];
         const Stat sx = stat[fx], sy = stat[fy];
+        q_codes(qs, qe, gx, gy, qs.cnt[qe.idx]);
+        if (qe.rel == 0) continue;
         const End X0 = end_old(gx, ((gx.flags >> 1) & 1) ? lcontbp[fx] : 0), Y0 = end_old(gy, ((gy.flags >> 1) & 1) ? lcontbp[fy] : 0);
         const float ex_old = ex_pair_ref(X0, sx, slx, fx, Y0, sy, sly, fy, nfpb, par, quirk);
         const double ln_old = log((double)ex_old), ob = (double)__int_as_float(qe.cnt);
@@ -1701,11 +1773,13 @@ __device__ __forceinline__ void price_contact_batch(const PriceArgs& pa, long lo
     {
         const unsigned long long e = b0 + ent;
         if (e >= nq_total) return;
-        const QEntry qe = pa.queue[e];
-        if (qe.rel == 0) return; // (a reserved slot whose contact failed the scan's third test)
+        QEntry qe = q_fetch(pa.q, e, pa.err);
+        if (qe.fx < 0) return;
         const int fx = qe.fx, fy = qe.fy;
         ContactVals cv = {pa.geo[fx], pa.geo[fy], pa.stat[fx], pa.stat[fy], qe.slots & 3, (qe.slots >> 2) & 3,
-                          (double)__int_as_float(qe.cnt), 0, 0, 0, 0, 0, 0, 0, 0};
+                          (double)__int_as_float(pa.q.cnt[qe.idx]), 0, 0, 0, 0, 0, 0, 0, 0};
+        q_codes(pa.q, qe, cv.gx, cv.gy, 0);
+        if (qe.rel == 0) return; // (both ends affected, but by no common neighbour)
         unsigned rel = qe.rel;
         while (rel) {
             const int k = (__ffs((int)rel) - 1) / CODE_BITS;
@@ -1845,7 +1919,9 @@ struct TmArgs { // first-needed pointers by value (see ScanArgs)
     int strict_inline_m;           // largest affected set k_tm prices itself in reference arithmetic (-1: none, k_strict_dense validation)
     // the finishing block's pointers, by value too
     unsigned long long* counters;
-    const QEntry* queue;
+    const QRaw* queue;
+    const int* cnt;
+    int multi;                     // bins have several sub-fragments
     const Stat* stat;
     const int* lcontbp;
     long long* acc;
@@ -2095,13 +2171,24 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
         if (t == 0) { ta.sync[0] = 0; __threadfence_system(); ta.host_res[0] = seq | NEED_FIN | (s_fin == 3 ? GAVE_UP : 0ll); __threadfence_system(); }
         return;
     }
+    // the queue's entries are expanded here (q_fetch + q_codes): the neighbours' piece keys, and a validated sequence tag per entry -- the
+    // scan's last stores may still be on their way
+    __shared__ PieceKey s_qkeys[MAXK];
+    __shared__ unsigned s_qlive;
+    if (t == 0) s_qlive = 0;
+    __syncthreads();
+    if (t < K) { s_qkeys[t] = ta.tabs[t].key; if (ta.tabs[t].fB != fA) atomicOr(&s_qlive, 1u << t); }
+    __syncthreads();
+    QSrc qs;
+    qs.queue = ta.queue; qs.geo2 = reinterpret_cast<const int2*>(ta.geo); qs.cnt = ta.cnt; qs.keys = s_qkeys; qs.live = s_qlive; qs.K = K;
+    qs.seq = (unsigned)seq; qs.concurrent = 1; qs.multi = ta.multi;
     if (ta.strict)
-        price_contacts_strict(ta.queue, ta.tabs, ta.geo, ta.stat, ta.lcontbp, ta.acc, ta.counters + NF_OFF, ta.nfpb, ta.par, ta.quirk != 0,
+        price_contacts_strict(qs, ta.counters + 6, ta.tabs, ta.geo, ta.stat, ta.lcontbp, ta.acc, ta.counters + NF_OFF, ta.nfpb, ta.par, ta.quirk != 0,
                               s_nq, t >> 6, (int)(blockDim.x >> 6), t & 63);
     else {
         PriceArgs pa;
         pa.pr_lds = s_prl; pa.pt_lds = s_ptl; pa.nt_lds = s_ntl;
-        pa.queue = ta.queue; pa.tabs = ta.tabs; pa.geo = ta.geo; pa.stat = ta.stat; pa.lcontbp = ta.lcontbp;
+        pa.q = qs; pa.err = ta.counters + 6; pa.tabs = ta.tabs; pa.geo = ta.geo; pa.stat = ta.stat; pa.lcontbp = ta.lcontbp;
         pa.out = ta.acc; pa.nf = ta.counters + NF_OFF; pa.nfpb = ta.nfpb; pa.par = ta.par;
         price_contacts(pa, s_nq, t >> 6, (int)(blockDim.x >> 6), t & 63);
     }
@@ -2109,38 +2196,6 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
     STAMP(5, t == 0);
     hand_out(ta.acc, ta.counters, ta.sync, K, nullptr, ta.host_res, seq);
     STAMP(6, t == 0);
-}
-
-struct StepKeys {
-    PieceKey key[MAXK];
-    unsigned live;   // bit k: neighbour k is a real pair (fB != fA)
-    unsigned intra;  // bit CODE_BITS*k: some candidate of neighbour k may change the geometry INSIDE a piece (circular model)
-};
-
-// relevance code of a fragment: CODE_BITS bits per neighbour = piece id (0..6), 0 = not in contig(fA) u contig(fB_k)
-
-__device__ __forceinline__ unsigned code_of(const StepKeys& S, int K, int id_c, int pos)
-{
-    unsigned code = 0;
-    for (int k = 0; k < K; k++)
-        if ((S.live >> k) & 1u) code |= (unsigned)piece_of(S.key[k], id_c, pos) << (CODE_BITS * k);
-    return code;
-}
-
-// can one of the 13 candidates of (fA, fB) change the circular model of a contig?  Contigs that are circular now can be
-// linearised / change length; a new circle only comes out of paste_contigs (ops 9-12) when, after the two splits, fA and
-// fB are the two ends of one contig (kernels3.cu:1960-1976)
-__device__ bool circ_may_change(int fA, int fB, int max_id, const Rec& A0, const Rec& B0)
-{
-    if (A0.circ == 1 || B0.circ == 1) return true;
-    if (A0.id_c != B0.id_c) return false;
-    for (int op = 9; op < N_OPS; op++) {
-        const Move m = make_move(op, fA, fB, max_id, A0, B0);
-        if (m.A2.id_c != m.B2.id_c) continue;
-        const int last = m.A2.l_cont - 1;
-        if ((m.A2.pos == 0 && m.B2.pos == last) || (m.A2.pos == last && m.B2.pos == 0)) return true;
-    }
-    return false;
 }
 
 // k_scan: ONE streaming pass over this rank's contact list for all 13*K candidates of the step.
@@ -2167,7 +2222,7 @@ struct ScanArgs { // by value: kernel-argument pointers are known to be GLOBAL (
     const int *cbase, *perm, *mates, *sub_ids, *sub2bin, *cnt;
     const int4 *row4, *col4;
     const int2* geo2;             // (id_c, flags) = first half of a Geo record
-    QEntry* queue;
+    QRaw* queue;
     unsigned long long* counters;
     unsigned* flags;              // [block] sequence number of the last step this block finished
     unsigned seq32;
@@ -2203,17 +2258,17 @@ __global__ __launch_bounds__(1024, (G <= 4 ? 8 : 4)) void k_scan(ScanArgs sa, in
                                                 int dry /* timing replays: count, do not queue */)
 {
     extern __shared__ unsigned s_bm[];
-    __shared__ StepKeys S;
     __shared__ Rec s_rec[MAXK + 1];
     __shared__ int s_cbase[MAXK + 1], s_clen[MAXK + 1], s_pref[MAXK + 2], s_fB[MAXK];
     __shared__ int s_waves_done, s_long;
+    __shared__ int s_hitbuf[16][64 * 3];   // per wave: the doubly-affected contacts of one iteration (row id, col id, contact index), dealt one per lane
     __shared__ unsigned s_keys_ready;
     __shared__ unsigned long long s_nrel;
     const int t = threadIdx.x;
     const int lane = t & 63;
     if (sa.relabel_seq != 0ull && blockIdx.x == 0 && t == 0)
         __hip_atomic_store(sa.relabel_flag, sa.relabel_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the relabel's writes were released when it ended)
-    if (max_id < 0) max_id = (int)sa.nc[0] - 1;   // (see k_tm; only wave 1 uses it, behind the block's barrier)
+    (void)max_id;   // (the candidates' geometry is k_tm's and the consumers' business; kept in the signature for the timing replays)
     STAMP(8, blockIdx.x == 0 && t == 0 && !dry);
     STAMP_BLK(0, t == 0 && !dry);
     // ---- prologue.  Only the affected BITMAP stands between a block and its stream, so wave 0 builds nothing else: one
@@ -2292,7 +2347,6 @@ __global__ __launch_bounds__(1024, (G <= 4 ? 8 : 4)) void k_scan(ScanArgs sa, in
     __syncthreads();
     if (t >= 64 && t < 128) {   // wave 1, BEHIND the barrier (in front of it, the whole block would wait for this work)
         const int u = t - 64;
-        if (u == 0) { S.live = 0; S.intra = 0; }
         if (u <= K) { s_rec[u] = rec_gl(my_geo, my_link, my_f); s_cbase[u] = my_cbase; }
         if (u < MAXK) s_fB[u] = sel_nb(nb, u);
         WSYNC();
@@ -2300,14 +2354,11 @@ __global__ __launch_bounds__(1024, (G <= 4 ? 8 : 4)) void k_scan(ScanArgs sa, in
             const Rec& A0 = s_rec[0];
             const Rec& B0 = s_rec[u + 1];
             const int fB = s_fB[u];
-            PieceKey key; key.cA = A0.id_c; key.a = A0.pos; key.cB = B0.id_c; key.b = B0.pos;
-            S.key[u] = key;
+            // (the piece keys, the circular-model flags and the neighbour masks of the queued contacts are the consumers' business
+            // now: q_codes)
             bool dup = (fB == fA) || (B0.id_c == A0.id_c);
-            if (fB != fA) {
-                atomicOr(&S.live, 1u << u);
-                if (circ_may_change(fA, fB, max_id, A0, B0)) atomicOr(&S.intra, 1u << (CODE_BITS * u));
+            if (fB != fA)
                 for (int j = 0; j < u; j++) if (s_fB[j] != fA && s_rec[j + 1].id_c == B0.id_c) dup = true;
-            }
             s_clen[u + 1] = (dup || B0.l_cont <= N_MATES) ? 0 : B0.l_cont;    // long contigs only: the short ones are marked from their rows
         }
         if (u == 0) s_clen[0] = s_rec[0].l_cont <= N_MATES ? 0 : s_rec[0].l_cont;
@@ -2334,8 +2385,7 @@ __global__ __launch_bounds__(1024, (G <= 4 ? 8 : 4)) void k_scan(ScanArgs sa, in
     }
     const int4* __restrict__ col4 = sa.col4;
     const int* __restrict__ sub2bin = sa.sub2bin;
-    const int2* __restrict__ geo2 = sa.geo2;
-    QEntry* __restrict__ queue = sa.queue;
+    QRaw* __restrict__ queue = sa.queue;
     unsigned long long* __restrict__ counters = sa.counters;
     unsigned long long n_rel = 0;
     STAMP_BLK(1, t == 0 && !dry);
@@ -2364,8 +2414,6 @@ __global__ __launch_bounds__(1024, (G <= 4 ? 8 : 4)) void k_scan(ScanArgs sa, in
     };
     // the rest of a batch in which some lane of the wave found an affected row (rare while contigs are short)
     auto process_hits = [&](const int4 (&rr)[G], const int ga, unsigned hit) {
-        wait_keys();   // (wave 1's keys: long there by the time a block has streamed its first batch)
-        const unsigned intra = S.intra;
         // second test, still wide: the col words of the groups with an affected row (up to G 16-byte loads in flight
         // together), all bitmap tests at once
         int4 cc[G];
@@ -2388,80 +2436,78 @@ __global__ __launch_bounds__(1024, (G <= 4 ? 8 : 4)) void k_scan(ScanArgs sa, in
         // third test rejects leave entries with an empty neighbour mask behind, which the pricing skips).  One reservation per
         // PASS of the loop below -- up to 16 per iteration, 10^5 per step when two long contigs are affected -- made the tail
         // of the queue the bottleneck of the late stage: same-address atomics with return, ~0.7 ms of a 0.8 ms scan.
-        unsigned slot = 0;
-        if (!dry && __ballot(hit != 0) != 0) {
-            const unsigned mine = (unsigned)__popc(hit);
-            unsigned incl = mine;
+#ifdef GRAAL_EXP_COLONLY   // (bisecting build: stop behind the second test -- wrong results)
+        n_rel += __popc(hit);
+        return;
+#endif
+        // ---- third test.  The doubly-affected contacts of this wave iteration are first DEALT to the lanes, one each, through a
+        // per-wave LDS list: they come in clusters -- the rows of a contig's fragments hold contacts with their contig mates next
+        // to each other, so one lane owns four of them while the others own none -- and a lane used to take its contacts one per
+        // pass, a dependent round trip each: four passes in a wave's last iteration ended the kernel 6 us late, every step
+        // (tools/ab.sh: 23.2 us per launch in a step, 16.8 without the third test).  Now one pass per 64 contacts: the gathers of
+        // all of them and the slot reservation are in flight together.
+        const unsigned mine = (unsigned)__popc(hit);
+        unsigned incl = mine;
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const unsigned y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
-            unsigned long long base = 0;
-            if (lane == 63) base = atomicAdd(&counters[2], (unsigned long long)incl);
-            slot = (unsigned)__shfl(base, 63, 64) + incl - mine;
-        }
-        // third test: one doubly-affected contact per lane and pass (a loop, not a 16-fold unrolled body: rare when contigs
-        // are short)
-        while (__ballot(hit != 0) != 0) {
-            unsigned rel = 0, q_ci = 0, q_cj = 0;
-            int j = 0, q_fx = 0, q_fy = 0, q_slots = 0, cnt_w = 0;
-            long long cidx = 0;
-            const bool cidx_valid = hit != 0; // this lane examines a contact in this pass
-            if (hit) {
-                j = __ffs((int)hit) - 1;
-                hit &= hit - 1;
-                const int rj = sel_words<G>(rr, j), cj_ = sel_words<G>(cc, j);
-                cidx = ((long long)(ga + (j >> 2) * stride) << 2) + (j & 3);
-                // (the count is requested together with the two fragment records below, not after the third test: one
-                // dependent round trip less in a chain that ends the kernel when the contact turns up in a late iteration)
-                if (!dry) cnt_w = sa.cnt[cidx];
-                {
-                    int fx, fy;
-                    if (SINGLE_SUB) { fx = rj; fy = cj_; }
-                    else { const int a = sub2bin[rj], b = sub2bin[cj_]; fx = a >> 2; fy = b >> 2; q_slots = (a & 3) | ((b & 3) << 2); }
-                    q_fx = fx; q_fy = fy;
-                    const int2 gi = geo2[2 * fx], gj = geo2[2 * fy];
-                    const unsigned ci = code_of(S, K, gi.x, geo_pos(gi.y)), cj = code_of(S, K, gj.x, geo_pos(gj.y));
-                    const unsigned nzi = (ci | (ci >> 1) | (ci >> 2)) & CODE_LSB;
-                    const unsigned nzj = (cj | (cj >> 1) | (cj >> 2)) & CODE_LSB;
-                    const unsigned df = ci ^ cj;
-                    const unsigned dnz = (df | (df >> 1) | (df >> 2)) & CODE_LSB;
-                    const unsigned both = nzi & nzj;
-                    // different pieces, or the same piece of a neighbour whose circular model may change (k_fin filters
-                    // by the exact per-candidate relation masks)
-                    rel = sa.strict ? both : both & (dnz | intra);
-                    if (!SINGLE_SUB && fx == fy) rel = 0; // a bin's own pixel is never revisited (kernels3.cu:3356-3380)
-                    q_ci = ci; q_cj = cj;
+        for (int o = 1; o < 64; o <<= 1) { const unsigned y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
+        const unsigned total = (unsigned)__shfl((int)incl, 63, 64);
+        if (total == 0) return;
+        HITSTAT_BEGIN();
+        // Queue slots for ALL of them are reserved with one atomic (the few that the third test rejects leave entries with an empty
+        // neighbour mask behind, which the pricing skips)
+        unsigned long long base = 0;
+        if (!dry && lane == 63) base = atomicAdd(&counters[2], (unsigned long long)total);
+        int* const hb = s_hitbuf[t >> 6];
+        for (unsigned n0 = 0; n0 < total; n0 += 64) {
+            {   // owners: my contacts number incl - mine .. incl - 1 of the iteration; those of this round go to the list
+                unsigned hh = hit, idx = incl - mine;
+                while (hh) {
+                    const int j = __ffs((int)hh) - 1;
+                    hh &= hh - 1;
+                    if (idx >= n0 && idx < n0 + 64) {
+                        const unsigned e = (idx - n0) * 3;
+                        hb[e] = sel_words<G>(rr, j); hb[e + 1] = sel_words<G>(cc, j);
+                        hb[e + 2] = (int)((((unsigned)(ga + (j >> 2) * stride)) << 2) + (unsigned)(j & 3));   // (contact index: < 2^32)
+                    }
+                    idx += 1;
                 }
             }
-            if (dry) { n_rel += __popc(rel); continue; }
-            if (cidx_valid) {
-                // device-scope (write-through) stores: the entry must reach the reader -- possibly a block of k_tm on
-                // another XCD -- without an L2 write-back fence, which costs this kernel several microseconds
-                unsigned long long* qw = reinterpret_cast<unsigned long long*>(queue + slot);
-                slot += 1;
-                // (entries read by k_tm's finishing block while this kernel may still run are written through, 8 bytes at a
-                // time; entries for the NEXT kernel on the stream (k_fin / k_strict) as two plain 16-byte stores -- four 8-byte
-                // write-through stores per entry made a scan that queues 2 M contacts run at 8 % of the HBM rate)
-                const unsigned long long w0 = (unsigned long long)(unsigned)cidx | ((unsigned long long)rel << 32);
-                const unsigned long long w1 = (unsigned long long)q_ci | ((unsigned long long)q_cj << 32);
-                const unsigned long long w2 = (unsigned long long)(unsigned)q_fx | ((unsigned long long)(unsigned)q_fy << 32);
-                const unsigned long long w3 = (unsigned long long)(unsigned)cnt_w | ((unsigned long long)(unsigned)q_slots << 32);
-                if (sa.wt_queue) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const unsigned n = n0 + (unsigned)lane;
+            unsigned cidx = 0;
+            int q_slots = 0, fx = 0, fy = 0;
+            if (n < total) {
+                const int rj = hb[3 * lane], cj_ = hb[3 * lane + 1];
+                cidx = (unsigned)hb[3 * lane + 2];
+                if (SINGLE_SUB) { fx = rj; fy = cj_; }
+                else { const int a = sub2bin[rj], b = sub2bin[cj_]; fx = a >> 2; fy = b >> 2; q_slots = (a & 3) | ((b & 3) << 2); }
+            }
+            // (all lanes: the reservation's result)
+            const unsigned slot_base = (unsigned)__shfl(base, 63, 64);
+            if (n < total && !dry) {
+                // 16 bytes per contact, tagged with the step's sequence number in both words (QRaw): no record gathers here, and nobody
+                // waits for these stores -- a consumer that runs next to this kernel checks the tags, one behind it needs nothing
+                unsigned long long* qw = reinterpret_cast<unsigned long long*>(queue + (slot_base + n));
+                const unsigned long long w0 = (unsigned long long)cidx | ((unsigned long long)sa.seq32 << 32);
+                const unsigned long long w1 = (unsigned long long)(unsigned)fx | ((unsigned long long)(unsigned)fy << 20) | ((unsigned long long)(unsigned)q_slots << 40)
+                                              | ((unsigned long long)(sa.seq32 & 0xfffffu) << 44);
+                if (sa.wt_queue) {   // device-scope (write-through) stores: the reader may be a block of k_tm on another XCD
                     __hip_atomic_store(qw + 0, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (rel) {
-                        __hip_atomic_store(qw + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(qw + 2, w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(qw + 3, w3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                } else if (rel) {
+                    __hip_atomic_store(qw + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
                     typedef unsigned long long v2u __attribute__((ext_vector_type(2)));
                     v2u a; a.x = w0; a.y = w1;
-                    v2u b; b.x = w2; b.y = w3;
-                    reinterpret_cast<v2u*>(qw)[0] = a;
-                    reinterpret_cast<v2u*>(qw)[1] = b;
-                } else qw[0] = w0;
-                n_rel += __popc(rel);
+                    *reinterpret_cast<v2u*>(qw) = a;
+                }
             }
+            const unsigned rel = n < total ? 1u : 0u;   // (statistics: doubly-affected contacts)
+            n_rel += __popc(rel);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+#ifdef GRAAL_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the stamp includes this wave's queue stores)
+#endif
+        HITSTAT_END();
     };
     // ---- main loop: G loads in flight, first test, (rarely) the rest.  (A two-buffer software pipeline of this loop was
     // measured in tools/scan_micro.hip: 15.4 -> 14.6 us per isolated launch with 2 x 2 groups through raw buffer loads, slower
@@ -2494,15 +2540,12 @@ __global__ __launch_bounds__(1024, (G <= 4 ? 8 : 4)) void k_scan(ScanArgs sa, in
     // atomic per WAVE on that one word was ~80 us of a late-stage scan)
     if (lane == 0 && n_rel && !dry) atomicAdd(&s_nrel, n_rel);
     if (dry == 0) {
-        // completion flag for k_tm's finishing block: one word (on its own cache line) per block holding the step's
-        // sequence number -- a shared counter would serialise 512 device-scope atomics at the memory side.  No block
-        // barrier here (a trailing __syncthreads measurably costs this kernel 5 us): each wave waits for its own
-        // (write-through) queue stores -- explicitly, below -- and counts itself in LDS; the last wave of the block signals.
-        // The queue entries are agent-scope (write-through) stores: "released" means this wave's stores have been
-        // acknowledged, i.e. its vector-memory counter is back to zero (gfx9 counts stores in vmcnt) -- an agent-scope release
-        // fence would add an L2 write-back, which costs the kernel several microseconds and which write-through stores do not
-        // need.  The workgroup fence only orders the LDS count behind it for the compiler.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // completion signal for k_tm's finishing block.  No block barrier here (a trailing __syncthreads measurably costs this
+        // kernel 5 us): each wave counts itself in LDS, the last wave of the block signals.  The slot reservations (atomics with
+        // return) have completed by then, so the queue's length is final when the last block has signalled; the entries themselves
+        // are agent-scope (write-through) stores that may still be in flight.
+        // (nobody waits for the queue stores any more: a consumer that may run before they have landed validates the sequence
+        // tag of every entry, QRaw)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         int last = 0;
         if (lane == 0) last = (atomicAdd(&s_waves_done, 1) == (int)(blockDim.x >> 6) - 1);
@@ -2534,7 +2577,9 @@ struct FinArgs { // first-needed pointers by value (see ScanArgs)
     long long* tm_done;
     const int* step_hdr;
     unsigned long long* counters;
-    const QEntry* queue;
+    const QRaw* queue;
+    const int* cnt;                // the contacts' counts (a queue entry holds the contact's index)
+    int multi;                     // bins have several sub-fragments
     const NbTables* tabs;
     const Geo* geo;
     const Stat* stat;
@@ -2549,13 +2594,13 @@ struct FinArgs { // first-needed pointers by value (see ScanArgs)
     unsigned long long* wq;        // work-queue counters: N_WQ for the mass units, N_WQ for the contact batches, WQ_STRIDE words apart (nullptr: static deal)
 };
 
-__global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinArgs fa, int K, int rank, int world,
+__global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinArgs fa, int fA, int K, int rank, int world,
                                               long long* __restrict__ d_q_out, volatile long long* host_res, long long seq)
 {
     const NbTables* __restrict__ tabs = fa.tabs;
     const Geo* __restrict__ geo = fa.geo;
     const Stat* __restrict__ stat = fa.stat;
-    const QEntry* __restrict__ queue = fa.queue;
+    const QRaw* __restrict__ queue = fa.queue;
     long long* __restrict__ out = fa.acc;
     unsigned long long* __restrict__ counters = fa.counters;
     const int lane = threadIdx.x & 63;
@@ -2611,7 +2656,11 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
             s_wt[threadIdx.x] = tabs[threadIdx.x].w_total;
         }
     }
+    __shared__ PieceKey s_qkeys[MAXK];   // what expands the queue's entries (q_fetch + q_codes)
+    __shared__ unsigned s_qlive;
+    if (threadIdx.x == 0) s_qlive = 0;
     __syncthreads();
+    if ((int)threadIdx.x < K && s_ok) { s_qkeys[threadIdx.x] = tabs[threadIdx.x].key; if (tabs[threadIdx.x].fB != fA) atomicOr(&s_qlive, 1u << threadIdx.x); }
     load_cw();
     STAMP(17, blockIdx.x == 0 && threadIdx.x == 0);
     const int* __restrict__ perm = A->perm;
@@ -2800,7 +2849,9 @@ __global__ __launch_bounds__(256) void k_fin(const DevArgs* __restrict__ A, FinA
         // ---- queued contacts ----
         PriceArgs pa;
         pa.pr_lds = nullptr; pa.pt_lds = nullptr; pa.nt_lds = nullptr;
-        pa.queue = queue; pa.tabs = tabs; pa.geo = geo; pa.stat = stat; pa.lcontbp = lcontbp; pa.out = s_accb; pa.nf = counters + NF_OFF; pa.nfpb = nfpb; pa.par = par;
+        pa.q.queue = queue; pa.q.geo2 = reinterpret_cast<const int2*>(geo); pa.q.cnt = fa.cnt; pa.q.keys = s_qkeys; pa.q.live = s_qlive; pa.q.K = K;
+        pa.q.seq = (unsigned)seq; pa.q.concurrent = 0; pa.q.multi = fa.multi; pa.err = counters + 6;
+        pa.tabs = tabs; pa.geo = geo; pa.stat = stat; pa.lcontbp = lcontbp; pa.out = s_accb; pa.nf = counters + NF_OFF; pa.nfpb = nfpb; pa.par = par;
         // (batches of queued contacts continue the round robin where this rank's mass units ended)
         const int mass_slots = (int)(((long long)total_units - rank + world - 1) / world % n_waves);
         const int B = contact_batch_size(nq_total, n_waves);
@@ -2922,8 +2973,10 @@ __global__ __launch_bounds__(256) void k_strict_dense(FinArgs fa, StrictArgs sa,
     __shared__ unsigned s_ident[MAXK][N_OPS];      // bit p: candidate op leaves piece p exactly where it is
     __shared__ int s_m[MAXK], s_lenA[MAXK], s_baseA[MAXK], s_baseB[MAXK], s_ubase[MAXK + 1];
     __shared__ int s_ok;
+    __shared__ PieceKey s_qkeys[MAXK];
+    __shared__ unsigned s_qlive;
     for (int i = threadIdx.x; i < MAXK * N_OPS; i += blockDim.x) s_accb[i] = 0;
-    if (threadIdx.x == 0) s_ok = 1;
+    if (threadIdx.x == 0) { s_ok = 1; s_qlive = 0; }
     __syncthreads();
     if ((int)threadIdx.x < K) { // the tables come from k_tm on another stream (bounded spin, as in k_fin)
         bool ok = false;
@@ -2943,6 +2996,8 @@ __global__ __launch_bounds__(256) void k_strict_dense(FinArgs fa, StrictArgs sa,
         }
         if ((int)threadIdx.x < K) {
             const int k = threadIdx.x, fB = tabs[k].fB;
+            s_qkeys[k] = tabs[k].key;
+            if (fB != fA) atomicOr(&s_qlive, 1u << k);
             const Geo gA = geo[fA], gB = geo[fB];
             const int lenA = sa.link[fA].l_cont, lenB = (fB == fA || gB.id_c == gA.id_c) ? 0 : sa.link[fB].l_cont;
             s_lenA[k] = lenA; s_baseA[k] = sa.cbase[fA]; s_baseB[k] = sa.cbase[fB];
@@ -3048,15 +3103,20 @@ __global__ __launch_bounds__(256) void k_strict_dense(FinArgs fa, StrictArgs sa,
         // ---- (2) the queued contacts (k_scan queued every contact with both ends in some neighbour's affected set): 16 lanes per
         // contact, lane = candidate; every candidate of every such neighbour is priced again
         {
+            QSrc qs;
+            qs.queue = fa.queue; qs.geo2 = reinterpret_cast<const int2*>(geo); qs.cnt = fa.cnt; qs.keys = s_qkeys; qs.live = s_qlive; qs.K = K;
+            qs.seq = (unsigned)seq; qs.concurrent = 0; qs.multi = fa.multi;
             const int op = lane & 15;
             for (unsigned long long e0 = (unsigned long long)(n_waves - 1 - wave) * 4; e0 < nq_total; e0 += (unsigned long long)n_waves * 4) {
                 const unsigned long long e = e0 + (lane >> 4);
                 if (e >= nq_total || op >= N_OPS) continue;
-                const QEntry qe = fa.queue[e];
-                if (qe.rel == 0) continue;
+                QEntry qe = q_fetch(qs, e, counters + 6);
+                if (qe.fx < 0) continue;
                 const int fx = qe.fx, fy = qe.fy, slx = qe.slots & 3, sly = (qe.slots >> 2) & 3;
                 const Geo gx = geo[fx], gy = geo[fy];
                 const Stat sx = stat[fx], sy = stat[fy];
+                q_codes(qs, qe, gx, gy, qs.cnt[qe.idx]);
+                if (qe.rel == 0) continue;
                 const End X0 = end_old(gx, ((gx.flags >> 1) & 1) ? sa.lcontbp[fx] : 0), Y0 = end_old(gy, ((gy.flags >> 1) & 1) ? sa.lcontbp[fy] : 0);
                 const float ex_old = ex_pair_ref(X0, sx, slx, fx, Y0, sy, sly, fy, sa.nfpb, sa.par, sa.quirk);
                 const double ln_old = log((double)ex_old), ob = (double)__int_as_float(qe.cnt);
@@ -3283,7 +3343,15 @@ __global__ __launch_bounds__(256) void k_strict(FinArgs fa, StrictArgs sa, int f
         const int k = i / (N_PAIRS * N_OPS), r = i - k * (N_PAIRS * N_OPS);
         s_crep[i] = tabs[k].crep[r / N_OPS][r % N_OPS]; s_cmask[i] = tabs[k].cmask[r / N_OPS][r % N_OPS];
     }
-    if ((int)threadIdx.x < K) s_sg[threadIdx.x] = set_geo(tabs[threadIdx.x], geo, sa.link, sa.cbase, fA);
+    __shared__ PieceKey s_qkeys[MAXK];   // what expands the queue's entries (q_fetch + q_codes)
+    __shared__ unsigned s_qlive;
+    if (threadIdx.x == 255) s_qlive = 0;
+    __syncthreads();
+    if ((int)threadIdx.x < K) {
+        s_sg[threadIdx.x] = set_geo(tabs[threadIdx.x], geo, sa.link, sa.cbase, fA);
+        s_qkeys[threadIdx.x] = tabs[threadIdx.x].key;
+        if (tabs[threadIdx.x].fB != fA) atomicOr(&s_qlive, 1u << threadIdx.x);
+    }
     __syncthreads();
     const unsigned long long nq_total = counters[2];          // written by k_scan, an earlier kernel on the stream
     const unsigned long long n_units = min(*list_n, sa.list_cap); // written by k_strict_cull, the previous kernel on the stream
@@ -3404,14 +3472,19 @@ __global__ __launch_bounds__(256) void k_strict(FinArgs fa, StrictArgs sa, int f
         WAVE_LDS_SYNC();   // (the next unit stages its tile over this one)
     }
     // ---- (2) the queued contacts: lane = contact, one evaluation per class
+    QSrc qs;
+    qs.queue = fa.queue; qs.geo2 = reinterpret_cast<const int2*>(geo); qs.cnt = fa.cnt; qs.keys = s_qkeys; qs.live = s_qlive; qs.K = K;
+    qs.seq = (unsigned)seq; qs.concurrent = 0; qs.multi = fa.multi;
     for (unsigned long long b0 = (unsigned long long)(n_waves - 1 - wave) * 64ull; b0 < nq_total; b0 += (unsigned long long)n_waves * 64ull) {
         const unsigned long long e = b0 + (unsigned long long)lane;
         if (e >= nq_total) continue;
-        const QEntry qe = fa.queue[e];
-        if (qe.rel == 0) continue;
+        QEntry qe = q_fetch(qs, e, counters + 6);
+        if (qe.fx < 0) continue;
         const int fx = qe.fx, fy = qe.fy, slx = qe.slots & 3, sly = (qe.slots >> 2) & 3;
         const Geo gx = geo[fx], gy = geo[fy];
         const Stat sx = stat[fx], sy = stat[fy];
+        q_codes(qs, qe, gx, gy, qs.cnt[qe.idx]);
+        if (qe.rel == 0) continue;
         const End X0 = end_old(gx, ((gx.flags >> 1) & 1) ? sa.lcontbp[fx] : 0), Y0 = end_old(gy, ((gy.flags >> 1) & 1) ? sa.lcontbp[fy] : 0);
         const float ex_old = ex_pair_ref(X0, sx, slx, fx, Y0, sy, sly, fy, nfpb, par, quirk);
         const double ln_old = log((double)ex_old), ob = (double)__int_as_float(qe.cnt);
@@ -3734,8 +3807,9 @@ struct Ctx {
     int uniform_accu = 0;
     int* sub2bin = nullptr;
     int *row = nullptr, *col = nullptr, *cnt = nullptr;
-    QEntry* queue = nullptr;
+    QRaw* queue = nullptr;
     int last_fA = 0, last_K = 0, last_max_id = 0; // proposal of the last evaluation (timing replays of the scan)
+    int last_fA_launch = 0;       // fA of the evaluation being launched (k_fin may be launched later, from eval_sync)
     int last_fB[MAXK] = {};
     int max_lcont = 0;            // longest contig at the last graal_begin_step (sizes k_fin's grid)
     int lcont_bound = 0;          // upper bound of the longest contig NOW (graal_step scores before it has the statistics)
@@ -4042,6 +4116,7 @@ int launch_fin(Ctx* h, int K, int rank, int world, long long* d_q_out, bool publ
     static const int fin_skip = getenv("GRAAL_FIN_SKIP") ? atoi(getenv("GRAAL_FIN_SKIP")) : 0;   // (diagnostics: wrong sums)
     FinArgs fa;
     fa.tm_done = h->tm_done; fa.step_hdr = h->step_hdr; fa.counters = (unsigned long long*)(h->d_scalars + 10); fa.queue = h->queue;
+    fa.cnt = h->cnt; fa.multi = h->single_sub ? 0 : 1;
     fa.tabs = h->tabs; fa.geo = h->geo; fa.stat = h->stat_frag; fa.acc = h->d_acc; fa.sync = h->d_sync;
     static const int fin_seg = getenv("GRAAL_FIN_SEG") ? atoi(getenv("GRAAL_FIN_SEG")) : 0;
     fa.ln_tab = h->d_ln_tab; fa.lut_n = h->d_ln_tab ? h->ln_lut_n : 0; fa.skip = fin_skip; fa.seg = fin_seg;
@@ -4050,7 +4125,7 @@ int launch_fin(Ctx* h, int K, int rank, int world, long long* d_q_out, bool publ
     fa.upw = fin_upw;
     static const bool fin_static = getenv("GRAAL_FIN_STATIC") != nullptr;   // (units and contact batches dealt statically)
     fa.wq = fin_static ? nullptr : h->d_wq;
-    k_fin<<<fin_blocks, 256, fin_dyn_lds(K), st>>>(h->d_args + h->cur, fa, K, rank, world, d_q_out, publish ? h->res_dev : nullptr, h->seq);
+    k_fin<<<fin_blocks, 256, fin_dyn_lds(K), st>>>(h->d_args + h->cur, fa, h->last_fA_launch, K, rank, world, d_q_out, publish ? h->res_dev : nullptr, h->seq);
     CK(hipGetLastError());
     return GRAAL_OK;
 }
@@ -4069,6 +4144,7 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
     CK(hipStreamWaitEvent(st, h->ev_tm, 0));   // the tables are complete before either kernel starts: nobody spins for them
     FinArgs fa;
     fa.tm_done = h->tm_done; fa.step_hdr = h->step_hdr; fa.counters = (unsigned long long*)(h->d_scalars + 10); fa.queue = h->queue;
+    fa.cnt = h->cnt; fa.multi = h->single_sub ? 0 : 1;
     fa.tabs = h->tabs; fa.geo = h->geo; fa.stat = h->stat_frag; fa.acc = h->d_acc; fa.sync = h->d_sync;
     fa.ln_tab = nullptr; fa.lut_n = 0; fa.skip = 0; fa.seg = 0; fa.norm_u = -1.0f; fa.upw = 4; fa.wq = nullptr;
     StrictArgs sx;
@@ -4452,7 +4528,7 @@ static int upload_contacts_impl(graal_ctx* h, const int32_t* row, const int32_t*
     const size_t bytes = sizeof(int) * (size_t)(nnz + 8); // +8: int4 tail reads stay in bounds
     CK(hipMalloc(&h->row, bytes)); CK(hipMalloc(&h->col, bytes)); CK(hipMalloc(&h->cnt, bytes));
     CK(hipMemset(h->row, 0, bytes)); CK(hipMemset(h->col, 0, bytes));
-    CK(hipMalloc(&h->queue, sizeof(QEntry) * (size_t)(nnz + 8))); // every contact may be relevant in the worst case
+    CK(hipMalloc(&h->queue, sizeof(QRaw) * (size_t)(nnz + 8))); // every contact may have both ends affected in the worst case
     if (nnz) {
         CK(hipMemcpy(h->row, row, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
         CK(hipMemcpy(h->col, col, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
@@ -4820,6 +4896,7 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     hipStream_t st = stream_v ? (hipStream_t)stream_v : h->stream;
     const DevArgs* A = h->d_args + h->cur;
     h->seq += 1;
+    h->last_fA_launch = fA;
     // (1) tables + small mass work on the auxiliary stream: overlaps the scan.  A previous asynchronous evaluation must
     // have finished with the tables first (the synchronous path has waited for its results already).  In the synchronous
     // single-rank path (h->publish) its last block also finishes the step when the work is small.
@@ -4850,7 +4927,7 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     const bool late_stage = h->max_lcont > 128 && (long long)h->n_contigs * 64 < (long long)h->n;
     ta.host_res = (h->publish && (world == 1 || h->x_host) && !no_finisher && h->finisher_ok && !h->has_rep && !late_stage && !(strict && strict_dense_cfg())) ? h->res_dev : nullptr;
     ta.wait_ticks = fin_wait_ticks(h);
-    ta.counters = (unsigned long long*)(h->d_scalars + 10); ta.queue = h->queue; ta.stat = h->stat_frag;
+    ta.counters = (unsigned long long*)(h->d_scalars + 10); ta.queue = h->queue; ta.cnt = h->cnt; ta.multi = h->single_sub ? 0 : 1; ta.stat = h->stat_frag;
     ta.lcontbp = h->soa[h->cur].p[F_LCONTBP]; ta.acc = h->d_acc; ta.nfpb = h->nfpb; ta.par = h->par;
     ta.relabel_flag = (const unsigned long long*)(h->d_scalars + RELABEL_FLAG);
     ta.relabel_seq = spin ? ++h->relabel_flag_seq : 0ull;
@@ -5240,6 +5317,20 @@ int graal_debug_stamps(graal_ctx* h, uint64_t out[32])
     CK(hipSetDevice(h->device));
     CK(hipDeviceSynchronize());
     CK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), 32 * sizeof(unsigned long long)));
+    return GRAAL_OK;
+#else
+    return fail(h, GRAAL_E_UNSUPPORTED, "library built without GRAAL_STAMPS");
+#endif
+}
+
+int graal_debug_hitstat(graal_ctx* h, uint64_t out[8], int reset)
+{
+    if (!h || !out) return GRAAL_E_ARG;
+#ifdef GRAAL_STAMPS
+    CK(hipSetDevice(h->device));
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hitstat), 8 * sizeof(unsigned long long)));
+    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_hitstat), z, sizeof z)); }
     return GRAAL_OK;
 #else
     return fail(h, GRAAL_E_UNSUPPORTED, "library built without GRAAL_STAMPS");
