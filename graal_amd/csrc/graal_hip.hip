@@ -1356,6 +1356,11 @@ __device__ int tables_block(const Geo* __restrict__ geo, const Link* __restrict_
         }
         __syncthreads();
         for (int e = t; e < N_PAIRS * N_OPS; e += blockDim.x) T.cmask[e / N_OPS][e % N_OPS] = (unsigned short)s_cmask[e / N_OPS][e % N_OPS];
+        // Reference arithmetic prices classes of inputs, not changed relations: the relation masks, the deduplicated task list and the
+        // work lists below serve the exact mode's kernels only (6 of this block's 17 us next to the scan: tools/stamps_step.py)
+        if (t == 0) { T.n_tasks = 0; T.n_items = 0; T.intra_any = 0; T.w_total = 0; step_hdr[k] = 0; s_pp[0] = 0; }
+        __syncthreads();
+        return 0;
     }
     // relations: one thread per (op, p <= q)
     for (int e = t; e < N_OPS * NPAIR; e += blockDim.x) {
