@@ -17,17 +17,22 @@ the ranks of the node and every host adds them up; the same region is then timed
 buffer instead, reported as `exchange_alt`).  Inputs are resident in HBM; proposals are drawn beforehand.  With N GPUs the SAME
 contact list is sharded N ways (strong scaling).
 
-Extra fields: `full_mcmc_step_ms` (scoring + sampling + commit + relabel + statistics), `full_eval_ms` (one full likelihood
-evaluation: what a nuisance-parameter step adds to every MCMC step), `full_mcmc_step_sample_param_ms`, `late_stage` (the scoring
-phase on the same map with its 7 original contigs -- thousands of mass work items and millions of queued contacts per step,
-sharded over the ranks), `exchange_alt` (N > 1).
+`value` is measured in REFERENCE ARITHMETIC (`config.reference_arithmetic` = "strict": every pixel of contig(A) u contig(B) re-priced
+from float32 kb coordinates like sub_compute_likelihood, kernels3.cu:3259-3718 -- the sampler's default, whose traces are the
+reference's); the same proposals are then timed in the exact arithmetic (`other_arithmetic`).  `--arithmetic exact` swaps the two.
 
-Output: one JSON line on rank 0 (contract in the task statement) with `roofline` (fused scan kernel: algorithmic bytes
-= 4 B x contacts (row words) + n/8 B (bitmap) + 64 B x queued contacts per launch; duration = HIP event pairs around the
-launches of the timed region (every 8th step) and of an untimed repeat of the same steps with a pair on every step; plus
-`roofline.hbm_control`: the same kernel, same layout, same proposals over a list whose row array (480 MB) cannot stay in the
-256 MiB Infinity Cache, so HBM-vs-cache is settled by measurement) and `cpu_baseline` (numpy re-score of the same sparse
-likelihood on the host, N = 1 only).
+Extra fields: `value_1000` (SURVEY 8d's 1,000-step region), `full_mcmc_step_ms` (graal_step: relabel + proposal + scoring + sampling +
+commit + statistics), `full_eval_ms` (one full likelihood evaluation: what a nuisance-parameter step adds to every MCMC step),
+`full_mcmc_step_sample_param_ms`, `late_stage` (the same map with its 7 original contigs -- millions of queued contacts and thousands
+of work units per step, sharded over the ranks -- in both arithmetics, with its own full-step / full-evaluation figures),
+`exchange_alt` and `distributed` (N > 1).
+
+Output: one JSON line on rank 0 (contract in the task statement) with `roofline` (fused scan kernel k_scan: algorithmic bytes
+= 4 B x contacts (row words) + n/8 B (bitmap) + 16 B x queued contacts per launch; duration = MEDIAN of HIP event pairs around the
+launches of the timed region (every 8th step) and of an untimed repeat of the same steps with a pair on every step; plus the flat
+`hbm_control_*` fields: the same kernel, same layout, same proposals over a list whose row array (480 MB) cannot stay in the
+256 MiB Infinity Cache, so HBM-vs-cache is settled by measurement), `cpu_baseline` (numpy re-score of the same sparse likelihood on
+the host) and `cpu_baseline_dense` (the C restatement of the reference's dense sub_compute_likelihood on the C2 stand-in), N = 1 only.
 """
 import argparse
 import json
@@ -163,7 +168,7 @@ def hbm_control(P, smp, props, max_id, n, repeat):
         c = e.last_counters()
         replay_ms = e.time_scan(len(use[-1][1]), reps=20)
         nnz = int(e.nnz)
-        bytes_per_launch = 4.0 * nnz + n / 8.0 + 64.0 * float(c[2])
+        bytes_per_launch = 4.0 * nnz + n / 8.0 + 16.0 * float(c[2])
         scan_s = float(np.mean(ms)) * 1e-3
         return {"contacts": nnz, "row_array_MB": 4.0 * nnz / 1e6, "how": "every contact of the C5 list listed %d times" % repeat,
                 "bytes_per_launch": bytes_per_launch, "avg_launch_ms": scan_s * 1e3, "launches_timed": int(len(ms)),
@@ -474,9 +479,9 @@ def main():
     if rank == 0:
         nnz_local = smp.engine.nnz
         # what the streaming pass must read: the row word of every contact (4 B), the affected-fragment bitmap
-        # (n/8 B) and, for the queued contacts only, col + count + two code words (SURVEY 8d priced a naive pass
+        # (n/8 B) and, for the queued contacts only, the 16-byte queue entry (SURVEY 8d priced a naive pass
         # at 12 B per contact; col words of affected rows that fail the second test are not counted -> conservative)
-        bytes_per_launch = 4.0 * nnz_local + n / 8.0 + 64.0 * float(counters[2])
+        bytes_per_launch = 4.0 * nnz_local + n / 8.0 + 16.0 * float(counters[2])
         # kernel duration: HIP events on the stream the kernel runs on.  (a) an event pair around the launches of the timed
         # region: the duration of a launch as the sampler experiences it -- block launch ramp, the prologue that builds the
         # affected-fragment bitmap, the stream, the drain.  This prices the roofline; rocprofv3's kernel-trace average
