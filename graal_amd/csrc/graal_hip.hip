@@ -4534,6 +4534,8 @@ static int upload_contacts_impl(graal_ctx* h, const int32_t* row, const int32_t*
     CK(hipMalloc(&h->row, bytes)); CK(hipMalloc(&h->col, bytes)); CK(hipMalloc(&h->cnt, bytes));
     CK(hipMemset(h->row, 0, bytes)); CK(hipMemset(h->col, 0, bytes));
     CK(hipMalloc(&h->queue, sizeof(QRaw) * (size_t)(nnz + 8))); // every contact may have both ends affected in the worst case
+    // (recycled device memory may hold another engine's entries, tags and all: a consumer that validates tags must never meet them)
+    CK(hipMemset(h->queue, 0, sizeof(QRaw) * (size_t)(nnz + 8)));
     if (nnz) {
         CK(hipMemcpy(h->row, row, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
         CK(hipMemcpy(h->col, col, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
