@@ -2235,6 +2235,9 @@ struct ScanArgs { // by value: kernel-argument pointers are known to be GLOBAL (
     int n_done;
     long long nnz;
     int bitmap_words;
+    unsigned bm_wmask;            // word index mask of the affected bitmap: all ones when every id has its own bit; 2^b - 1 when the ids are
+                                  // FOLDED onto 2^b words (more ids than LDS bits): a folded bit may be set by another id, the contact is then
+                                  // queued for nothing and the consumers' own membership test (q_codes: piece 0) drops it
     int strict;                   // GRAAL_MODE_STRICT: queue every contact with both ends in a neighbour's affected set
     int wt_queue;                 // queue entries are read by k_tm's finishing block (concurrent kernel): write-through stores
     unsigned token;               // unique per launch: "wave 1's keys of THIS launch are in LDS"
@@ -2312,13 +2315,18 @@ __global__ __launch_bounds__(1024, (G <= 4 ? 8 : 4)) void k_scan(ScanArgs sa, in
         for (int i = 0; i < G; i++) f[i] = ldg(g0 + i * stride);
     }
 #define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#ifdef GRAAL_EXP_NOFOLD   // (A/B build, tools/ab.sh: what the fold's one AND per id costs)
+    const unsigned wm = 0xffffffffu;
+#else
+    const unsigned wm = sa.bm_wmask;
+#endif
     auto set_bits = [&](int fr) {   // mark fragment fr: its id, or the ids of its sub-fragments
-        if (SINGLE_SUB) atomicOr(&s_bm[fr >> 5], 1u << (fr & 31));
+        if (SINGLE_SUB) atomicOr(&s_bm[((unsigned)fr >> 5) & wm], 1u << (fr & 31));
         else {
             const int4 ids = reinterpret_cast<const int4*>(sa.sub_ids)[fr];
-            atomicOr(&s_bm[ids.x >> 5], 1u << (ids.x & 31));
-            if (ids.w > 1) atomicOr(&s_bm[ids.y >> 5], 1u << (ids.y & 31));
-            if (ids.w > 2) atomicOr(&s_bm[ids.z >> 5], 1u << (ids.z & 31));
+            atomicOr(&s_bm[((unsigned)ids.x >> 5) & wm], 1u << (ids.x & 31));
+            if (ids.w > 1) atomicOr(&s_bm[((unsigned)ids.y >> 5) & wm], 1u << (ids.y & 31));
+            if (ids.w > 2) atomicOr(&s_bm[((unsigned)ids.z >> 5) & wm], 1u << (ids.z & 31));
         }
     };
     if (t < 64) {
@@ -2412,8 +2420,8 @@ __global__ __launch_bounds__(1024, (G <= 4 ? 8 : 4)) void k_scan(ScanArgs sa, in
 #pragma unroll
         for (int i = 0; i < G; i++) {
             const int4 q = rr[i];
-            hit |= (((s_bm[q.x >> 5] >> (q.x & 31)) & 1u) | (((s_bm[q.y >> 5] >> (q.y & 31)) & 1u) << 1)
-                    | (((s_bm[q.z >> 5] >> (q.z & 31)) & 1u) << 2) | (((s_bm[q.w >> 5] >> (q.w & 31)) & 1u) << 3)) << (4 * i);
+            hit |= (((s_bm[((unsigned)q.x >> 5) & wm] >> (q.x & 31)) & 1u) | (((s_bm[((unsigned)q.y >> 5) & wm] >> (q.y & 31)) & 1u) << 1)
+                    | (((s_bm[((unsigned)q.z >> 5) & wm] >> (q.z & 31)) & 1u) << 2) | (((s_bm[((unsigned)q.w >> 5) & wm] >> (q.w & 31)) & 1u) << 3)) << (4 * i);
         }
         return hit & vmask;
     };
@@ -2432,8 +2440,8 @@ __global__ __launch_bounds__(1024, (G <= 4 ? 8 : 4)) void k_scan(ScanArgs sa, in
 #pragma unroll
             for (int i = 0; i < G; i++) {
                 const int4 q = cc[i];
-                hit2 |= (((s_bm[q.x >> 5] >> (q.x & 31)) & 1u) | (((s_bm[q.y >> 5] >> (q.y & 31)) & 1u) << 1)
-                         | (((s_bm[q.z >> 5] >> (q.z & 31)) & 1u) << 2) | (((s_bm[q.w >> 5] >> (q.w & 31)) & 1u) << 3)) << (4 * i);
+                hit2 |= (((s_bm[((unsigned)q.x >> 5) & wm] >> (q.x & 31)) & 1u) | (((s_bm[((unsigned)q.y >> 5) & wm] >> (q.y & 31)) & 1u) << 1)
+                         | (((s_bm[((unsigned)q.z >> 5) & wm] >> (q.z & 31)) & 1u) << 2) | (((s_bm[((unsigned)q.w >> 5) & wm] >> (q.w & 31)) & 1u) << 3)) << (4 * i);
             }
             hit &= hit2;
         }
@@ -3981,7 +3989,7 @@ constexpr int MAX_SCAN_BLOCKS = 4096;
 constexpr int FULL_BAD = 27; // d_scalars[FULL_BAD]: a term of the last full evaluation was not finite / out of range
 constexpr int SLIST_N = 28;  // d_scalars[SLIST_N]: length of k_strict's unit list (zero at rest)
 constexpr int RELABEL_FLAG = 30; // d_scalars[RELABEL_FLAG]: sequence number of the last relabel k_scan has announced as complete (k_tm spins on it)
-constexpr int SCAN_LDS_MAX = 48 * 1024; // affected bitmap of k_scan: 1 bit per contact-list id -> <= 393,216 ids
+constexpr int SCAN_LDS_MAX = 48 * 1024; // affected bitmap of k_scan: 1 bit per contact-list id up to 393,216 ids, folded beyond (launch_scan)
 
 // threads per block of the streaming pass: 1024 (two blocks per CU) for the lists it is built for; a list of a few hundred
 // thousand contacts (a yeast-sized genome at 3 sub-fragments per bin) would fill only a handful of such blocks, each marking
@@ -4030,12 +4038,21 @@ int scan_grid(const Ctx* h)
 int launch_scan(Ctx* h, int fA, const Neigh& nb, int K, int max_id, int dry, hipStream_t st, bool finisher_reads = true)
 {
     const int nbk = scan_grid(h), scan_threads = scan_threads_cfg(h);
-    const size_t shm = (size_t)((h->n_sub_total + 31) / 32 + 2) * 4;
-    if (shm > (size_t)SCAN_LDS_MAX) return fail(h, GRAAL_E_UNSUPPORTED, "more than 393,216 sub-fragments: the affected bitmap does not fit the scan's LDS budget");
+    // one bit per contact-list id while they fit the LDS budget (393,216 ids); beyond that the ids are folded onto 2^18 bits
+    // (ScanArgs::bm_wmask): with a' affected ids a fraction a' / 2^18 of the rows takes the second test for nothing and
+    // (a' / 2^18)^2 of the contacts is queued for nothing -- dropped by the consumers' membership test, results unchanged.
+    // GRAAL_SCAN_FOLD_BITS = b folds onto 2^b bits whatever the size (tests: b = 10 makes every other row a false positive)
+    static const int fold_bits = getenv("GRAAL_SCAN_FOLD_BITS") ? std::min(18, std::max(5, atoi(getenv("GRAAL_SCAN_FOLD_BITS")))) : 0;
+    size_t shm = (size_t)((h->n_sub_total + 31) / 32 + 2) * 4;
+    unsigned wmask = 0xffffffffu;
+    if (shm > (size_t)SCAN_LDS_MAX || fold_bits) {
+        const int b = fold_bits ? fold_bits : 18;
+        if ((size_t)1 << b < (size_t)h->n_sub_total) { wmask = (1u << (b - 5)) - 1u; shm = ((size_t)1 << (b - 5)) * 4; }
+    }
     ScanArgs sa;
     sa.geo = h->geo; sa.link = h->link; sa.mates = h->mates; sa.cnt = h->cnt;
     sa.cbase = h->cbase; sa.perm = h->perm; sa.sub_ids = h->d_sub_ids;
-    sa.row4 = reinterpret_cast<const int4*>(h->row); sa.nnz = h->nnz; sa.bitmap_words = (int)(shm / 4);
+    sa.row4 = reinterpret_cast<const int4*>(h->row); sa.nnz = h->nnz; sa.bitmap_words = (int)(shm / 4); sa.bm_wmask = wmask;
     sa.col4 = reinterpret_cast<const int4*>(h->col); sa.geo2 = reinterpret_cast<const int2*>(h->geo); sa.sub2bin = h->sub2bin;
     sa.queue = h->queue; sa.counters = (unsigned long long*)(h->d_scalars + 10);
     sa.flags = h->d_flags; sa.seq32 = (unsigned)h->seq;

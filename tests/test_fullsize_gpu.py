@@ -322,3 +322,39 @@ def test_c4_shape_mid_run_properties():
         assert abs(d[k, op] - (after - before)) / abs(before) < 1e-8, (fA, nb[k], op, d[k, op], after - before)
     assert needed_fin >= 10                                       # the regime this test is about did occur
     smp.free_gpu()
+
+
+# More contact-list ids than the scan's LDS bitmap has bits (393,216): the ids are folded onto 2^18 bits (launch_scan), a folded
+# bit set by another id queues a contact for nothing and the consumers drop it.  450,000 sub-fragments, properties as above.
+@pytest.mark.timeout(900)
+def test_more_sub_fragments_than_bitmap_bits():
+    import bench
+    from graal_amd import synth
+    P = synth.make_problem(n_bins=150000, nnz=3_000_000, n_sub=3, seed=77, accu=4, grid_bp=1000)
+    assert int(P["init_n_sub_frags"]) > 393216
+    P["S_o_A_frags"] = bench.exploded_layout(P)
+    rng = np.random.RandomState(43)
+    smp = bench.build_sampler(P, rng, None, 0, arithmetic="exact")
+    smp.init_likelihood()
+    n = int(smp.n_new_frags)
+    for i in rng.randint(0, n, size=400):             # grow some contigs first
+        smp.step_max_likelihood(int(i), 5)
+    carried = smp.likelihood_t
+    assert carried == pytest.approx(smp.eval_likelihood(), rel=1e-9)
+    queued = 0
+    for fA in rng.randint(0, n, size=12):
+        fA = int(fA)
+        max_id = smp.modify_gl_cuda_buffer(0)
+        before = smp._full_likelihood()
+        nb = smp.return_neighbours(fA, 5); nb.sort()
+        d = smp._candidate_deltas(fA, nb, max_id)
+        queued += int(smp.engine.last_counters()[2])
+        smp.engine.set_finisher(False)
+        assert np.array_equal(d, smp._candidate_deltas(fA, nb, max_id))
+        smp.engine.set_finisher(True)
+        k, op = np.unravel_index(np.argmax(np.abs(d)), d.shape)
+        smp.test_copy_struct(fA, nb[k], int(op), max_id)
+        after = smp.eval_likelihood()
+        assert abs(d[k, op] - (after - before)) / abs(before) < 1e-8, (fA, nb[k], op, d[k, op], after - before)
+    assert queued > 0
+    smp.free_gpu()

@@ -160,7 +160,8 @@ def _child_deltas():
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("env", [{"GRAAL_SCAN_THREADS": "1024", "GRAAL_SCAN_BLOCKS": "4"},
                                  {"GRAAL_SCAN_THREADS": "1024", "GRAAL_SCAN_BLOCKS": "4", "GRAAL_SCAN_G": "8"},
-                                 {"GRAAL_SCAN_DONE": "flags", "GRAAL_FIN_BLOCKS": "2048"}])
+                                 {"GRAAL_SCAN_DONE": "flags", "GRAAL_FIN_BLOCKS": "2048"},
+                                 {"GRAAL_SCAN_FOLD_BITS": "10"}])   # (3,258 ids folded onto 1,024 bits: most queued contacts are false positives)
 def test_forced_scan_configurations_agree_with_the_oracle(env):
     """A 120 k-contact list takes the 256-thread scan by default; the tuning knobs are read once per process, so a child
     process runs the 1,024-thread, multi-block configuration (what a 20 M-contact list uses) against the oracle."""
