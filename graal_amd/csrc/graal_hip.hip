@@ -29,6 +29,7 @@
 
 #include "../../include/graal_hip.h"
 #include "frag_ops.h"
+#include "model_math.h"
 
 using namespace graal;
 
@@ -72,32 +73,14 @@ __device__ __forceinline__ void st_rec(const SoaPtr& s, int f, const Rec& r)
 // rounded powf returns, e.g. glibc's in the oracle); the general powf costs ~100 instructions more
 __device__ __forceinline__ float sq(float x) { return x * x; }
 
-// powf(x, y) for x > 0: the device library's own algorithm -- extended-precision ln x (__ocmlpriv_epln_f32), y * ln x in
-// two floats, extended-precision exp (__ocmlpriv_expep_f32) -- WITHOUT the ~35 instructions of powf's special cases (x <= 0,
-// infinities, NaN, integer y and the sign of the result), none of which a distance in (0, d_max) can reach.  Bit-identical
-// to powf there: tools/powf_pos_check.hip compares them over all 260 M floats between 2^-15 and 2^16 for eight exponents
-// (tests/test_engine_gpu.py runs it).  The contact model is ~200 instructions per evaluation, 130 of them powf.
-typedef float v2f_t __attribute__((ext_vector_type(2)));
-extern "C" __device__ v2f_t __ocmlpriv_epln_f32(float);
-extern "C" __device__ float __ocmlpriv_expep_f32(v2f_t);
-__device__ __forceinline__ float powf_pos(float x, float y)
-{
-    const v2f_t ln = __ocmlpriv_epln_f32(x); // (.y high part, .x low part)
-    const float yh = y * ln.y;
-    const float err = fmaf(y, ln.y, -yh);
-    const float t = fmaf(y, ln.x, err);
-    const float hi = yh + t;
-    const float lo = t - (hi - yh);
-    v2f_t a; a.x = lo; a.y = hi;
-    return __ocmlpriv_expep_f32(a);
-}
-
+// powf / expf / log of the model: correctly rounded, self-contained (model_math.h).  The contact model is ~110 instructions per
+// evaluation with them (it was ~200 with the device library's float-float powf).
 // rippe_contacts kernels3.cu:120
 __device__ __forceinline__ float rippe(float s, const Par& p)
 {
     float result = 0.0f;
     if ((s > 0.0f) && (s < p.d_max))
-        result = (p.c1 * powf_pos(s, p.slope) * expf((p.d - 2) / (sq(s * p.lm / p.kuhn) + p.d))) * p.fact;
+        result = (p.c1 * mm_powf_pos(s, p.slope) * mm_expf((p.d - 2) / (sq(s * p.lm / p.kuhn) + p.d))) * p.fact;
     return fmaxf(result, p.v_inter);
 }
 
@@ -111,8 +94,8 @@ __device__ __forceinline__ float rippe_circ(float s, float s_tot, const Par& p)
         const float n = K * s * (s_tot - s) / s_tot;
         const float norm_lin = rippe(s, p);
         const float norm_circ =
-            (powf(p.kuhn, -3.0f) * powf(nmax, p.slope) * expf((p.d - 2.0f) / (sq(nmax) + p.d))) * p.fact;
-        const float val = (powf(p.kuhn, -3.0f) * powf(n, p.slope) * expf((p.d - 2.0f) / (sq(n) + p.d))) * p.fact;
+            (mm_powf(p.kuhn, -3.0f) * mm_powf(nmax, p.slope) * mm_expf((p.d - 2.0f) / (sq(nmax) + p.d))) * p.fact;
+        const float val = (mm_powf(p.kuhn, -3.0f) * mm_powf(n, p.slope) * mm_expf((p.d - 2.0f) / (sq(n) + p.d))) * p.fact;
         result = val * norm_lin / norm_circ;
     }
     return fmaxf(result, p.v_inter);
@@ -845,7 +828,7 @@ __global__ __launch_bounds__(256) void k_full_nnz_u(const int4* __restrict__ row
                                                      long long* __restrict__ out, long long* __restrict__ bad_flag)
 {
     const float norm = (float)(accu * accu) / nfpb;
-    const double ln_trans = log((double)(par.v_inter * norm));
+    const double ln_trans = mm_ln(par.v_inter * norm);
     long long acc = 0;
     bool bad = false;
     const int n4 = (int)(nnz >> 2);
@@ -884,7 +867,7 @@ __global__ __launch_bounds__(256) void k_full_nnz_u(const int4* __restrict__ row
                         const int bin_a = rec_full[w4(r[i], j)].bin & 0x7fffffff;
                         ex = rippe_circ(sd, (float)lcontbp[bin_a] / 1000.0f, par) * norm;
                     } else ex = rippe(sd, par) * norm;
-                    ln_ex = log((double)ex);
+                    ln_ex = mm_ln(ex);
                 }
                 const long long q = to_q((double)__int_as_float(w4(w[i], j)) * ln_ex);
                 if (q == Q_BAD) bad = true; else acc += q;
@@ -924,7 +907,7 @@ __global__ __launch_bounds__(1024) void k_full_nnz_l(const int4* __restrict__ ro
     __syncthreads();
     auto lab = [&](int id) -> unsigned { return (s_lab[id >> 1] >> ((id & 1) << 4)) & 0xffffu; };
     const float norm = (float)(accu * accu) / nfpb;
-    const double ln_trans = log((double)(par.v_inter * norm));
+    const double ln_trans = mm_ln(par.v_inter * norm);
     long long acc = 0;
     bool bad = false;
     const int n4 = (int)(nnz >> 2);
@@ -954,7 +937,7 @@ __global__ __launch_bounds__(1024) void k_full_nnz_l(const int4* __restrict__ ro
                             const int bin_a = rec_full[ia].bin & 0x7fffffff;
                             ex = rippe_circ(sd, (float)lcontbp[bin_a] / 1000.0f, par) * norm;
                         } else ex = rippe(sd, par) * norm;
-                        ln_ex = log((double)ex);
+                        ln_ex = mm_ln(ex);
                     }
                 }
                 const long long q = to_q((double)__int_as_float(w4(w[i], j)) * ln_ex);
@@ -981,7 +964,7 @@ __global__ __launch_bounds__(256) void k_full_nnz(const int4* __restrict__ row4,
                                                    long long* __restrict__ out, long long* __restrict__ bad_flag)
 {
     __shared__ double s_ln_trans[LN_TRANS_LUT];
-    for (int p = threadIdx.x; p < lut_n; p += blockDim.x) s_ln_trans[p] = log((double)(par.v_inter * ((float)p / nfpb)));
+    for (int p = threadIdx.x; p < lut_n; p += blockDim.x) s_ln_trans[p] = mm_ln(par.v_inter * ((float)p / nfpb));
     __syncthreads();
     long long acc = 0;
     bool bad = false;
@@ -1028,7 +1011,7 @@ __global__ __launch_bounds__(256) void k_full_nnz(const int4* __restrict__ row4,
                         const float sd = fabsf(B.centre - A.centre);
                         ex = (A.bin < 0 ? rippe_circ(sd, (float)lcontbp[bin_a] / 1000.0f, par) : rippe(sd, par)) * norm;
                     }
-                    ln_ex = log((double)ex);
+                    ln_ex = mm_ln(ex);
                 }
                 const long long q = to_q((double)__int_as_float(w4(w[i], j)) * ln_ex); // counts are float32 (the reference's obs type)
                 if (q == Q_BAD) bad = true; else acc += q;
@@ -1627,7 +1610,7 @@ __device__ __forceinline__ double ln_trans_of(const Stat& sx, int slx, const Sta
 {
     const int prod = stat_accu(sx, slx) * stat_accu(sy, sly);
     if ((unsigned)prod < (unsigned)lut_n) return ln_tab[prod];   // (k_ln_tab: the same expression)
-    return log((double)(par.v_inter * ((float)prod / nfpb)));
+    return mm_ln(par.v_inter * ((float)prod / nfpb));
 }
 
 // one contact's values: Q(ob ln ex) of the current layout, of the trans relation, and of the last new relation evaluated
@@ -1644,7 +1627,7 @@ struct ContactVals {
         const End X = end_xf(gx, xa), Y = end_xf(gy, xb);
         const int fl = (X.fwd ? 1 : 0) | (Y.fwd ? 2 : 0) | (X.circ << 2);
         if ((have & 4) && X.start_bp == m_xs && Y.start_bp == m_ys && fl == m_fl && X.lbp == m_lbp) return q_memo;
-        q_memo = to_q(ob * log((double)ex_pair(X, sx, slx, Y, sy, sly, nfpb, par)));
+        q_memo = to_q(ob * mm_ln(ex_pair(X, sx, slx, Y, sy, sly, nfpb, par)));
         m_xs = X.start_bp; m_ys = Y.start_bp; m_fl = fl; m_lbp = X.lbp; have |= 4;
         return q_memo;
     }
@@ -1699,7 +1682,7 @@ __device__ __forceinline__ void price_contacts(const PriceArgs& pa, unsigned lon
                     if (!(cv.have & 1)) {   // (the current layout: the same value whatever the neighbour)
                         const bool straight = p == tk.p;
                         const End X = end_xf(cv.gx, straight ? tk.xp : tk.xq), Y = end_xf(cv.gy, straight ? tk.xq : tk.xp);
-                        cv.q_old = to_q(cv.ob * log((double)ex_pair(X, cv.sx, cv.slx, Y, cv.sy, cv.sly, pa.nfpb, pa.par)));
+                        cv.q_old = to_q(cv.ob * mm_ln(ex_pair(X, cv.sx, cv.slx, Y, cv.sy, cv.sly, pa.nfpb, pa.par)));
                         cv.have |= 1;
                     }
                     if (cv.q_old == Q_BAD) bad = true; else acc += sg * cv.q_old;
@@ -1741,7 +1724,7 @@ __device__ __forceinline__ void price_contacts_strict(const QSrc& qs, unsigned l
         if (qe.rel == 0) continue;
         const End X0 = end_old(gx, ((gx.flags >> 1) & 1) ? lcontbp[fx] : 0), Y0 = end_old(gy, ((gy.flags >> 1) & 1) ? lcontbp[fy] : 0);
         const float ex_old = ex_pair_ref(X0, sx, slx, fx, Y0, sy, sly, fy, nfpb, par, quirk);
-        const double ln_old = log((double)ex_old), ob = (double)__int_as_float(qe.cnt);
+        const double ln_old = mm_ln(ex_old), ob = (double)__int_as_float(qe.cnt);
         unsigned rel = qe.rel;
         while (rel) {
             const int k = (__ffs((int)rel) - 1) / CODE_BITS;
@@ -1752,7 +1735,7 @@ __device__ __forceinline__ void price_contacts_strict(const QSrc& qs, unsigned l
             const End X = end_xf(gx, T.xf[op][p]), Y = end_xf(gy, T.xf[op][q]);
             const float ex_new = ex_pair_ref(X, sx, slx, fx, Y, sy, sly, fy, nfpb, par, quirk);
             if (ex_new == ex_old) continue;
-            const long long qv = to_q(ob * (log((double)ex_new) - ln_old));
+            const long long qv = to_q(ob * (mm_ln(ex_new) - ln_old));
             if (qv == Q_BAD) nf_flag(nf, k, op);
             else if (qv != 0) atomicAdd((unsigned long long*)&out[k * N_OPS + op], (unsigned long long)qv);
         }
@@ -1805,7 +1788,7 @@ __device__ __forceinline__ void price_contact_batch(const PriceArgs& pa, long lo
                     if (!(cv.have & 1)) {
                         const bool straight = p == tk.p;
                         const End X = end_xf(cv.gx, straight ? tk.xp : tk.xq), Y = end_xf(cv.gy, straight ? tk.xq : tk.xp);
-                        cv.q_old = to_q(cv.ob * log((double)ex_pair(X, cv.sx, cv.slx, Y, cv.sy, cv.sly, pa.nfpb, pa.par)));
+                        cv.q_old = to_q(cv.ob * mm_ln(ex_pair(X, cv.sx, cv.slx, Y, cv.sy, cv.sly, pa.nfpb, pa.par)));
                         cv.have |= 1;
                     }
                     if (cv.q_old == Q_BAD) nf_flag_ops(pa.nf, k, tk.plus | tk.minus);
@@ -1846,7 +1829,7 @@ __device__ __forceinline__ void fold_contact_sums(const NbTables* __restrict__ t
 __global__ void k_ln_tab(double* __restrict__ tab, int n, float nfpb, Par par)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < n) tab[p] = log((double)(par.v_inter * ((float)p / nfpb)));
+    if (p < n) tab[p] = mm_ln(par.v_inter * ((float)p / nfpb));
 }
 
 // the last block of a step: read the K*13 sums, reset the accumulators and counters for the next step, hand the sums
@@ -3132,7 +3115,7 @@ __global__ __launch_bounds__(256) void k_strict_dense(FinArgs fa, StrictArgs sa,
                 if (qe.rel == 0) continue;
                 const End X0 = end_old(gx, ((gx.flags >> 1) & 1) ? sa.lcontbp[fx] : 0), Y0 = end_old(gy, ((gy.flags >> 1) & 1) ? sa.lcontbp[fy] : 0);
                 const float ex_old = ex_pair_ref(X0, sx, slx, fx, Y0, sy, sly, fy, sa.nfpb, sa.par, sa.quirk);
-                const double ln_old = log((double)ex_old), ob = (double)__int_as_float(qe.cnt);
+                const double ln_old = mm_ln(ex_old), ob = (double)__int_as_float(qe.cnt);
                 unsigned rel = qe.rel;
                 while (rel) {
                     const int k = (__ffs((int)rel) - 1) / CODE_BITS;
@@ -3143,7 +3126,7 @@ __global__ __launch_bounds__(256) void k_strict_dense(FinArgs fa, StrictArgs sa,
                     const End X = end_xf(gx, s_xf[k][op][p]), Y = end_xf(gy, s_xf[k][op][q]);
                     const float ex_new = ex_pair_ref(X, sx, slx, fx, Y, sy, sly, fy, sa.nfpb, sa.par, sa.quirk);
                     if (ex_new == ex_old) continue;
-                    const long long qv = to_q(ob * (log((double)ex_new) - ln_old));
+                    const long long qv = to_q(ob * (mm_ln(ex_new) - ln_old));
                     if (qv == Q_BAD) nf_flag(counters + NF_OFF, k, op);
                     else if (qv != 0) atomicAdd((unsigned long long*)&s_accb[k * N_OPS + op], (unsigned long long)qv);
                 }
@@ -3500,7 +3483,7 @@ __global__ __launch_bounds__(256) void k_strict(FinArgs fa, StrictArgs sa, int f
         if (qe.rel == 0) continue;
         const End X0 = end_old(gx, ((gx.flags >> 1) & 1) ? sa.lcontbp[fx] : 0), Y0 = end_old(gy, ((gy.flags >> 1) & 1) ? sa.lcontbp[fy] : 0);
         const float ex_old = ex_pair_ref(X0, sx, slx, fx, Y0, sy, sly, fy, nfpb, par, quirk);
-        const double ln_old = log((double)ex_old), ob = (double)__int_as_float(qe.cnt);
+        const double ln_old = mm_ln(ex_old), ob = (double)__int_as_float(qe.cnt);
         unsigned rel = qe.rel;
         while (rel) {
             const int k = (__ffs((int)rel) - 1) / CODE_BITS;
@@ -3512,7 +3495,7 @@ __global__ __launch_bounds__(256) void k_strict(FinArgs fa, StrictArgs sa, int f
                 const End X = end_xf(gx, XF_(k, op, p)), Y = end_xf(gy, XF_(k, op, q));
                 const float ex_new = ex_pair_ref(X, sx, slx, fx, Y, sy, sly, fy, nfpb, par, quirk);
                 if (ex_new == ex_old) continue;
-                const long long qv = to_q(ob * (log((double)ex_new) - ln_old));
+                const long long qv = to_q(ob * (mm_ln(ex_new) - ln_old));
                 if (qv == Q_BAD) nf_flag_ops(counters + NF_OFF, k, CMASK_(k, pr, op));
                 else if (qv != 0) add_ops(k, CMASK_(k, pr, op), qv);
             }
@@ -3593,8 +3576,9 @@ __device__ __forceinline__ double lik_double(double ex, double ob)
 {
     double res = 0.0;
     if (ex != 0.0) {
-        if (ob >= 15.0) res = ob * log(ex) - ex - (ob * log(ob) - ob + log(sqrt(ob * 2.0 * M_PI)));
-        else if (ob > 0.0) res = ob * log(ex) - ex - log((double)factorial_f((float)ob));
+        const double ln_ex = mm_ln((float)ex);   // (ex is a float32 expected value in double)
+        if (ob >= 15.0) res = ob * ln_ex - ex - (ob * log(ob) - ob + log(sqrt(ob * 2.0 * M_PI)));
+        else if (ob > 0.0) res = ob * ln_ex - ex - log((double)factorial_f((float)ob));
         else if (ob == 0.0) res = -ex;
     }
     return res;

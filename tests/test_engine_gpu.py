@@ -102,8 +102,8 @@ def test_full_likelihood(n_sub, seed):
         e.relabel_contigs()
         got = e.eval_full()
         want = dense.evaluate(s)
-        assert got == pytest.approx(want, rel=1e-6)          # north_star tolerance is 1e-5 relative
-        assert got == pytest.approx(sparse.full(s), rel=1e-6)
+        assert got == pytest.approx(want, rel=1e-8)          # north_star tolerance is 1e-5 relative
+        assert got == pytest.approx(sparse.full(s), rel=1e-6)   # (numpy's own float32 power / exp: last-place differences, 4e-8 measured)
         e.close()
 
 
@@ -159,11 +159,11 @@ def test_candidate_deltas(n_sub, seed, p_circ):
             fBs = [int(v) for v in rng.choice(np.setdiff1d(np.arange(P["n_frags"]), [fA]), 3, replace=False)]
             base, want = oracle_deltas(P, dense, s, fA, fBs, max_id)
             got = e.eval_candidates(fA, fBs, max_id)
-            tol = 1e-7 * abs(base)
+            tol = 1e-8 * abs(base)
             assert np.all(np.abs(got - want) <= tol), (fA, fBs, np.abs(got - want).max(), tol, got - want)
             worst = max(worst, np.abs(got - want).max() / abs(base))
         e.close()
-    assert worst < 1e-7
+    assert worst < 1e-8
 
 
 def test_candidates_generic_coordinates_within_tolerance():
@@ -222,7 +222,7 @@ def test_unsorted_contact_list_gives_the_same_deltas():
 
 
 # ------------------------------------------------------------------------------------------------ edge cases
-def _deltas_match(P, s, fA, fBs, tol_rel=1e-7):
+def _deltas_match(P, s, fA, fBs, tol_rel=1e-8):
     dense = dense_for(P)
     want_state = O.copy_state(s)
     max_id = relabel_ref(want_state)
@@ -250,7 +250,7 @@ def test_empty_contact_list():
     got, want = _deltas_match(P, s, 4, [5, 17, 22])
     e = engine_for(P, s)
     e.relabel_contigs()
-    assert e.eval_full() == pytest.approx(dense_for(P).evaluate(s), rel=1e-6)   # pure expected mass
+    assert e.eval_full() == pytest.approx(dense_for(P).evaluate(s), rel=1e-8)   # pure expected mass
     assert np.any(np.abs(want) > 0)
 
 
@@ -286,7 +286,7 @@ def test_large_counts_use_the_stirling_branches():
     s = random_state_for(P, np.random.RandomState(55), n_contigs=4, p_circ=0.3)
     e = engine_for(P, s)
     e.relabel_contigs()
-    assert e.eval_full() == pytest.approx(dense_for(P).evaluate(s), rel=1e-6)
+    assert e.eval_full() == pytest.approx(dense_for(P).evaluate(s), rel=1e-8)
     _deltas_match(P, s, 3, [4, 20, 33])
 
 
@@ -297,7 +297,7 @@ def test_two_sub_fragments_per_bin():
     s = random_state_for(P, np.random.RandomState(56), n_contigs=5, p_circ=0.3)
     e = engine_for(P, s)
     e.relabel_contigs()
-    assert e.eval_full() == pytest.approx(dense_for(P).evaluate(s), rel=1e-6)
+    assert e.eval_full() == pytest.approx(dense_for(P).evaluate(s), rel=1e-8)
     _deltas_match(P, s, 8, [9, 25, 41, 2])
 
 
@@ -333,7 +333,7 @@ def test_short_contigs_finished_by_the_table_kernel(n_sub, seed, p_circ):
         got = e1.eval_candidates(fA, fBs, max_id)
         assert np.array_equal(got, e2.eval_candidates(fA, fBs, max_id))
         base, want = oracle_deltas(P, dense, s, fA, fBs, max_id)
-        assert np.all(np.abs(got - want) <= 1e-7 * max(abs(base), 1.0)), np.abs(got - want).max()
+        assert np.all(np.abs(got - want) <= 1e-8 * max(abs(base), 1.0)), np.abs(got - want).max()
     e1.close(); e2.close()
 
 
@@ -394,22 +394,30 @@ def test_two_commits_between_begin_steps_fall_back_to_the_sort():
     e.close()
 
 
-def test_powf_pos_is_the_device_librarys_powf_bit_for_bit(tmp_path):
-    """The contact model calls powf_pos (graal_hip.hip: the device library's powf algorithm without its special cases) for
-    distances in (0, d_max).  tools/powf_pos_check.hip compares it with powf over every float between 2^-15 and 2^16 for eight
-    exponents on the GPU."""
+def test_model_math_is_correctly_rounded(tmp_path):
+    """The contact model's powf / expf / log (graal_amd/csrc/model_math.h: self-contained, double precision inside) return the
+    CORRECTLY ROUNDED float32 -- the one value every libm should agree on; glibc's powf, which the oracle calls, misses it for
+    0.06 % of the arguments, the ROCm device library's for 25 %.  tools/model_math_check.hip compares them with the device
+    library's double-precision pow / exp / log over every float32 of the model's ranges."""
+    import re
     import shutil
     import subprocess
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc on this box")
-    exe = str(tmp_path / "powf_pos_check")
+    exe = str(tmp_path / "model_math_check")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value", "-o", exe,
-                           os.path.join(root, "tools", "powf_pos_check.hip")])
-    out = subprocess.run([exe], capture_output=True, text=True, timeout=300, check=True).stdout
-    lines = [l for l in out.splitlines() if l.startswith("y=")]
-    assert len(lines) == 8 and all("mismatches 0 " in l for l in lines), out
+                           os.path.join(root, "tools", "model_math_check.hip")])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600, check=True).stdout
+    print(out)
+    pw = [int(re.search(r"mismatches (\d+)", l).group(1)) for l in out.splitlines() if l.startswith("pow y=")]
+    ex = [int(re.search(r"mismatches (\d+)", l).group(1)) for l in out.splitlines() if l.startswith("exp:")]
+    ln = [int(re.search(r"difference (\d+) ulp", l).group(1)) for l in out.splitlines() if l.startswith("ln:")]
+    # (2.6e8 arguments per exponent; a handful within 1e-7 ulp of a rounding tie may fall either way in BOTH implementations)
+    assert len(pw) == 8 and max(pw) <= 40, out
+    assert len(ex) == 1 and ex[0] <= 200, out
+    assert len(ln) == 1 and ln[0] <= 16, out
 
 
 def test_non_finite_terms_surface_as_nan_not_as_arbitrary_numbers():
@@ -458,7 +466,7 @@ def test_window_of_hundreds_of_fragments_long_pieces(n_sub, n_bins, K):
         base, want = oracle_deltas(P, dense, s, fA, fBs, max_id)
         got = e.eval_candidates(fA, fBs, max_id)
         err = np.abs(got - want).max()
-        assert err <= 1e-7 * abs(base), (trial, fA, fBs, err / abs(base), got[0], want[0])
+        assert err <= 1e-8 * abs(base), (trial, fA, fBs, err / abs(base), got[0], want[0])
     e.close()
 
 

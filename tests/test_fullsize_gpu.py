@@ -75,6 +75,7 @@ def test_c5_properties(c5):
     e2.upload_contacts(c5["coo_row"], c5["coo_col"], c5["coo_val"])
     e2.set_params(c5["param_simu"])
     e2.upload_frags(state)
+    e2.set_mode(ref_trans_accu=True, strict=True)        # (the sampler's arithmetic: bench.build_sampler's default)
     st2, max2 = e2.begin_step()
     st1, max1 = smp.engine.begin_step()
     assert max1 == max2 and list(st1[:7]) == list(st2[:7])

@@ -81,7 +81,7 @@ def test_full_likelihood_with_repeats(n_sub, seed):
         e.relabel_contigs()
         want = dense.evaluate(s)
         got = e.eval_full()
-        assert got == pytest.approx(want, rel=1e-6), (trial, got, want)
+        assert got == pytest.approx(want, rel=1e-8), (trial, got, want)
         e.close()
 
 
@@ -145,7 +145,7 @@ def test_trace_with_repeats_matches_oracle(n_sub, seed, dup):
     assert np.array_equal(t_gpu.mutations(), m_ref)
     assert (m_ref[:, 2] == 8).any()                                     # activity swaps occurred
     assert t_gpu.n_contigs == t_ref.n_contigs and t_gpu.dist == t_ref.dist
-    assert np.allclose(t_gpu.likelihood, t_ref.likelihood, rtol=1e-6, atol=0)
+    assert np.allclose(t_gpu.likelihood, t_ref.likelihood, rtol=1e-8, atol=0)
     g.gpu_vect_frags.copy_from_gpu()
     for k in O.FIELDS:
         assert np.array_equal(getattr(g.gpu_vect_frags, k), ora.gpu_vect_frags[k]), k
@@ -171,7 +171,7 @@ def test_trace_with_repeats_and_a_blacklist_matches_oracle():
     t_gpu = em.run_em(g, 2, 3, rng=rng)
     assert np.array_equal(t_gpu.mutations(), t_ref.mutations())
     assert t_gpu.n_contigs == t_ref.n_contigs and t_gpu.dist == t_ref.dist
-    assert np.allclose(t_gpu.likelihood, t_ref.likelihood, rtol=1e-6, atol=0)
+    assert np.allclose(t_gpu.likelihood, t_ref.likelihood, rtol=1e-8, atol=0)
     g.gpu_vect_frags.copy_from_gpu()
     for k in O.FIELDS:
         assert np.array_equal(getattr(g.gpu_vect_frags, k), ora.gpu_vect_frags[k]), k

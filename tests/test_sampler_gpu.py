@@ -48,14 +48,14 @@ def test_trace_matches_oracle(n_sub, seed, n_bins, nnz, cycles, delta):
     assert t_gpu.n_contigs == t_ref.n_contigs
     assert t_gpu.mean_len == t_ref.mean_len
     assert t_gpu.dist == t_ref.dist
-    assert np.allclose(t_gpu.likelihood, t_ref.likelihood, rtol=1e-6, atol=0)
+    assert np.allclose(t_gpu.likelihood, t_ref.likelihood, rtol=1e-8, atol=0)
     g.gpu_vect_frags.copy_from_gpu()
     for k in O.FIELDS:                                                    # fragment ordering, bit-exact
         assert np.array_equal(getattr(g.gpu_vect_frags, k), ora.gpu_vect_frags[k]), k
     # the run did something: contigs were merged back from the exploded genome
     assert t_gpu.n_contigs[-1] < 0.7 * P["n_frags"]
     # full re-evaluation agrees with the carried-over likelihood
-    assert g.eval_likelihood() == pytest.approx(ora.init_likelihood(), rel=1e-6)
+    assert g.eval_likelihood() == pytest.approx(ora.init_likelihood(), rel=1e-8)
     g.free_gpu()
 
 
@@ -74,7 +74,7 @@ def test_trace_with_nuisance_parameter_sampling_matches_oracle():
     assert t_gpu.success == t_ref.success and 0 < sum(t_ref.success) < len(t_ref.success)
     for a, b in ((t_gpu.fact, t_ref.fact), (t_gpu.slope, t_ref.slope), (t_gpu.d_max, t_ref.d_max), (t_gpu.d_nuc, t_ref.d_nuc)):
         assert np.array_equal(np.asarray(a, np.float32), np.asarray(b, np.float32))   # parameters are float32: bit-exact
-    assert np.allclose(t_gpu.likelihood_nuisance, t_ref.likelihood_nuisance, rtol=1e-6, atol=0)
+    assert np.allclose(t_gpu.likelihood_nuisance, t_ref.likelihood_nuisance, rtol=1e-8, atol=0)
     g.gpu_vect_frags.copy_from_gpu()
     for k in O.FIELDS:
         assert np.array_equal(getattr(g.gpu_vect_frags, k), ora.gpu_vect_frags[k]), k
@@ -125,12 +125,12 @@ def test_trace_with_blacklisted_fragments_matches_oracle(n_sub, seed):
     t_ref = em.run_em(ora, 2, 4, rng=ora.rng)
     gpu_rng = np.random.RandomState(seed)
     g = make_gpu_sampler(P, gpu_rng)
-    assert g.eval_likelihood() == pytest.approx(O.OracleSampler(P, np.random.RandomState(0), fix_trans_accu=True).init_likelihood(), rel=1e-6)
+    assert g.eval_likelihood() == pytest.approx(O.OracleSampler(P, np.random.RandomState(0), fix_trans_accu=True).init_likelihood(), rel=1e-8)
     t_gpu = em.run_em(g, 2, 4, rng=gpu_rng)
     assert np.array_equal(t_gpu.mutations(), t_ref.mutations())
     assert (np.asarray(t_ref.mutations())[:, 2] == -1).sum() == 2 * len(P["id_frags_blacklisted"])   # skipped steps are in the trace
     assert t_gpu.n_contigs == t_ref.n_contigs and t_gpu.dist == t_ref.dist
-    assert np.allclose(t_gpu.likelihood, t_ref.likelihood, rtol=1e-6, atol=0)
+    assert np.allclose(t_gpu.likelihood, t_ref.likelihood, rtol=1e-8, atol=0)
     g.gpu_vect_frags.copy_from_gpu()
     for k in O.FIELDS:
         assert np.array_equal(getattr(g.gpu_vect_frags, k), ora.gpu_vect_frags[k]), k
@@ -255,8 +255,8 @@ def test_blacklisted_fragments_with_parameter_sampling_match_oracle():
     assert t_gpu.success == t_ref.success and 0 < sum(t_ref.success) < len(t_ref.success)
     for a, b in ((t_gpu.fact, t_ref.fact), (t_gpu.slope, t_ref.slope), (t_gpu.d_max, t_ref.d_max), (t_gpu.d_nuc, t_ref.d_nuc)):
         assert np.array_equal(np.asarray(a, np.float32), np.asarray(b, np.float32))
-    assert np.allclose(t_gpu.likelihood, t_ref.likelihood, rtol=1e-6, atol=0)
-    assert np.allclose(t_gpu.likelihood_nuisance, t_ref.likelihood_nuisance, rtol=1e-6, atol=0)
+    assert np.allclose(t_gpu.likelihood, t_ref.likelihood, rtol=1e-8, atol=0)
+    assert np.allclose(t_gpu.likelihood_nuisance, t_ref.likelihood_nuisance, rtol=1e-8, atol=0)
     g.gpu_vect_frags.copy_from_gpu()
     for k in O.FIELDS:
         if k != "id_c":
