@@ -282,6 +282,7 @@ __device__ __forceinline__ int4 ld_stream(const int4* p)
 __device__ unsigned long long g_stamps[32];
 __device__ unsigned long long g_hitstat[8];   // [0] launches' max third-stage duration (ticks) [1] latest third-stage end [2] count [3] sum of durations [4] max passes
 #define STAMP(i, cond) do { if (cond) g_stamps[i] = wall_clock64(); } while (0)
+#define STAMP_MAX(i, cond) do { if (cond) atomicMax(&g_stamps[i], wall_clock64()); } while (0)   // (the clock only grows: the latest wave of the latest step)
 #define HITSTAT_BEGIN() const unsigned long long hs_t0 = wall_clock64()
 #define HITSTAT_END() do { if (lane == 0 && !dry) { const unsigned long long hs_t1 = wall_clock64(); atomicMax(&g_hitstat[0], hs_t1 - hs_t0); atomicMax(&g_hitstat[1], hs_t1); atomicAdd(&g_hitstat[2], 1ull); atomicAdd(&g_hitstat[3], hs_t1 - hs_t0); } } while (0)
 __device__ unsigned long long g_blk[4096 * 4]; // per block of k_scan: start, past prologue, loop done
@@ -289,6 +290,7 @@ __device__ unsigned long long g_blk[4096 * 4]; // per block of k_scan: start, pa
 #define STAMP_FBLK(j, cond) do { if ((cond) && blockIdx.x < 2048) g_blk[4 * (2048 + blockIdx.x) + (j)] = wall_clock64(); } while (0) // k_fin's blocks
 #else
 #define STAMP(i, cond) do { } while (0)
+#define STAMP_MAX(i, cond) do { } while (0)
 #define HITSTAT_BEGIN() do { } while (0)
 #define HITSTAT_END() do { } while (0)
 #define STAMP_BLK(j, cond) do { } while (0)
@@ -2081,7 +2083,7 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
         // release: the tables of neighbour k are complete; the word carries the work-list header for k_fin
         const unsigned long long w = ((unsigned long long)(unsigned)seq << 32) | (inl ? 0x80000000ull : 0ull) | (unsigned long long)(unsigned)ta.step_hdr[k];
         __hip_atomic_store((unsigned long long*)&A->tm_done[k], w, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        STAMP(3, k == 0);
+        STAMP_MAX(3, true);
     }
     if (ta.host_res == nullptr) return;
     // ---- finisher: the last table block ----
@@ -2104,6 +2106,13 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
     }
     __syncthreads();
     if (s_fin == 0) return;
+    if (s_fin == 2) {
+        // some neighbour's work is left to k_fin / k_strict whatever the scan finds: say so AT ONCE -- the host's launches then
+        // queue up behind the scan on its stream while it is still running, instead of starting their trip when it has ended
+        // (contigs of 20-100 bins, the middle of a run: ~10 us of a 130 us step)
+        if (t == 0) { ta.sync[0] = 0; __threadfence_system(); ta.host_res[0] = seq | NEED_FIN; __threadfence_system(); }
+        return;
+    }
     {   // all blocks of k_scan done?  Every thread polls its share of the flags, for a bounded TIME: when the two kernels
         // do not actually run concurrently (a profiler or debugger serialising dispatches, streams sharing a hardware
         // queue) the scan cannot even start before this block exits -- then the step is handed to k_fin, which the host
@@ -3167,22 +3176,27 @@ __global__ __launch_bounds__(256) void k_strict_dense(FinArgs fa, StrictArgs sa,
 // scan queued every contact with both ends in a neighbour's set): lane = contact, one evaluation per class.
 struct SetGeo { int m, lenA, lenB, baseA, baseB, tilesA, nt, lbpA, lbpB, cA, cB, pad; };   // one neighbour's affected set
 
-__device__ __forceinline__ SetGeo set_geo(const NbTables& T, const Geo* __restrict__ geo, const Link* __restrict__ link,
-                                          const int* __restrict__ cbase, int fA)
+// (the layout's part: needs nothing of k_tm's tables; `live` = the set is left to the strict kernels, NbTables::set_m > 0)
+__device__ __forceinline__ SetGeo set_geo_of(int fA, int fB, bool live, const Geo* __restrict__ geo, const Link* __restrict__ link,
+                                             const int* __restrict__ cbase)
 {
     SetGeo g;
-    const int fB = T.fB;
     const Geo gA = geo[fA], gB = geo[fB];
     const Link lA = link[fA], lB = link[fB];
     g.cA = gA.id_c; g.cB = gB.id_c;
     g.lenA = lA.l_cont; g.lenB = (fB == fA || gB.id_c == gA.id_c) ? 0 : lB.l_cont;
-    g.m = T.set_m > 0 ? g.lenA + g.lenB : 0;      // (0: fB == fA, or priced by k_tm already)
+    g.m = live ? g.lenA + g.lenB : 0;      // (0: fB == fA, or priced by k_tm already)
     g.baseA = cbase[fA]; g.baseB = cbase[fB];
     g.lbpA = lA.l_cont_bp; g.lbpB = lB.l_cont_bp;
     g.tilesA = (g.lenA + 63) >> 6;
     g.nt = g.m > 0 ? g.tilesA + ((g.lenB + 63) >> 6) : 0;
     g.pad = 0;
     return g;
+}
+__device__ __forceinline__ SetGeo set_geo(const NbTables& T, const Geo* __restrict__ geo, const Link* __restrict__ link,
+                                          const int* __restrict__ cbase, int fA)
+{
+    return set_geo_of(fA, T.fB, T.set_m > 0, geo, link, cbase);
 }
 
 // old bp interval [lo, hi) of piece p of the neighbour and its contig (0 = contig(fA), 1 = contig(fB)); lo >= hi: empty
@@ -3220,6 +3234,7 @@ __global__ __launch_bounds__(256) void k_strict_cull(const NbTables* __restrict_
     __shared__ int s_rbase[MAXK + 1];
     __shared__ int s_row[4];      // the row's x tile: lo, hi (old bp), side
     const int t = threadIdx.x;
+    STAMP(24, blockIdx.x == 0 && t == 0);
     if (t < K) {
         const SetGeo sg = set_geo(tabs[t], geo, link, cbase, fA);
         s_sg[t] = sg;
@@ -3332,6 +3347,7 @@ __global__ __launch_bounds__(256) void k_strict(FinArgs fa, StrictArgs sa, int f
 #define XF_(k_, op_, p_) s_xf[((k_) * N_OPS + (op_)) * NP + (p_)]
 #define CREP_(k_, pr_, op_) s_crep[((k_) * N_PAIRS + (pr_)) * N_OPS + (op_)]
 #define CMASK_(k_, pr_, op_) s_cmask[((k_) * N_PAIRS + (pr_)) * N_OPS + (op_)]
+    STAMP(16, blockIdx.x == 0 && threadIdx.x == 0);
     for (int i = threadIdx.x; i < STRICT_ACC_COPIES * MAXK * N_OPS; i += blockDim.x) (&s_accb[0][0])[i] = 0;
     // (the tables are complete: the launch is ordered behind k_tm by an event)
     for (int i = threadIdx.x; i < K * N_OPS * NP; i += blockDim.x) { const int k = i / (N_OPS * NP), r = i - k * (N_OPS * NP); s_xf[i] = tabs[k].xf[r / NP][r % NP]; }
@@ -3359,6 +3375,7 @@ __global__ __launch_bounds__(256) void k_strict(FinArgs fa, StrictArgs sa, int f
     auto add_ops = [&](int k, unsigned ops, long long v) {
         while (ops) { const int b = __ffs((int)ops) - 1; ops &= ops - 1; atomicAdd((unsigned long long*)&my_acc[k * N_OPS + b], (unsigned long long)v); }
     };
+    STAMP(17, blockIdx.x == 0 && threadIdx.x == 0);
     // ---- (1) the listed units
     STileW* tile = s_tile[wib];
     for (unsigned long long u = (unsigned long long)wave; u < n_units; u += (unsigned long long)n_waves) {
@@ -3467,6 +3484,7 @@ __global__ __launch_bounds__(256) void k_strict(FinArgs fa, StrictArgs sa, int f
         if (lane == 0 && bad) nf_flag_ops(counters + NF_OFF, k, bad & 0xffffu);
         WAVE_LDS_SYNC();   // (the next unit stages its tile over this one)
     }
+    STAMP_MAX(18, lane == 0);
     // ---- (2) the queued contacts: lane = contact, one evaluation per class
     QSrc qs;
     qs.queue = fa.queue; qs.geo2 = reinterpret_cast<const int2*>(geo); qs.cnt = fa.cnt; qs.keys = s_qkeys; qs.live = s_qlive; qs.K = K;
@@ -3501,6 +3519,7 @@ __global__ __launch_bounds__(256) void k_strict(FinArgs fa, StrictArgs sa, int f
             }
         }
     }
+    STAMP_MAX(19, lane == 0);
     __syncthreads();
     for (int i = threadIdx.x; i < K * N_OPS; i += blockDim.x) {
         long long v = 0;
@@ -3521,6 +3540,197 @@ __global__ __launch_bounds__(256) void k_strict(FinArgs fa, StrictArgs sa, int f
     __threadfence();
     if (threadIdx.x == 0) *list_n = 0;   // (every block has read it: the list is empty again for the next step)
     hand_out(fa.acc, counters, fa.sync, K, d_q_out, host_res, seq);
+    STAMP(20, threadIdx.x == 0);
+#undef XF_
+#undef CREP_
+#undef CMASK_
+}
+
+// k_strict_flat: the same sums as k_strict_cull + k_strict for SMALL affected sets -- the middle of a run, contigs of 20-100 bins:
+// a step there has a handful of tile-pair units and a few hundred queued contacts, and k_strict spends 40 us on each part with
+// one wave walking 4 fragments y x ~9 classes, or 5 neighbours x ~9 classes of one contact, one evaluation after the other
+// (tools/stamps_c4.py).  Here every (fragment pair, class) and every (contact, neighbour, class) is a LANE: two evaluations deep,
+// whatever the set's size; no unit list, no culling kernel, no event -- the kernel sits behind the scan on its stream and waits for
+// k_tm's tables by itself (its grid cannot fill the chip: k_tm always finds room).  Sets with more than FLAT_CAP_PAIRS pairs
+// are left to the tiled kernels: the step's last block then publishes NEED_FIN and touches nothing.
+// Same per-pair / per-contact terms, rounded to Q the same way: bit-identical to k_strict (tests/test_strict_windowed_gpu.py).
+constexpr long long FLAT_CAP_PAIRS = 40000;     // x 13 class slots = 520 k lanes = ~11 rounds of the grid
+constexpr int FLAT_BLOCKS = 192;                // < 256 CUs: blocks that wait for k_tm can never keep it off the chip
+template <bool MULTI>
+__global__ __launch_bounds__(256) void k_strict_flat(FinArgs fa, StrictArgs sa, int fA, Neigh nb, int K, long long* __restrict__ d_q_out,
+                                                      volatile long long* host_res, long long seq)
+{
+    const NbTables* __restrict__ tabs = fa.tabs;
+    const Geo* __restrict__ geo = fa.geo;
+    const Stat* __restrict__ stat = fa.stat;
+    unsigned long long* __restrict__ counters = fa.counters;
+    const int t = threadIdx.x, lane = t & 63;
+    __shared__ long long s_accb[STRICT_ACC_COPIES][MAXK * N_OPS];
+    __shared__ SetGeo s_sg[MAXK];
+    __shared__ long long s_pbase[MAXK + 1];
+    __shared__ PieceKey s_qkeys[MAXK];
+    __shared__ unsigned s_qlive;
+    __shared__ int s_ok, s_last;
+    // (the transforms and classes are read where they are needed, from k_tm's tables in L2: a lane wants two transforms and one
+    // class entry -- staging all K x 13 x 6 of them in LDS first, as k_strict does for its long loops, was 6 us of a 30 us kernel)
+#define XF_(k_, op_, p_) tabs[k_].xf[op_][p_]
+#define CREP_(k_, pr_, op_) tabs[k_].crep[pr_][op_]
+#define CMASK_(k_, pr_, op_) tabs[k_].cmask[pr_][op_]
+    STAMP(16, blockIdx.x == 0 && t == 0);
+    const unsigned long long nq_total = counters[2];          // written by k_scan, an earlier kernel on the stream (on its way during the wait below)
+    if (t == 0) { s_ok = 1; s_qlive = 0; }
+    for (int i = t; i < STRICT_ACC_COPIES * MAXK * N_OPS; i += blockDim.x) (&s_accb[0][0])[i] = 0;
+    __syncthreads();
+    if (t < K) {   // k_tm's tables of neighbour t (and its own pricing of the small sets): complete?  Bounded wait.
+        // (what the layout alone says about the set is on its way meanwhile)
+        const int fB_t = sel_nb(nb, t);
+        s_sg[t] = set_geo_of(fA, fB_t, true, geo, sa.link, sa.cbase);
+        if (fB_t != fA) atomicOr(&s_qlive, 1u << t);
+        bool ok = false;
+        for (int spin = 0; spin < (1 << 22); spin++) {
+            const unsigned long long w = (unsigned long long)__hip_atomic_load(&fa.tm_done[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(w >> 32) == (unsigned)seq) { ok = true; break; }
+            if ((spin & 63) == 63 && (__hip_atomic_load(&counters[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4ull)) break;   // k_tm gave up (see there)
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (!ok) { s_ok = 0; atomicOr(&counters[6], 1ull); }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    STAMP(21, blockIdx.x == 0 && t == 0);
+    const bool ok = s_ok != 0;
+    if (ok) {
+        if (t < K) {
+            s_qkeys[t] = tabs[t].key;
+            if (!(tabs[t].set_m > 0)) { s_sg[t].m = 0; s_sg[t].nt = 0; }   // (fB == fA, or priced by k_tm already)
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
+        long long acc = 0;
+        for (int k = 0; k < K; k++) { s_pbase[k] = acc; const long long m = ok ? s_sg[k].m : 0; acc += m * (m - 1) / 2; }
+        s_pbase[K] = acc;
+    }
+    __syncthreads();
+    const long long total_pairs = s_pbase[K];
+    const bool too_big = total_pairs > FLAT_CAP_PAIRS;   // (every block finds the same: the tables are the same)
+    STAMP(17, blockIdx.x == 0 && t == 0);
+    if (ok && !too_big) {
+        const float nfpb = sa.nfpb;
+        const Par par = sa.par;
+        const bool quirk = sa.quirk != 0;
+        const int reach_bp = sa.reach_bp;
+        long long* const my_acc = s_accb[lane & (STRICT_ACC_COPIES - 1)];
+        auto add_ops = [&](int k, unsigned ops, long long v) {
+            while (ops) { const int b = __ffs((int)ops) - 1; ops &= ops - 1; atomicAdd((unsigned long long*)&my_acc[k * N_OPS + b], (unsigned long long)v); }
+        };
+        const long long gi = (long long)blockIdx.x * blockDim.x + t, stride = (long long)gridDim.x * blockDim.x;
+        QSrc qs;
+        qs.queue = fa.queue; qs.geo2 = reinterpret_cast<const int2*>(geo); qs.cnt = fa.cnt; qs.keys = s_qkeys; qs.live = s_qlive; qs.K = K;
+        qs.seq = (unsigned)seq; qs.concurrent = 0; qs.multi = fa.multi;
+        const long long per_contact = (long long)K * N_OPS;
+        // one item space: the pairs' lanes first (whole waves), the contacts' lanes behind them -- both kinds are in flight together
+        const long long pair_items = (total_pairs * N_OPS + 63) & ~63ll, all_items = pair_items + (long long)nq_total * per_contact;
+        for (long long it0 = gi; it0 < all_items; it0 += stride) {
+          if (it0 < pair_items) {
+            // ---- (1) lane = (fragment pair of a neighbour's set, class slot)
+            const long long it = it0;
+            if (it >= total_pairs * N_OPS) continue;
+            const long long pi = it / N_OPS;
+            const int op = (int)(it - pi * N_OPS);
+            int k = 0;
+            for (int j = 1; j < K; j++) k += pi >= s_pbase[j] ? 1 : 0;
+            const long long local = pi - s_pbase[k];
+            // pair number -> (i < j): local = j (j - 1) / 2 + i
+            int j = (int)((1.0 + sqrt(1.0 + 8.0 * (double)local)) * 0.5);
+            while ((long long)j * (j - 1) / 2 > local) j -= 1;
+            while ((long long)(j + 1) * j / 2 <= local) j += 1;
+            const int i = (int)(local - (long long)j * (j - 1) / 2);
+            const SetGeo sg = s_sg[k];
+            const int fx = i < sg.lenA ? sa.perm[sg.baseA + i] : sa.perm[sg.baseB + i - sg.lenA];
+            const int fy = j < sg.lenA ? sa.perm[sg.baseA + j] : sa.perm[sg.baseB + j - sg.lenA];
+            const Geo gx = geo[fx], gy = geo[fy];
+            const Stat sx = stat[fx], sy = stat[fy];
+            if (sx.n == 0 || sy.n == 0) continue;                     // (a copy of a repeated bin: priced by k_rep_delta)
+            const PieceKey key = s_qkeys[k];
+            const int px = piece_of(key, gx.id_c, geo_pos(gx.flags)), py = piece_of(key, gy.id_c, geo_pos(gy.flags));
+            const int pr = pair_index(px, py);
+            if (CREP_(k, pr, op) != op) continue;                     // a class is priced once, under its first candidate
+            const int lbpx = ((gx.flags >> 1) & 1) ? (gx.id_c == sg.cA ? sg.lbpA : sg.lbpB) : 0;
+            const int lbpy = ((gy.flags >> 1) & 1) ? (gy.id_c == sg.cA ? sg.lbpA : sg.lbpB) : 0;
+            const End X0 = end_old(gx, lbpx), Y0 = end_old(gy, lbpy);
+            const End X = end_xf(gx, XF_(k, op, px)), Y = end_xf(gy, XF_(k, op, py));
+            const bool near_old = X0.label == Y0.label && gap_bp(X0, gx.len_bp, Y0, gy.len_bp) <= reach_bp;
+            const bool near_new = X.label == Y.label && gap_bp(X, gx.len_bp, Y, gy.len_bp) <= reach_bp;
+            const bool always = quirk && (!stat_uniform(sx) || !stat_uniform(sy));
+            if (!near_old && !near_new && !always) continue;          // the trans value both times, slot by slot: exactly zero
+            double acc = 0.0;
+            if (MULTI) {
+#pragma unroll
+                for (int a = 0; a < 3; a++)
+#pragma unroll
+                    for (int b = 0; b < 3; b++)
+                        if (a < sx.n && b < sy.n)
+                            acc += (double)ex_pair_ref(X0, sx, a, fx, Y0, sy, b, fy, nfpb, par, quirk) - (double)ex_pair_ref(X, sx, a, fx, Y, sy, b, fy, nfpb, par, quirk);
+            } else acc += (double)ex_pair_ref(X0, sx, 0, fx, Y0, sy, 0, fy, nfpb, par, quirk) - (double)ex_pair_ref(X, sx, 0, fx, Y, sy, 0, fy, nfpb, par, quirk);
+            const long long q1 = to_q(acc);
+            if (q1 == Q_BAD) nf_flag_ops(counters + NF_OFF, k, CMASK_(k, pr, op));
+            else if (q1 != 0) add_ops(k, CMASK_(k, pr, op), q1);
+            STAMP_MAX(18, lane == 0);
+          } else {
+            // ---- (2) lane = (queued contact, neighbour, class slot)
+            const long long it = it0 - pair_items;
+            const unsigned long long e = (unsigned long long)(it / per_contact);
+            const int r = (int)(it - (long long)e * per_contact), k = r / N_OPS, op = r - k * N_OPS;
+            QEntry qe = q_fetch(qs, e, counters + 6);
+            if (qe.fx < 0) continue;
+            const int fx = qe.fx, fy = qe.fy, slx = qe.slots & 3, sly = (qe.slots >> 2) & 3;
+            const Geo gx = geo[fx], gy = geo[fy];
+            const Stat sx = stat[fx], sy = stat[fy];
+            q_codes(qs, qe, gx, gy, qs.cnt[qe.idx]);
+            if (!((qe.rel >> (CODE_BITS * k)) & 1u)) continue;
+            const int p = (qe.ci >> (CODE_BITS * k)) & 7, q = (qe.cj >> (CODE_BITS * k)) & 7;
+            const int pr = pair_index(p, q);
+            if (CREP_(k, pr, op) != op) continue;
+            const End X0 = end_old(gx, ((gx.flags >> 1) & 1) ? sa.lcontbp[fx] : 0), Y0 = end_old(gy, ((gy.flags >> 1) & 1) ? sa.lcontbp[fy] : 0);
+            const float ex_old = ex_pair_ref(X0, sx, slx, fx, Y0, sy, sly, fy, nfpb, par, quirk);
+            const End X = end_xf(gx, XF_(k, op, p)), Y = end_xf(gy, XF_(k, op, q));
+            const float ex_new = ex_pair_ref(X, sx, slx, fx, Y, sy, sly, fy, nfpb, par, quirk);
+            if (ex_new == ex_old) continue;
+            const double ob = (double)__int_as_float(qe.cnt);
+            const long long qv = to_q(ob * (mm_ln(ex_new) - mm_ln(ex_old)));
+            if (qv == Q_BAD) nf_flag_ops(counters + NF_OFF, k, CMASK_(k, pr, op));
+            else if (qv != 0) add_ops(k, CMASK_(k, pr, op), qv);
+            STAMP_MAX(19, lane == 0);
+          }
+        }
+    }
+    __syncthreads();
+    for (int i = t; i < K * N_OPS; i += blockDim.x) {
+        long long v = 0;
+#pragma unroll
+        for (int c = 0; c < STRICT_ACC_COPIES; c++) v += s_accb[c][i];
+        if (v != 0) atomicAdd((unsigned long long*)&fa.acc[i], (unsigned long long)v);
+    }
+    if (t == 255 && blockIdx.x == 0 && ok && !too_big) atomicAdd(&counters[1], (unsigned long long)total_pairs);
+    ATOMICS_DONE();
+    __syncthreads();
+    if (t == 0) {
+        const unsigned long long ticket = atomicAdd(&counters[5], 1ull);
+        s_last = (ticket == (unsigned long long)gridDim.x - 1ull);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (ok && too_big) {   // nothing was priced, nothing is reset: the tiled kernels find the step as k_scan and k_tm left it
+        if (t == 0) { counters[5] = 0; __threadfence_system(); if (host_res) host_res[0] = seq | NEED_FIN; __threadfence_system(); }
+        return;
+    }
+    // (was this kernel needed at all?  The host keeps a running mean of the answer and lets k_tm finish the steps by itself again
+    // when it is mostly "no": eval_sync)
+    if (t == 0 && host_res) host_res[1 + MAXK * N_OPS] = (total_pairs > 0 || nq_total > (unsigned long long)FIN_INLINE_Q) ? 1 : 0;
+    hand_out(fa.acc, counters, fa.sync, K, d_q_out, host_res, seq);
+    STAMP(20, t == 0);
 #undef XF_
 #undef CREP_
 #undef CMASK_
@@ -3846,6 +4056,16 @@ struct Ctx {
     int event_every = 8;          // a HIP event pair around k_scan on every n-th evaluation (they cost a few us of gaps)
     long long eval_calls = 0;
     DevArgs* d_args = nullptr;    // [2]: one argument block per layout buffer
+    // GRAAL_EVAL_TIMING: host clock of the synchronous evaluation, printed when the context is destroyed (us per step: launches, until
+    // k_tm asked for the finishing kernels, their launches, until the result) -- [0] steps, [1] steps that needed them
+    // reference arithmetic, one rank: `mid_run` = k_strict_flat goes out behind every scan and k_tm's last block does not try to
+    // finish the step (set while most steps need more than k_tm: need_ema, a running mean of "this step did"); flat_tried = this
+    // step's flat kernel has been launched (if it also says NEED_FIN, the tiled kernels follow)
+    bool mid_run = false, flat_tried = false, step_needed_fin = false;
+    double need_ema = 0.0;
+    bool eval_timing = getenv("GRAAL_EVAL_TIMING") != nullptr;
+    double et[6] = {0, 0, 0, 0, 0, 0};
+    long long et_n[2] = {0, 0};
     long long* h_res = nullptr;   // pinned host: [0] sequence number of the published step, [1..] K*13 sums
     long long* h_stats = nullptr; // pinned host: [0] sequence number, [1..16] the statistics words of k_stats_fin
     long long* h_full = nullptr;  // pinned host: [0] sequence number, [1..4] the sums / flags of the last full evaluation (k_full_pub)
@@ -4146,8 +4366,8 @@ bool strict_dense_cfg()
 // reference arithmetic: what k_tm left (sets larger than STRICT_INLINE_M, the queued contacts when there are many), hand-out
 int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out, bool publish, hipStream_t st)
 {
-    CK(hipEventRecord(h->ev_tm, h->aux));      // (k_tm is on the auxiliary stream, done or not: the event completes behind it)
-    CK(hipStreamWaitEvent(st, h->ev_tm, 0));   // the tables are complete before either kernel starts: nobody spins for them
+    // k_strict_cull needs k_tm's tables and nothing of the scan: it goes out on the AUXILIARY stream, behind k_tm, and runs under
+    // the scan; k_strict waits for both (the event on the auxiliary stream, the scan in front of it on its own)
     FinArgs fa;
     fa.tm_done = h->tm_done; fa.step_hdr = h->step_hdr; fa.counters = (unsigned long long*)(h->d_scalars + 10); fa.queue = h->queue;
     fa.cnt = h->cnt; fa.multi = h->single_sub ? 0 : 1;
@@ -4160,6 +4380,8 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
     sx.list_cap = 0;
     sx.seg = 64;
     if (strict_dense_cfg()) {
+        CK(hipEventRecord(h->ev_tm, h->aux));      // (k_tm is on the auxiliary stream, done or not: the event completes behind it)
+        CK(hipStreamWaitEvent(st, h->ev_tm, 0));   // the tables are complete before the kernel starts: nobody spins for them
         k_strict_dense<<<1024, 256, 0, st>>>(fa, sx, fA, K, rank, world, d_q_out, publish ? h->res_dev : nullptr, h->seq);
         CK(hipGetLastError());
         return GRAAL_OK;
@@ -4185,6 +4407,7 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
     const unsigned long long need = (unsigned long long)K * nt * (nt + 1ull) / 2ull * (unsigned long long)(64 / seg) + 64ull;
     if (need > h->slist_cap) {
         CK(hipStreamSynchronize(st));
+        CK(hipStreamSynchronize(h->aux));
         if (h->d_slist) CK(hipFree(h->d_slist));
         h->d_slist = nullptr;
         const unsigned long long cap = std::max<unsigned long long>(need + need / 2ull, 1ull << 16);
@@ -4198,13 +4421,47 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
     const int no_window = (sx.quirk && h->n_ubins > 0) ? 1 : 0;
     // rows of candidate units = tiles of the affected sets: a block per row up to the chip's width
     const int cull_blocks = (int)std::min<unsigned long long>(1024ull, std::max<unsigned long long>(1ull, (unsigned long long)K * nt));
-    k_strict_cull<<<cull_blocks, 256, 0, st>>>(h->tabs, h->geo, h->link, h->cbase, h->perm, fA, K, rank, world, sx.reach_bp, no_window, seg,
-                                               h->d_slist, h->d_slist_n, h->slist_cap, (unsigned long long*)(h->d_scalars + 10));
+    k_strict_cull<<<cull_blocks, 256, 0, h->aux>>>(h->tabs, h->geo, h->link, h->cbase, h->perm, fA, K, rank, world, sx.reach_bp, no_window, seg,
+                                                   h->d_slist, h->d_slist_n, h->slist_cap, (unsigned long long*)(h->d_scalars + 10));
     CK(hipGetLastError());
+    CK(hipEventRecord(h->ev_tm, h->aux));      // (behind k_tm and the cull: tables and unit list complete -- nobody spins for them)
+    CK(hipStreamWaitEvent(st, h->ev_tm, 0));
     if (h->single_sub) k_strict<false><<<blocks, 256, strict_dyn_lds(K), st>>>(fa, sx, fA, K, h->d_slist, h->d_slist_n, d_q_out, publish ? h->res_dev : nullptr, h->seq);
     else k_strict<true><<<blocks, 256, strict_dyn_lds(K), st>>>(fa, sx, fA, K, h->d_slist, h->d_slist_n, d_q_out, publish ? h->res_dev : nullptr, h->seq);
     CK(hipGetLastError());
     return GRAAL_OK;
+}
+
+// reference arithmetic, small affected sets (k_strict_flat): behind the scan on its stream, no event, no unit list
+int launch_flat(Ctx* h, int fA, const Neigh* nbp /* nullptr: the neighbours of the evaluation in flight */, int K, long long* d_q_out, bool publish, hipStream_t st)
+{
+    FinArgs fa;
+    fa.tm_done = h->tm_done; fa.step_hdr = h->step_hdr; fa.counters = (unsigned long long*)(h->d_scalars + 10); fa.queue = h->queue;
+    fa.cnt = h->cnt; fa.multi = h->single_sub ? 0 : 1;
+    fa.tabs = h->tabs; fa.geo = h->geo; fa.stat = h->stat_frag; fa.acc = h->d_acc; fa.sync = h->d_sync;
+    fa.ln_tab = nullptr; fa.lut_n = 0; fa.skip = 0; fa.seg = 0; fa.norm_u = -1.0f; fa.upw = 4; fa.wq = nullptr;
+    StrictArgs sx;
+    sx.perm = h->perm; sx.cbase = h->cbase; sx.lcontbp = h->soa[h->cur].p[F_LCONTBP]; sx.link = h->link; sx.nfpb = h->nfpb; sx.par = h->par;
+    sx.quirk = (h->mode & GRAAL_MODE_REF_TRANS_ACCU) ? 1 : 0;
+    sx.reach_bp = reach_bp(h);
+    sx.list_cap = 0;
+    sx.seg = 64;
+    static const int blocks_env = getenv("GRAAL_FLAT_BLOCKS") ? atoi(getenv("GRAAL_FLAT_BLOCKS")) : 0;
+    const int blocks = blocks_env > 0 ? std::min(blocks_env, FLAT_BLOCKS) : FLAT_BLOCKS;
+    Neigh nb;
+    for (int k = 0; k < MAXK; k++) nb.fB[k] = nbp ? nbp->fB[k] : h->last_fB[k];
+    if (h->single_sub) k_strict_flat<false><<<blocks, 256, 0, st>>>(fa, sx, fA, nb, K, d_q_out, publish ? h->res_dev : nullptr, h->seq);
+    else k_strict_flat<true><<<blocks, 256, 0, st>>>(fa, sx, fA, nb, K, d_q_out, publish ? h->res_dev : nullptr, h->seq);
+    CK(hipGetLastError());
+    return GRAAL_OK;
+}
+
+// may this evaluation use k_strict_flat?  One rank only: the flat and the tiled kernels deal the pairs to the ranks differently, and a
+// rank picks the one or the other by what ITS k_tm / k_scan found
+bool flat_allowed(const Ctx* h, int world)
+{
+    static const bool no_flat = getenv("GRAAL_NO_FLAT") != nullptr;
+    return !no_flat && (h->mode & GRAAL_MODE_STRICT) && !strict_dense_cfg() && world == 1 && h->publish;
 }
 
 } // namespace
@@ -4330,6 +4587,13 @@ int graal_create(int device, graal_ctx** out)
 void graal_destroy(graal_ctx* h)
 {
     if (!h) return;
+    if (h->eval_timing && h->et_n[0]) {
+        const double n = (double)h->et_n[0], m = (double)std::max<long long>(h->et_n[1], 1);
+        fprintf(stderr, "graal eval timing: %lld synchronous evaluations, launches %.1f us each; %lld finished by k_tm (%.1f us from launch to result); "
+                        "%lld needed k_fin / k_strict: %.1f us until k_tm said so, %.1f us to launch them, %.1f us until the result (%.1f us in all)\n",
+                h->et_n[0], h->et[0] / n, h->et_n[0] - h->et_n[1], h->et[4] / (double)std::max<long long>(h->et_n[0] - h->et_n[1], 1),
+                h->et_n[1], h->et[1] / m, h->et[2] / m, h->et[3] / m, h->et[5] / m);
+    }
     if (h->stream) {
         (void)hipSetDevice(h->device);
         (void)hipStreamSynchronize(h->stream);
@@ -4362,10 +4626,12 @@ int graal_set_params(graal_ctx* h, const float* p)
 {
     if (h && h->stream) (void)hipStreamSynchronize(h->stream); // (graal_begin_step may have left its relabel kernels running)
     if (!h || !p) return GRAAL_E_ARG;
-    if (h->have_par && memcmp(&h->par, p, sizeof(Par)) == 0) return GRAAL_OK;   // (re-sending the parameters in force)
-    memcpy(&h->par, p, sizeof(Par));
-    if (!(h->par.v_inter > 0.0f)) return fail(h, GRAAL_E_ARG, "v_inter must be > 0 (the sparse form prices every pixel at >= v_inter)");
-    if (!(h->par.d_max > 0.0f) || !(h->par.d_max < 2.0e6f)) return fail(h, GRAAL_E_ARG, "d_max out of range");
+    Par np_;   // (validated before it is compared or committed: h->par never holds rejected values)
+    memcpy(&np_, p, sizeof(Par));
+    if (!(np_.v_inter > 0.0f)) return fail(h, GRAAL_E_ARG, "v_inter must be > 0 (the sparse form prices every pixel at >= v_inter)");
+    if (!(np_.d_max > 0.0f) || !(np_.d_max < 2.0e6f)) return fail(h, GRAAL_E_ARG, "d_max out of range");
+    if (h->have_par && memcmp(&h->par, &np_, sizeof(Par)) == 0) return GRAAL_OK;   // (re-sending the parameters in force)
+    h->par = np_;
     h->have_par = true;
     compute_t_all(h, h->t_hist.empty());
     CK(hipSetDevice(h->device));
@@ -4863,9 +5129,19 @@ int graal_eval_full_q(graal_ctx* h, int64_t q_out[2])
         const RepArgs R = rep_args(h);
         k_rep_full<<<blocks_for((long long)h->n_dup * h->n_bins, 256), 256, 0, h->stream>>>(R, h->d_scalars + 17, h->d_scalars + FULL_BAD);
     }
+    // the accumulators (d_scalars[8], [9], [17], [FULL_BAD]) are zero at rest because k_full_pub clears them behind the sums it
+    // publishes: a call that fails between its first kernel and that publication must not leave partial sums to the next one
+    auto reset_acc = [&]() {
+        (void)hipStreamSynchronize(h->stream);
+        (void)hipGetLastError();
+        (void)hipMemset(h->d_scalars + 8, 0, 2 * sizeof(long long));
+        (void)hipMemset(h->d_scalars + 17, 0, sizeof(long long));
+        (void)hipMemset(h->d_scalars + FULL_BAD, 0, sizeof(long long));
+    };
+    { const hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { reset_acc(); h->err = hipGetErrorString(e_); return GRAAL_E_HIP; } }
     h->full_seq += 1;
     k_full_pub<<<1, 64, 0, h->stream>>>(h->d_scalars, h->h_full, h->full_seq);
-    CK(hipGetLastError());
+    { const hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { reset_acc(); h->err = hipGetErrorString(e_); return GRAAL_E_HIP; } }
     {
         volatile long long* p = h->h_full;
         bool seen = false;
@@ -4875,8 +5151,8 @@ int graal_eval_full_q(graal_ctx* h, int64_t q_out[2])
             __builtin_ia32_pause();
         }
         if (!seen) {
-            CK(hipStreamSynchronize(h->stream));
-            if (p[0] != h->full_seq) return fail(h, GRAAL_E_HIP, "the full evaluation did not publish its sums");
+            const hipError_t e_ = hipStreamSynchronize(h->stream);
+            if (e_ != hipSuccess || p[0] != h->full_seq) { reset_acc(); return fail(h, GRAAL_E_HIP, "the full evaluation did not publish its sums"); }
         }
         __sync_synchronize();
     }
@@ -4923,7 +5199,7 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     ta.strict = strict ? 1 : 0;
     ta.quirk = (h->mode & GRAAL_MODE_REF_TRANS_ACCU) ? 1 : 0;
     ta.nc = h->d_scalars + NC_WORD;
-    ta.strict_inline_m = strict_dense_cfg() ? -1 : STRICT_INLINE_M;
+
     ta.geo = h->geo; ta.link = h->link; ta.cbase = h->cbase; ta.mates = h->mates; ta.tabs = h->tabs; ta.step_hdr = h->step_hdr;
     static const bool no_finisher = getenv("GRAAL_NO_FINISHER") != nullptr; // always finish with k_fin (diagnostics)
     ta.flags = h->d_flags;
@@ -4933,7 +5209,12 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     // (late stage -- a few long contigs hold nearly every fragment: nearly every step needs k_fin anyway, so it is launched
     // right behind the scan instead of after k_tm's verdict has made the round trip through the host, ~10 us per step)
     const bool late_stage = h->max_lcont > 128 && (long long)h->n_contigs * 64 < (long long)h->n;
-    ta.host_res = (h->publish && (world == 1 || h->x_host) && !no_finisher && h->finisher_ok && !h->has_rep && !late_stage && !(strict && strict_dense_cfg())) ? h->res_dev : nullptr;
+    const bool mid = flat_allowed(h, world) && h->mid_run && !late_stage && h->finisher_ok && !no_finisher;
+    h->flat_tried = false;
+    // (with k_strict_flat behind the scan k_tm prices nothing itself: one thread per pair walking the classes is 30-50 us for a set
+    // of 20 fragments, and the flat kernel would wait for it)
+    ta.strict_inline_m = strict_dense_cfg() ? -1 : (mid ? 0 : STRICT_INLINE_M);
+    ta.host_res = (h->publish && (world == 1 || h->x_host) && !no_finisher && h->finisher_ok && !h->has_rep && !late_stage && !mid && !(strict && strict_dense_cfg())) ? h->res_dev : nullptr;
     ta.wait_ticks = fin_wait_ticks(h);
     ta.counters = (unsigned long long*)(h->d_scalars + 10); ta.queue = h->queue; ta.cnt = h->cnt; ta.multi = h->single_sub ? 0 : 1; ta.stat = h->stat_frag;
     ta.lcontbp = h->soa[h->cur].p[F_LCONTBP]; ta.acc = h->d_acc; ta.nfpb = h->nfpb; ta.par = h->par;
@@ -4969,7 +5250,9 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     }
     if (strict) {
         if (ta.host_res == nullptr) {
-            int rc_ = launch_strict(h, fA, K, rank, world, (long long*)d_q_out, h->publish, st);
+            int rc_ = 0;
+            if (mid) { rc_ = launch_flat(h, fA, &nb, K, (long long*)d_q_out, h->publish, st); h->flat_tried = true; }
+            else rc_ = launch_strict(h, fA, K, rank, world, (long long*)d_q_out, h->publish, st);
             if (rc_) return rc_;
             if (!h->publish) { CK(hipEventRecord(h->ev_fin, st)); h->fin_pending = true; }
         }
@@ -4997,10 +5280,16 @@ static int eval_sync(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int
         h->res_host = h->x_host + off;
         h->res_dev = h->x_dev + off;
     } else { h->res_host = h->res_dev = h->h_res; }
+    auto now_us = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = h->eval_timing ? now_us() : 0.0;
+    double t1 = 0.0, t2 = 0.0, t3 = 0.0;
     h->publish = true;
+    h->step_needed_fin = false;
     int rc = graal_eval_candidates_q(h, fA, fB, K, max_id, rank, world, (int64_t*)h->d_qout, nullptr);
     h->publish = false;
     if (rc) return rc;
+    const bool launched_mid = h->flat_tried;   // (k_strict_flat went out with the step: it reports whether it was needed)
+    if (h->eval_timing) t1 = now_us();
     volatile long long* res = h->res_host;
     bool seen = false;
     for (long long spin = 0; spin < 200000000ll; spin++) {
@@ -5009,11 +5298,18 @@ static int eval_sync(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int
         if (v == (want | NEED_FIN) || v == (want | NEED_FIN | GAVE_UP)) { // k_tm left (the heavy part of) the step to k_fin
             if ((v & GAVE_UP) && ++h->gave_up >= 3) h->finisher_ok = false;
             res[0] = 0;
+            if (h->eval_timing) t2 = now_us();
             h->publish = true;
-            rc = (h->mode & GRAAL_MODE_STRICT) ? launch_strict(h, fA, K, rank, world, (long long*)h->d_qout, true, h->stream)
-                                               : launch_fin(h, K, rank, world, (long long*)h->d_qout, true, h->stream);
+            h->step_needed_fin = true;
+            if ((h->mode & GRAAL_MODE_STRICT) && flat_allowed(h, world) && !h->flat_tried) { // small sets first; if they are not, it says NEED_FIN again
+                h->flat_tried = true;
+                rc = launch_flat(h, fA, nullptr, K, (long long*)h->d_qout, true, h->stream);
+            } else
+                rc = (h->mode & GRAAL_MODE_STRICT) ? launch_strict(h, fA, K, rank, world, (long long*)h->d_qout, true, h->stream)
+                                                   : launch_fin(h, K, rank, world, (long long*)h->d_qout, true, h->stream);
             h->publish = false;
             if (rc) return rc;
+            if (h->eval_timing) t3 = now_us();
             continue;
         }
         if ((spin & 0xfffff) == 0xfffff && hipStreamQuery(h->stream) != hipErrorNotReady && hipStreamQuery(h->aux) != hipErrorNotReady) {
@@ -5028,6 +5324,20 @@ static int eval_sync(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int
         CK(hipStreamSynchronize(h->aux));
         if (res[0] != want && res[0] != -want) return fail(h, GRAAL_E_HIP, "the step's last block did not publish its results");
     }
+    if (world == 1 && (h->mode & GRAAL_MODE_STRICT) && (res[0] == want)) {
+        // running mean of "k_tm alone would not have finished this step": above 1/2 the flat kernel goes out with every step and
+        // k_tm does not wait for the scan; below 1/4 k_tm finishes the steps by itself again
+        const bool needed = launched_mid ? (res[1 + MAXK * N_OPS] != 0 || h->step_needed_fin) : h->step_needed_fin;
+        h->need_ema = 0.9 * h->need_ema + (needed ? 0.1 : 0.0);
+        if (!h->mid_run && h->need_ema > 0.5) h->mid_run = true;
+        else if (h->mid_run && h->need_ema < 0.25) h->mid_run = false;
+    }
+    if (h->eval_timing) {
+        const double t4 = now_us();
+        h->et_n[0] += 1; h->et[0] += t1 - t0;
+        if (t2 > 0.0) { h->et_n[1] += 1; h->et[1] += t2 - t1; h->et[2] += t3 - t2; h->et[3] += t4 - t3; h->et[5] += t4 - t0; }
+        else h->et[4] += t4 - t1;
+    }
     if (res[0] == -want && h->spin_used) {
         // k_tm gave up waiting for k_scan's announcement: the two kernels did not run side by side (a tool serialising dispatches).
         // Everything of the step has ended by now; put the step's accumulators back to rest and repeat it ordered by the host --
@@ -5036,7 +5346,8 @@ static int eval_sync(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int
         if (h->pub_in_flight) h->stats_pub_pending = true;   // (its publication block gave up with the others)
         CK(hipStreamSynchronize(h->stream));
         CK(hipStreamSynchronize(h->aux));
-        CK(hipMemset(h->d_scalars + 10, 0, 8 * sizeof(long long)));
+        CK(hipMemset(h->d_scalars + 10, 0, 3 * sizeof(long long)));   // step counters [0..2]; NOT words 13 / 14 (layout statistics: stale flag, circular contigs)
+        CK(hipMemset(h->d_scalars + 15, 0, 2 * sizeof(long long)));   // ticket, error
         CK(hipMemset(h->d_scalars + 10 + NF_OFF, 0, 3 * sizeof(long long)));
         CK(hipMemset(h->d_scalars + SLIST_N, 0, sizeof(long long)));
         CK(hipMemset(h->d_acc, 0, MAXK * N_OPS * sizeof(long long)));

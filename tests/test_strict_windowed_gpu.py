@@ -1,5 +1,5 @@
-"""GPU: the windowed reference-arithmetic candidate kernels (k_tm's own pricing of small sets, k_strict_cull + k_strict, the
-finishing block's contacts) -- the path `reference_arithmetic="strict"` runs and bench.py measures.
+"""GPU: the windowed reference-arithmetic candidate kernels (k_tm's own pricing of small sets, k_strict_flat for sets of up to
+~280 fragments, k_strict_cull + k_strict beyond, the finishing block's contacts) -- the path `reference_arithmetic="strict"` runs and bench.py measures.
 
 * equal, BIT FOR BIT, to k_strict_dense -- the O(m^2) kernel that prices every pixel of contig(fA) u contig(fB) under every
   candidate the way sub_compute_likelihood does (kernels3.cu:3259-3718) -- run in a child process (GRAAL_STRICT_DENSE=1);
@@ -32,6 +32,13 @@ def test_windowed_kernels_equal_the_dense_validation_kernel_bit_for_bit(tmp_path
     dense = np.load(out)
     got = strict_cases.run_cases()
     assert os.environ.get("GRAAL_STRICT_DENSE") in (None, "0")
+    # the tiled kernels (k_strict_cull + k_strict) on the small sets too, which k_strict_flat takes by default
+    out_t = str(tmp_path / "tiled.npz")
+    subprocess.check_call([sys.executable, "-m", "tests.strict_cases", out_t, "0,1,2,3"], cwd=ROOT, env=dict(os.environ, GRAAL_NO_FLAT="1"), timeout=1200)
+    tiled = np.load(out_t)
+    for i, (name, *_rest) in enumerate(strict_cases.CASES):
+        if "case%d" % i in tiled:
+            assert np.array_equal(tiled["case%d" % i], got[name]), name
     for i, (name, *_rest) in enumerate(strict_cases.CASES):
         want = dense["case%d" % i]
         assert got[name].shape == want.shape

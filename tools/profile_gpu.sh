@@ -4,6 +4,7 @@
 # Usage: tools/profile_gpu.sh <tag> [c5|late|c2]     -> gpurun_out/prof_<tag>/summary_<tag>.{md,json}
 #   c5   : the bench workload (C5 exploded + 2,000 warm-up steps), 100 timed steps
 #   late : C5 on its 7 original contigs (bench.py --layout original), 30 timed steps
+#   c4   : the C4 stand-in (40,000 bins, 8 M contacts), explode + 2 cycles of a headless run (PROF_TRACE_ONLY=1: kernel trace only)
 #   c2   : the C2 stand-in (1,086 bins x 3 sub-fragments) on its 7 contigs, 400 full MCMC steps (tools/step_breakdown.py)
 set -u
 TAG=${1:-r02}
@@ -16,16 +17,19 @@ case $WHAT in
   c5)   ARGS="$REPO/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-late-stage --no-hbm-control" ;;
   late) ARGS="$REPO/bench.py --layout original --steps 30 --warmup 5 --mcmc-warmup 0 --no-cpu-baseline --no-late-stage --no-hbm-control" ;;
   c2)   ARGS="$REPO/tools/step_breakdown.py --n-bins 1086 --nnz 120000 --n-sub 3 --original --steps 400" ;;
+  c4)   ARGS="$REPO/tools/run_configs.py C4 --cycles 2" ;;
 esac
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
 echo "trace rc=$?"
+if [ -z "${PROF_TRACE_ONLY:-}" ]; then
 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 $ARGS > $OUT/fetch.log 2>&1
 echo "fetch rc=$?"
 timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 $ARGS > $OUT/write.log 2>&1
 echo "write rc=$?"
 timeout 900 rocprofv3 --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d $OUT/sq -- python3 $ARGS > $OUT/sq.log 2>&1
 echo "sq rc=$?"
+fi
 cd $REPO
 python3 tools/summarize_prof.py $OUT $TAG
 # raw CSVs are too big to travel back (64 MiB cap): keep only the summaries and logs
