@@ -3234,7 +3234,7 @@ __global__ __launch_bounds__(256) void k_strict_cull(const NbTables* __restrict_
     __shared__ int s_rbase[MAXK + 1];
     __shared__ int s_row[4];      // the row's x tile: lo, hi (old bp), side
     const int t = threadIdx.x;
-    STAMP(24, blockIdx.x == 0 && t == 0);
+    STAMP(29, blockIdx.x == 0 && t == 0);
     if (t < K) {
         const SetGeo sg = set_geo(tabs[t], geo, link, cbase, fA);
         s_sg[t] = sg;

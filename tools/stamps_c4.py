@@ -39,7 +39,7 @@ for j, i in enumerate(order[:N]):
 strict = S[:, 16] > S[:, 8]          # k_strict ran in this step (its stamp is younger than the step's scan start)
 print("%d of %d steps needed k_strict; host time per step: those %.1f us, the others %.1f us" % (strict.sum(), N, host[strict].mean(), host[~strict].mean()))
 print("queued contacts per strict step: mean %.0f median %.0f max %.0f; work units: mean %.0f median %.0f max %.0f" % (C[strict][:, 2].mean(), np.median(C[strict][:, 2]), C[strict][:, 2].max(), C[strict][:, 3].mean(), np.median(C[strict][:, 3]), C[strict][:, 3].max()))
-names = [(22, "k_incr start"), (0, "k_tm start"), (8, "k_scan start"), (1, "k_tm tables done"), (10, "k_scan block 0 loop done"), (24, "k_strict_cull start"),
+names = [(22, "k_incr start"), (0, "k_tm start"), (8, "k_scan start"), (24, "k_tm: fA / fB records loaded"), (25, "k_tm: piece representatives loaded"), (26, "k_tm: transforms"), (1, "k_tm tables done"), (10, "k_scan block 0 loop done"), (29, "k_strict_cull start (tiled path only)"),
          (3, "k_tm: last neighbour's tables released"), (16, "k_strict[_flat] start (block 0)"), (21, "k_strict_flat: tables seen"), (17, "k_strict block 0 past its prologue"), (18, "k_strict units done (latest wave)"),
          (19, "k_strict queued contacts done (latest wave)"), (20, "k_strict published")]
 ref = S[strict][:, 8]

@@ -34,7 +34,7 @@ for j, i in enumerate(order[2000:2000 + N]):
     assert L.graal_debug_stamps(smp.engine._h, st.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))) == 0   # (synchronises the device)
     S[j] = st.astype(np.float64) * 0.01      # us
     host[j] = (h0 * 1e6, h1 * 1e6)
-names = [(22, "k_incr start"), (23, "k_incr end (a late block)"), (31, "statistics published"), (0, "k_tm start"), (8, "k_scan start"), (1, "k_tm tables done"),
+names = [(22, "k_incr start"), (23, "k_incr end (a late block)"), (31, "statistics published"), (0, "k_tm start"), (8, "k_scan start"), (24, "k_tm: fA / fB records loaded"), (25, "k_tm: piece representatives loaded"), (26, "k_tm: transforms"), (1, "k_tm tables done"),
          (2, "k_tm mass done"), (10, "k_scan block 0 loop done"), (4, "finisher: scan seen complete"), (5, "finisher: contacts priced"), (6, "finisher: published"),
          (7, "k_apply start"), (15, "k_apply end (last block)")]
 ref = S[:, 22]
