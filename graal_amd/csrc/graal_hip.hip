@@ -2089,6 +2089,9 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
     // ---- finisher: the last table block ----
     __shared__ int s_fin; // 0 = not the last block, 1 = finish here, 2 = leave it to k_fin
     __shared__ unsigned long long s_nq;
+    // what expands the queue's entries (q_fetch + q_codes): the neighbours' piece keys -- fetched while the block waits for the scan
+    __shared__ PieceKey s_qkeys[MAXK];
+    __shared__ unsigned s_qlive;
     // (dynamic LDS, requested only when a finisher can exist: a k_tm block that k_fin's resident blocks wait for must stay small
     // enough to be placed next to them -- tm_fin_dyn_lds / fin_blocks_no_wait)
     extern __shared__ long long s_tm_dyn[];
@@ -2103,6 +2106,7 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
         const unsigned long long after = ticket + (inl ? 1ull : (1ull + (1ull << 16)));
         if ((after & 0xffffull) == (unsigned long long)K) mode = (after >> 16) ? 2 : 1;
         s_fin = mode;
+        s_qlive = 0;
     }
     __syncthreads();
     if (s_fin == 0) return;
@@ -2122,6 +2126,11 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
         __shared__ int s_seen;
         // the other waves meanwhile copy what the pricing needs of all K tables into LDS (the other blocks released their
         // tables before they took their tickets)
+        if (t >= 64 && t < 64 + K && s_fin == 1) {   // (the other blocks released their tables before they took their tickets)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            s_qkeys[t - 64] = ta.tabs[t - 64].key;
+            if (ta.tabs[t - 64].fB != fA) atomicOr(&s_qlive, 1u << (t - 64));
+        }
         if (t >= 64 && s_fin == 1 && !ta.strict) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             const int u = t - 64, nu = (int)blockDim.x - 64;
@@ -2168,14 +2177,8 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
         if (t == 0) { ta.sync[0] = 0; __threadfence_system(); ta.host_res[0] = seq | NEED_FIN | (s_fin == 3 ? GAVE_UP : 0ll); __threadfence_system(); }
         return;
     }
-    // the queue's entries are expanded here (q_fetch + q_codes): the neighbours' piece keys, and a validated sequence tag per entry -- the
-    // scan's last stores may still be on their way
-    __shared__ PieceKey s_qkeys[MAXK];
-    __shared__ unsigned s_qlive;
-    if (t == 0) s_qlive = 0;
-    __syncthreads();
-    if (t < K) { s_qkeys[t] = ta.tabs[t].key; if (ta.tabs[t].fB != fA) atomicOr(&s_qlive, 1u << t); }
-    __syncthreads();
+    // the queue's entries are expanded here (q_fetch + q_codes): the neighbours' piece keys (above), and a validated sequence tag per
+    // entry -- the scan's last stores may still be on their way
     QSrc qs;
     qs.queue = ta.queue; qs.geo2 = reinterpret_cast<const int2*>(ta.geo); qs.cnt = ta.cnt; qs.keys = s_qkeys; qs.live = s_qlive; qs.K = K;
     qs.seq = (unsigned)seq; qs.concurrent = 1; qs.multi = ta.multi;
