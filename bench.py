@@ -498,12 +498,14 @@ def main():
         achieved = bytes_per_launch / scan_s / 1e9
         replay_s = scan_replay_ms * 1e-3
         traffic = None
+        trace_us = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")  # HBM bytes / launch from a committed rocprofv3 --pmc run
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 if tj.get("nnz") == int(nnz_local) and tj.get("n_frags") == n:
                     traffic = tj.get("hbm_bytes_per_launch")
+                    trace_us = tj.get("kernel_avg_us_rocprof_in_a_step")
             except Exception:
                 traffic = None
         out = {
@@ -531,6 +533,11 @@ def main():
                          "launch_ms_mean_without_host_stalls": float(np.mean(kept)),
                          "launches_timed": int(len(scan_ms)), "host_stall_samples": int(len(scan_ms) - len(kept)),
                          "launch_ms_samples": [round(float(x), 5) for x in scan_ms[:96]],
+                         # (an event pair around ONE kernel also spans the command processor's handling of the two markers: the
+                         # kernel-trace duration of the same kernel in the same flow is ~2 us shorter.  `frac` stays with the events.)
+                         "kernel_trace_avg_ms": None if trace_us is None else trace_us * 1e-3,
+                         "frac_kernel_trace": None if trace_us is None else bytes_per_launch / (trace_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                         "kernel_trace_source": "committed rocprofv3 --kernel-trace run of this workload (profiles/r03_rocprof_c5.md, k_scan [in a step]), not measured in this run",
                          "back_to_back_replay_ms": replay_s * 1e3,
                          "frac_back_to_back_replays": bytes_per_launch / replay_s / 1e9 / HBM_PEAK_GBS,
                          "isolated_replay_ms": scan_isolated_ms,
