@@ -326,6 +326,33 @@ int graal_step_finish(graal_ctx* h, void* mt_state, double likelihood_t, int32_t
     return hs_finish(h, (MtState*)mt_state, likelihood_t, (flags & 4) != 0, out);
 }
 
+/* A run of MCMC steps in one call (the inner loop of start_EM, cuda_lib_gl.py:2196-2220: one step_max_likelihood per fragment of the
+ * shuffled list): graal_step for ids[0], ids[1], ... with the carried total and the circular-contig count handed from step to step.
+ * Stops BEHIND the first step that does not end GRAAL_STEP_DONE (its state is in `out`: the caller finishes it exactly as after
+ * graal_step) or whose score is not finite (the caller re-evaluates).  rows[i][GRAAL_STEPS_ROW] of every step that ended DONE:
+ * o, contigs, shortest, total bp / contigs, longest, op, fragment, genome-distance half units, circular contigs, stale pastes. */
+int graal_steps(graal_ctx* h, void* mt_state, const int32_t* ids, int32_t n, int32_t delta, double likelihood_t, int32_t flags,
+                int32_t prev_circ, double* rows, int32_t* n_done, graal_step_out* out)
+{
+    if (!h || !mt_state || !ids || !rows || !n_done || !out || n < 0) return 16 + GRAAL_E_ARG;
+    *n_done = 0;
+    int rc = GRAAL_STEP_DONE;
+    for (int i = 0; i < n; i++) {
+        rc = graal_step(h, mt_state, ids[i], delta, likelihood_t, flags, prev_circ, out);
+        if (rc != GRAAL_STEP_DONE) return rc;
+        double* r = rows + (size_t)GRAAL_STEPS_ROW * (size_t)i;
+        r[0] = out->o; r[1] = (double)out->stats[0]; r[2] = (double)out->stats[5];
+        r[3] = (double)out->stats[3] / (double)out->stats[2];     // (float(st[3]) / float(st[2]) of the Python path: both exact in float64)
+        r[4] = (double)out->stats[4]; r[5] = (double)out->op_sampled; r[6] = (double)out->id_f_sampled;
+        r[7] = (double)out->dist_half_units; r[8] = (double)out->stats[6]; r[9] = (double)out->stats[7];
+        *n_done = i + 1;
+        likelihood_t = out->o;
+        prev_circ = (int32_t)out->stats[6];
+        if (!std::isfinite(out->o)) break;
+    }
+    return rc;
+}
+
 /* test hooks of the host logic (CPU-only: no device call): numpy's sum, the neighbour draw and the move sampling */
 double graal_host_np_sum(const double* a, int64_t n) { return np_sum(a, (long)n); }
 int graal_host_select_move(void* mt_state, const double* score, int32_t n, int32_t n_tmp) { return hs_select((MtState*)mt_state, score, n, n_tmp); }

@@ -39,6 +39,27 @@ def run_em(sampler, n_cycles, n_neighbours, rng=None, sample_param=False, scramb
     n_iter = np.float32(n_cycles)
     for j in range(0, n_cycles):
         rng.shuffle(list_frags)
+        if not sample_param and on_step is None and hasattr(sampler, "steps_max_likelihood"):
+            # the cycle's steps in runs behind the C ABI (sampler.steps_max_likelihood); same values, same order
+            res = sampler.steps_max_likelihood(list_frags, n_neighbours, 512, dt, np.float32(j), n_iter)
+            kuhn, lm, c1, slope, d, d_max, fact, d_nuc = [sampler.param_simu[0][k] for k in sampler.param_simu.dtype.names]
+            for i, (o, n_contigs, min_len, mean_len, max_len, op_sampled, id_f_sampled, dist, temp) in zip(list_frags, res):
+                trace.full_likelihood.append(o)
+                trace.likelihood.append(o)
+                trace.n_contigs.append(n_contigs)
+                trace.mean_len.append(mean_len)
+                trace.op_sampled.append(op_sampled)
+                trace.id_fB.append(id_f_sampled)
+                trace.id_fA.append(i)
+                trace.dist.append(dist)
+                trace.fact.append(fact)
+                trace.d.append(d)
+                trace.d_max.append(d_max)
+                trace.d_nuc.append(d_nuc)
+                trace.slope.append(slope)
+                trace.likelihood_nuisance.append(o)
+                trace.success.append(1)
+            continue
         for i in list_frags:
             o, n_contigs, min_len, mean_len, max_len, op_sampled, id_f_sampled, dist, temp = \
                 sampler.step_max_likelihood(i, n_neighbours, 512, dt, np.float32(j), n_iter)

@@ -11,7 +11,7 @@ import numpy as np
 from . import build as _build
 
 N_OPS = 13
-ABI_VERSION = 3
+ABI_VERSION = 4
 MODE_REF_TRANS_ACCU, MODE_STRICT = 1, 2
 MAX_NEIGHBOURS = 10
 Q_SCALE = float(1 << 30)
@@ -29,9 +29,10 @@ SYMBOLS = ("graal_abi_version", "graal_create", "graal_destroy", "graal_last_err
            "graal_upload_subfrags", "graal_upload_repeats", "graal_upload_contacts", "graal_upload_contacts_f32", "graal_upload_frags", "graal_download_frags",
            "graal_relabel_contigs", "graal_begin_step", "graal_begin_step_launch", "graal_layout_stats", "graal_eval_full_q", "graal_eval_candidates_q",
            "graal_eval_candidates", "graal_exchange_bytes", "graal_attach_exchange", "graal_eval_candidates_x", "graal_exchange_selftest", "graal_detach_exchange", "graal_upload_distance_ref", "graal_genome_distance", "graal_apply_move", "graal_set_finisher", "graal_set_mode", "graal_set_timing", "graal_last_timing", "graal_scan_times", "graal_time_scan", "graal_last_counters",
-           "graal_upload_proposal_tables", "graal_step", "graal_step_finish", "graal_host_np_sum", "graal_host_select_move", "graal_host_neighbours")
+           "graal_upload_proposal_tables", "graal_step", "graal_step_finish", "graal_steps", "graal_host_np_sum", "graal_host_select_move", "graal_host_neighbours")
 
 STEP_DONE, STEP_PAUSED, STEP_FALLBACK = 0, 1, 2
+STEPS_ROW = 10   # GRAAL_STEPS_ROW: doubles per step in graal_steps' rows
 
 
 class StepOut(ctypes.Structure):
@@ -102,6 +103,8 @@ def load():
         L.graal_step.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_double, ctypes.c_int32,
                                  ctypes.c_int32, ctypes.POINTER(StepOut)]
         L.graal_step_finish.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_int32, ctypes.POINTER(StepOut)]
+        L.graal_steps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, _i32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_double, ctypes.c_int32,
+                                  ctypes.c_int32, _f64p, _i32p, ctypes.POINTER(StepOut)]
         L.graal_host_np_sum.restype = ctypes.c_double
         L.graal_host_np_sum.argtypes = [_f64p, ctypes.c_int64]
         L.graal_host_select_move.argtypes = [ctypes.c_void_p, _f64p, ctypes.c_int32, ctypes.c_int32]
@@ -382,6 +385,18 @@ class Engine:
         if rc >= 16:
             self._ck(rc - 16, "graal_step")
         return rc
+
+    def steps(self, mt_addr, ids, delta, likelihood_t, flags, prev_circ):
+        """graal_steps: a run of steps in one call.  Returns (rc of the last step started, rows[n_done, STEPS_ROW]); a step that
+        did not end STEP_DONE has left its state in self.step_out, like step()."""
+        ids = _c(ids, np.int32)
+        rows = np.empty((len(ids), STEPS_ROW), dtype=np.float64)
+        n_done = ctypes.c_int32(0)
+        rc = self._L.graal_steps(self._h, mt_addr, ids.ctypes.data_as(_i32p), len(ids), delta, likelihood_t, flags, prev_circ,
+                                 rows.ctypes.data_as(_f64p), ctypes.byref(n_done), self._step_ref)
+        if rc >= 16:
+            self._ck(rc - 16, "graal_steps")
+        return rc, rows[:n_done.value]
 
     def step_finish(self, mt_addr, likelihood_t, flags):
         rc = self._L.graal_step_finish(self._h, mt_addr, likelihood_t, flags, self._step_ref)

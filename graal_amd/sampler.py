@@ -775,6 +775,13 @@ class sampler(object):
             self.dist_inter_genome()                               # (uploads the reference layout of the distance once)
         rc = e.step(self._mt_addr, id_fA, int(delta), 0.0 if self.likelihood_t is None else float(self.likelihood_t), flags,
                     self._n_circ_prev)
+        return self._step_c_tail(rc, id_fA, flags, resync, F_t)
+
+    def _step_c_tail(self, rc, id_fA, flags, resync, F_t):
+        """What follows graal_step's return (also for the step graal_steps stopped at): the full re-evaluations, the rare fallback
+        to numpy's own selection, the 9-tuple."""
+        e = self.engine
+        so = e.step_out
         if rc == STEP_FALLBACK:
             return None
         st = so.stats
@@ -813,6 +820,64 @@ class sampler(object):
             self._force_full = True   # (a flagged candidate won: the carried total is not a likelihood; re-evaluate next step)
         return (o, int(st[0]), np.int32(st[5]), float(st[3]) / float(st[2]), np.int32(st[4]), op_sampled, id_f_sampled, dist, F_t)
 
+    # ------------------------------------------------------------------ a run of MCMC steps (the inner loop of start_EM)
+    def steps_max_likelihood(self, ids, delta, size_block=512, dt=0, t=0, n_step=1):
+        """step_max_likelihood for every fragment of `ids`, in order (the inner loop of start_EM, ``cuda_lib_gl.py:2196-2220``);
+        returns the list of their 9-tuples.  Runs of steps that need nothing from Python -- no blacklisted fragment, no full
+        re-evaluation due, temperature 1 -- go through graal_steps in ONE call each (the per-step Python around graal_step is
+        ~25 us of a 55-90 us step); everything else takes step_max_likelihood, and so does the step a run stopped at."""
+        ids = [int(i) for i in ids]
+        out = []
+        i = 0
+        n = len(ids)
+        F_t = self.temperature(t, n_step)
+        while i < n:
+            room = self.resync_every - self._steps_since_full - 1 if self.likelihood_t is not None and not self._force_full else 0
+            if not (self._c_step and F_t == 1.0 and room >= 2 and (not self.compute_dist or self._dist_ref_uploaded)):
+                out.append(self.step_max_likelihood(ids[i], delta, size_block, dt, t, n_step))
+                i += 1
+                continue
+            j = i
+            while j < n and j - i < room and ids[j] not in self._black_set:
+                j += 1
+            if j - i < 2:
+                out.append(self.step_max_likelihood(ids[i], delta, size_block, dt, t, n_step))
+                i += 1
+                continue
+            e = self.engine
+            flags = (0 if self._single_sub else 1) | (4 if self.compute_dist else 0)
+            rc, rows = e.steps(self._mt_addr, ids[i:j], int(delta), float(self.likelihood_t), flags, self._n_circ_prev)
+            for r in rows:
+                o = float(r[0])
+                if self.compute_dist:
+                    norm_distance = 3.0 * (len(self.np_init_prev) - self.n_frags_4_dist)
+                    dist = (norm_distance - 0.5 * int(r[7])) / norm_distance
+                else:
+                    dist = 0.0
+                out.append((o, int(r[1]), np.int32(r[2]), float(r[3]), np.int32(r[4]), int(r[5]), int(r[6]), dist, F_t))
+            k = len(rows)
+            if k:
+                last = rows[-1]
+                self.n_stale_paste += int(rows[:, 9].sum())
+                self._steps_since_full += k
+                self._n_circ_prev = int(last[8])
+                self.o = self.likelihood_t = float(last[0])
+                if rc == STEP_DONE:              # (what the last step left, as after step_max_likelihood)
+                    so = e.step_out
+                    K = int(so.n_neighbours)
+                    self.last_neighbours = list(so.neighbours[:K])
+                    self.score = e.step_scores[:K * self.n_tmp_struct]
+                if not np.isfinite(self.likelihood_t):
+                    self._force_full = True
+            i += k
+            if rc != STEP_DONE and i < n:        # the step the run stopped at: its state is in step_out, as after graal_step
+                res = self._step_c_tail(rc, ids[i], flags, False, F_t)
+                if res is None:                  # (handed back before anything was drawn: the Python path takes it)
+                    res = self._step_py(ids[i], delta, size_block, dt, t, n_step)
+                out.append(res)
+                i += 1
+        return out
+
     # ------------------------------------------------------------------ one MCMC step
     def step_max_likelihood(self, id_fA, delta, size_block=512, dt=0, t=0, n_step=1):
         """``cuda_lib_gl.py:1793-1980``.  Returns (o, n_contigs, min_len, mean_len_bp, max_len, op_sampled,
@@ -822,6 +887,10 @@ class sampler(object):
             res = self._step_c(id_fA, delta, t, n_step)
             if res is not None:
                 return res
+        return self._step_py(id_fA, delta, size_block, dt, t, n_step)
+
+    def _step_py(self, id_fA, delta, size_block=512, dt=0, t=0, n_step=1):
+        """The step with its host logic in Python (blacklisted fragments, temperatures other than 1, whatever graal_step hands back)."""
         # relabel + index are launched; the proposal is drawn while they run (nothing between here and the reference's
         # return_neighbours call draws from the generator, so the stream is the reference's); then the statistics are read
         self.engine.begin_step_launch()

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GRAAL_ABI_VERSION 3
+#define GRAAL_ABI_VERSION 4
 #define GRAAL_N_OPS 13        /* candidates per (fA, fB): cuda_lib_gl.py:112 n_tmp_struct */
 #define GRAAL_MAX_NEIGHBOURS 10 /* neighbours scored by one scan pass (the reference proposes at most n_neighbors = 10, cuda_lib_gl.py:444) */
 #define GRAAL_Q_BITS 30
@@ -228,6 +228,14 @@ int graal_upload_proposal_tables(graal_ctx* h, const int32_t* xk, const float* p
 int graal_step(graal_ctx* h, void* mt_state, int32_t fA, int32_t delta, double likelihood_t, int32_t flags, int32_t prev_circ,
                graal_step_out* out);
 int graal_step_finish(graal_ctx* h, void* mt_state, double likelihood_t, int32_t flags, graal_step_out* out);
+/* A run of steps in one call -- the inner loop of start_EM (cuda_lib_gl.py:2196-2220): graal_step for ids[0 .. n), the carried total
+ * and the circular-contig count handed from step to step.  Stops behind the first step that does not end GRAAL_STEP_DONE (`out` holds
+ * its state: finish it as after graal_step) or whose score is not finite.  *n_done = steps that ended DONE; rows[i][GRAAL_STEPS_ROW] =
+ * o, contigs, shortest contig, total bp / contigs, longest contig, op, fragment, genome-distance half units, circular contigs,
+ * stale pastes of step i.  Returns the last step's graal_step code. */
+#define GRAAL_STEPS_ROW 10
+int graal_steps(graal_ctx* h, void* mt_state, const int32_t* ids, int32_t n, int32_t delta, double likelihood_t, int32_t flags,
+                int32_t prev_circ, double* rows, int32_t* n_done, graal_step_out* out);
 /* test hooks of that logic; no device needed (a handle whose graal_create failed for lack of a GPU will do) */
 double graal_host_np_sum(const double* a, int64_t n);
 int graal_host_select_move(void* mt_state, const double* score, int32_t n, int32_t n_tmp);

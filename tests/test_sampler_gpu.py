@@ -297,3 +297,30 @@ def test_c_step_equals_python_step_and_survives_its_fallbacks(monkeypatch):
         assert np.array_equal(got[0], want[0]), (env, fin)
         assert got[1] == want[1] and got[2] == want[2] and got[3] == want[3], (env, fin)
         assert got[4] == want[4] and np.array_equal(got[5], want[5]), (env, fin)
+
+
+def test_runs_of_steps_in_one_call_equal_single_steps():
+    """sampler.steps_max_likelihood (graal_steps: a run of MCMC steps behind the C ABI in one call, em.run_em's path) against one
+    step_max_likelihood call per step (run_em with a per-step callback): traces, likelihood series, statistics, final layout and
+    generator state -- with a full re-evaluation due every 7th step, so that the runs are cut and resumed all the time."""
+    P = problem(1, 53, 160, 6000)
+
+    def go(batched, resync):
+        rng = np.random.RandomState(53)
+        g = make_gpu_sampler(P, rng)
+        g.resync_every = resync
+        calls = []
+        t = em.run_em(g, 2, 4, rng=rng, on_step=None if batched else (lambda j, i, tr: calls.append(i)))
+        st = rng.get_state(legacy=False)["state"]
+        g.gpu_vect_frags.copy_from_gpu()
+        lay = {k: np.copy(getattr(g.gpu_vect_frags, k)) for k in O.FIELDS}
+        out = (np.asarray(t.mutations()), list(t.likelihood), list(t.full_likelihood), list(t.n_contigs), list(t.mean_len), int(st["pos"]),
+               st["key"].copy(), lay, g.n_stale_paste)
+        g.free_gpu()
+        return out
+    for resync in (512, 7):
+        a, b = go(True, resync), go(False, resync)
+        assert np.array_equal(a[0], b[0]) and a[1] == b[1] and a[2] == b[2] and a[3] == b[3] and a[4] == b[4], resync
+        assert a[5] == b[5] and np.array_equal(a[6], b[6]) and a[8] == b[8], resync
+        for k in O.FIELDS:
+            assert np.array_equal(a[7][k], b[7][k]), (resync, k)
