@@ -314,18 +314,24 @@ def main():
     # command-processor marker gaps: 64 us per step with a pair on every step against 40 without, profiles/r02_event_sampling.log);
     # right behind it the same steps run once more, untimed, with a pair on EVERY step (at most 64): those samples -- in-step
     # launches of the same proposals -- price the roofline, so that a 20-step run has 20 of them rather than 2.
-    EVENT_EVERY = int(os.environ.get("GRAAL_BENCH_EVENT_EVERY", 8))
+    # (a run of fewer than 64 steps -- the driver's 20 -- carries ONE pair in its timed region: three pairs were 2.3 us per step of it)
+    EVENT_EVERY = int(os.environ.get("GRAAL_BENCH_EVENT_EVERY", 8 if args.steps >= 64 else max(8, args.steps)))
     smp.engine.set_timing(EVENT_EVERY)
     for f, nb in props[:args.warmup]:
         smp._candidate_deltas(f, nb, max_id)
     n_cand = 0
     sync_all()
     t0 = time.perf_counter()
+    step_t = [] if os.environ.get("GRAAL_BENCH_STEP_TIMES") else None   # (diagnostics: host clock after every step of the timed region)
     for f, nb in props[args.warmup:args.warmup + args.steps]:
         smp._candidate_deltas(f, nb, max_id)   # records a HIP event pair around k_scan on the stream it runs on
         n_cand += 13 * len(nb)
+        if step_t is not None:
+            step_t.append(time.perf_counter())
     sync_all()
     elapsed = time.perf_counter() - t0
+    if step_t is not None and rank == 0:
+        print("per-step us:", " ".join("%.1f" % (1e6 * (b - a)) for a, b in zip([t0] + step_t[:-1], step_t)), file=sys.stderr)
     n_timed_pairs = min(args.steps // EVENT_EVERY, 1024)
     scan_ms_timed = smp.engine.scan_times(n_timed_pairs) if n_timed_pairs else np.zeros(0, np.float32)   # pairs of the timed region
     elapsed = max_over_ranks(elapsed)
