@@ -658,6 +658,17 @@ __global__ __launch_bounds__(256) void k_incr(SoaPtr s, int n, const Changed* __
         STAMP(31, t == 0);
         return;
     }
+    // this thread's fragment: everything it needs of the committed layout and of the old ranking is requested HERE, above the plan's
+    // own chain of ~6 dependent round trips (commit record -> old lengths -> 4 rounds of the bound search -> old offsets): two more
+    // round trips behind it otherwise
+    const int f = blockIdx.x * blockDim.x + t;
+    int c = 0, pos = 0, w_start = 0, w_len = 0, w_ori = 0, w_circ = 0, w_activ = 0, w_rep = 0, w_lcont = 0, w_lcontbp = 0, w_prev = 0, w_next = 0;
+    int lenc_u = 0, off_u = 0;
+    if (f < n) {
+        c = s.p[F_IDC][f]; pos = s.p[F_POS][f]; w_start = s.p[F_START][f]; w_len = s.p[F_LEN][f]; w_ori = s.p[F_ORI][f]; w_circ = s.p[F_CIRC][f];
+        w_activ = s.p[F_ACTIV][f]; w_rep = s.p[F_REP][f]; w_lcont = s.p[F_LCONT][f]; w_lcontbp = s.p[F_LCONTBP][f]; w_prev = s.p[F_PREV][f]; w_next = s.p[F_NEXT][f];
+        if ((unsigned)c < (unsigned)nc_old) { lenc_u = len_old[c]; off_u = off_old[c]; }   // (a touched contig's new label may lie beyond the old ranks)
+    }
     if (t == 0) {
         IncrPlan p;
         p.n_removed = 0;
@@ -717,33 +728,30 @@ __global__ __launch_bounds__(256) void k_incr(SoaPtr s, int n, const Changed* __
         sp.new_rank[i] = rank; sp.new_off[i] = off;
     }
     __syncthreads();
-    const int f = blockIdx.x * blockDim.x + t;
     const IncrPlan p = sp;
     if (f < chg_n) chg_clear[f] = 0; // the OTHER commit record (consumed by the previous relabel): clear for the next commit
     if (f == 0) off_new[p.nc_new] = n;
     if (f >= p.nc_new && f < n) len_new[f] = 0; // keep the tail of the length array zero
     if (f >= n) return;
-    const int c = s.p[F_IDC][f];
     int rank = -1, off = 0, lenc = 0;
     for (int i = 0; i < 4; i++)
         if (i < p.n_new && c == p.new_lab[i]) { rank = p.new_rank[i]; off = p.new_off[i]; lenc = p.new_len[i]; }
     const bool touched = rank >= 0;
     if (rank < 0) { // untouched contig: c is its old rank
-        lenc = len_old[c]; rank = c; off = off_old[c];
+        lenc = lenc_u; rank = c; off = off_u;
         for (int r = 0; r < 2; r++)
             if (r < p.n_removed && p.removed[r] < c) { rank -= 1; off -= p.removed_len[r]; }
         for (int i = 0; i < 4; i++)
             if (i < p.n_new && key_less(p.new_len[i], p.new_lab[i], lenc, c)) { rank += 1; off += p.new_len[i]; }
     }
-    const int pos = s.p[F_POS][f];
     s.p[F_IDC][f] = rank;
     if (pos == 0) { len_new[rank] = lenc; off_new[rank] = off; }
     perm[off + pos] = f;
     cbase[f] = off;
-    Geo g; g.id_c = rank; g.start_bp = s.p[F_START][f]; g.len_bp = s.p[F_LEN][f];
-    g.flags = geo_flags(s.p[F_ORI][f], s.p[F_CIRC][f], pos, s.p[F_ACTIV][f], s.p[F_REP][f]);
+    Geo g; g.id_c = rank; g.start_bp = w_start; g.len_bp = w_len;
+    g.flags = geo_flags(w_ori, w_circ, pos, w_activ, w_rep);
     geo[f] = g;
-    Link l; l.l_cont = s.p[F_LCONT][f]; l.l_cont_bp = s.p[F_LCONTBP][f]; l.prev = s.p[F_PREV][f]; l.next = s.p[F_NEXT][f];
+    Link l; l.l_cont = w_lcont; l.l_cont_bp = w_lcontbp; l.prev = w_prev; l.next = w_next;
     link[f] = l;
     // mates row (first N_MATES fragments of the fragment's contig, read only for contigs that short): members and order of
     // an untouched contig did not change, so only the fragments of the <= 4 touched contigs rewrite theirs -- by walking
@@ -1235,7 +1243,11 @@ struct TabViews {   // what the strict pricing of k_tm reads of the block's tabl
     const unsigned* cmask;         // [N_PAIRS][N_OPS]
     const Rec *A0, *B0;
 };
-__device__ int tables_block(const Geo* __restrict__ geo, const Link* __restrict__ link, const int* __restrict__ cbase,
+// (inlined: the pointers are then known to be global -- as arguments of a called function they were generic, the loads FLAT, and the
+// compiler ordered every one of them against the LDS stores around it: the four mates-row loads of the first thread went out one
+// round trip after the other, 5 us of this block's 13; blockDim.x, re-read from the dispatch packet in every loop, is a constant here)
+constexpr int TM_THREADS = 256;
+__device__ __forceinline__ int tables_block(const Geo* __restrict__ geo, const Link* __restrict__ link, const int* __restrict__ cbase,
                             const int* __restrict__ mates, const Stat* __restrict__ stat, int fA, int fB, int max_id, NbTables& T,
                             int k, int* __restrict__ step_hdr, Task* s_task, int* s_pp, SmallCtx& sc, int strict, int quirk, TabViews& tv)
 {
@@ -1290,7 +1302,7 @@ __device__ int tables_block(const Geo* __restrict__ geo, const Link* __restrict_
     }
     STAMP(24, k == 0 && t == 0); // A0 / B0 loaded
     if (t < N_OPS) changed[t] = 0;
-    for (int e = t; e < NENT; e += blockDim.x) { e_valid[e] = 0; e_plus[e] = 0; e_minus[e] = 0; e_owner[e] = e; e_slot[e] = -1; }
+    for (int e = t; e < NENT; e += TM_THREADS) { e_valid[e] = 0; e_plus[e] = 0; e_minus[e] = 0; e_owner[e] = e; e_slot[e] = -1; }
     if (t < NPAIR) { t_plus[t] = 0; t_minus[t] = 0; p_cnt[t] = 0; p_old[t] = 0xffff; }
     __syncthreads();
     if (t < NP) {
@@ -1324,23 +1336,44 @@ __device__ int tables_block(const Geo* __restrict__ geo, const Link* __restrict_
     __shared__ unsigned s_cmask[N_PAIRS][N_OPS];
     tv.xf = &xf[0][0]; tv.xf_old = xf_old; tv.crep = &s_crep[0][0]; tv.cmask = &s_cmask[0][0]; tv.A0 = &A0; tv.B0 = &B0;
     if (strict) {   // classes of equal contact-model inputs (see NbTables::crep): one thread per (piece pair, candidate)
-        for (int e = t; e < N_PAIRS * N_OPS; e += blockDim.x) s_cmask[e / N_OPS][e % N_OPS] = 0;
+        // what same_inputs (frag_ops.h) compares, packed into 128 bits per (pair, candidate) -- and per pair for the current layout:
+        // two keys are equal iff same_inputs says so.  A thread then compares its key with its up to 12 predecessors' at one 16-byte LDS
+        // read each (same_inputs on the transforms themselves reads 20 words per comparison: 5-7 us of this block, on the step's
+        // critical path -- tools/stamps_step.py, tools/stamps_c4.py)
+        __shared__ int4 s_key[N_PAIRS][N_OPS + 1];
+        auto key_of = [&](const Xf& a, const Xf& b) {
+            const bool cis = a.label == b.label;
+            int4 k4;
+            k4.x = cis ? a.off : 0; k4.y = cis ? b.off : 0; k4.z = (cis && a.circ == 1) ? a.lbp : 0;
+            const bool sig = cis || quirk != 0;
+            k4.w = (cis ? 1 : 0) | ((sig && a.sigma > 0) ? 2 : 0) | ((sig && b.sigma > 0) ? 4 : 0) | (cis ? (a.circ << 3) : 0);
+            return k4;
+        };
+        for (int e = t; e < N_PAIRS * (N_OPS + 1); e += TM_THREADS) {
+            const int pair = e / (N_OPS + 1), op = e - pair * (N_OPS + 1);
+            int p, q;
+            pair_of_index(pair, p, q);
+            s_key[pair][op] = op == N_OPS ? key_of(xf_old[p], xf_old[q]) : key_of(xf[op][p], xf[op][q]);
+            if (op < N_OPS) s_cmask[pair][op] = 0;
+        }
         __syncthreads();
-        for (int e = t; e < N_PAIRS * N_OPS; e += blockDim.x) {
+        for (int e = t; e < N_PAIRS * N_OPS; e += TM_THREADS) {
             const int pair = e / N_OPS, op = e - pair * N_OPS;
             int p, q;
             pair_of_index(pair, p, q);
+            const int4 mine = s_key[pair][op];
+            auto eq = [&](const int4& o4) { return o4.x == mine.x && o4.y == mine.y && o4.z == mine.z && o4.w == mine.w; };
             int r = op;
-            if (rep[p] < 0 || rep[q] < 0 || same_inputs(xf_old[p], xf_old[q], xf[op][p], xf[op][q], quirk != 0)) r = CREP_OLD;
+            if (rep[p] < 0 || rep[q] < 0 || eq(s_key[pair][N_OPS])) r = CREP_OLD;
             else
                 for (int o = 0; o < op; o++)
-                    if (same_inputs(xf[o][p], xf[o][q], xf[op][p], xf[op][q], quirk != 0)) { r = o; break; }
+                    if (eq(s_key[pair][o])) { r = o; break; }
             s_crep[pair][op] = (unsigned char)r;
             T.crep[pair][op] = (unsigned char)r;
             if (r != CREP_OLD) atomicOr(&s_cmask[pair][r], 1u << op);
         }
         __syncthreads();
-        for (int e = t; e < N_PAIRS * N_OPS; e += blockDim.x) T.cmask[e / N_OPS][e % N_OPS] = (unsigned short)s_cmask[e / N_OPS][e % N_OPS];
+        for (int e = t; e < N_PAIRS * N_OPS; e += TM_THREADS) T.cmask[e / N_OPS][e % N_OPS] = (unsigned short)s_cmask[e / N_OPS][e % N_OPS];
         // Reference arithmetic prices classes of inputs, not changed relations: the relation masks, the deduplicated task list and the
         // work lists below serve the exact mode's kernels only (6 of this block's 17 us next to the scan: tools/stamps_step.py)
         if (t == 0) { T.n_tasks = 0; T.n_items = 0; T.intra_any = 0; T.w_total = 0; step_hdr[k] = 0; s_pp[0] = 0; }
@@ -1348,7 +1381,7 @@ __device__ int tables_block(const Geo* __restrict__ geo, const Link* __restrict_
         return 0;
     }
     // relations: one thread per (op, p <= q)
-    for (int e = t; e < N_OPS * NPAIR; e += blockDim.x) {
+    for (int e = t; e < N_OPS * NPAIR; e += TM_THREADS) {
         const int op = e / NPAIR;
         int p, q;
         pair_of_index(e % NPAIR, p, q);
@@ -1367,7 +1400,7 @@ __device__ int tables_block(const Geo* __restrict__ geo, const Link* __restrict_
     __syncthreads();
     STAMP(27, k == 0 && t == 0); // relations
     // dedupe new-relation entries against every earlier entry with the same relative geometry
-    for (int e = NPAIR + t; e < NENT; e += blockDim.x) {
+    for (int e = NPAIR + t; e < NENT; e += TM_THREADS) {
         if (!e_valid[e]) continue;
         const int ee = e - NPAIR, op = ee / NPAIR, pair = ee % NPAIR;
         int p, q;
@@ -1388,17 +1421,17 @@ __device__ int tables_block(const Geo* __restrict__ geo, const Link* __restrict_
         e_owner[e] = owner;
     }
     __syncthreads();
-    for (int e = NPAIR + t; e < NENT; e += blockDim.x)
+    for (int e = NPAIR + t; e < NENT; e += TM_THREADS)
         if (e_valid[e] && e_owner[e] != e) { atomicOr(&e_plus[e_owner[e]], e_plus[e]); }
     __syncthreads();
     STAMP(28, k == 0 && t == 0); // dedupe
     // slots of the surviving (owner) entries, in entry order
-    for (int e = t; e < NENT; e += blockDim.x) e_flag[e] = (e_valid[e] && e_owner[e] == e) ? 1 : 0;
+    for (int e = t; e < NENT; e += TM_THREADS) e_flag[e] = (e_valid[e] && e_owner[e] == e) ? 1 : 0;
     __syncthreads();
     if (t < 64) wave_excl_scan(e_flag, s_start, NENT); // s_start used as scratch: slot of entry e
     __syncthreads();
     const int n_tasks = s_start[NENT];
-    for (int e = t; e < NENT; e += blockDim.x) if (e_flag[e]) e_slot[e] = s_start[e];
+    for (int e = t; e < NENT; e += TM_THREADS) if (e_flag[e]) e_slot[e] = s_start[e];
     __syncthreads();
     STAMP(29, k == 0 && t == 0); // slots
     if (t == 0) {
@@ -1406,7 +1439,7 @@ __device__ int tables_block(const Geo* __restrict__ geo, const Link* __restrict_
         T.intra_any = intra_any;
         for (int op = 0; op < N_OPS; op++) T.changed[op] = changed[op];
     }
-    for (int e = t; e < NENT; e += blockDim.x) {
+    for (int e = t; e < NENT; e += TM_THREADS) {
         if (e_slot[e] < 0) continue;
         const int pair = (e < NPAIR) ? e : (e - NPAIR) % NPAIR;
         int p, q;
@@ -1439,7 +1472,7 @@ __device__ int tables_block(const Geo* __restrict__ geo, const Link* __restrict_
     const int n_items = s_start[n_tasks];
     if (t == 0) { T.n_items = n_items; step_hdr[k] = n_items; }
     // (the tasks and the per-pair lists are needed by whoever prices the queued contacts, always)
-    for (int i = t; i < n_tasks; i += blockDim.x) T.task[i] = s_task[i];
+    for (int i = t; i < n_tasks; i += TM_THREADS) T.task[i] = s_task[i];
     if (t < NPAIR) {
         T.tplus[t] = (unsigned short)t_plus[t]; T.tminus[t] = (unsigned short)t_minus[t]; T.pair_n[t] = (unsigned short)p_cnt[t];
         T.pair_old[t] = (unsigned short)p_old[t];
@@ -1450,8 +1483,8 @@ __device__ int tables_block(const Geo* __restrict__ geo, const Link* __restrict_
         for (int i = 0; i < p_cnt[t]; i++) T.pair_task[t][i] = p_list[t][i];
     }
     if (s_pp[n_tasks] > INLINE_PAIRS) { // k_fin will price this neighbour's mass: it needs the work list in memory
-        for (int i = t; i <= n_tasks; i += blockDim.x) T.item_start[i] = s_start[i];
-        for (int i = t; i < n_tasks; i += blockDim.x) T.cw[i] = (s_chunks[i] << 19) | (s_task[i].p == s_task[i].q ? s_task[i].np : s_task[i].nq);
+        for (int i = t; i <= n_tasks; i += TM_THREADS) T.item_start[i] = s_start[i];
+        for (int i = t; i < n_tasks; i += TM_THREADS) T.cw[i] = (s_chunks[i] << 19) | (s_task[i].p == s_task[i].q ? s_task[i].np : s_task[i].nq);
         if (t >= 128 && t < 192) {
             long long w = 0;
             for (int i = t - 128; i < n_tasks; i += 64) w += (long long)s_chunks[i] * (long long)(s_task[i].p == s_task[i].q ? s_task[i].np : s_task[i].nq);
@@ -1459,7 +1492,7 @@ __device__ int tables_block(const Geo* __restrict__ geo, const Link* __restrict_
             if (t == 128) T.w_total = w;
         }
         if (n_items <= ITEM_CAP)
-            for (int i = t; i < n_tasks; i += blockDim.x)
+            for (int i = t; i < n_tasks; i += TM_THREADS)
                 for (int w = s_start[i]; w < s_start[i + 1]; w++) T.item_tc[w] = (unsigned)i | ((unsigned)(w - s_start[i]) << 16);
     }
     return n_tasks;
@@ -1814,7 +1847,7 @@ __device__ __forceinline__ void price_contact_batch(const PriceArgs& pa, long lo
 // the block's per-relation sums of price_contacts_bulk -> its per-candidate sums (acc: K * N_OPS words in LDS)
 __device__ __forceinline__ void fold_contact_sums(const NbTables* __restrict__ tabs, const long long* __restrict__ S, long long* __restrict__ acc, int K)
 {
-    for (int e = threadIdx.x; e < K * S_PER_K; e += blockDim.x) {
+    for (int e = threadIdx.x; e < K * S_PER_K; e += TM_THREADS) {
         const long long v = S[e];
         if (v == 0) continue;
         const int k = e / S_PER_K, j = e - k * S_PER_K;
@@ -1830,7 +1863,7 @@ __device__ __forceinline__ void fold_contact_sums(const NbTables* __restrict__ t
 
 __global__ void k_ln_tab(double* __restrict__ tab, int n, float nfpb, Par par)
 {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int p = blockIdx.x * TM_THREADS + threadIdx.x;
     if (p < n) tab[p] = mm_ln(par.v_inter * ((float)p / nfpb));
 }
 
@@ -1842,7 +1875,7 @@ __device__ __forceinline__ void hand_out(long long* out, unsigned long long* cou
                                          long long* d_q_out, volatile long long* host_res, long long seq)
 {
     const bool failed = atomicAdd(&counters[6], 0ull) != 0ull;
-    for (int i = threadIdx.x; i < K * N_OPS; i += blockDim.x) {
+    for (int i = threadIdx.x; i < K * N_OPS; i += TM_THREADS) {
         long long v = (long long)atomicExch((unsigned long long*)&out[i], 0ull); // read the final sum, reset for the next step
         if ((atomicAdd(&counters[NF_OFF + (i >> 6)], 0ull) >> (i & 63)) & 1ull) v = Q_NAN; // a term was not finite / out of range
         if (host_res) host_res[1 + i] = v; else d_q_out[i] = v;
@@ -1877,6 +1910,9 @@ __device__ __forceinline__ int sel_nb(const Neigh& nb, int j)
 }
 
 struct TmArgs { // first-needed pointers by value (see ScanArgs)
+    const int* perm;               // (position index; by value like the others: pointers read from DevArgs in memory are generic -> FLAT loads)
+    int reach_bp;
+    long long* tm_done;
     const Geo* geo;
     const Link* link;
     const int *cbase, *mates;
@@ -1982,16 +2018,16 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
     if (ta.strict && t == 0) T.set_m = inl ? 0 : s_m;
     STAMP(1, k == 0 && t == 0);
     if (ta.strict && inl && s_m > 1) {
-        const int* __restrict__ perm = A->perm;
+        const int* __restrict__ perm = ta.perm;
         const Geo* __restrict__ geo = ta.geo;
         const Stat* __restrict__ stat = ta.stat;
         const float nfpb = ta.nfpb;
         const Par par = ta.par;
-        const int reach_bp = A->reach_bp;
+        const int reach_bp = ta.reach_bp;
         const bool quirk = ta.quirk != 0;
         const Rec A0 = *tv.A0, B0 = *tv.B0;
         const PieceKey key = T.key;
-        for (int it = rank + world * t; it < s_pairs * N_OPS; it += world * (int)blockDim.x) {
+        for (int it = rank + world * t; it < s_pairs * N_OPS; it += world * 256) {
             const int e = it / N_OPS, op = it - e * N_OPS;
             int j = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)e)) * 0.5f);   // pair e = (i < j): j (j - 1) / 2 <= e < j (j + 1) / 2
             while (j * (j - 1) / 2 > e) j--;
@@ -2031,14 +2067,14 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
         }
     }
     if (!ta.strict && inl && total > 0) {
-        const int* __restrict__ perm = A->perm;
+        const int* __restrict__ perm = ta.perm;
         const Geo* __restrict__ geo = ta.geo;
         const Stat* __restrict__ stat = ta.stat;
         const float nfpb = ta.nfpb;
         const Par par = ta.par;
-        const int reach_bp = A->reach_bp;
+        const int reach_bp = ta.reach_bp;
         // (sums of the block in LDS: a handful of lanes have anything to add, and 13 wave reductions cost microseconds)
-        for (int i = rank + world * t; i < total; i += world * (int)blockDim.x) {
+        for (int i = rank + world * t; i < total; i += world * 256) {
             int lo_t = 0, hi_t = n_tasks - 1; // last task with s_pp <= i
             while (lo_t < hi_t) { const int mid = (lo_t + hi_t + 1) >> 1; if (s_pp[mid] <= i) lo_t = mid; else hi_t = mid - 1; }
             const Task& tk = s_task[lo_t];
@@ -2078,11 +2114,11 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
     __syncthreads();
     STAMP(2, k == 0 && t == 0);
     if (t == 0) {
-        if (inl && rank == 0) atomicAdd(&A->counters[1], (unsigned long long)ta.step_hdr[k]);
+        if (inl && rank == 0) atomicAdd(&ta.counters[1], (unsigned long long)ta.step_hdr[k]);
         ta.step_hdr[MAXK + k] = inl ? 1 : 0;
         // release: the tables of neighbour k are complete; the word carries the work-list header for k_fin
         const unsigned long long w = ((unsigned long long)(unsigned)seq << 32) | (inl ? 0x80000000ull : 0ull) | (unsigned long long)(unsigned)ta.step_hdr[k];
-        __hip_atomic_store((unsigned long long*)&A->tm_done[k], w, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store((unsigned long long*)&ta.tm_done[k], w, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         STAMP_MAX(3, true);
     }
     if (ta.host_res == nullptr) return;
@@ -2133,7 +2169,7 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
         }
         if (t >= 64 && s_fin == 1 && !ta.strict) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            const int u = t - 64, nu = (int)blockDim.x - 64;
+            const int u = t - 64, nu = 256 - 64;
             for (int e = u; e < K * N_PAIRS; e += nu) {
                 const int k = e / N_PAIRS, pr = e - k * N_PAIRS;
                 const NbTables& T = ta.tabs[k];
@@ -2184,13 +2220,13 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
     qs.seq = (unsigned)seq; qs.concurrent = 1; qs.multi = ta.multi;
     if (ta.strict)
         price_contacts_strict(qs, ta.counters + 6, ta.tabs, ta.geo, ta.stat, ta.lcontbp, ta.acc, ta.counters + NF_OFF, ta.nfpb, ta.par, ta.quirk != 0,
-                              s_nq, t >> 6, (int)(blockDim.x >> 6), t & 63);
+                              s_nq, t >> 6, 4, t & 63);
     else {
         PriceArgs pa;
         pa.pr_lds = s_prl; pa.pt_lds = s_ptl; pa.nt_lds = s_ntl;
         pa.q = qs; pa.err = ta.counters + 6; pa.tabs = ta.tabs; pa.geo = ta.geo; pa.stat = ta.stat; pa.lcontbp = ta.lcontbp;
         pa.out = ta.acc; pa.nf = ta.counters + NF_OFF; pa.nfpb = ta.nfpb; pa.par = ta.par;
-        price_contacts(pa, s_nq, t >> 6, (int)(blockDim.x >> 6), t & 63);
+        price_contacts(pa, s_nq, t >> 6, 4, t & 63);
     }
     __syncthreads(); // (waits for this block's atomics: they are complete, at the memory side, before hand_out reads the sums)
     STAMP(5, t == 0);
@@ -3339,7 +3375,7 @@ __global__ __launch_bounds__(256) void k_strict(FinArgs fa, StrictArgs sa, int f
     const Stat* __restrict__ stat = fa.stat;
     unsigned long long* __restrict__ counters = fa.counters;
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    const int wave = blockIdx.x * (blockDim.x >> 6) + wib, n_waves = gridDim.x * (blockDim.x >> 6);
+    const int wave = blockIdx.x * 4 + wib, n_waves = gridDim.x * 4;
     __shared__ STileW s_tile[4][64];
     __shared__ long long s_accb[STRICT_ACC_COPIES][MAXK * N_OPS];
     __shared__ SetGeo s_sg[MAXK];
@@ -3351,10 +3387,10 @@ __global__ __launch_bounds__(256) void k_strict(FinArgs fa, StrictArgs sa, int f
 #define CREP_(k_, pr_, op_) s_crep[((k_) * N_PAIRS + (pr_)) * N_OPS + (op_)]
 #define CMASK_(k_, pr_, op_) s_cmask[((k_) * N_PAIRS + (pr_)) * N_OPS + (op_)]
     STAMP(16, blockIdx.x == 0 && threadIdx.x == 0);
-    for (int i = threadIdx.x; i < STRICT_ACC_COPIES * MAXK * N_OPS; i += blockDim.x) (&s_accb[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < STRICT_ACC_COPIES * MAXK * N_OPS; i += 256u) (&s_accb[0][0])[i] = 0;
     // (the tables are complete: the launch is ordered behind k_tm by an event)
-    for (int i = threadIdx.x; i < K * N_OPS * NP; i += blockDim.x) { const int k = i / (N_OPS * NP), r = i - k * (N_OPS * NP); s_xf[i] = tabs[k].xf[r / NP][r % NP]; }
-    for (int i = threadIdx.x; i < K * N_PAIRS * N_OPS; i += blockDim.x) {
+    for (int i = threadIdx.x; i < K * N_OPS * NP; i += 256u) { const int k = i / (N_OPS * NP), r = i - k * (N_OPS * NP); s_xf[i] = tabs[k].xf[r / NP][r % NP]; }
+    for (int i = threadIdx.x; i < K * N_PAIRS * N_OPS; i += 256u) {
         const int k = i / (N_PAIRS * N_OPS), r = i - k * (N_PAIRS * N_OPS);
         s_crep[i] = tabs[k].crep[r / N_OPS][r % N_OPS]; s_cmask[i] = tabs[k].cmask[r / N_OPS][r % N_OPS];
     }
@@ -3524,7 +3560,7 @@ __global__ __launch_bounds__(256) void k_strict(FinArgs fa, StrictArgs sa, int f
     }
     STAMP_MAX(19, lane == 0);
     __syncthreads();
-    for (int i = threadIdx.x; i < K * N_OPS; i += blockDim.x) {
+    for (int i = threadIdx.x; i < K * N_OPS; i += 256u) {
         long long v = 0;
 #pragma unroll
         for (int c = 0; c < STRICT_ACC_COPIES; c++) v += s_accb[c][i];
@@ -3582,7 +3618,7 @@ __global__ __launch_bounds__(256) void k_strict_flat(FinArgs fa, StrictArgs sa, 
     STAMP(16, blockIdx.x == 0 && t == 0);
     const unsigned long long nq_total = counters[2];          // written by k_scan, an earlier kernel on the stream (on its way during the wait below)
     if (t == 0) { s_ok = 1; s_qlive = 0; }
-    for (int i = t; i < STRICT_ACC_COPIES * MAXK * N_OPS; i += blockDim.x) (&s_accb[0][0])[i] = 0;
+    for (int i = t; i < STRICT_ACC_COPIES * MAXK * N_OPS; i += 256u) (&s_accb[0][0])[i] = 0;
     __syncthreads();
     if (t < K) {   // k_tm's tables of neighbour t (and its own pricing of the small sets): complete?  Bounded wait.
         // (what the layout alone says about the set is on its way meanwhile)
@@ -3597,18 +3633,15 @@ __global__ __launch_bounds__(256) void k_strict_flat(FinArgs fa, StrictArgs sa, 
             __builtin_amdgcn_s_sleep(2);
         }
         if (!ok) { s_ok = 0; atomicOr(&counters[6], 1ull); }
-    }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    STAMP(21, blockIdx.x == 0 && t == 0);
-    const bool ok = s_ok != 0;
-    if (ok) {
-        if (t < K) {
+        else {   // (the acquire above covers this thread's reads of neighbour t's tables)
             s_qkeys[t] = tabs[t].key;
             if (!(tabs[t].set_m > 0)) { s_sg[t].m = 0; s_sg[t].nt = 0; }   // (fB == fA, or priced by k_tm already)
         }
     }
     __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    STAMP(21, blockIdx.x == 0 && t == 0);
+    const bool ok = s_ok != 0;
     if (t == 0) {
         long long acc = 0;
         for (int k = 0; k < K; k++) { s_pbase[k] = acc; const long long m = ok ? s_sg[k].m : 0; acc += m * (m - 1) / 2; }
@@ -3627,7 +3660,7 @@ __global__ __launch_bounds__(256) void k_strict_flat(FinArgs fa, StrictArgs sa, 
         auto add_ops = [&](int k, unsigned ops, long long v) {
             while (ops) { const int b = __ffs((int)ops) - 1; ops &= ops - 1; atomicAdd((unsigned long long*)&my_acc[k * N_OPS + b], (unsigned long long)v); }
         };
-        const long long gi = (long long)blockIdx.x * blockDim.x + t, stride = (long long)gridDim.x * blockDim.x;
+        const long long gi = (long long)blockIdx.x * 256u + t, stride = (long long)gridDim.x * 256u;
         QSrc qs;
         qs.queue = fa.queue; qs.geo2 = reinterpret_cast<const int2*>(geo); qs.cnt = fa.cnt; qs.keys = s_qkeys; qs.live = s_qlive; qs.K = K;
         qs.seq = (unsigned)seq; qs.concurrent = 0; qs.multi = fa.multi;
@@ -3709,7 +3742,7 @@ __global__ __launch_bounds__(256) void k_strict_flat(FinArgs fa, StrictArgs sa, 
         }
     }
     __syncthreads();
-    for (int i = t; i < K * N_OPS; i += blockDim.x) {
+    for (int i = t; i < K * N_OPS; i += 256u) {
         long long v = 0;
 #pragma unroll
         for (int c = 0; c < STRICT_ACC_COPIES; c++) v += s_accb[c][i];
@@ -5204,6 +5237,7 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     ta.nc = h->d_scalars + NC_WORD;
 
     ta.geo = h->geo; ta.link = h->link; ta.cbase = h->cbase; ta.mates = h->mates; ta.tabs = h->tabs; ta.step_hdr = h->step_hdr;
+    ta.perm = h->perm; ta.reach_bp = reach_bp(h); ta.tm_done = h->tm_done;
     static const bool no_finisher = getenv("GRAAL_NO_FINISHER") != nullptr; // always finish with k_fin (diagnostics)
     ta.flags = h->d_flags;
     ta.sync = h->d_sync; ta.n_scan_blocks = scan_grid(h);
