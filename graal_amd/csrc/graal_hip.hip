@@ -1180,6 +1180,10 @@ struct NbTables {        // everything the finishing kernel needs about one neig
 };
 constexpr unsigned char CREP_OLD = 0xff;
 
+// "these values are needed HERE": keeps the compiler from sinking independent loads below a data-dependent branch -- two dependent
+// memory round trips where one would do
+__device__ __forceinline__ void keep_xf(Xf& a, Xf& b) { asm volatile("" : "+v"(a.label), "+v"(a.sigma), "+v"(a.off), "+v"(a.circ), "+v"(a.lbp), "+v"(b.label), "+v"(b.sigma), "+v"(b.off), "+v"(b.circ), "+v"(b.lbp)); }
+
 // LDS hand-over between the lanes of ONE wave: LDS operations of a wave execute in program order, so no hardware barrier is
 // needed -- only the compiler must not move them across lanes' dependencies
 #define WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
@@ -1766,8 +1770,11 @@ __device__ __forceinline__ void price_contacts_strict(const QSrc& qs, unsigned l
             rel &= rel - 1;
             const int p = (qe.ci >> (CODE_BITS * k)) & 7, q = (qe.cj >> (CODE_BITS * k)) & 7;
             const NbTables& T = tabs[k];
-            if (T.crep[pair_index(p, q)][op] == CREP_OLD) continue;   // the inputs of the current layout: the same value
-            const End X = end_xf(gx, T.xf[op][p]), Y = end_xf(gy, T.xf[op][q]);
+            const unsigned char cls = T.crep[pair_index(p, q)][op];
+            Xf xa = T.xf[op][p], xb = T.xf[op][q];     // (requested together with the class entry)
+            keep_xf(xa, xb);
+            if (cls == CREP_OLD) continue;   // the inputs of the current layout: the same value
+            const End X = end_xf(gx, xa), Y = end_xf(gy, xb);
             const float ex_new = ex_pair_ref(X, sx, slx, fx, Y, sy, sly, fy, nfpb, par, quirk);
             if (ex_new == ex_old) continue;
             const long long qv = to_q(ob * (mm_ln(ex_new) - ln_old));
@@ -3691,11 +3698,15 @@ __global__ __launch_bounds__(256) void k_strict_flat(FinArgs fa, StrictArgs sa, 
             const PieceKey key = s_qkeys[k];
             const int px = piece_of(key, gx.id_c, geo_pos(gx.flags)), py = piece_of(key, gy.id_c, geo_pos(gy.flags));
             const int pr = pair_index(px, py);
-            if (CREP_(k, pr, op) != op) continue;                     // a class is priced once, under its first candidate
+            const int cls = CREP_(k, pr, op);
+            Xf xa = XF_(k, op, px), xb = XF_(k, op, py);              // (requested together with the class entry)
+            const unsigned cm = CMASK_(k, pr, op);
+            keep_xf(xa, xb);
+            if (cls != op) continue;                                  // a class is priced once, under its first candidate
             const int lbpx = ((gx.flags >> 1) & 1) ? (gx.id_c == sg.cA ? sg.lbpA : sg.lbpB) : 0;
             const int lbpy = ((gy.flags >> 1) & 1) ? (gy.id_c == sg.cA ? sg.lbpA : sg.lbpB) : 0;
             const End X0 = end_old(gx, lbpx), Y0 = end_old(gy, lbpy);
-            const End X = end_xf(gx, XF_(k, op, px)), Y = end_xf(gy, XF_(k, op, py));
+            const End X = end_xf(gx, xa), Y = end_xf(gy, xb);
             const bool near_old = X0.label == Y0.label && gap_bp(X0, gx.len_bp, Y0, gy.len_bp) <= reach_bp;
             const bool near_new = X.label == Y.label && gap_bp(X, gx.len_bp, Y, gy.len_bp) <= reach_bp;
             const bool always = quirk && (!stat_uniform(sx) || !stat_uniform(sy));
@@ -3710,8 +3721,8 @@ __global__ __launch_bounds__(256) void k_strict_flat(FinArgs fa, StrictArgs sa, 
                             acc += (double)ex_pair_ref(X0, sx, a, fx, Y0, sy, b, fy, nfpb, par, quirk) - (double)ex_pair_ref(X, sx, a, fx, Y, sy, b, fy, nfpb, par, quirk);
             } else acc += (double)ex_pair_ref(X0, sx, 0, fx, Y0, sy, 0, fy, nfpb, par, quirk) - (double)ex_pair_ref(X, sx, 0, fx, Y, sy, 0, fy, nfpb, par, quirk);
             const long long q1 = to_q(acc);
-            if (q1 == Q_BAD) nf_flag_ops(counters + NF_OFF, k, CMASK_(k, pr, op));
-            else if (q1 != 0) add_ops(k, CMASK_(k, pr, op), q1);
+            if (q1 == Q_BAD) nf_flag_ops(counters + NF_OFF, k, cm);
+            else if (q1 != 0) add_ops(k, cm, q1);
             STAMP_MAX(18, lane == 0);
           } else {
             // ---- (2) lane = (queued contact, neighbour, class slot)
@@ -3727,16 +3738,20 @@ __global__ __launch_bounds__(256) void k_strict_flat(FinArgs fa, StrictArgs sa, 
             if (!((qe.rel >> (CODE_BITS * k)) & 1u)) continue;
             const int p = (qe.ci >> (CODE_BITS * k)) & 7, q = (qe.cj >> (CODE_BITS * k)) & 7;
             const int pr = pair_index(p, q);
-            if (CREP_(k, pr, op) != op) continue;
+            const int cls = CREP_(k, pr, op);
+            Xf xa = XF_(k, op, p), xb = XF_(k, op, q);
+            const unsigned cm = CMASK_(k, pr, op);
+            keep_xf(xa, xb);
+            if (cls != op) continue;
             const End X0 = end_old(gx, ((gx.flags >> 1) & 1) ? sa.lcontbp[fx] : 0), Y0 = end_old(gy, ((gy.flags >> 1) & 1) ? sa.lcontbp[fy] : 0);
             const float ex_old = ex_pair_ref(X0, sx, slx, fx, Y0, sy, sly, fy, nfpb, par, quirk);
-            const End X = end_xf(gx, XF_(k, op, p)), Y = end_xf(gy, XF_(k, op, q));
+            const End X = end_xf(gx, xa), Y = end_xf(gy, xb);
             const float ex_new = ex_pair_ref(X, sx, slx, fx, Y, sy, sly, fy, nfpb, par, quirk);
             if (ex_new == ex_old) continue;
             const double ob = (double)__int_as_float(qe.cnt);
             const long long qv = to_q(ob * (mm_ln(ex_new) - mm_ln(ex_old)));
-            if (qv == Q_BAD) nf_flag_ops(counters + NF_OFF, k, CMASK_(k, pr, op));
-            else if (qv != 0) add_ops(k, CMASK_(k, pr, op), qv);
+            if (qv == Q_BAD) nf_flag_ops(counters + NF_OFF, k, cm);
+            else if (qv != 0) add_ops(k, cm, qv);
             STAMP_MAX(19, lane == 0);
           }
         }
