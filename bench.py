@@ -261,6 +261,10 @@ def main():
             td.init_process_group(args.backend, timeout=tmo)
     group = gdist.Group(rank, world)
 
+    def phase(msg):   # (diagnostics: GRAAL_BENCH_PHASES=1 prints where the run is)
+        if os.environ.get("GRAAL_BENCH_PHASES"):
+            print("[bench %.2f s] %s" % (time.perf_counter(), msg), file=sys.stderr, flush=True)
+    phase("start")
     t_gen = time.perf_counter()
     P = synth.make_problem(n_bins=args.n_bins, nnz=args.nnz, n_sub=1, seed=20141217)
     soa_original = P["S_o_A_frags"]
@@ -269,8 +273,10 @@ def main():
     t_gen = time.perf_counter() - t_gen
     rng = np.random.RandomState(20141217)
     t_setup = time.perf_counter()
+    phase("problem generated")
     smp = build_sampler(P, rng, group, local if world > 1 else 0, args.arithmetic)
     t_setup = time.perf_counter() - t_setup
+    phase("sampler built")
 
     def set_arithmetic(sm, which):
         sm.engine.set_mode(ref_trans_accu=which == "strict", strict=which == "strict")
@@ -280,12 +286,16 @@ def main():
 
     # ---- layout: exploded genome + real MCMC warm-up steps (every rank runs the same, sharded, steps) --------
     smp.init_likelihood()
+    phase("first full evaluation done")
     t_mcmc = time.perf_counter()
     order = np.arange(n, dtype=np.int32)
     rng.shuffle(order)
-    for i in order[:args.mcmc_warmup]:
+    for j_, i in enumerate(order[:args.mcmc_warmup]):
         smp.step_max_likelihood(int(i), K)
+        if j_ < 4 or j_ % 500 == 0:
+            phase("MCMC warm-up step %d done" % j_)
     torch.cuda.synchronize()
+    phase("MCMC warm-up done")
     t_mcmc = time.perf_counter() - t_mcmc
     stats = smp.engine.layout_stats()
     max_id = smp.modify_gl_cuda_buffer(0)

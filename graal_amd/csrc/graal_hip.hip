@@ -658,17 +658,6 @@ __global__ __launch_bounds__(256) void k_incr(SoaPtr s, int n, const Changed* __
         STAMP(31, t == 0);
         return;
     }
-    // this thread's fragment: everything it needs of the committed layout and of the old ranking is requested HERE, above the plan's
-    // own chain of ~6 dependent round trips (commit record -> old lengths -> 4 rounds of the bound search -> old offsets): two more
-    // round trips behind it otherwise
-    const int f = blockIdx.x * blockDim.x + t;
-    int c = 0, pos = 0, w_start = 0, w_len = 0, w_ori = 0, w_circ = 0, w_activ = 0, w_rep = 0, w_lcont = 0, w_lcontbp = 0, w_prev = 0, w_next = 0;
-    int lenc_u = 0, off_u = 0;
-    if (f < n) {
-        c = s.p[F_IDC][f]; pos = s.p[F_POS][f]; w_start = s.p[F_START][f]; w_len = s.p[F_LEN][f]; w_ori = s.p[F_ORI][f]; w_circ = s.p[F_CIRC][f];
-        w_activ = s.p[F_ACTIV][f]; w_rep = s.p[F_REP][f]; w_lcont = s.p[F_LCONT][f]; w_lcontbp = s.p[F_LCONTBP][f]; w_prev = s.p[F_PREV][f]; w_next = s.p[F_NEXT][f];
-        if ((unsigned)c < (unsigned)nc_old) { lenc_u = len_old[c]; off_u = off_old[c]; }   // (a touched contig's new label may lie beyond the old ranks)
-    }
     if (t == 0) {
         IncrPlan p;
         p.n_removed = 0;
@@ -728,30 +717,33 @@ __global__ __launch_bounds__(256) void k_incr(SoaPtr s, int n, const Changed* __
         sp.new_rank[i] = rank; sp.new_off[i] = off;
     }
     __syncthreads();
+    const int f = blockIdx.x * blockDim.x + t;
     const IncrPlan p = sp;
     if (f < chg_n) chg_clear[f] = 0; // the OTHER commit record (consumed by the previous relabel): clear for the next commit
     if (f == 0) off_new[p.nc_new] = n;
     if (f >= p.nc_new && f < n) len_new[f] = 0; // keep the tail of the length array zero
     if (f >= n) return;
+    const int c = s.p[F_IDC][f];
     int rank = -1, off = 0, lenc = 0;
     for (int i = 0; i < 4; i++)
         if (i < p.n_new && c == p.new_lab[i]) { rank = p.new_rank[i]; off = p.new_off[i]; lenc = p.new_len[i]; }
     const bool touched = rank >= 0;
     if (rank < 0) { // untouched contig: c is its old rank
-        lenc = lenc_u; rank = c; off = off_u;
+        lenc = len_old[c]; rank = c; off = off_old[c];
         for (int r = 0; r < 2; r++)
             if (r < p.n_removed && p.removed[r] < c) { rank -= 1; off -= p.removed_len[r]; }
         for (int i = 0; i < 4; i++)
             if (i < p.n_new && key_less(p.new_len[i], p.new_lab[i], lenc, c)) { rank += 1; off += p.new_len[i]; }
     }
+    const int pos = s.p[F_POS][f];
     s.p[F_IDC][f] = rank;
     if (pos == 0) { len_new[rank] = lenc; off_new[rank] = off; }
     perm[off + pos] = f;
     cbase[f] = off;
-    Geo g; g.id_c = rank; g.start_bp = w_start; g.len_bp = w_len;
-    g.flags = geo_flags(w_ori, w_circ, pos, w_activ, w_rep);
+    Geo g; g.id_c = rank; g.start_bp = s.p[F_START][f]; g.len_bp = s.p[F_LEN][f];
+    g.flags = geo_flags(s.p[F_ORI][f], s.p[F_CIRC][f], pos, s.p[F_ACTIV][f], s.p[F_REP][f]);
     geo[f] = g;
-    Link l; l.l_cont = w_lcont; l.l_cont_bp = w_lcontbp; l.prev = w_prev; l.next = w_next;
+    Link l; l.l_cont = s.p[F_LCONT][f]; l.l_cont_bp = s.p[F_LCONTBP][f]; l.prev = s.p[F_PREV][f]; l.next = s.p[F_NEXT][f];
     link[f] = l;
     // mates row (first N_MATES fragments of the fragment's contig, read only for contigs that short): members and order of
     // an untouched contig did not change, so only the fragments of the <= 4 touched contigs rewrite theirs -- by walking
