@@ -658,6 +658,13 @@ __global__ __launch_bounds__(256) void k_incr(SoaPtr s, int n, const Changed* __
         STAMP(31, t == 0);
         return;
     }
+#if defined(GRAAL_STAMPS) && defined(GRAAL_EXP_INCR_CHECK)
+    // (diagnostics, tools/incr_check.py: is the committed layout complete when this kernel STARTS?  The fragment's label and position
+    // are read here and again behind the plan; g_stamps[27] counts the fragments for which the two reads differ)
+    const int f_early = blockIdx.x * blockDim.x + t;
+    const int c_early = f_early < n ? __hip_atomic_load(&s.p[F_IDC][f_early], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    const int pos_early = f_early < n ? __hip_atomic_load(&s.p[F_POS][f_early], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+#endif
     if (t == 0) {
         IncrPlan p;
         p.n_removed = 0;
@@ -724,6 +731,9 @@ __global__ __launch_bounds__(256) void k_incr(SoaPtr s, int n, const Changed* __
     if (f >= p.nc_new && f < n) len_new[f] = 0; // keep the tail of the length array zero
     if (f >= n) return;
     const int c = s.p[F_IDC][f];
+#if defined(GRAAL_STAMPS) && defined(GRAAL_EXP_INCR_CHECK)
+    if (c != c_early || s.p[F_POS][f] != pos_early) atomicAdd(&g_stamps[27], 1ull);
+#endif
     int rank = -1, off = 0, lenc = 0;
     for (int i = 0; i < 4; i++)
         if (i < p.n_new && c == p.new_lab[i]) { rank = p.new_rank[i]; off = p.new_off[i]; lenc = p.new_len[i]; }
