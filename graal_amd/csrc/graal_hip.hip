@@ -4005,6 +4005,8 @@ struct Ctx {
     std::string err;
     hipStream_t stream = nullptr;
     hipStream_t aux = nullptr;    // k_tm runs here, concurrently with k_scan on the main stream
+    hipStream_t fstream = nullptr; // a full evaluation that runs NEXT TO a step's scoring kernels (graal_step, flag 8)
+    hipEvent_t ev_full = nullptr;  // the relabel in front of it
     hipEvent_t ev_fin = nullptr;  // end of the last asynchronous evaluation (orders the next k_tm after it)
     hipEvent_t ev_relabel = nullptr; // end of the relabel kernels graal_begin_step left running (orders the next k_tm, on aux)
     hipEvent_t ev_tm = nullptr;   // end of the step's k_tm (orders a chip-filling k_fin behind it, see launch_fin)
@@ -4589,6 +4591,8 @@ int graal_create(int device, graal_ctx** out)
         CK(hipDeviceGetStreamPriorityRange(&least, &greatest));
         CK(hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, greatest));
     }
+    CK(hipStreamCreateWithFlags(&h->fstream, hipStreamNonBlocking));
+    CK(hipEventCreateWithFlags(&h->ev_full, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&h->ev_fin, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&h->ev_relabel, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&h->ev_tm, hipEventDisableTiming));
@@ -4667,6 +4671,8 @@ void graal_destroy(graal_ctx* h)
         if (h->ev_relabel) (void)hipEventDestroy(h->ev_relabel);
         if (h->ev_tm) (void)hipEventDestroy(h->ev_tm);
         if (h->aux) (void)hipStreamDestroy(h->aux);
+        if (h->fstream) (void)hipStreamDestroy(h->fstream);
+        if (h->ev_full) (void)hipEventDestroy(h->ev_full);
         (void)hipStreamDestroy(h->stream);
     }
     hs_free(h->hs);
@@ -5114,9 +5120,10 @@ static int begin_step_collect(graal_ctx* h, int64_t stats[8], int32_t* max_id)
 
 int graal_relabel_contigs(graal_ctx* h, int32_t* max_id) { return graal_begin_step(h, nullptr, max_id); }
 
-int graal_eval_full_q(graal_ctx* h, int64_t q_out[2])
+// the full evaluation in two halves: the kernels (and the publication of the sums) on stream `fs`, and the wait for them.  A caller
+// that launches on another stream than the engine's orders it behind the relabel itself (graal_step, flag 8).
+static int full_launch(graal_ctx* h, hipStream_t fs)
 {
-    if (!h || !q_out) return GRAAL_E_ARG;
     if (!(h->have_frags && h->have_contacts && h->have_par)) return fail(h, GRAAL_E_STATE, "upload fragments, contacts and parameters first");
     if (!h->order_valid) return fail(h, GRAAL_E_STATE, "call graal_relabel_contigs after changing the layout");
     CK(hipSetDevice(h->device));
@@ -5127,7 +5134,7 @@ int graal_eval_full_q(graal_ctx* h, int64_t q_out[2])
         // (equal RF counts everywhere: the reference's trans-branch indexing picks the same count whatever the orientation, so
         // the compact records serve that mode too)
         const bool compact = h->uniform_accu > 0 && !no_compact;
-        k_subrec<<<blocks_for(h->n, 256), 256, 0, h->stream>>>(h->n, h->geo, h->stat_frag, h->d_sub_ids, h->sub_rec, compact ? h->sub_rec8 : nullptr, h->sub_lab16);
+        k_subrec<<<blocks_for(h->n, 256), 256, 0, fs>>>(h->n, h->geo, h->stat_frag, h->d_sub_ids, h->sub_rec, compact ? h->sub_rec8 : nullptr, h->sub_lab16);
         // 8 blocks of 256 threads per CU; every lane takes FULL_G groups of 4 contacts per iteration
         static const int full_g = getenv("GRAAL_FULL_G") ? atoi(getenv("GRAAL_FULL_G")) : 2;
         static const int full_bpc = getenv("GRAAL_FULL_BPC") ? atoi(getenv("GRAAL_FULL_BPC")) : 8;   // blocks per CU
@@ -5150,42 +5157,42 @@ int graal_eval_full_q(graal_ctx* h, int64_t q_out[2])
 #define FULL_NNZ_L_ARGS reinterpret_cast<const int4*>(h->row), reinterpret_cast<const int4*>(h->col), reinterpret_cast<const int4*>(h->cnt), \
                         h->nnz, h->sub_lab16, h->n_sub_total, h->sub_rec8, h->sub_rec, s.p[F_LCONTBP], h->nfpb, h->par, h->uniform_accu,        \
                         h->d_scalars + 8, h->d_scalars + FULL_BAD
-            if (FG == 2) k_full_nnz_l<2><<<nbl, 1024, lab_bytes, h->stream>>>(FULL_NNZ_L_ARGS);
-            else k_full_nnz_l<4><<<nbl, 1024, lab_bytes, h->stream>>>(FULL_NNZ_L_ARGS);
+            if (FG == 2) k_full_nnz_l<2><<<nbl, 1024, lab_bytes, fs>>>(FULL_NNZ_L_ARGS);
+            else k_full_nnz_l<4><<<nbl, 1024, lab_bytes, fs>>>(FULL_NNZ_L_ARGS);
 #undef FULL_NNZ_L_ARGS
         }
         else if (compact) {
 #define FULL_NNZ_U_ARGS reinterpret_cast<const int4*>(h->row), reinterpret_cast<const int4*>(h->col), reinterpret_cast<const int4*>(h->cnt), \
                         h->nnz, h->sub_rec8, h->sub_rec, s.p[F_LCONTBP], h->nfpb, h->par, h->uniform_accu, h->d_scalars + 8, h->d_scalars + FULL_BAD
-            if (FG == 1) k_full_nnz_u<1><<<nb, 256, 0, h->stream>>>(FULL_NNZ_U_ARGS);
-            else if (FG == 4) k_full_nnz_u<4><<<nb, 256, 0, h->stream>>>(FULL_NNZ_U_ARGS);
-            else k_full_nnz_u<2><<<nb, 256, 0, h->stream>>>(FULL_NNZ_U_ARGS);
+            if (FG == 1) k_full_nnz_u<1><<<nb, 256, 0, fs>>>(FULL_NNZ_U_ARGS);
+            else if (FG == 4) k_full_nnz_u<4><<<nb, 256, 0, fs>>>(FULL_NNZ_U_ARGS);
+            else k_full_nnz_u<2><<<nb, 256, 0, fs>>>(FULL_NNZ_U_ARGS);
 #undef FULL_NNZ_U_ARGS
         }
-        else if (FG == 1) k_full_nnz<1><<<nb, 256, 0, h->stream>>>(FULL_NNZ_ARGS);
-        else if (FG == 4) k_full_nnz<4><<<nb, 256, 0, h->stream>>>(FULL_NNZ_ARGS);
-        else k_full_nnz<2><<<nb, 256, 0, h->stream>>>(FULL_NNZ_ARGS);
+        else if (FG == 1) k_full_nnz<1><<<nb, 256, 0, fs>>>(FULL_NNZ_ARGS);
+        else if (FG == 4) k_full_nnz<4><<<nb, 256, 0, fs>>>(FULL_NNZ_ARGS);
+        else k_full_nnz<2><<<nb, 256, 0, fs>>>(FULL_NNZ_ARGS);
 #undef FULL_NNZ_ARGS
     }
     if (quirk && h->n_ubins) // T_all prices every pair of different bins with the plain trans value: add the indexing's difference
-        k_quirk_mass<<<blocks_for((long long)h->n_ubins * h->n_bins, 256), 256, 0, h->stream>>>(h->n_ubins, h->d_ubins, h->n_bins, h->geo, h->stat_frag,
+        k_quirk_mass<<<blocks_for((long long)h->n_ubins * h->n_bins, 256), 256, 0, fs>>>(h->n_ubins, h->d_ubins, h->n_bins, h->geo, h->stat_frag,
                                                                                              h->nfpb, h->par, h->d_scalars + 9, h->d_scalars + FULL_BAD);
     if (h->n <= 16384)
-        k_full_mass<64><<<blocks_for(h->n, 4), 256, 0, h->stream>>>(h->n, h->perm, h->contig_off2[h->cur], h->geo, h->stat_frag, s.p[F_LCONT],
+        k_full_mass<64><<<blocks_for(h->n, 4), 256, 0, fs>>>(h->n, h->perm, h->contig_off2[h->cur], h->geo, h->stat_frag, s.p[F_LCONT],
                                                                     s.p[F_LCONTBP], s.p[F_POS], h->nfpb, h->par, reach_bp(h),
                                                                     h->d_scalars + 9, h->d_scalars + FULL_BAD);
     else
-        k_full_mass<16><<<blocks_for(h->n, 16), 256, 0, h->stream>>>(h->n, h->perm, h->contig_off2[h->cur], h->geo, h->stat_frag, s.p[F_LCONT],
+        k_full_mass<16><<<blocks_for(h->n, 16), 256, 0, fs>>>(h->n, h->perm, h->contig_off2[h->cur], h->geo, h->stat_frag, s.p[F_LCONT],
                                                                      s.p[F_LCONTBP], s.p[F_POS], h->nfpb, h->par, reach_bp(h),
                                                                      h->d_scalars + 9, h->d_scalars + FULL_BAD);
     if (h->has_rep) { // every pixel of a repeated bin, densely (identical on every rank: it goes with the mass part)
         const RepArgs R = rep_args(h);
-        k_rep_full<<<blocks_for((long long)h->n_dup * h->n_bins, 256), 256, 0, h->stream>>>(R, h->d_scalars + 17, h->d_scalars + FULL_BAD);
+        k_rep_full<<<blocks_for((long long)h->n_dup * h->n_bins, 256), 256, 0, fs>>>(R, h->d_scalars + 17, h->d_scalars + FULL_BAD);
     }
     // the accumulators (d_scalars[8], [9], [17], [FULL_BAD]) are zero at rest because k_full_pub clears them behind the sums it
     // publishes: a call that fails between its first kernel and that publication must not leave partial sums to the next one
     auto reset_acc = [&]() {
-        (void)hipStreamSynchronize(h->stream);
+        (void)hipStreamSynchronize(fs);
         (void)hipGetLastError();
         (void)hipMemset(h->d_scalars + 8, 0, 2 * sizeof(long long));
         (void)hipMemset(h->d_scalars + 17, 0, sizeof(long long));
@@ -5193,18 +5200,30 @@ int graal_eval_full_q(graal_ctx* h, int64_t q_out[2])
     };
     { const hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { reset_acc(); h->err = hipGetErrorString(e_); return GRAAL_E_HIP; } }
     h->full_seq += 1;
-    k_full_pub<<<1, 64, 0, h->stream>>>(h->d_scalars, h->h_full, h->full_seq);
+    k_full_pub<<<1, 64, 0, fs>>>(h->d_scalars, h->h_full, h->full_seq);
     { const hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { reset_acc(); h->err = hipGetErrorString(e_); return GRAAL_E_HIP; } }
+    return GRAAL_OK;
+}
+
+static int full_collect(graal_ctx* h, hipStream_t fs, int64_t q_out[2])
+{
+    auto reset_acc = [&]() {
+        (void)hipStreamSynchronize(fs);
+        (void)hipGetLastError();
+        (void)hipMemset(h->d_scalars + 8, 0, 2 * sizeof(long long));
+        (void)hipMemset(h->d_scalars + 17, 0, sizeof(long long));
+        (void)hipMemset(h->d_scalars + FULL_BAD, 0, sizeof(long long));
+    };
     {
         volatile long long* p = h->h_full;
         bool seen = false;
         for (long long spin = 0; spin < 400000000ll; spin++) {
             if (p[0] == h->full_seq) { seen = true; break; }
-            if ((spin & 0xfffff) == 0xfffff && hipStreamQuery(h->stream) != hipErrorNotReady) { seen = (p[0] == h->full_seq); break; }
+            if ((spin & 0xfffff) == 0xfffff && hipStreamQuery(fs) != hipErrorNotReady) { seen = (p[0] == h->full_seq); break; }
             __builtin_ia32_pause();
         }
         if (!seen) {
-            const hipError_t e_ = hipStreamSynchronize(h->stream);
+            const hipError_t e_ = hipStreamSynchronize(fs);
             if (e_ != hipSuccess || p[0] != h->full_seq) { reset_acc(); return fail(h, GRAAL_E_HIP, "the full evaluation did not publish its sums"); }
         }
         __sync_synchronize();
@@ -5215,6 +5234,13 @@ int graal_eval_full_q(graal_ctx* h, int64_t q_out[2])
     q_out[1] = -(res[1] + (int64_t)llrint(h->t_all * Q_SCALE)) + rep_q;
     if (bad) { q_out[0] = Q_BAD; q_out[1] = 0; } // a term was not finite / out of range: INT64_MIN exactly, the host reports NaN
     return GRAAL_OK;
+}
+
+int graal_eval_full_q(graal_ctx* h, int64_t q_out[2])
+{
+    if (!h || !q_out) return GRAAL_E_ARG;
+    const int rc = full_launch(h, h->stream);
+    return rc ? rc : full_collect(h, h->stream, q_out);
 }
 
 int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int32_t max_id, int32_t rank, int32_t world,

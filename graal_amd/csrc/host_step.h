@@ -234,21 +234,39 @@ static int hs_select(MtState* mt, const double* score, int n, int n_tmp)
 
 // second half of a step: score the candidates of the neighbours drawn by graal_step, sample, commit.  Returns GRAAL_STEP_DONE,
 // GRAAL_STEP_FALLBACK or 16 + a GRAAL_E_* code (error codes 1 and 2 must not be taken for PAUSED / FALLBACK)
-static int hs_finish(graal_ctx* h, MtState* mt, double likelihood_t, int want_dist, graal_step_out* out, bool deferred = false)
+#define CK16(call) do { const hipError_t e16_ = (call); if (e16_ != hipSuccess) { h->err = hipGetErrorString(e16_); return 16 + GRAAL_E_HIP; } } while (0)
+static int hs_finish(graal_ctx* h, MtState* mt, double likelihood_t, int want_dist, graal_step_out* out, bool deferred = false,
+                     bool full_inside = false)
 {
     if (!h->hs) return 16 + fail(h, GRAAL_E_STATE, "graal_upload_proposal_tables first");
     HostStep& S = *h->hs;
     const int K = (int)S.nb.size();
     if (K < 1 || K > 128) return 16 + fail(h, GRAAL_E_STATE, "graal_step_finish: no step in progress");
-    long long q[MAXK * N_OPS];
+    if (full_inside) {
+        // the step's total is due for a full re-evaluation (the reference re-evaluates every step, cuda_lib_gl.py:1828-1848): its kernels
+        // go out on a stream of their own, behind the relabel, and run NEXT TO the scoring kernels -- which are latency, not throughput
+        CK16(hipEventRecord(h->ev_full, h->stream));
+        CK16(hipStreamWaitEvent(h->fstream, h->ev_full, 0));
+        const int rc = full_launch(h, h->fstream);
+        if (rc) return 16 + rc;
+    }
+    long long q[128 * N_OPS];
     for (int k0 = 0; k0 < K; k0 += MAXK) {
         const int kk = std::min(MAXK, K - k0);
-        const int rc = eval_sync(h, S.fA, S.nb.data() + k0, kk, S.max_id, h->x_host ? h->x_rank : 0, h->x_host ? h->x_world : 1, q);
+        const int rc = eval_sync(h, S.fA, S.nb.data() + k0, kk, S.max_id, h->x_host ? h->x_rank : 0, h->x_host ? h->x_world : 1, q + k0 * N_OPS);
+        if (rc) { if (full_inside) { int64_t dump[2]; (void)full_collect(h, h->fstream, dump); } return 16 + rc; }
+    }
+    if (full_inside) {
+        int64_t fq[2];
+        const int rc = full_collect(h, h->fstream, fq);
         if (rc) return 16 + rc;
-        for (int i = 0; i < kk * N_OPS; i++) {
-            const double d = llabs(q[i]) >= (Q_NAN >> 1) ? (double)NAN : (double)q[i] / Q_SCALE;
-            out->scores[k0 * N_OPS + i] = d + likelihood_t;
-        }
+        // (float(q0 + q1) / Q_SCALE of the Python path: the integer sum is exact, one conversion, one division by a power of two)
+        likelihood_t = fq[0] == Q_BAD ? (double)NAN : (double)(fq[0] + fq[1]) / Q_SCALE;
+        out->full_likelihood = likelihood_t;
+    }
+    for (int i = 0; i < K * N_OPS; i++) {
+        const double d = llabs(q[i]) >= (Q_NAN >> 1) ? (double)NAN : (double)q[i] / Q_SCALE;
+        out->scores[i] = d + likelihood_t;
     }
     const double t2 = S.timing ? hs_now() : 0.0;
     if (deferred) {   // the statistics of the layout this step started from: published long ago, read now
@@ -316,7 +334,11 @@ int graal_step(graal_ctx* h, void* mt_state, int32_t fA, int32_t delta, double l
     rc = graal_begin_step(h, out->stats, &out->max_id);
     if (rc) { *mt = keep; S.nb.clear(); return 16 + rc; }
     S.max_id = out->max_id;
-    if ((flags & 2) || ((flags & 1) && (out->stats[6] != 0 || prev_circ != 0))) return GRAAL_STEP_PAUSED;
+    if ((flags & 2) || ((flags & 1) && (out->stats[6] != 0 || prev_circ != 0))) {
+        // a full re-evaluation is due: inside the step (flag 8; one rank, whose sums are the whole likelihood) or by the caller
+        if ((flags & 8) && !h->x_host) return hs_finish(h, mt, likelihood_t, (flags & 4) != 0, out, false, true);
+        return GRAAL_STEP_PAUSED;
+    }
     return hs_finish(h, mt, likelihood_t, (flags & 4) != 0, out);
 }
 

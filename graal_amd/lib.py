@@ -11,7 +11,7 @@ import numpy as np
 from . import build as _build
 
 N_OPS = 13
-ABI_VERSION = 4
+ABI_VERSION = 5
 MODE_REF_TRANS_ACCU, MODE_STRICT = 1, 2
 MAX_NEIGHBOURS = 10
 Q_SCALE = float(1 << 30)
@@ -40,7 +40,7 @@ class StepOut(ctypes.Structure):
     _fields_ = [("stats", ctypes.c_int64 * 8), ("max_id", ctypes.c_int32), ("n_neighbours", ctypes.c_int32),
                 ("neighbours", ctypes.c_int32 * 128), ("sample_out", ctypes.c_int32), ("op_sampled", ctypes.c_int32),
                 ("id_f_sampled", ctypes.c_int32), ("pad", ctypes.c_int32), ("o", ctypes.c_double),
-                ("dist_half_units", ctypes.c_int64), ("scores", ctypes.c_double * (128 * N_OPS))]
+                ("dist_half_units", ctypes.c_int64), ("scores", ctypes.c_double * (128 * N_OPS)), ("full_likelihood", ctypes.c_double)]
 
 
 _lib = None

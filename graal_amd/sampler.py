@@ -771,6 +771,8 @@ class sampler(object):
         resync = self.likelihood_t is None or self._force_full or self._steps_since_full + 1 >= self.resync_every
         if resync:
             flags |= 2
+        if self.group.world == 1:
+            flags |= 8    # a full re-evaluation that is due (resync, circular contigs with sub-fragments) runs INSIDE the step, next to the scoring kernels
         if self.compute_dist and not self._dist_ref_uploaded:
             self.dist_inter_genome()                               # (uploads the reference layout of the distance once)
         rc = e.step(self._mt_addr, id_fA, int(delta), 0.0 if self.likelihood_t is None else float(self.likelihood_t), flags,
@@ -788,6 +790,9 @@ class sampler(object):
         n_circ = int(st[6])
         self.n_stale_paste += int(st[7])
         self._steps_since_full += 1
+        if (flags & 8) and rc != STEP_PAUSED and resync:   # (re-evaluated inside the step: graal_step_out.full_likelihood)
+            self._steps_since_full = 0
+            self._force_full = False
         if rc == STEP_PAUSED:
             if resync:
                 self.likelihood_t = self._full_likelihood()

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GRAAL_ABI_VERSION 4
+#define GRAAL_ABI_VERSION 5
 #define GRAAL_N_OPS 13        /* candidates per (fA, fB): cuda_lib_gl.py:112 n_tmp_struct */
 #define GRAAL_MAX_NEIGHBOURS 10 /* neighbours scored by one scan pass (the reference proposes at most n_neighbors = 10, cuda_lib_gl.py:444) */
 #define GRAAL_Q_BITS 30
@@ -210,6 +210,7 @@ typedef struct graal_step_out {
     double o;                /* its score (likelihood_t + delta) */
     int64_t dist_half_units; /* graal_genome_distance of the new layout (flag bit 2) */
     double scores[128 * GRAAL_N_OPS];
+    double full_likelihood;  /* flag 8: the full likelihood of the layout the step started from, re-evaluated inside the step */
 } graal_step_out;
 
 enum { GRAAL_STEP_DONE = 0, GRAAL_STEP_PAUSED = 1, GRAAL_STEP_FALLBACK = 2 /* 16 + GRAAL_E_*: error */ };
@@ -222,7 +223,8 @@ int graal_upload_proposal_tables(graal_ctx* h, const int32_t* xk, const float* p
 /* One MCMC step for a fragment that is not blacklisted: relabel + statistics (graal_begin_step), proposal, candidate scores
  * (graal_eval_candidates / _x), sampling, commit (graal_apply_move), optionally the genome distance.
  * flags: 1 = pause after the proposal if circular contigs exist now or did at the previous step (`prev_circ`); 2 = pause
- * always; 4 = genome distance.  Returns GRAAL_STEP_DONE, GRAAL_STEP_PAUSED (the caller refreshes its total and calls
+ * always; 4 = genome distance; 8 = instead of pausing, re-evaluate the full likelihood INSIDE the step, next to the scoring
+ * kernels (out->full_likelihood replaces `likelihood_t`; one rank only -- with an exchange attached the step pauses as before).  Returns GRAAL_STEP_DONE, GRAAL_STEP_PAUSED (the caller refreshes its total and calls
  * graal_step_finish), GRAAL_STEP_FALLBACK (an unusual case numpy itself has to judge: nothing drawn, nothing committed; after
  * graal_step_finish: out->scores are valid, the selection is the caller's) or 16 + an error code. */
 int graal_step(graal_ctx* h, void* mt_state, int32_t fA, int32_t delta, double likelihood_t, int32_t flags, int32_t prev_circ,
