@@ -3271,7 +3271,8 @@ __device__ __forceinline__ void piece_extent(const PieceKey& key, const Geo& gA,
 
 __global__ __launch_bounds__(256) void k_strict_cull(const NbTables* __restrict__ tabs, const Geo* __restrict__ geo, const Link* __restrict__ link,
                                                       const int* __restrict__ cbase, const int* __restrict__ perm, int fA, int K, int rank, int world,
-                                                      int reach_bp, int no_window, int seg, unsigned long long* __restrict__ list,
+                                                      int reach_bp, int no_window, int seg_fixed /* 0: chosen here */, int seg_min,
+                                                      unsigned long long target_units, unsigned long long* __restrict__ list,
                                                       unsigned long long* __restrict__ list_n, unsigned long long cap,
                                                       unsigned long long* __restrict__ counters)
 {
@@ -3295,6 +3296,18 @@ __global__ __launch_bounds__(256) void k_strict_cull(const NbTables* __restrict_
     if (t == 0) { s_rbase[0] = 0; for (int k = 0; k < K; k++) s_rbase[k + 1] = s_rbase[k] + s_sg[k].nt; }
     __syncthreads();
     const int n_rows = s_rbase[K];
+    // fragments y per unit (a power of two): the y tiles are cut so that the step has ~target_units units -- from the sets of THIS step
+    // (every block finds the same value).  (The host used to choose it from the longest contig of the layout: a step between two
+    // contigs of 400 bins in a layout that also holds one of 2,000 got units of 32 fragments y x ~5 classes, a few hundred units
+    // for 2,048 waves.)
+    int seg = seg_fixed;
+    if (seg <= 0) {
+        unsigned long long est = 0;
+        for (int k = 0; k < K; k++) { const unsigned long long nt = (unsigned long long)s_sg[k].nt; est += nt * (nt + 1ull) / 2ull; }
+        seg = 64;
+        while (seg > seg_min && est * (unsigned long long)(64 / seg) < target_units) seg >>= 1;
+    }
+    const unsigned long long lg_seg = (unsigned long long)(31 - __clz(seg));
     // old bp extent of tile tt of neighbour k
     auto tile_extent = [&](int k, int tt, int& lo, int& hi, int& side) {
         const SetGeo& sg = s_sg[k];
@@ -3360,7 +3373,7 @@ __global__ __launch_bounds__(256) void k_strict_cull(const NbTables* __restrict_
                 base = __shfl(base, 0, 64);
                 for (int e = 0; e < ne; e++) {
                     const unsigned long long at = base + (unsigned long long)(incl - ne + e);
-                    if (at < cap) list[at] = ((unsigned long long)k << 56) | ((unsigned long long)ti << 32) | ((unsigned long long)tj << 8) | (unsigned long long)e;
+                    if (at < cap) list[at] = ((unsigned long long)k << 56) | (lg_seg << 52) | ((unsigned long long)ti << 32) | ((unsigned long long)tj << 8) | (unsigned long long)e;
                     else atomicOr(&counters[6], 2ull);   // (cannot happen: the host sizes the list for the longest contig)
                 }
             }
@@ -3428,7 +3441,8 @@ __global__ __launch_bounds__(256) void k_strict(FinArgs fa, StrictArgs sa, int f
     STileW* tile = s_tile[wib];
     for (unsigned long long u = (unsigned long long)wave; u < n_units; u += (unsigned long long)n_waves) {
         const unsigned long long ent = list[u];
-        const int k = (int)(ent >> 56), ti = (int)((ent >> 32) & 0xffffffull), tj = (int)((ent >> 8) & 0xffffffull), j0 = (int)(ent & 0xffull) * sa.seg;
+        const int seg = 1 << (int)((ent >> 52) & 7ull);   // (fragments y of this unit: chosen per step by k_strict_cull)
+        const int k = (int)(ent >> 56), ti = (int)((ent >> 32) & 0xfffffull), tj = (int)((ent >> 8) & 0xffffffull), j0 = (int)(ent & 0xffull) * seg;
         const SetGeo sg = s_sg[k];
         const PieceKey key = tabs[k].key;
         auto frag_at = [&](int tt, int l, bool& ok) {
@@ -3451,7 +3465,7 @@ __global__ __launch_bounds__(256) void k_strict(FinArgs fa, StrictArgs sa, int f
         {   // the unit's segment of the y tile: fragments j0 .. j0 + seg of it
             bool has_y;
             const int fy = frag_at(tj, j0 + lane, has_y);
-            has_y = has_y && lane < sa.seg;
+            has_y = has_y && lane < seg;
             if (has_y) {
                 STileW y; y.frag = fy; y.g = geo[fy]; y.st = stat[fy];
                 y.piece = piece_of(key, y.g.id_c, geo_pos(y.g.flags));
@@ -4449,17 +4463,17 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
     // fragments y per unit: a 64 x 64 tile pair under half a dozen classes with nine slot pairs each is a millisecond of dependent
     // float32 powf / expf in ONE wave -- with contigs of a few hundred bins a step has a few dozen tile pairs, and the C2 stand-in
     // ran at 3.2 ms per step.  The y tile is cut into segments so that the grid has ~6 units per wave (bounded below: the x tile
-    // is loaded once per unit).
+    // is loaded once per unit) -- by k_strict_cull, which knows the sets of THIS step; GRAAL_STRICT_SEG fixes it.
     static const int seg_env = getenv("GRAAL_STRICT_SEG") ? atoi(getenv("GRAAL_STRICT_SEG")) : 0;
-    int seg = 64;
-    {
-        const unsigned long long est = (unsigned long long)K * nt * (nt + 1ull) / 2ull, target = 6ull * 4ull * (unsigned long long)blocks;
-        const int seg_min = h->single_sub ? 4 : 1;
-        while (seg > seg_min && est * (unsigned long long)(64 / seg) < target) seg >>= 1;
-        if (seg_env == 1 || seg_env == 2 || seg_env == 4 || seg_env == 8 || seg_env == 16 || seg_env == 32 || seg_env == 64) seg = seg_env;
-    }
-    sx.seg = seg;
-    const unsigned long long need = (unsigned long long)K * nt * (nt + 1ull) / 2ull * (unsigned long long)(64 / seg) + 64ull;
+    const int seg_fixed = (seg_env == 1 || seg_env == 2 || seg_env == 4 || seg_env == 8 || seg_env == 16 || seg_env == 32 || seg_env == 64) ? seg_env : 0;
+    const int seg_min = h->single_sub ? 4 : 1;
+    const unsigned long long target = 6ull * 4ull * (unsigned long long)blocks;
+    sx.seg = 0;
+    // units: at most one per tile pair when the segments stay whole tiles, below 2 x target once they are cut (the cut stops at the
+    // first size that reaches the target), or every tile pair cut to the fixed / smallest size
+    const unsigned long long pairs_max = (unsigned long long)K * nt * (nt + 1ull) / 2ull;
+    const unsigned long long need = (seg_fixed ? pairs_max * (unsigned long long)(64 / seg_fixed)
+                                               : std::max(pairs_max, std::min(pairs_max * (unsigned long long)(64 / seg_min), 2ull * target))) + 64ull;
     if (need > h->slist_cap) {
         CK(hipStreamSynchronize(st));
         CK(hipStreamSynchronize(h->aux));
@@ -4476,7 +4490,7 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
     const int no_window = (sx.quirk && h->n_ubins > 0) ? 1 : 0;
     // rows of candidate units = tiles of the affected sets: a block per row up to the chip's width
     const int cull_blocks = (int)std::min<unsigned long long>(1024ull, std::max<unsigned long long>(1ull, (unsigned long long)K * nt));
-    k_strict_cull<<<cull_blocks, 256, 0, h->aux>>>(h->tabs, h->geo, h->link, h->cbase, h->perm, fA, K, rank, world, sx.reach_bp, no_window, seg,
+    k_strict_cull<<<cull_blocks, 256, 0, h->aux>>>(h->tabs, h->geo, h->link, h->cbase, h->perm, fA, K, rank, world, sx.reach_bp, no_window, seg_fixed, seg_min, target,
                                                    h->d_slist, h->d_slist_n, h->slist_cap, (unsigned long long*)(h->d_scalars + 10));
     CK(hipGetLastError());
     CK(hipEventRecord(h->ev_tm, h->aux));      // (behind k_tm and the cull: tables and unit list complete -- nobody spins for them)
