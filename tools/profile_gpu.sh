@@ -17,7 +17,7 @@ case $WHAT in
   c5)   ARGS="$REPO/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-late-stage --no-hbm-control" ;;
   late) ARGS="$REPO/bench.py --layout original --steps 30 --warmup 5 --mcmc-warmup 0 --no-cpu-baseline --no-late-stage --no-hbm-control" ;;
   c2)   ARGS="$REPO/tools/step_breakdown.py --n-bins 1086 --nnz 120000 --n-sub 3 --original --steps 400" ;;
-  c4)   ARGS="$REPO/tools/run_configs.py C4 --cycles 2" ;;
+  c4)   ARGS="$REPO/tools/run_configs.py C4 --cycles ${C4_CYCLES:-2}" ;;
 esac
 cd /tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
