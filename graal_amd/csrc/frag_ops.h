@@ -432,6 +432,20 @@ GR_HD bool same_inputs(const Xf& p1, const Xf& q1, const Xf& p2, const Xf& q2, b
     return p1.circ != 1 || p1.lbp == p2.lbp;
 }
 
+// what same_inputs compares, packed into four words: inputs_key(p1, q1) == inputs_key(p2, q2) (all four words) <=> same_inputs(p1, q1,
+// p2, q2).  The table kernel compares these keys -- one 16-byte LDS read per comparison instead of four 5-word transforms
+// (tests/test_host_logic.py checks the equivalence on the host).
+struct InputsKey { int x, y, z, w; };
+GR_HD InputsKey inputs_key(const Xf& a, const Xf& b, bool quirk)
+{
+    const bool cis = a.label == b.label;
+    InputsKey k;
+    k.x = cis ? a.off : 0; k.y = cis ? b.off : 0; k.z = (cis && a.circ == 1) ? a.lbp : 0;
+    const bool sig = cis || quirk;
+    k.w = (cis ? 1 : 0) | ((sig && a.sigma == 1) ? 2 : 0) | ((sig && b.sigma == 1) ? 4 : 0) | (cis ? (int)((unsigned)a.circ << 3) : 0);
+    return k;
+}
+
 // geometry inside ONE piece changes only through the circular model (or if the piece is torn, which
 // cannot happen: pieces are the tear units)
 GR_HD bool intra_changed(const Xf& p_old, const Xf& p_new)

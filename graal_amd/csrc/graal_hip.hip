@@ -1348,12 +1348,8 @@ __device__ __forceinline__ int tables_block(const Geo* __restrict__ geo, const L
         // critical path -- tools/stamps_step.py, tools/stamps_c4.py)
         __shared__ int4 s_key[N_PAIRS][N_OPS + 1];
         auto key_of = [&](const Xf& a, const Xf& b) {
-            const bool cis = a.label == b.label;
-            int4 k4;
-            k4.x = cis ? a.off : 0; k4.y = cis ? b.off : 0; k4.z = (cis && a.circ == 1) ? a.lbp : 0;
-            const bool sig = cis || quirk != 0;
-            k4.w = (cis ? 1 : 0) | ((sig && a.sigma > 0) ? 2 : 0) | ((sig && b.sigma > 0) ? 4 : 0) | (cis ? (a.circ << 3) : 0);
-            return k4;
+            const InputsKey ik = inputs_key(a, b, quirk != 0);   // (frag_ops.h)
+            return make_int4(ik.x, ik.y, ik.z, ik.w);
         };
         for (int e = t; e < N_PAIRS * (N_OPS + 1); e += TM_THREADS) {
             const int pair = e / (N_OPS + 1), op = e - pair * (N_OPS + 1);

@@ -82,4 +82,21 @@ void hc_piece_tables(int fA, int fB, int max_id, int32_t* const* s, int n, int32
     }
 }
 
+// inputs_key against same_inputs on n random quadruples of transforms drawn from small ranges (so that equal inputs occur):
+// returns the number of disagreements
+int hc_inputs_key_disagreements(int n, unsigned seed, int quirk)
+{
+    unsigned st_ = seed * 2654435761u + 12345u;
+    auto rnd = [&](int m) { st_ = st_ * 1664525u + 1013904223u; return (int)((st_ >> 16) % (unsigned)m); };
+    auto rxf = [&]() { Xf x; x.label = rnd(3); x.sigma = rnd(2) ? 1 : -1; x.off = rnd(4) * 1000 - 1000; x.circ = rnd(2); x.lbp = 5000 + 1000 * rnd(3); return x; };
+    int bad = 0;
+    for (int i = 0; i < n; i++) {
+        const Xf p1 = rxf(), q1 = rxf(), p2 = rxf(), q2 = rxf();
+        const InputsKey a = inputs_key(p1, q1, quirk != 0), b = inputs_key(p2, q2, quirk != 0);
+        const bool eq = a.x == b.x && a.y == b.y && a.z == b.z && a.w == b.w;
+        bad += eq != same_inputs(p1, q1, p2, q2, quirk != 0);
+    }
+    return bad;
+}
+
 } // extern "C"

@@ -309,3 +309,13 @@ def test_c_neighbour_proposal_equals_the_python_path_values_and_generator_state(
         sa, sb = a.get_state(legacy=False)["state"], b.get_state(legacy=False)["state"]
         assert np.array_equal(sa["key"], sb["key"]) and sa["pos"] == sb["pos"], trial
     L.graal_destroy(h)
+
+
+def test_packed_class_keys_are_equivalent_to_same_inputs():
+    """The table kernel sorts the 13 candidates of a piece pair into classes of equal contact-model inputs by comparing 128-bit keys
+    (frag_ops.h: inputs_key); the definition of "equal inputs" is same_inputs.  On two million random quadruples of transforms drawn
+    from small ranges (so that equal inputs do occur), with and without the trans-branch RF-count indexing: key equality == same_inputs."""
+    from tests import util
+    hc = util.hostcheck()
+    for quirk in (0, 1):
+        assert hc.hc_inputs_key_disagreements(1_000_000, 7 + quirk, quirk) == 0
