@@ -30,7 +30,7 @@ def hipcc_path():
 
 def build_hip(force=False, verbose=False):
     srcs = [os.path.join(CSRC, "graal_hip.hip"), os.path.join(CSRC, "frag_ops.h"), os.path.join(CSRC, "host_step.h"),
-            os.path.join(CSRC, "model_math.h"), os.path.join(ROOT, "include", "graal_hip.h")]
+            os.path.join(CSRC, "model_math.h"), os.path.join(CSRC, "strict_sets.h"), os.path.join(CSRC, "strict2.h"), os.path.join(ROOT, "include", "graal_hip.h")]
     if force or _newer(HIP_LIB, srcs):
         cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-ffp-contract=off",  # float32 model arithmetic exactly as written (parity with the oracle)
@@ -42,7 +42,7 @@ def build_hip(force=False, verbose=False):
 
 
 def build_hostcheck(force=False):
-    srcs = [os.path.join(CSRC, "host_check.cpp"), os.path.join(CSRC, "frag_ops.h")]
+    srcs = [os.path.join(CSRC, "host_check.cpp"), os.path.join(CSRC, "frag_ops.h"), os.path.join(CSRC, "strict_sets.h")]
     if force or _newer(HOSTCHECK_LIB, srcs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", HOSTCHECK_LIB, srcs[0]])
     return HOSTCHECK_LIB

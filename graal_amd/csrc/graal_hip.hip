@@ -29,6 +29,7 @@
 
 #include "../../include/graal_hip.h"
 #include "frag_ops.h"
+#include "strict_sets.h"
 #include "model_math.h"
 
 using namespace graal;
@@ -3799,6 +3800,8 @@ __global__ __launch_bounds__(256) void k_strict_flat(FinArgs fa, StrictArgs sa, 
 #undef CMASK_
 }
 
+#include "strict2.h"
+
 // ------------------------------------------------------------------ repeated bins (allow_repeats)
 // A repeated ("duplicated") bin has several fragment copies (frag_dispatcher / collector_id_repeats,
 // simulation_loader.py:258-277); the expected value of a pixel is the float32 sum over the ACTIVE copy pairs of its two
@@ -4111,6 +4114,9 @@ struct Ctx {
     unsigned long long* d_slist = nullptr;   // k_strict's unit list (k_strict_cull fills it), slist_cap entries
     unsigned long long* d_slist_n = nullptr; // its length, a word of d_scalars (zero at rest: k_strict's last block clears it)
     unsigned long long slist_cap = 0;
+    USet* d_uset = nullptr;       // reference arithmetic over the step's union set (strict2.h): the set, the classes per pair of global pieces
+    GClass* d_cls = nullptr;
+    int* d_cls_n = nullptr;
     unsigned scan_token = 0x5ca90000u; // k_scan launches so far (ScanArgs.token)
     double* d_ln_tab = nullptr;   // [LN_TRANS_LUT] ln of the trans value by RF-count product (k_ln_tab; rebuilt by sync_args)
     int* d_ubins = nullptr;       // bins whose sub-fragments carry different RF counts (k_quirk_mass)
@@ -4451,6 +4457,58 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
         CK(hipGetLastError());
         return GRAAL_OK;
     }
+    static const bool v1 = getenv("GRAAL_STRICT_V1") != nullptr && atoi(getenv("GRAAL_STRICT_V1")) != 0;   // (A/B: the per-neighbour kernels of round 3)
+    if (!v1) {
+        // the union set's kernels (strict2.h): k_gprep (classes per pair of global pieces + the unit list) on the auxiliary stream behind
+        // k_tm, under the scan; k_strict2 waits for both
+        if (!h->d_uset) {
+            CK(hipMalloc(&h->d_uset, sizeof(USet)));
+            CK(hipMalloc(&h->d_cls, sizeof(GClass) * (size_t)US_MAXPAIRS * US_NCAND));
+            CK(hipMalloc(&h->d_cls_n, sizeof(int) * US_MAXPAIRS));
+            CK(hipMemset(h->d_cls_n, 0, sizeof(int) * US_MAXPAIRS));
+        }
+        const int lc = std::max(std::max(h->max_lcont, h->lcont_bound), 1);
+        static const int blocks_env = getenv("GRAAL_STRICT_BLOCKS") ? atoi(getenv("GRAAL_STRICT_BLOCKS")) : 0;
+        const int blocks = blocks_env > 0 ? blocks_env : (lc <= 64 ? 32 : (lc <= 1024 ? 512 : 1024));
+        // tiles of the union: at most K + 1 contigs, at most every fragment; + one partial tile per global piece
+        const unsigned long long nt = std::min<unsigned long long>((unsigned long long)(K + 1) * (unsigned long long)((lc + 63) / 64),
+                                                                   (unsigned long long)((h->n + 63) / 64 + K + 1)) + (unsigned long long)US_MAXP;
+        if (nt >= 65536ull) return fail(h, GRAAL_E_STATE, "reference arithmetic: more than 65,535 tiles in a step's union set");
+        static const int seg_env = getenv("GRAAL_STRICT_SEG") ? atoi(getenv("GRAAL_STRICT_SEG")) : 0;
+        const int seg_max = h->single_sub ? 16 : 4, seg_min = h->single_sub ? 4 : 1;
+        const int seg_fixed = (seg_env == 1 || seg_env == 2 || seg_env == 4 || seg_env == 8 || seg_env == 16) && seg_env <= seg_max ? seg_env : 0;
+        const unsigned long long target = 6ull * 4ull * (unsigned long long)blocks;
+        const unsigned long long pairs_max = nt * (nt + 1ull) / 2ull;
+        const unsigned long long need = (seg_fixed ? pairs_max * (unsigned long long)(64 / seg_fixed)
+                                                   : std::max(pairs_max * (unsigned long long)(64 / seg_max), std::min(pairs_max * (unsigned long long)(64 / seg_min), 2ull * target))) + 64ull;
+        if (need > h->slist_cap) {
+            CK(hipStreamSynchronize(st));
+            CK(hipStreamSynchronize(h->aux));
+            if (h->d_slist) CK(hipFree(h->d_slist));
+            h->d_slist = nullptr;
+            const unsigned long long cap = std::max<unsigned long long>(need + need / 2ull, 1ull << 16);
+            CK(hipMalloc(&h->d_slist, cap * sizeof(unsigned long long)));
+            h->slist_cap = cap;
+        }
+        h->d_slist_n = (unsigned long long*)(h->d_scalars + SLIST_N);
+        sx.list_cap = h->slist_cap;
+        sx.seg = 0;
+        fa.norm_u = h->uniform_accu > 0 ? (float)(h->uniform_accu * h->uniform_accu) / h->nfpb : -1.0f;
+        const int no_window = (sx.quirk && h->n_ubins > 0) ? 1 : 0;
+        S2Args s2;
+        s2.uset = h->d_uset; s2.cls = h->d_cls; s2.cls_n = h->d_cls_n;
+        const int cull_blocks = (int)std::min<unsigned long long>(1024ull, std::max<unsigned long long>(1ull, nt));
+        k_gprep<<<GPREP_CLS_BLOCKS + cull_blocks, 256, 0, h->aux>>>(h->tabs, h->geo, h->link, h->cbase, h->perm, fA, K, rank, world, sx.reach_bp, no_window, sx.quirk,
+                                                                     seg_fixed, seg_min, seg_max, target, h->d_slist, h->d_slist_n, h->slist_cap,
+                                                                     (unsigned long long*)(h->d_scalars + 10), s2);
+        CK(hipGetLastError());
+        CK(hipEventRecord(h->ev_tm, h->aux));      // (behind k_tm and k_gprep: tables, classes and unit list complete -- nobody spins for them)
+        CK(hipStreamWaitEvent(st, h->ev_tm, 0));
+        if (h->single_sub) k_strict2<false><<<blocks, 256, 0, st>>>(fa, sx, s2, K, h->d_slist, h->d_slist_n, d_q_out, publish ? h->res_dev : nullptr, h->seq);
+        else k_strict2<true><<<blocks, 256, 0, st>>>(fa, sx, s2, K, h->d_slist, h->d_slist_n, d_q_out, publish ? h->res_dev : nullptr, h->seq);
+        CK(hipGetLastError());
+        return GRAAL_OK;
+    }
     // the unit list holds at most K * nt (nt + 1) / 2 entries, nt = tiles of the two longest contigs (grow-only)
     const unsigned long long nt = 2ull * (unsigned long long)((std::max(std::max(h->max_lcont, h->lcont_bound), 1) + 63) / 64);
     static const int blocks_env = getenv("GRAAL_STRICT_BLOCKS") ? atoi(getenv("GRAAL_STRICT_BLOCKS")) : 0;
@@ -4665,7 +4723,7 @@ void graal_destroy(graal_ctx* h)
         (void)hipSetDevice(h->device);
         (void)hipStreamSynchronize(h->stream);
         if (h->aux) (void)hipStreamSynchronize(h->aux);
-        void* ptrs[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->stat, h->sub_rec, h->sub_rec8, h->sub_lab16, h->d_ubins, h->d_ln_tab, h->sub2bin, h->row, h->col, h->cnt, h->queue, h->d_sub_ids, h->d_acc, h->tm_done, h->d_sync, h->d_done, h->d_wq, h->d_flags, h->d_slist, h->stat_frag, h->d_dup_bins, h->d_dup_index,
+        void* ptrs[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->stat, h->sub_rec, h->sub_rec8, h->sub_lab16, h->d_ubins, h->d_ln_tab, h->sub2bin, h->row, h->col, h->cnt, h->queue, h->d_sub_ids, h->d_acc, h->tm_done, h->d_sync, h->d_done, h->d_wq, h->d_flags, h->d_slist, h->d_uset, h->d_cls, h->d_cls_n, h->stat_frag, h->d_dup_bins, h->d_dup_index,
                         h->d_dispatcher, h->d_collector, h->d_sub_ids_all, h->d_rep_obs,
                         h->keys, h->keys_sorted, h->o2n, h->len_of2[0], h->len_of2[1], h->contig_off2[0], h->contig_off2[1], h->perm, h->cbase, h->link, h->mates, h->cub_tmp, h->tabs, h->step_hdr, h->d_args, h->d_chg, h->d_part,
                         h->d_scalars, h->d_qout, h->d_dref, h->d_dist};

@@ -1,9 +1,15 @@
-// host_check.cpp -- TEST ONLY.  Host build of frag_ops.h so that the CPU test-suite can compare the engine's
-// layout algebra (mutations, pieces, per-piece transforms, relation flags) with the oracle without a GPU.
+// host_check.cpp -- TEST ONLY.  Host build of frag_ops.h / strict_sets.h so that the CPU test-suite can compare the engine's
+// layout algebra (mutations, pieces, per-piece transforms, relation flags; the union set of a step, its classes of equal inputs
+// and its work units) with the oracle and with brute force without a GPU.
 // No likelihood code here and nothing in graal_amd/ loads this library.
+#include <stddef.h>
 #include <stdint.h>
 
+#include <vector>
+#include <map>
+
 #include "frag_ops.h"
+#include "strict_sets.h"
 
 using namespace graal;
 
@@ -96,6 +102,215 @@ int hc_inputs_key_disagreements(int n, unsigned seed, int quirk)
         const bool eq = a.x == b.x && a.y == b.y && a.z == b.z && a.w == b.w;
         bad += eq != same_inputs(p1, q1, p2, q2, quirk != 0);
     }
+    return bad;
+}
+
+// ---- strict_sets.h: the union set of a step, its global pieces, the classes of equal inputs per piece pair and the unit list,
+// checked against brute force on one proposal (fA, fB[0..K)) of a layout:
+//   (1) every fragment of the K sets lies in exactly one global piece, whose per-neighbour piece ids are piece_of's;
+//   (2) for every unordered pair of union fragments and every candidate (k, op) whose set holds both: the model's inputs obtained by
+//       applying the candidate move to the two fragments THEMSELVES (apply_move) equal those of the pair's class representative
+//       (or the current layout's, when the candidate is in no class);
+//   (3) two candidates of one class have equal inputs_key, two classes different ones, no class has the current layout's;
+//   (4) the unit list with every tile pair alive covers every unordered pair of union fragments exactly once.
+// Returns the number of violations (0 = fine); info[0..9]: pieces, tiles, contigs, piece pairs with classes, classes, units, pairs, candidates checked, model evaluations
+// (no window) over the union's classes, the same one neighbour at a time.
+int hc_union_check(int fA, const int32_t* fB, int K, int max_id, int32_t* const* s, int n, int quirk, int seg, int64_t* info)
+{
+    int bad = 0;
+    // position index
+    std::map<int, int> base_of;
+    std::vector<int> perm(n), cbase(n);
+    {
+        std::map<int, int> len;
+        for (int f = 0; f < n; f++) len[s[F_IDC][f]] = s[F_LCONT][f];
+        int b = 0;
+        for (auto& kv : len) { base_of[kv.first] = b; b += kv.second; }
+        for (int f = 0; f < n; f++) { cbase[f] = base_of[s[F_IDC][f]]; perm[cbase[f] + s[F_POS][f]] = f; }
+    }
+    auto end_of = [&](int f) { UEnd e; e.label = s[F_IDC][f]; e.pos = s[F_POS][f]; e.base = cbase[f]; e.len = s[F_LCONT][f]; e.lbp = s[F_LCONTBP][f]; e.circ = s[F_CIRC][f]; return e; };
+    // per-neighbour tables (as k_tm builds them)
+    std::vector<Xf> xf((size_t)K * N_OPS * (MAX_PIECES + 1));
+    std::vector<PieceKey> keys(K);
+    std::vector<UEnd> B(K);
+    unsigned live = 0;
+    const Rec A0 = ld(s, fA);
+    for (int k = 0; k < K; k++) {
+        const Rec B0 = ld(s, fB[k]);
+        PieceKey key; key.cA = A0.id_c; key.a = A0.pos; key.cB = B0.id_c; key.b = B0.pos;
+        keys[k] = key; B[k] = end_of(fB[k]);
+        if (fB[k] != fA) live |= 1u << k;
+        int rep[MAX_PIECES + 1];
+        piece_representatives(key, fA, fB[k], A0, B0, rep);
+        for (int op = 0; op < N_OPS; op++) {
+            const Move m = make_move(op, fA, fB[k], max_id, A0, B0);
+            for (int p = 0; p <= MAX_PIECES; p++) {
+                Xf x; x.label = -1 - p; x.sigma = 1; x.off = 0; x.circ = 0; x.lbp = 0;
+                if (rep[p] >= 0) {
+                    const Rec ro = ld(s, rep[p]);
+                    x = xf_identity(ro);
+                    if (p >= 1) { bool stale; x = xf_from(ro, apply_move(m, rep[p], ro, &stale)); }
+                }
+                xf[((size_t)k * N_OPS + op) * (MAX_PIECES + 1) + p] = x;
+            }
+        }
+    }
+    auto XF = [&](int k, int op, int p) -> const Xf& { return xf[((size_t)k * N_OPS + op) * (MAX_PIECES + 1) + p]; };
+    USet U;
+    int cuts[US_MAXC * (US_MAXK + 1)], ncut[US_MAXC];
+    uset_build(U, end_of(fA), B.data(), keys.data(), K, live, live, cuts, ncut);
+    info[0] = U.n_pieces; info[1] = U.n_tiles; info[2] = U.n_contigs;
+    if (U.n_pieces > US_MAXP || U.n_contigs > US_MAXC) return 1000000;
+    // (1) membership
+    std::vector<int> piece(n, -1);
+    for (int f = 0; f < n; f++) {
+        bool in_union = s[F_IDC][f] == A0.id_c;
+        for (int k = 0; k < K; k++) if (((live >> k) & 1u) && s[F_IDC][f] == s[F_IDC][fB[k]]) in_union = true;
+        const int g = ufrag_piece(U, s[F_IDC][f], s[F_POS][f]);
+        if (in_union != (g >= 0)) { bad++; continue; }
+        piece[f] = g;
+        if (g < 0) continue;
+        int hits = 0;
+        for (int i = 0; i < U.n_pieces; i++) hits += (U.c[U.p[i].contig].label == s[F_IDC][f] && s[F_POS][f] >= U.p[i].lo && s[F_POS][f] < U.p[i].lo + U.p[i].n);
+        if (hits != 1) bad++;
+        for (int k = 0; k < K; k++) {
+            const int want = ((live >> k) & 1u) ? piece_of(keys[k], s[F_IDC][f], s[F_POS][f]) : 0;
+            if (want != U.p[g].pk[k]) bad++;
+        }
+        if (perm[U.c[U.p[g].contig].base + s[F_POS][f]] != f) bad++;
+    }
+    // classes (the algorithm of k_gprep: candidates in index order, a class is represented by its first candidate)
+    struct Cls { GClass c; InputsKey key; };
+    std::vector<std::vector<Cls>> classes(US_MAXPAIRS);
+    std::vector<InputsKey> old_key(US_MAXPAIRS);
+    long long n_cls = 0, n_pairs_cls = 0;
+    double work_union = 0.0, work_single = 0.0;
+    for (int g = 0; g < U.n_pieces; g++)
+        for (int h = g; h < U.n_pieces; h++) {
+            const int pr = upair_index(g, h);
+            old_key[pr] = inputs_key(uxf_old(U, g), uxf_old(U, h), quirk != 0);
+            for (int k = 0; k < K; k++) {
+                if (!U.p[g].pk[k] || !U.p[h].pk[k]) continue;
+                for (int op = 0; op < N_OPS; op++) {
+                    const Xf &a = XF(k, op, U.p[g].pk[k]), &b = XF(k, op, U.p[h].pk[k]);
+                    const InputsKey key = inputs_key(a, b, quirk != 0);
+                    if (ikey_eq(key, old_key[pr])) continue;
+                    const int cand = k * N_OPS + op;
+                    Cls* hit = nullptr;
+                    for (auto& c : classes[pr]) if (ikey_eq(c.key, key)) { hit = &c; break; }
+                    if (!hit) { Cls c; c.c = gclass_make(a, b, cand); c.key = key; classes[pr].push_back(c); hit = &classes[pr].back(); }
+                    if (cand < 64) hit->c.m0 |= 1ull << cand; else if (cand < 128) hit->c.m1 |= 1ull << (cand - 64); else hit->c.m2 |= 1u << (cand - 128);
+                }
+            }
+            n_cls += (long long)classes[pr].size();
+            n_pairs_cls += classes[pr].empty() ? 0 : 1;
+            {   // evaluations without a window: the union's classes (+ the current layout once) against one neighbour at a time
+                const double np_ = g == h ? 0.5 * U.p[g].n * (U.p[g].n - 1.0) : (double)U.p[g].n * U.p[h].n;
+                if (!classes[pr].empty()) work_union += np_ * (1.0 + (double)classes[pr].size());
+                for (int k = 0; k < K; k++) {
+                    if (!U.p[g].pk[k] || !U.p[h].pk[k]) continue;
+                    std::vector<InputsKey> seen_k;
+                    for (int op = 0; op < N_OPS; op++) {
+                        const InputsKey key = inputs_key(XF(k, op, U.p[g].pk[k]), XF(k, op, U.p[h].pk[k]), quirk != 0);
+                        if (ikey_eq(key, old_key[pr])) continue;
+                        bool dup = false;
+                        for (auto& o : seen_k) dup = dup || ikey_eq(o, key);
+                        if (!dup) seen_k.push_back(key);
+                    }
+                    if (!seen_k.empty()) work_single += np_ * (1.0 + (double)seen_k.size());
+                }
+            }
+            // (3)
+            for (size_t i = 0; i < classes[pr].size(); i++) {
+                if (ikey_eq(classes[pr][i].key, old_key[pr])) bad++;
+                for (size_t j = i + 1; j < classes[pr].size(); j++) if (ikey_eq(classes[pr][i].key, classes[pr][j].key)) bad++;
+            }
+        }
+    info[3] = n_pairs_cls; info[4] = n_cls;
+    info[8] = (int64_t)work_union; info[9] = (int64_t)work_single;
+    // (2) brute force
+    long long n_checked = 0, n_pairs = 0;
+    std::vector<int> uf;
+    for (int f = 0; f < n; f++) if (piece[f] >= 0) uf.push_back(f);
+    // union order: contig index, then position
+    std::vector<long long> ukey(n, 0);
+    for (int f : uf) ukey[f] = (long long)U.p[piece[f]].contig * (1ll << 32) + s[F_POS][f];
+    for (size_t i = 0; i < uf.size(); i++)
+        for (size_t j = 0; j < uf.size(); j++) {
+            const int fx = uf[i], fy = uf[j];
+            if (!(ukey[fx] < ukey[fy])) continue;
+            n_pairs++;
+            const int g = piece[fx], h = piece[fy];
+            if (g > h) { bad++; continue; }
+            const int pr = upair_index(g, h);
+            const Rec rx = ld(s, fx), ry = ld(s, fy);
+            for (int k = 0; k < K; k++) {
+                if (!U.p[g].pk[k] || !U.p[h].pk[k]) continue;
+                const Rec B0 = ld(s, fB[k]);
+                for (int op = 0; op < N_OPS; op++) {
+                    const Move m = make_move(op, fA, fB[k], max_id, A0, B0);
+                    bool st1, st2;
+                    const Rec nx = apply_move(m, fx, rx, &st1), ny = apply_move(m, fy, ry, &st2);
+                    const int cand = k * N_OPS + op;
+                    const GClass* c = nullptr;
+                    for (auto& cc : classes[pr]) {
+                        const bool in = cand < 64 ? ((cc.c.m0 >> cand) & 1ull) : (cand < 128 ? ((cc.c.m1 >> (cand - 64)) & 1ull) : ((cc.c.m2 >> (cand - 128)) & 1u));
+                        if (in) { if (c) bad++; c = &cc.c; }
+                    }
+                    // predicted inputs
+                    bool cis; int sx, sy, ox, oy, circ, lbp;
+                    if (c) {
+                        cis = (c->flags & 4u) != 0;
+                        sx = gclass_start(c->flags & 1u, c->offx, rx.start_bp, rx.len_bp); sy = gclass_start(c->flags & 2u, c->offy, ry.start_bp, ry.len_bp);
+                        ox = (c->flags & 1u) ? rx.ori : -rx.ori; oy = (c->flags & 2u) ? ry.ori : -ry.ori;
+                        circ = (c->flags & 8u) ? 1 : 0; lbp = c->lbp;
+                    } else {
+                        cis = rx.id_c == ry.id_c; sx = rx.start_bp; sy = ry.start_bp; ox = rx.ori; oy = ry.ori; circ = rx.circ; lbp = rx.l_cont_bp;
+                    }
+                    const bool cis_t = nx.id_c == ny.id_c;
+                    n_checked++;
+                    if (cis != cis_t) { bad++; continue; }
+                    if (cis_t) {
+                        if (sx != nx.start_bp || sy != ny.start_bp || ox != nx.ori || oy != ny.ori) bad++;
+                        if ((circ == 1) != (nx.circ == 1) || nx.circ != ny.circ) bad++;
+                        else if (nx.circ == 1 && (lbp != nx.l_cont_bp || nx.l_cont_bp != ny.l_cont_bp)) bad++;
+                    } else if (quirk) { if (ox != nx.ori || oy != ny.ori) bad++; }
+                }
+            }
+        }
+    info[6] = n_pairs; info[7] = n_checked;
+    // (4) the unit list, every tile pair alive
+    std::map<std::pair<int, int>, int> seen;
+    long long n_units = 0;
+    auto frag_at = [&](int t, int l) { int off; const int g = utile_piece(U, t, off); return perm[U.c[U.p[g].contig].base + U.p[g].lo + off * US_TILE + l]; };
+    for (int ti = 0; ti < U.n_tiles; ti++)
+        for (int tj = ti; tj < U.n_tiles; tj++) {
+            const int ci = utile_count(U, ti), cj = utile_count(U, tj);
+            const int lanes_first = ci >= cj ? 1 : 0;
+            const int cs = lanes_first ? cj : ci;            // fragments of the segment side
+            for (int j0 = 0; j0 < cs; j0 += seg) {
+                const int cnt = cs - j0 < seg ? cs - j0 : seg;
+                const unsigned long long u = uunit_pack(ti, tj, j0, cnt, lanes_first);
+                n_units++;
+                // decode as k_strict2 does
+                const int dti = (int)(u & 0xffffull), dtj = (int)((u >> 16) & 0xffffull), dj0 = (int)((u >> 32) & 63ull), dcnt = (int)((u >> 38) & 63ull);
+                const int lf = (int)((u >> 44) & 1ull);
+                const int tl = lf ? dti : dtj, ts = lf ? dtj : dti, cl = utile_count(U, tl);
+                for (int lane = 0; lane < US_TILE; lane++) {
+                    if (lane >= cl) continue;
+                    for (int j = 0; j < dcnt; j++) {
+                        if (dti == dtj && !(lane < dj0 + j)) continue;     // the diagonal tile pair: every unordered pair once
+                        const int fl = frag_at(tl, lane), fs = frag_at(ts, dj0 + j);
+                        const int first = lf ? fl : fs, second = lf ? fs : fl;
+                        if (!(ukey[first] < ukey[second])) bad++;
+                        seen[{first, second}]++;
+                    }
+                }
+            }
+        }
+    info[5] = n_units;
+    if ((long long)seen.size() != n_pairs) bad++;
+    for (auto& kv : seen) if (kv.second != 1) bad++;
     return bad;
 }
 

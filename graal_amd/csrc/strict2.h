@@ -1,0 +1,467 @@
+// strict2.h -- reference arithmetic over the step's UNION SET (strict_sets.h): k_gprep + k_strict2.  Included by graal_hip.hip
+// inside its anonymous namespace, behind the per-neighbour strict kernels whose helpers it uses.
+//
+// Same sums as k_strict_dense (the O(m^2) validation kernel: every pixel of contig(fA) u contig(fB_k) under every candidate,
+// kernels3.cu:3259-3718 as written) -- every term it adds that is not exactly zero, each exactly once per class of equal inputs:
+//   * the K sets of a step are priced TOGETHER: the current layout's value of a fragment pair is computed once per step, not once
+//     per neighbour, and candidates of different neighbours that hand the model the same inputs (eject / flip of fA: all K of them;
+//     the K sets are mostly the same contigs) share one evaluation (classes per pair of GLOBAL pieces: k_gprep);
+//   * tiles never straddle a global piece, so the class list of a unit is WAVE-UNIFORM: the class loop is scalar, the lanes' side
+//     of a class (transformed start, orientation, sub-fragment centres) is computed once per (unit, class), the segment side once
+//     per (fragment, class) by one lane each; what remains per (pair, class) is the contact model itself;
+//   * the lanes of a wave take the fuller tile of a tile pair (a cut fragment is a tile of its own).
+// Unit list by the cull blocks of k_gprep (interval arithmetic on tile extents, as k_strict_cull), dealt to ranks by (ti + tj) % world.
+
+struct S2Args {
+    USet* uset;            // written by block 0 of k_gprep
+    GClass* cls;           // [US_MAXPAIRS][US_NCAND]
+    int* cls_n;            // [US_MAXPAIRS]
+};
+
+constexpr int GPREP_CLS_BLOCKS = 64;   // blocks of k_gprep that build classes (one wave per piece pair, round robin); the rest cull
+
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// old bp extent [lo, hi) of tile t (fragments of ONE global piece, consecutive positions of one contig)
+__device__ __forceinline__ void utile_extent(const USet& U, const Geo* __restrict__ geo, const int* __restrict__ perm, int t, int& lo, int& hi, int& g,
+                                             int& cnt)
+{
+    int off;
+    g = utile_piece(U, t, off);
+    const UPiece& P = U.p[g];
+    const UContig& C = U.c[P.contig];
+    const int first = P.lo + off * US_TILE;
+    const int left = P.n - off * US_TILE;
+    cnt = left < US_TILE ? left : US_TILE;
+    lo = geo[perm[C.base + first]].start_bp;
+    hi = first + cnt >= C.len ? C.lbp : geo[perm[C.base + first + cnt]].start_bp;
+}
+
+__global__ __launch_bounds__(256) void k_gprep(const NbTables* __restrict__ tabs, const Geo* __restrict__ geo, const Link* __restrict__ link,
+                                                const int* __restrict__ cbase, const int* __restrict__ perm, int fA, int K, int rank, int world,
+                                                int reach_bp, int no_window, int quirk, int seg_fixed, int seg_min, int seg_max,
+                                                unsigned long long target_units, unsigned long long* __restrict__ list,
+                                                unsigned long long* __restrict__ list_n, unsigned long long cap,
+                                                unsigned long long* __restrict__ counters, S2Args s2)
+{
+    __shared__ USet s_U;
+    __shared__ UEnd s_A, s_B[MAXK];
+    __shared__ PieceKey s_keys[MAXK];
+    __shared__ unsigned s_live, s_mass;
+    __shared__ int s_cuts[US_MAXC * (US_MAXK + 1)], s_ncut[US_MAXC];
+    __shared__ Xf s_xf[MAXK][N_OPS][NP];
+    __shared__ int s_row[4];
+    const int t = threadIdx.x, lane = t & 63, wib = t >> 6;
+    if (t == 0) { s_live = 0; s_mass = 0; }
+    __syncthreads();
+    if (t <= K) {   // thread K: fA; threads 0..K-1: the neighbours
+        const int f = t == K ? fA : tabs[t].fB;
+        const Geo g = geo[f];
+        const Link l = link[f];
+        UEnd e; e.label = g.id_c; e.pos = geo_pos(g.flags); e.base = cbase[f]; e.len = l.l_cont; e.lbp = l.l_cont_bp; e.circ = (g.flags >> 1) & 1;
+        if (t == K) s_A = e;
+        else {
+            s_B[t] = e;
+            s_keys[t] = tabs[t].key;
+            if (f != fA) atomicOr(&s_live, 1u << t);
+            if (tabs[t].set_m > 0) atomicOr(&s_mass, 1u << t);   // (0: fB == fA, or its fragment pairs were priced by k_tm already)
+        }
+    }
+    for (int i = t; i < K * N_OPS * NP; i += 256) { const int k = i / (N_OPS * NP), r = i - k * (N_OPS * NP); s_xf[k][r / NP][r % NP] = tabs[k].xf[r / NP][r % NP]; }
+    __syncthreads();
+    if (t == 0) uset_build(s_U, s_A, s_B, s_keys, K, s_live, s_mass, s_cuts, s_ncut);
+    __syncthreads();
+    const USet& U = s_U;
+    if (blockIdx.x == 0) {
+        int* dst = reinterpret_cast<int*>(s2.uset);
+        const int* src = reinterpret_cast<const int*>(&s_U);
+        for (int i = t; i < (int)(sizeof(USet) / 4); i += 256) dst[i] = src[i];
+    }
+    const int np = U.n_pieces;
+    if ((int)blockIdx.x < GPREP_CLS_BLOCKS) {
+        // ---- classes of equal inputs per pair of global pieces: one wave per pair.  Lane l holds the candidates l, l + 64, l + 128
+        // (candidate = k * 13 + op); a class is the ballot of the lanes whose key equals the first unassigned candidate's.
+        const int n_pairs = np * (np + 1) / 2;
+        for (int pi = blockIdx.x * 4 + wib; pi < n_pairs; pi += GPREP_CLS_BLOCKS * 4) {
+            int g = 0, rem = pi;
+            while (rem >= np - g) { rem -= np - g; g++; }
+            const int h = g + rem;
+            const int pair = upair_index(g, h);
+            const InputsKey old = inputs_key(uxf_old(U, g), uxf_old(U, h), quirk != 0);
+            InputsKey key[3];
+            bool un[3], ms[3];
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                const int cand = lane + 64 * r, k = cand / N_OPS, op = cand - k * N_OPS;
+                un[r] = false;
+                ms[r] = cand < K * N_OPS && ((U.mass >> k) & 1u);
+                key[r] = old;
+                if (cand < K * N_OPS) {
+                    const int pg = U.p[g].pk[k], ph = U.p[h].pk[k];
+                    if (pg && ph) {
+                        key[r] = inputs_key(s_xf[k][op][pg], s_xf[k][op][ph], quirk != 0);
+                        un[r] = !ikey_eq(key[r], old);
+                    }
+                }
+            }
+            GClass* out = s2.cls + (size_t)pair * US_NCAND;
+            int nc = 0;
+            for (;;) {
+                const unsigned long long b0 = __ballot(un[0]), b1 = __ballot(un[1]), b2 = __ballot(un[2]);
+                if (!(b0 | b1 | b2)) break;
+                const int r = b0 ? 0 : (b1 ? 1 : 2);
+                const unsigned long long br = b0 ? b0 : (b1 ? b1 : b2);
+                const int ll = __ffsll((long long)br) - 1;
+                const InputsKey mine = r == 0 ? key[0] : (r == 1 ? key[1] : key[2]);
+                InputsKey lead;
+                lead.x = __shfl(mine.x, ll, 64); lead.y = __shfl(mine.y, ll, 64); lead.z = __shfl(mine.z, ll, 64); lead.w = __shfl(mine.w, ll, 64);
+                bool m[3];
+#pragma unroll
+                for (int q = 0; q < 3; q++) { m[q] = un[q] && ikey_eq(key[q], lead); un[q] = un[q] && !m[q]; }
+                const unsigned long long m0 = __ballot(m[0]), m1 = __ballot(m[1]), m2 = __ballot(m[2]);
+                const unsigned long long w0 = __ballot(m[0] && ms[0]), w1 = __ballot(m[1] && ms[1]), w2 = __ballot(m[2] && ms[2]);
+                if (lane == 0) {
+                    const int cand = ll + 64 * r, k = cand / N_OPS, op = cand - k * N_OPS;
+                    GClass c = gclass_make(s_xf[k][op][U.p[g].pk[k]], s_xf[k][op][U.p[h].pk[k]], cand);
+                    c.m0 = m0; c.m1 = m1; c.m2 = (unsigned)(m2 & 3ull);
+                    c.w0 = w0; c.w1 = w1; c.w2 = (unsigned)(w2 & 3ull);
+                    out[nc] = c;
+                }
+                nc++;
+            }
+            if (lane == 0) s2.cls_n[pair] = nc;
+        }
+        return;
+    }
+    // ---- unit list: rows = tiles; a tile pair is listed iff some fragment pair of it can be inside the window under the current
+    // layout or under some candidate whose inputs differ from the current layout's (interval arithmetic, no per-pair work)
+    const int n_tiles = U.n_tiles;
+    int seg = seg_fixed;
+    if (seg <= 0) {
+        const unsigned long long est = (unsigned long long)n_tiles * (unsigned long long)(n_tiles + 1) / 2ull;
+        seg = seg_max;
+        while (seg > seg_min && est * (unsigned long long)(US_TILE / seg) < target_units) seg >>= 1;
+    }
+    const int n_cull = (int)gridDim.x - GPREP_CLS_BLOCKS;
+    for (int ti = (int)blockIdx.x - GPREP_CLS_BLOCKS; ti < n_tiles; ti += n_cull) {
+        __syncthreads();
+        if (t == 0) { int lo, hi, g, cnt; utile_extent(U, geo, perm, ti, lo, hi, g, cnt); s_row[0] = lo; s_row[1] = hi; s_row[2] = g; s_row[3] = cnt; }
+        __syncthreads();
+        const int xlo = s_row[0], xhi = s_row[1], g = s_row[2], cnt_i = s_row[3];
+        const int cx = U.p[g].contig;
+        for (int tj0 = ti; tj0 < n_tiles; tj0 += 256) {
+            const int tj = tj0 + t;
+            bool alive = false;
+            int cnt_j = 0;
+            if (tj < n_tiles && ((ti + tj) % world) == rank) {
+                int ylo, yhi, h;
+                utile_extent(U, geo, perm, tj, ylo, yhi, h, cnt_j);
+                const bool near_old = U.p[h].contig == cx && max(ylo - xhi, xlo - yhi) <= reach_bp;
+                const InputsKey old = inputs_key(uxf_old(U, g), uxf_old(U, h), quirk != 0);
+                for (int k = 0; k < K && !alive; k++) {
+                    const int pg = U.p[g].pk[k], ph = U.p[h].pk[k];
+                    if (!pg || !ph || !((U.mass >> k) & 1u)) continue;
+                    for (int op = 0; op < N_OPS; op++) {
+                        const Xf a = s_xf[k][op][pg], b = s_xf[k][op][ph];
+                        if (ikey_eq(inputs_key(a, b, quirk != 0), old)) continue;   // the current layout's inputs: nothing to price
+                        if (no_window || near_old) { alive = true; break; }
+                        if (a.label != b.label) continue;
+                        const int xs2 = a.sigma > 0 ? xlo + a.off : a.off - xhi, xe2 = a.sigma > 0 ? xhi + a.off : a.off - xlo;
+                        const int ys2 = b.sigma > 0 ? ylo + b.off : b.off - yhi, ye2 = b.sigma > 0 ? yhi + b.off : b.off - ylo;
+                        if (max(ys2 - xe2, xs2 - ye2) <= reach_bp) { alive = true; break; }
+                    }
+                }
+            }
+            const int lanes_first = cnt_i >= cnt_j ? 1 : 0;
+            const int cs = lanes_first ? cnt_j : cnt_i;
+            const int ne = alive ? (cs + seg - 1) / seg : 0;
+            if (__ballot(alive)) {
+                int incl = ne;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
+                const int total = __shfl(incl, 63, 64);
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(list_n, (unsigned long long)total);
+                base = __shfl(base, 0, 64);
+                for (int e = 0; e < ne; e++) {
+                    const unsigned long long at = base + (unsigned long long)(incl - ne + e);
+                    const int j0 = e * seg, c = cs - j0 < seg ? cs - j0 : seg;
+                    if (at < cap) list[at] = uunit_pack(ti, tj, j0, c, lanes_first);
+                    else atomicOr(&counters[6], 2ull);   // (cannot happen: the host sizes the list)
+                }
+            }
+        }
+    }
+}
+
+struct STile2 { int start_bp, len_bp, flags, frag; Stat st; };   // one staged fragment of the segment side, 48 bytes
+
+// one slot pair in one layout.  c_first / c_second: centres (kb) of the two sub-fragments, first = the fragment that comes first in the
+// union's order (the `X` of ex_pair); the same operations in the same order as ex_pair / ex_pair_ref
+__device__ __forceinline__ float s2_ex(bool cis, float c_first, float c_second, float norm, int circ, float s_tot, const Par& p)
+{
+    if (!cis) return p.v_inter * norm;
+    const float s = fabsf(c_second - c_first);
+    if (circ) return rippe_circ(s, s_tot, p) * norm;
+    return rippe(s, p) * norm;
+}
+
+// candidates of a class (bits of m0, m1, m2) += v, in the block's LDS sums: lane l takes the candidates l, l + 64, l + 128
+__device__ __forceinline__ void s2_add_mask(long long* __restrict__ acc, unsigned long long m0, unsigned long long m1, unsigned m2, long long v, int lane)
+{
+    if ((m0 >> lane) & 1ull) atomicAdd((unsigned long long*)&acc[lane], (unsigned long long)v);
+    if ((m1 >> lane) & 1ull) atomicAdd((unsigned long long*)&acc[64 + lane], (unsigned long long)v);
+    if (lane < 2 && ((m2 >> lane) & 1u)) atomicAdd((unsigned long long*)&acc[128 + lane], (unsigned long long)v);
+}
+__device__ __forceinline__ void s2_flag_mask(unsigned long long* nf, unsigned long long m0, unsigned long long m1, unsigned m2, int lane)
+{
+    for (int r = 0; r < 3; r++) {
+        const int cand = lane + 64 * r;
+        const bool in = r == 0 ? ((m0 >> lane) & 1ull) : (r == 1 ? ((m1 >> lane) & 1ull) : (lane < 2 && ((m2 >> lane) & 1u)));
+        if (in) nf_flag(nf, cand / N_OPS, cand % N_OPS);
+    }
+}
+
+template <bool MULTI>
+__global__ __launch_bounds__(256) void k_strict2(FinArgs fa, StrictArgs sa, S2Args s2, int K, const unsigned long long* __restrict__ list,
+                                                  unsigned long long* __restrict__ list_n, long long* __restrict__ d_q_out,
+                                                  volatile long long* host_res, long long seq)
+{
+    constexpr int SEG = MULTI ? 4 : 16;        // fragments of a unit's segment at most
+    constexpr int NS = MULTI ? 3 : 1;          // sub-fragment slots per bin at most
+    constexpr int NSP = NS * NS;
+    const Geo* __restrict__ geo = fa.geo;
+    const Stat* __restrict__ stat = fa.stat;
+    unsigned long long* __restrict__ counters = fa.counters;
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int wave = blockIdx.x * 4 + wib, n_waves = gridDim.x * 4;
+    __shared__ USet s_U;
+    __shared__ long long s_acc[US_NCAND];
+    __shared__ STile2 s_tile[4][SEG];
+    __shared__ float s_cy[4][SEG][4];          // the segment side's centres (and its orientation, [3]) in the layout being priced
+    __shared__ float s_exo[4][SEG * NSP][64];  // the current layout's values of the unit's slot pairs, [segment fragment][slot pair][lane]
+    __shared__ int s_last;
+    for (int i = threadIdx.x; i < US_NCAND; i += 256) s_acc[i] = 0;
+    {
+        const int* src = reinterpret_cast<const int*>(s2.uset);
+        int* dst = reinterpret_cast<int*>(&s_U);
+        for (int i = threadIdx.x; i < (int)(sizeof(USet) / 4); i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const USet& U = s_U;
+    const unsigned long long nq_total = counters[2];              // written by k_scan, an earlier kernel on the stream
+    const unsigned long long n_units = min(*list_n, sa.list_cap); // written by k_gprep (ordered by an event)
+    const float nfpb = sa.nfpb;
+    const Par par = sa.par;
+    const bool quirk = sa.quirk != 0;
+    const int reach_bp = sa.reach_bp;
+    const float norm_u = fa.norm_u;
+    STile2* const tile = s_tile[wib];
+    float (*const cy)[4] = s_cy[wib];
+    float (*const exo)[64] = s_exo[wib];
+    // ---- (1) the listed units, one wave each
+    for (unsigned long long u = (unsigned long long)wave; u < n_units; u += (unsigned long long)n_waves) {
+        const unsigned long long ent = list[u];
+        const int ti = rfl((int)(ent & 0xffffull)), tj = rfl((int)((ent >> 16) & 0xffffull)), j0 = rfl((int)((ent >> 32) & 63ull));
+        const int cnt = rfl((int)((ent >> 38) & 63ull)), lf = rfl((int)((ent >> 44) & 1ull));
+        int offi, offj;
+        const int g = rfl(utile_piece(U, ti, offi)), h = rfl(utile_piece(U, tj, offj));
+        offi = rfl(offi); offj = rfl(offj);
+        const int gl = lf ? g : h, gs = lf ? h : g, offl = lf ? offi : offj, offs = lf ? offj : offi;
+        const UPiece& PL = U.p[gl];
+        const UPiece& PS = U.p[gs];
+        const UContig& CL = U.c[PL.contig];
+        const UContig& CS = U.c[PS.contig];
+        const int nl = rfl(min(US_TILE, PL.n - offl * US_TILE));
+        const bool has_l = lane < nl;
+        const int fl = has_l ? sa.perm[CL.base + PL.lo + offl * US_TILE + lane] : 0;
+        Geo gL = {0, 0, 0, 0};
+        Stat stL = {0.0f, 0.0f, 0.0f, 0, 0, 0, 0, 0};
+        if (has_l) { gL = geo[fl]; stL = stat[fl]; }
+        if (lane < cnt) {
+            STile2 y;
+            y.frag = sa.perm[CS.base + PS.lo + offs * US_TILE + j0 + lane];
+            const Geo gy = geo[y.frag];
+            y.start_bp = gy.start_bp; y.len_bp = gy.len_bp; y.flags = gy.flags; y.st = stat[y.frag];
+            tile[lane] = y;
+        }
+        WAVE_LDS_SYNC();
+        const bool cis_old = rfl(PL.contig) == rfl(PS.contig);
+        const int circ_old = rfl(CL.circ), lbp_old = rfl(CL.lbp);
+        // old bp extents of the two sides (positions grow with start_bp inside a contig)
+        const int xs = rfl(gL.start_bp), xe = __builtin_amdgcn_readlane(gL.start_bp + gL.len_bp, nl - 1);
+        const int ys = rfl(tile[0].start_bp), ye = rfl(tile[cnt - 1].start_bp + tile[cnt - 1].len_bp);
+        const bool near_old = cis_old && max(ys - xe, xs - ye) <= reach_bp;
+        bool always = false;
+        if (quirk) always = __ballot((has_l && !stat_uniform(stL)) || (lane < cnt && !stat_uniform(tile[lane < cnt ? lane : 0].st))) != 0ull;
+        const int pair = upair_index(g, h);
+        const int nc = rfl(s2.cls_n[pair]);
+        const GClass* __restrict__ cp = s2.cls + (size_t)pair * US_NCAND;
+        // is there anything to price?  (a listed unit has, but for the finer extents of its segment)
+        bool any = false;
+        for (int c = 0; c < nc && !any; c++) {
+            if (!(cp[c].w0 | cp[c].w1 | (unsigned long long)cp[c].w2)) continue;   // (a class of neighbours priced by the table kernel)
+            if (near_old || always) { any = true; break; }
+            const unsigned flags = (unsigned)rfl((int)cp[c].flags);
+            if (!(flags & 4u)) continue;
+            const int offx = rfl(cp[c].offx), offy = rfl(cp[c].offy);
+            const int sig_l = lf ? (flags & 1u) : ((flags >> 1) & 1u), sig_s = lf ? ((flags >> 1) & 1u) : (flags & 1u);
+            const int off_l = lf ? offx : offy, off_s = lf ? offy : offx;
+            const int xs2 = sig_l ? xs + off_l : off_l - xe, xe2 = sig_l ? xe + off_l : off_l - xs;
+            const int ys2 = sig_s ? ys + off_s : off_s - ye, ye2 = sig_s ? ye + off_s : off_s - ys;
+            if (max(ys2 - xe2, xs2 - ye2) <= reach_bp) any = true;
+        }
+        if (!any) { WAVE_LDS_SYNC(); continue; }
+        const bool fwdL = (gL.flags & 1) != 0;
+        const bool diag = ti == tj;
+        for (int c = -1; c < nc; c++) {     // c = -1: the current layout (its values are kept in LDS), then the classes
+            bool cis = cis_old;
+            int circ = cis_old ? circ_old : 0, lbp = lbp_old, sig_l = 1, sig_s = 1, off_l = 0, off_s = 0;
+            unsigned long long m0 = 0, m1 = 0;
+            unsigned m2 = 0;
+            if (c >= 0) {
+                const unsigned flags = (unsigned)rfl((int)cp[c].flags);
+                const int offx = rfl(cp[c].offx), offy = rfl(cp[c].offy);
+                cis = (flags & 4u) != 0; circ = (flags >> 3) & 1u; lbp = rfl(cp[c].lbp);
+                sig_l = lf ? (flags & 1u) : ((flags >> 1) & 1u); sig_s = lf ? ((flags >> 1) & 1u) : (flags & 1u);
+                off_l = lf ? offx : offy; off_s = lf ? offy : offx;
+                if (!(near_old || always)) {   // the trans value both times, slot by slot: exactly zero
+                    if (!cis) continue;
+                    const int xs2 = sig_l ? xs + off_l : off_l - xe, xe2 = sig_l ? xe + off_l : off_l - xs;
+                    const int ys2 = sig_s ? ys + off_s : off_s - ye, ye2 = sig_s ? ye + off_s : off_s - ys;
+                    if (max(ys2 - xe2, xs2 - ye2) > reach_bp) continue;
+                }
+                const unsigned long long mm0 = cp[c].w0, mm1 = cp[c].w1;
+                m0 = ((unsigned long long)(unsigned)rfl((int)(mm0 >> 32)) << 32) | (unsigned long long)(unsigned)rfl((int)mm0);
+                m1 = ((unsigned long long)(unsigned)rfl((int)(mm1 >> 32)) << 32) | (unsigned long long)(unsigned)rfl((int)mm1);
+                m2 = (unsigned)rfl((int)cp[c].w2);
+                if (!(m0 | m1 | (unsigned long long)m2)) continue;
+            }
+            const float s_tot = (float)lbp / 1000.0f;
+            // the lanes' side in this layout
+            const int startL = gclass_start(sig_l, off_l, gL.start_bp, gL.len_bp);
+            const bool fwdLn = fwdL == (sig_l != 0);
+            float cl[NS];
+#pragma unroll
+            for (int a = 0; a < NS; a++) cl[a] = a < stL.n ? centre_kb(startL, fwdLn, stL, a) : 0.0f;
+            // the segment side: one lane per fragment
+            if (lane < cnt) {
+                const STile2& y = tile[lane];
+                const int startS = gclass_start(sig_s, off_s, y.start_bp, y.len_bp);
+                const bool fwdSn = ((y.flags & 1) != 0) == (sig_s != 0);
+#pragma unroll
+                for (int b = 0; b < NS; b++) cy[lane][b] = b < y.st.n ? centre_kb(startS, fwdSn, y.st, b) : 0.0f;
+                cy[lane][3] = fwdSn ? 1.0f : 0.0f;
+            }
+            WAVE_LDS_SYNC();
+            long long accq = 0;
+            bool bad = false;
+            for (int j = 0; j < cnt; j++) {
+                const STile2& y = tile[j];
+                const int ny = y.st.n, fs = y.frag;
+                const bool valid = has_l && stL.n > 0 && ny > 0 && !(diag && !(lane < j0 + j));
+                const bool fwdSn = cy[j][3] != 0.0f;
+                double acc = 0.0;
+                // slot pairs in the order of the O(m^2) kernel: the FIRST fragment's slots outside (first = earlier in the union's order:
+                // tile ti's side), the second's inside
+                const int n_first = lf ? stL.n : ny, n_second = lf ? ny : stL.n;
+                for (int a = 0; a < NS; a++)
+                    for (int b = 0; b < NS; b++) {
+                        if (MULTI && !(a < n_first && b < n_second)) continue;
+                        const int sl = lf ? a : b, ss = lf ? b : a;       // the lane fragment's slot, the segment fragment's slot
+                        const float c_l = NS == 1 ? cl[0] : sel3(cl[0], cl[NS > 1 ? 1 : 0], cl[NS > 2 ? 2 : 0], sl);
+                        const float c_s = cy[j][ss];
+                        int ax = stat_accu(stL, sl), ay = stat_accu(y.st, ss);
+                        if (quirk && !cis) {   // the reference's trans-branch indexing: a reversed lower-id bin is priced with its LAST RF count
+                            if (fl < fs) { if (!fwdLn) ax = stat_accu(stL, stL.n - 1); }
+                            else if (!fwdSn) ay = stat_accu(y.st, ny - 1);
+                        }
+                        const float norm = norm_u >= 0.0f ? norm_u : (float)(ax * ay) / nfpb;
+                        const float ex = s2_ex(cis, lf ? c_l : c_s, lf ? c_s : c_l, norm, circ, s_tot, par);
+                        float* const slot = &exo[j * NSP + a * NS + b][lane];
+                        if (c < 0) *slot = ex;
+                        else acc += (double)*slot - (double)ex;
+                    }
+                if (c >= 0 && valid) {
+                    const long long q1 = to_q(acc);
+                    if (q1 == Q_BAD) bad = true; else accq += q1;
+                }
+            }
+            if (c >= 0) {
+                const long long qs = wave_sum_ll(accq);
+                const long long v = ((long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(qs >> 32)) << 32) | (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)qs);
+                if (v != 0) s2_add_mask(s_acc, m0, m1, m2, v, lane);
+                if (__ballot(bad)) s2_flag_mask(counters + NF_OFF, m0, m1, m2, lane);
+            }
+            WAVE_LDS_SYNC();   // (the next pass writes the segment's centres again)
+        }
+    }
+    // ---- (2) the queued contacts (the scan queued every contact with both ends in some neighbour's set): lane = contact, one
+    // evaluation per class of its piece pair
+    {
+        QSrc qs;
+        qs.queue = fa.queue; qs.geo2 = reinterpret_cast<const int2*>(geo); qs.cnt = fa.cnt; qs.keys = nullptr; qs.live = 0; qs.K = K;
+        qs.seq = (unsigned)seq; qs.concurrent = 0; qs.multi = fa.multi;
+        for (unsigned long long b0 = (unsigned long long)(n_waves - 1 - wave) * 64ull; b0 < nq_total; b0 += (unsigned long long)n_waves * 64ull) {
+            const unsigned long long e = b0 + (unsigned long long)lane;
+            if (e >= nq_total) continue;
+            const QEntry qe = q_fetch(qs, e, counters + 6);
+            if (qe.fx < 0) continue;
+            const int fx = qe.fx, fy = qe.fy, slx = qe.slots & 3, sly = (qe.slots >> 2) & 3;
+            const Geo gx = geo[fx], gy = geo[fy];
+            const Stat sx = stat[fx], sy = stat[fy];
+            const int cnt_bits = fa.cnt[qe.idx];
+            const int pgx = ufrag_piece(U, gx.id_c, geo_pos(gx.flags)), pgy = ufrag_piece(U, gy.id_c, geo_pos(gy.flags));
+            if (pgx < 0 || pgy < 0) continue;
+            const bool x_low = pgx <= pgy;                 // the class records name the lower piece "x"
+            const int pair = x_low ? upair_index(pgx, pgy) : upair_index(pgy, pgx);
+            const int nc = s2.cls_n[pair];
+            if (nc == 0) continue;
+            const GClass* __restrict__ cp = s2.cls + (size_t)pair * US_NCAND;
+            const End X0 = end_old(gx, ((gx.flags >> 1) & 1) ? sa.lcontbp[fx] : 0), Y0 = end_old(gy, ((gy.flags >> 1) & 1) ? sa.lcontbp[fy] : 0);
+            const float ex_old = ex_pair_ref(X0, sx, slx, fx, Y0, sy, sly, fy, nfpb, par, quirk);
+            const double ln_old = mm_ln(ex_old), ob = (double)__int_as_float(cnt_bits);
+            for (int c = 0; c < nc; c++) {
+                const GClass cr = cp[c];
+                const int sig_x = x_low ? (cr.flags & 1u) : ((cr.flags >> 1) & 1u), sig_y = x_low ? ((cr.flags >> 1) & 1u) : (cr.flags & 1u);
+                const int off_x = x_low ? cr.offx : cr.offy, off_y = x_low ? cr.offy : cr.offx;
+                End X, Y;
+                const bool cis = (cr.flags & 4u) != 0;
+                X.label = 0; Y.label = cis ? 0 : 1;
+                X.start_bp = gclass_start(sig_x, off_x, gx.start_bp, gx.len_bp); Y.start_bp = gclass_start(sig_y, off_y, gy.start_bp, gy.len_bp);
+                X.fwd = ((gx.flags & 1) != 0) == (sig_x != 0); Y.fwd = ((gy.flags & 1) != 0) == (sig_y != 0);
+                X.circ = Y.circ = (cr.flags >> 3) & 1u; X.lbp = Y.lbp = cr.lbp;
+                const float ex_new = ex_pair_ref(X, sx, slx, fx, Y, sy, sly, fy, nfpb, par, quirk);
+                if (ex_new == ex_old) continue;
+                const long long qv = to_q(ob * (mm_ln(ex_new) - ln_old));
+                unsigned long long mm[3] = {cr.m0, cr.m1, (unsigned long long)cr.m2};
+                for (int r = 0; r < 3; r++) {
+                    unsigned long long m = mm[r];
+                    while (m) {
+                        const int cand = 64 * r + __ffsll((long long)m) - 1;
+                        m &= m - 1ull;
+                        if (qv == Q_BAD) nf_flag(counters + NF_OFF, cand / N_OPS, cand % N_OPS);
+                        else if (qv != 0) atomicAdd((unsigned long long*)&s_acc[cand], (unsigned long long)qv);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < K * N_OPS; i += 256) {
+        const long long v = s_acc[i];
+        if (v != 0) atomicAdd((unsigned long long*)&fa.acc[i], (unsigned long long)v);
+    }
+    if (threadIdx.x == 255 && blockIdx.x == 0) atomicAdd(&counters[1], n_units);
+    ATOMICS_DONE();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long ticket = atomicAdd(&counters[5], 1ull);
+        s_last = (ticket == (unsigned long long)gridDim.x - 1ull);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (threadIdx.x == 0) *list_n = 0;   // (every block has read it: the list is empty again for the next step)
+    hand_out(fa.acc, counters, fa.sync, K, d_q_out, host_res, seq);
+}
