@@ -194,6 +194,15 @@ constexpr long long Q_NAN = 1ll << 59;   // handed out instead of a flagged cand
                                          // may legitimately exceed 2^58) is flagged by the exact value INT64_MIN instead
 constexpr int NF_OFF = 14;               // counters[NF_OFF .. NF_OFF + 2]: bit (k * 13 + op) = that candidate met a bad term
 __device__ __forceinline__ long long to_q(double v) { return fabs(v) < 2147483648.0 ? __double2ll_rn(v * Q_SCALE) : Q_BAD; }
+// the same value in fewer instructions for the pair loops (|v| < 2^30: v = hi + lo with hi = rint(v); hi 2^30 is an even integer, so rounding
+// lo 2^30 to the nearest-even integer rounds the sum the same way; both parts fit int32)
+__device__ __forceinline__ long long to_q_fast(double v)
+{
+    if (!(fabs(v) < 1073741824.0)) return to_q(v);
+    const double hi = rint(v);
+    const int lo = __double2int_rn((v - hi) * Q_SCALE);
+    return (long long)__double2int_rn(hi) * (1ll << 30) + (long long)lo;
+}
 __device__ __forceinline__ void nf_flag(unsigned long long* nf, int k, int op)
 {
     const int i = k * N_OPS + op;
@@ -4475,12 +4484,16 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
                                                                    (unsigned long long)((h->n + 63) / 64 + K + 1)) + (unsigned long long)US_MAXP;
         if (nt >= 65536ull) return fail(h, GRAAL_E_STATE, "reference arithmetic: more than 65,535 tiles in a step's union set");
         static const int seg_env = getenv("GRAAL_STRICT_SEG") ? atoi(getenv("GRAAL_STRICT_SEG")) : 0;
-        const int seg_max = h->single_sub ? 16 : 4, seg_min = h->single_sub ? 4 : 1;
-        const int seg_fixed = (seg_env == 1 || seg_env == 2 || seg_env == 4 || seg_env == 8 || seg_env == 16) && seg_env <= seg_max ? seg_env : 0;
+        const int seg_max = h->single_sub ? 16 : 2, seg_min = h->single_sub ? 4 : 1;   // (k_strict2's SEG)
+        const int seg_fixed = ((seg_env == 1 || seg_env == 2 || seg_env == 4 || seg_env == 8 || seg_env == 16) && seg_env <= seg_max) ? seg_env : 0;
         const unsigned long long target = 6ull * 4ull * (unsigned long long)blocks;
         const unsigned long long pairs_max = nt * (nt + 1ull) / 2ull;
-        const unsigned long long need = (seg_fixed ? pairs_max * (unsigned long long)(64 / seg_fixed)
-                                                   : std::max(pairs_max * (unsigned long long)(64 / seg_max), std::min(pairs_max * (unsigned long long)(64 / seg_min), 2ull * target))) + 64ull;
+        static const int rep_env = getenv("GRAAL_STRICT_REP") ? atoi(getenv("GRAAL_STRICT_REP")) : 8;   // waves that may share a unit's classes (1, 2, 4, 8)
+        const int rep_max = rep_env >= 8 ? 8 : (rep_env >= 4 ? 4 : (rep_env >= 2 ? 2 : 1));
+        // units: every tile pair cut to the chosen segment size, times the waves per unit: the cuts / the sharing stop at the first size that
+        // reaches the target, i.e. below 2 x target unless the largest segments / one wave per unit already give more
+        const unsigned long long need = (seg_fixed ? std::max(pairs_max * (unsigned long long)(64 / seg_fixed), std::min(pairs_max * (unsigned long long)(64 / seg_fixed) * (unsigned long long)rep_max, 2ull * target))
+                                                   : std::max(pairs_max * (unsigned long long)(64 / seg_max), std::min(pairs_max * (unsigned long long)(64 / seg_min) * (unsigned long long)rep_max, 2ull * target))) + 64ull;
         if (need > h->slist_cap) {
             CK(hipStreamSynchronize(st));
             CK(hipStreamSynchronize(h->aux));
@@ -4494,12 +4507,14 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
         sx.list_cap = h->slist_cap;
         sx.seg = 0;
         fa.norm_u = h->uniform_accu > 0 ? (float)(h->uniform_accu * h->uniform_accu) / h->nfpb : -1.0f;
+        static const int s2_skip = getenv("GRAAL_S2_SKIP") ? atoi(getenv("GRAAL_S2_SKIP")) : 0;   // (diagnostics: wrong sums.  1 = no units, 2 = no queued contacts)
+        fa.skip = s2_skip;
         const int no_window = (sx.quirk && h->n_ubins > 0) ? 1 : 0;
         S2Args s2;
         s2.uset = h->d_uset; s2.cls = h->d_cls; s2.cls_n = h->d_cls_n;
         const int cull_blocks = (int)std::min<unsigned long long>(1024ull, std::max<unsigned long long>(1ull, nt));
         k_gprep<<<GPREP_CLS_BLOCKS + cull_blocks, 256, 0, h->aux>>>(h->tabs, h->geo, h->link, h->cbase, h->perm, fA, K, rank, world, sx.reach_bp, no_window, sx.quirk,
-                                                                     seg_fixed, seg_min, seg_max, target, h->d_slist, h->d_slist_n, h->slist_cap,
+                                                                     seg_fixed, seg_min, seg_max, rep_max, target, h->d_slist, h->d_slist_n, h->slist_cap,
                                                                      (unsigned long long*)(h->d_scalars + 10), s2);
         CK(hipGetLastError());
         CK(hipEventRecord(h->ev_tm, h->aux));      // (behind k_tm and k_gprep: tables, classes and unit list complete -- nobody spins for them)

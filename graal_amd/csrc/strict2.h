@@ -39,7 +39,7 @@ __device__ __forceinline__ void utile_extent(const USet& U, const Geo* __restric
 
 __global__ __launch_bounds__(256) void k_gprep(const NbTables* __restrict__ tabs, const Geo* __restrict__ geo, const Link* __restrict__ link,
                                                 const int* __restrict__ cbase, const int* __restrict__ perm, int fA, int K, int rank, int world,
-                                                int reach_bp, int no_window, int quirk, int seg_fixed, int seg_min, int seg_max,
+                                                int reach_bp, int no_window, int quirk, int seg_fixed, int seg_min, int seg_max, int rep_max,
                                                 unsigned long long target_units, unsigned long long* __restrict__ list,
                                                 unsigned long long* __restrict__ list_n, unsigned long long cap,
                                                 unsigned long long* __restrict__ counters, S2Args s2)
@@ -51,6 +51,8 @@ __global__ __launch_bounds__(256) void k_gprep(const NbTables* __restrict__ tabs
     __shared__ int s_cuts[US_MAXC * (US_MAXK + 1)], s_ncut[US_MAXC];
     __shared__ Xf s_xf[MAXK][N_OPS][NP];
     __shared__ int s_row[4];
+    __shared__ int s_ne[256], s_off[257], s_tp[256];
+    __shared__ unsigned long long s_base;
     const int t = threadIdx.x, lane = t & 63, wib = t >> 6;
     if (t == 0) { s_live = 0; s_mass = 0; }
     __syncthreads();
@@ -69,7 +71,9 @@ __global__ __launch_bounds__(256) void k_gprep(const NbTables* __restrict__ tabs
     }
     for (int i = t; i < K * N_OPS * NP; i += 256) { const int k = i / (N_OPS * NP), r = i - k * (N_OPS * NP); s_xf[k][r / NP][r % NP] = tabs[k].xf[r / NP][r % NP]; }
     __syncthreads();
-    if (t == 0) uset_build(s_U, s_A, s_B, s_keys, K, s_live, s_mass, s_cuts, s_ncut);
+    if (t == 0) uset_build_geometry(s_U, s_A, s_B, K, s_live, s_mass, s_cuts, s_ncut);
+    __syncthreads();
+    for (int i = t; i < s_U.n_pieces * US_MAXK; i += 256) uset_piece_pk(s_U, s_keys, K, i / US_MAXK, i % US_MAXK);
     __syncthreads();
     const USet& U = s_U;
     if (blockIdx.x == 0) {
@@ -142,6 +146,12 @@ __global__ __launch_bounds__(256) void k_gprep(const NbTables* __restrict__ tabs
         seg = seg_max;
         while (seg > seg_min && est * (unsigned long long)(US_TILE / seg) < target_units) seg >>= 1;
     }
+    // still too few units for the grid: deal every unit to R waves, which share its classes (uunit_pack)
+    int R = 1;
+    {
+        const unsigned long long est = (unsigned long long)n_tiles * (unsigned long long)(n_tiles + 1) / 2ull * (unsigned long long)(US_TILE / seg);
+        while (R < rep_max && est * (unsigned long long)R < target_units) R <<= 1;
+    }
     const int n_cull = (int)gridDim.x - GPREP_CLS_BLOCKS;
     for (int ti = (int)blockIdx.x - GPREP_CLS_BLOCKS; ti < n_tiles; ti += n_cull) {
         __syncthreads();
@@ -174,22 +184,30 @@ __global__ __launch_bounds__(256) void k_gprep(const NbTables* __restrict__ tabs
             }
             const int lanes_first = cnt_i >= cnt_j ? 1 : 0;
             const int cs = lanes_first ? cnt_j : cnt_i;
-            const int ne = alive ? (cs + seg - 1) / seg : 0;
-            if (__ballot(alive)) {
-                int incl = ne;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
-                const int total = __shfl(incl, 63, 64);
-                unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(list_n, (unsigned long long)total);
-                base = __shfl(base, 0, 64);
-                for (int e = 0; e < ne; e++) {
-                    const unsigned long long at = base + (unsigned long long)(incl - ne + e);
-                    const int j0 = e * seg, c = cs - j0 < seg ? cs - j0 : seg;
-                    if (at < cap) list[at] = uunit_pack(ti, tj, j0, c, lanes_first);
+            const int ne = alive ? ((cs + seg - 1) / seg) * R : 0;
+            // the block writes the units of its alive tile pairs together: thread o takes entry o of the round (a tile pair has up to 64 / seg x R
+            // of them: written by its own thread, one after the other, they were most of this kernel at mid-size shapes)
+            s_ne[t] = ne;
+            s_tp[t] = tj | (lanes_first << 16) | (cs << 17);
+            __syncthreads();
+            if (t < 64) wave_excl_scan(s_ne, s_off, 256);
+            __syncthreads();
+            const int total = s_off[256];
+            if (total > 0) {
+                if (t == 0) s_base = atomicAdd(list_n, (unsigned long long)total);
+                __syncthreads();
+                const unsigned long long base = s_base;
+                for (int o = t; o < total; o += 256) {
+                    int lo = 0, hi = 255;     // last thread whose first entry is <= o
+                    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_off[mid] <= o) lo = mid; else hi = mid - 1; }
+                    const int e = o - s_off[lo], tp = s_tp[lo];
+                    const int cs_o = (tp >> 17) & 127, j0 = (e / R) * seg, c = cs_o - j0 < seg ? cs_o - j0 : seg;
+                    const unsigned long long at = base + (unsigned long long)o;
+                    if (at < cap) list[at] = uunit_pack(ti, tp & 0xffff, j0, c, (tp >> 16) & 1, e % R, R);
                     else atomicOr(&counters[6], 2ull);   // (cannot happen: the host sizes the list)
                 }
             }
+            __syncthreads();
         }
     }
 }
@@ -202,7 +220,12 @@ __device__ __forceinline__ float s2_ex(bool cis, float c_first, float c_second, 
 {
     if (!cis) return p.v_inter * norm;
     const float s = fabsf(c_second - c_first);
-    if (circ) return rippe_circ(s, s_tot, p) * norm;
+    if (circ) {   // (rare, wave-uniform.  The barrier keeps the circular model's arithmetic inside the branch: the compiler used to pair its
+                  // divisions with the linear model's -- packed float32 -- and computed them for every pair)
+        float s2 = s;
+        asm volatile("" : "+v"(s2));
+        return rippe_circ(s2, s_tot, p) * norm;
+    }
     return rippe(s, p) * norm;
 }
 
@@ -227,7 +250,8 @@ __global__ __launch_bounds__(256) void k_strict2(FinArgs fa, StrictArgs sa, S2Ar
                                                   unsigned long long* __restrict__ list_n, long long* __restrict__ d_q_out,
                                                   volatile long long* host_res, long long seq)
 {
-    constexpr int SEG = MULTI ? 4 : 16;        // fragments of a unit's segment at most
+    constexpr int SEG = MULTI ? 2 : 16;        // fragments of a unit's segment at most (several sub-fragments: 9 slot pairs per fragment pair
+                                               // already amortise a class's set-up, and the current layout's values of a unit live in LDS)
     constexpr int NS = MULTI ? 3 : 1;          // sub-fragment slots per bin at most
     constexpr int NSP = NS * NS;
     const Geo* __restrict__ geo = fa.geo;
@@ -260,10 +284,11 @@ __global__ __launch_bounds__(256) void k_strict2(FinArgs fa, StrictArgs sa, S2Ar
     float (*const cy)[4] = s_cy[wib];
     float (*const exo)[64] = s_exo[wib];
     // ---- (1) the listed units, one wave each
-    for (unsigned long long u = (unsigned long long)wave; u < n_units; u += (unsigned long long)n_waves) {
+    for (unsigned long long u = (unsigned long long)wave; u < ((fa.skip & 1) ? 0ull : n_units); u += (unsigned long long)n_waves) {
         const unsigned long long ent = list[u];
         const int ti = rfl((int)(ent & 0xffffull)), tj = rfl((int)((ent >> 16) & 0xffffull)), j0 = rfl((int)((ent >> 32) & 63ull));
         const int cnt = rfl((int)((ent >> 38) & 63ull)), lf = rfl((int)((ent >> 44) & 1ull));
+        const int rep_r = rfl((int)((ent >> 45) & 7ull)), rep_n = rfl((int)((ent >> 48) & 15ull));
         int offi, offj;
         const int g = rfl(utile_piece(U, ti, offi)), h = rfl(utile_piece(U, tj, offj));
         offi = rfl(offi); offj = rfl(offj);
@@ -299,7 +324,7 @@ __global__ __launch_bounds__(256) void k_strict2(FinArgs fa, StrictArgs sa, S2Ar
         const GClass* __restrict__ cp = s2.cls + (size_t)pair * US_NCAND;
         // is there anything to price?  (a listed unit has, but for the finer extents of its segment)
         bool any = false;
-        for (int c = 0; c < nc && !any; c++) {
+        for (int c = rep_r; c < nc && !any; c += rep_n) {
             if (!(cp[c].w0 | cp[c].w1 | (unsigned long long)cp[c].w2)) continue;   // (a class of neighbours priced by the table kernel)
             if (near_old || always) { any = true; break; }
             const unsigned flags = (unsigned)rfl((int)cp[c].flags);
@@ -314,7 +339,11 @@ __global__ __launch_bounds__(256) void k_strict2(FinArgs fa, StrictArgs sa, S2Ar
         if (!any) { WAVE_LDS_SYNC(); continue; }
         const bool fwdL = (gL.flags & 1) != 0;
         const bool diag = ti == tj;
-        for (int c = -1; c < nc; c++) {     // c = -1: the current layout (its values are kept in LDS), then the classes
+        unsigned vmask = 0;   // bit j: this lane's fragment and fragment j of the segment are a pair to price (every unordered pair once; never a
+                              // bin with itself; copies of repeated bins -- no sub-fragments here -- are priced by k_rep_delta)
+        for (int j = 0; j < cnt; j++)
+            if (has_l && stL.n > 0 && tile[j].st.n > 0 && !(diag && !(lane < j0 + j))) vmask |= 1u << j;
+        for (int c = -1; c < nc; c = c < 0 ? rep_r : c + rep_n) {     // c = -1: the current layout (its values are kept in LDS), then this wave's classes
             bool cis = cis_old;
             int circ = cis_old ? circ_old : 0, lbp = lbp_old, sig_l = 1, sig_s = 1, off_l = 0, off_s = 0;
             unsigned long long m0 = 0, m1 = 0;
@@ -356,10 +385,32 @@ __global__ __launch_bounds__(256) void k_strict2(FinArgs fa, StrictArgs sa, S2Ar
             WAVE_LDS_SYNC();
             long long accq = 0;
             bool bad = false;
+            auto add_pair = [&](int j, double acc) {   // one fragment pair of the class: rounded to Q once
+                if ((vmask >> j) & 1u) {
+                    const long long q1 = to_q_fast(acc);
+                    if (q1 == Q_BAD) bad = true; else accq += q1;
+                }
+            };
+            if (!MULTI && norm_u >= 0.0f && !(quirk && !cis)) {
+                // one sub-fragment per bin, one RF count: nothing per pair but the model
+                if (!cis) {
+                    const float ex = par.v_inter * norm_u;
+                    for (int j = 0; j < cnt; j++) {
+                        if (c < 0) exo[j][lane] = ex;
+                        else add_pair(j, (double)exo[j][lane] - (double)ex);
+                    }
+                } else {
+                    for (int j = 0; j < cnt; j++) {
+                        const float c_s = cy[j][0];
+                        const float ex = s2_ex(true, lf ? cl[0] : c_s, lf ? c_s : cl[0], norm_u, circ, s_tot, par);
+                        if (c < 0) exo[j][lane] = ex;
+                        else add_pair(j, (double)exo[j][lane] - (double)ex);
+                    }
+                }
+            } else
             for (int j = 0; j < cnt; j++) {
                 const STile2& y = tile[j];
                 const int ny = y.st.n, fs = y.frag;
-                const bool valid = has_l && stL.n > 0 && ny > 0 && !(diag && !(lane < j0 + j));
                 const bool fwdSn = cy[j][3] != 0.0f;
                 double acc = 0.0;
                 // slot pairs in the order of the O(m^2) kernel: the FIRST fragment's slots outside (first = earlier in the union's order:
@@ -382,10 +433,7 @@ __global__ __launch_bounds__(256) void k_strict2(FinArgs fa, StrictArgs sa, S2Ar
                         if (c < 0) *slot = ex;
                         else acc += (double)*slot - (double)ex;
                     }
-                if (c >= 0 && valid) {
-                    const long long q1 = to_q(acc);
-                    if (q1 == Q_BAD) bad = true; else accq += q1;
-                }
+                if (c >= 0) add_pair(j, acc);
             }
             if (c >= 0) {
                 const long long qs = wave_sum_ll(accq);
@@ -402,7 +450,7 @@ __global__ __launch_bounds__(256) void k_strict2(FinArgs fa, StrictArgs sa, S2Ar
         QSrc qs;
         qs.queue = fa.queue; qs.geo2 = reinterpret_cast<const int2*>(geo); qs.cnt = fa.cnt; qs.keys = nullptr; qs.live = 0; qs.K = K;
         qs.seq = (unsigned)seq; qs.concurrent = 0; qs.multi = fa.multi;
-        for (unsigned long long b0 = (unsigned long long)(n_waves - 1 - wave) * 64ull; b0 < nq_total; b0 += (unsigned long long)n_waves * 64ull) {
+        for (unsigned long long b0 = (unsigned long long)(n_waves - 1 - wave) * 64ull; b0 < ((fa.skip & 2) ? 0ull : nq_total); b0 += (unsigned long long)n_waves * 64ull) {
             const unsigned long long e = b0 + (unsigned long long)lane;
             if (e >= nq_total) continue;
             const QEntry qe = q_fetch(qs, e, counters + 6);

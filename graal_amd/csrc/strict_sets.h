@@ -43,20 +43,30 @@ struct UEnd { int label, pos, base, len, lbp, circ; };
 GR_HD int upiece_tiles(int n) { return (n + US_TILE - 1) / US_TILE; }
 GR_HD int upair_index(int g, int h) { return g * US_MAXP - g * (g - 1) / 2 + (h - g); }   // g <= h
 
-// Build the union set.  cuts: workspace of US_MAXC * (US_MAXK + 1) ints, ncut: US_MAXC ints (LDS on the device: one thread runs this).
-GR_HD void uset_build(USet& U, const UEnd& A, const UEnd* B, const PieceKey* keys, int K, unsigned live, unsigned mass, int* cuts, int* ncut)
+// Build the union set, in two parts: the contigs, cuts, pieces and tiles (one thread), then every piece's id under every neighbour
+// (independent entries: one thread each on the device).  cuts: workspace of US_MAXC * (US_MAXK + 1) ints, ncut: US_MAXC ints.
+GR_HD void uset_add_piece(USet& U, int& np, int& tile, int ci, int lo, int n)
+{
+    if (n <= 0) return;
+    UPiece& P = U.p[np];
+    np += 1;
+    P.contig = ci; P.lo = lo; P.n = n; P.tile0 = tile;
+    P.pad[0] = 0; P.pad[1] = 0;
+    tile += upiece_tiles(n);
+}
+GR_HD void uset_build_geometry(USet& U, const UEnd& A, const UEnd* B, int K, unsigned live, unsigned mass, int* cuts, int* ncut)
 {
     constexpr int CW = US_MAXK + 1;
     U.live = live; U.mass = mass & live; U.pad = 0;
-    U.n_contigs = 1;
+    int nc = 1;
     U.c[0].label = A.label; U.c[0].base = A.base; U.c[0].len = A.len; U.c[0].lbp = A.lbp; U.c[0].circ = A.circ; U.c[0].pad = 0;
     cuts[0] = A.pos; ncut[0] = 1;
     for (int k = 0; k < K; k++) {
         if (!((live >> k) & 1u)) continue;
         int ci = -1;
-        for (int i = 0; i < U.n_contigs; i++) if (U.c[i].label == B[k].label) ci = i;
+        for (int i = 0; i < nc; i++) if (U.c[i].label == B[k].label) ci = i;
         if (ci < 0) {
-            ci = U.n_contigs++;
+            ci = nc++;
             U.c[ci].label = B[k].label; U.c[ci].base = B[k].base; U.c[ci].len = B[k].len; U.c[ci].lbp = B[k].lbp; U.c[ci].circ = B[k].circ;
             U.c[ci].pad = 0;
             ncut[ci] = 0;
@@ -70,28 +80,31 @@ GR_HD void uset_build(USet& U, const UEnd& A, const UEnd* B, const PieceKey* key
         cc[at] = B[k].pos;
         ncut[ci] = n + 1;
     }
+    U.n_contigs = nc;
     int np = 0, tile = 0;
-    auto add = [&](int ci, int lo, int n) {
-        if (n <= 0) return;
-        UPiece& P = U.p[np++];
-        P.contig = ci; P.lo = lo; P.n = n; P.tile0 = tile;
-        tile += upiece_tiles(n);
-        for (int k = 0; k < US_MAXK; k++)
-            P.pk[k] = (unsigned char)((k < K && ((live >> k) & 1u)) ? piece_of(keys[k], U.c[ci].label, lo) : 0);
-        P.pad[0] = 0; P.pad[1] = 0;
-    };
-    for (int ci = 0; ci < U.n_contigs; ci++) {
+    for (int ci = 0; ci < nc; ci++) {
         const int* cc = cuts + ci * CW;
         int prev = 0;
         for (int i = 0; i < ncut[ci]; i++) {
-            add(ci, prev, cc[i] - prev);
-            add(ci, cc[i], 1);
+            uset_add_piece(U, np, tile, ci, prev, cc[i] - prev);
+            uset_add_piece(U, np, tile, ci, cc[i], 1);
             prev = cc[i] + 1;
         }
-        add(ci, prev, U.c[ci].len - prev);
+        uset_add_piece(U, np, tile, ci, prev, U.c[ci].len - prev);
     }
     U.n_pieces = np;
     U.n_tiles = tile;
+}
+GR_HD void uset_piece_pk(USet& U, const PieceKey* keys, int K, int g, int k)
+{
+    UPiece& P = U.p[g];
+    P.pk[k] = (unsigned char)((k < K && ((U.live >> k) & 1u)) ? piece_of(keys[k], U.c[P.contig].label, P.lo) : 0);
+}
+GR_HD void uset_build(USet& U, const UEnd& A, const UEnd* B, const PieceKey* keys, int K, unsigned live, unsigned mass, int* cuts, int* ncut)
+{
+    uset_build_geometry(U, A, B, K, live, mass, cuts, ncut);
+    for (int g = 0; g < U.n_pieces; g++)
+        for (int k = 0; k < US_MAXK; k++) uset_piece_pk(U, keys, K, g, k);
 }
 
 // the global piece of tile t, and the tile's offset (in tiles) inside it
@@ -151,10 +164,13 @@ GR_HD int gclass_start(int sigma_pos, int off, int start_bp, int len_bp) { retur
 // against a full tile it is one segment of one fragment, not 64 lanes of which one works); the other tile is walked in segments.
 //   bits  0..15 ti   16..31 tj   32..37 first fragment of the segment (inside its tile)   38..43 fragments of the segment
 //   bit 44: the lanes are tile ti's fragments (else tile tj's)
-GR_HD unsigned long long uunit_pack(int ti, int tj, int j0, int cnt, int lanes_first)
+//   bits 45..47 r, 48..51 R: the unit is dealt to R waves, wave r of them prices the classes r, r + R, r + 2R, ... of its piece pair (each with
+//   the current layout's values of its own: when a step has few units, their depth -- all classes of a pair one after the other --
+//   is what the step waits for)
+GR_HD unsigned long long uunit_pack(int ti, int tj, int j0, int cnt, int lanes_first, int r = 0, int R = 1)
 {
     return (unsigned long long)ti | ((unsigned long long)tj << 16) | ((unsigned long long)j0 << 32) | ((unsigned long long)cnt << 38) |
-           ((unsigned long long)(lanes_first ? 1 : 0) << 44);
+           ((unsigned long long)(lanes_first ? 1 : 0) << 44) | ((unsigned long long)r << 45) | ((unsigned long long)R << 48);
 }
 GR_HD int utile_count(const USet& U, int t)
 {

@@ -22,11 +22,13 @@ esac
 cd /tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
 echo "trace rc=$?"
-if [ -z "${PROF_TRACE_ONLY:-}" ]; then
+if [ -z "${PROF_TRACE_ONLY:-}" ] && [ -z "${PROF_SQ_ONLY:-}" ]; then
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 $ARGS > $OUT/fetch.log 2>&1
 echo "fetch rc=$?"
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 $ARGS > $OUT/write.log 2>&1
 echo "write rc=$?"
+fi
+if [ -z "${PROF_TRACE_ONLY:-}" ]; then
 timeout -k 10 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d $OUT/sq -- python3 $ARGS > $OUT/sq.log 2>&1
 echo "sq rc=$?"
 fi
