@@ -4483,17 +4483,16 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
         const unsigned long long nt = std::min<unsigned long long>((unsigned long long)(K + 1) * (unsigned long long)((lc + 63) / 64),
                                                                    (unsigned long long)((h->n + 63) / 64 + K + 1)) + (unsigned long long)US_MAXP;
         if (nt >= 65536ull) return fail(h, GRAAL_E_STATE, "reference arithmetic: more than 65,535 tiles in a step's union set");
+        // the unit list's entries: 4 fragments of the segment side (one sub-fragment per bin; k_strict2 merges up to 4 of them) or 1 (several:
+        // up to 2); GRAAL_STRICT_SEG fixes the entry size, GRAAL_STRICT_REP the waves that may share one unit's classes (1, 2, 4, 8)
         static const int seg_env = getenv("GRAAL_STRICT_SEG") ? atoi(getenv("GRAAL_STRICT_SEG")) : 0;
-        const int seg_max = h->single_sub ? 16 : 2, seg_min = h->single_sub ? 4 : 1;   // (k_strict2's SEG)
-        const int seg_fixed = ((seg_env == 1 || seg_env == 2 || seg_env == 4 || seg_env == 8 || seg_env == 16) && seg_env <= seg_max) ? seg_env : 0;
+        const int seg_max = h->single_sub ? 16 : 2;   // (k_strict2's SEG)
+        const int seg_unit = ((seg_env == 1 || seg_env == 2 || seg_env == 4 || seg_env == 8 || seg_env == 16) && seg_env <= seg_max) ? seg_env : (h->single_sub ? 4 : 1);
+        static const int rep_env = getenv("GRAAL_STRICT_REP") ? atoi(getenv("GRAAL_STRICT_REP")) : 8;
+        const int rep_max = rep_env >= 16 ? 16 : (rep_env >= 8 ? 8 : (rep_env >= 4 ? 4 : (rep_env >= 2 ? 2 : 1)));
         const unsigned long long target = 6ull * 4ull * (unsigned long long)blocks;
         const unsigned long long pairs_max = nt * (nt + 1ull) / 2ull;
-        static const int rep_env = getenv("GRAAL_STRICT_REP") ? atoi(getenv("GRAAL_STRICT_REP")) : 8;   // waves that may share a unit's classes (1, 2, 4, 8)
-        const int rep_max = rep_env >= 8 ? 8 : (rep_env >= 4 ? 4 : (rep_env >= 2 ? 2 : 1));
-        // units: every tile pair cut to the chosen segment size, times the waves per unit: the cuts / the sharing stop at the first size that
-        // reaches the target, i.e. below 2 x target unless the largest segments / one wave per unit already give more
-        const unsigned long long need = (seg_fixed ? std::max(pairs_max * (unsigned long long)(64 / seg_fixed), std::min(pairs_max * (unsigned long long)(64 / seg_fixed) * (unsigned long long)rep_max, 2ull * target))
-                                                   : std::max(pairs_max * (unsigned long long)(64 / seg_max), std::min(pairs_max * (unsigned long long)(64 / seg_min) * (unsigned long long)rep_max, 2ull * target))) + 64ull;
+        const unsigned long long need = pairs_max * (unsigned long long)(64 / seg_unit) + 64ull;
         if (need > h->slist_cap) {
             CK(hipStreamSynchronize(st));
             CK(hipStreamSynchronize(h->aux));
@@ -4511,10 +4510,10 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
         fa.skip = s2_skip;
         const int no_window = (sx.quirk && h->n_ubins > 0) ? 1 : 0;
         S2Args s2;
-        s2.uset = h->d_uset; s2.cls = h->d_cls; s2.cls_n = h->d_cls_n;
+        s2.uset = h->d_uset; s2.cls = h->d_cls; s2.cls_n = h->d_cls_n; s2.seg_unit = seg_unit; s2.rep_max = rep_max; s2.target = target;
         const int cull_blocks = (int)std::min<unsigned long long>(1024ull, std::max<unsigned long long>(1ull, nt));
         k_gprep<<<GPREP_CLS_BLOCKS + cull_blocks, 256, 0, h->aux>>>(h->tabs, h->geo, h->link, h->cbase, h->perm, fA, K, rank, world, sx.reach_bp, no_window, sx.quirk,
-                                                                     seg_fixed, seg_min, seg_max, rep_max, target, h->d_slist, h->d_slist_n, h->slist_cap,
+                                                                     seg_unit, h->d_slist, h->d_slist_n, h->slist_cap,
                                                                      (unsigned long long*)(h->d_scalars + 10), s2);
         CK(hipGetLastError());
         CK(hipEventRecord(h->ev_tm, h->aux));      // (behind k_tm and k_gprep: tables, classes and unit list complete -- nobody spins for them)

@@ -16,7 +16,16 @@ struct S2Args {
     USet* uset;            // written by block 0 of k_gprep
     GClass* cls;           // [US_MAXPAIRS][US_NCAND]
     int* cls_n;            // [US_MAXPAIRS]
+    int seg_unit;          // fragments of the segment side per entry of the unit list (k_gprep), a power of two
+    int rep_max;           // waves that may share one unit's classes at most (1, 2, 4, 8)
+    unsigned long long target;   // units the grid wants (a few per wave)
 };
+
+#ifdef GRAAL_STAMPS
+#define S2_COUNT(i, v) do { atomicAdd(&g_hitstat[i], (unsigned long long)(v)); } while (0)
+#else
+#define S2_COUNT(i, v) do { } while (0)
+#endif
 
 constexpr int GPREP_CLS_BLOCKS = 64;   // blocks of k_gprep that build classes (one wave per piece pair, round robin); the rest cull
 
@@ -39,8 +48,7 @@ __device__ __forceinline__ void utile_extent(const USet& U, const Geo* __restric
 
 __global__ __launch_bounds__(256) void k_gprep(const NbTables* __restrict__ tabs, const Geo* __restrict__ geo, const Link* __restrict__ link,
                                                 const int* __restrict__ cbase, const int* __restrict__ perm, int fA, int K, int rank, int world,
-                                                int reach_bp, int no_window, int quirk, int seg_fixed, int seg_min, int seg_max, int rep_max,
-                                                unsigned long long target_units, unsigned long long* __restrict__ list,
+                                                int reach_bp, int no_window, int quirk, int seg_unit, unsigned long long* __restrict__ list,
                                                 unsigned long long* __restrict__ list_n, unsigned long long cap,
                                                 unsigned long long* __restrict__ counters, S2Args s2)
 {
@@ -54,6 +62,7 @@ __global__ __launch_bounds__(256) void k_gprep(const NbTables* __restrict__ tabs
     __shared__ int s_ne[256], s_off[257], s_tp[256];
     __shared__ unsigned long long s_base;
     const int t = threadIdx.x, lane = t & 63, wib = t >> 6;
+    STAMP(11, blockIdx.x == 0 && t == 0);
     if (t == 0) { s_live = 0; s_mass = 0; }
     __syncthreads();
     if (t <= K) {   // thread K: fA; threads 0..K-1: the neighbours
@@ -82,6 +91,7 @@ __global__ __launch_bounds__(256) void k_gprep(const NbTables* __restrict__ tabs
         for (int i = t; i < (int)(sizeof(USet) / 4); i += 256) dst[i] = src[i];
     }
     const int np = U.n_pieces;
+    STAMP(12, blockIdx.x == 0 && t == 0);
     if ((int)blockIdx.x < GPREP_CLS_BLOCKS) {
         // ---- classes of equal inputs per pair of global pieces: one wave per pair.  Lane l holds the candidates l, l + 64, l + 128
         // (candidate = k * 13 + op); a class is the ballot of the lanes whose key equals the first unassigned candidate's.
@@ -135,23 +145,14 @@ __global__ __launch_bounds__(256) void k_gprep(const NbTables* __restrict__ tabs
             }
             if (lane == 0) s2.cls_n[pair] = nc;
         }
+        STAMP_MAX(13, lane == 0);
         return;
     }
     // ---- unit list: rows = tiles; a tile pair is listed iff some fragment pair of it can be inside the window under the current
     // layout or under some candidate whose inputs differ from the current layout's (interval arithmetic, no per-pair work)
     const int n_tiles = U.n_tiles;
-    int seg = seg_fixed;
-    if (seg <= 0) {
-        const unsigned long long est = (unsigned long long)n_tiles * (unsigned long long)(n_tiles + 1) / 2ull;
-        seg = seg_max;
-        while (seg > seg_min && est * (unsigned long long)(US_TILE / seg) < target_units) seg >>= 1;
-    }
-    // still too few units for the grid: deal every unit to R waves, which share its classes (uunit_pack)
-    int R = 1;
-    {
-        const unsigned long long est = (unsigned long long)n_tiles * (unsigned long long)(n_tiles + 1) / 2ull * (unsigned long long)(US_TILE / seg);
-        while (R < rep_max && est * (unsigned long long)R < target_units) R <<= 1;
-    }
+    // (entries of seg_unit fragments of the segment side: k_strict2 merges neighbouring entries or deals one to several waves, by their number)
+    const int seg = seg_unit, R = 1;
     const int n_cull = (int)gridDim.x - GPREP_CLS_BLOCKS;
     for (int ti = (int)blockIdx.x - GPREP_CLS_BLOCKS; ti < n_tiles; ti += n_cull) {
         __syncthreads();
@@ -210,6 +211,7 @@ __global__ __launch_bounds__(256) void k_gprep(const NbTables* __restrict__ tabs
             __syncthreads();
         }
     }
+    STAMP_MAX(14, t == 0);
 }
 
 struct STile2 { int start_bp, len_bp, flags, frag; Stat st; };   // one staged fragment of the segment side, 48 bytes
@@ -246,7 +248,7 @@ __device__ __forceinline__ void s2_flag_mask(unsigned long long* nf, unsigned lo
 }
 
 template <bool MULTI>
-__global__ __launch_bounds__(256) void k_strict2(FinArgs fa, StrictArgs sa, S2Args s2, int K, const unsigned long long* __restrict__ list,
+__global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S2Args s2, int K, const unsigned long long* __restrict__ list,
                                                   unsigned long long* __restrict__ list_n, long long* __restrict__ d_q_out,
                                                   volatile long long* host_res, long long seq)
 {
@@ -265,6 +267,9 @@ __global__ __launch_bounds__(256) void k_strict2(FinArgs fa, StrictArgs sa, S2Ar
     __shared__ float s_cy[4][SEG][4];          // the segment side's centres (and its orientation, [3]) in the layout being priced
     __shared__ float s_exo[4][SEG * NSP][64];  // the current layout's values of the unit's slot pairs, [segment fragment][slot pair][lane]
     __shared__ int s_last;
+    constexpr int CLS_CHUNK = 32;              // class records of a unit's piece pair staged per wave (a pair has up to 130; most have a dozen)
+    __shared__ GClass s_cls[4][CLS_CHUNK];
+    STAMP(16, blockIdx.x == 0 && threadIdx.x == 0);
     for (int i = threadIdx.x; i < US_NCAND; i += 256) s_acc[i] = 0;
     {
         const int* src = reinterpret_cast<const int*>(s2.uset);
@@ -283,12 +288,37 @@ __global__ __launch_bounds__(256) void k_strict2(FinArgs fa, StrictArgs sa, S2Ar
     STile2* const tile = s_tile[wib];
     float (*const cy)[4] = s_cy[wib];
     float (*const exo)[64] = s_exo[wib];
-    // ---- (1) the listed units, one wave each
-    for (unsigned long long u = (unsigned long long)wave; u < ((fa.skip & 1) ? 0ull : n_units); u += (unsigned long long)n_waves) {
-        const unsigned long long ent = list[u];
+    STAMP(17, blockIdx.x == 0 && threadIdx.x == 0);
+    // ---- (1) the listed units.  The list holds entries of at most seg_unit fragments of the segment side; a wave takes m neighbouring
+    // entries -- merged into one unit where they continue each other (many entries: fewer, longer units, the lanes' side loaded once) -- or
+    // one entry is dealt to R waves that share its classes (few entries: a unit's depth, all classes of a pair one after the other, is what a
+    // step of a few hundred fragments waits for)
+    int mrg = 1, rep_n = 1;
+    {
+        const int m_max = SEG / s2.seg_unit;
+        while (mrg < m_max && n_units / (unsigned long long)(2 * mrg) >= s2.target) mrg <<= 1;
+        // (sharing a unit costs every sharing wave the current layout's values again: only while there are fewer units than waves)
+        if (mrg == 1) while (rep_n < s2.rep_max && n_units * (unsigned long long)rep_n < (unsigned long long)n_waves) rep_n <<= 1;
+    }
+    S2_COUNT(7, (blockIdx.x == 0 && threadIdx.x == 0) ? (unsigned long long)n_units * 1000000ull + (unsigned long long)(mrg * 100 + rep_n) : 0ull);
+    const unsigned long long n_virtual = (fa.skip & 1) ? 0ull : ((n_units + (unsigned long long)mrg - 1ull) / (unsigned long long)mrg) * (unsigned long long)rep_n;
+    for (unsigned long long v = (unsigned long long)wave; v < n_virtual; v += (unsigned long long)n_waves) {
+      const int rep_r = (int)(v % (unsigned long long)rep_n);
+      unsigned long long e = (v / (unsigned long long)rep_n) * (unsigned long long)mrg;
+      const unsigned long long e1 = min(n_units, e + (unsigned long long)mrg);
+      while (e < e1) {
+        const unsigned long long ent = list[e];
+        e += 1;
         const int ti = rfl((int)(ent & 0xffffull)), tj = rfl((int)((ent >> 16) & 0xffffull)), j0 = rfl((int)((ent >> 32) & 63ull));
-        const int cnt = rfl((int)((ent >> 38) & 63ull)), lf = rfl((int)((ent >> 44) & 1ull));
-        const int rep_r = rfl((int)((ent >> 45) & 7ull)), rep_n = rfl((int)((ent >> 48) & 15ull));
+        int cnt = rfl((int)((ent >> 38) & 63ull));
+        const int lf = rfl((int)((ent >> 44) & 1ull));
+        while (e < e1) {   // entries that continue this one
+            const unsigned long long nx = list[e];
+            const int c2 = rfl((int)((nx >> 38) & 63ull));
+            if (rfl((int)(nx & 0xffffffffull)) != rfl((int)(ent & 0xffffffffull)) || rfl((int)((nx >> 32) & 63ull)) != j0 + cnt || cnt + c2 > SEG) break;
+            cnt += c2;
+            e += 1;
+        }
         int offi, offj;
         const int g = rfl(utile_piece(U, ti, offi)), h = rfl(utile_piece(U, tj, offj));
         offi = rfl(offi); offj = rfl(offj);
@@ -321,15 +351,31 @@ __global__ __launch_bounds__(256) void k_strict2(FinArgs fa, StrictArgs sa, S2Ar
         if (quirk) always = __ballot((has_l && !stat_uniform(stL)) || (lane < cnt && !stat_uniform(tile[lane < cnt ? lane : 0].st))) != 0ull;
         const int pair = upair_index(g, h);
         const int nc = rfl(s2.cls_n[pair]);
-        const GClass* __restrict__ cp = s2.cls + (size_t)pair * US_NCAND;
+        const GClass* __restrict__ cg = s2.cls + (size_t)pair * US_NCAND;
+        // the pair's class records: into LDS in one round trip (read one by one where they are needed, each was a round trip of its own -- with
+        // a dozen classes per unit, most of a small step)
+        GClass* const cp = s_cls[wib];
+        int c_base = 0;                      // cp[i] = class c_base + i, CLS_CHUNK of them
+        auto stage = [&](int c0) {
+            WAVE_LDS_SYNC();
+            const uint4* src = reinterpret_cast<const uint4*>(cg + c0);
+            uint4* dst = reinterpret_cast<uint4*>(cp);
+            const int n4 = min(nc - c0, CLS_CHUNK) * 4;
+            for (int i = lane; i < n4; i += 64) dst[i] = src[i];
+            c_base = c0;
+            WAVE_LDS_SYNC();
+        };
+        stage(0);
         // is there anything to price?  (a listed unit has, but for the finer extents of its segment)
         bool any = false;
         for (int c = rep_r; c < nc && !any; c += rep_n) {
-            if (!(cp[c].w0 | cp[c].w1 | (unsigned long long)cp[c].w2)) continue;   // (a class of neighbours priced by the table kernel)
+            if (c < c_base || c >= c_base + CLS_CHUNK) stage(c);
+            const GClass& cr = cp[c - c_base];
+            if (!(cr.w0 | cr.w1 | (unsigned long long)cr.w2)) continue;   // (a class of neighbours priced by the table kernel)
             if (near_old || always) { any = true; break; }
-            const unsigned flags = (unsigned)rfl((int)cp[c].flags);
+            const unsigned flags = (unsigned)rfl((int)cr.flags);
             if (!(flags & 4u)) continue;
-            const int offx = rfl(cp[c].offx), offy = rfl(cp[c].offy);
+            const int offx = rfl(cr.offx), offy = rfl(cr.offy);
             const int sig_l = lf ? (flags & 1u) : ((flags >> 1) & 1u), sig_s = lf ? ((flags >> 1) & 1u) : (flags & 1u);
             const int off_l = lf ? offx : offy, off_s = lf ? offy : offx;
             const int xs2 = sig_l ? xs + off_l : off_l - xe, xe2 = sig_l ? xe + off_l : off_l - xs;
@@ -349,9 +395,11 @@ __global__ __launch_bounds__(256) void k_strict2(FinArgs fa, StrictArgs sa, S2Ar
             unsigned long long m0 = 0, m1 = 0;
             unsigned m2 = 0;
             if (c >= 0) {
-                const unsigned flags = (unsigned)rfl((int)cp[c].flags);
-                const int offx = rfl(cp[c].offx), offy = rfl(cp[c].offy);
-                cis = (flags & 4u) != 0; circ = (flags >> 3) & 1u; lbp = rfl(cp[c].lbp);
+                if (c < c_base || c >= c_base + CLS_CHUNK) stage(c);
+                const GClass& cr = cp[c - c_base];
+                const unsigned flags = (unsigned)rfl((int)cr.flags);
+                const int offx = rfl(cr.offx), offy = rfl(cr.offy);
+                cis = (flags & 4u) != 0; circ = (flags >> 3) & 1u; lbp = rfl(cr.lbp);
                 sig_l = lf ? (flags & 1u) : ((flags >> 1) & 1u); sig_s = lf ? ((flags >> 1) & 1u) : (flags & 1u);
                 off_l = lf ? offx : offy; off_s = lf ? offy : offx;
                 if (!(near_old || always)) {   // the trans value both times, slot by slot: exactly zero
@@ -360,10 +408,10 @@ __global__ __launch_bounds__(256) void k_strict2(FinArgs fa, StrictArgs sa, S2Ar
                     const int ys2 = sig_s ? ys + off_s : off_s - ye, ye2 = sig_s ? ye + off_s : off_s - ys;
                     if (max(ys2 - xe2, xs2 - ye2) > reach_bp) continue;
                 }
-                const unsigned long long mm0 = cp[c].w0, mm1 = cp[c].w1;
+                const unsigned long long mm0 = cr.w0, mm1 = cr.w1;
                 m0 = ((unsigned long long)(unsigned)rfl((int)(mm0 >> 32)) << 32) | (unsigned long long)(unsigned)rfl((int)mm0);
                 m1 = ((unsigned long long)(unsigned)rfl((int)(mm1 >> 32)) << 32) | (unsigned long long)(unsigned)rfl((int)mm1);
-                m2 = (unsigned)rfl((int)cp[c].w2);
+                m2 = (unsigned)rfl((int)cr.w2);
                 if (!(m0 | m1 | (unsigned long long)m2)) continue;
             }
             const float s_tot = (float)lbp / 1000.0f;
@@ -383,6 +431,8 @@ __global__ __launch_bounds__(256) void k_strict2(FinArgs fa, StrictArgs sa, S2Ar
                 cy[lane][3] = fwdSn ? 1.0f : 0.0f;
             }
             WAVE_LDS_SYNC();
+            S2_COUNT(5, lane == 0 ? 1 : 0);                                   // (unit, layout) passes
+            S2_COUNT(6, __popc(vmask));                                      // fragment pairs priced in them
             long long accq = 0;
             bool bad = false;
             auto add_pair = [&](int j, double acc) {   // one fragment pair of the class: rounded to Q once
@@ -443,7 +493,9 @@ __global__ __launch_bounds__(256) void k_strict2(FinArgs fa, StrictArgs sa, S2Ar
             }
             WAVE_LDS_SYNC();   // (the next pass writes the segment's centres again)
         }
+      }
     }
+    STAMP_MAX(18, lane == 0);
     // ---- (2) the queued contacts (the scan queued every contact with both ends in some neighbour's set): lane = contact, one
     // evaluation per class of its piece pair
     {
@@ -495,6 +547,7 @@ __global__ __launch_bounds__(256) void k_strict2(FinArgs fa, StrictArgs sa, S2Ar
             }
         }
     }
+    STAMP_MAX(19, lane == 0);
     __syncthreads();
     for (int i = threadIdx.x; i < K * N_OPS; i += 256) {
         const long long v = s_acc[i];
@@ -512,4 +565,5 @@ __global__ __launch_bounds__(256) void k_strict2(FinArgs fa, StrictArgs sa, S2Ar
     __threadfence();
     if (threadIdx.x == 0) *list_n = 0;   // (every block has read it: the list is empty again for the next step)
     hand_out(fa.acc, counters, fa.sync, K, d_q_out, host_res, seq);
+    STAMP(20, threadIdx.x == 0);
 }
