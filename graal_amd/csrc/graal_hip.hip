@@ -81,7 +81,12 @@ __device__ __forceinline__ float rippe(float s, const Par& p)
 {
     float result = 0.0f;
     if ((s > 0.0f) && (s < p.d_max))
-        result = (p.c1 * mm_powf_pos(s, p.slope) * mm_expf((p.d - 2) / (sq(s * p.lm / p.kuhn) + p.d))) * p.fact;
+    {
+        // (x / 1.0f is x: a Kuhn length of one -- the fitted models' -- needs no division; wave-uniform, the parameters are kernel arguments)
+        float n = s * p.lm;
+        if (p.kuhn != 1.0f) { asm volatile("" : "+v"(n)); n = n / p.kuhn; }   // (the barrier keeps this a branch: as a select, both sides were computed)
+        result = (p.c1 * mm_powf_pos(s, p.slope) * mm_expf((p.d - 2) / (sq(n) + p.d))) * p.fact;
+    }
     return fmaxf(result, p.v_inter);
 }
 
@@ -4473,8 +4478,9 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
         if (!h->d_uset) {
             CK(hipMalloc(&h->d_uset, sizeof(USet)));
             CK(hipMalloc(&h->d_cls, sizeof(GClass) * (size_t)US_MAXPAIRS * US_NCAND));
-            CK(hipMalloc(&h->d_cls_n, sizeof(int) * US_MAXPAIRS));
-            CK(hipMemset(h->d_cls_n, 0, sizeof(int) * US_MAXPAIRS));
+            CK(hipMalloc(&h->d_cls_n, sizeof(int) * US_MAXPAIRS + 16));   // (+ the units' draw counter)
+            CK(hipMemset(h->d_cls_n, 0, sizeof(int) * US_MAXPAIRS + 16));
+            CK(hipDeviceSynchronize());
         }
         const int lc = std::max(std::max(h->max_lcont, h->lcont_bound), 1);
         static const int blocks_env = getenv("GRAAL_STRICT_BLOCKS") ? atoi(getenv("GRAAL_STRICT_BLOCKS")) : 0;
@@ -4511,6 +4517,7 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
         const int no_window = (sx.quirk && h->n_ubins > 0) ? 1 : 0;
         S2Args s2;
         s2.uset = h->d_uset; s2.cls = h->d_cls; s2.cls_n = h->d_cls_n; s2.seg_unit = seg_unit; s2.rep_max = rep_max; s2.target = target;
+        s2.next = reinterpret_cast<unsigned long long*>(h->d_cls_n + US_MAXPAIRS + (US_MAXPAIRS & 1));
         const int cull_blocks = (int)std::min<unsigned long long>(1024ull, std::max<unsigned long long>(1ull, nt));
         k_gprep<<<GPREP_CLS_BLOCKS + cull_blocks, 256, 0, h->aux>>>(h->tabs, h->geo, h->link, h->cbase, h->perm, fA, K, rank, world, sx.reach_bp, no_window, sx.quirk,
                                                                      seg_unit, h->d_slist, h->d_slist_n, h->slist_cap,

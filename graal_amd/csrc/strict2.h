@@ -19,6 +19,7 @@ struct S2Args {
     int seg_unit;          // fragments of the segment side per entry of the unit list (k_gprep), a power of two
     int rep_max;           // waves that may share one unit's classes at most (1, 2, 4, 8)
     unsigned long long target;   // units the grid wants (a few per wave)
+    unsigned long long* next;    // the next unit nobody has taken yet, minus the grid's waves (zero at rest: the step's last block clears it)
 };
 
 #ifdef GRAAL_STAMPS
@@ -302,7 +303,13 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
     }
     S2_COUNT(7, (blockIdx.x == 0 && threadIdx.x == 0) ? (unsigned long long)n_units * 1000000ull + (unsigned long long)(mrg * 100 + rep_n) : 0ull);
     const unsigned long long n_virtual = (fa.skip & 1) ? 0ull : ((n_units + (unsigned long long)mrg - 1ull) / (unsigned long long)mrg) * (unsigned long long)rep_n;
-    for (unsigned long long v = (unsigned long long)wave; v < n_virtual; v += (unsigned long long)n_waves) {
+    // a wave's first unit is its own number; the others it draws from a counter -- the draw goes out when a unit is started and is read
+    // when it is finished (units differ in cost by the classes of their piece pair and by the window: dealt round robin, the waves that
+    // got the heavy ones finished a fifth of the kernel after the others)
+    const bool draw = n_virtual >= 8ull * (unsigned long long)n_waves;   // (few units per wave: dealt round robin -- a draw is a round trip)
+    for (unsigned long long v = (unsigned long long)wave; v < n_virtual;) {
+      unsigned long long drawn = 0;
+      if (draw && lane == 0) drawn = atomicAdd(s2.next, 1ull);
       const int rep_r = (int)(v % (unsigned long long)rep_n);
       unsigned long long e = (v / (unsigned long long)rep_n) * (unsigned long long)mrg;
       const unsigned long long e1 = min(n_units, e + (unsigned long long)mrg);
@@ -441,22 +448,39 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
                     if (q1 == Q_BAD) bad = true; else accq += q1;
                 }
             };
+            // the same without branches for the common case (to_q_fast: |v| < 2^30 is v = hi + lo, hi = rint(v), both parts int32; summed apart,
+            // joined behind the loop); a larger term takes the slow way
+            long long acc_hi = 0, acc_lo = 0;
+            auto add_pair_fast = [&](int j, double v) {
+                const bool ok = ((vmask >> j) & 1u) != 0;
+                const bool big = ok && !(fabs(v) < 1073741824.0);
+                const double hi = rint(v);
+                const int ih = __double2int_rn(hi), il = __double2int_rn((v - hi) * Q_SCALE);
+                const bool take = ok && !big;
+                acc_hi += take ? (long long)ih : 0ll;
+                acc_lo += take ? (long long)il : 0ll;
+                if (__builtin_expect(big, 0)) {
+                    const long long q1 = to_q(v);
+                    if (q1 == Q_BAD) bad = true; else accq += q1;
+                }
+            };
             if (!MULTI && norm_u >= 0.0f && !(quirk && !cis)) {
                 // one sub-fragment per bin, one RF count: nothing per pair but the model
                 if (!cis) {
                     const float ex = par.v_inter * norm_u;
                     for (int j = 0; j < cnt; j++) {
                         if (c < 0) exo[j][lane] = ex;
-                        else add_pair(j, (double)exo[j][lane] - (double)ex);
+                        else add_pair_fast(j, (double)exo[j][lane] - (double)ex);
                     }
                 } else {
                     for (int j = 0; j < cnt; j++) {
                         const float c_s = cy[j][0];
                         const float ex = s2_ex(true, lf ? cl[0] : c_s, lf ? c_s : cl[0], norm_u, circ, s_tot, par);
                         if (c < 0) exo[j][lane] = ex;
-                        else add_pair(j, (double)exo[j][lane] - (double)ex);
+                        else add_pair_fast(j, (double)exo[j][lane] - (double)ex);
                     }
                 }
+                accq += acc_hi * (1ll << 30) + acc_lo;
             } else
             for (int j = 0; j < cnt; j++) {
                 const STile2& y = tile[j];
@@ -494,6 +518,8 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
             WAVE_LDS_SYNC();   // (the next pass writes the segment's centres again)
         }
       }
+      if (draw) v = (unsigned long long)n_waves + (((unsigned long long)(unsigned)rfl((int)(drawn >> 32)) << 32) | (unsigned long long)(unsigned)rfl((int)drawn));
+      else v += (unsigned long long)n_waves;
     }
     STAMP_MAX(18, lane == 0);
     // ---- (2) the queued contacts (the scan queued every contact with both ends in some neighbour's set): lane = contact, one
@@ -563,7 +589,7 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
     __syncthreads();
     if (!s_last) return;
     __threadfence();
-    if (threadIdx.x == 0) *list_n = 0;   // (every block has read it: the list is empty again for the next step)
+    if (threadIdx.x == 0) { *list_n = 0; *s2.next = 0; }   // (every block has read them: the list is empty again for the next step)
     hand_out(fa.acc, counters, fa.sync, K, d_q_out, host_res, seq);
     STAMP(20, threadIdx.x == 0);
 }
