@@ -4484,13 +4484,14 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
         }
         const int lc = std::max(std::max(h->max_lcont, h->lcont_bound), 1);
         static const int blocks_env = getenv("GRAAL_STRICT_BLOCKS") ? atoi(getenv("GRAAL_STRICT_BLOCKS")) : 0;
-        const int blocks = blocks_env > 0 ? blocks_env : (lc <= 64 ? 32 : (lc <= 1024 ? 512 : 1024));
+        const int blocks = blocks_env > 0 ? blocks_env : (lc <= 64 ? 32 : (lc <= 256 ? 512 : 1024));
         // tiles of the union: at most K + 1 contigs, at most every fragment; + one partial tile per global piece
         const unsigned long long nt = std::min<unsigned long long>((unsigned long long)(K + 1) * (unsigned long long)((lc + 63) / 64),
                                                                    (unsigned long long)((h->n + 63) / 64 + K + 1)) + (unsigned long long)US_MAXP;
         if (nt >= 65536ull) return fail(h, GRAAL_E_STATE, "reference arithmetic: more than 65,535 tiles in a step's union set");
         // the unit list's entries: 4 fragments of the segment side (one sub-fragment per bin; k_strict2 merges up to 4 of them) or 1 (several:
-        // up to 2); GRAAL_STRICT_SEG fixes the entry size, GRAAL_STRICT_REP the waves that may share one unit's classes (1, 2, 4, 8)
+        // up to 2); GRAAL_STRICT_SEG fixes the entry size (entries of one fragment at one sub-fragment per bin: the list's traffic cost the C4
+        // stand-in 20 % of its run), GRAAL_STRICT_REP the waves that may share one unit's classes (1, 2, 4, 8)
         static const int seg_env = getenv("GRAAL_STRICT_SEG") ? atoi(getenv("GRAAL_STRICT_SEG")) : 0;
         const int seg_max = h->single_sub ? 16 : 2;   // (k_strict2's SEG)
         const int seg_unit = ((seg_env == 1 || seg_env == 2 || seg_env == 4 || seg_env == 8 || seg_env == 16) && seg_env <= seg_max) ? seg_env : (h->single_sub ? 4 : 1);
@@ -4517,6 +4518,8 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
         const int no_window = (sx.quirk && h->n_ubins > 0) ? 1 : 0;
         S2Args s2;
         s2.uset = h->d_uset; s2.cls = h->d_cls; s2.cls_n = h->d_cls_n; s2.seg_unit = seg_unit; s2.rep_max = rep_max; s2.target = target;
+        static const int draw_env = getenv("GRAAL_STRICT_DRAW") ? atoi(getenv("GRAAL_STRICT_DRAW")) : 8;
+        s2.draw_min = draw_env > 0 ? draw_env : 8;
         s2.next = reinterpret_cast<unsigned long long*>(h->d_cls_n + US_MAXPAIRS + (US_MAXPAIRS & 1));
         const int cull_blocks = (int)std::min<unsigned long long>(1024ull, std::max<unsigned long long>(1ull, nt));
         k_gprep<<<GPREP_CLS_BLOCKS + cull_blocks, 256, 0, h->aux>>>(h->tabs, h->geo, h->link, h->cbase, h->perm, fA, K, rank, world, sx.reach_bp, no_window, sx.quirk,

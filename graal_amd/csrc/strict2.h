@@ -19,6 +19,7 @@ struct S2Args {
     int seg_unit;          // fragments of the segment side per entry of the unit list (k_gprep), a power of two
     int rep_max;           // waves that may share one unit's classes at most (1, 2, 4, 8)
     unsigned long long target;   // units the grid wants (a few per wave)
+    int draw_min;                // units per wave from which the waves draw their units from the counter instead of taking every n-th
     unsigned long long* next;    // the next unit nobody has taken yet, minus the grid's waves (zero at rest: the step's last block clears it)
 };
 
@@ -270,6 +271,7 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
     __shared__ int s_last;
     constexpr int CLS_CHUNK = 32;              // class records of a unit's piece pair staged per wave (a pair has up to 130; most have a dozen)
     __shared__ GClass s_cls[4][CLS_CHUNK];
+    __shared__ unsigned long long s_ent[4][16];   // the unit-list entries a wave is working through
     STAMP(16, blockIdx.x == 0 && threadIdx.x == 0);
     for (int i = threadIdx.x; i < US_NCAND; i += 256) s_acc[i] = 0;
     {
@@ -306,26 +308,28 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
     // a wave's first unit is its own number; the others it draws from a counter -- the draw goes out when a unit is started and is read
     // when it is finished (units differ in cost by the classes of their piece pair and by the window: dealt round robin, the waves that
     // got the heavy ones finished a fifth of the kernel after the others)
-    const bool draw = n_virtual >= 8ull * (unsigned long long)n_waves;   // (few units per wave: dealt round robin -- a draw is a round trip)
+    const bool draw = n_virtual >= (unsigned long long)s2.draw_min * (unsigned long long)n_waves;   // (few units per wave: dealt round robin -- a draw is a round trip)
     for (unsigned long long v = (unsigned long long)wave; v < n_virtual;) {
       unsigned long long drawn = 0;
       if (draw && lane == 0) drawn = atomicAdd(s2.next, 1ull);
       const int rep_r = (int)(v % (unsigned long long)rep_n);
-      unsigned long long e = (v / (unsigned long long)rep_n) * (unsigned long long)mrg;
-      const unsigned long long e1 = min(n_units, e + (unsigned long long)mrg);
-      while (e < e1) {
-        const unsigned long long ent = list[e];
-        e += 1;
-        const int ti = rfl((int)(ent & 0xffffull)), tj = rfl((int)((ent >> 16) & 0xffffull)), j0 = rfl((int)((ent >> 32) & 63ull));
-        int cnt = rfl((int)((ent >> 38) & 63ull));
-        const int lf = rfl((int)((ent >> 44) & 1ull));
-        while (e < e1) {   // entries that continue this one
-            const unsigned long long nx = list[e];
-            const int c2 = rfl((int)((nx >> 38) & 63ull));
-            if (rfl((int)(nx & 0xffffffffull)) != rfl((int)(ent & 0xffffffffull)) || rfl((int)((nx >> 32) & 63ull)) != j0 + cnt || cnt + c2 > SEG) break;
-            cnt += c2;
-            e += 1;
-        }
+      const unsigned long long e0 = (v / (unsigned long long)rep_n) * (unsigned long long)mrg;
+      const int m_in = (int)(min(n_units, e0 + (unsigned long long)mrg) - e0);
+      // the group's entries, one per lane (one round trip); runs of entries that continue each other become one unit
+      if (lane < m_in) s_ent[wib][lane] = list[e0 + (unsigned long long)lane];   // (kept in LDS: live across a unit they cost registers the pair loop needs)
+      WAVE_LDS_SYNC();
+      int pos = 0;
+      while (pos < m_in) {
+        const unsigned long long my = lane < m_in ? s_ent[wib][lane] : 0ull;
+        const int my_key = (int)(my & 0xffffffffull), my_j0 = (int)((my >> 32) & 63ull), my_cnt = (int)((my >> 38) & 63ull), my_lf = (int)((my >> 44) & 1ull);
+        const int key0 = __shfl(my_key, pos, 64), j0 = rfl(__shfl(my_j0, pos, 64)), lf = rfl(__shfl(my_lf, pos, 64));
+        const bool cont = lane >= pos && lane < m_in && my_key == key0 && my_lf == lf && my_j0 == j0 + (lane - pos) * s2.seg_unit;
+        const unsigned long long bl = __ballot(cont) >> pos;          // bit i: entry pos + i continues the run (bit 0: the entry itself)
+        int run = (int)__ffsll((long long)~bl) - 1;
+        run = min(run, SEG / s2.seg_unit);
+        const int cnt = rfl((run - 1) * s2.seg_unit + __shfl(my_cnt, pos + run - 1, 64));
+        const int ti = rfl(key0 & 0xffff), tj = rfl((key0 >> 16) & 0xffff);
+        pos += run;
         int offi, offj;
         const int g = rfl(utile_piece(U, ti, offi)), h = rfl(utile_piece(U, tj, offj));
         offi = rfl(offi); offj = rfl(offj);
@@ -518,6 +522,7 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
             WAVE_LDS_SYNC();   // (the next pass writes the segment's centres again)
         }
       }
+      WAVE_LDS_SYNC();
       if (draw) v = (unsigned long long)n_waves + (((unsigned long long)(unsigned)rfl((int)(drawn >> 32)) << 32) | (unsigned long long)(unsigned)rfl((int)drawn));
       else v += (unsigned long long)n_waves;
     }
