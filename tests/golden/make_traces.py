@@ -16,18 +16,22 @@ sys.path.insert(0, ROOT)
 from graal_amd import em, synth  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
-CASES = [  # name, n_sub, seed, n_bins, nnz, cycles, neighbours, blacklist, repeated bins
+CASES = [  # name, n_sub, seed, n_bins, nnz, cycles, neighbours, blacklist, repeated bins[, generic]
     ("single_sub", 1, 41, 70, 1200, 2, 3, [], []),
     ("three_sub", 3, 42, 60, 1500, 2, 4, [], []),
     ("blacklist", 3, 48, 50, 900, 2, 4, [3, 4, 5, 17, 31], []),
     ("repeats", 3, 92, 45, 900, 2, 3, [], [5, 18, 30]),
+    # generic bp lengths (float32 kb coordinates inexact) and RF counts 1..9 per sub-fragment: what the reference's own arithmetic is
+    # sensitive to (coordinate rounding noise of unchanged pairs, the trans-branch RF-count indexing: kernels3.cu:2997-3078, 3155 / 3638);
+    # the oracle runs with fix_trans_accu=False, the engine in its default mode (reference arithmetic)
+    ("generic_coordinates", 3, 57, 60, 1500, 2, 4, [], [], True),
 ]
 
 
-def problem(n_sub, seed, n_bins, nnz, blacklist, repeats=()):
+def problem(n_sub, seed, n_bins, nnz, blacklist, repeats=(), generic=False):
     par = synth.make_param_simu(fact=200.0, v_inter=0.02)
     P = synth.make_problem(n_bins=n_bins, nnz=nnz, n_sub=n_sub, seed=seed, contig_weights=(5, 4, 3), mean_len_bp=2000.0,
-                           accu=9 if n_sub > 1 else 1, param=par, grid_bp=2000)
+                           accu=(("random", 1, 9) if generic else 9) if n_sub > 1 else 1, param=par, grid_bp=None if generic else 2000)
     P = synth.with_dense(P)
     if len(repeats):
         P = synth.add_repeats(P, repeats, 2)   # two extra copies of every repeated bin
@@ -37,12 +41,13 @@ def problem(n_sub, seed, n_bins, nnz, blacklist, repeats=()):
 
 def main():
     out = {}
-    for name, n_sub, seed, n_bins, nnz, cycles, delta, black, reps in CASES:
-        P = problem(n_sub, seed, n_bins, nnz, black, reps)
-        ora = O.OracleSampler(P, np.random.RandomState(seed), fix_trans_accu=True)
+    for name, n_sub, seed, n_bins, nnz, cycles, delta, black, reps, *rest in CASES:
+        generic = bool(rest and rest[0])
+        P = problem(n_sub, seed, n_bins, nnz, black, reps, generic)
+        ora = O.OracleSampler(P, np.random.RandomState(seed), fix_trans_accu=not generic)
         t = em.run_em(ora, cycles, delta, rng=ora.rng)
         out[name] = {"n_sub": n_sub, "seed": seed, "n_bins": n_bins, "nnz": nnz, "cycles": cycles, "neighbours": delta,
-                     "blacklist": black, "repeats": reps, "mutations": np.asarray(t.mutations()).tolist(),
+                     "blacklist": black, "repeats": reps, "generic": generic, "mutations": np.asarray(t.mutations()).tolist(),
                      "likelihood": [float(x) for x in t.likelihood], "n_contigs": [int(x) for x in t.n_contigs],
                      "dist": [float(x) for x in t.dist],
                      "final_id_c": ora.gpu_vect_frags["id_c"].tolist(), "final_pos": ora.gpu_vect_frags["pos"].tolist(),

@@ -15,11 +15,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = json.load(open(os.path.join(HERE, "golden", "traces.json")))
 
 
-def test_oracle_reproduces_the_committed_trace():
+@pytest.mark.parametrize("name", ["repeats", "generic_coordinates"])
+def test_oracle_reproduces_the_committed_trace(name):
     from oracle import oracle as O
-    g = GOLD["repeats"]
-    P = problem(g["n_sub"], g["seed"], g["n_bins"], g["nnz"], g["blacklist"], g["repeats"])
-    ora = O.OracleSampler(P, np.random.RandomState(g["seed"]), fix_trans_accu=True)
+    g = GOLD[name]
+    P = problem(g["n_sub"], g["seed"], g["n_bins"], g["nnz"], g["blacklist"], g["repeats"], g.get("generic", False))
+    ora = O.OracleSampler(P, np.random.RandomState(g["seed"]), fix_trans_accu=not g.get("generic", False))
     t = em.run_em(ora, g["cycles"], g["neighbours"], rng=ora.rng)
     assert np.asarray(t.mutations()).tolist() == g["mutations"]
     assert np.allclose(t.likelihood, g["likelihood"], rtol=1e-9, atol=0)
@@ -31,7 +32,7 @@ def test_oracle_reproduces_the_committed_trace():
 def test_engine_reproduces_the_committed_trace(name):
     from tests.test_sampler_gpu import make_gpu_sampler
     g = GOLD[name]
-    P = problem(g["n_sub"], g["seed"], g["n_bins"], g["nnz"], g["blacklist"], g["repeats"])
+    P = problem(g["n_sub"], g["seed"], g["n_bins"], g["nnz"], g["blacklist"], g["repeats"], g.get("generic", False))
     rng = np.random.RandomState(g["seed"])
     s = make_gpu_sampler(P, rng)
     t = em.run_em(s, g["cycles"], g["neighbours"], rng=rng)

@@ -104,6 +104,62 @@ def test_strict_deltas_match_the_reference_arithmetic(n_sub, seed, p_circ):
     assert worst <= 2e-9
 
 
+def _strict_deltas_on(P, states, n_props, K, seed, tol=2e-9):
+    """Strict candidate deltas of n_props proposals per layout against the reference-arithmetic oracle; the worst |error| / |logL|
+    and the last step's counters."""
+    dense = ref_dense(P)
+    rng = np.random.RandomState(seed)
+    n = P["n_frags"]
+    worst, c = 0.0, None
+    for s in states:
+        max_id = relabel_ref(s)
+        e = engine_for(P, s)
+        e.set_mode(ref_trans_accu=True, strict=True)
+        assert e.relabel_contigs() == max_id
+        for _ in range(n_props):
+            fA = int(rng.randint(n))
+            fBs = sorted(int(v) for v in rng.choice(np.setdiff1d(np.arange(n), [fA]), K, replace=False))
+            base, want = ref_deltas(P, dense, s, fA, fBs, max_id)
+            got = e.eval_candidates(fA, fBs, max_id)
+            err = np.abs(got - want).max() / abs(base)
+            assert err <= tol, (fA, fBs, err)
+            worst = max(worst, err)
+        c = e.last_counters()
+        e.close()
+    return worst, c
+
+
+def _zero_based(P):
+    s = O.copy_state(P["S_o_A_frags"])
+    s["id_c"][:] -= 1
+    return s
+
+
+@pytest.mark.timeout(1500)
+def test_strict_deltas_at_the_c3_like_shape():
+    """Reference arithmetic -- the sampler's default -- against the oracle run the reference's way (fix_trans_accu=False) at the
+    T. reesei level-3 stand-in's shape: 3,500 bins x 3 sub-fragments on GENERIC bp lengths with RF counts 1..9, contigs of up to
+    ~730 bins (the union-set kernels: several tiles per global piece, hundreds of units per step; kernels3.cu:3259-3718)."""
+    P = ref_problem(3500, 600_000, 2015, contig_weights=synth.C5_CONTIG_WEIGHTS, mean_len_bp=660.0, fact=200.0, v_inter=0.02)
+    rng = np.random.RandomState(5)
+    states = [_zero_based(P), random_state_for(P, rng, n_contigs=7, p_circ=0.4)]
+    worst, counters = _strict_deltas_on(P, states, n_props=2, K=3, seed=6)
+    print("strict deltas, C3-like shape: worst |error| / |logL| = %.3e, queued contacts %d, units %d" % (worst, counters[2], counters[1]))
+    assert counters[2] > 1000 and counters[1] > 0
+
+
+@pytest.mark.timeout(1500)
+def test_strict_deltas_with_ten_neighbours_and_sub_fragments():
+    """K = 10 (the reference's n_neighbors cap, cuda_lib_gl.py:444) in one pass, sub-fragments with RF counts 1..9, generic coordinates,
+    the C2 stand-in's shape: the union of up to 11 contigs, up to 33 global pieces, 130 candidates per piece pair."""
+    P = ref_problem(1086, 120_000, 2017, contig_weights=synth.C5_CONTIG_WEIGHTS, mean_len_bp=660.0, fact=200.0, v_inter=0.02)
+    rng = np.random.RandomState(7)
+    states = [_zero_based(P), random_state_for(P, rng, n_contigs=12, p_circ=0.3)]
+    worst, counters = _strict_deltas_on(P, states, n_props=2, K=10, seed=8)
+    print("strict deltas, K = 10 at the C2 shape: worst |error| / |logL| = %.3e" % worst)
+    assert counters[1] > 0
+
+
 def _samplers(P, seed, mode):
     from tests.test_sampler_gpu import make_gpu_sampler
     ora = O.OracleSampler(P, np.random.RandomState(seed), fix_trans_accu=False)
@@ -134,6 +190,26 @@ def test_strict_trace_is_bit_exact_on_generic_coordinates(n_sub, seed, n_bins, n
     ora, g, gpu_rng = _samplers(P, seed, "strict")
     t_ref = em.run_em(ora, 2, delta, rng=ora.rng)
     t_gpu = em.run_em(g, 2, delta, rng=gpu_rng)
+    assert np.array_equal(t_gpu.mutations(), t_ref.mutations())
+    assert t_gpu.n_contigs == t_ref.n_contigs and t_gpu.dist == t_ref.dist
+    assert np.allclose(t_gpu.likelihood, t_ref.likelihood, rtol=1e-8, atol=0)
+    g.gpu_vect_frags.copy_from_gpu()
+    for k in O.FIELDS:
+        assert np.array_equal(getattr(g.gpu_vect_frags, k), ora.gpu_vect_frags[k]), k
+    g.free_gpu()
+
+
+@pytest.mark.timeout(1500)
+def test_c2_shape_strict_trace_from_the_exploded_genome():
+    """400 steps of start_EM at the C2 stand-in's shape from the EXPLODED genome (main_gl.py:219: every run starts there), generic bp
+    lengths and RF counts 1..9, reference arithmetic against the oracle run the reference's way: accepted moves, contig counts, genome
+    distance and layout bit for bit.  (From its 7 original contigs: the next test.)"""
+    P = ref_problem(1086, 120_000, 2016, contig_weights=synth.C5_CONTIG_WEIGHTS, mean_len_bp=660.0, fact=200.0, v_inter=0.02)
+    n_steps = 400
+    ora, g, gpu_rng = _samplers(P, 33, "strict")
+    t_ref = _run(ora, ora.rng, 3, n_steps, scrambled=True)
+    t_gpu = _run(g, gpu_rng, 3, n_steps, scrambled=True)
+    assert len(t_gpu.id_fA) == len(t_ref.id_fA) == n_steps
     assert np.array_equal(t_gpu.mutations(), t_ref.mutations())
     assert t_gpu.n_contigs == t_ref.n_contigs and t_gpu.dist == t_ref.dist
     assert np.allclose(t_gpu.likelihood, t_ref.likelihood, rtol=1e-8, atol=0)
