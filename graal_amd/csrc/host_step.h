@@ -7,7 +7,8 @@
 // caller passes the address of its numpy MT19937 state (`RandomState._bit_generator.ctypes.state_address`: uint32 key[624],
 // int pos), which is advanced in place exactly as RandomState.random_sample would.  Anything unusual (probabilities that do not
 // sum to one, no candidate, a temperature other than 1) is NOT handled here: the call returns GRAAL_STEP_FALLBACK before any
-// draw and the Python path takes the step.  tests/test_host_logic.py compares values AND generator state with the Python
+// draw and the Python path takes the step; a score vector the selection does not judge itself comes back as GRAAL_STEP_SELECT --
+// neighbours drawn, scores valid, the selection (and its draw) left to the caller.  tests/test_host_logic.py compares values AND generator state with the Python
 // path (and so, transitively, with numpy itself).
 
 namespace {
@@ -87,7 +88,10 @@ struct HostStep {
     std::vector<int> nnz_row;        // entries != 0 per row
     std::vector<int> id_d, disp, coll;
     std::vector<unsigned char> is_dup, black;
+    bool trace = getenv("GRAAL_STEP_TRACE") != nullptr;      // debug: one line per proposal / selection on stderr
+    bool force_select = getenv("GRAAL_STEP_FORCE_SELECT") != nullptr;   // test hook: every selection is handed back (GRAAL_STEP_SELECT)
     // between begin and finish
+    bool paused = false;             // graal_step returned GRAAL_STEP_PAUSED: graal_step_finish is due (and nothing else)
     int fA = -1, max_id = 0;
     std::vector<int> nb;
     long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -188,7 +192,7 @@ static bool hs_neighbours(HostStep& S, MtState* mt, int fA, int delta0, std::vec
 // (nothing drawn).  score: n values.
 static int hs_select(MtState* mt, const double* score, int n, int n_tmp)
 {
-    if (n < 1 || n > MAXK * N_OPS * 8) return -1;
+    if (n < 1 || n > 128 * N_OPS) return -1;   // (graal_step takes up to 128 neighbours)
     int id_max = 0;
     bool any_nan = false;
     double mn = score[0];
@@ -226,14 +230,15 @@ static int hs_select(MtState* mt, const double* score, int n, int n_tmp)
     const double tot = cdf[m - 1];
     if (!(fabs(tot - 1.0) < 1e-9)) return -1;
     for (long i = 0; i < m; i++) cdf[i] /= tot;
+    const MtState keep = *mt;
     const double u = mt_double(mt);
     long idx = (long)(std::upper_bound(cdf.begin(), cdf.end(), u) - cdf.begin());
-    if (idx >= m) return -1;
+    if (idx >= m) { *mt = keep; return -1; }   // (cannot happen -- cdf[m - 1] is 1 -- but -1 promises that nothing was drawn)
     return ids[(size_t)idx];
 }
 
 // second half of a step: score the candidates of the neighbours drawn by graal_step, sample, commit.  Returns GRAAL_STEP_DONE,
-// GRAAL_STEP_FALLBACK or 16 + a GRAAL_E_* code (error codes 1 and 2 must not be taken for PAUSED / FALLBACK)
+// GRAAL_STEP_SELECT or 16 + a GRAAL_E_* code (error codes 1 .. 3 must not be taken for PAUSED / FALLBACK / SELECT)
 #define CK16(call) do { const hipError_t e16_ = (call); if (e16_ != hipSuccess) { h->err = hipGetErrorString(e16_); return 16 + GRAAL_E_HIP; } } while (0)
 static int hs_finish(graal_ctx* h, MtState* mt, double likelihood_t, int want_dist, graal_step_out* out, bool deferred = false,
                      bool full_inside = false)
@@ -241,7 +246,9 @@ static int hs_finish(graal_ctx* h, MtState* mt, double likelihood_t, int want_di
     if (!h->hs) return 16 + fail(h, GRAAL_E_STATE, "graal_upload_proposal_tables first");
     HostStep& S = *h->hs;
     const int K = (int)S.nb.size();
+    S.paused = false;                                  // (whatever happens below, the step is no longer waiting for graal_step_finish)
     if (K < 1 || K > 128) return 16 + fail(h, GRAAL_E_STATE, "graal_step_finish: no step in progress");
+    struct Drop { HostStep& s; bool keep = false; ~Drop() { if (!keep) s.nb.clear(); } } drop{S};   // an error leaves no stale proposal behind
     if (full_inside) {
         // the step's total is due for a full re-evaluation (the reference re-evaluates every step, cuda_lib_gl.py:1828-1848): its kernels
         // go out on a stream of their own, behind the relabel, and run NEXT TO the scoring kernels -- which are latency, not throughput
@@ -276,10 +283,11 @@ static int hs_finish(graal_ctx* h, MtState* mt, double likelihood_t, int want_di
     }
     const double t3 = S.timing ? hs_now() : 0.0;
     const int pos_before = mt->pos;
-    const int pick = hs_select(mt, out->scores, K * N_OPS, N_OPS);
-    if (getenv("GRAAL_STEP_TRACE")) fprintf(stderr, "[step] fA %d K %d deferred %d pick %d mt.pos %d -> %d max_id %d seq %lld spin_ok %d\n", S.fA, K, (int)deferred, pick, pos_before, mt->pos, S.max_id, h->seq, (int)h->spin_ok);
+    const int pick = S.force_select ? -1 : hs_select(mt, out->scores, K * N_OPS, N_OPS);
+    if (S.trace) fprintf(stderr, "[step] fA %d K %d deferred %d pick %d mt.pos %d -> %d max_id %d seq %lld spin_ok %d\n", S.fA, K, (int)deferred, pick, pos_before, mt->pos, S.max_id, h->seq, (int)h->spin_ok);
     const double t4 = S.timing ? hs_now() : 0.0;
-    if (pick < 0) return GRAAL_STEP_FALLBACK;   // (the scores are in out->scores; nothing was drawn for the selection)
+    if (pick < 0) return GRAAL_STEP_SELECT;   // (the neighbours were drawn and the scores are in out->scores; nothing was drawn for the selection:
+                                              // the caller selects and commits.  NOT GRAAL_STEP_FALLBACK, which promises that nothing was drawn at all)
     out->sample_out = pick;
     out->id_f_sampled = S.nb[pick / N_OPS];
     out->op_sampled = pick % N_OPS;
@@ -289,8 +297,7 @@ static int hs_finish(graal_ctx* h, MtState* mt, double likelihood_t, int want_di
     if (S.timing && deferred) { S.t_acc[2] += t2 - S.t_mark; S.t_acc[3] += t3 - t2; S.t_acc[4] += t4 - t3; S.t_acc[5] += hs_now() - t4; S.t_n += 1; }
     out->dist_half_units = 0;
     if (want_dist) { rc = graal_genome_distance(h, &out->dist_half_units); if (rc) return 16 + rc; }
-    S.nb.clear();
-    return GRAAL_STEP_DONE;
+    return GRAAL_STEP_DONE;   // (the proposal is dropped with `drop`)
 }
 
 /* One MCMC step of step_max_likelihood (cuda_lib_gl.py:1793-1980) for a fragment that is not blacklisted: relabel + statistics,
@@ -311,6 +318,8 @@ int graal_step(graal_ctx* h, void* mt_state, int32_t fA, int32_t delta, double l
     if (fA < 0 || fA >= S.n || S.n != h->n) return 16 + fail(h, GRAAL_E_ARG, "graal_step: fA out of range");
     MtState* mt = (MtState*)mt_state;
     if (mt->pos < 0 || mt->pos > 624) return 16 + fail(h, GRAAL_E_ARG, "graal_step: not an MT19937 state");
+    S.paused = false;
+    if (S.black[fA]) { S.nb.clear(); return GRAAL_STEP_FALLBACK; }   // nothing is proposed for a blacklisted fragment (cuda_lib_gl.py:1962-1978): the caller's branch
     const double t0 = S.timing ? hs_now() : 0.0;
     const bool defer = (flags & 3) == 0;
     int rc = h->begin_launched ? GRAAL_OK : begin_step_launch(h, defer);
@@ -320,7 +329,7 @@ int graal_step(graal_ctx* h, void* mt_state, int32_t fA, int32_t delta, double l
     MtState keep = *mt;
     if (!hs_neighbours(S, mt, fA, delta, S.nb) || S.nb.empty() || S.nb.size() > 128) { *mt = keep; S.nb.clear(); return GRAAL_STEP_FALLBACK; }
     std::sort(S.nb.begin(), S.nb.end());
-    if (getenv("GRAAL_STEP_TRACE")) fprintf(stderr, "[step] fA %d proposal drawn: mt.pos %d -> %d, %d neighbours, first %d\n", fA, keep.pos, mt->pos, (int)S.nb.size(), S.nb[0]);
+    if (S.trace) fprintf(stderr, "[step] fA %d proposal drawn: mt.pos %d -> %d, %d neighbours, first %d\n", fA, keep.pos, mt->pos, (int)S.nb.size(), S.nb[0]);
     S.fA = fA;
     out->n_neighbours = (int32_t)S.nb.size();
     for (size_t i = 0; i < S.nb.size(); i++) out->neighbours[i] = S.nb[i];
@@ -337,6 +346,7 @@ int graal_step(graal_ctx* h, void* mt_state, int32_t fA, int32_t delta, double l
     if ((flags & 2) || ((flags & 1) && (out->stats[6] != 0 || prev_circ != 0))) {
         // a full re-evaluation is due: inside the step (flag 8; one rank, whose sums are the whole likelihood) or by the caller
         if ((flags & 8) && !h->x_host) return hs_finish(h, mt, likelihood_t, (flags & 4) != 0, out, false, true);
+        S.paused = true;
         return GRAAL_STEP_PAUSED;
     }
     return hs_finish(h, mt, likelihood_t, (flags & 4) != 0, out);
@@ -345,7 +355,10 @@ int graal_step(graal_ctx* h, void* mt_state, int32_t fA, int32_t delta, double l
 int graal_step_finish(graal_ctx* h, void* mt_state, double likelihood_t, int32_t flags, graal_step_out* out)
 {
     if (!h || !mt_state || !out) return 16 + GRAAL_E_ARG;
-    return hs_finish(h, (MtState*)mt_state, likelihood_t, (flags & 4) != 0, out);
+    if (!h->hs || !h->hs->paused) return 16 + fail(h, GRAAL_E_STATE, "graal_step_finish: no paused step (graal_step did not return GRAAL_STEP_PAUSED)");
+    MtState* mt = (MtState*)mt_state;
+    if (mt->pos < 0 || mt->pos > 624) return 16 + fail(h, GRAAL_E_ARG, "graal_step_finish: not an MT19937 state");
+    return hs_finish(h, mt, likelihood_t, (flags & 4) != 0, out);
 }
 
 /* A run of MCMC steps in one call (the inner loop of start_EM, cuda_lib_gl.py:2196-2220: one step_max_likelihood per fragment of the

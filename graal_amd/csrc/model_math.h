@@ -13,7 +13,9 @@
 #include <hip/hip_runtime.h>
 
 // ln x for a finite NORMAL double x > 0 (every positive float32, subnormals included, converts to one):
-// x = m 2^e with m in [sqrt(1/2), sqrt(2)), ln m = 2 atanh(s), s = (m - 1) / (m + 1), |s| <= 0.1716; ~4 ulp of double.
+// x = m 2^e with m in [sqrt(1/2), sqrt(2)), ln m = 2 atanh(s), s = (m - 1) / (m + 1), |s| <= 0.1716.  Accurate to ~4 ulp of DOUBLE (not
+// correctly rounded in double: the reference takes the float64 log of a float32 expected value, kernels3.cu:191-210, and this agrees with
+// any libm's to a few 1e-16 relative -- far inside what a float64 sum over contacts resolves).
 __device__ __forceinline__ double mm_ln_pos(double x)
 {
     const long long bits = __double_as_longlong(x);
@@ -38,7 +40,9 @@ __device__ __forceinline__ double mm_ln_pos(double x)
     return fma((double)e, 0.6931471805599453094, lnm);
 }
 
-// e^t for |t| < 700: t = n ln 2 + r, |r| <= 0.3466, Taylor polynomial of degree 11 (next term below 2e-16), scaled by 2^n
+// e^t for |t| <= 800 (the callers clamp to that): t = n ln 2 + r, |r| <= 0.3466, Taylor polynomial of degree 11 (next term below 2e-16),
+// scaled by 2^n.  Beyond |t| ~ 709 the double result saturates through ldexp -- +inf, or 0 / a subnormal -- which is what the callers want:
+// they round to float32, where e^800 is +inf and e^-800 is 0 anyway.
 __device__ __forceinline__ double mm_exp(double t)
 {
     const double n = rint(t * 1.4426950408889634074);
@@ -91,6 +95,8 @@ __device__ __forceinline__ float mm_powf_pos(float x, float y)
 
 // powf(x, y), correctly rounded, for x > 0.  x = 0 and x = +inf give powf's limits; a negative base or a NaN gives NaN (powf
 // allows negative bases with integer exponents: the model has none -- distances, the Kuhn length).  Overflow -> +inf, underflow -> 0.
+// One deviation from C's powf: powf(1, NaN) is 1 there and NaN here (y != y wins) -- the model's exponents are parameters that
+// graal_set_params has checked to be finite, so it cannot occur.
 __device__ __forceinline__ float mm_powf(float x, float y)
 {
     const bool ok = x > 0.0f && x < __builtin_inff();

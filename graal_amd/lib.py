@@ -31,7 +31,7 @@ SYMBOLS = ("graal_abi_version", "graal_create", "graal_destroy", "graal_last_err
            "graal_eval_candidates", "graal_exchange_bytes", "graal_attach_exchange", "graal_eval_candidates_x", "graal_exchange_selftest", "graal_detach_exchange", "graal_upload_distance_ref", "graal_genome_distance", "graal_apply_move", "graal_set_finisher", "graal_set_mode", "graal_set_timing", "graal_last_timing", "graal_scan_times", "graal_time_scan", "graal_last_counters",
            "graal_upload_proposal_tables", "graal_step", "graal_step_finish", "graal_steps", "graal_host_np_sum", "graal_host_select_move", "graal_host_neighbours")
 
-STEP_DONE, STEP_PAUSED, STEP_FALLBACK = 0, 1, 2
+STEP_DONE, STEP_PAUSED, STEP_FALLBACK, STEP_SELECT = 0, 1, 2, 3
 STEPS_ROW = 10   # GRAAL_STEPS_ROW: doubles per step in graal_steps' rows
 
 
@@ -380,7 +380,7 @@ class Engine:
         self.step_scores = np.frombuffer(self.step_out, dtype=np.float64, count=128 * N_OPS, offset=StepOut.scores.offset)
 
     def step(self, mt_addr, fA, delta, likelihood_t, flags, prev_circ):
-        """graal_step: STEP_DONE / STEP_PAUSED / STEP_FALLBACK; results in self.step_out"""
+        """graal_step: STEP_DONE / STEP_PAUSED / STEP_FALLBACK / STEP_SELECT; results in self.step_out"""
         rc = self._L.graal_step(self._h, mt_addr, fA, delta, likelihood_t, flags, prev_circ, self._step_ref)
         if rc >= 16:
             self._ck(rc - 16, "graal_step")

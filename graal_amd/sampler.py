@@ -26,7 +26,7 @@ import numpy as np
 
 from . import dist as gdist
 from .gpustruct import GPUStruct
-from .lib import FIELDS, MAX_NEIGHBOURS, N_OPS, Q_FULL_BAD, Q_SCALE, STEP_DONE, STEP_FALLBACK, STEP_PAUSED, Engine
+from .lib import FIELDS, MAX_NEIGHBOURS, N_OPS, Q_FULL_BAD, Q_SCALE, STEP_DONE, STEP_FALLBACK, STEP_PAUSED, STEP_SELECT, Engine
 
 N_TMP_STRUCT = N_OPS  # cuda_lib_gl.py:112
 MODIFICATION_STR = ['eject frag', 'flip frag',
@@ -806,7 +806,8 @@ class sampler(object):
         self.last_neighbours = list(so.neighbours[:K])
         self.score = e.step_scores[:K * self.n_tmp_struct]
         max_id = np.int32(so.max_id)
-        if rc == STEP_FALLBACK:                                    # an unusual score vector: numpy judges (and raises) itself
+        if rc == STEP_SELECT:                                      # an unusual score vector: numpy judges (and raises) itself -- the
+                                                                   # neighbours are drawn and scored, only the selection is left
             sample_out, o = select_move(self.score, self.n_tmp_struct, self.rng, F_t)
             id_f_sampled = self.last_neighbours[sample_out // self.n_tmp_struct]
             op_sampled = sample_out % self.n_tmp_struct

@@ -213,7 +213,7 @@ typedef struct graal_step_out {
     double full_likelihood;  /* flag 8: the full likelihood of the layout the step started from, re-evaluated inside the step */
 } graal_step_out;
 
-enum { GRAAL_STEP_DONE = 0, GRAAL_STEP_PAUSED = 1, GRAAL_STEP_FALLBACK = 2 /* 16 + GRAAL_E_*: error */ };
+enum { GRAAL_STEP_DONE = 0, GRAAL_STEP_PAUSED = 1, GRAAL_STEP_FALLBACK = 2, GRAAL_STEP_SELECT = 3 /* 16 + GRAAL_E_*: error */ };
 
 /* setup_distri_frags' tables (cuda_lib_gl.py:2363-2390): xk[n_bins][k], pk[n_bins][k] (float32); id_d[n_frags] (fragment ->
  * bin), frag_dispatcher / collector_id_repeats, one flag per bin (repeated) and per fragment (blacklisted) */
@@ -225,8 +225,10 @@ int graal_upload_proposal_tables(graal_ctx* h, const int32_t* xk, const float* p
  * flags: 1 = pause after the proposal if circular contigs exist now or did at the previous step (`prev_circ`); 2 = pause
  * always; 4 = genome distance; 8 = instead of pausing, re-evaluate the full likelihood INSIDE the step, next to the scoring
  * kernels (out->full_likelihood replaces `likelihood_t`; one rank only -- with an exchange attached the step pauses as before).  Returns GRAAL_STEP_DONE, GRAAL_STEP_PAUSED (the caller refreshes its total and calls
- * graal_step_finish), GRAAL_STEP_FALLBACK (an unusual case numpy itself has to judge: nothing drawn, nothing committed; after
- * graal_step_finish: out->scores are valid, the selection is the caller's) or 16 + an error code. */
+ * graal_step_finish -- valid only then), GRAAL_STEP_FALLBACK (a blacklisted fragment, or an unusual proposal numpy itself has to judge:
+ * NOTHING drawn from the generator, nothing committed: take the step through the individual entry points), GRAAL_STEP_SELECT (the
+ * neighbours are drawn and out->neighbours / out->scores / out->stats / out->max_id [/ out->full_likelihood] valid, but the selection
+ * is left to the caller -- nothing drawn for it, nothing committed: select, then graal_apply_move) or 16 + an error code. */
 int graal_step(graal_ctx* h, void* mt_state, int32_t fA, int32_t delta, double likelihood_t, int32_t flags, int32_t prev_circ,
                graal_step_out* out);
 int graal_step_finish(graal_ctx* h, void* mt_state, double likelihood_t, int32_t flags, graal_step_out* out);

@@ -299,6 +299,39 @@ def test_c_step_equals_python_step_and_survives_its_fallbacks(monkeypatch):
         assert got[4] == want[4] and np.array_equal(got[5], want[5]), (env, fin)
 
 
+@pytest.mark.parametrize("n_sub,seed", [(1, 55), (3, 56)])
+def test_selection_handed_back_by_the_c_step_keeps_the_generator_stream(monkeypatch, n_sub, seed):
+    """GRAAL_STEP_SELECT: graal_step has drawn the neighbours and scored them, but leaves the selection to the caller (a score vector
+    hs_select does not judge itself; forced here for EVERY step by the test hook GRAAL_STEP_FORCE_SELECT).  The caller must select
+    and commit WITHOUT drawing the neighbours again -- the return code used to be GRAAL_STEP_FALLBACK ("nothing drawn"), the Python
+    path redid the step and the generator stream silently left the reference's.  Trace, likelihood series and generator state must
+    equal the pure Python path's -- one step at a time and through graal_steps; with sub-fragments the step carries a full
+    re-evaluation inside (flag 8), whose value must survive the hand-over too."""
+    P = problem(n_sub, seed, 120, 4000)
+
+    def go(env, batched):
+        for k in ("GRAAL_PY_STEP", "GRAAL_STEP_FORCE_SELECT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        rng = np.random.RandomState(seed)
+        g = make_gpu_sampler(P, rng)
+        t = em.run_em(g, 2, 4, rng=rng, on_step=None if batched else (lambda j, i, tr: None))
+        st = rng.get_state(legacy=False)["state"]
+        out = (np.asarray(t.mutations()), list(t.likelihood), list(t.n_contigs), int(st["pos"]), st["key"].copy())
+        used_c = g._c_step
+        g.free_gpu()
+        return out, used_c
+    want, used_c = go({"GRAAL_PY_STEP": "1"}, False)
+    assert not used_c
+    for batched in (False, True):
+        got, used_c = go({"GRAAL_STEP_FORCE_SELECT": "1"}, batched)
+        assert used_c
+        assert np.array_equal(got[0], want[0]), batched
+        assert got[1] == want[1] and got[2] == want[2], batched
+        assert got[3] == want[3] and np.array_equal(got[4], want[4]), batched
+
+
 def test_runs_of_steps_in_one_call_equal_single_steps():
     """sampler.steps_max_likelihood (graal_steps: a run of MCMC steps behind the C ABI in one call, em.run_em's path) against one
     step_max_likelihood call per step (run_em with a per-step callback): traces, likelihood series, statistics, final layout and
