@@ -47,6 +47,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+# VALU issue ceiling the late stage's kernel is priced against: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction -- what one
+# wave's stream sustains on a SIMD (MI355X_MICROARCH.md, constants table: `v_fma_f32` 4 cycles for one wave alone, 2 with several waves
+# per SIMD for single-rate float32 / integer instructions; the kernel's mix is half float64 FMAs)
+VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 4
 
 
 def build_sampler(P, rng, group, device, arithmetic="strict"):
@@ -216,6 +220,8 @@ def main():
                                                       "the multi-rank code path with several ranks on ONE GPU)")
     ap.add_argument("--layout", choices=("exploded", "original"), default="exploded",
                     help="exploded (+ MCMC warm-up) is the BASELINE workload; original = the 7 reference contigs (late-stage regime)")
+    ap.add_argument("--late-only", action="store_true", help="only the late stage's reference-arithmetic scoring steps (what profiles/valu_late.json is profiled on)")
+    ap.add_argument("--late-repeats", type=int, default=1, help="--late-only: run the timed steps this many times")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / sharding check without a GPU (CPU test-suite)")
     args = ap.parse_args()
 
@@ -261,6 +267,27 @@ def main():
             td.init_process_group(args.backend, timeout=tmo)
     group = gdist.Group(rank, world)
 
+    def sync_all():
+        group.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        return float(t.cpu()[0])
+
+    def timed_region(sm, pr, mid, n_steps):
+        nc = 0
+        sync_all()
+        tt = time.perf_counter()
+        for f, nb in pr[:n_steps]:
+            sm._candidate_deltas(f, nb, mid)
+            nc += 13 * len(nb)
+        sync_all()
+        return nc, max_over_ranks(time.perf_counter() - tt)
+
     def phase(msg):   # (diagnostics: GRAAL_BENCH_PHASES=1 prints where the run is)
         if os.environ.get("GRAAL_BENCH_PHASES"):
             print("[bench %.2f s] %s" % (time.perf_counter(), msg), file=sys.stderr, flush=True)
@@ -271,6 +298,106 @@ def main():
     if args.layout == "exploded":
         P["S_o_A_frags"] = exploded_layout(P)
     t_gen = time.perf_counter() - t_gen
+    n = args.n_bins
+    K = args.neighbours
+    other = "exact" if args.arithmetic == "strict" else "strict"
+
+    def set_arithmetic(sm, which):
+        sm.engine.set_mode(ref_trans_accu=which == "strict", strict=which == "strict")
+
+    def run_late(strict_only=False, repeats=1):
+        """The same map in its LATE stage (the 7 original contigs of 2.7-6.8k fragments): scoring phase in both arithmetics, the VALU
+        roofline of the reference-arithmetic kernel (k_strict2), a full MCMC step, a full evaluation."""
+        P2 = dict(P)
+        P2["S_o_A_frags"] = soa_original
+        rng2 = np.random.RandomState(20141217)
+        smp2 = build_sampler(P2, rng2, group, local if world > 1 else 0, args.arithmetic)
+        smp2.init_likelihood()
+        max_id2 = smp2.modify_gl_cuda_buffer(0)
+        props2 = []
+        for f in rng2.randint(0, n, size=3 + 12):
+            nb = smp2.return_neighbours(int(f), K)
+            nb.sort()
+            props2.append((int(f), nb))
+        st2 = smp2.engine.layout_stats()
+        late = {"workload": "same map, its %d original contigs (longest %d fragments)" % (int(st2[0]), int(st2[4]))}
+        smp2.engine.set_timing(1)     # (an event pair around k_scan and around k_strict2 on every step: a few us of a 1.5 ms step)
+        for which in ((args.arithmetic,) if strict_only else (args.arithmetic, other)):
+            set_arithmetic(smp2, which)
+            for f, nb in props2[:3]:
+                smp2._candidate_deltas(f, nb, max_id2)
+            n_timed = len(props2[3:])
+            for _ in range(max(1, repeats)):
+                n_cand2, tl = timed_region(smp2, props2[3:], max_id2, n_timed)
+            c2 = smp2.engine.last_counters()
+            blk = {"value": n_cand2 / tl, "unit": "candidate logL evals/s", "ms_per_step": 1e3 * tl / n_timed, "steps": n_timed,
+                   "queued_contacts_last_step_this_rank": int(c2[2]), "work_units_last_step_this_rank": int(c2[3])}
+            if which == "strict" and rank == 0:
+                blk["roofline"] = valu_roofline(smp2, n_timed)
+            if which == args.arithmetic:
+                late.update(blk)
+                late["arithmetic"] = which
+            else:
+                late["other_arithmetic"] = dict(blk, arithmetic=which)
+        if strict_only:
+            smp2.free_gpu()
+            return late
+        # a full MCMC step (+ the nuisance-parameter step of the reference GUI's default) in this regime
+        set_arithmetic(smp2, args.arithmetic)
+        smp2.bins = np.arange(1.0, 41.0, 1.0)
+        smp2.step_nuisance_parameters(0, 0, 1)
+        order2 = np.arange(n, dtype=np.int32)
+        rng2.shuffle(order2)
+        torch.cuda.synchronize()
+        tl = time.perf_counter()
+        for i in order2[:8]:
+            smp2.step_max_likelihood(int(i), K)
+        torch.cuda.synchronize()
+        late["full_mcmc_step_ms"] = 1e3 * (time.perf_counter() - tl) / 8
+        tl = time.perf_counter()
+        for i in order2[8:16]:
+            smp2.step_max_likelihood(int(i), K)
+            smp2.step_nuisance_parameters(0, 0, 1)
+        torch.cuda.synchronize()
+        late["full_mcmc_step_sample_param_ms"] = 1e3 * (time.perf_counter() - tl) / 8
+        smp2.engine.eval_full_q()
+        tl = time.perf_counter()
+        for _ in range(5):
+            smp2.engine.eval_full_q()
+        late["full_eval_ms"] = 1e3 * (time.perf_counter() - tl) / 5
+        smp2.free_gpu()
+        return late
+
+    def valu_roofline(sm, n_timed):
+        """VALU roofline of the reference-arithmetic kernel over the late stage's timed steps: wave instructions per launch from a committed
+        rocprofv3 --pmc SQ_INSTS_VALU pass of exactly these launches (profiles/valu_late.json, written by tools/summarize_prof.py from
+        `bench.py --late-only`) divided by the launch duration measured HERE (HIP events around the kernel on its stream); peak = 1,024
+        SIMDs x 2.4 GHz / 4 cycles per wave instruction (MI355X_MICROARCH.md)."""
+        ms = sm.engine.strict_times(n_timed)
+        dur_s = float(np.mean(ms)) * 1e-3
+        r = {"bound": "valu", "kernel": "k_strict2", "peak": VALU_PEAK_WAVE_INSTR, "unit": "wave instructions/s", "avg_launch_ms": dur_s * 1e3,
+             "launches_timed": int(len(ms)), "achieved": None, "frac": None, "wave_instr_per_launch": None}
+        vpath = os.path.join(ROOT, "profiles", "valu_late.json")
+        if os.path.exists(vpath):
+            try:
+                vj = json.load(open(vpath))
+                if vj.get("n_frags") == n and vj.get("nnz") == len(P["coo_row"]):
+                    r["wave_instr_per_launch"] = vj["wave_instr_per_launch"]
+                    r["achieved"] = vj["wave_instr_per_launch"] / dur_s
+                    r["frac"] = r["achieved"] / VALU_PEAK_WAVE_INSTR
+                    r["kernel_trace_avg_ms"] = vj.get("kernel_avg_us_rocprof", 0.0) * 1e-3
+                    r["frac_kernel_trace"] = vj["wave_instr_per_launch"] / (vj["kernel_avg_us_rocprof"] * 1e-6) / VALU_PEAK_WAVE_INSTR
+                    r["instr_source"] = "committed rocprofv3 --pmc SQ_INSTS_VALU pass of `bench.py --late-only` (profiles/valu_late.json, profiles/r04_rocprof_late.md): mean over the same launches, not measured in this run"
+            except Exception:
+                pass
+        return r
+
+    if args.late_only:   # (what tools/profile_gpu.sh profiles for late_stage.roofline: nothing but the late stage's strict scoring steps)
+        late = run_late(strict_only=True, repeats=args.late_repeats)
+        if rank == 0:
+            print(json.dumps({"late_stage": late}), flush=True)
+        return
+
     rng = np.random.RandomState(20141217)
     t_setup = time.perf_counter()
     phase("problem generated")
@@ -278,11 +405,21 @@ def main():
     t_setup = time.perf_counter() - t_setup
     phase("sampler built")
 
-    def set_arithmetic(sm, which):
-        sm.engine.set_mode(ref_trans_accu=which == "strict", strict=which == "strict")
-    other = "exact" if args.arithmetic == "strict" else "strict" 
-    n = int(smp.n_new_frags)
-    K = args.neighbours
+    assert n == int(smp.n_new_frags)
+
+    # ---- proposals for the timed regions, drawn BEFORE the MCMC warm-up (the neighbour distribution is the contact map's, not the
+    # layout's): drawn right in front of the timed region -- ~1,000 Python calls, 30 ms -- they left the GPU idle, and the first timed
+    # steps were 10 us slower than the rest (r03: 1.645 M in the driver's 20-step run against 1.754 M over 1,000).  The generator is put back
+    # where it was: the warm-up steps draw what they always drew.
+    total = args.warmup + max(args.steps, args.long_steps)
+    rng_state = rng.get_state()
+    frags = rng.randint(0, n, size=total)
+    props = []
+    for f in frags:
+        nb = smp.return_neighbours(int(f), K)
+        nb.sort()
+        props.append((int(f), nb))
+    rng.set_state(rng_state)
 
     # ---- layout: exploded genome + real MCMC warm-up steps (every rank runs the same, sharded, steps) --------
     smp.init_likelihood()
@@ -299,26 +436,6 @@ def main():
     t_mcmc = time.perf_counter() - t_mcmc
     stats = smp.engine.layout_stats()
     max_id = smp.modify_gl_cuda_buffer(0)
-
-    # ---- proposals for the timed region, drawn beforehand ---------------------------------------------------------
-    total = args.warmup + max(args.steps, args.long_steps)
-    frags = rng.randint(0, n, size=total)
-    props = []
-    for f in frags:
-        nb = smp.return_neighbours(int(f), K)
-        nb.sort()
-        props.append((int(f), nb))
-
-    def sync_all():
-        group.barrier()
-        torch.cuda.synchronize()
-
-    def max_over_ranks(x):
-        if world == 1:
-            return x
-        t = torch.tensor([x], dtype=torch.float64, device="cuda")
-        td.all_reduce(t, op=td.ReduceOp.MAX)
-        return float(t.cpu()[0])
 
     # The timed region carries a HIP event pair around k_scan on every 8th step only (a pair costs the step ~10-25 us of
     # command-processor marker gaps: 64 us per step with a pair on every step against 40 without, profiles/r02_event_sampling.log);
@@ -353,16 +470,6 @@ def main():
     scan_ms = np.concatenate([smp.engine.scan_times(n2), scan_ms_timed])
     smp.engine.set_timing(EVENT_EVERY)
     counters = smp.engine.last_counters()
-    def timed_region(sm, pr, mid, n_steps):
-        nc = 0
-        sync_all()
-        tt = time.perf_counter()
-        for f, nb in pr[:n_steps]:
-            sm._candidate_deltas(f, nb, mid)
-            nc += 13 * len(nb)
-        sync_all()
-        return nc, max_over_ranks(time.perf_counter() - tt)
-
     # SURVEY 8d's region: 1,000 steps (the driver's 20 steps last under a millisecond)
     long_region = None
     if args.long_steps > 0:
@@ -439,56 +546,7 @@ def main():
     late = None
     if args.layout == "exploded" and not args.no_late_stage:
         try:
-            P2 = dict(P)
-            P2["S_o_A_frags"] = soa_original
-            rng2 = np.random.RandomState(20141217)
-            smp2 = build_sampler(P2, rng2, group, local if world > 1 else 0, args.arithmetic)
-            smp2.init_likelihood()
-            max_id2 = smp2.modify_gl_cuda_buffer(0)
-            props2 = []
-            for f in rng2.randint(0, n, size=3 + 12):
-                nb = smp2.return_neighbours(int(f), K)
-                nb.sort()
-                props2.append((int(f), nb))
-            st2 = smp2.engine.layout_stats()
-            late = {"workload": "same map, its %d original contigs (longest %d fragments)" % (int(st2[0]), int(st2[4]))}
-            for which in (args.arithmetic, other):
-                set_arithmetic(smp2, which)
-                for f, nb in props2[:3]:
-                    smp2._candidate_deltas(f, nb, max_id2)
-                n_cand2, tl = timed_region(smp2, props2[3:], max_id2, len(props2[3:]))
-                c2 = smp2.engine.last_counters()
-                blk = {"value": n_cand2 / tl, "unit": "candidate logL evals/s", "ms_per_step": 1e3 * tl / len(props2[3:]), "steps": len(props2[3:]),
-                       "queued_contacts_last_step_this_rank": int(c2[2]), "work_units_last_step_this_rank": int(c2[3])}
-                if which == args.arithmetic:
-                    late.update(blk)
-                    late["arithmetic"] = which
-                else:
-                    late["other_arithmetic"] = dict(blk, arithmetic=which)
-            # a full MCMC step (+ the nuisance-parameter step of the reference GUI's default) in this regime
-            set_arithmetic(smp2, args.arithmetic)
-            smp2.bins = np.arange(1.0, 41.0, 1.0)
-            smp2.step_nuisance_parameters(0, 0, 1)
-            order2 = np.arange(n, dtype=np.int32)
-            rng2.shuffle(order2)
-            torch.cuda.synchronize()
-            tl = time.perf_counter()
-            for i in order2[:8]:
-                smp2.step_max_likelihood(int(i), K)
-            torch.cuda.synchronize()
-            late["full_mcmc_step_ms"] = 1e3 * (time.perf_counter() - tl) / 8
-            tl = time.perf_counter()
-            for i in order2[8:16]:
-                smp2.step_max_likelihood(int(i), K)
-                smp2.step_nuisance_parameters(0, 0, 1)
-            torch.cuda.synchronize()
-            late["full_mcmc_step_sample_param_ms"] = 1e3 * (time.perf_counter() - tl) / 8
-            smp2.engine.eval_full_q()
-            tl = time.perf_counter()
-            for _ in range(5):
-                smp2.engine.eval_full_q()
-            late["full_eval_ms"] = 1e3 * (time.perf_counter() - tl) / 5
-            smp2.free_gpu()
+            late = run_late()
         except Exception as e:   # an extra must not cost the headline line (a rank that fails alone makes the others' next
             late = {"error": repr(e)}   # collective time out after 300 s: they land here too)
 

@@ -4052,6 +4052,9 @@ struct Ctx {
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> ring; // pairs of events around k_scan, one pair per call (graal_scan_times)
     long long ring_calls = 0;
+    std::vector<hipEvent_t> sring; // pairs of events around the tiled reference-arithmetic kernel of a call (k_strict2 / k_strict; graal_strict_times)
+    long long sring_calls = 0;
+    bool ev_this_call = false;     // the evaluation being launched carries the event pairs
     bool timing_valid = false;
     bool scan_ready = false;
     bool publish = false;         // k_post publishes the sums to pinned host memory (synchronous single-GPU path)
@@ -4528,9 +4531,12 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
         CK(hipGetLastError());
         CK(hipEventRecord(h->ev_tm, h->aux));      // (behind k_tm and k_gprep: tables, classes and unit list complete -- nobody spins for them)
         CK(hipStreamWaitEvent(st, h->ev_tm, 0));
+        const size_t sslot = (size_t)(h->sring_calls % (long long)(h->sring.size() / 2));
+        if (h->ev_this_call) CK(hipEventRecord(h->sring[2 * sslot], st));   // (behind the wait: the pair spans the kernel, not the scan in front of it)
         if (h->single_sub) k_strict2<false><<<blocks, 256, 0, st>>>(fa, sx, s2, K, h->d_slist, h->d_slist_n, d_q_out, publish ? h->res_dev : nullptr, h->seq);
         else k_strict2<true><<<blocks, 256, 0, st>>>(fa, sx, s2, K, h->d_slist, h->d_slist_n, d_q_out, publish ? h->res_dev : nullptr, h->seq);
         CK(hipGetLastError());
+        if (h->ev_this_call) { CK(hipEventRecord(h->sring[2 * sslot + 1], st)); h->sring_calls += 1; }
         return GRAAL_OK;
     }
     // the unit list holds at most K * nt (nt + 1) / 2 entries, nt = tiles of the two longest contigs (grow-only)
@@ -4691,6 +4697,8 @@ int graal_create(int device, graal_ctx** out)
     for (auto& ev : h->ev) CK(hipEventCreate(&ev));
     h->ring.resize(2 * 1024, nullptr);
     for (auto& ev : h->ring) CK(hipEventCreate(&ev));
+    h->sring.resize(2 * 256, nullptr);
+    for (auto& ev : h->sring) CK(hipEventCreate(&ev));
     CK(hipMalloc(&h->d_scalars, 32 * sizeof(long long)));
     CK(hipMemset(h->d_scalars, 0, 32 * sizeof(long long)));
     CK(hipMalloc(&h->d_acc, MAXK * N_OPS * sizeof(long long)));
@@ -4759,6 +4767,7 @@ void graal_destroy(graal_ctx* h)
         if (h->h_dist) (void)hipHostFree(h->h_dist);
         for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
         for (auto& ev : h->ring) if (ev) (void)hipEventDestroy(ev);
+        for (auto& ev : h->sring) if (ev) (void)hipEventDestroy(ev);
         if (h->ev_fin) (void)hipEventDestroy(h->ev_fin);
         if (h->ev_relabel) (void)hipEventDestroy(h->ev_relabel);
         if (h->ev_tm) (void)hipEventDestroy(h->ev_tm);
@@ -5404,6 +5413,7 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     // (the event that orders a chip-filling k_fin / the strict kernels behind k_tm is recorded where they are launched)
     // (2) the streaming pass, with a HIP event pair around it on every event_every-th call
     const bool ev = h->want_events && (h->eval_calls % h->event_every == 0);
+    h->ev_this_call = ev;
     h->eval_calls += 1;
     const size_t slot = (size_t)(h->ring_calls % (long long)(h->ring.size() / 2));
     if (ev) CK(hipEventRecord(h->ring[2 * slot], st));
@@ -5755,6 +5765,20 @@ int graal_scan_times(graal_ctx* h, int32_t n, float* out_ms)
         const size_t slot = (size_t)((h->ring_calls - n + i) % cap);
         CK(hipEventSynchronize(h->ring[2 * slot + 1]));
         CK(hipEventElapsedTime(&out_ms[i], h->ring[2 * slot], h->ring[2 * slot + 1]));
+    }
+    return GRAAL_OK;
+}
+
+int graal_strict_times(graal_ctx* h, int32_t n, float* out_ms)
+{
+    if (!h || !out_ms || n < 1) return GRAAL_E_ARG;
+    const long long cap = (long long)(h->sring.size() / 2);
+    if (h->sring_calls < n || n > cap) return fail(h, GRAAL_E_STATE, "not enough timed launches of the tiled reference-arithmetic kernel");
+    CK(hipSetDevice(h->device));
+    for (int i = 0; i < n; i++) {
+        const size_t slot = (size_t)((h->sring_calls - n + i) % cap);
+        CK(hipEventSynchronize(h->sring[2 * slot + 1]));
+        CK(hipEventElapsedTime(&out_ms[i], h->sring[2 * slot], h->sring[2 * slot + 1]));
     }
     return GRAAL_OK;
 }

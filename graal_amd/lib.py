@@ -11,7 +11,7 @@ import numpy as np
 from . import build as _build
 
 N_OPS = 13
-ABI_VERSION = 5
+ABI_VERSION = 6
 MODE_REF_TRANS_ACCU, MODE_STRICT = 1, 2
 MAX_NEIGHBOURS = 10
 Q_SCALE = float(1 << 30)
@@ -28,7 +28,7 @@ _f64p = ctypes.POINTER(ctypes.c_double)
 SYMBOLS = ("graal_abi_version", "graal_create", "graal_destroy", "graal_last_error", "graal_set_params",
            "graal_upload_subfrags", "graal_upload_repeats", "graal_upload_contacts", "graal_upload_contacts_f32", "graal_upload_frags", "graal_download_frags",
            "graal_relabel_contigs", "graal_begin_step", "graal_begin_step_launch", "graal_layout_stats", "graal_eval_full_q", "graal_eval_candidates_q",
-           "graal_eval_candidates", "graal_exchange_bytes", "graal_attach_exchange", "graal_eval_candidates_x", "graal_exchange_selftest", "graal_detach_exchange", "graal_upload_distance_ref", "graal_genome_distance", "graal_apply_move", "graal_set_finisher", "graal_set_mode", "graal_set_timing", "graal_last_timing", "graal_scan_times", "graal_time_scan", "graal_last_counters",
+           "graal_eval_candidates", "graal_exchange_bytes", "graal_attach_exchange", "graal_eval_candidates_x", "graal_exchange_selftest", "graal_detach_exchange", "graal_upload_distance_ref", "graal_genome_distance", "graal_apply_move", "graal_set_finisher", "graal_set_mode", "graal_set_timing", "graal_last_timing", "graal_scan_times", "graal_strict_times", "graal_time_scan", "graal_last_counters",
            "graal_upload_proposal_tables", "graal_step", "graal_step_finish", "graal_steps", "graal_host_np_sum", "graal_host_select_move", "graal_host_neighbours")
 
 STEP_DONE, STEP_PAUSED, STEP_FALLBACK, STEP_SELECT = 0, 1, 2, 3
@@ -96,6 +96,7 @@ def load():
         L.graal_set_finisher.argtypes = [ctypes.c_void_p, ctypes.c_int32]
         L.graal_set_mode.argtypes = [ctypes.c_void_p, ctypes.c_int32]
         L.graal_scan_times.argtypes = [ctypes.c_void_p, ctypes.c_int32, _f32p]
+        L.graal_strict_times.argtypes = [ctypes.c_void_p, ctypes.c_int32, _f32p]
         L.graal_time_scan.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, _f32p]
         _u8p = ctypes.POINTER(ctypes.c_uint8)
         L.graal_upload_proposal_tables.argtypes = [ctypes.c_void_p, _i32p, _f32p, ctypes.c_int32, ctypes.c_int32, _i32p, ctypes.c_int32,
@@ -425,6 +426,12 @@ class Engine:
         """k_scan durations (ms) of the last n candidate evaluations (HIP event pairs recorded around each launch)."""
         t = np.zeros(int(n), dtype=np.float32)
         self._ck(self._L.graal_scan_times(self._h, int(n), t.ctypes.data_as(_f32p)), "graal_scan_times")
+        return t
+
+    def strict_times(self, n):
+        """Durations (ms) of the tiled reference-arithmetic kernel (k_strict2) in the last n evaluations that carried an event pair."""
+        t = np.zeros(int(n), dtype=np.float32)
+        self._ck(self._L.graal_strict_times(self._h, int(n), t.ctypes.data_as(_f32p)), "graal_strict_times")
         return t
 
     def time_scan(self, K, reps=50):

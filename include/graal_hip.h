@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GRAAL_ABI_VERSION 5
+#define GRAAL_ABI_VERSION 6
 #define GRAAL_N_OPS 13        /* candidates per (fA, fB): cuda_lib_gl.py:112 n_tmp_struct */
 #define GRAAL_MAX_NEIGHBOURS 10 /* neighbours scored by one scan pass (the reference proposes at most n_neighbors = 10, cuda_lib_gl.py:444) */
 #define GRAAL_Q_BITS 30
@@ -181,6 +181,9 @@ int graal_set_timing(graal_ctx* h, int32_t enabled);
  * from rocprofv3).  graal_scan_times returns the last n calls (a ring of 1024 event pairs). */
 int graal_last_timing(graal_ctx* h, float out[4]);
 int graal_scan_times(graal_ctx* h, int32_t n, float* out_ms);
+/* the same for the tiled reference-arithmetic kernel (k_strict2) of the last n calls that launched it with an event pair (a ring of 256
+ * pairs): the duration that prices its VALU roofline (bench.py: late_stage.roofline) */
+int graal_strict_times(graal_ctx* h, int32_t n, float* out_ms);
 /* reps < 0: MEDIAN duration of -reps ISOLATED replays (an event pair around each launch, the device idle in between: what a launch
  * costs on its own, without the other kernels of a step).  reps > 0:
  * average duration (ms) of the streaming scan kernel over `reps` back-to-back replays of the last call's scan between

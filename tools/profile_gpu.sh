@@ -3,7 +3,7 @@
 # counters do not fit one pass, MI355X_MICROARCH.md "rocprofv3 PMC slots") of one workload.
 # Usage: tools/profile_gpu.sh <tag> [c5|late|c2]     -> gpurun_out/prof_<tag>/summary_<tag>.{md,json}
 #   c5   : the bench workload (C5 exploded + 2,000 warm-up steps), 100 timed steps
-#   late : C5 on its 7 original contigs (bench.py --layout original), 30 timed steps
+#   late : C5 on its 7 original contigs, the late stage's reference-arithmetic scoring steps of bench.py (--late-only): 3 + 3 x 12 steps
 #   c4   : the C4 stand-in (40,000 bins, 8 M contacts), explode + 2 cycles of a headless run (PROF_TRACE_ONLY=1: kernel trace only)
 #   c2   : the C2 stand-in (1,086 bins x 3 sub-fragments) on its 7 contigs, 400 full MCMC steps (tools/step_breakdown.py)
 set -u
@@ -15,7 +15,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 case $WHAT in
   c5)   ARGS="$REPO/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-late-stage --no-hbm-control" ;;
-  late) ARGS="$REPO/bench.py --layout original --steps 30 --warmup 5 --mcmc-warmup 0 --no-cpu-baseline --no-late-stage --no-hbm-control" ;;
+  late) ARGS="$REPO/bench.py --late-only --late-repeats 3" ;;   # exactly the launches bench.py's late_stage.roofline is quoted on (3 warm-up + 3 x 12 timed steps)
   c2)   ARGS="$REPO/tools/step_breakdown.py --n-bins 1086 --nnz 120000 --n-sub 3 --original --steps 400" ;;
   c4)   ARGS="$REPO/tools/run_configs.py C4 --cycles ${C4_CYCLES:-2}" ;;
 esac

@@ -95,6 +95,18 @@ def main():
         res["k_scan_hbm_bytes_per_launch"] = (2.0 * fetch + write) * 1024.0
         res["k_scan_fetch_size_kib"] = fetch
         res["k_scan_write_size_kib"] = write
+    # VALU roofline of every kernel with an SQ_INSTS_VALU count: wave instructions per dispatch / kernel-trace duration against
+    # 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction (bench.py: VALU_PEAK_WAVE_INSTR)
+    peak = 256 * 4 * 2.4e9 / 4
+    valu = {}
+    for k, cs in res.get("pmc_sq", {}).items():
+        if "SQ_INSTS_VALU" in cs and k in res.get("kernel_trace", {}):
+            instr, us = cs["SQ_INSTS_VALU"]["mean"], res["kernel_trace"][k]["avg_us"]
+            if us > 0:
+                valu[k] = {"wave_instr_per_launch": instr, "kernel_avg_us_rocprof": us, "launches": cs["SQ_INSTS_VALU"]["n"],
+                           "achieved_wave_instr_per_s": instr / (us * 1e-6), "peak": peak, "frac": instr / (us * 1e-6) / peak,
+                           "wait_frac": (cs["SQ_WAIT_ANY"]["mean"] / cs["SQ_WAVE_CYCLES"]["mean"]) if "SQ_WAIT_ANY" in cs and "SQ_WAVE_CYCLES" in cs and cs["SQ_WAVE_CYCLES"]["mean"] > 0 else None}
+    res["valu_roofline"] = valu
     with open(os.path.join(d, "summary_%s.json" % tag), "w") as f:
         json.dump(res, f, indent=1)
     # human readable
@@ -114,6 +126,12 @@ def main():
             f.write("\n## HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (mean of the last 100 launches)\n\n| kernel | MB |\n|---|---|\n")
             for k, v in sorted(res["hbm_bytes_per_launch"].items(), key=lambda kv: -kv[1]):
                 f.write("| %s | %.3f |\n" % (k[:70], v / 1e6))
+        if res.get("valu_roofline"):
+            f.write("\n## VALU roofline = SQ_INSTS_VALU per dispatch / kernel-trace duration / (1,024 SIMDs x 2.4 GHz / 4) (mean over all launches)\n\n"
+                    "| kernel | launches | wave instr / launch | avg us | wave instr / s | fraction of 6.14e11 | SQ_WAIT_ANY / SQ_WAVE_CYCLES |\n|---|---|---|---|---|---|---|\n")
+            for k, v in sorted(res["valu_roofline"].items(), key=lambda kv: -kv[1]["wave_instr_per_launch"] * kv[1]["launches"]):
+                f.write("| %s | %d | %.4g | %.2f | %.3g | %.3f | %s |\n" % (k[:70], v["launches"], v["wave_instr_per_launch"], v["kernel_avg_us_rocprof"],
+                                                                        v["achieved_wave_instr_per_s"], v["frac"], "%.2f" % v["wait_frac"] if v["wait_frac"] is not None else "-"))
         if "k_scan_hbm_bytes_per_launch" in res:
             f.write("\nk_scan HBM bytes / launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 = %.0f\n" % res["k_scan_hbm_bytes_per_launch"])
         if "kernel_stats_csv" in res:
