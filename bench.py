@@ -441,9 +441,18 @@ def main():
     # command-processor marker gaps: 64 us per step with a pair on every step against 40 without, profiles/r02_event_sampling.log);
     # right behind it the same steps run once more, untimed, with a pair on EVERY step (at most 64): those samples -- in-step
     # launches of the same proposals -- price the roofline, so that a 20-step run has 20 of them rather than 2.
-    # (a run of fewer than 64 steps -- the driver's 20 -- carries ONE pair in its timed region: three pairs were 2.3 us per step of it)
-    EVENT_EVERY = int(os.environ.get("GRAAL_BENCH_EVENT_EVERY", 8 if args.steps >= 64 else max(8, args.steps)))
+    # (a run of fewer than 64 steps -- the driver's 20 -- carries NO pair in its timed region: the one pair it used to carry cost a single step
+    # 100 us, a tenth of the region; its roofline samples are those of the untimed repeat, one per step)
+    EVENT_EVERY = int(os.environ.get("GRAAL_BENCH_EVENT_EVERY", 8 if args.steps >= 64 else 0))
     smp.engine.set_timing(EVENT_EVERY)
+    # (set-up, untimed: the GPU has been busy for a tenth of a second -- 2,000 warm-up steps -- since it sat idle through the problem's
+    # generation, and its clocks are still on their way up: the first 6-16 steps of a 20-step region took 50-70 us, the rest 35
+    # (GRAAL_BENCH_STEP_TIMES=1).  A quarter of a second of the same scoring steps first; then the W warm-up steps and the K timed ones.)
+    t_settle = time.perf_counter()
+    settle_s = float(os.environ.get("GRAAL_BENCH_SETTLE_S", 0.25))
+    while time.perf_counter() - t_settle < settle_s:
+        for f, nb in props[args.warmup:args.warmup + 64]:
+            smp._candidate_deltas(f, nb, max_id)
     for f, nb in props[:args.warmup]:
         smp._candidate_deltas(f, nb, max_id)
     n_cand = 0
@@ -459,7 +468,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if step_t is not None and rank == 0:
         print("per-step us:", " ".join("%.1f" % (1e6 * (b - a)) for a, b in zip([t0] + step_t[:-1], step_t)), file=sys.stderr)
-    n_timed_pairs = min(args.steps // EVENT_EVERY, 1024)
+    n_timed_pairs = min(args.steps // EVENT_EVERY, 1024) if EVENT_EVERY > 0 else 0
     scan_ms_timed = smp.engine.scan_times(n_timed_pairs) if n_timed_pairs else np.zeros(0, np.float32)   # pairs of the timed region
     elapsed = max_over_ranks(elapsed)
     n2 = min(args.steps, 64)
@@ -468,7 +477,7 @@ def main():
         smp._candidate_deltas(f, nb, max_id)
     sync_all()
     scan_ms = np.concatenate([smp.engine.scan_times(n2), scan_ms_timed])
-    smp.engine.set_timing(EVENT_EVERY)
+    smp.engine.set_timing(EVENT_EVERY if EVENT_EVERY > 0 else 8)
     counters = smp.engine.last_counters()
     # SURVEY 8d's region: 1,000 steps (the driver's 20 steps last under a millisecond)
     long_region = None
