@@ -193,10 +193,16 @@ __device__ __forceinline__ float ex_pair(const End& X, const Stat& sx, int slx, 
 // running int64 sums hold +-8.6e9 log-likelihood units) gives Q_BAD: the caller flags the candidate (nf_flag) and the host
 // reports NaN for it -- the reference's evaluate_likelihood_double would have produced -inf / NaN there (kernels3.cu:191-210).
 constexpr long long Q_BAD = (long long)0x8000000000000000ull;
-constexpr long long Q_NAN = 1ll << 59;   // handed out instead of a flagged candidate sum; |q| >= 2^58 on the host means NaN
-                                         // (a legitimate candidate delta is far below 2^58 / 2^30 = 2.7e8 log-likelihood units;
-                                         // the sum of <= 8 ranks' values stays below 2^63).  The full likelihood (whose Q value
-                                         // may legitimately exceed 2^58) is flagged by the exact value INT64_MIN instead
+constexpr long long Q_NAN = Q_BAD;       // handed out instead of a flagged candidate sum: the EXACT value INT64_MIN (like the full likelihood's flag).  A
+                                         // legitimate sum may be anything else -- a hopeless candidate's -8.6e8 log-likelihood units are -9.2e17 in Q30, beyond
+                                         // the 2^58 that used to stand for NaN; ranks' values are summed with the marker sticky (eval_sync), and the device
+                                         // buffer of the RCCL path carries the flags as counts of their own (hand_out), which an all-reduce can sum
+// a candidate's value from its two sums (the host's conversion everywhere): NaN if flagged, else coarse + fine / 2^30
+static inline double q_value(long long q, long long c)
+{
+    if (q == Q_NAN) return (double)NAN;
+    return c == 0 ? (double)q / Q_SCALE : (double)c + (double)q / Q_SCALE;
+}
 constexpr int NF_OFF = 14;               // counters[NF_OFF .. NF_OFF + 2]: bit (k * 13 + op) = that candidate met a bad term
 __device__ __forceinline__ long long to_q(double v) { return fabs(v) < 2147483648.0 ? __double2ll_rn(v * Q_SCALE) : Q_BAD; }
 // the same value in fewer instructions for the pair loops (|v| < 2^30: v = hi + lo with hi = rint(v); hi 2^30 is an even integer, so rounding
@@ -217,6 +223,26 @@ __device__ __forceinline__ void nf_flag_ops(unsigned long long* nf, int k, unsig
 {
     while (ops) { nf_flag(nf, k, __ffs((int)ops) - 1); ops &= ops - 1; }
 }
+
+// A term that does not fit Q30 (|v| >= 2^31 log-likelihood units) but is finite: the reference adds it into its float64 sum like any
+// other (kernels3.cu:191-210, 3703-3717) and reports a finite, hopeless score -- a circular contig closing over bp-sized fragments prices a
+// pair at > 2e9 under C5's parameters.  Such terms are rounded to whole units (relative error < 2.4e-10) and summed in a SECOND int64
+// per candidate (acc[MAXK * N_OPS + candidate], "coarse"), order independent like the first; the candidate's value is coarse + fine / 2^30.
+// They are rare: added with one device-scope atomic each, where they turn up.  NaN / inf / |v| >= 2^62 still flag the candidate.
+__device__ __forceinline__ bool to_coarse(double v, long long& c)
+{
+    if (!(fabs(v) < 4611686018427387904.0)) return false;
+    c = __double2ll_rn(v);
+    return true;
+}
+// candidates `ops` (13-bit mask) of neighbour k += v, coarse; or flag them
+__device__ __forceinline__ void coarse_add_ops(long long* __restrict__ acc, unsigned long long* __restrict__ nf, int k, unsigned ops, double v)
+{
+    long long c;
+    if (!to_coarse(v, c)) { nf_flag_ops(nf, k, ops); return; }
+    while (ops) { const int b = __ffs((int)ops) - 1; ops &= ops - 1; atomicAdd((unsigned long long*)&acc[MAXK * N_OPS + k * N_OPS + b], (unsigned long long)c); }
+}
+
 
 // The same with the reference's own accu indexing in the TRANS branch (kernels3.cu:3155 / 3638): when the bin with the LOWER
 // id of the pixel ("fi" = min, kernels3.cu:2884-2888 / 3364-3365) is reversed, every one of its slots is priced with the RF count
@@ -240,9 +266,9 @@ __device__ __forceinline__ float ex_pair_ref(const End& X, const Stat& sx, int s
 // priced from the float32 coordinates of their layout (kernels3.cu:3383-3697 against the stored evaluate_likelihood value),
 // rounded to Q once per fragment pair.  X0 / Y0: the two fragments in the current layout, X / Y: under the candidate.
 __device__ __forceinline__ long long strict_pair_q(const End& X0, const End& Y0, const End& X, const End& Y, const Stat& sx, int fx,
-                                                   const Stat& sy, int fy, float nfpb, const Par& par, bool quirk)
+                                                   const Stat& sy, int fy, float nfpb, const Par& par, bool quirk, double& acc)
 {
-    double acc = 0.0;
+    acc = 0.0;
 #pragma unroll
     for (int a = 0; a < 3; a++)
 #pragma unroll
@@ -1887,6 +1913,9 @@ __global__ void k_ln_tab(double* __restrict__ tab, int n, float nfpb, Par par)
     if (p < n) tab[p] = mm_ln(par.v_inter * ((float)p / nfpb));
 }
 
+constexpr int X_SLOT_WORDS = 512;         // exchange slot: sequence word + MAXK*13 sums [+ a word of k_strict_flat]; from word X_COARSE the coarse sums; 4 KB
+constexpr int X_COARSE = 256;
+static_assert(2 + MAXK * N_OPS <= X_COARSE && X_COARSE + MAXK * N_OPS < X_SLOT_WORDS, "exchange slot too small");
 // the last block of a step: read the K*13 sums, reset the accumulators and counters for the next step, hand the sums
 // out -- to d_q_out (device; the caller all-reduces them) or to PINNED HOST memory followed by the step's sequence
 // number (the host spins on that word instead of paying for a device->host copy and a stream-synchronise wake-up).
@@ -1897,8 +1926,10 @@ __device__ __forceinline__ void hand_out(long long* out, unsigned long long* cou
     const bool failed = atomicAdd(&counters[6], 0ull) != 0ull;
     for (int i = threadIdx.x; i < K * N_OPS; i += TM_THREADS) {
         long long v = (long long)atomicExch((unsigned long long*)&out[i], 0ull); // read the final sum, reset for the next step
-        if ((atomicAdd(&counters[NF_OFF + (i >> 6)], 0ull) >> (i & 63)) & 1ull) v = Q_NAN; // a term was not finite / out of range
-        if (host_res) host_res[1 + i] = v; else d_q_out[i] = v;
+        const long long c = (long long)atomicExch((unsigned long long*)&out[MAXK * N_OPS + i], 0ull);   // the coarse sum (to_coarse), zero but for a rare candidate
+        const bool flagged = ((atomicAdd(&counters[NF_OFF + (i >> 6)], 0ull) >> (i & 63)) & 1ull) != 0ull; // a term was not finite / out of range
+        if (host_res) { host_res[1 + i] = flagged ? Q_NAN : v; host_res[X_COARSE + i] = c; }
+        else { d_q_out[i] = flagged ? 0ll : v; d_q_out[MAXK * N_OPS + i] = c; d_q_out[2 * MAXK * N_OPS + i] = flagged ? 1ll : 0ll; }
     }
     __syncthreads();
     if (threadIdx.x >= 4 && threadIdx.x < 7) counters[NF_OFF + threadIdx.x - 4] = 0;
@@ -1911,8 +1942,6 @@ __device__ __forceinline__ void hand_out(long long* out, unsigned long long* cou
 
 constexpr long long NEED_FIN = 1ll << 62; // published instead of the sums: k_tm left work for k_fin, launch it
 constexpr long long GAVE_UP = 1ll << 61;  // (with NEED_FIN) k_tm's last block stopped waiting for k_scan
-constexpr int X_SLOT_WORDS = 256;         // exchange slot: sequence word + MAXK*13 sums, padded to 2 KB
-static_assert(1 + MAXK * N_OPS <= X_SLOT_WORDS, "exchange slot too small");
 constexpr int FIN_INLINE_Q = 64;          // queued contacts the finishing block of k_tm prices itself
 
 // ------------------------------------------------------------------ per-step kernels
@@ -2079,9 +2108,10 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
             // beyond the window (or between two contigs) before AND after, every slot pair has the trans value both times: the
             // difference is exactly zero -- unless the reference's trans-branch RF-count indexing is on and a bin's counts differ
             if (!near_old && !near_new && !(quirk && (!stat_uniform(sx) || !stat_uniform(sy)))) continue;
-            const long long qv = strict_pair_q(X0, Y0, X, Y, sx, fx, sy, fy, nfpb, par, quirk);
+            double v;
+            const long long qv = strict_pair_q(X0, Y0, X, Y, sx, fx, sy, fy, nfpb, par, quirk, v);
             if (qv == 0) continue;
-            if (qv == Q_BAD) { nf_flag_ops(ta.counters + NF_OFF, k, ops); continue; }
+            if (qv == Q_BAD) { coarse_add_ops(ta.acc, ta.counters + NF_OFF, k, ops, v); continue; }
             unsigned o2 = ops;
             while (o2) { const int b = __ffs((int)o2) - 1; o2 &= o2 - 1; atomicAdd((unsigned long long*)&s_acc[b], (unsigned long long)qv); }
         }
@@ -3152,7 +3182,7 @@ __global__ __launch_bounds__(256) void k_strict_dense(FinArgs fa, StrictArgs sa,
                             if (a < sx.n && b < sy.n)
                                 acc += (double)exo[a][b] - (double)ex_pair_ref(X, sx, a, fx, Y, sy, b, y.frag, sa.nfpb, sa.par, sa.quirk);
                     const long long q1 = to_q(acc);
-                    if (q1 == Q_BAD) bad |= 1u << op; else accq[op] += q1;
+                    if (q1 == Q_BAD) coarse_add_ops(fa.acc, counters + NF_OFF, k, 1u << op, acc); else accq[op] += q1;
                 }
             }
 #pragma unroll
@@ -3160,8 +3190,7 @@ __global__ __launch_bounds__(256) void k_strict_dense(FinArgs fa, StrictArgs sa,
                 const long long qv = wave_sum_ll(accq[op]);
                 if (lane == 0 && qv != 0) atomicAdd((unsigned long long*)&s_accb[k * N_OPS + op], (unsigned long long)qv);
             }
-            for (int o = 32; o > 0; o >>= 1) bad |= __shfl_down(bad, o, 64);
-            if (lane == 0 && bad) nf_flag_ops(counters + NF_OFF, k, bad);
+            (void)bad;
             WAVE_LDS_SYNC();
         }
         // ---- (2) the queued contacts (k_scan queued every contact with both ends in some neighbour's affected set): 16 lanes per
@@ -3540,7 +3569,7 @@ __global__ __launch_bounds__(256) void k_strict(FinArgs fa, StrictArgs sa, int f
                             if (a < sx.n && b < sy.n) acc += (double)exo[a][b] - (double)ex_pair_ref(X, sx, a, fx, Y, sy, b, y.frag, nfpb, par, quirk);
                 } else acc += (double)exo[0][0] - (double)ex_pair_ref(X, sx, 0, fx, Y, sy, 0, y.frag, nfpb, par, quirk);
                 const long long q1 = to_q(acc);
-                if (q1 == Q_BAD) bad |= (unsigned)CMASK_(k, pr, op) | (1u << 16);
+                if (q1 == Q_BAD) coarse_add_ops(fa.acc, counters + NF_OFF, k, (unsigned)CMASK_(k, pr, op), acc);
                 else {
                     // (`op` is wave-uniform -- the loop counter -- so this is a scalar jump to one 64-bit add, not 13 selects)
                     switch (op) {
@@ -3748,7 +3777,7 @@ __global__ __launch_bounds__(256) void k_strict_flat(FinArgs fa, StrictArgs sa, 
                             acc += (double)ex_pair_ref(X0, sx, a, fx, Y0, sy, b, fy, nfpb, par, quirk) - (double)ex_pair_ref(X, sx, a, fx, Y, sy, b, fy, nfpb, par, quirk);
             } else acc += (double)ex_pair_ref(X0, sx, 0, fx, Y0, sy, 0, fy, nfpb, par, quirk) - (double)ex_pair_ref(X, sx, 0, fx, Y, sy, 0, fy, nfpb, par, quirk);
             const long long q1 = to_q(acc);
-            if (q1 == Q_BAD) nf_flag_ops(counters + NF_OFF, k, cm);
+            if (q1 == Q_BAD) coarse_add_ops(fa.acc, counters + NF_OFF, k, cm, acc);
             else if (q1 != 0) add_ops(k, cm, q1);
             STAMP_MAX(18, lane == 0);
           } else {
@@ -4701,8 +4730,8 @@ int graal_create(int device, graal_ctx** out)
     for (auto& ev : h->sring) CK(hipEventCreate(&ev));
     CK(hipMalloc(&h->d_scalars, 32 * sizeof(long long)));
     CK(hipMemset(h->d_scalars, 0, 32 * sizeof(long long)));
-    CK(hipMalloc(&h->d_acc, MAXK * N_OPS * sizeof(long long)));
-    CK(hipMemset(h->d_acc, 0, MAXK * N_OPS * sizeof(long long)));
+    CK(hipMalloc(&h->d_acc, 2 * MAXK * N_OPS * sizeof(long long)));   // (fine sums, coarse sums: to_coarse)
+    CK(hipMemset(h->d_acc, 0, 2 * MAXK * N_OPS * sizeof(long long)));
     CK(hipMalloc(&h->tm_done, MAXK * sizeof(long long)));
     CK(hipMemset(h->tm_done, 0, MAXK * sizeof(long long)));
     CK(hipMalloc(&h->d_wq, 2 * N_WQ * WQ_STRIDE * sizeof(unsigned long long)));
@@ -4714,7 +4743,7 @@ int graal_create(int device, graal_ctx** out)
     CK(hipMalloc(&h->d_flags, (size_t)MAX_SCAN_BLOCKS * FLAG_STRIDE * sizeof(unsigned)));
     CK(hipMemset(h->d_flags, 0, (size_t)MAX_SCAN_BLOCKS * FLAG_STRIDE * sizeof(unsigned)));
     if (getenv("GRAAL_EVENT_EVERY")) h->event_every = std::max(1, atoi(getenv("GRAAL_EVENT_EVERY")));
-    CK(hipMalloc(&h->d_qout, MAXK * N_OPS * sizeof(long long)));
+    CK(hipMalloc(&h->d_qout, 3 * MAXK * N_OPS * sizeof(long long)));   // (fine sums, coarse sums, not-finite flags: hand_out)
     CK(hipMalloc(&h->tabs, MAXK * sizeof(NbTables)));
     CK(hipMalloc(&h->step_hdr, 2 * MAXK * sizeof(int)));
     CK(hipMemset(h->step_hdr, 0, 2 * MAXK * sizeof(int)));
@@ -5453,7 +5482,7 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
 // synchronous evaluation: launch the step, spin on the sequence word its last block writes into pinned host memory (fall
 // back to a stream synchronise if it does not show up -- it always does unless the launch failed); q_sum[K*13] = the Q sums
 // of this rank, plus -- with an exchange attached -- those the other ranks of the node published for the same step
-static int eval_sync(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int32_t max_id, int rank, int world, long long* q_sum)
+static int eval_sync(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int32_t max_id, int rank, int world, long long* q_sum, long long* c_sum)
 {
     const long long want = h->seq + 1;
     if (world > 1) { // this rank's slot of the step's parity (two steps later the slot is reused: every rank has read it by then,
@@ -5532,15 +5561,15 @@ static int eval_sync(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int
         CK(hipMemset(h->d_scalars + 15, 0, 2 * sizeof(long long)));   // ticket, error
         CK(hipMemset(h->d_scalars + 10 + NF_OFF, 0, 3 * sizeof(long long)));
         CK(hipMemset(h->d_scalars + SLIST_N, 0, sizeof(long long)));
-        CK(hipMemset(h->d_acc, 0, MAXK * N_OPS * sizeof(long long)));
+        CK(hipMemset(h->d_acc, 0, 2 * MAXK * N_OPS * sizeof(long long)));
         CK(hipMemset(h->d_sync, 0, 32 * sizeof(unsigned long long)));
         CK(hipDeviceSynchronize());
         res[0] = 0;
-        return eval_sync(h, fA, fB, K, max_id, rank, world, q_sum);
+        return eval_sync(h, fA, fB, K, max_id, rank, world, q_sum, c_sum);
     }
     if (res[0] == -want) return fail(h, GRAAL_E_HIP, "timed out waiting for the candidate tables / the scan (a kernel of the step did not run)");
     __sync_synchronize();
-    for (int i = 0; i < K * N_OPS; i++) q_sum[i] = res[1 + i];
+    for (int i = 0; i < K * N_OPS; i++) { q_sum[i] = res[1 + i]; c_sum[i] = res[X_COARSE + i]; }
     // the other ranks' slots: their GPUs write them, this host reads them (coherent host memory; 8-byte words, the
     // sequence word last).  A rank that died leaves its word behind: give up after ~60 s instead of spinning for ever.
     for (int r = 0; r < world; r++) {
@@ -5557,7 +5586,11 @@ static int eval_sync(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int
             __builtin_ia32_pause();
         }
         __sync_synchronize();
-        for (int i = 0; i < K * N_OPS; i++) q_sum[i] += o[1 + i];
+        for (int i = 0; i < K * N_OPS; i++) {
+            const long long oq = o[1 + i];
+            q_sum[i] = (q_sum[i] == Q_NAN || oq == Q_NAN) ? Q_NAN : (long long)((unsigned long long)q_sum[i] + (unsigned long long)oq);   // (the marker is sticky)
+            c_sum[i] += o[X_COARSE + i];
+        }
     }
     return GRAAL_OK;
 }
@@ -5565,10 +5598,10 @@ static int eval_sync(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int
 int graal_eval_candidates(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int32_t max_id, double* delta)
 {
     if (!h || !delta) return GRAAL_E_ARG;
-    long long q[MAXK * N_OPS];
-    const int rc = eval_sync(h, fA, fB, K, max_id, 0, 1, q);
+    long long q[MAXK * N_OPS], c[MAXK * N_OPS];
+    const int rc = eval_sync(h, fA, fB, K, max_id, 0, 1, q, c);
     if (rc) return rc;
-    for (int i = 0; i < K * N_OPS; i++) delta[i] = llabs(q[i]) >= (Q_NAN >> 1) ? (double)NAN : (double)q[i] / Q_SCALE;
+    for (int i = 0; i < K * N_OPS; i++) delta[i] = q_value(q[i], c[i]);
     return GRAAL_OK;
 }
 
@@ -5641,14 +5674,14 @@ int graal_detach_exchange(graal_ctx* h)
     return GRAAL_OK;
 }
 
-int graal_eval_candidates_x(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int32_t max_id, int64_t* q_sum)
+int graal_eval_candidates_x(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int32_t max_id, int64_t* q_sum, int64_t* c_sum)
 {
-    if (!h || !q_sum) return GRAAL_E_ARG;
+    if (!h || !q_sum || !c_sum) return GRAAL_E_ARG;
     if (!h->x_host) return fail(h, GRAAL_E_STATE, "graal_attach_exchange first");
-    long long q[MAXK * N_OPS];
-    const int rc = eval_sync(h, fA, fB, K, max_id, h->x_rank, h->x_world, q);
+    long long q[MAXK * N_OPS], c[MAXK * N_OPS];
+    const int rc = eval_sync(h, fA, fB, K, max_id, h->x_rank, h->x_world, q, c);
     if (rc) return rc;
-    for (int i = 0; i < K * N_OPS; i++) q_sum[i] = q[i];
+    for (int i = 0; i < K * N_OPS; i++) { q_sum[i] = q[i]; c_sum[i] = c[i]; }
     return GRAAL_OK;
 }
 

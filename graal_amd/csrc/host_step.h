@@ -257,10 +257,10 @@ static int hs_finish(graal_ctx* h, MtState* mt, double likelihood_t, int want_di
         const int rc = full_launch(h, h->fstream);
         if (rc) return 16 + rc;
     }
-    long long q[128 * N_OPS];
+    long long q[128 * N_OPS], qc[128 * N_OPS];
     for (int k0 = 0; k0 < K; k0 += MAXK) {
         const int kk = std::min(MAXK, K - k0);
-        const int rc = eval_sync(h, S.fA, S.nb.data() + k0, kk, S.max_id, h->x_host ? h->x_rank : 0, h->x_host ? h->x_world : 1, q + k0 * N_OPS);
+        const int rc = eval_sync(h, S.fA, S.nb.data() + k0, kk, S.max_id, h->x_host ? h->x_rank : 0, h->x_host ? h->x_world : 1, q + k0 * N_OPS, qc + k0 * N_OPS);
         if (rc) { if (full_inside) { int64_t dump[2]; (void)full_collect(h, h->fstream, dump); } return 16 + rc; }
     }
     if (full_inside) {
@@ -272,7 +272,7 @@ static int hs_finish(graal_ctx* h, MtState* mt, double likelihood_t, int want_di
         out->full_likelihood = likelihood_t;
     }
     for (int i = 0; i < K * N_OPS; i++) {
-        const double d = llabs(q[i]) >= (Q_NAN >> 1) ? (double)NAN : (double)q[i] / Q_SCALE;
+        const double d = q_value(q[i], qc[i]);
         out->scores[i] = d + likelihood_t;
     }
     const double t2 = S.timing ? hs_now() : 0.0;

@@ -240,6 +240,23 @@ __device__ __forceinline__ void s2_add_mask(long long* __restrict__ acc, unsigne
     if ((m1 >> lane) & 1ull) atomicAdd((unsigned long long*)&acc[64 + lane], (unsigned long long)v);
     if (lane < 2 && ((m2 >> lane) & 1u)) atomicAdd((unsigned long long*)&acc[128 + lane], (unsigned long long)v);
 }
+// a term beyond Q30's range (to_coarse): into the candidates' coarse sums, or their flags -- by the lane that met it (rare)
+__device__ __forceinline__ void s2_coarse_mask(long long* __restrict__ acc, unsigned long long* __restrict__ nf, unsigned long long m0, unsigned long long m1,
+                                               unsigned m2, double v)
+{
+    long long c;
+    const bool ok = to_coarse(v, c);
+    unsigned long long mm[3] = {m0, m1, (unsigned long long)m2};
+    for (int r = 0; r < 3; r++) {
+        unsigned long long m = mm[r];
+        while (m) {
+            const int cand = 64 * r + __ffsll((long long)m) - 1;
+            m &= m - 1ull;
+            if (ok) atomicAdd((unsigned long long*)&acc[MAXK * N_OPS + cand], (unsigned long long)c);
+            else nf_flag(nf, cand / N_OPS, cand % N_OPS);
+        }
+    }
+}
 __device__ __forceinline__ void s2_flag_mask(unsigned long long* nf, unsigned long long m0, unsigned long long m1, unsigned m2, int lane)
 {
     for (int r = 0; r < 3; r++) {
@@ -445,11 +462,10 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
             S2_COUNT(5, lane == 0 ? 1 : 0);                                   // (unit, layout) passes
             S2_COUNT(6, __popc(vmask));                                      // fragment pairs priced in them
             long long accq = 0;
-            bool bad = false;
             auto add_pair = [&](int j, double acc) {   // one fragment pair of the class: rounded to Q once
                 if ((vmask >> j) & 1u) {
                     const long long q1 = to_q_fast(acc);
-                    if (q1 == Q_BAD) bad = true; else accq += q1;
+                    if (q1 == Q_BAD) s2_coarse_mask(fa.acc, counters + NF_OFF, m0, m1, m2, acc); else accq += q1;
                 }
             };
             // the same without branches for the common case (to_q_fast: |v| < 2^30 is v = hi + lo, hi = rint(v), both parts int32; summed apart,
@@ -465,7 +481,7 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
                 acc_lo += take ? (long long)il : 0ll;
                 if (__builtin_expect(big, 0)) {
                     const long long q1 = to_q(v);
-                    if (q1 == Q_BAD) bad = true; else accq += q1;
+                    if (q1 == Q_BAD) s2_coarse_mask(fa.acc, counters + NF_OFF, m0, m1, m2, v); else accq += q1;
                 }
             };
             if (!MULTI && norm_u >= 0.0f && !(quirk && !cis)) {
@@ -517,7 +533,6 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
                 const long long qs = wave_sum_ll(accq);
                 const long long v = ((long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(qs >> 32)) << 32) | (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)qs);
                 if (v != 0) s2_add_mask(s_acc, m0, m1, m2, v, lane);
-                if (__ballot(bad)) s2_flag_mask(counters + NF_OFF, m0, m1, m2, lane);
             }
             WAVE_LDS_SYNC();   // (the next pass writes the segment's centres again)
         }

@@ -120,15 +120,3 @@ class Group:
             if self.rank == 0:
                 os.unlink(path)
         return m
-
-
-Q_NAN_LIMIT = 1 << 58   # a candidate's |q| at or above this: a term of that sum was not finite / out of range (graal_hip.hip: Q_NAN)
-
-
-def q_to_float(q):
-    q = np.asarray(q, dtype=np.int64)
-    out = q.astype(np.float64) / float(1 << 30)
-    bad = np.abs(q) >= Q_NAN_LIMIT
-    if bad.any():
-        out = np.where(bad, np.nan, out)
-    return out

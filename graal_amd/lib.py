@@ -15,7 +15,25 @@ ABI_VERSION = 6
 MODE_REF_TRANS_ACCU, MODE_STRICT = 1, 2
 MAX_NEIGHBOURS = 10
 Q_SCALE = float(1 << 30)
-Q_NAN_LIMIT = 1 << 58   # a candidate's |Q| at or above this stands for NaN: a term was not finite / did not fit (graal_hip.hip: Q_NAN)
+Q_NAN = -(1 << 63)      # a candidate's Q sum EXACTLY this (INT64_MIN) stands for NaN: a term was not finite (graal_hip.hip: Q_NAN)
+
+
+def q_to_float(q, c=None, flags=None):
+    """A candidate's value from its two int64 sums (graal_hip.hip: q_value): coarse + fine / 2^30; NaN where the fine sum carries the
+    not-finite marker (or `flags` is not zero).  `c` -- zero but for a rare candidate -- holds the finite terms of 2^31 log-likelihood units and more, rounded to
+    whole units (kernels3.cu:191-210 adds such terms into its float64 sum like any other: the result must stay finite)."""
+    q = np.asarray(q, dtype=np.int64)
+    out = q.astype(np.float64) / Q_SCALE
+    if c is not None:
+        c = np.asarray(c, dtype=np.int64)
+        if c.any():
+            out = np.where(c != 0, c.astype(np.float64) + out, out)
+    bad = q == Q_NAN
+    if flags is not None:          # (the device buffer of the RCCL path: flags summed over the ranks)
+        bad = bad | (np.asarray(flags) != 0)
+    if bad.any():
+        out = np.where(bad, np.nan, out)
+    return out
 Q_FULL_BAD = -(1 << 63)  # graal_eval_full_q: q[0] == INT64_MIN exactly flags a non-finite / out-of-range term
 FIELDS = ("pos", "id_c", "start_bp", "len_bp", "circ", "id", "prev", "next", "l_cont", "l_cont_bp", "ori", "rep",
           "activ", "id_d")  # struct frag, kernels3.cu:9-24
@@ -85,7 +103,7 @@ def load():
                                             ctypes.c_int64, _i64p]
         L.graal_exchange_selftest.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32]
         L.graal_detach_exchange.argtypes = [ctypes.c_void_p]
-        L.graal_eval_candidates_x.argtypes = [ctypes.c_void_p, ctypes.c_int32, _i32p, ctypes.c_int32, ctypes.c_int32, _i64p]
+        L.graal_eval_candidates_x.argtypes = [ctypes.c_void_p, ctypes.c_int32, _i32p, ctypes.c_int32, ctypes.c_int32, _i64p, _i64p]
         L.graal_upload_distance_ref.argtypes = [ctypes.c_void_p, _i32p, _i32p, _i32p, _i32p, ctypes.POINTER(ctypes.c_uint8),
                                                 ctypes.c_int32]
         L.graal_genome_distance.argtypes = [ctypes.c_void_p, _i64p]
@@ -146,6 +164,8 @@ class Engine:
         self._delta_ptr = self._delta_buf.ctypes.data_as(_f64p)
         self._q_buf = np.zeros(MAX_NEIGHBOURS * N_OPS, dtype=np.int64)
         self._q_ptr = self._q_buf.ctypes.data_as(_i64p)
+        self._c_buf = np.zeros(MAX_NEIGHBOURS * N_OPS, dtype=np.int64)     # the coarse sums (graal_eval_candidates_x)
+        self._c_ptr = self._c_buf.ctypes.data_as(_i64p)
         self._st_buf = np.zeros(8, dtype=np.int64)
         self._st_ptr = self._st_buf.ctypes.data_as(_i64p)
         self._max_id = ctypes.c_int32(0)
@@ -342,14 +362,10 @@ class Engine:
         K = len(fB)
         if 1 <= K <= MAX_NEIGHBOURS:
             self._fb_buf[:K] = fB
-            rc = self._L.graal_eval_candidates_x(self._h, int(fA), self._fb_ptr, K, int(max_id), self._q_ptr)
+            rc = self._L.graal_eval_candidates_x(self._h, int(fA), self._fb_ptr, K, int(max_id), self._q_ptr, self._c_ptr)
             if rc != 0:
                 self._ck(rc, "graal_eval_candidates_x")
-            q = self._q_buf[:K * N_OPS]
-            out = q.astype(np.float64) / Q_SCALE
-            if (np.abs(q) >= Q_NAN_LIMIT).any():
-                out[np.abs(q) >= Q_NAN_LIMIT] = np.nan
-            return out.reshape(K, N_OPS)
+            return q_to_float(self._q_buf[:K * N_OPS], self._c_buf[:K * N_OPS]).reshape(K, N_OPS)
         fb = _c(fB, np.int32)
         out = np.zeros((len(fb), N_OPS), dtype=np.float64)
         for k0 in range(0, len(fb), MAX_NEIGHBOURS):

@@ -26,7 +26,7 @@ import numpy as np
 
 from . import dist as gdist
 from .gpustruct import GPUStruct
-from .lib import FIELDS, MAX_NEIGHBOURS, N_OPS, Q_FULL_BAD, Q_SCALE, STEP_DONE, STEP_FALLBACK, STEP_PAUSED, STEP_SELECT, Engine
+from .lib import FIELDS, MAX_NEIGHBOURS, N_OPS, Q_FULL_BAD, Q_SCALE, STEP_DONE, STEP_FALLBACK, STEP_PAUSED, STEP_SELECT, Engine, q_to_float
 
 N_TMP_STRUCT = N_OPS  # cuda_lib_gl.py:112
 MODIFICATION_STR = ['eject frag', 'flip frag',
@@ -620,7 +620,7 @@ class sampler(object):
         out = np.zeros((len(id_neighbours), N_OPS), dtype=np.float64)
         dev = torch.device("cuda", self.engine.device)
         if self._d_q is None:
-            self._d_q = torch.zeros(MAX_NEIGHBOURS * N_OPS, dtype=torch.int64, device=dev)
+            self._d_q = torch.zeros(3 * MAX_NEIGHBOURS * N_OPS, dtype=torch.int64, device=dev)   # (fine sums, coarse sums, not-finite flags: include/graal_hip.h)
             # a dedicated, non-null stream: the C ABI reads a null handle as "the engine's own stream", and the
             # collective must be ordered after the kernels that fill the buffer
             self._torch_stream = torch.cuda.Stream(device=dev)
@@ -630,8 +630,10 @@ class sampler(object):
                 self.engine.eval_candidates_q_async(id_fA, part, max_id, self._d_q.data_ptr(),
                                                     self._torch_stream.cuda_stream, self.group.rank, self.group.world)
                 self.group.all_reduce_sum_(self._d_q)
-                q = self._d_q[:len(part) * N_OPS].cpu().numpy()
-                out[k0:k0 + len(part)] = gdist.q_to_float(q).reshape(len(part), N_OPS)
+                qc = self._d_q.cpu().numpy()
+                nq = len(part) * N_OPS
+                m = MAX_NEIGHBOURS * N_OPS
+                out[k0:k0 + len(part)] = q_to_float(qc[:nq], qc[m:m + nq], qc[2 * m:2 * m + nq]).reshape(len(part), N_OPS)
         return out
 
     # ------------------------------------------------------------------ layout maintenance

@@ -105,9 +105,12 @@ int graal_eval_full_q(graal_ctx* h, int64_t q_out[2]);
 
 /* delta log-likelihood of the 13 candidates of each of K (<= GRAAL_MAX_NEIGHBOURS) neighbours fB[k]
  * of fA, over this rank's contact shard; rank / world shard the expected-mass work.
- * Writes K*13 int64 Q values to the DEVICE buffer d_q_out on `stream` (asynchronous; a NULL stream means the
- * engine's own stream, NOT the HIP default stream -- pass an explicit stream to order a collective after it): sum them over
- * ranks (one RCCL all-reduce) then divide by 2^GRAAL_Q_BITS.  max_id must be the value returned by
+ * Writes to the DEVICE buffer d_q_out -- 3 * GRAAL_MAX_NEIGHBOURS * 13 int64: the K*13 Q values at [0, K*13), their coarse
+ * companions (terms of 2^31 log-likelihood units and more, rounded to whole units; zero but for a rare candidate) at
+ * [GRAAL_MAX_NEIGHBOURS*13, ... + K*13) and at [2*GRAAL_MAX_NEIGHBOURS*13, ... + K*13) 1 for a candidate that met a term that was not
+ * finite (its Q value is then 0), else 0 -- on `stream` (asynchronous; a NULL stream means the engine's own stream, NOT the HIP
+ * default stream -- pass an explicit stream to order a collective after it): sum all three over ranks (one RCCL all-reduce of the
+ * whole buffer); a candidate's value is NaN where the flags' sum is not 0, else coarse + Q / 2^GRAAL_Q_BITS.  max_id must be the value returned by
  * graal_relabel_contigs for the current layout.
  * Replaces new_perform_modificationS + 13 x sub_compute_likelihood per neighbour
  * (cuda_lib_gl.py:2392-2546). */
@@ -136,8 +139,10 @@ int graal_attach_exchange(graal_ctx* h, void* segment, int64_t bytes, int32_t ra
  * all-reduce of graal_eval_candidates_q). */
 int graal_exchange_selftest(graal_ctx* h, int64_t tag, int32_t phase);
 int graal_detach_exchange(graal_ctx* h);
-/* synchronous, sharded: K*13 int64 Q sums over ALL ranks into a host buffer (every rank must make the same call) */
-int graal_eval_candidates_x(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int32_t max_id, int64_t* q_sum);
+/* synchronous, sharded: K*13 int64 Q sums over ALL ranks into host buffers (every rank must make the same call).  A candidate's value is
+ * c_sum + q_sum / 2^30: q_sum holds the terms below 2^31 in fixed point (2^-30), c_sum -- zero but for a rare candidate -- the larger finite
+ * ones rounded to whole log-likelihood units; q_sum == INT64_MIN exactly: a term was not finite (NaN). */
+int graal_eval_candidates_x(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int32_t max_id, int64_t* q_sum, int64_t* c_sum);
 
 /* Reference-arithmetic switches (default 0 = neither).
  * GRAAL_MODE_REF_TRANS_ACCU: trans pixels are priced with the reference's RF-count indexing of reversed bins

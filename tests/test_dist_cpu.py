@@ -107,7 +107,10 @@ def test_group_world1_needs_no_process_group():
     assert g.all_reduce_sum_(t).tolist() == [0, 1, 2, 3, 4]
     assert g.all_reduce_sum_int(7) == 7
     g.barrier()
-    assert np.array_equal(gdist.q_to_float(np.array([1 << 30, -(1 << 29)])), [1.0, -0.5])
+    from graal_amd.lib import q_to_float
+    assert np.array_equal(q_to_float(np.array([1 << 30, -(1 << 29)])), [1.0, -0.5])
+    v = q_to_float(np.array([1 << 29, -(1 << 63), 0, 5]), np.array([-3000000000, 5, 7, 0]), np.array([0, 0, 0, 2]))   # coarse + fine / 2^30; the marker / a flag wins
+    assert v[0] == -3000000000 + 0.5 and np.isnan(v[1]) and v[2] == 7.0 and np.isnan(v[3])
 
 
 def test_env_world_defaults(monkeypatch):

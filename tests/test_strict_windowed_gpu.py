@@ -47,6 +47,44 @@ def test_windowed_kernels_equal_the_dense_validation_kernel_bit_for_bit(tmp_path
         assert len(bad) == 0, (name, len(bad), bad[:5], (got[name] - want)[tuple(bad[0])])
 
 
+@pytest.mark.timeout(1500)
+def test_terms_beyond_the_fixed_point_range_stay_finite_like_the_reference():
+    """The reference accumulates in float64 (kernels3.cu:191-210, 3703-3717): a pair priced at > 2^31 log-likelihood units -- a circular
+    contig closing over bp-sized fragments under C5's `fact` -- gives a hopeless but FINITE score (-8.6e8 here), and the sampler must see
+    that score, not NaN.  The engine's Q30 sums cannot hold such a term; it goes to the candidate's coarse sum (whole units).  Against the
+    oracle run the reference's way on the case of tests/strict_cases.py that used to flag: finite wherever the oracle is finite,
+    within 1e-5 relative on the large scores (north_star's tolerance) and 2e-9 |logL| on the others."""
+    from tests.test_strict_gpu import ref_deltas
+    name, pk, cfg, n_props, K = strict_cases.CASES[5]     # (one contig of 900 bins: four of the 13 x 5 candidates close it into a circle)
+    assert pk["fact"] == 1e4
+    P = synth.with_dense(strict_cases._problem(**pk))
+    dense = O.DenseOracle(P["hic_matrix"], P["np_sub_frags_id"], P["np_sub_frags_len_bp"], P["np_sub_frags_accu"],
+                          P["frag_dispatcher"], P["collector_id_repeats"], P["n_frags"], P["mean_squared_frags_per_bin"],
+                          P["param_simu"], fix_trans_accu=not cfg["quirk"])
+    from graal_amd.lib import Engine
+    n_large = 0
+    for s, max_id, props in strict_cases.layouts_and_proposals(P, cfg, n_props, K, 1000 + 5):
+        e = Engine(0)
+        e.upload_subfrags(P["np_sub_frags_id"], P["np_sub_frags_len_bp"], P["np_sub_frags_accu"], P["init_n_sub_frags"], P["mean_squared_frags_per_bin"])
+        e.upload_contacts(P["coo_row"], P["coo_col"], P["coo_val"])
+        e.set_params(P["param_simu"])
+        e.upload_frags(s)
+        e.set_mode(ref_trans_accu=cfg["quirk"], strict=True)
+        assert e.relabel_contigs() == max_id
+        for fA, fBs in props:
+            got = e.eval_candidates(fA, fBs, max_id)
+            base, want = ref_deltas(P, dense, s, fA, fBs, max_id)
+            assert np.array_equal(np.isfinite(got), np.isfinite(want)), (fA, fBs, got[~np.isfinite(got)], want[~np.isfinite(got)])
+            big = np.abs(want) >= 1.0e8
+            n_large += int(big.sum())
+            if big.any():
+                assert np.all(np.abs(got[big] - want[big]) <= 1e-5 * np.abs(want[big])), (fA, fBs, got[big], want[big])
+            small = ~big & np.isfinite(want)
+            assert np.all(np.abs(got[small] - want[small]) <= 2e-9 * abs(base) + 1e-5 * np.abs(want[small]) * (np.abs(want[small]) > 1e6)), (fA, fBs)
+        e.close()
+    assert n_large > 0, "no candidate with a score of -1e8 and beyond: the case no longer tests the coarse sums"
+
+
 def rep_problem_ref(n_sub, seed, n_bins=40, nnz=900, dup=(7, 21), n_copies=2):
     """Repeated bins on generic coordinates with non-uniform RF counts: what the reference arithmetic is sensitive to."""
     par = synth.make_param_simu(fact=300.0, v_inter=0.03)
