@@ -1942,6 +1942,7 @@ __device__ __forceinline__ void hand_out(long long* out, unsigned long long* cou
 
 constexpr long long NEED_FIN = 1ll << 62; // published instead of the sums: k_tm left work for k_fin, launch it
 constexpr long long GAVE_UP = 1ll << 61;  // (with NEED_FIN) k_tm's last block stopped waiting for k_scan
+constexpr long long NEED_GEOM = 1ll << 60; // (with NEED_FIN) ... because a neighbour's set is beyond k_tm's own pricing: the layout says so, every rank sees the same
 constexpr int FIN_INLINE_Q = 64;          // queued contacts the finishing block of k_tm prices itself
 
 // ------------------------------------------------------------------ per-step kernels
@@ -2200,7 +2201,7 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
         // some neighbour's work is left to k_fin / k_strict whatever the scan finds: say so AT ONCE -- the host's launches then
         // queue up behind the scan on its stream while it is still running, instead of starting their trip when it has ended
         // (contigs of 20-100 bins, the middle of a run: ~10 us of a 130 us step)
-        if (t == 0) { ta.sync[0] = 0; __threadfence_system(); ta.host_res[0] = seq | NEED_FIN; __threadfence_system(); }
+        if (t == 0) { ta.sync[0] = 0; __threadfence_system(); ta.host_res[0] = seq | NEED_FIN | NEED_GEOM; __threadfence_system(); }
         return;
     }
     {   // all blocks of k_scan done?  Every thread polls its share of the flags, for a bounded TIME: when the two kernels
@@ -3659,7 +3660,7 @@ __global__ __launch_bounds__(256) void k_strict(FinArgs fa, StrictArgs sa, int f
 constexpr long long FLAT_CAP_PAIRS = 40000;     // x 13 class slots = 520 k lanes = ~11 rounds of the grid
 constexpr int FLAT_BLOCKS = 192;                // < 256 CUs: blocks that wait for k_tm can never keep it off the chip
 template <bool MULTI>
-__global__ __launch_bounds__(256) void k_strict_flat(FinArgs fa, StrictArgs sa, int fA, Neigh nb, int K, long long* __restrict__ d_q_out,
+__global__ __launch_bounds__(256) void k_strict_flat(FinArgs fa, StrictArgs sa, int fA, Neigh nb, int K, int rank, int world, long long* __restrict__ d_q_out,
                                                       volatile long long* host_res, long long seq)
 {
     const NbTables* __restrict__ tabs = fa.tabs;
@@ -3735,6 +3736,8 @@ __global__ __launch_bounds__(256) void k_strict_flat(FinArgs fa, StrictArgs sa, 
             // ---- (1) lane = (fragment pair of a neighbour's set, class slot)
             const long long it = it0;
             if (it >= total_pairs * N_OPS) continue;
+            if ((int)((it0 >> 6) % (long long)world) != rank) continue;   // the pairs' lanes are dealt to the ranks wave by wave (the queued contacts are
+                                                                          // this rank's own: its shard of the list)
             const long long pi = it / N_OPS;
             const int op = (int)(it - pi * N_OPS);
             int k = 0;
@@ -3819,7 +3822,7 @@ __global__ __launch_bounds__(256) void k_strict_flat(FinArgs fa, StrictArgs sa, 
         for (int c = 0; c < STRICT_ACC_COPIES; c++) v += s_accb[c][i];
         if (v != 0) atomicAdd((unsigned long long*)&fa.acc[i], (unsigned long long)v);
     }
-    if (t == 255 && blockIdx.x == 0 && ok && !too_big) atomicAdd(&counters[1], (unsigned long long)total_pairs);
+    if (t == 255 && blockIdx.x == 0 && ok && !too_big && rank == 0) atomicAdd(&counters[1], (unsigned long long)total_pairs);
     ATOMICS_DONE();
     __syncthreads();
     if (t == 0) {
@@ -3835,7 +3838,13 @@ __global__ __launch_bounds__(256) void k_strict_flat(FinArgs fa, StrictArgs sa, 
     }
     // (was this kernel needed at all?  The host keeps a running mean of the answer and lets k_tm finish the steps by itself again
     // when it is mostly "no": eval_sync)
-    if (t == 0 && host_res) host_res[1 + MAXK * N_OPS] = (total_pairs > 0 || nq_total > (unsigned long long)FIN_INLINE_Q) ? 1 : 0;
+    // (bit 1: what the sets' geometry alone says -- some set is beyond what k_tm prices itself -- the same on every rank: with an exchange
+    // attached the ranks must switch between the two flows together, see eval_sync)
+    if (t == 0 && host_res) {
+        long long big = 0;
+        for (int k = 0; k < K; k++) big += s_sg[k].m > STRICT_INLINE_M ? 1 : 0;
+        host_res[1 + MAXK * N_OPS] = ((total_pairs > 0 || nq_total > (unsigned long long)FIN_INLINE_Q) ? 1 : 0) | (big ? 2 : 0);
+    }
     hand_out(fa.acc, counters, fa.sync, K, d_q_out, host_res, seq);
     STAMP(20, t == 0);
 #undef XF_
@@ -4178,7 +4187,7 @@ struct Ctx {
     // reference arithmetic, one rank: `mid_run` = k_strict_flat goes out behind every scan and k_tm's last block does not try to
     // finish the step (set while most steps need more than k_tm: need_ema, a running mean of "this step did"); flat_tried = this
     // step's flat kernel has been launched (if it also says NEED_FIN, the tiled kernels follow)
-    bool mid_run = false, flat_tried = false, step_needed_fin = false;
+    bool mid_run = false, flat_tried = false, step_needed_fin = false, step_needed_geom = false;
     double need_ema = 0.0;
     bool eval_timing = getenv("GRAAL_EVAL_TIMING") != nullptr;
     double et[6] = {0, 0, 0, 0, 0, 0};
@@ -4615,7 +4624,7 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
 }
 
 // reference arithmetic, small affected sets (k_strict_flat): behind the scan on its stream, no event, no unit list
-int launch_flat(Ctx* h, int fA, const Neigh* nbp /* nullptr: the neighbours of the evaluation in flight */, int K, long long* d_q_out, bool publish, hipStream_t st)
+int launch_flat(Ctx* h, int fA, const Neigh* nbp /* nullptr: the neighbours of the evaluation in flight */, int K, int rank, int world, long long* d_q_out, bool publish, hipStream_t st)
 {
     FinArgs fa;
     fa.tm_done = h->tm_done; fa.step_hdr = h->step_hdr; fa.counters = (unsigned long long*)(h->d_scalars + 10); fa.queue = h->queue;
@@ -4632,18 +4641,20 @@ int launch_flat(Ctx* h, int fA, const Neigh* nbp /* nullptr: the neighbours of t
     const int blocks = blocks_env > 0 ? std::min(blocks_env, FLAT_BLOCKS) : FLAT_BLOCKS;
     Neigh nb;
     for (int k = 0; k < MAXK; k++) nb.fB[k] = nbp ? nbp->fB[k] : h->last_fB[k];
-    if (h->single_sub) k_strict_flat<false><<<blocks, 256, 0, st>>>(fa, sx, fA, nb, K, d_q_out, publish ? h->res_dev : nullptr, h->seq);
-    else k_strict_flat<true><<<blocks, 256, 0, st>>>(fa, sx, fA, nb, K, d_q_out, publish ? h->res_dev : nullptr, h->seq);
+    if (h->single_sub) k_strict_flat<false><<<blocks, 256, 0, st>>>(fa, sx, fA, nb, K, rank, world, d_q_out, publish ? h->res_dev : nullptr, h->seq);
+    else k_strict_flat<true><<<blocks, 256, 0, st>>>(fa, sx, fA, nb, K, rank, world, d_q_out, publish ? h->res_dev : nullptr, h->seq);
     CK(hipGetLastError());
     return GRAAL_OK;
 }
 
-// may this evaluation use k_strict_flat?  One rank only: the flat and the tiled kernels deal the pairs to the ranks differently, and a
-// rank picks the one or the other by what ITS k_tm / k_scan found
+// may this evaluation use k_strict_flat?  With several ranks (an exchange attached) too: the flat and the tiled kernels deal the fragment
+// pairs to the ranks differently, so every rank must pick the same one -- and it does: the choice between them is the sets' geometry
+// (k_tm says at once that a set is beyond its own pricing, k_strict_flat that the pairs are too many), the same on every rank; what a
+// rank's own scan found -- its shard's queued contacts -- only decides WHO prices those contacts, which are that rank's alone
 bool flat_allowed(const Ctx* h, int world)
 {
     static const bool no_flat = getenv("GRAAL_NO_FLAT") != nullptr;
-    return !no_flat && (h->mode & GRAAL_MODE_STRICT) && !strict_dense_cfg() && world == 1 && h->publish;
+    return !no_flat && (h->mode & GRAAL_MODE_STRICT) && !strict_dense_cfg() && (world == 1 || h->x_host != nullptr) && h->publish;
 }
 
 } // namespace
@@ -5366,6 +5377,41 @@ static int full_collect(graal_ctx* h, hipStream_t fs, int64_t q_out[2])
     return GRAAL_OK;
 }
 
+// The full likelihood of a sharded contact list inside graal_step (flag 8): every rank has evaluated its shard (q[0]: the contacts' part,
+// rounded term by term: an integer sum, the same for any sharding) and the whole mass part (q[1], computed by every rank alike).  The
+// ranks' q[0] are summed through spare words of the exchange slots -- written and read by the HOSTS (the segment is shared memory),
+// tagged with the sequence number of the step's last candidate evaluation, which every rank has published by now; a slot is written
+// again two steps later, when every rank has read it (the argument of eval_sync).  Q_BAD (a term was not finite) is sticky.
+constexpr int X_FULL = 400;   // slot words [X_FULL] = q[0], [X_FULL + 1] = tag
+static_assert(X_COARSE + MAXK * N_OPS <= X_FULL && X_FULL + 2 < X_SLOT_WORDS - 1, "exchange slot layout");
+static int full_exchange(graal_ctx* h, int64_t q[2])
+{
+    const long long tag = h->seq;
+    const size_t world = (size_t)h->x_world, par = (size_t)(tag & 1);
+    volatile long long* mine = h->x_host + (par * world + (size_t)h->x_rank) * X_SLOT_WORDS;
+    mine[X_FULL] = q[0];
+    __sync_synchronize();
+    mine[X_FULL + 1] = tag;
+    __sync_synchronize();
+    long long sum = q[0];
+    for (int r = 0; r < h->x_world; r++) {
+        if (r == h->x_rank) continue;
+        volatile long long* o = h->x_host + (par * world + (size_t)r) * X_SLOT_WORDS;
+        const auto t0 = std::chrono::steady_clock::now();
+        long long spin = 0;
+        while (o[X_FULL + 1] != tag) {
+            if ((++spin & 0xfffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60))
+                return fail(h, GRAAL_E_STATE, "exchange: another rank did not publish its full likelihood within 60 s (ranks out of step, or a rank died)");
+            __builtin_ia32_pause();
+        }
+        __sync_synchronize();
+        const long long oq = o[X_FULL];
+        sum = (sum == Q_BAD || oq == Q_BAD) ? Q_BAD : (long long)((unsigned long long)sum + (unsigned long long)oq);
+    }
+    q[0] = sum;
+    return GRAAL_OK;
+}
+
 int graal_eval_full_q(graal_ctx* h, int64_t q_out[2])
 {
     if (!h || !q_out) return GRAAL_E_ARG;
@@ -5419,7 +5465,10 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     // (late stage -- a few long contigs hold nearly every fragment: nearly every step needs k_fin anyway, so it is launched
     // right behind the scan instead of after k_tm's verdict has made the round trip through the host, ~10 us per step)
     const bool late_stage = h->max_lcont > 128 && (long long)h->n_contigs * 64 < (long long)h->n;
-    const bool mid = flat_allowed(h, world) && h->mid_run && !late_stage && h->finisher_ok && !no_finisher;
+    // (one rank only: in this flow k_tm prices no small sets itself, and the ranks would have to enter and leave it together -- a rank whose
+    // finisher is off, or whose running mean differs, must not deal a small set's pairs one way while its peers deal them the other.  With
+    // several ranks k_strict_flat goes out on k_tm's word instead: one host round trip later)
+    const bool mid = flat_allowed(h, world) && world == 1 && h->mid_run && !late_stage && h->finisher_ok && !no_finisher;
     h->flat_tried = false;
     // (with k_strict_flat behind the scan k_tm prices nothing itself: one thread per pair walking the classes is 30-50 us for a set
     // of 20 fragments, and the flat kernel would wait for it)
@@ -5462,7 +5511,9 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     if (strict) {
         if (ta.host_res == nullptr) {
             int rc_ = 0;
-            if (mid) { rc_ = launch_flat(h, fA, &nb, K, (long long*)d_q_out, h->publish, st); h->flat_tried = true; }
+            // (several ranks: whoever finishes a step that is not in the late stage -- this rank's finisher may be off while its peers' are on --
+            // goes through k_strict_flat first, like a rank that k_tm sent there: the flat and the tiled kernels deal the pairs differently)
+            if (mid || (world > 1 && !late_stage && flat_allowed(h, world))) { rc_ = launch_flat(h, fA, &nb, K, rank, world, (long long*)d_q_out, h->publish, st); h->flat_tried = true; }
             else rc_ = launch_strict(h, fA, K, rank, world, (long long*)d_q_out, h->publish, st);
             if (rc_) return rc_;
             if (!h->publish) { CK(hipEventRecord(h->ev_fin, st)); h->fin_pending = true; }
@@ -5496,6 +5547,7 @@ static int eval_sync(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int
     double t1 = 0.0, t2 = 0.0, t3 = 0.0;
     h->publish = true;
     h->step_needed_fin = false;
+    h->step_needed_geom = false;
     int rc = graal_eval_candidates_q(h, fA, fB, K, max_id, rank, world, (int64_t*)h->d_qout, nullptr);
     h->publish = false;
     if (rc) return rc;
@@ -5506,15 +5558,16 @@ static int eval_sync(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int
     for (long long spin = 0; spin < 200000000ll; spin++) {
         const long long v = res[0];
         if (v == want || v == -want) { seen = true; break; }
-        if (v == (want | NEED_FIN) || v == (want | NEED_FIN | GAVE_UP)) { // k_tm left (the heavy part of) the step to k_fin
+        if ((v & ~(GAVE_UP | NEED_GEOM)) == (want | NEED_FIN)) { // k_tm left (the heavy part of) the step to k_fin
             if ((v & GAVE_UP) && ++h->gave_up >= 3) h->finisher_ok = false;
+            if (v & NEED_GEOM) h->step_needed_geom = true;
             res[0] = 0;
             if (h->eval_timing) t2 = now_us();
             h->publish = true;
             h->step_needed_fin = true;
             if ((h->mode & GRAAL_MODE_STRICT) && flat_allowed(h, world) && !h->flat_tried) { // small sets first; if they are not, it says NEED_FIN again
                 h->flat_tried = true;
-                rc = launch_flat(h, fA, nullptr, K, (long long*)h->d_qout, true, h->stream);
+                rc = launch_flat(h, fA, nullptr, K, rank, world, (long long*)h->d_qout, true, h->stream);
             } else
                 rc = (h->mode & GRAAL_MODE_STRICT) ? launch_strict(h, fA, K, rank, world, (long long*)h->d_qout, true, h->stream)
                                                    : launch_fin(h, K, rank, world, (long long*)h->d_qout, true, h->stream);
@@ -5525,7 +5578,7 @@ static int eval_sync(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int
         }
         if ((spin & 0xfffff) == 0xfffff && hipStreamQuery(h->stream) != hipErrorNotReady && hipStreamQuery(h->aux) != hipErrorNotReady) {
             seen = (res[0] == want || res[0] == -want);
-            if (!seen && (res[0] & ~GAVE_UP) == (want | NEED_FIN)) continue;
+            if (!seen && (res[0] & ~(GAVE_UP | NEED_GEOM)) == (want | NEED_FIN)) continue;
             break;
         }
         __builtin_ia32_pause();
@@ -5535,10 +5588,13 @@ static int eval_sync(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int
         CK(hipStreamSynchronize(h->aux));
         if (res[0] != want && res[0] != -want) return fail(h, GRAAL_E_HIP, "the step's last block did not publish its results");
     }
-    if (world == 1 && (h->mode & GRAAL_MODE_STRICT) && (res[0] == want)) {
+    if ((h->mode & GRAAL_MODE_STRICT) && (res[0] == want)) {
         // running mean of "k_tm alone would not have finished this step": above 1/2 the flat kernel goes out with every step and
-        // k_tm does not wait for the scan; below 1/4 k_tm finishes the steps by itself again
-        const bool needed = launched_mid ? (res[1 + MAXK * N_OPS] != 0 || h->step_needed_fin) : h->step_needed_fin;
+        // k_tm does not wait for the scan; below 1/4 k_tm finishes the steps by itself again.  With several ranks only what the LAYOUT says
+        // counts (a set beyond k_tm's own pricing), not the rank's own queue: the ranks must change flows together -- in one flow k_tm prices
+        // the small sets (dealt to the ranks its way), in the other k_strict_flat does (dealt its way)
+        const bool needed = world > 1 ? (launched_mid ? (res[1 + MAXK * N_OPS] & 2) != 0 : h->step_needed_geom)
+                                      : (launched_mid ? ((res[1 + MAXK * N_OPS] & 1) != 0 || h->step_needed_fin) : h->step_needed_fin);
         h->need_ema = 0.9 * h->need_ema + (needed ? 0.1 : 0.0);
         if (!h->mid_run && h->need_ema > 0.5) h->mid_run = true;
         else if (h->mid_run && h->need_ema < 0.25) h->mid_run = false;

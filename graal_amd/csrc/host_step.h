@@ -265,8 +265,9 @@ static int hs_finish(graal_ctx* h, MtState* mt, double likelihood_t, int want_di
     }
     if (full_inside) {
         int64_t fq[2];
-        const int rc = full_collect(h, h->fstream, fq);
+        int rc = full_collect(h, h->fstream, fq);
         if (rc) return 16 + rc;
+        if (h->x_host) { rc = full_exchange(h, fq); if (rc) return 16 + rc; }   // several ranks: the contacts' part is the sum over their shards
         // (float(q0 + q1) / Q_SCALE of the Python path: the integer sum is exact, one conversion, one division by a power of two)
         likelihood_t = fq[0] == Q_BAD ? (double)NAN : (double)(fq[0] + fq[1]) / Q_SCALE;
         out->full_likelihood = likelihood_t;
@@ -344,8 +345,9 @@ int graal_step(graal_ctx* h, void* mt_state, int32_t fA, int32_t delta, double l
     if (rc) { *mt = keep; S.nb.clear(); return 16 + rc; }
     S.max_id = out->max_id;
     if ((flags & 2) || ((flags & 1) && (out->stats[6] != 0 || prev_circ != 0))) {
-        // a full re-evaluation is due: inside the step (flag 8; one rank, whose sums are the whole likelihood) or by the caller
-        if ((flags & 8) && !h->x_host) return hs_finish(h, mt, likelihood_t, (flags & 4) != 0, out, false, true);
+        // a full re-evaluation is due: inside the step (flag 8; with an exchange attached the ranks' contact parts are summed through
+        // it, full_exchange) or by the caller
+        if (flags & 8) return hs_finish(h, mt, likelihood_t, (flags & 4) != 0, out, false, true);
         S.paused = true;
         return GRAAL_STEP_PAUSED;
     }

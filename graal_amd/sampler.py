@@ -773,8 +773,9 @@ class sampler(object):
         resync = self.likelihood_t is None or self._force_full or self._steps_since_full + 1 >= self.resync_every
         if resync:
             flags |= 2
-        if self.group.world == 1:
-            flags |= 8    # a full re-evaluation that is due (resync, circular contigs with sub-fragments) runs INSIDE the step, next to the scoring kernels
+        if self.group.world == 1 or self.exchange == "host":
+            flags |= 8    # a full re-evaluation that is due (resync, circular contigs with sub-fragments) runs INSIDE the step, next to the scoring
+                          # kernels (several ranks: their contact parts are summed through the exchange segment, host_step.h / full_exchange)
         if self.compute_dist and not self._dist_ref_uploaded:
             self.dist_inter_genome()                               # (uploads the reference layout of the distance once)
         rc = e.step(self._mt_addr, id_fA, int(delta), 0.0 if self.likelihood_t is None else float(self.likelihood_t), flags,

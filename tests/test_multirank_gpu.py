@@ -12,9 +12,15 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _problem():
+def _problem(which="sub3"):
     from graal_amd import synth
     par = synth.make_param_simu(fact=200.0, v_inter=0.02)
+    if which == "mid":
+        # the middle of a run at one sub-fragment per bin (the C4 stand-in's regime in small): contigs of tens to hundreds of bins -- affected
+        # sets beyond what k_tm prices itself: k_strict_flat, and k_gprep + k_strict2 for the larger ones -- on GENERIC bp lengths, in
+        # reference arithmetic (the default)
+        # (10 contigs of ~50 bins: not the late stage's direct launch of the tiled kernels -- k_tm sends every rank to k_strict_flat)
+        return synth.make_problem(n_bins=500, nnz=15000, n_sub=1, seed=19, contig_weights=(1,) * 10, mean_len_bp=1500.0, accu=1, param=par)
     return synth.make_problem(n_bins=90, nnz=2500, n_sub=3, seed=17, contig_weights=(5, 4, 3), mean_len_bp=2000.0, accu=9,
                               param=par, grid_bp=2000)
 
@@ -29,9 +35,9 @@ def _make(P, rng, group, exchange=None):
                    device=0, rng=rng, group=group, param_simu=P["param_simu"], compute_dist=False, exchange=exchange)
 
 
-def _run(group, exchange=None):
+def _run(group, exchange=None, which="sub3"):
     from graal_amd import em
-    P = _problem()
+    P = _problem(which)
     rng = np.random.RandomState(5)
     want = exchange
     if exchange == "auto-fallback":
@@ -45,7 +51,10 @@ def _run(group, exchange=None):
     g = _make(P, rng, group, exchange)
     assert g.exchange == ("none" if group.world == 1 else want)
     scores = []
-    t = em.run_em(g, 1, 4, rng=rng, on_step=lambda j, i, tr: scores.append(np.copy(g.score)))
+    # ("mid": from the map's own ten contigs of ~50 bins, not from the exploded genome: affected sets of ~100 fragments from the first step)
+    t = em.run_em(g, 1, 4, rng=rng, scrambled=which != "mid", on_step=lambda j, i, tr: scores.append(np.copy(g.score)))
+    if which == "mid":
+        assert max(t.n_contigs) < 60, "the run left the regime of contigs of tens to hundreds of bins"
     g.gpu_vect_frags.copy_from_gpu()
     out = (t.mutations(), np.concatenate(scores), {k: np.copy(v) for k, v in g.gpu_vect_frags.as_dict().items()},
            g.eval_likelihood())
@@ -53,14 +62,14 @@ def _run(group, exchange=None):
     return out
 
 
-def _worker(rank, world, port, q, exchange):
+def _worker(rank, world, port, q, exchange, which="sub3"):
     import torch.distributed as td
     from graal_amd import dist as gdist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     td.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        mut, scores, soa, full = _run(gdist.Group(rank, world), exchange)
+        mut, scores, soa, full = _run(gdist.Group(rank, world), exchange, which)
         q.put((rank, mut, scores, soa, full))
     finally:
         td.destroy_process_group()
@@ -69,18 +78,19 @@ def _worker(rank, world, port, q, exchange):
 _REF = {}
 
 
-@pytest.mark.timeout(600)
-@pytest.mark.parametrize("world,exchange", [(2, "host"), (3, "host"), (2, "rccl"), (2, "auto-fallback")])
-def test_ranks_reproduce_the_single_rank_run_bit_for_bit(world, exchange):
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,exchange,which", [(2, "host", "sub3"), (3, "host", "sub3"), (2, "rccl", "sub3"), (2, "auto-fallback", "sub3"),
+                                                  (2, "host", "mid"), (3, "host", "mid"), (2, "rccl", "mid")])
+def test_ranks_reproduce_the_single_rank_run_bit_for_bit(world, exchange, which):
     import torch.multiprocessing as mp
     from graal_amd import dist as gdist
-    if "ref" not in _REF:
-        _REF["ref"] = _run(gdist.Group(0, 1))
-    ref_mut, ref_scores, ref_soa, ref_full = _REF["ref"]
+    if which not in _REF:
+        _REF[which] = _run(gdist.Group(0, 1), which=which)
+    ref_mut, ref_scores, ref_soa, ref_full = _REF[which]
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange, which)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=500) for _ in range(world)), key=lambda r: r[0])
