@@ -496,7 +496,12 @@ def main():
     # device buffer per step through torch.distributed -- RCCL with the nccl backend), reported next to the default
     alt = None
     if world > 1 and smp.exchange == "host":
+        # (north_star's wording: ONE RCCL all-reduce of the per-shard logL vector per step.  With torch.distributed on RCCL the library
+        # drives it itself -- graal_attach_rccl: ncclAllReduce on the engine's stream, the total published behind it; with the gloo
+        # rehearsal it is torch's all-reduce of the device buffer)
+        smp.engine.detach_exchange()
         smp.exchange = "rccl"
+        smp._attach_rccl_c()
         for f, nb in props[:args.warmup]:
             smp._candidate_deltas(f, nb, max_id)
         sync_all()
@@ -505,9 +510,13 @@ def main():
             smp._candidate_deltas(f, nb, max_id)
         sync_all()
         ta = max_over_ranks(time.perf_counter() - ta)
-        smp.exchange = "host"
-        alt = {"exchange": "%s all-reduce of a device buffer (graal_eval_candidates_q + torch.distributed)" % args.backend,
-               "value": n_cand / ta, "ms_per_step": 1e3 * ta / args.steps}
+        alt = {"exchange": ("one ncclAllReduce(3 x 130 int64) per step on the engine's stream, driven by the library (graal_attach_rccl)" if smp._rccl_c else
+                            "%s all-reduce of a device buffer (graal_eval_candidates_q + torch.distributed)" % args.backend),
+               "driven_by_the_library": bool(smp._rccl_c), "value": n_cand / ta, "ms_per_step": 1e3 * ta / args.steps}
+        if smp._rccl_c:
+            smp.engine.detach_rccl()
+            smp._rccl_c = False
+        smp.exchange = smp._setup_exchange("host")     # (collective: a fresh segment, its self-test)
     # for reference: back-to-back replays of the last step's scan between two events (per-launch event overhead amortised)
     scan_replay_ms = smp.engine.time_scan(len(props[-1][1]), reps=100)
     scan_isolated_ms = smp.engine.time_scan(len(props[-1][1]), reps=-40)   # median of isolated replays (device idle in between)

@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <dlfcn.h>
 #include <map>
 #include <string>
 #include <vector>
@@ -4204,6 +4205,8 @@ struct Ctx {
     long long* x_dev = nullptr;
     size_t x_bytes = 0;
     int x_rank = 0, x_world = 1;
+    void* nccl_comm = nullptr;    // graal_attach_rccl: the ranks' Q vectors are summed by ONE ncclAllReduce on the engine's stream (eval_sync)
+    int n_rank = 0, n_world = 1;
     long long stats_seq = 0;
     int4* d_dref = nullptr;       // genome-distance reference (graal_upload_distance_ref)
     unsigned long long* d_dist = nullptr; // [0] sum, [1] ticket
@@ -4701,6 +4704,36 @@ __global__ void k_full_pub(long long* __restrict__ sc, volatile long long* host,
 
 struct graal_ctx : Ctx {};
 
+// ---- RCCL, resolved at run time: the library carries no link-time dependency on it (the CPU build and a single-rank run never load it)
+struct NcclId { char b[128]; };   // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES 128), passed by value like the original
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(NcclId*) = nullptr;
+    int (*CommInitRank)(void**, int, NcclId, int) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+static Rccl* rccl_load(std::string* err)
+{
+    static Rccl R;
+    if (R.lib) return &R;
+    const char* names[] = {getenv("GRAAL_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void* lib = nullptr;
+    for (const char* n : names) if (n && !lib) lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (!lib) { if (err) *err = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "dlopen failed"); return nullptr; }
+    R.GetUniqueId = (int (*)(NcclId*))dlsym(lib, "ncclGetUniqueId");
+    R.CommInitRank = (int (*)(void**, int, NcclId, int))dlsym(lib, "ncclCommInitRank");
+    R.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(lib, "ncclAllReduce");
+    R.CommDestroy = (int (*)(void*))dlsym(lib, "ncclCommDestroy");
+    R.GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
+    if (!R.GetUniqueId || !R.CommInitRank || !R.AllReduce || !R.CommDestroy) { if (err) *err = "RCCL: a symbol is missing"; dlclose(lib); return nullptr; }
+    R.lib = lib;
+    return &R;
+}
+constexpr int NCCL_INT64 = 4, NCCL_SUM = 0;   // rccl.h: ncclInt64, ncclSum
+
+
 extern "C" {
 
 int graal_abi_version(void) { return GRAAL_ABI_VERSION; }
@@ -4800,6 +4833,7 @@ void graal_destroy(graal_ctx* h)
                         h->keys, h->keys_sorted, h->o2n, h->len_of2[0], h->len_of2[1], h->contig_off2[0], h->contig_off2[1], h->perm, h->cbase, h->link, h->mates, h->cub_tmp, h->tabs, h->step_hdr, h->d_args, h->d_chg, h->d_part,
                         h->d_scalars, h->d_qout, h->d_dref, h->d_dist};
         for (void* p : ptrs) if (p) (void)hipFree(p);
+        if (h->nccl_comm) { Rccl* R = rccl_load(nullptr); if (R) (void)R->CommDestroy(h->nccl_comm); h->nccl_comm = nullptr; }
         if (h->x_host) (void)hipHostUnregister(h->x_host);
         if (h->h_res) (void)hipHostFree(h->h_res);
         if (h->h_stats) (void)hipHostFree(h->h_stats);
@@ -5530,12 +5564,52 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     return GRAAL_OK;
 }
 
+// behind the all-reduce: the summed device buffer (hand_out's layout: Q sums, coarse sums, not-finite flags) to pinned host memory in the
+// layout the single-rank step publishes, the sequence word last
+__global__ void k_qout_pub(const long long* __restrict__ q, volatile long long* host, int K, long long seq)
+{
+    for (int i = threadIdx.x; i < K * N_OPS; i += blockDim.x) {
+        host[1 + i] = q[2 * MAXK * N_OPS + i] != 0 ? Q_NAN : q[i];
+        host[X_COARSE + i] = q[MAXK * N_OPS + i];
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) { host[0] = seq; __threadfence_system(); }
+}
+
 // synchronous evaluation: launch the step, spin on the sequence word its last block writes into pinned host memory (fall
 // back to a stream synchronise if it does not show up -- it always does unless the launch failed); q_sum[K*13] = the Q sums
 // of this rank, plus -- with an exchange attached -- those the other ranks of the node published for the same step
 static int eval_sync(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int32_t max_id, int rank, int world, long long* q_sum, long long* c_sum)
 {
     const long long want = h->seq + 1;
+    if (h->nccl_comm) {
+        // the north star's exchange: every rank's finishing kernel leaves its sums in a device buffer, ONE ncclAllReduce over xGMI on the
+        // engine's stream sums them, a last tiny kernel publishes the total to this rank's pinned host memory -- all on the GPU timeline, the
+        // host waits once.  (k_tm's last block cannot finish such a step: the finishing kernel always runs; k_strict_flat -- which may hand
+        // the step back through the host -- is not used.)
+        Rccl* R = rccl_load(&h->err);
+        if (!R) return GRAAL_E_STATE;
+        h->res_host = h->res_dev = h->h_res;
+        h->publish = false;
+        int rc = graal_eval_candidates_q(h, fA, fB, K, max_id, rank, world, (int64_t*)h->d_qout, nullptr);
+        if (rc) return rc;
+        const int nrc = R->AllReduce(h->d_qout, h->d_qout, (size_t)3 * MAXK * N_OPS, NCCL_INT64, NCCL_SUM, h->nccl_comm, h->stream);
+        if (nrc != 0) { h->err = std::string("ncclAllReduce failed: ") + (R->GetErrorString ? R->GetErrorString(nrc) : "?"); return GRAAL_E_HIP; }
+        k_qout_pub<<<1, 256, 0, h->stream>>>(h->d_qout, h->h_res, K, want);
+        CK(hipGetLastError());
+        volatile long long* res = h->h_res;
+        bool seen = false;
+        for (long long spin = 0; spin < 2000000000ll; spin++) {
+            if (res[0] == want) { seen = true; break; }
+            if ((spin & 0xfffff) == 0xfffff && hipStreamQuery(h->stream) != hipErrorNotReady) { seen = res[0] == want; break; }
+            __builtin_ia32_pause();
+        }
+        if (!seen) { CK(hipStreamSynchronize(h->stream)); if (res[0] != want) return fail(h, GRAAL_E_HIP, "the all-reduced sums were not published"); }
+        __sync_synchronize();
+        for (int i = 0; i < K * N_OPS; i++) { q_sum[i] = res[1 + i]; c_sum[i] = res[X_COARSE + i]; }
+        return GRAAL_OK;
+    }
     if (world > 1) { // this rank's slot of the step's parity (two steps later the slot is reused: every rank has read it by then,
                      // because nobody finishes step s+1 before everybody has published it, i.e. has finished reading step s)
         const size_t off = ((size_t)(want & 1) * (size_t)world + (size_t)rank) * X_SLOT_WORDS;
@@ -5655,7 +5729,7 @@ int graal_eval_candidates(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K
 {
     if (!h || !delta) return GRAAL_E_ARG;
     long long q[MAXK * N_OPS], c[MAXK * N_OPS];
-    const int rc = eval_sync(h, fA, fB, K, max_id, 0, 1, q, c);
+    const int rc = eval_sync(h, fA, fB, K, max_id, h->nccl_comm ? h->n_rank : 0, h->nccl_comm ? h->n_world : 1, q, c);   // (RCCL attached: the ranks' sum)
     if (rc) return rc;
     for (int i = 0; i < K * N_OPS; i++) delta[i] = q_value(q[i], c[i]);
     return GRAAL_OK;
@@ -5730,12 +5804,52 @@ int graal_detach_exchange(graal_ctx* h)
     return GRAAL_OK;
 }
 
+int graal_rccl_unique_id(void* id128)
+{
+    if (!id128) return GRAAL_E_ARG;
+    Rccl* R = rccl_load(nullptr);
+    if (!R) return GRAAL_E_STATE;
+    return R->GetUniqueId((NcclId*)id128) == 0 ? GRAAL_OK : GRAAL_E_HIP;
+}
+
+int graal_attach_rccl(graal_ctx* h, const void* id128, int32_t rank, int32_t world)
+{
+    if (!h || !id128 || world < 1 || rank < 0 || rank >= world) return GRAAL_E_ARG;
+    if (h->nccl_comm) return fail(h, GRAAL_E_STATE, "RCCL: already attached");
+    if (h->x_host) return fail(h, GRAAL_E_STATE, "RCCL: the host exchange is attached (one exchange at a time)");
+    Rccl* R = rccl_load(&h->err);
+    if (!R) return GRAAL_E_STATE;
+    CK(hipSetDevice(h->device));
+    CK(hipStreamSynchronize(h->stream));
+    CK(hipStreamSynchronize(h->aux));
+    NcclId id;
+    memcpy(&id, id128, sizeof id);
+    void* comm = nullptr;
+    const int nrc = R->CommInitRank(&comm, world, id, rank);
+    if (nrc != 0 || !comm) { h->err = std::string("ncclCommInitRank failed: ") + (R->GetErrorString ? R->GetErrorString(nrc) : "?"); return GRAAL_E_HIP; }
+    h->nccl_comm = comm; h->n_rank = rank; h->n_world = world;
+    return GRAAL_OK;
+}
+
+int graal_detach_rccl(graal_ctx* h)
+{
+    if (!h) return GRAAL_E_ARG;
+    if (!h->nccl_comm) return GRAAL_OK;
+    CK(hipSetDevice(h->device));
+    CK(hipStreamSynchronize(h->stream));
+    CK(hipStreamSynchronize(h->aux));
+    Rccl* R = rccl_load(nullptr);
+    if (R) (void)R->CommDestroy(h->nccl_comm);
+    h->nccl_comm = nullptr; h->n_rank = 0; h->n_world = 1;
+    return GRAAL_OK;
+}
+
 int graal_eval_candidates_x(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int32_t max_id, int64_t* q_sum, int64_t* c_sum)
 {
     if (!h || !q_sum || !c_sum) return GRAAL_E_ARG;
-    if (!h->x_host) return fail(h, GRAAL_E_STATE, "graal_attach_exchange first");
+    if (!h->x_host && !h->nccl_comm) return fail(h, GRAAL_E_STATE, "graal_attach_exchange or graal_attach_rccl first");
     long long q[MAXK * N_OPS], c[MAXK * N_OPS];
-    const int rc = eval_sync(h, fA, fB, K, max_id, h->x_rank, h->x_world, q, c);
+    const int rc = eval_sync(h, fA, fB, K, max_id, h->nccl_comm ? h->n_rank : h->x_rank, h->nccl_comm ? h->n_world : h->x_world, q, c);
     if (rc) return rc;
     for (int i = 0; i < K * N_OPS; i++) { q_sum[i] = q[i]; c_sum[i] = c[i]; }
     return GRAAL_OK;

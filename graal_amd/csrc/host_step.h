@@ -260,7 +260,8 @@ static int hs_finish(graal_ctx* h, MtState* mt, double likelihood_t, int want_di
     long long q[128 * N_OPS], qc[128 * N_OPS];
     for (int k0 = 0; k0 < K; k0 += MAXK) {
         const int kk = std::min(MAXK, K - k0);
-        const int rc = eval_sync(h, S.fA, S.nb.data() + k0, kk, S.max_id, h->x_host ? h->x_rank : 0, h->x_host ? h->x_world : 1, q + k0 * N_OPS, qc + k0 * N_OPS);
+        const int rc = eval_sync(h, S.fA, S.nb.data() + k0, kk, S.max_id, h->nccl_comm ? h->n_rank : (h->x_host ? h->x_rank : 0),
+                                 h->nccl_comm ? h->n_world : (h->x_host ? h->x_world : 1), q + k0 * N_OPS, qc + k0 * N_OPS);
         if (rc) { if (full_inside) { int64_t dump[2]; (void)full_collect(h, h->fstream, dump); } return 16 + rc; }
     }
     if (full_inside) {
@@ -347,7 +348,7 @@ int graal_step(graal_ctx* h, void* mt_state, int32_t fA, int32_t delta, double l
     if ((flags & 2) || ((flags & 1) && (out->stats[6] != 0 || prev_circ != 0))) {
         // a full re-evaluation is due: inside the step (flag 8; with an exchange attached the ranks' contact parts are summed through
         // it, full_exchange) or by the caller
-        if (flags & 8) return hs_finish(h, mt, likelihood_t, (flags & 4) != 0, out, false, true);
+        if ((flags & 8) && !(h->nccl_comm && h->n_world > 1)) return hs_finish(h, mt, likelihood_t, (flags & 4) != 0, out, false, true);
         S.paused = true;
         return GRAAL_STEP_PAUSED;
     }

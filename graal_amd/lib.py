@@ -46,7 +46,7 @@ _f64p = ctypes.POINTER(ctypes.c_double)
 SYMBOLS = ("graal_abi_version", "graal_create", "graal_destroy", "graal_last_error", "graal_set_params",
            "graal_upload_subfrags", "graal_upload_repeats", "graal_upload_contacts", "graal_upload_contacts_f32", "graal_upload_frags", "graal_download_frags",
            "graal_relabel_contigs", "graal_begin_step", "graal_begin_step_launch", "graal_layout_stats", "graal_eval_full_q", "graal_eval_candidates_q",
-           "graal_eval_candidates", "graal_exchange_bytes", "graal_attach_exchange", "graal_eval_candidates_x", "graal_exchange_selftest", "graal_detach_exchange", "graal_upload_distance_ref", "graal_genome_distance", "graal_apply_move", "graal_set_finisher", "graal_set_mode", "graal_set_timing", "graal_last_timing", "graal_scan_times", "graal_strict_times", "graal_time_scan", "graal_last_counters",
+           "graal_eval_candidates", "graal_exchange_bytes", "graal_attach_exchange", "graal_eval_candidates_x", "graal_exchange_selftest", "graal_detach_exchange", "graal_rccl_unique_id", "graal_attach_rccl", "graal_detach_rccl", "graal_upload_distance_ref", "graal_genome_distance", "graal_apply_move", "graal_set_finisher", "graal_set_mode", "graal_set_timing", "graal_last_timing", "graal_scan_times", "graal_strict_times", "graal_time_scan", "graal_last_counters",
            "graal_upload_proposal_tables", "graal_step", "graal_step_finish", "graal_steps", "graal_host_np_sum", "graal_host_select_move", "graal_host_neighbours")
 
 STEP_DONE, STEP_PAUSED, STEP_FALLBACK, STEP_SELECT = 0, 1, 2, 3
@@ -103,6 +103,9 @@ def load():
                                             ctypes.c_int64, _i64p]
         L.graal_exchange_selftest.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32]
         L.graal_detach_exchange.argtypes = [ctypes.c_void_p]
+        L.graal_rccl_unique_id.argtypes = [ctypes.c_void_p]
+        L.graal_attach_rccl.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32]
+        L.graal_detach_rccl.argtypes = [ctypes.c_void_p]
         L.graal_eval_candidates_x.argtypes = [ctypes.c_void_p, ctypes.c_int32, _i32p, ctypes.c_int32, ctypes.c_int32, _i64p, _i64p]
         L.graal_upload_distance_ref.argtypes = [ctypes.c_void_p, _i32p, _i32p, _i32p, _i32p, ctypes.POINTER(ctypes.c_uint8),
                                                 ctypes.c_int32]
@@ -346,6 +349,22 @@ class Engine:
         if phase == 0:
             self._ck(rc, "graal_exchange_selftest")
         return rc == 0
+
+    @staticmethod
+    def rccl_unique_id():
+        """The 128-byte id of a new RCCL communicator (rank 0 makes it, every rank attaches with it)."""
+        buf = ctypes.create_string_buffer(128)
+        rc = load().graal_rccl_unique_id(buf)
+        if rc != 0:
+            raise GraalError("graal_rccl_unique_id failed (%d): RCCL not found?" % rc)
+        return bytes(buf.raw)
+
+    def attach_rccl(self, id128, rank, world):
+        """From now on the ranks' Q vectors are summed by one ncclAllReduce on the engine's stream (include/graal_hip.h)."""
+        self._ck(self._L.graal_attach_rccl(self._h, ctypes.c_char_p(bytes(id128)), int(rank), int(world)), "graal_attach_rccl")
+
+    def detach_rccl(self):
+        self._ck(self._L.graal_detach_rccl(self._h), "graal_detach_rccl")
 
     def detach_exchange(self):
         self._ck(self._L.graal_detach_exchange(self._h), "graal_detach_exchange")

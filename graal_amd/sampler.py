@@ -581,7 +581,11 @@ class sampler(object):
         ``"rccl"``: one RCCL all-reduce of a device buffer per step (the only choice across nodes).  Both are bit
         identical (int64 sums).  Default: ``GRAAL_EXCHANGE`` or "host" when every rank is on this node."""
         import os
+        self._rccl_c = False
         if self.group.world == 1:
+            if os.environ.get("GRAAL_RCCL_FORCE"):   # (test hook: a one-rank communicator, so that ONE GPU exercises the all-reduce flow)
+                self.engine.attach_rccl(self.engine.rccl_unique_id(), 0, 1)
+                self._rccl_c = True
             return "none"
         mode = mode or os.environ.get("GRAAL_EXCHANGE", "auto")
         if mode not in ("auto", "host", "rccl"):
@@ -590,6 +594,7 @@ class sampler(object):
         if mode == "host" and not same_node:
             raise RuntimeError("exchange='host' needs every rank on one node")
         if mode == "rccl" or not same_node:
+            self._attach_rccl_c()
             return "rccl"
         seg = self.group.shared_host_segment(self.engine.exchange_bytes(self.group.world))
         floor = self.group.all_reduce_max_int(self.engine.step_seq())
@@ -606,15 +611,41 @@ class sampler(object):
             import warnings
             warnings.warn("graal_amd: the shared-host-memory exchange failed its self-test; using the RCCL all-reduce")
             self.group.barrier()
+            self._attach_rccl_c()
             return "rccl"
         self.group.barrier()
         return "host"
+
+    def _attach_rccl_c(self):
+        """exchange="rccl" driven by the library (include/graal_hip.h: graal_attach_rccl): one ncclAllReduce per step on the engine's
+        stream, the step's host logic in C.  Only when torch.distributed itself runs on RCCL (one process per GPU); with the gloo
+        rehearsal -- several ranks on ONE GPU, which RCCL refuses -- the all-reduce stays torch's (the Python path below)."""
+        import os
+        self._rccl_c = False
+        try:
+            import torch.distributed as td
+            if not td.is_initialized() or td.get_backend() != "nccl" or os.environ.get("GRAAL_RCCL_TORCH"):
+                return
+            box = [self.engine.rccl_unique_id() if self.group.rank == 0 else None]
+            td.broadcast_object_list(box, src=0)
+            ok = 1
+            try:
+                self.engine.attach_rccl(box[0], self.group.rank, self.group.world)
+            except Exception:
+                ok = 0
+            if self.group.all_reduce_max_int(1 - ok) != 0:     # all or none
+                if ok:
+                    self.engine.detach_rccl()
+                return
+            self._rccl_c = True
+        except Exception:
+            self._rccl_c = False
 
     def _candidate_deltas(self, id_fA, id_neighbours, max_id):
         """float64 [K, 13]; one fused scan per group of <= 8 neighbours, one exchange per scan when sharded."""
         if self.group.world == 1:
             return self.engine.eval_candidates(id_fA, id_neighbours, max_id)
-        if self.exchange == "host":
+        if self.exchange == "host" or self._rccl_c:
             return self.engine.eval_candidates_x(id_fA, id_neighbours, max_id)
         import torch
         out = np.zeros((len(id_neighbours), N_OPS), dtype=np.float64)
@@ -745,7 +776,7 @@ class sampler(object):
         self._c_step = False
         if os.environ.get("GRAAL_PY_STEP"):        # (the Python path, for comparison)
             return
-        if self.exchange == "rccl":                # the all-reduce is torch's: the Python path drives it
+        if self.exchange == "rccl" and not self._rccl_c:   # the all-reduce is torch's: the Python path drives it
             return
         self._mt_addr = self._mt_state_address()
         if self._mt_addr is None:

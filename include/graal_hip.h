@@ -139,6 +139,15 @@ int graal_attach_exchange(graal_ctx* h, void* segment, int64_t bytes, int32_t ra
  * all-reduce of graal_eval_candidates_q). */
 int graal_exchange_selftest(graal_ctx* h, int64_t tag, int32_t phase);
 int graal_detach_exchange(graal_ctx* h);
+/* The RCCL form of the exchange, driven by the library: graal_attach_rccl joins a communicator (rank 0 makes the 128-byte id with
+ * graal_rccl_unique_id and hands it to the others -- torch.distributed's broadcast in graal_amd/sampler.py; librccl is dlopen'ed, no
+ * link-time dependency); from then on every candidate evaluation of this handle -- graal_eval_candidates, _x, graal_step -- leaves the
+ * rank's sums in a device buffer, sums them with ONE ncclAllReduce (3 * GRAAL_MAX_NEIGHBOURS * 13 int64) on the engine's stream and
+ * publishes the total to pinned host memory behind it: collective and publication are on the GPU timeline, the host waits once.
+ * Every rank must make the same calls.  Not together with graal_attach_exchange. */
+int graal_rccl_unique_id(void* id128);
+int graal_attach_rccl(graal_ctx* h, const void* id128, int32_t rank, int32_t world);
+int graal_detach_rccl(graal_ctx* h);
 /* synchronous, sharded: K*13 int64 Q sums over ALL ranks into host buffers (every rank must make the same call).  A candidate's value is
  * c_sum + q_sum / 2^30: q_sum holds the terms below 2^31 in fixed point (2^-30), c_sum -- zero but for a rare candidate -- the larger finite
  * ones rounded to whole log-likelihood units; q_sum == INT64_MIN exactly: a term was not finite (NaN). */

@@ -105,6 +105,42 @@ def test_ranks_reproduce_the_single_rank_run_bit_for_bit(world, exchange, which)
         assert full == ref_full
 
 
+def _rccl_child(out_path, which):
+    """(a child process: RCCL initialises once per process and GPU)"""
+    from graal_amd import dist as gdist
+    mut, scores, soa, full = _run(gdist.Group(0, 1), which=which)
+    np.savez(out_path, mut=np.asarray(mut), scores=scores, full=full, **{"soa_" + k: v for k, v in soa.items()})
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("which", ["sub3", "mid"])
+def test_rccl_all_reduce_driven_by_the_library_on_the_gpu_timeline(which, tmp_path):
+    """exchange="rccl" as north_star words it -- one RCCL all-reduce of the per-shard logL vector per MCMC step -- driven by the library:
+    the finishing kernel leaves the sums in a device buffer, ncclAllReduce runs on the engine's stream, a last kernel publishes the total,
+    graal_step waits once (graal_attach_rccl).  One GPU cannot hold two RCCL ranks, so the FLOW is exercised with a one-rank
+    communicator (GRAAL_RCCL_FORCE): every step goes device buffer -> all-reduce -> publication, and must reproduce the plain
+    single-rank run bit for bit -- scores, trace, layout, full likelihood.  (What several ranks add -- the sharding -- is covered with the
+    host exchange and with torch's all-reduce above; several RCCL ranks need several GPUs: the driver's scaling run.)"""
+    import subprocess
+    import sys
+    from graal_amd import dist as gdist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if which not in _REF:
+        _REF[which] = _run(gdist.Group(0, 1), which=which)
+    ref_mut, ref_scores, ref_soa, ref_full = _REF[which]
+    out = str(tmp_path / "rccl.npz")
+    env = dict(os.environ, GRAAL_RCCL_FORCE="1", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-c", "import tests.test_multirank_gpu as t; t._rccl_child(%r, %r)" % (out, which)], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    got = np.load(out)
+    assert np.array_equal(got["mut"], np.asarray(ref_mut))
+    assert np.array_equal(got["scores"], ref_scores)
+    assert float(got["full"]) == ref_full
+    for k in ref_soa:
+        assert np.array_equal(got["soa_" + k], ref_soa[k]), k
+
+
 @pytest.mark.timeout(900)
 def test_bench_runs_two_ranks_from_one_command():
     """`python bench.py --gpus 2` (no torchrun around it) on a small map: the launcher starts both ranks (here both on this one
