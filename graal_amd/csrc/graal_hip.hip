@@ -5605,7 +5605,11 @@ static int eval_sync(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int
             if ((spin & 0xfffff) == 0xfffff && hipStreamQuery(h->stream) != hipErrorNotReady) { seen = res[0] == want; break; }
             __builtin_ia32_pause();
         }
-        if (!seen) { CK(hipStreamSynchronize(h->stream)); if (res[0] != want) return fail(h, GRAAL_E_HIP, "the all-reduced sums were not published"); }
+        if (!seen) {   // (bounded: a collective that a peer never enters must not hang this rank for ever)
+            const auto t0 = std::chrono::steady_clock::now();
+            while (res[0] != want && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(60)) __builtin_ia32_pause();
+            if (res[0] != want) return fail(h, GRAAL_E_HIP, "RCCL exchange: the all-reduced sums were not published within 60 s (a rank out of step, or the collective hangs)");
+        }
         __sync_synchronize();
         for (int i = 0; i < K * N_OPS; i++) { q_sum[i] = res[1 + i]; c_sum[i] = res[X_COARSE + i]; }
         return GRAAL_OK;
