@@ -1182,6 +1182,111 @@ __global__ __launch_bounds__(256) void k_full_mass(int n, const int* __restrict_
     }
 }
 
+// LDS hand-over between the lanes of ONE wave: LDS operations of a wave execute in program order, so no hardware barrier is
+// needed -- only the compiler must not move them across lanes' dependencies
+#define WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+// The same sum for LONG contigs (thousands of fragments inside the window: C5 on its 7 contigs holds 1.2e8 such pairs), tiled like the
+// reference-arithmetic candidate kernel (strict2.h): a wave's lanes are 64 consecutive fragments x of the position index, the fragments y
+// behind them are staged in LDS 64 at a time -- record, statistics and sub-fragment centres computed ONCE per y, not once per pair -- and
+// every lane walks the staged tile; S waves share an x tile, wave s takes the tiles y number s, s + S, ...  Per pair what is left is the
+// contact model.  The same per-pair values, rounded to Q once per pair: bit-identical to k_full_mass.
+struct FMTile { int label, start_bp, n, frag; float c0, c1, c2; int a0, a1, a2, pad0, pad1; };   // 48 bytes
+template <bool MULTI>
+__global__ __launch_bounds__(256) void k_full_mass_t(int n, const int* __restrict__ perm, const Geo* __restrict__ geo, const Stat* __restrict__ stat,
+                                                      const int* __restrict__ lcont, const int* __restrict__ lcontbp, const int* __restrict__ pos,
+                                                      float nfpb, Par par, int reach_bp, int S, float norm_u, long long* __restrict__ out,
+                                                      long long* __restrict__ bad_flag)
+{
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int W = blockIdx.x * 4 + wib, tile = W / S, s = W - tile * S;
+    __shared__ FMTile s_y[4][64];
+    FMTile* const ty = s_y[wib];
+    const int i = tile * 64 + lane;
+    long long accq = 0;
+    bool bad = false;
+    Geo gx = {0, 0, 0, 0};
+    Stat sx = {0.0f, 0.0f, 0.0f, 0, 0, 0, 0, 0};
+    Ctr cx = {0.0f, 0.0f, 0.0f};
+    int last = -1, circ = 0, lbp = 0;       // last slot of x's contig; its circular model
+    if (i < n) {
+        const int fx = perm[i];
+        gx = geo[fx];
+        sx = stat[fx];
+        const End X = end_cur(gx, lcontbp, fx);
+        cx = centres_of(X.start_bp, X.fwd, sx);
+        circ = X.circ; lbp = X.lbp;
+        last = i + (lcont[fx] - 1 - pos[fx]);
+        if (s == 0) {   // x's own sub-fragment pairs
+            double acc = 0.0;
+            for (int a = 0; a < sx.n; a++)
+                for (int b = a + 1; b < sx.n; b++) acc += (double)ex_pair(X, sx, a, X, sx, b, nfpb, par);
+            const long long q = to_q(acc);
+            if (q == Q_BAD) bad = true; else accq += q;
+        }
+    }
+    const float s_tot = (float)lbp / 1000.0f;
+    const int x_end = gx.start_bp + gx.len_bp;
+    bool live = i < n && last > i;          // (start_bp grows along a contig: once a y of x's contig is beyond the window, all later ones are)
+    for (int c = s; ; c += S) {
+        const int j0 = tile * 64 + 64 * c;
+        // any lane still has fragments of its contig at or behind this tile?
+        if (__ballot(live && last >= j0) == 0ull) break;
+        {
+            const int j = j0 + lane;
+            FMTile y;
+            y.label = -1; y.start_bp = 0; y.n = 0; y.frag = 0; y.c0 = y.c1 = y.c2 = 0.0f; y.a0 = y.a1 = y.a2 = 0; y.pad0 = y.pad1 = 0;
+            if (j < n) {
+                const int fy = perm[j];
+                const Geo gy = geo[fy];
+                const Stat sy = stat[fy];
+                const Ctr cy = centres_of(gy.start_bp, (gy.flags & 1) != 0, sy);
+                y.label = gy.id_c; y.start_bp = gy.start_bp; y.n = sy.n; y.frag = fy; y.c0 = cy.c0; y.c1 = cy.c1; y.c2 = cy.c2; y.a0 = sy.a0; y.a1 = sy.a1; y.a2 = sy.a2;
+            }
+            ty[lane] = y;
+        }
+        WAVE_LDS_SYNC();
+        const int cnt = min(64, n - j0);
+        if (live && last >= j0) {
+            for (int jj = 0; jj < cnt; jj++) {
+                const int j = j0 + jj;
+                if (j <= i || j > last) continue;                         // every unordered pair once; x's contig only
+                const FMTile& y = ty[jj];
+                if (y.start_bp - x_end > reach_bp) { live = false; break; } // beyond the window: exactly zero, and so is everything behind it
+                double acc = 0.0;
+                if (!MULTI) {
+                    if (sx.n > 0 && y.n > 0) {
+                        const float norm = norm_u >= 0.0f ? norm_u : (float)(sx.a0 * y.a0) / nfpb;
+                        const float sd = fabsf(y.c0 - cx.c0);
+                        const float ex = (circ == 1 ? rippe_circ(sd, s_tot, par) : rippe(sd, par)) * norm;
+                        acc = 0.0 + ((double)ex - (double)(par.v_inter * norm));
+                    }
+                } else {
+                    for (int a = 0; a < sx.n; a++)
+                        for (int b = 0; b < y.n; b++) {
+                            const float norm = norm_u >= 0.0f ? norm_u : (float)(stat_accu(sx, a) * sel3(y.a0, y.a1, y.a2, b)) / nfpb;
+                            const float sd = fabsf(sel3(y.c0, y.c1, y.c2, b) - sel3(cx.c0, cx.c1, cx.c2, a));
+                            const float ex = (circ == 1 ? rippe_circ(sd, s_tot, par) : rippe(sd, par)) * norm;
+                            acc += (double)ex - (double)(par.v_inter * norm);
+                        }
+                }
+                const long long q = to_q_fast(acc);
+                if (q == Q_BAD) bad = true; else accq += q;
+            }
+        }
+        WAVE_LDS_SYNC();
+    }
+    if (bad) atomicOr((unsigned long long*)bad_flag, 1ull);
+    __shared__ long long s_part[4];
+    const long long q = wave_sum_ll(accq);
+    if (lane == 0) s_part[wib] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const long long v = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        if (v != 0) atomicAdd((unsigned long long*)out, (unsigned long long)v);
+    }
+}
+
 // ------------------------------------------------------------------ candidate tables
 struct Task {            // windowed cis sum between piece p and piece q in one layout
     int p, q;            // piece ids; p == q: pairs inside the piece.  The larger piece is p (the parallel axis)
@@ -1227,10 +1332,6 @@ constexpr unsigned char CREP_OLD = 0xff;
 // "these values are needed HERE": keeps the compiler from sinking independent loads below a data-dependent branch -- two dependent
 // memory round trips where one would do
 __device__ __forceinline__ void keep_xf(Xf& a, Xf& b) { asm volatile("" : "+v"(a.label), "+v"(a.sigma), "+v"(a.off), "+v"(a.circ), "+v"(a.lbp), "+v"(b.label), "+v"(b.sigma), "+v"(b.off), "+v"(b.circ), "+v"(b.lbp)); }
-
-// LDS hand-over between the lanes of ONE wave: LDS operations of a wave execute in program order, so no hardware barrier is
-// needed -- only the compiler must not move them across lanes' dependencies
-#define WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
 // one staged fragment y of the mass walk (k_fin): transformed geometry + statistics, 64 bytes
 struct YTile { int start_bp, len_bp, flags, label, lbp; float c0, c1, c2; Stat st; };   // (c*: centres of its sub-fragments, kb)
@@ -5352,7 +5453,19 @@ static int full_launch(graal_ctx* h, hipStream_t fs)
     if (quirk && h->n_ubins) // T_all prices every pair of different bins with the plain trans value: add the indexing's difference
         k_quirk_mass<<<blocks_for((long long)h->n_ubins * h->n_bins, 256), 256, 0, fs>>>(h->n_ubins, h->d_ubins, h->n_bins, h->geo, h->stat_frag,
                                                                                              h->nfpb, h->par, h->d_scalars + 9, h->d_scalars + FULL_BAD);
-    if (h->n <= 16384)
+    static const int fmt_env = getenv("GRAAL_FULL_MASS_TILED") ? atoi(getenv("GRAAL_FULL_MASS_TILED")) : -1;   // (A/B: 0 = never, 1 = always)
+    const int lc_full = std::max(std::max(h->max_lcont, h->lcont_bound), 1);
+    if (fmt_env == 1 || (fmt_env != 0 && lc_full > 256)) {
+        // long contigs: the tiled kernel; S waves share an x tile so that the grid has a few thousand waves whatever the contigs' length
+        const int n_tiles = (h->n + 63) / 64;
+        const int S = std::min(16, std::max(1, ((std::min(lc_full, h->n) + 63) / 64 + 7) / 8));
+        const float norm_u = h->uniform_accu > 0 ? (float)(h->uniform_accu * h->uniform_accu) / h->nfpb : -1.0f;
+        const int nb = (n_tiles * S + 3) / 4;
+        if (h->single_sub) k_full_mass_t<false><<<nb, 256, 0, fs>>>(h->n, h->perm, h->geo, h->stat_frag, s.p[F_LCONT], s.p[F_LCONTBP], s.p[F_POS], h->nfpb, h->par,
+                                                                   reach_bp(h), S, norm_u, h->d_scalars + 9, h->d_scalars + FULL_BAD);
+        else k_full_mass_t<true><<<nb, 256, 0, fs>>>(h->n, h->perm, h->geo, h->stat_frag, s.p[F_LCONT], s.p[F_LCONTBP], s.p[F_POS], h->nfpb, h->par,
+                                                     reach_bp(h), S, norm_u, h->d_scalars + 9, h->d_scalars + FULL_BAD);
+    } else if (h->n <= 16384)
         k_full_mass<64><<<blocks_for(h->n, 4), 256, 0, fs>>>(h->n, h->perm, h->contig_off2[h->cur], h->geo, h->stat_frag, s.p[F_LCONT],
                                                                     s.p[F_LCONTBP], s.p[F_POS], h->nfpb, h->par, reach_bp(h),
                                                                     h->d_scalars + 9, h->d_scalars + FULL_BAD);

@@ -280,6 +280,21 @@ def test_full_evaluation_with_labels_in_lds_is_bit_identical():
     assert "bit-identical sums" in out.stdout
 
 
+@pytest.mark.timeout(1500)
+def test_tiled_windowed_mass_of_the_full_evaluation_is_bit_identical():
+    """k_full_mass_t (long contigs: a wave's lanes are 64 fragments x, the fragments y behind them staged in LDS with their centres computed
+    once) against k_full_mass (one lane per fragment pair, records and centres per pair): both int64 sums of graal_eval_full_q on C5's two
+    layouts and on circular / reversed / 1-3 sub-fragment layouts in both RF-count indexings -- forced on and off in child processes
+    (tools/full_mass_check.py asserts the equality).  evaluate_likelihood, kernels3.cu:2802-3222."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "full_mass_check.py")], cwd=root, capture_output=True, text=True, timeout=1400)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    assert "bit-identical sums" in out.stdout
+
+
 # ------------------------------------------------------------------------------------------------ BASELINE config 4 shape, mid-run
 # 40,000 bins x 1 sub-fragment, 8,000,000 contacts (tools/run_configs.py C4), on grid coordinates, after one full cycle from
 # the exploded genome: ~3,000 contigs of a few to ~100 bins.  Here most steps leave k_tm's thresholds and are finished by
