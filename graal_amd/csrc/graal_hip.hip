@@ -5455,7 +5455,9 @@ static int full_launch(graal_ctx* h, hipStream_t fs)
                                                                                              h->nfpb, h->par, h->d_scalars + 9, h->d_scalars + FULL_BAD);
     static const int fmt_env = getenv("GRAAL_FULL_MASS_TILED") ? atoi(getenv("GRAAL_FULL_MASS_TILED")) : -1;   // (A/B: 0 = never, 1 = always)
     const int lc_full = std::max(std::max(h->max_lcont, h->lcont_bound), 1);
-    if (fmt_env == 1 || (fmt_env != 0 && lc_full > 256)) {
+    // (maps of a few thousand bins keep the kernel with one WAVE per fragment x: 3,500 bins are 55 tiles -- the C3 stand-in, which evaluates the
+    // full likelihood every step, went from 237 to 522 us per step with the tiled kernel)
+    if (fmt_env == 1 || (fmt_env != 0 && lc_full > 256 && h->n > 16384)) {
         // long contigs: the tiled kernel; S waves share an x tile so that the grid has a few thousand waves whatever the contigs' length
         const int n_tiles = (h->n + 63) / 64;
         const int S = std::min(16, std::max(1, ((std::min(lc_full, h->n) + 63) / 64 + 7) / 8));

@@ -23,7 +23,7 @@ struct S2Args {
     unsigned long long* next;    // the next unit nobody has taken yet, minus the grid's waves (zero at rest: the step's last block clears it)
 };
 
-#ifdef GRAAL_STAMPS
+#if defined(GRAAL_STAMPS) && defined(GRAAL_S2_COUNTS)   // (work counters: per-lane atomics -- they distort the stamps' timeline)
 #define S2_COUNT(i, v) do { atomicAdd(&g_hitstat[i], (unsigned long long)(v)); } while (0)
 #else
 #define S2_COUNT(i, v) do { } while (0)

@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 so = os.path.join(ROOT, "graal_amd", "libgraal_hip_stamps.so")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-                       "-DGRAAL_STAMPS", "-o", so, os.path.join(ROOT, "graal_amd", "csrc", "graal_hip.hip")])
+                       "-DGRAAL_STAMPS"] + (["-DGRAAL_S2_COUNTS"] if os.environ.get("STAMPS_COUNTS") else []) + ["-o", so, os.path.join(ROOT, "graal_amd", "csrc", "graal_hip.hip")])
 from graal_amd import build
 build.HIP_LIB = so
 from graal_amd import lib, synth
