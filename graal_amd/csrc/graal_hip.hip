@@ -4667,12 +4667,25 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
         s2.draw_min = draw_env > 0 ? draw_env : 8;
         s2.next = reinterpret_cast<unsigned long long*>(h->d_cls_n + US_MAXPAIRS + (US_MAXPAIRS & 1));
         const int cull_blocks = (int)std::min<unsigned long long>(1024ull, std::max<unsigned long long>(1ull, nt));
-        k_gprep<<<GPREP_CLS_BLOCKS + cull_blocks, 256, 0, h->aux>>>(h->tabs, h->geo, h->link, h->cbase, h->perm, fA, K, rank, world, sx.reach_bp, no_window, sx.quirk,
+        // Where k_gprep goes.  A long scan (millions of contacts): on the auxiliary stream behind k_tm, under the scan; k_strict2 waits for both
+        // through an event.  A short one (a map of a few thousand bins: the scan is over before k_tm's tables are): on the MAIN stream, behind
+        // the scan and an event of k_tm that has long completed when the stream gets there -- k_strict2 then follows k_gprep in stream order,
+        // without the ~10 us a kernel waits behind an event that completes right in front of it (tools/stamps_s2.py, C2 stand-in:
+        // k_gprep done 27 us, k_strict2 started 38.7 us)
+        static const int inorder_env = getenv("GRAAL_STRICT_INORDER") ? atoi(getenv("GRAAL_STRICT_INORDER")) : -1;
+        const bool inorder = inorder_env > 0;   // (measured: no gain -- the event in front of k_gprep costs what the one in front of k_strict2 did; kept as a switch)
+        if (inorder) {
+            CK(hipEventRecord(h->ev_tm, h->aux));
+            CK(hipStreamWaitEvent(st, h->ev_tm, 0));
+        }
+        k_gprep<<<GPREP_CLS_BLOCKS + cull_blocks, 256, 0, inorder ? st : h->aux>>>(h->tabs, h->geo, h->link, h->cbase, h->perm, fA, K, rank, world, sx.reach_bp, no_window, sx.quirk,
                                                                      seg_unit, h->d_slist, h->d_slist_n, h->slist_cap,
                                                                      (unsigned long long*)(h->d_scalars + 10), s2);
         CK(hipGetLastError());
-        CK(hipEventRecord(h->ev_tm, h->aux));      // (behind k_tm and k_gprep: tables, classes and unit list complete -- nobody spins for them)
-        CK(hipStreamWaitEvent(st, h->ev_tm, 0));
+        if (!inorder) {
+            CK(hipEventRecord(h->ev_tm, h->aux));      // (behind k_tm and k_gprep: tables, classes and unit list complete -- nobody spins for them)
+            CK(hipStreamWaitEvent(st, h->ev_tm, 0));
+        }
         const size_t sslot = (size_t)(h->sring_calls % (long long)(h->sring.size() / 2));
         if (h->ev_this_call) CK(hipEventRecord(h->sring[2 * sslot], st));   // (behind the wait: the pair spans the kernel, not the scan in front of it)
         if (h->single_sub) k_strict2<false><<<blocks, 256, 0, st>>>(fa, sx, s2, K, h->d_slist, h->d_slist_n, d_q_out, publish ? h->res_dev : nullptr, h->seq);

@@ -318,7 +318,8 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
         const int m_max = SEG / s2.seg_unit;
         while (mrg < m_max && n_units / (unsigned long long)(2 * mrg) >= s2.target) mrg <<= 1;
         // (sharing a unit costs every sharing wave the current layout's values again: only while there are fewer units than waves)
-        if (mrg == 1) while (rep_n < s2.rep_max && n_units * (unsigned long long)rep_n < (unsigned long long)n_waves) rep_n <<= 1;
+        // ... and never more than one unit per wave through sharing (a second unit is a second chain of dependent loads and passes)
+        if (mrg == 1) while (2 * rep_n <= s2.rep_max && n_units * (unsigned long long)(2 * rep_n) <= (unsigned long long)n_waves) rep_n <<= 1;
     }
     S2_COUNT(7, (blockIdx.x == 0 && threadIdx.x == 0) ? (unsigned long long)n_units * 1000000ull + (unsigned long long)(mrg * 100 + rep_n) : 0ull);
     const unsigned long long n_virtual = (fa.skip & 1) ? 0ull : ((n_units + (unsigned long long)mrg - 1ull) / (unsigned long long)mrg) * (unsigned long long)rep_n;
@@ -355,6 +356,12 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
         const UPiece& PS = U.p[gs];
         const UContig& CL = U.c[PL.contig];
         const UContig& CS = U.c[PS.contig];
+        // (the pair's first CLS_CHUNK class records and their number: requested NOW, with the fragments' records -- they depend on the piece pair
+        // alone.  Records behind the pair's last one are read for nothing: the table holds US_NCAND per pair)
+        const int pair = upair_index(g, h);
+        const GClass* __restrict__ cg = s2.cls + (size_t)pair * US_NCAND;
+        const uint4 cls_pre0 = reinterpret_cast<const uint4*>(cg)[lane], cls_pre1 = reinterpret_cast<const uint4*>(cg)[64 + lane];
+        const int nc_pre = s2.cls_n[pair];
         const int nl = rfl(min(US_TILE, PL.n - offl * US_TILE));
         const bool has_l = lane < nl;
         const int fl = has_l ? sa.perm[CL.base + PL.lo + offl * US_TILE + lane] : 0;
@@ -377,9 +384,7 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
         const bool near_old = cis_old && max(ys - xe, xs - ye) <= reach_bp;
         bool always = false;
         if (quirk) always = __ballot((has_l && !stat_uniform(stL)) || (lane < cnt && !stat_uniform(tile[lane < cnt ? lane : 0].st))) != 0ull;
-        const int pair = upair_index(g, h);
-        const int nc = rfl(s2.cls_n[pair]);
-        const GClass* __restrict__ cg = s2.cls + (size_t)pair * US_NCAND;
+        const int nc = rfl(nc_pre);
         // the pair's class records: into LDS in one round trip (read one by one where they are needed, each was a round trip of its own -- with
         // a dozen classes per unit, most of a small step)
         GClass* const cp = s_cls[wib];
@@ -393,7 +398,11 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
             c_base = c0;
             WAVE_LDS_SYNC();
         };
-        stage(0);
+        {   // (the first chunk was requested with the unit's fragments, above: one round trip for both)
+            uint4* dst = reinterpret_cast<uint4*>(cp);
+            dst[lane] = cls_pre0; dst[64 + lane] = cls_pre1;
+            WAVE_LDS_SYNC();
+        }
         // is there anything to price?  (a listed unit has, but for the finer extents of its segment)
         bool any = false;
         for (int c = rep_r; c < nc && !any; c += rep_n) {
@@ -548,8 +557,20 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
         QSrc qs;
         qs.queue = fa.queue; qs.geo2 = reinterpret_cast<const int2*>(geo); qs.cnt = fa.cnt; qs.keys = nullptr; qs.live = 0; qs.K = K;
         qs.seq = (unsigned)seq; qs.concurrent = 0; qs.multi = fa.multi;
-        for (unsigned long long b0 = (unsigned long long)(n_waves - 1 - wave) * 64ull; b0 < ((fa.skip & 2) ? 0ull : nq_total); b0 += (unsigned long long)n_waves * 64ull) {
-            const unsigned long long e = b0 + (unsigned long long)lane;
+        // (a step with fewer units than waves: the waves WITHOUT a unit take the contacts -- if their lanes can hold them all -- and price them while
+        // the others are still at their units; else every wave takes its share behind its units, from the other end of the grid)
+        const unsigned long long n_idle = n_virtual < (unsigned long long)n_waves ? (unsigned long long)n_waves - n_virtual : 0ull;
+        const bool idle_take = n_idle * 64ull >= nq_total && nq_total > 0ull;
+        const unsigned long long c_waves = idle_take ? n_idle : (unsigned long long)n_waves;
+        // lanes per contact: a contact's classes -- a dozen or two, each a record fetched from memory and two evaluations -- are a chain of that
+        // many round trips in ONE lane; with few contacts per wave 4 or 16 lanes share a contact's classes (lane s takes the classes s, s + LPC, ...)
+        const int lpc = nq_total > 16ull * c_waves ? 1 : (nq_total > 4ull * c_waves ? 4 : 16);
+        const int per_wave = 64 / lpc;
+        const unsigned long long c_first = idle_take ? (unsigned long long)wave - n_virtual : (unsigned long long)(n_waves - 1 - wave);
+        const unsigned long long c_end = ((fa.skip & 2) || (idle_take && (unsigned long long)wave < n_virtual)) ? 0ull : nq_total;
+        for (unsigned long long b0 = c_first * (unsigned long long)per_wave; b0 < c_end; b0 += c_waves * (unsigned long long)per_wave) {
+            const unsigned long long e = b0 + (unsigned long long)(lane / lpc);
+            const int sub = lane % lpc;
             if (e >= nq_total) continue;
             const QEntry qe = q_fetch(qs, e, counters + 6);
             if (qe.fx < 0) continue;
@@ -562,13 +583,15 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
             const bool x_low = pgx <= pgy;                 // the class records name the lower piece "x"
             const int pair = x_low ? upair_index(pgx, pgy) : upair_index(pgy, pgx);
             const int nc = s2.cls_n[pair];
-            if (nc == 0) continue;
+            if (sub >= nc) continue;
             const GClass* __restrict__ cp = s2.cls + (size_t)pair * US_NCAND;
+            GClass nx = cp[sub];                            // (the next class's record is on its way while this one is priced)
             const End X0 = end_old(gx, ((gx.flags >> 1) & 1) ? sa.lcontbp[fx] : 0), Y0 = end_old(gy, ((gy.flags >> 1) & 1) ? sa.lcontbp[fy] : 0);
             const float ex_old = ex_pair_ref(X0, sx, slx, fx, Y0, sy, sly, fy, nfpb, par, quirk);
             const double ln_old = mm_ln(ex_old), ob = (double)__int_as_float(cnt_bits);
-            for (int c = 0; c < nc; c++) {
-                const GClass cr = cp[c];
+            for (int c = sub; c < nc; c += lpc) {
+                const GClass cr = nx;
+                if (c + lpc < nc) nx = cp[c + lpc];
                 const int sig_x = x_low ? (cr.flags & 1u) : ((cr.flags >> 1) & 1u), sig_y = x_low ? ((cr.flags >> 1) & 1u) : (cr.flags & 1u);
                 const int off_x = x_low ? cr.offx : cr.offy, off_y = x_low ? cr.offy : cr.offx;
                 End X, Y;

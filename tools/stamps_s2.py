@@ -17,12 +17,18 @@ if shape in ("c2", "c3"):
     P = synth.make_problem(n_bins=3500 if shape == "c3" else 1086, nnz=600000 if shape == "c3" else 120000, n_sub=3, seed=2014,
                            contig_weights=(6.8, 6.2, 5.3, 4.6, 4.0, 3.4, 2.7), mean_len_bp=660.0 * 27 / 3, accu=9)
     K = 3
+elif shape == "c4":   # the C4 stand-in after some cycles from the exploded genome (STAMPS_CYCLES, default 3): contigs of tens to hundreds of bins
+    P = synth.make_problem(n_bins=40000, nnz=8_000_000, n_sub=1, seed=2014, contig_weights=(6.8, 6.2, 5.3, 4.6, 4.0, 3.4, 2.7), mean_len_bp=660.0, accu=1)
+    K = 5
 else:
     P = synth.make_problem(n_bins=50000, nnz=20_000_000, n_sub=1, seed=20141217)
     K = 5
 NB = P["n_frags"]
 rng = np.random.RandomState(20141217)
 smp = bench.build_sampler(P, rng, None, 0, "strict")
+if shape == "c4":
+    from graal_amd import em
+    em.run_em(smp, int(os.environ.get("STAMPS_CYCLES", 3)), K, rng=rng)
 smp.init_likelihood()
 max_id = smp.modify_gl_cuda_buffer(0)
 L = lib.load()
@@ -35,7 +41,7 @@ acc = np.zeros(32); cnt = np.zeros(32); hs = np.zeros(8); n = 0
 import time
 smp.engine.set_timing(0)
 wall = 0.0
-for f in rng.randint(0, NB, size=(12 if shape == "c5late" else 120)):
+for f in rng.randint(0, NB, size=(12 if shape == "c5late" else (400 if shape == "c4" else 120))):
     nb = smp.return_neighbours(int(f), K); nb.sort()
     z = np.zeros(8, dtype=np.uint64)
     L.graal_debug_hitstat(smp.engine._h, z.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), 1)
