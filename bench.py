@@ -450,16 +450,34 @@ def main():
     # (GRAAL_BENCH_STEP_TIMES=1).  A quarter of a second of the same scoring steps first; then the W warm-up steps and the K timed ones.)
     t_settle = time.perf_counter()
     settle_s = float(os.environ.get("GRAAL_BENCH_SETTLE_S", 0.25))
+    settle_t = [] if os.environ.get("GRAAL_BENCH_STEP_TIMES") else None
+    settle_sync = int(os.environ.get("GRAAL_BENCH_SETTLE_SYNC", 0))   # (diagnostics: a device synchronize every n-th step of the settling phase)
     while time.perf_counter() - t_settle < settle_s:
         for f, nb in props[args.warmup:args.warmup + 64]:
             smp._candidate_deltas(f, nb, max_id)
+            if settle_t is not None:
+                settle_t.append(time.perf_counter())
+                if settle_sync and len(settle_t) % settle_sync == 0:
+                    torch.cuda.synchronize()
+    # (the HIP runtime keeps the commands of a stream until a synchronize -- or, every ~1,000 launches without one, a marker of its own -- lets it
+    # release them, and the release is felt: 3-12 steps of 60 us and, a millisecond later, one of 110-150 us, every 1,019 steps of this loop
+    # = every 35.8 ms (GRAAL_BENCH_STEP_TIMES=1 lists them; 0.4 % of a long run, and value_1000 carries its share).  A quarter of a second is 7.0
+    # of those periods: the tail of the 7th fell into the K timed steps of about a third of the driver-style runs -- a 115 us step and a
+    # 180-210 us closing synchronize, 1.1-1.4 M where the other runs gave 1.70-1.77 M.  So the settling phase ends with a synchronize (the
+    # release of what it left), 64 more steps (2 ms: that release is over) and a second synchronize (128 commands: nothing to feel); the W
+    # warm-up steps and the K timed ones then run between two of the runtime's releases rather than, by accident, across one.)
+    sync_all()
+    for f, nb in props[args.warmup:args.warmup + 64]:
+        smp._candidate_deltas(f, nb, max_id)
+    sync_all()
     for f, nb in props[:args.warmup]:
         smp._candidate_deltas(f, nb, max_id)
     n_cand = 0
+    step_t = [] if os.environ.get("GRAAL_BENCH_STEP_TIMES") else None   # (diagnostics: host clock after every step of the timed region)
+    timed_props = props[args.warmup:args.warmup + args.steps]
     sync_all()
     t0 = time.perf_counter()
-    step_t = [] if os.environ.get("GRAAL_BENCH_STEP_TIMES") else None   # (diagnostics: host clock after every step of the timed region)
-    for f, nb in props[args.warmup:args.warmup + args.steps]:
+    for f, nb in timed_props:
         smp._candidate_deltas(f, nb, max_id)   # records a HIP event pair around k_scan on the stream it runs on
         n_cand += 13 * len(nb)
         if step_t is not None:
@@ -467,7 +485,42 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if step_t is not None and rank == 0:
-        print("per-step us:", " ".join("%.1f" % (1e6 * (b - a)) for a, b in zip([t0] + step_t[:-1], step_t)), file=sys.stderr)
+        print("per-step us:", " ".join("%.1f" % (1e6 * (b - a)) for a, b in zip([t0] + step_t[:-1], step_t)),
+              "| closing barrier + synchronize: %.1f" % (1e6 * (t0 + elapsed - step_t[-1])), file=sys.stderr)
+    if settle_t and rank == 0:   # (diagnostics: when, behind the start of the settling phase, steps took more than 1.3x the median)
+        d_ = np.diff(np.asarray(settle_t))
+        med = float(np.median(d_))
+        slow = np.flatnonzero(d_ > 1.3 * med)
+        eps, j = [], 0
+        while j < len(slow):
+            k = j
+            while k + 1 < len(slow) and slow[k + 1] - slow[k] <= 4:
+                k += 1
+            eps.append("%.1f ms: %d steps, mean %.0f us" % (1e3 * (settle_t[slow[j]] - t_settle), slow[k] - slow[j] + 1, 1e6 * float(d_[slow[j]:slow[k] + 1].mean())))
+            j = k + 1
+        print("settling: %d steps, median %.1f us, slow episodes: %s" % (len(d_), 1e6 * med, "; ".join(eps[:60])), file=sys.stderr)
+    if step_t is not None and rank == 0:
+        # what the bracket itself costs (diagnostics): a synchronize with nothing pending, the first step behind one, the first step behind a pause without one
+        def one(i):
+            ta = time.perf_counter()
+            smp._candidate_deltas(props[args.warmup + i][0], props[args.warmup + i][1], max_id)
+            return 1e6 * (time.perf_counter() - ta)
+        def sync_us():
+            ta = time.perf_counter()
+            torch.cuda.synchronize()
+            return 1e6 * (time.perf_counter() - ta)
+        for rep in range(3):
+            a = [one(i) for i in range(6)]
+            s1, s2 = sync_us(), sync_us()
+            b = [one(i) for i in range(6)]
+            ta = time.perf_counter()
+            while time.perf_counter() - ta < 200e-6:
+                pass
+            c = [one(i) for i in range(6)]
+            time.sleep(0.002)
+            d = [one(i) for i in range(6)]
+            print("bracket: steps %s | synchronize %.1f, again %.1f | steps behind it %s | behind a 200 us spin %s | behind a 2 ms sleep %s" % (
+                " ".join("%.0f" % x for x in a), s1, s2, " ".join("%.0f" % x for x in b), " ".join("%.0f" % x for x in c), " ".join("%.0f" % x for x in d)), file=sys.stderr)
     n_timed_pairs = min(args.steps // EVENT_EVERY, 1024) if EVENT_EVERY > 0 else 0
     scan_ms_timed = smp.engine.scan_times(n_timed_pairs) if n_timed_pairs else np.zeros(0, np.float32)   # pairs of the timed region
     elapsed = max_over_ranks(elapsed)
@@ -629,7 +682,7 @@ def main():
                          # kernel-trace duration of the same kernel in the same flow is ~2 us shorter.  `frac` stays with the events.)
                          "kernel_trace_avg_ms": None if trace_us is None else trace_us * 1e-3,
                          "frac_kernel_trace": None if trace_us is None else bytes_per_launch / (trace_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                         "kernel_trace_source": "committed rocprofv3 --kernel-trace run of this workload (profiles/r03_rocprof_c5.md, k_scan [in a step]), not measured in this run",
+                         "kernel_trace_source": "committed rocprofv3 --kernel-trace run of this workload (profiles/r04_rocprof_c5.md, k_scan [in a step]), not measured in this run",
                          "back_to_back_replay_ms": replay_s * 1e3,
                          "frac_back_to_back_replays": bytes_per_launch / replay_s / 1e9 / HBM_PEAK_GBS,
                          "isolated_replay_ms": scan_isolated_ms,
