@@ -583,13 +583,15 @@ __global__ void k_relabel_apply(SoaPtr s, int n, const int* __restrict__ o2n)
     s.p[F_IDC][f] = o2n[s.p[F_IDC][f]];
 }
 
-__global__ void k_build_perm(SoaPtr s, int n, const int* __restrict__ contig_off, int* __restrict__ perm, int* __restrict__ cbase)
+__global__ void k_build_perm(SoaPtr s, int n, const int* __restrict__ contig_off, int* __restrict__ perm, int* __restrict__ cbase,
+                             int* __restrict__ pstart)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n) return;
     const int base = contig_off[s.p[F_IDC][f]];
     cbase[f] = base; // first slot of the fragment's contig in the position index
     perm[base + s.p[F_POS][f]] = f;
+    pstart[base + s.p[F_POS][f]] = s.p[F_START][f];   // start_bp in position order: a tile's extent in one round trip (k_gprep)
 }
 
 // What one commit did to the contig set: only contig(fA), contig(fB) and up to two fresh labels can change.
@@ -684,7 +686,7 @@ __device__ __forceinline__ bool key_less(int l1, int c1, int l2, int c2) { retur
 // re-arms the stale-paste counter the commit's statistics reported and clears the commit record the NEXT commit fills.
 __global__ __launch_bounds__(256) void k_incr(SoaPtr s, int n, const Changed* __restrict__ chg, const int* __restrict__ len_old,
                                               const int* __restrict__ off_old, int nc_old, int* __restrict__ len_new,
-                                              int* __restrict__ off_new, int* __restrict__ perm, int* __restrict__ cbase,
+                                              int* __restrict__ off_new, int* __restrict__ perm, int* __restrict__ pstart, int* __restrict__ cbase,
                                               Geo* __restrict__ geo, Link* __restrict__ link, long long* __restrict__ stats,
                                               int* __restrict__ mates, int* __restrict__ chg_clear, int chg_n,
                                               const long long* __restrict__ part, int n_part, volatile long long* host, long long seq)
@@ -708,25 +710,31 @@ __global__ __launch_bounds__(256) void k_incr(SoaPtr s, int n, const Changed* __
     const int pos_early = f_early < n ? __hip_atomic_load(&s.p[F_POS][f_early], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
 #endif
     if (t == 0) {
-        IncrPlan p;
-        p.n_removed = 0;
-        const int cand[2] = {chg->cA, chg->cB};
-        for (int i = 0; i < 2; i++) {
-            if (i == 1 && cand[1] == cand[0]) continue;
-            p.removed[p.n_removed] = cand[i]; p.removed_len[p.n_removed] = len_old[cand[i]]; p.n_removed++;
-        }
-        for (int i = p.n_removed; i < 2; i++) { p.removed[i] = -1; p.removed_len[i] = 0; }
-        p.n_new = 0;
+        // (built in LDS: as a private struct its dynamically indexed arrays lived in scratch memory -- two dozen dependent scratch accesses in
+        // front of every block of this kernel)
+        IncrPlan& p = sp;
+        const int cA = chg->cA, cB = chg->cB;
+        const int lA = len_old[cA], lB = len_old[cB];
+        int ex[4], lab[4], ln[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { ex[j] = chg->exists[j]; lab[j] = chg->lab[j]; ln[j] = chg->len[j]; }
+        p.removed[0] = cA; p.removed_len[0] = lA;
+        const int n_removed = cB == cA ? 1 : 2;
+        p.removed[1] = cB == cA ? -1 : cB; p.removed_len[1] = cB == cA ? 0 : lB;
+        p.n_removed = n_removed;
+        int n_new = 0;
+#pragma unroll
         for (int j = 0; j < 4; j++) {
-            if (!chg->exists[j]) continue;
-            if (j == 1 && chg->lab[1] == chg->lab[0]) continue;
-            p.new_lab[p.n_new] = chg->lab[j]; p.new_len[p.n_new] = chg->len[j]; p.n_new++;
+            if (!ex[j]) continue;
+            if (j == 1 && lab[1] == lab[0]) continue;
+            p.new_lab[n_new] = lab[j]; p.new_len[n_new] = ln[j]; n_new++;
         }
-        for (int i = p.n_new; i < 4; i++) { p.new_lab[i] = -1; p.new_len[i] = 0; }
+        for (int i = n_new; i < 4; i++) { p.new_lab[i] = -1; p.new_len[i] = 0; }
+#pragma unroll
         for (int i = 0; i < 4; i++) { p.new_rank[i] = -1; p.new_off[i] = 0; }
-        p.nc_new = nc_old - p.n_removed + p.n_new;
-        sp = p;
-        if (blockIdx.x == 0) stats[NC_WORD] = p.nc_new;
+        p.n_new = n_new;
+        p.nc_new = nc_old - n_removed + n_new;
+        if (blockIdx.x == 0) stats[NC_WORD] = nc_old - n_removed + n_new;
     }
     __syncthreads();
     {   // old contigs with key < (l, c): lower / upper bound of l in the sorted length array, for each of the <= 4 new contigs.
@@ -793,6 +801,7 @@ __global__ __launch_bounds__(256) void k_incr(SoaPtr s, int n, const Changed* __
     perm[off + pos] = f;
     cbase[f] = off;
     Geo g; g.id_c = rank; g.start_bp = s.p[F_START][f]; g.len_bp = s.p[F_LEN][f];
+    pstart[off + pos] = g.start_bp;
     g.flags = geo_flags(s.p[F_ORI][f], s.p[F_CIRC][f], pos, s.p[F_ACTIV][f], s.p[F_REP][f]);
     geo[f] = g;
     Link l; l.l_cont = s.p[F_LCONT][f]; l.l_cont_bp = s.p[F_LCONTBP][f]; l.prev = s.p[F_PREV][f]; l.next = s.p[F_NEXT][f];
@@ -1325,6 +1334,7 @@ struct NbTables {        // everything the finishing kernel needs about one neig
     unsigned char crep[N_PAIRS][N_OPS];
     unsigned short cmask[N_PAIRS][N_OPS];
     int set_m;                         // strict: fragments of contig(fA) u contig(fB) that are left to k_strict (0: priced by k_tm, or fB == fA)
+    UEnd endA, endB;                   // the contigs of fA and fB as the union set's builder wants them (k_gprep: one round trip instead of three)
     Task task[MAX_TASKS];
 };
 constexpr unsigned char CREP_OLD = 0xff;
@@ -1432,6 +1442,12 @@ __device__ __forceinline__ int tables_block(const Geo* __restrict__ geo, const L
         sc.mates[1][4] = mB1.x; sc.mates[1][5] = mB1.y; sc.mates[1][6] = mB1.z; sc.mates[1][7] = mB1.w;
         PieceKey key; key.cA = A0.id_c; key.a = A0.pos; key.cB = B0.id_c; key.b = B0.pos;
         T.key = key; T.fB = fB;
+        {
+            UEnd ea, eb;
+            ea.label = A0.id_c; ea.pos = A0.pos; ea.base = s_baseA; ea.len = lA.l_cont; ea.lbp = lA.l_cont_bp; ea.circ = A0.circ;
+            eb.label = B0.id_c; eb.pos = B0.pos; eb.base = s_baseB; eb.len = lB.l_cont; eb.lbp = lB.l_cont_bp; eb.circ = B0.circ;
+            T.endA = ea; T.endB = eb;
+        }
         piece_representatives(key, fA, fB, A0, B0, rep);
         intra_any = 0;
         for (int p = 0; p < NP; p++) { s_lo[p] = 0; s_hi[p] = -1; s_contig[p] = -1; }
@@ -1589,13 +1605,11 @@ __device__ __forceinline__ int tables_block(const Geo* __restrict__ geo, const L
         const int pair = (e < NPAIR) ? e : (e - NPAIR) % NPAIR;
         int p, q;
         pair_of_index(pair, p, q);
+        if (s_hi[p] - s_lo[p] < s_hi[q] - s_lo[q]) { const int tp = p; p = q; q = tp; } // the larger piece goes on the parallel (lane) axis
+        // (the pieces are swapped BEFORE their transforms are fetched: swapping the 5-word records went through scratch memory)
         Task tk; tk.p = p; tk.q = q;
         if (e < NPAIR) { tk.xp = xf_old[p]; tk.xq = xf_old[q]; }
         else { const int op = (e - NPAIR) / NPAIR; tk.xp = xf[op][p]; tk.xq = xf[op][q]; }
-        if (s_hi[tk.p] - s_lo[tk.p] < s_hi[tk.q] - s_lo[tk.q]) { // the larger piece goes on the parallel (lane) axis
-            const int tp = tk.p; tk.p = tk.q; tk.q = tp;
-            const Xf tx = tk.xp; tk.xp = tk.xq; tk.xq = tx;
-        }
         tk.plus = e_plus[e]; tk.minus = e_minus[e];
         tk.np = s_hi[tk.p] - s_lo[tk.p] + 1; tk.nq = s_hi[tk.q] - s_lo[tk.q] + 1;
         tk.base_p = s_cbase[tk.p] + s_lo[tk.p];
@@ -4248,6 +4262,7 @@ struct Ctx {
     int* d_sub_ids = nullptr;     // [n_bins][4], only when some bin has more than one sub-fragment
     unsigned long long *keys = nullptr, *keys_sorted = nullptr;
     int *o2n = nullptr, *perm = nullptr, *cbase = nullptr;
+    int* pstart = nullptr;         // start_bp in position order (the position index's twin: written wherever it is)
     int *len_of2[2] = {nullptr, nullptr}, *contig_off2[2] = {nullptr, nullptr}; // per layout buffer (see k_incr)
     long long* d_part = nullptr;  // [<= 1024][N_STAT] the commit kernel's per-block statistics (published by the next k_incr)
     Changed* d_chg = nullptr;     // [2] commit records: a commit fills one, the relabel that consumes it clears the other
@@ -4594,7 +4609,7 @@ bool strict_dense_cfg()
 }
 
 // reference arithmetic: what k_tm left (sets larger than STRICT_INLINE_M, the queued contacts when there are many), hand-out
-int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out, bool publish, hipStream_t st)
+int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out, bool publish, hipStream_t st, bool chain = false)
 {
     // k_strict_cull needs k_tm's tables and nothing of the scan: it goes out on the AUXILIARY stream, behind k_tm, and runs under
     // the scan; k_strict waits for both (the event on the auxiliary stream, the scan in front of it on its own)
@@ -4678,20 +4693,32 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
             CK(hipEventRecord(h->ev_tm, h->aux));
             CK(hipStreamWaitEvent(st, h->ev_tm, 0));
         }
-        k_gprep<<<GPREP_CLS_BLOCKS + cull_blocks, 256, 0, inorder ? st : h->aux>>>(h->tabs, h->geo, h->link, h->cbase, h->perm, fA, K, rank, world, sx.reach_bp, no_window, sx.quirk,
+        k_gprep<<<GPREP_CLS_BLOCKS + cull_blocks, 256, 0, inorder ? st : h->aux>>>(h->tabs, h->pstart, fA, K, rank, world, sx.reach_bp, no_window, sx.quirk,
                                                                      seg_unit, h->d_slist, h->d_slist_n, h->slist_cap,
                                                                      (unsigned long long*)(h->d_scalars + 10), s2);
         CK(hipGetLastError());
-        if (!inorder) {
+        // Where k_strict2 goes.  chain (the caller launched the scan with write-through queue stores and publishes the step's sums from this
+        // kernel): on the AUXILIARY stream right behind k_gprep -- stream order, no event: a kernel behind an event that completes right in front
+        // of it starts ~10 us late (tools/stamps_s2.py: k_gprep done 24 us, k_strict2 started 35 us) -- and next to the scan, whose completion
+        // its waves await before the queued contacts (S2Args::done).  Else: on the main stream behind the scan, behind k_gprep through an event.
+        chain = chain && !inorder && publish;
+        s2.done = nullptr; s2.n_done = 0; s2.wait_ticks = 0;
+        for (int c = 0; c < N_DONE; c++) s2.done_target[c] = 0ull;
+        if (chain) {
+            s2.done = h->d_done; s2.n_done = scan_done_n(); s2.wait_ticks = std::max(fin_wait_ticks(h), 200000);   // (>= 2 ms: the scan is resident long before a wave gets there)
+            for (int c = 0; c < s2.n_done; c++) s2.done_target[c] = h->scan_done_total[c];   // (this step's scan is launched: its blocks are counted in)
+        }
+        hipStream_t ks = chain ? h->aux : st;
+        if (!inorder && !chain) {
             CK(hipEventRecord(h->ev_tm, h->aux));      // (behind k_tm and k_gprep: tables, classes and unit list complete -- nobody spins for them)
             CK(hipStreamWaitEvent(st, h->ev_tm, 0));
         }
         const size_t sslot = (size_t)(h->sring_calls % (long long)(h->sring.size() / 2));
-        if (h->ev_this_call) CK(hipEventRecord(h->sring[2 * sslot], st));   // (behind the wait: the pair spans the kernel, not the scan in front of it)
-        if (h->single_sub) k_strict2<false><<<blocks, 256, 0, st>>>(fa, sx, s2, K, h->d_slist, h->d_slist_n, d_q_out, publish ? h->res_dev : nullptr, h->seq);
-        else k_strict2<true><<<blocks, 256, 0, st>>>(fa, sx, s2, K, h->d_slist, h->d_slist_n, d_q_out, publish ? h->res_dev : nullptr, h->seq);
+        if (h->ev_this_call) CK(hipEventRecord(h->sring[2 * sslot], ks));   // (behind the wait: the pair spans the kernel, not the scan in front of it)
+        if (h->single_sub) k_strict2<false><<<blocks, 256, 0, ks>>>(fa, sx, s2, K, h->d_slist, h->d_slist_n, d_q_out, publish ? h->res_dev : nullptr, h->seq);
+        else k_strict2<true><<<blocks, 256, 0, ks>>>(fa, sx, s2, K, h->d_slist, h->d_slist_n, d_q_out, publish ? h->res_dev : nullptr, h->seq);
         CK(hipGetLastError());
-        if (h->ev_this_call) { CK(hipEventRecord(h->sring[2 * sslot + 1], st)); h->sring_calls += 1; }
+        if (h->ev_this_call) { CK(hipEventRecord(h->sring[2 * sslot + 1], ks)); h->sring_calls += 1; }
         return GRAAL_OK;
     }
     // the unit list holds at most K * nt (nt + 1) / 2 entries, nt = tiles of the two longest contigs (grow-only)
@@ -4944,7 +4971,7 @@ void graal_destroy(graal_ctx* h)
         if (h->aux) (void)hipStreamSynchronize(h->aux);
         void* ptrs[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->stat, h->sub_rec, h->sub_rec8, h->sub_lab16, h->d_ubins, h->d_ln_tab, h->sub2bin, h->row, h->col, h->cnt, h->queue, h->d_sub_ids, h->d_acc, h->tm_done, h->d_sync, h->d_done, h->d_wq, h->d_flags, h->d_slist, h->d_uset, h->d_cls, h->d_cls_n, h->stat_frag, h->d_dup_bins, h->d_dup_index,
                         h->d_dispatcher, h->d_collector, h->d_sub_ids_all, h->d_rep_obs,
-                        h->keys, h->keys_sorted, h->o2n, h->len_of2[0], h->len_of2[1], h->contig_off2[0], h->contig_off2[1], h->perm, h->cbase, h->link, h->mates, h->cub_tmp, h->tabs, h->step_hdr, h->d_args, h->d_chg, h->d_part,
+                        h->keys, h->keys_sorted, h->o2n, h->len_of2[0], h->len_of2[1], h->contig_off2[0], h->contig_off2[1], h->perm, h->pstart, h->cbase, h->link, h->mates, h->cub_tmp, h->tabs, h->step_hdr, h->d_args, h->d_chg, h->d_part,
                         h->d_scalars, h->d_qout, h->d_dref, h->d_dist};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (h->nccl_comm) { Rccl* R = rccl_load(nullptr); if (R) (void)R->CommDestroy(h->nccl_comm); h->nccl_comm = nullptr; }
@@ -5198,7 +5225,7 @@ int graal_upload_frags(graal_ctx* h, const int32_t* const soa[GRAAL_N_FIELDS], i
             return fail(h, GRAAL_E_ARG, "rep and activ must be 0 or 1");
     }
     if (h->n != n) {
-        void* old[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->keys, h->keys_sorted, h->o2n, h->len_of2[0], h->len_of2[1], h->contig_off2[0], h->contig_off2[1], h->perm, h->cbase, h->link, h->mates, h->cub_tmp};
+        void* old[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->keys, h->keys_sorted, h->o2n, h->len_of2[0], h->len_of2[1], h->contig_off2[0], h->contig_off2[1], h->perm, h->pstart, h->cbase, h->link, h->mates, h->cub_tmp};
         for (void* p : old) if (p) (void)hipFree(p);
         for (int b = 0; b < 2; b++) {
             CK(hipMalloc(&h->soa_mem[b], sizeof(int) * (size_t)n * GRAAL_N_FIELDS));
@@ -5213,6 +5240,7 @@ int graal_upload_frags(graal_ctx* h, const int32_t* const soa[GRAAL_N_FIELDS], i
             CK(hipMalloc(&h->contig_off2[b], sizeof(int) * (size_t)(n + 2)));
         }
         CK(hipMalloc(&h->perm, sizeof(int) * (size_t)n));
+        CK(hipMalloc(&h->pstart, sizeof(int) * (size_t)n));
         CK(hipMalloc(&h->cbase, sizeof(int) * (size_t)n));
         CK(hipMalloc(&h->link, sizeof(Link) * (size_t)n));
         CK(hipMalloc(&h->mates, sizeof(int) * N_MATES * (size_t)n));
@@ -5300,7 +5328,7 @@ static int begin_step_launch(graal_ctx* h, bool defer = false)
     } else if (incr) {
         // exactly one commit since the last ranking: count instead of sort (rank arrays of buffer 1-cur -> buffer cur)
         k_incr<<<blocks_for(n + 1, bs) + 1, bs, 0, h->stream>>>(s, n, h->d_chg + h->chg_last, h->len_of2[1 - cur], h->contig_off2[1 - cur], h->n_contigs,
-                                                           h->len_of2[cur], h->contig_off2[cur], h->perm, h->cbase, h->geo, h->link, h->d_scalars,
+                                                           h->len_of2[cur], h->contig_off2[cur], h->perm, h->pstart, h->cbase, h->geo, h->link, h->d_scalars,
                                                            h->mates, (int*)(h->d_chg + (1 - h->chg_last)), (int)(sizeof(Changed) / sizeof(int)),
                                                            (defer_stats ? nullptr : h->d_part), h->apply_blocks, from_apply ? h->h_stats : nullptr, h->stats_seq);
         CK(hipGetLastError());
@@ -5323,7 +5351,7 @@ static int begin_step_launch(graal_ctx* h, bool defer = false)
         CK(hipGetLastError());
         tb = h->cub_tmp_bytes;
         CK(hipcub::DeviceScan::ExclusiveSum(h->cub_tmp, tb, h->len_of2[cur], h->contig_off2[cur], n + 1, h->stream));
-        k_build_perm<<<nb, bs, 0, h->stream>>>(s, n, h->contig_off2[cur], h->perm, h->cbase);
+        k_build_perm<<<nb, bs, 0, h->stream>>>(s, n, h->contig_off2[cur], h->perm, h->cbase, h->pstart);
         CK(hipGetLastError());
         int rc = refresh(h);
         if (rc) return rc;
@@ -5657,7 +5685,15 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     h->eval_calls += 1;
     const size_t slot = (size_t)(h->ring_calls % (long long)(h->ring.size() / 2));
     if (ev) CK(hipEventRecord(h->ring[2 * slot], st));
-    { int rc_ = launch_scan(h, fA, nb, K, max_id, 0, st, ta.host_res != nullptr); if (rc_) return rc_; }
+    // (reference arithmetic, tiled kernels straight away: k_strict2 is chained behind k_gprep on the auxiliary stream and reads the queue while the
+    // scan may still be storing -- launch_strict)
+    static const bool chain_env = getenv("GRAAL_STRICT_CHAIN") == nullptr || atoi(getenv("GRAAL_STRICT_CHAIN")) != 0;
+    // (spin_ok: kernels of the two streams do run side by side -- else, e.g. under a tool that serialises dispatches, the waves' bounded wait ends
+    // the step as failed, eval_sync repeats it ordered by the host and stays with events: spin_used)
+    const bool s2_chain = chain_env && strict && ta.host_res == nullptr && !(mid || (world > 1 && !late_stage && flat_allowed(h, world))) && h->publish &&
+                          !h->has_rep && scan_done_counter() && !strict_dense_cfg() && h->spin_ok;
+    if (s2_chain) h->spin_used = true;
+    { int rc_ = launch_scan(h, fA, nb, K, max_id, 0, st, ta.host_res != nullptr || s2_chain); if (rc_) return rc_; }
     if (ev) { CK(hipEventRecord(h->ring[2 * slot + 1], st)); h->ring_calls += 1; }
     // (3) finishing kernel -- unless k_tm's last block does that job (it asks for k_fin through the result word if not)
     if (h->has_rep) { // the repeated bins' pixels, densely, for all 13 K candidates
@@ -5676,7 +5712,7 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
             // (several ranks: whoever finishes a step that is not in the late stage -- this rank's finisher may be off while its peers' are on --
             // goes through k_strict_flat first, like a rank that k_tm sent there: the flat and the tiled kernels deal the pairs differently)
             if (mid || (world > 1 && !late_stage && flat_allowed(h, world))) { rc_ = launch_flat(h, fA, &nb, K, rank, world, (long long*)d_q_out, h->publish, st); h->flat_tried = true; }
-            else rc_ = launch_strict(h, fA, K, rank, world, (long long*)d_q_out, h->publish, st);
+            else rc_ = launch_strict(h, fA, K, rank, world, (long long*)d_q_out, h->publish, st, s2_chain);
             if (rc_) return rc_;
             if (!h->publish) { CK(hipEventRecord(h->ev_fin, st)); h->fin_pending = true; }
         }

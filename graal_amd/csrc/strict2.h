@@ -21,6 +21,11 @@ struct S2Args {
     unsigned long long target;   // units the grid wants (a few per wave)
     int draw_min;                // units per wave from which the waves draw their units from the counter instead of taking every n-th
     unsigned long long* next;    // the next unit nobody has taken yet, minus the grid's waves (zero at rest: the step's last block clears it)
+    // k_strict2 launched BEHIND k_gprep on the auxiliary stream, next to the scan instead of behind it (its units need nothing of the scan): the
+    // waves wait here for the scan's completion counters before they turn to the queued contacts.  nullptr: the kernel follows the scan in its stream
+    const unsigned long long* done;
+    int n_done, wait_ticks;
+    unsigned long long done_target[N_DONE];
 };
 
 #if defined(GRAAL_STAMPS) && defined(GRAAL_S2_COUNTS)   // (work counters: per-lane atomics -- they distort the stamps' timeline)
@@ -29,13 +34,13 @@ struct S2Args {
 #define S2_COUNT(i, v) do { } while (0)
 #endif
 
-constexpr int GPREP_CLS_BLOCKS = 64;   // blocks of k_gprep that build classes (one wave per piece pair, round robin); the rest cull
+constexpr int S2_BAL_MAX = 1024;       // units of a step up to which k_strict2 deals its waves to them by their classes
+constexpr int GPREP_CLS_BLOCKS = 144;  // blocks of k_gprep that build classes (one wave per piece pair: 561 pairs at most, 576 waves); the rest cull
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // old bp extent [lo, hi) of tile t (fragments of ONE global piece, consecutive positions of one contig)
-__device__ __forceinline__ void utile_extent(const USet& U, const Geo* __restrict__ geo, const int* __restrict__ perm, int t, int& lo, int& hi, int& g,
-                                             int& cnt)
+__device__ __forceinline__ void utile_extent(const USet& U, const int* __restrict__ pstart, int t, int& lo, int& hi, int& g, int& cnt)
 {
     int off;
     g = utile_piece(U, t, off);
@@ -44,12 +49,11 @@ __device__ __forceinline__ void utile_extent(const USet& U, const Geo* __restric
     const int first = P.lo + off * US_TILE;
     const int left = P.n - off * US_TILE;
     cnt = left < US_TILE ? left : US_TILE;
-    lo = geo[perm[C.base + first]].start_bp;
-    hi = first + cnt >= C.len ? C.lbp : geo[perm[C.base + first + cnt]].start_bp;
+    lo = pstart[C.base + first];
+    hi = first + cnt >= C.len ? C.lbp : pstart[C.base + first + cnt];
 }
 
-__global__ __launch_bounds__(256) void k_gprep(const NbTables* __restrict__ tabs, const Geo* __restrict__ geo, const Link* __restrict__ link,
-                                                const int* __restrict__ cbase, const int* __restrict__ perm, int fA, int K, int rank, int world,
+__global__ __launch_bounds__(256) void k_gprep(const NbTables* __restrict__ tabs, const int* __restrict__ pstart, int fA, int K, int rank, int world,
                                                 int reach_bp, int no_window, int quirk, int seg_unit, unsigned long long* __restrict__ list,
                                                 unsigned long long* __restrict__ list_n, unsigned long long cap,
                                                 unsigned long long* __restrict__ counters, S2Args s2)
@@ -60,30 +64,30 @@ __global__ __launch_bounds__(256) void k_gprep(const NbTables* __restrict__ tabs
     __shared__ unsigned s_live, s_mass;
     __shared__ int s_cuts[US_MAXC * (US_MAXK + 1)], s_ncut[US_MAXC];
     __shared__ Xf s_xf[MAXK][N_OPS][NP];
-    __shared__ int s_row[4];
-    __shared__ int s_ne[256], s_off[257], s_tp[256];
+    __shared__ int s_ne[256], s_off[257], s_tp[256], s_pr[256];
+    __shared__ unsigned long long s_cmask[4][US_NCAND][4];   // the class blocks' membership masks, per wave
     __shared__ unsigned long long s_base;
-    const int t = threadIdx.x, lane = t & 63, wib = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, wib = rfl(t >> 6);
     STAMP(11, blockIdx.x == 0 && t == 0);
+    STAMP_MAX(25, t == 0);
     if (t == 0) { s_live = 0; s_mass = 0; }
     __syncthreads();
-    if (t <= K) {   // thread K: fA; threads 0..K-1: the neighbours
-        const int f = t == K ? fA : tabs[t].fB;
-        const Geo g = geo[f];
-        const Link l = link[f];
-        UEnd e; e.label = g.id_c; e.pos = geo_pos(g.flags); e.base = cbase[f]; e.len = l.l_cont; e.lbp = l.l_cont_bp; e.circ = (g.flags >> 1) & 1;
-        if (t == K) s_A = e;
+    if (t <= K) {   // thread K: fA; threads 0..K-1: the neighbours.  (The ends' records come from k_tm's tables: fragment -> geometry -> contig base
+                    // were three dependent round trips, 10 us of them under a scan that saturates the memory system)
+        if (t == K) s_A = tabs[0].endA;
         else {
-            s_B[t] = e;
+            s_B[t] = tabs[t].endB;
             s_keys[t] = tabs[t].key;
-            if (f != fA) atomicOr(&s_live, 1u << t);
+            if (tabs[t].fB != fA) atomicOr(&s_live, 1u << t);
             if (tabs[t].set_m > 0) atomicOr(&s_mass, 1u << t);   // (0: fB == fA, or its fragment pairs were priced by k_tm already)
         }
     }
     for (int i = t; i < K * N_OPS * NP; i += 256) { const int k = i / (N_OPS * NP), r = i - k * (N_OPS * NP); s_xf[k][r / NP][r % NP] = tabs[k].xf[r / NP][r % NP]; }
     __syncthreads();
+    STAMP(21, blockIdx.x == 0 && t == 0);
     if (t == 0) uset_build_geometry(s_U, s_A, s_B, K, s_live, s_mass, s_cuts, s_ncut);
     __syncthreads();
+    STAMP(22, blockIdx.x == 0 && t == 0);
     for (int i = t; i < s_U.n_pieces * US_MAXK; i += 256) uset_piece_pk(s_U, s_keys, K, i / US_MAXK, i % US_MAXK);
     __syncthreads();
     const USet& U = s_U;
@@ -105,6 +109,7 @@ __global__ __launch_bounds__(256) void k_gprep(const NbTables* __restrict__ tabs
             const int pair = upair_index(g, h);
             const InputsKey old = inputs_key(uxf_old(U, g), uxf_old(U, h), quirk != 0);
             InputsKey key[3];
+            Xf xa[3], xb[3];
             bool un[3], ms[3];
 #pragma unroll
             for (int r = 0; r < 3; r++) {
@@ -112,39 +117,68 @@ __global__ __launch_bounds__(256) void k_gprep(const NbTables* __restrict__ tabs
                 un[r] = false;
                 ms[r] = cand < K * N_OPS && ((U.mass >> k) & 1u);
                 key[r] = old;
+                xa[r] = uxf_old(U, g); xb[r] = xa[r];
                 if (cand < K * N_OPS) {
                     const int pg = U.p[g].pk[k], ph = U.p[h].pk[k];
                     if (pg && ph) {
-                        key[r] = inputs_key(s_xf[k][op][pg], s_xf[k][op][ph], quirk != 0);
+                        xa[r] = s_xf[k][op][pg]; xb[r] = s_xf[k][op][ph];
+                        key[r] = inputs_key(xa[r], xb[r], quirk != 0);
                         un[r] = !ikey_eq(key[r], old);
                     }
                 }
             }
             GClass* out = s2.cls + (size_t)pair * US_NCAND;
             int nc = 0;
+            STAMP_MAX(26, lane == 0);
+            // One round per class: the first unassigned candidate leads, the lanes with its key join.  A round is a chain -- ballots, the leader's
+            // key, compares -- of a wave that has its SIMD to itself, so it is kept short (built by lane 0 from LDS, record by record, with the
+            // class's masks by six more ballots, a round was 0.25 us and the classes of a pair 10 us of this kernel): the key comes through
+            // v_readlane (the leader's lane is wave-uniform), a candidate only NOTES its class; the masks are ORed together in LDS behind the
+            // rounds, all candidates at once, and every leader writes its own record from the transforms it already holds.
+            int cls_of[3] = {-1, -1, -1};
+            bool lead_r[3] = {false, false, false};
             for (;;) {
                 const unsigned long long b0 = __ballot(un[0]), b1 = __ballot(un[1]), b2 = __ballot(un[2]);
                 if (!(b0 | b1 | b2)) break;
                 const int r = b0 ? 0 : (b1 ? 1 : 2);
                 const unsigned long long br = b0 ? b0 : (b1 ? b1 : b2);
                 const int ll = __ffsll((long long)br) - 1;
-                const InputsKey mine = r == 0 ? key[0] : (r == 1 ? key[1] : key[2]);
-                InputsKey lead;
-                lead.x = __shfl(mine.x, ll, 64); lead.y = __shfl(mine.y, ll, 64); lead.z = __shfl(mine.z, ll, 64); lead.w = __shfl(mine.w, ll, 64);
-                bool m[3];
+                // (word by word: `r == 0 ? key[0] : ...` on the structs selects an ADDRESS, which kept the three keys in scratch memory)
+                InputsKey mine, lead;
+                mine.x = r == 0 ? key[0].x : (r == 1 ? key[1].x : key[2].x); mine.y = r == 0 ? key[0].y : (r == 1 ? key[1].y : key[2].y);
+                mine.z = r == 0 ? key[0].z : (r == 1 ? key[1].z : key[2].z); mine.w = r == 0 ? key[0].w : (r == 1 ? key[1].w : key[2].w);
+                lead.x = __builtin_amdgcn_readlane(mine.x, ll); lead.y = __builtin_amdgcn_readlane(mine.y, ll);
+                lead.z = __builtin_amdgcn_readlane(mine.z, ll); lead.w = __builtin_amdgcn_readlane(mine.w, ll);
 #pragma unroll
-                for (int q = 0; q < 3; q++) { m[q] = un[q] && ikey_eq(key[q], lead); un[q] = un[q] && !m[q]; }
-                const unsigned long long m0 = __ballot(m[0]), m1 = __ballot(m[1]), m2 = __ballot(m[2]);
-                const unsigned long long w0 = __ballot(m[0] && ms[0]), w1 = __ballot(m[1] && ms[1]), w2 = __ballot(m[2] && ms[2]);
-                if (lane == 0) {
-                    const int cand = ll + 64 * r, k = cand / N_OPS, op = cand - k * N_OPS;
-                    GClass c = gclass_make(s_xf[k][op][U.p[g].pk[k]], s_xf[k][op][U.p[h].pk[k]], cand);
-                    c.m0 = m0; c.m1 = m1; c.m2 = (unsigned)(m2 & 3ull);
-                    c.w0 = w0; c.w1 = w1; c.w2 = (unsigned)(w2 & 3ull);
-                    out[nc] = c;
+                for (int q = 0; q < 3; q++) {
+                    const bool m = un[q] && ikey_eq(key[q], lead);
+                    if (m) { cls_of[q] = nc; un[q] = false; lead_r[q] = (q == r) && lane == ll; }
                 }
                 nc++;
             }
+            unsigned long long (*const cm)[4] = s_cmask[wib];   // per class: members 0..63, 64..127, 128..129 | the "mass" members likewise, packed below
+            for (int c = lane; c < nc; c += 64) { cm[c][0] = 0; cm[c][1] = 0; cm[c][2] = 0; cm[c][3] = 0; }
+            WAVE_LDS_SYNC();
+#pragma unroll
+            for (int q = 0; q < 3; q++)
+                if (cls_of[q] >= 0) {
+                    // word 0 / 1: members (candidates 0..63 / 64..127); word 2: members 128, 129 in bits 0, 1 and the mass members 128, 129 in bits 2, 3;
+                    // word 3 is not enough for two more 64-bit masks: the mass members 0..127 are the members ANDed with the wave's mass ballots
+                    if (q < 2) atomicOr(&cm[cls_of[q]][q], 1ull << lane);
+                    else atomicOr(&cm[cls_of[q]][2], (1ull << lane) | (ms[2] ? (4ull << lane) : 0ull));
+                }
+            const unsigned long long ms0 = __ballot(ms[0]), ms1 = __ballot(ms[1]);
+            WAVE_LDS_SYNC();
+#pragma unroll
+            for (int q = 0; q < 3; q++)
+                if (lead_r[q]) {
+                    GClass c = gclass_make(xa[q], xb[q], lane + 64 * q);
+                    const unsigned long long* w = cm[cls_of[q]];
+                    c.m0 = w[0]; c.m1 = w[1]; c.m2 = (unsigned)(w[2] & 3ull);
+                    c.w0 = w[0] & ms0; c.w1 = w[1] & ms1; c.w2 = (unsigned)((w[2] >> 2) & 3ull);
+                    out[cls_of[q]] = c;
+                }
+            WAVE_LDS_SYNC();   // (the next pair of this wave clears the masks again)
             if (lane == 0) s2.cls_n[pair] = nc;
         }
         STAMP_MAX(13, lane == 0);
@@ -157,18 +191,18 @@ __global__ __launch_bounds__(256) void k_gprep(const NbTables* __restrict__ tabs
     const int seg = seg_unit, R = 1;
     const int n_cull = (int)gridDim.x - GPREP_CLS_BLOCKS;
     for (int ti = (int)blockIdx.x - GPREP_CLS_BLOCKS; ti < n_tiles; ti += n_cull) {
-        __syncthreads();
-        if (t == 0) { int lo, hi, g, cnt; utile_extent(U, geo, perm, ti, lo, hi, g, cnt); s_row[0] = lo; s_row[1] = hi; s_row[2] = g; s_row[3] = cnt; }
-        __syncthreads();
-        const int xlo = s_row[0], xhi = s_row[1], g = s_row[2], cnt_i = s_row[3];
+        // (the row's extent by every thread for itself, next to its own tile's: the same two addresses for all lanes, one round trip for both tiles --
+        // fetched by thread 0 and handed round through LDS they were two more dependent round trips in front of every row)
+        int xlo, xhi, g, cnt_i;
+        utile_extent(U, pstart, ti, xlo, xhi, g, cnt_i);
         const int cx = U.p[g].contig;
         for (int tj0 = ti; tj0 < n_tiles; tj0 += 256) {
             const int tj = tj0 + t;
             bool alive = false;
-            int cnt_j = 0;
+            int cnt_j = 0, h = g;
             if (tj < n_tiles && ((ti + tj) % world) == rank) {
-                int ylo, yhi, h;
-                utile_extent(U, geo, perm, tj, ylo, yhi, h, cnt_j);
+                int ylo, yhi;
+                utile_extent(U, pstart, tj, ylo, yhi, h, cnt_j);
                 const bool near_old = U.p[h].contig == cx && max(ylo - xhi, xlo - yhi) <= reach_bp;
                 const InputsKey old = inputs_key(uxf_old(U, g), uxf_old(U, h), quirk != 0);
                 for (int k = 0; k < K && !alive; k++) {
@@ -192,6 +226,7 @@ __global__ __launch_bounds__(256) void k_gprep(const NbTables* __restrict__ tabs
             // of them: written by its own thread, one after the other, they were most of this kernel at mid-size shapes)
             s_ne[t] = ne;
             s_tp[t] = tj | (lanes_first << 16) | (cs << 17);
+            s_pr[t] = upair_index(g, h);
             __syncthreads();
             if (t < 64) wave_excl_scan(s_ne, s_off, 256);
             __syncthreads();
@@ -206,7 +241,7 @@ __global__ __launch_bounds__(256) void k_gprep(const NbTables* __restrict__ tabs
                     const int e = o - s_off[lo], tp = s_tp[lo];
                     const int cs_o = (tp >> 17) & 127, j0 = (e / R) * seg, c = cs_o - j0 < seg ? cs_o - j0 : seg;
                     const unsigned long long at = base + (unsigned long long)o;
-                    if (at < cap) list[at] = uunit_pack(ti, tp & 0xffff, j0, c, (tp >> 16) & 1, e % R, R);
+                    if (at < cap) list[at] = uunit_pack(ti, tp & 0xffff, j0, c, (tp >> 16) & 1, e % R, R, s_pr[lo]);
                     else atomicOr(&counters[6], 2ull);   // (cannot happen: the host sizes the list)
                 }
             }
@@ -278,7 +313,8 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
     const Geo* __restrict__ geo = fa.geo;
     const Stat* __restrict__ stat = fa.stat;
     unsigned long long* __restrict__ counters = fa.counters;
-    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wib = rfl(threadIdx.x >> 6);   // (wave-uniform, and the compiler is told so: what hangs on it -- the wave's
+                                                                      // unit numbers, its LDS rows, the class loop's bounds -- lives in scalar registers)
     const int wave = blockIdx.x * 4 + wib, n_waves = gridDim.x * 4;
     __shared__ USet s_U;
     __shared__ long long s_acc[US_NCAND];
@@ -289,6 +325,7 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
     constexpr int CLS_CHUNK = 32;              // class records of a unit's piece pair staged per wave (a pair has up to 130; most have a dozen)
     __shared__ GClass s_cls[4][CLS_CHUNK];
     __shared__ unsigned long long s_ent[4][16];   // the unit-list entries a wave is working through
+    __shared__ int s_pref[S2_BAL_MAX + 1], s_bsum[256], s_boff[257];   // the waves of a step's few units (see `bal`)
     STAMP(16, blockIdx.x == 0 && threadIdx.x == 0);
     for (int i = threadIdx.x; i < US_NCAND; i += 256) s_acc[i] = 0;
     {
@@ -298,7 +335,8 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
     }
     __syncthreads();
     const USet& U = s_U;
-    const unsigned long long nq_total = counters[2];              // written by k_scan, an earlier kernel on the stream
+    const bool chain = s2.done != nullptr;
+    unsigned long long nq_total = chain ? 0ull : counters[2];     // written by k_scan: an earlier kernel on the stream, or (chain) awaited below
     const unsigned long long n_units = min(*list_n, sa.list_cap); // written by k_gprep (ordered by an event)
     const float nfpb = sa.nfpb;
     const Par par = sa.par;
@@ -309,6 +347,7 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
     float (*const cy)[4] = s_cy[wib];
     float (*const exo)[64] = s_exo[wib];
     STAMP(17, blockIdx.x == 0 && threadIdx.x == 0);
+    STAMP_FBLK(0, threadIdx.x == 0);
     // ---- (1) the listed units.  The list holds entries of at most seg_unit fragments of the segment side; a wave takes m neighbouring
     // entries -- merged into one unit where they continue each other (many entries: fewer, longer units, the lanes' side loaded once) -- or
     // one entry is dealt to R waves that share its classes (few entries: a unit's depth, all classes of a pair one after the other, is what a
@@ -322,20 +361,69 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
         if (mrg == 1) while (2 * rep_n <= s2.rep_max && n_units * (unsigned long long)(2 * rep_n) <= (unsigned long long)n_waves) rep_n <<= 1;
     }
     S2_COUNT(7, (blockIdx.x == 0 && threadIdx.x == 0) ? (unsigned long long)n_units * 1000000ull + (unsigned long long)(mrg * 100 + rep_n) : 0ull);
-    const unsigned long long n_virtual = (fa.skip & 1) ? 0ull : ((n_units + (unsigned long long)mrg - 1ull) / (unsigned long long)mrg) * (unsigned long long)rep_n;
+    // A step with fewer units than waves (contigs of a few hundred bins): the waves are dealt to the units BY THEIR CLASSES.  A unit's cost
+    // is its piece pair's classes -- 0 to 60 of them, one pass over the unit each -- and with the same number of waves for every unit the
+    // step waited for the waves of the heaviest one (C2 stand-in, 7 contigs: 348 units, wave 0 of the blocks done with its units after 17 us
+    // on average, the last one after 47).  Every block derives the same plan: classes per unit from the entries' pair index, q classes per
+    // wave so that the plan fits the grid, units u's waves = [s_pref[u], s_pref[u + 1]).
+    const bool bal = mrg == 1 && n_units > 0ull && n_units <= (unsigned long long)S2_BAL_MAX && n_units * 2ull <= (unsigned long long)n_waves && s2.rep_max > 1;
+    if (bal) {
+        const int nu = (int)n_units, t = threadIdx.x;
+        int ncu[4], mine = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int u = 4 * t + i;
+            ncu[i] = 0;
+            if (u < nu) { const int nc_u = s2.cls_n[uunit_pair(list[u])]; ncu[i] = nc_u > 1 ? nc_u : 1; }
+            mine += ncu[i];
+        }
+        s_bsum[t] = mine;
+        __syncthreads();
+        if (t < 64) wave_excl_scan(s_bsum, s_boff, 256);
+        __syncthreads();
+        // (an eighth of the grid stays free for the queued contacts: the waves without a unit price them while the others are at their units; with
+        // every wave at a unit the contacts waited for the units, 10 us more on the C2 stand-in)
+        const int c_res = n_waves / 8;
+        const int total = s_boff[256], spare = max(n_waves - c_res - nu, 1);
+        const int q = spare > 0 ? (total + spare - 1) / spare : total;     // sum of ceil(nc / q) <= total / q + units <= waves
+        __syncthreads();
+        mine = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { ncu[i] = ncu[i] > 0 ? (ncu[i] + q - 1) / (q > 0 ? q : 1) : 0; mine += ncu[i]; }
+        s_bsum[t] = mine;
+        __syncthreads();
+        if (t < 64) wave_excl_scan(s_bsum, s_boff, 256);
+        __syncthreads();
+        int at = s_boff[t];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const int u = 4 * t + i; if (u < nu) s_pref[u] = at; at += ncu[i]; }
+        if (t == 0) s_pref[nu] = s_boff[256];
+        __syncthreads();
+    }
+    const unsigned long long n_virtual = (fa.skip & 1) ? 0ull : (bal ? (unsigned long long)s_pref[(int)n_units] :
+                                         ((n_units + (unsigned long long)mrg - 1ull) / (unsigned long long)mrg) * (unsigned long long)rep_n);
     // a wave's first unit is its own number; the others it draws from a counter -- the draw goes out when a unit is started and is read
     // when it is finished (units differ in cost by the classes of their piece pair and by the window: dealt round robin, the waves that
     // got the heavy ones finished a fifth of the kernel after the others)
     const bool draw = n_virtual >= (unsigned long long)s2.draw_min * (unsigned long long)n_waves;   // (few units per wave: dealt round robin -- a draw is a round trip)
+    const int rep_sh = __ffs(rep_n) - 1;
     for (unsigned long long v = (unsigned long long)wave; v < n_virtual;) {
       unsigned long long drawn = 0;
       if (draw && lane == 0) drawn = atomicAdd(s2.next, 1ull);
-      const int rep_r = (int)(v % (unsigned long long)rep_n);
-      const unsigned long long e0 = (v / (unsigned long long)rep_n) * (unsigned long long)mrg;
+      int rep_r = (int)(v & (unsigned long long)(rep_n - 1));                             // (rep_n, mrg: powers of two)
+      unsigned long long e0 = (v >> rep_sh) * (unsigned long long)mrg;
+      if (bal) {   // the unit whose waves hold number v
+          int lo = 0, hi = (int)n_units - 1;
+          while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_pref[mid] <= (int)v) lo = mid; else hi = mid - 1; }
+          e0 = (unsigned long long)lo;
+          rep_r = (int)v - s_pref[lo];
+          rep_n = s_pref[lo + 1] - s_pref[lo];
+      }
       const int m_in = (int)(min(n_units, e0 + (unsigned long long)mrg) - e0);
       // the group's entries, one per lane (one round trip); runs of entries that continue each other become one unit
       if (lane < m_in) s_ent[wib][lane] = list[e0 + (unsigned long long)lane];   // (kept in LDS: live across a unit they cost registers the pair loop needs)
       WAVE_LDS_SYNC();
+      STAMP_FBLK(1, threadIdx.x == 0 && v == (unsigned long long)wave && s_ent[wib][0] != 0xffffffffffffffffull);
       int pos = 0;
       while (pos < m_in) {
         const unsigned long long my = lane < m_in ? s_ent[wib][lane] : 0ull;
@@ -376,6 +464,7 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
             tile[lane] = y;
         }
         WAVE_LDS_SYNC();
+        STAMP_FBLK(2, threadIdx.x == 0 && v == (unsigned long long)wave && pos == run && tile[0].frag >= 0 && gL.start_bp != -12345);
         const bool cis_old = rfl(PL.contig) == rfl(PS.contig);
         const int circ_old = rfl(CL.circ), lbp_old = rfl(CL.lbp);
         // old bp extents of the two sides (positions grow with start_bp inside a contig)
@@ -426,6 +515,7 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
                               // bin with itself; copies of repeated bins -- no sub-fragments here -- are priced by k_rep_delta)
         for (int j = 0; j < cnt; j++)
             if (has_l && stL.n > 0 && tile[j].st.n > 0 && !(diag && !(lane < j0 + j))) vmask |= 1u << j;
+        STAMP_FBLK(3, threadIdx.x == 0 && v == (unsigned long long)wave && pos == run);
         for (int c = -1; c < nc; c = c < 0 ? rep_r : c + rep_n) {     // c = -1: the current layout (its values are kept in LDS), then this wave's classes
             bool cis = cis_old;
             int circ = cis_old ? circ_old : 0, lbp = lbp_old, sig_l = 1, sig_s = 1, off_l = 0, off_s = 0;
@@ -556,7 +646,25 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
     {
         QSrc qs;
         qs.queue = fa.queue; qs.geo2 = reinterpret_cast<const int2*>(geo); qs.cnt = fa.cnt; qs.keys = nullptr; qs.live = 0; qs.K = K;
-        qs.seq = (unsigned)seq; qs.concurrent = 0; qs.multi = fa.multi;
+        qs.seq = (unsigned)seq; qs.concurrent = chain ? 1 : 0; qs.multi = fa.multi;
+        if (chain) {
+            // the scan runs next to this kernel: complete when its blocks have all added themselves to the completion counters (k_tm's finishing
+            // block waits the same way).  It was launched first and its whole grid is resident from the start, so the wait is over before most
+            // waves get here; the bound is the exit every wave reaches if it is not (the step then fails: counters[6])
+            const unsigned long long t_end = wall_clock64() + (unsigned long long)s2.wait_ticks;
+            bool ok = false;
+            for (;;) {
+                bool missing = false;
+                if (lane < s2.n_done) missing = __hip_atomic_load(s2.done + DONE_STRIDE * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < s2.done_target[lane];
+                if (__ballot(missing) == 0ull) { ok = true; break; }
+                if (__ballot(wall_clock64() > t_end) != 0ull) break;
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (!ok && lane == 0) atomicOr(&counters[6], 8ull);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            nq_total = ok ? __hip_atomic_load(&counters[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            nq_total = ((unsigned long long)(unsigned)rfl((int)(nq_total >> 32)) << 32) | (unsigned long long)(unsigned)rfl((int)nq_total);
+        }
         // (a step with fewer units than waves: the waves WITHOUT a unit take the contacts -- if their lanes can hold them all -- and price them while
         // the others are still at their units; else every wave takes its share behind its units, from the other end of the grid)
         const unsigned long long n_idle = n_virtual < (unsigned long long)n_waves ? (unsigned long long)n_waves - n_virtual : 0ull;

@@ -167,11 +167,15 @@ GR_HD int gclass_start(int sigma_pos, int off, int start_bp, int len_bp) { retur
 //   bits 45..47 r, 48..51 R: the unit is dealt to R waves, wave r of them prices the classes r, r + R, r + 2R, ... of its piece pair (each with
 //   the current layout's values of its own: when a step has few units, their depth -- all classes of a pair one after the other --
 //   is what the step waits for)
-GR_HD unsigned long long uunit_pack(int ti, int tj, int j0, int cnt, int lanes_first, int r = 0, int R = 1)
+//   bits 52..61: the index of the tiles' pair of global pieces (upair_index): what k_strict2 needs to find the unit's classes -- and their
+//   number, by which it deals a step's few units to its many waves -- without walking the set's pieces
+GR_HD unsigned long long uunit_pack(int ti, int tj, int j0, int cnt, int lanes_first, int r = 0, int R = 1, int pair = 0)
 {
     return (unsigned long long)ti | ((unsigned long long)tj << 16) | ((unsigned long long)j0 << 32) | ((unsigned long long)cnt << 38) |
-           ((unsigned long long)(lanes_first ? 1 : 0) << 44) | ((unsigned long long)r << 45) | ((unsigned long long)R << 48);
+           ((unsigned long long)(lanes_first ? 1 : 0) << 44) | ((unsigned long long)r << 45) | ((unsigned long long)R << 48) |
+           ((unsigned long long)pair << 52);
 }
+GR_HD int uunit_pair(unsigned long long u) { return (int)((u >> 52) & 1023ull); }
 GR_HD int utile_count(const USet& U, int t)
 {
     int off;

@@ -34,10 +34,13 @@ max_id = smp.modify_gl_cuda_buffer(0)
 L = lib.load()
 L.graal_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
 L.graal_debug_hitstat.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
-names = {0: "k_tm start", 3: "k_tm released its tables", 8: "k_scan start", 10: "k_scan block 0 loop done", 11: "k_gprep start", 12: "k_gprep: union set built", 13: "k_gprep: classes done (last wave)",
+names = {0: "k_tm start", 3: "k_tm released its tables", 8: "k_scan start", 10: "k_scan block 0 loop done", 11: "k_gprep start", 12: "k_gprep: union set built", 13: "k_gprep: classes done (last wave)", 21: "k_gprep: ends and transforms loaded", 22: "k_gprep: geometry built (thread 0)", 23: "k_strict2: last block started",
+         24: "k_strict2: last block past its prologue", 25: "k_gprep: last block started", 28: "k_strict2: last unit's fragments and classes loaded", 29: "k_strict2: last unit's current-layout pass done", 26: "k_gprep: last class wave has its keys",
          14: "k_gprep: unit list done (last block)", 16: "k_strict2 start", 17: "k_strict2 prologue done", 18: "k_strict2 units done (last wave)", 19: "k_strict2 contacts done (last wave)",
          20: "k_strict2 sums handed out"}
 acc = np.zeros(32); cnt = np.zeros(32); hs = np.zeros(8); n = 0
+blk_mean = np.zeros(4); blk_max = np.zeros(4); blk_n = np.zeros(4)
+L.graal_debug_block_stamps.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
 import time
 smp.engine.set_timing(0)
 wall = 0.0
@@ -54,6 +57,17 @@ for f in rng.randint(0, NB, size=(12 if shape == "c5late" else (400 if shape == 
     st = st.astype(np.float64)
     if st[16] == 0:
         continue
+    bk = np.zeros(4096 * 4, dtype=np.uint64)
+    assert L.graal_debug_block_stamps(smp.engine._h, bk.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))) == 0
+    bk = bk.reshape(4096, 4)[2048:].astype(np.float64)
+    live = bk[:, 0] >= min(st[0], st[8])        # the blocks of THIS step's k_strict2
+    if live.any():
+        d_ = (bk[live] - min(st[0], st[8])) * 0.01
+        ok_ = bk[live] > 0
+        for j in range(4):
+            col = d_[:, j][ok_[:, j] & (d_[:, j] > 0) & (d_[:, j] < 1e6)]
+            if len(col):
+                blk_mean[j] += col.mean(); blk_max[j] += col.max(); blk_n[j] += 1
     t0 = min(st[0], st[8])
     d = (st - t0) * 0.01
     ok = (st > 0) & (np.abs(d) < 1e6)
@@ -65,4 +79,7 @@ print("shape %s: %d proposals through k_strict2, %.1f us per scoring call (host 
 for i in sorted(names):
     if cnt[i] > 0:
         print("%-44s %8.2f us" % (names[i], a[i]))
+for j, nm in enumerate(("past the prologue", "wave 0, first unit: list entries read", "wave 0, first unit: fragments and class records in", "wave 0, first unit: at the class loop")):
+    if blk_n[j] > 0:
+        print("k_strict2 blocks, %-52s mean %8.2f us   last %8.2f us" % (nm, blk_mean[j] / blk_n[j], blk_max[j] / blk_n[j]))
 print("per step: list entries %.0f, merged x%.2f, shared by %.2f waves, (unit, layout) passes %.0f, fragment pairs priced in them %.3g" % (hs[4] / n, hs[3] / n, hs[2] / n, hs[5] / n, hs[6] / n))
