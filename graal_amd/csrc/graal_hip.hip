@@ -4697,10 +4697,12 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
                                                                      seg_unit, h->d_slist, h->d_slist_n, h->slist_cap,
                                                                      (unsigned long long*)(h->d_scalars + 10), s2);
         CK(hipGetLastError());
-        // Where k_strict2 goes.  chain (the caller launched the scan with write-through queue stores and publishes the step's sums from this
-        // kernel): on the AUXILIARY stream right behind k_gprep -- stream order, no event: a kernel behind an event that completes right in front
-        // of it starts ~10 us late (tools/stamps_s2.py: k_gprep done 24 us, k_strict2 started 35 us) -- and next to the scan, whose completion
-        // its waves await before the queued contacts (S2Args::done).  Else: on the main stream behind the scan, behind k_gprep through an event.
+        // Where k_strict2 goes.  chain (one rank; the caller launched the scan with write-through queue stores and publishes the step's sums from
+        // this kernel): on the AUXILIARY stream right behind k_gprep -- stream order, no event: a kernel behind an event of another stream starts
+        // ~10 us late, whether the event completes right in front of it or has long completed (tools/stamps_s2.py, C2 stand-in: k_gprep done 24 us,
+        // k_strict2 started 35 us behind k_gprep's event on the main stream, 36 us behind an event of the scan on the auxiliary stream, 26 us in
+        // stream order) -- and NEXT to the scan, whose completion counters its waves await before the queued contacts (S2Args::done).
+        // Else: on the main stream behind the scan, behind k_gprep through an event.
         chain = chain && !inorder && publish;
         s2.done = nullptr; s2.n_done = 0; s2.wait_ticks = 0;
         for (int c = 0; c < N_DONE; c++) s2.done_target[c] = 0ull;
@@ -5687,10 +5689,13 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     if (ev) CK(hipEventRecord(h->ring[2 * slot], st));
     // (reference arithmetic, tiled kernels straight away: k_strict2 is chained behind k_gprep on the auxiliary stream and reads the queue while the
     // scan may still be storing -- launch_strict)
-    static const bool chain_env = getenv("GRAAL_STRICT_CHAIN") == nullptr || atoi(getenv("GRAAL_STRICT_CHAIN")) != 0;
+    // (GRAAL_STRICT_CHAIN=1; off by default: 8-10 us less per scoring call on its own, but in full runs -- the commit's kernels and the in-step full
+    // evaluation on their streams next to the step's -- not a gain (C2 stand-in, 100 cycles: 130 us per step without, 134-146 with), and on the
+    // C4 stand-in the scan was once kept off the CUs by the waiting waves until their bound ran out)
+    static const bool chain_env = getenv("GRAAL_STRICT_CHAIN") != nullptr && atoi(getenv("GRAAL_STRICT_CHAIN")) != 0;
     // (spin_ok: kernels of the two streams do run side by side -- else, e.g. under a tool that serialises dispatches, the waves' bounded wait ends
     // the step as failed, eval_sync repeats it ordered by the host and stays with events: spin_used)
-    const bool s2_chain = chain_env && strict && ta.host_res == nullptr && !(mid || (world > 1 && !late_stage && flat_allowed(h, world))) && h->publish &&
+    const bool s2_chain = chain_env && strict && ta.host_res == nullptr && !mid && world == 1 && h->publish &&
                           !h->has_rep && scan_done_counter() && !strict_dense_cfg() && h->spin_ok;
     if (s2_chain) h->spin_used = true;
     { int rc_ = launch_scan(h, fA, nb, K, max_id, 0, st, ta.host_res != nullptr || s2_chain); if (rc_) return rc_; }
@@ -5852,6 +5857,8 @@ static int eval_sync(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int
         // Everything of the step has ended by now; put the step's accumulators back to rest and repeat it ordered by the host --
         // and stay with events from here on.
         h->spin_ok = false; h->spin_used = false;
+        fprintf(stderr, "graal: kernels of the engine's two streams did not run side by side (a tool that serialises dispatches?): step repeated, "
+                        "the steps are ordered through events from here on\n");
         if (h->pub_in_flight) h->stats_pub_pending = true;   // (its publication block gave up with the others)
         CK(hipStreamSynchronize(h->stream));
         CK(hipStreamSynchronize(h->aux));
