@@ -4609,7 +4609,7 @@ bool strict_dense_cfg()
 }
 
 // reference arithmetic: what k_tm left (sets larger than STRICT_INLINE_M, the queued contacts when there are many), hand-out
-int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out, bool publish, hipStream_t st, bool chain = false)
+int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out, bool publish, hipStream_t st)
 {
     // k_strict_cull needs k_tm's tables and nothing of the scan: it goes out on the AUXILIARY stream, behind k_tm, and runs under
     // the scan; k_strict waits for both (the event on the auxiliary stream, the scan in front of it on its own)
@@ -4697,24 +4697,16 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
                                                                      seg_unit, h->d_slist, h->d_slist_n, h->slist_cap,
                                                                      (unsigned long long*)(h->d_scalars + 10), s2);
         CK(hipGetLastError());
-        // Where k_strict2 goes.  chain (one rank; the caller launched the scan with write-through queue stores and publishes the step's sums from
-        // this kernel): on the AUXILIARY stream right behind k_gprep -- stream order, no event: a kernel behind an event of another stream starts
-        // ~10 us late, whether the event completes right in front of it or has long completed (tools/stamps_s2.py, C2 stand-in: k_gprep done 24 us,
-        // k_strict2 started 35 us behind k_gprep's event on the main stream, 36 us behind an event of the scan on the auxiliary stream, 26 us in
-        // stream order) -- and NEXT to the scan, whose completion counters its waves await before the queued contacts (S2Args::done).
-        // Else: on the main stream behind the scan, behind k_gprep through an event.
-        chain = chain && !inorder && publish;
-        s2.done = nullptr; s2.n_done = 0; s2.wait_ticks = 0;
-        for (int c = 0; c < N_DONE; c++) s2.done_target[c] = 0ull;
-        if (chain) {
-            s2.done = h->d_done; s2.n_done = scan_done_n(); s2.wait_ticks = std::max(fin_wait_ticks(h), 200000);   // (>= 2 ms: the scan is resident long before a wave gets there)
-            for (int c = 0; c < s2.n_done; c++) s2.done_target[c] = h->scan_done_total[c];   // (this step's scan is launched: its blocks are counted in)
-        }
-        hipStream_t ks = chain ? h->aux : st;
-        if (!inorder && !chain) {
+        // (k_strict2 on the auxiliary stream right behind k_gprep -- stream order instead of the event, next to the scan, its waves waiting for the
+        // scan's completion counters before the queued contacts -- was tried: it starts 9 us earlier (a kernel behind an event of another stream
+        // starts ~10 us late whether the event completes right in front of it or has long completed), but full runs gained nothing (C2 stand-in,
+        // 100 cycles: 130 us per step without, 134-146 with) and on the C4 stand-in the waiting waves once kept the scan off the CUs until their
+        // bound ran out.  Not kept.)
+        if (!inorder) {
             CK(hipEventRecord(h->ev_tm, h->aux));      // (behind k_tm and k_gprep: tables, classes and unit list complete -- nobody spins for them)
             CK(hipStreamWaitEvent(st, h->ev_tm, 0));
         }
+        hipStream_t ks = st;
         const size_t sslot = (size_t)(h->sring_calls % (long long)(h->sring.size() / 2));
         if (h->ev_this_call) CK(hipEventRecord(h->sring[2 * sslot], ks));   // (behind the wait: the pair spans the kernel, not the scan in front of it)
         if (h->single_sub) k_strict2<false><<<blocks, 256, 0, ks>>>(fa, sx, s2, K, h->d_slist, h->d_slist_n, d_q_out, publish ? h->res_dev : nullptr, h->seq);
@@ -5687,18 +5679,7 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     h->eval_calls += 1;
     const size_t slot = (size_t)(h->ring_calls % (long long)(h->ring.size() / 2));
     if (ev) CK(hipEventRecord(h->ring[2 * slot], st));
-    // (reference arithmetic, tiled kernels straight away: k_strict2 is chained behind k_gprep on the auxiliary stream and reads the queue while the
-    // scan may still be storing -- launch_strict)
-    // (GRAAL_STRICT_CHAIN=1; off by default: 8-10 us less per scoring call on its own, but in full runs -- the commit's kernels and the in-step full
-    // evaluation on their streams next to the step's -- not a gain (C2 stand-in, 100 cycles: 130 us per step without, 134-146 with), and on the
-    // C4 stand-in the scan was once kept off the CUs by the waiting waves until their bound ran out)
-    static const bool chain_env = getenv("GRAAL_STRICT_CHAIN") != nullptr && atoi(getenv("GRAAL_STRICT_CHAIN")) != 0;
-    // (spin_ok: kernels of the two streams do run side by side -- else, e.g. under a tool that serialises dispatches, the waves' bounded wait ends
-    // the step as failed, eval_sync repeats it ordered by the host and stays with events: spin_used)
-    const bool s2_chain = chain_env && strict && ta.host_res == nullptr && !mid && world == 1 && h->publish &&
-                          !h->has_rep && scan_done_counter() && !strict_dense_cfg() && h->spin_ok;
-    if (s2_chain) h->spin_used = true;
-    { int rc_ = launch_scan(h, fA, nb, K, max_id, 0, st, ta.host_res != nullptr || s2_chain); if (rc_) return rc_; }
+    { int rc_ = launch_scan(h, fA, nb, K, max_id, 0, st, ta.host_res != nullptr); if (rc_) return rc_; }
     if (ev) { CK(hipEventRecord(h->ring[2 * slot + 1], st)); h->ring_calls += 1; }
     // (3) finishing kernel -- unless k_tm's last block does that job (it asks for k_fin through the result word if not)
     if (h->has_rep) { // the repeated bins' pixels, densely, for all 13 K candidates
@@ -5717,7 +5698,7 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
             // (several ranks: whoever finishes a step that is not in the late stage -- this rank's finisher may be off while its peers' are on --
             // goes through k_strict_flat first, like a rank that k_tm sent there: the flat and the tiled kernels deal the pairs differently)
             if (mid || (world > 1 && !late_stage && flat_allowed(h, world))) { rc_ = launch_flat(h, fA, &nb, K, rank, world, (long long*)d_q_out, h->publish, st); h->flat_tried = true; }
-            else rc_ = launch_strict(h, fA, K, rank, world, (long long*)d_q_out, h->publish, st, s2_chain);
+            else rc_ = launch_strict(h, fA, K, rank, world, (long long*)d_q_out, h->publish, st);
             if (rc_) return rc_;
             if (!h->publish) { CK(hipEventRecord(h->ev_fin, st)); h->fin_pending = true; }
         }

@@ -21,11 +21,6 @@ struct S2Args {
     unsigned long long target;   // units the grid wants (a few per wave)
     int draw_min;                // units per wave from which the waves draw their units from the counter instead of taking every n-th
     unsigned long long* next;    // the next unit nobody has taken yet, minus the grid's waves (zero at rest: the step's last block clears it)
-    // k_strict2 launched BEHIND k_gprep on the auxiliary stream, next to the scan instead of behind it (its units need nothing of the scan): the
-    // waves wait here for the scan's completion counters before they turn to the queued contacts.  nullptr: the kernel follows the scan in its stream
-    const unsigned long long* done;
-    int n_done, wait_ticks;
-    unsigned long long done_target[N_DONE];
 };
 
 #if defined(GRAAL_STAMPS) && defined(GRAAL_S2_COUNTS)   // (work counters: per-lane atomics -- they distort the stamps' timeline)
@@ -313,8 +308,9 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
     const Geo* __restrict__ geo = fa.geo;
     const Stat* __restrict__ stat = fa.stat;
     unsigned long long* __restrict__ counters = fa.counters;
-    const int lane = threadIdx.x & 63, wib = rfl(threadIdx.x >> 6);   // (wave-uniform, and the compiler is told so: what hangs on it -- the wave's
-                                                                      // unit numbers, its LDS rows, the class loop's bounds -- lives in scalar registers)
+    // (wib is NOT declared wave-uniform to the compiler: with readfirstlane on it the kernel needs no scratch memory -- 60-72 bytes of it are spilled
+    // outside the pair loops otherwise -- but the pair loops come out 3 % slower: C5's 7 contigs 1.41 ms against 1.36, tools/ab_late.sh)
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int wave = blockIdx.x * 4 + wib, n_waves = gridDim.x * 4;
     __shared__ USet s_U;
     __shared__ long long s_acc[US_NCAND];
@@ -335,8 +331,7 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
     }
     __syncthreads();
     const USet& U = s_U;
-    const bool chain = s2.done != nullptr;
-    unsigned long long nq_total = chain ? 0ull : counters[2];     // written by k_scan: an earlier kernel on the stream, or (chain) awaited below
+    const unsigned long long nq_total = counters[2];              // written by k_scan, an earlier kernel on the stream
     const unsigned long long n_units = min(*list_n, sa.list_cap); // written by k_gprep (ordered by an event)
     const float nfpb = sa.nfpb;
     const Par par = sa.par;
@@ -646,25 +641,7 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
     {
         QSrc qs;
         qs.queue = fa.queue; qs.geo2 = reinterpret_cast<const int2*>(geo); qs.cnt = fa.cnt; qs.keys = nullptr; qs.live = 0; qs.K = K;
-        qs.seq = (unsigned)seq; qs.concurrent = chain ? 1 : 0; qs.multi = fa.multi;
-        if (chain) {
-            // the scan runs next to this kernel: complete when its blocks have all added themselves to the completion counters (k_tm's finishing
-            // block waits the same way).  It was launched first and its whole grid is resident from the start, so the wait is over before most
-            // waves get here; the bound is the exit every wave reaches if it is not (the step then fails: counters[6])
-            const unsigned long long t_end = wall_clock64() + (unsigned long long)s2.wait_ticks;
-            bool ok = false;
-            for (;;) {
-                bool missing = false;
-                if (lane < s2.n_done) missing = __hip_atomic_load(s2.done + DONE_STRIDE * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < s2.done_target[lane];
-                if (__ballot(missing) == 0ull) { ok = true; break; }
-                if (__ballot(wall_clock64() > t_end) != 0ull) break;
-                __builtin_amdgcn_s_sleep(4);
-            }
-            if (!ok && lane == 0) atomicOr(&counters[6], 8ull);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            nq_total = ok ? __hip_atomic_load(&counters[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-            nq_total = ((unsigned long long)(unsigned)rfl((int)(nq_total >> 32)) << 32) | (unsigned long long)(unsigned)rfl((int)nq_total);
-        }
+        qs.seq = (unsigned)seq; qs.concurrent = 0; qs.multi = fa.multi;
         // (a step with fewer units than waves: the waves WITHOUT a unit take the contacts -- if their lanes can hold them all -- and price them while
         // the others are still at their units; else every wave takes its share behind its units, from the other end of the grid)
         const unsigned long long n_idle = n_virtual < (unsigned long long)n_waves ? (unsigned long long)n_waves - n_virtual : 0ull;

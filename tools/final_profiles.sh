@@ -1,0 +1,5 @@
+bash tools/profile_gpu.sh r04_c5 c5 > gpurun_out/prof_r04_c5.log 2>&1
+PROF_SQ_ONLY=1 bash tools/profile_gpu.sh r04_late late > gpurun_out/prof_r04_late.log 2>&1
+PROF_SQ_ONLY=1 bash tools/profile_gpu.sh r04_c2 c2 > gpurun_out/prof_r04_c2.log 2>&1
+C4_CYCLES=4 PROF_TRACE_ONLY=1 bash tools/profile_gpu.sh r04_c4 c4 > gpurun_out/prof_r04_c4.log 2>&1
+echo profiles done
