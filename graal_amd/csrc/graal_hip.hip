@@ -1903,8 +1903,11 @@ __device__ __forceinline__ void price_contacts(const PriceArgs& pa, unsigned lon
 __device__ __forceinline__ void price_contacts_strict(const QSrc& qs, unsigned long long* __restrict__ err, const NbTables* __restrict__ tabs, const Geo* __restrict__ geo,
                                                       const Stat* __restrict__ stat, const int* __restrict__ lcontbp, long long* __restrict__ out,
                                                       unsigned long long* __restrict__ nf, float nfpb, const Par& par, bool quirk,
-                                                      unsigned long long nq_total, int first, int n_waves, int lane)
+                                                      unsigned long long nq_total, int first, int n_waves, int lane,
+                                                      const Xf* xf_lds = nullptr, const unsigned char* crep_lds = nullptr)
 {
+    // (xf_lds / crep_lds: the K tables' transforms [K][N_OPS][NP] and class representatives [K][N_PAIRS][N_OPS] in LDS -- k_tm's finishing block
+    // copies them while it waits for the scan; from the tables in memory they are a round trip per (contact, neighbour))
     const int op = lane & 15;
     for (unsigned long long e0 = (unsigned long long)first * 4; e0 < nq_total; e0 += (unsigned long long)n_waves * 4) {
         const unsigned long long e = e0 + (lane >> 4);
@@ -1924,10 +1927,17 @@ __device__ __forceinline__ void price_contacts_strict(const QSrc& qs, unsigned l
             const int k = (__ffs((int)rel) - 1) / CODE_BITS;
             rel &= rel - 1;
             const int p = (qe.ci >> (CODE_BITS * k)) & 7, q = (qe.cj >> (CODE_BITS * k)) & 7;
-            const NbTables& T = tabs[k];
-            const unsigned char cls = T.crep[pair_index(p, q)][op];
-            Xf xa = T.xf[op][p], xb = T.xf[op][q];     // (requested together with the class entry)
-            keep_xf(xa, xb);
+            unsigned char cls;
+            Xf xa, xb;
+            if (xf_lds) {
+                cls = crep_lds[(k * N_PAIRS + pair_index(p, q)) * N_OPS + op];
+                xa = xf_lds[(k * N_OPS + op) * NP + p]; xb = xf_lds[(k * N_OPS + op) * NP + q];
+            } else {
+                const NbTables& T = tabs[k];
+                cls = T.crep[pair_index(p, q)][op];
+                xa = T.xf[op][p]; xb = T.xf[op][q];     // (requested together with the class entry)
+                keep_xf(xa, xb);
+            }
             if (cls == CREP_OLD) continue;   // the inputs of the current layout: the same value
             const End X = end_xf(gx, xa), Y = end_xf(gy, xb);
             const float ex_new = ex_pair_ref(X, sx, slx, fx, Y, sy, sly, fy, nfpb, par, quirk);
@@ -2334,6 +2344,14 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
             s_qkeys[t - 64] = ta.tabs[t - 64].key;
             if (ta.tabs[t - 64].fB != fA) atomicOr(&s_qlive, 1u << (t - 64));
         }
+        if (t >= 64 && s_fin == 1 && ta.strict) {   // reference arithmetic: the transforms and class representatives of all K tables (22 KB at K = 10)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const int u = t - 64, nu = 256 - 64;
+            Xf* const sx = reinterpret_cast<Xf*>(s_tm_dyn);
+            unsigned char* const sc = reinterpret_cast<unsigned char*>(sx + MAXK * N_OPS * NP);
+            for (int e = u; e < K * N_OPS * NP; e += nu) { const int k = e / (N_OPS * NP), r = e - k * (N_OPS * NP); sx[e] = ta.tabs[k].xf[r / NP][r % NP]; }
+            for (int e = u; e < K * N_PAIRS * N_OPS; e += nu) { const int k = e / (N_PAIRS * N_OPS), r = e - k * (N_PAIRS * N_OPS); sc[e] = ta.tabs[k].crep[r / N_OPS][r % N_OPS]; }
+        }
         if (t >= 64 && s_fin == 1 && !ta.strict) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             const int u = t - 64, nu = 256 - 64;
@@ -2387,7 +2405,8 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
     qs.seq = (unsigned)seq; qs.concurrent = 1; qs.multi = ta.multi;
     if (ta.strict)
         price_contacts_strict(qs, ta.counters + 6, ta.tabs, ta.geo, ta.stat, ta.lcontbp, ta.acc, ta.counters + NF_OFF, ta.nfpb, ta.par, ta.quirk != 0,
-                              s_nq, t >> 6, 4, t & 63);
+                              s_nq, t >> 6, 4, t & 63, reinterpret_cast<const Xf*>(s_tm_dyn),
+                              reinterpret_cast<const unsigned char*>(reinterpret_cast<const Xf*>(s_tm_dyn) + MAXK * N_OPS * NP));
     else {
         PriceArgs pa;
         pa.pr_lds = s_prl; pa.pt_lds = s_ptl; pa.nt_lds = s_ntl;
