@@ -2119,6 +2119,7 @@ struct TmArgs { // first-needed pointers by value (see ScanArgs)
     long long stats_seq;
     long long* stats_dev;
     int strict_inline_m;           // largest affected set k_tm prices itself in reference arithmetic (-1: none, k_strict_dense validation)
+    int stage_tables;              // reference arithmetic: the finishing block copies the tables' transforms and classes to LDS while it waits for the scan
     // the finishing block's pointers, by value too
     unsigned long long* counters;
     const QRaw* queue;
@@ -2344,7 +2345,7 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
             s_qkeys[t - 64] = ta.tabs[t - 64].key;
             if (ta.tabs[t - 64].fB != fA) atomicOr(&s_qlive, 1u << (t - 64));
         }
-        if (t >= 64 && s_fin == 1 && ta.strict) {   // reference arithmetic: the transforms and class representatives of all K tables (22 KB at K = 10)
+        if (t >= 64 && s_fin == 1 && ta.strict && ta.stage_tables) {   // reference arithmetic: the transforms and class representatives of all K tables (22 KB at K = 10)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             const int u = t - 64, nu = 256 - 64;
             Xf* const sx = reinterpret_cast<Xf*>(s_tm_dyn);
@@ -2405,7 +2406,7 @@ __global__ __launch_bounds__(256) void k_tm(const DevArgs* __restrict__ A, TmArg
     qs.seq = (unsigned)seq; qs.concurrent = 1; qs.multi = ta.multi;
     if (ta.strict)
         price_contacts_strict(qs, ta.counters + 6, ta.tabs, ta.geo, ta.stat, ta.lcontbp, ta.acc, ta.counters + NF_OFF, ta.nfpb, ta.par, ta.quirk != 0,
-                              s_nq, t >> 6, 4, t & 63, reinterpret_cast<const Xf*>(s_tm_dyn),
+                              s_nq, t >> 6, 4, t & 63, ta.stage_tables ? reinterpret_cast<const Xf*>(s_tm_dyn) : nullptr,
                               reinterpret_cast<const unsigned char*>(reinterpret_cast<const Xf*>(s_tm_dyn) + MAXK * N_OPS * NP));
     else {
         PriceArgs pa;
@@ -5676,6 +5677,9 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
     // (with k_strict_flat behind the scan k_tm prices nothing itself: one thread per pair walking the classes is 30-50 us for a set
     // of 20 fragments, and the flat kernel would wait for it)
     ta.strict_inline_m = strict_dense_cfg() ? -1 : (mid ? 0 : STRICT_INLINE_M);
+    // (a long scan -- millions of contacts: the copy is over before the scan is.  A short one -- the C2 / C3 stand-ins -- is complete before the
+    // tables are: the copy would stand in front of the contacts, two round trips for a handful of them; C2 stand-in 130 -> 137 us per step)
+    ta.stage_tables = h->nnz >= 4000000 ? 1 : 0;
     ta.host_res = (h->publish && (world == 1 || h->x_host) && !no_finisher && h->finisher_ok && !h->has_rep && !late_stage && !mid && !(strict && strict_dense_cfg())) ? h->res_dev : nullptr;
     ta.wait_ticks = fin_wait_ticks(h);
     ta.counters = (unsigned long long*)(h->d_scalars + 10); ta.queue = h->queue; ta.cnt = h->cnt; ta.multi = h->single_sub ? 0 : 1; ta.stat = h->stat_frag;
