@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
     float (*const cy)[4] = s_cy[wib];
     float (*const exo)[64] = s_exo[wib];
     STAMP(17, blockIdx.x == 0 && threadIdx.x == 0);
-    STAMP_FBLK(0, threadIdx.x == 0);
+    STAMP_FBLK(0, threadIdx.x == 0);   // (debug build, per block: past the prologue | wave 0's first unit: entries read | fragments and classes in | at the class loop)
     // ---- (1) the listed units.  The list holds entries of at most seg_unit fragments of the segment side; a wave takes m neighbouring
     // entries -- merged into one unit where they continue each other (many entries: fewer, longer units, the lanes' side loaded once) -- or
     // one entry is dealt to R waves that share its classes (few entries: a unit's depth, all classes of a pair one after the other, is what a
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
       // the group's entries, one per lane (one round trip); runs of entries that continue each other become one unit
       if (lane < m_in) s_ent[wib][lane] = list[e0 + (unsigned long long)lane];   // (kept in LDS: live across a unit they cost registers the pair loop needs)
       WAVE_LDS_SYNC();
-      STAMP_FBLK(1, threadIdx.x == 0 && v == (unsigned long long)wave && s_ent[wib][0] != 0xffffffffffffffffull);
+      STAMP_FBLK(1, threadIdx.x == 0 && v == (unsigned long long)wave && s_ent[wib][0] != ~0ull);   // (the condition reads the entry: the stamp waits for it)
       int pos = 0;
       while (pos < m_in) {
         const unsigned long long my = lane < m_in ? s_ent[wib][lane] : 0ull;
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
             tile[lane] = y;
         }
         WAVE_LDS_SYNC();
-        STAMP_FBLK(2, threadIdx.x == 0 && v == (unsigned long long)wave && pos == run && tile[0].frag >= 0 && gL.start_bp != -12345);
+        STAMP_FBLK(2, threadIdx.x == 0 && v == (unsigned long long)wave && pos == run && tile[0].frag >= 0 && gL.start_bp != -12345);   // (reads what was loaded, likewise)
         const bool cis_old = rfl(PL.contig) == rfl(PS.contig);
         const int circ_old = rfl(CL.circ), lbp_old = rfl(CL.lbp);
         // old bp extents of the two sides (positions grow with start_bp inside a contig)
