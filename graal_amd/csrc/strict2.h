@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void k_gprep(const NbTables* __restrict__ tabs
     __shared__ int s_cuts[US_MAXC * (US_MAXK + 1)], s_ncut[US_MAXC];
     __shared__ Xf s_xf[MAXK][N_OPS][NP];
     __shared__ int s_ne[256], s_off[257], s_tp[256], s_pr[256];
-    __shared__ unsigned long long s_cmask[4][US_NCAND][4];   // the class blocks' membership masks, per wave
+    __shared__ unsigned long long s_key2[4][US_NCAND][2];    // the class blocks' candidate keys (two 64-bit words each), per wave
     __shared__ unsigned long long s_base;
     const int t = threadIdx.x, lane = t & 63, wib = rfl(t >> 6);
     STAMP(11, blockIdx.x == 0 && t == 0);
@@ -125,55 +125,77 @@ __global__ __launch_bounds__(256) void k_gprep(const NbTables* __restrict__ tabs
             GClass* out = s2.cls + (size_t)pair * US_NCAND;
             int nc = 0;
             STAMP_MAX(26, lane == 0);
-            // One round per class: the first unassigned candidate leads, the lanes with its key join.  A round is a chain -- ballots, the leader's
-            // key, compares -- of a wave that has its SIMD to itself, so it is kept short (built by lane 0 from LDS, record by record, with the
-            // class's masks by six more ballots, a round was 0.25 us and the classes of a pair 10 us of this kernel): the key comes through
-            // v_readlane (the leader's lane is wave-uniform), a candidate only NOTES its class; the masks are ORed together in LDS behind the
-            // rounds, all candidates at once, and every leader writes its own record from the transforms it already holds.
-            int cls_of[3] = {-1, -1, -1};
-            bool lead_r[3] = {false, false, false};
-            for (;;) {
-                const unsigned long long b0 = __ballot(un[0]), b1 = __ballot(un[1]), b2 = __ballot(un[2]);
-                if (!(b0 | b1 | b2)) break;
-                const int r = b0 ? 0 : (b1 ? 1 : 2);
-                const unsigned long long br = b0 ? b0 : (b1 ? b1 : b2);
-                const int ll = __ffsll((long long)br) - 1;
-                // (word by word: `r == 0 ? key[0] : ...` on the structs selects an ADDRESS, which kept the three keys in scratch memory)
-                InputsKey mine, lead;
-                mine.x = r == 0 ? key[0].x : (r == 1 ? key[1].x : key[2].x); mine.y = r == 0 ? key[0].y : (r == 1 ? key[1].y : key[2].y);
-                mine.z = r == 0 ? key[0].z : (r == 1 ? key[1].z : key[2].z); mine.w = r == 0 ? key[0].w : (r == 1 ? key[1].w : key[2].w);
-                lead.x = __builtin_amdgcn_readlane(mine.x, ll); lead.y = __builtin_amdgcn_readlane(mine.y, ll);
-                lead.z = __builtin_amdgcn_readlane(mine.z, ll); lead.w = __builtin_amdgcn_readlane(mine.w, ll);
+            // Classes without rounds: every candidate compares its key with every candidate that differs from the current layout (their keys go
+            // round through LDS, one wave-uniform broadcast read each) and so collects the 130-bit mask of ITS class; the class's lowest
+            // candidate leads it, a leader's number is the count of leaders below it, and it writes the record from the transforms it already
+            // holds.  (One round per class -- first unassigned candidate, ballots, its key, compares -- was a chain of 0.2 us per class in a wave
+            // that has its SIMD to itself: 6-10 us of this kernel per pair; this is 0.6-3 us whatever the number of classes.)
+            unsigned long long (*const kk)[2] = s_key2[wib];
 #pragma unroll
-                for (int q = 0; q < 3; q++) {
-                    const bool m = un[q] && ikey_eq(key[q], lead);
-                    if (m) { cls_of[q] = nc; un[q] = false; lead_r[q] = (q == r) && lane == ll; }
+            for (int r = 0; r < 3; r++) {
+                const int cand = lane + 64 * r;
+                if (cand < K * N_OPS) {
+                    kk[cand][0] = (unsigned long long)(unsigned)key[r].x | ((unsigned long long)(unsigned)key[r].y << 32);
+                    kk[cand][1] = (unsigned long long)(unsigned)key[r].z | ((unsigned long long)(unsigned)key[r].w << 32);
                 }
-                nc++;
             }
-            unsigned long long (*const cm)[4] = s_cmask[wib];   // per class: members 0..63, 64..127, 128..129 | the "mass" members likewise, packed below
-            for (int c = lane; c < nc; c += 64) { cm[c][0] = 0; cm[c][1] = 0; cm[c][2] = 0; cm[c][3] = 0; }
-            WAVE_LDS_SYNC();
+            unsigned long long ka[3], kb[3], mm0[3] = {0ull, 0ull, 0ull}, mm1[3] = {0ull, 0ull, 0ull};
+            unsigned mm2[3] = {0u, 0u, 0u};
 #pragma unroll
-            for (int q = 0; q < 3; q++)
-                if (cls_of[q] >= 0) {
-                    // word 0 / 1: members (candidates 0..63 / 64..127); word 2: members 128, 129 in bits 0, 1 and the mass members 128, 129 in bits 2, 3;
-                    // word 3 is not enough for two more 64-bit masks: the mass members 0..127 are the members ANDed with the wave's mass ballots
-                    if (q < 2) atomicOr(&cm[cls_of[q]][q], 1ull << lane);
-                    else atomicOr(&cm[cls_of[q]][2], (1ull << lane) | (ms[2] ? (4ull << lane) : 0ull));
-                }
-            const unsigned long long ms0 = __ballot(ms[0]), ms1 = __ballot(ms[1]);
+            for (int r = 0; r < 3; r++) {
+                ka[r] = (unsigned long long)(unsigned)key[r].x | ((unsigned long long)(unsigned)key[r].y << 32);
+                kb[r] = (unsigned long long)(unsigned)key[r].z | ((unsigned long long)(unsigned)key[r].w << 32);
+            }
+            const unsigned long long u0 = __ballot(un[0]), u1 = __ballot(un[1]), u2 = __ballot(un[2]);
+            const int nr = (K * N_OPS + 63) >> 6;      // candidates per lane that exist at this K (wave-uniform)
             WAVE_LDS_SYNC();
+            for (unsigned long long bits = u0; bits; bits &= bits - 1ull) {
+                const int j = __ffsll((long long)bits) - 1;
+                const unsigned long long ja = kk[j][0], jb = kk[j][1];
+                const unsigned long long bit = 1ull << j;
+                mm0[0] |= (ka[0] == ja && kb[0] == jb) ? bit : 0ull;
+                if (nr > 1) mm0[1] |= (ka[1] == ja && kb[1] == jb) ? bit : 0ull;
+                if (nr > 2) mm0[2] |= (ka[2] == ja && kb[2] == jb) ? bit : 0ull;
+            }
+            for (unsigned long long bits = u1; bits; bits &= bits - 1ull) {
+                const int j = __ffsll((long long)bits) - 1;
+                const unsigned long long ja = kk[64 + j][0], jb = kk[64 + j][1];
+                const unsigned long long bit = 1ull << j;
+                mm1[0] |= (ka[0] == ja && kb[0] == jb) ? bit : 0ull;
+                mm1[1] |= (ka[1] == ja && kb[1] == jb) ? bit : 0ull;
+                if (nr > 2) mm1[2] |= (ka[2] == ja && kb[2] == jb) ? bit : 0ull;
+            }
+            for (unsigned bits = (unsigned)(u2 & 3ull); bits; bits &= bits - 1u) {
+                const int j = __ffs((int)bits) - 1;
+                const unsigned long long ja = kk[128 + j][0], jb = kk[128 + j][1];
+                const unsigned bit = 1u << j;
+                mm2[0] |= (ka[0] == ja && kb[0] == jb) ? bit : 0u;
+                mm2[1] |= (ka[1] == ja && kb[1] == jb) ? bit : 0u;
+                mm2[2] |= (ka[2] == ja && kb[2] == jb) ? bit : 0u;
+            }
+            // (a candidate whose key is the current layout's belongs to no class: it is compared with nobody -- the loops run over the others --
+            // and leads nothing)
+            bool lead[3];
 #pragma unroll
-            for (int q = 0; q < 3; q++)
-                if (lead_r[q]) {
-                    GClass c = gclass_make(xa[q], xb[q], lane + 64 * q);
-                    const unsigned long long* w = cm[cls_of[q]];
-                    c.m0 = w[0]; c.m1 = w[1]; c.m2 = (unsigned)(w[2] & 3ull);
-                    c.w0 = w[0] & ms0; c.w1 = w[1] & ms1; c.w2 = (unsigned)((w[2] >> 2) & 3ull);
-                    out[cls_of[q]] = c;
+            for (int r = 0; r < 3; r++) {
+                const int lowest = mm0[r] ? __ffsll((long long)mm0[r]) - 1 : (mm1[r] ? 64 + __ffsll((long long)mm1[r]) - 1 : (mm2[r] ? 128 + __ffs((int)mm2[r]) - 1 : -1));
+                lead[r] = un[r] && lowest == lane + 64 * r;
+            }
+            const unsigned long long l0 = __ballot(lead[0]), l1 = __ballot(lead[1]), l2 = __ballot(lead[2]);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const int n0 = __popcll(l0), n1 = __popcll(l1);
+            nc = n0 + n1 + __popcll(l2);
+            const unsigned long long ms0 = __ballot(ms[0]), ms1 = __ballot(ms[1]), ms2 = __ballot(ms[2]);
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+                if (lead[r]) {
+                    const int idx = (r == 0 ? 0 : (r == 1 ? n0 : n0 + n1)) + __popcll((r == 0 ? l0 : (r == 1 ? l1 : l2)) & below);
+                    GClass c = gclass_make(xa[r], xb[r], lane + 64 * r);
+                    c.m0 = mm0[r]; c.m1 = mm1[r]; c.m2 = mm2[r] & 3u;
+                    c.w0 = mm0[r] & ms0; c.w1 = mm1[r] & ms1; c.w2 = mm2[r] & (unsigned)(ms2 & 3ull);
+                    out[idx] = c;
                 }
-            WAVE_LDS_SYNC();   // (the next pair of this wave clears the masks again)
+            WAVE_LDS_SYNC();   // (the next pair of this wave writes its keys over these)
             if (lane == 0) s2.cls_n[pair] = nc;
         }
         STAMP_MAX(13, lane == 0);
