@@ -452,7 +452,9 @@ def main():
     settle_s = float(os.environ.get("GRAAL_BENCH_SETTLE_S", 0.25))
     settle_t = [] if os.environ.get("GRAAL_BENCH_STEP_TIMES") else None
     settle_sync = int(os.environ.get("GRAAL_BENCH_SETTLE_SYNC", 0))   # (diagnostics: a device synchronize every n-th step of the settling phase)
-    while time.perf_counter() - t_settle < settle_s:
+    # (several ranks: a scoring step is a collective -- every rank must run the same number of them, so the ranks agree on every round of 64:
+    # one more while ANY rank's clock says so)
+    while max_over_ranks(1.0 if time.perf_counter() - t_settle < settle_s else 0.0) > 0.0:
         for f, nb in props[args.warmup:args.warmup + 64]:
             smp._candidate_deltas(f, nb, max_id)
             if settle_t is not None:
