@@ -4658,8 +4658,8 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
         if (!h->d_uset) {
             CK(hipMalloc(&h->d_uset, sizeof(USet)));
             CK(hipMalloc(&h->d_cls, sizeof(GClass) * (size_t)US_MAXPAIRS * US_NCAND));
-            CK(hipMalloc(&h->d_cls_n, sizeof(int) * US_MAXPAIRS + 16));   // (+ the units' draw counter)
-            CK(hipMemset(h->d_cls_n, 0, sizeof(int) * US_MAXPAIRS + 16));
+            CK(hipMalloc(&h->d_cls_n, sizeof(int) * US_MAXPAIRS + 1024));   // (+ the units' draw counter, k_gprep's ticket and completion word: a line of its own each)
+            CK(hipMemset(h->d_cls_n, 0, sizeof(int) * US_MAXPAIRS + 1024));
             CK(hipDeviceSynchronize());
         }
         const int lc = std::max(std::max(h->max_lcont, h->lcont_bound), 1);
@@ -4701,6 +4701,19 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
         static const int draw_env = getenv("GRAAL_STRICT_DRAW") ? atoi(getenv("GRAAL_STRICT_DRAW")) : 8;
         s2.draw_min = draw_env > 0 ? draw_env : 8;
         s2.next = reinterpret_cast<unsigned long long*>(h->d_cls_n + US_MAXPAIRS + (US_MAXPAIRS & 1));
+        // k_strict2 behind k_gprep WITHOUT an event (S2Args::gp): a kernel behind an event of another stream starts ~11 us after the event
+        // completes (tools/stamps_s2.py, C2 stand-in: k_gprep done 23 us, k_strict2 started 37; without any ordering -- GRAAL_DEBUG runs -- 26, as
+        // soon as the host has submitted it).  k_gprep's results go out as device-scope stores, its last block stores the step's number, and
+        // k_strict2's blocks wait for that word.  Only a grid that leaves room for k_gprep's blocks on every CU may wait for them in the kernel
+        // (512 blocks: two per CU; cf. fin_blocks_no_wait), only one rank (a repeated step must not leave the ranks out of step), only while
+        // the engine's streams are known to run side by side (spin_ok).  (768 blocks -- three per CU, still room -- with the wait instead of 1,024
+        // behind the event: C3 / C4 stand-ins 214-221 / 238-243 us per step against 200-203 / 222-225.)
+        static const bool gwait_env = getenv("GRAAL_STRICT_GWAIT") == nullptr || atoi(getenv("GRAAL_STRICT_GWAIT")) != 0;
+        const bool gwait = gwait_env && publish && world == 1 && h->spin_ok && blocks <= 512;
+        s2.gp = gwait ? s2.next + 32 : nullptr;   // (ticket: 256 bytes behind the draw counter; the completion word 256 bytes behind the ticket: GP_DONE)
+        s2.gp_seq = (unsigned long long)h->seq;
+        s2.gp_wait_ticks = 200000;   // 2 ms
+        if (gwait) h->spin_used = true;
         const int cull_blocks = (int)std::min<unsigned long long>(1024ull, std::max<unsigned long long>(1ull, nt));
         // Where k_gprep goes.  A long scan (millions of contacts): on the auxiliary stream behind k_tm, under the scan; k_strict2 waits for both
         // through an event.  A short one (a map of a few thousand bins: the scan is over before k_tm's tables are): on the MAIN stream, behind
@@ -4722,7 +4735,7 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
         // starts ~10 us late whether the event completes right in front of it or has long completed), but full runs gained nothing (C2 stand-in,
         // 100 cycles: 130 us per step without, 134-146 with) and on the C4 stand-in the waiting waves once kept the scan off the CUs until their
         // bound ran out.  Not kept.)
-        if (!inorder) {
+        if (!inorder && !gwait) {
             CK(hipEventRecord(h->ev_tm, h->aux));      // (behind k_tm and k_gprep: tables, classes and unit list complete -- nobody spins for them)
             CK(hipStreamWaitEvent(st, h->ev_tm, 0));
         }
@@ -4983,6 +4996,7 @@ void graal_destroy(graal_ctx* h)
         (void)hipSetDevice(h->device);
         (void)hipStreamSynchronize(h->stream);
         if (h->aux) (void)hipStreamSynchronize(h->aux);
+        if (h->fstream) (void)hipStreamSynchronize(h->fstream);
         void* ptrs[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->stat, h->sub_rec, h->sub_rec8, h->sub_lab16, h->d_ubins, h->d_ln_tab, h->sub2bin, h->row, h->col, h->cnt, h->queue, h->d_sub_ids, h->d_acc, h->tm_done, h->d_sync, h->d_done, h->d_wq, h->d_flags, h->d_slist, h->d_uset, h->d_cls, h->d_cls_n, h->stat_frag, h->d_dup_bins, h->d_dup_index,
                         h->d_dispatcher, h->d_collector, h->d_sub_ids_all, h->d_rep_obs,
                         h->keys, h->keys_sorted, h->o2n, h->len_of2[0], h->len_of2[1], h->contig_off2[0], h->contig_off2[1], h->perm, h->pstart, h->cbase, h->link, h->mates, h->cub_tmp, h->tabs, h->step_hdr, h->d_args, h->d_chg, h->d_part,
@@ -5932,6 +5946,7 @@ int graal_attach_exchange(graal_ctx* h, void* segment, int64_t bytes, int32_t ra
     CK(hipSetDevice(h->device));
     CK(hipStreamSynchronize(h->stream));
     CK(hipStreamSynchronize(h->aux));
+    CK(hipStreamSynchronize(h->fstream));
     CK(hipHostRegister(segment, (size_t)bytes, hipHostRegisterMapped | hipHostRegisterPortable));
     void* dp = nullptr;
     hipError_t e = hipHostGetDevicePointer(&dp, segment, 0);
@@ -5977,6 +5992,8 @@ int graal_detach_exchange(graal_ctx* h)
     CK(hipSetDevice(h->device));
     CK(hipStreamSynchronize(h->stream));
     CK(hipStreamSynchronize(h->aux));
+    CK(hipStreamSynchronize(h->fstream));   // (the in-step full evaluation publishes the ranks' contact parts into the segment from ITS stream: one still
+                                            // in flight at the unregistration was a GPU memory fault at the segment's host address -- seen once, two ranks)
     CK(hipHostUnregister(h->x_host));
     h->x_host = nullptr; h->x_dev = nullptr; h->x_bytes = 0; h->x_rank = 0; h->x_world = 1;
     h->res_host = h->res_dev = h->h_res;

@@ -21,6 +21,11 @@ struct S2Args {
     unsigned long long target;   // units the grid wants (a few per wave)
     int draw_min;                // units per wave from which the waves draw their units from the counter instead of taking every n-th
     unsigned long long* next;    // the next unit nobody has taken yet, minus the grid's waves (zero at rest: the step's last block clears it)
+    // k_strict2 WITHOUT an event behind k_gprep (a grid of <= 512 blocks, one rank): k_gprep's last block stores the step's number in gp[GP_DONE] (gp[0]
+    // is its blocks' ticket), k_strict2's blocks wait for it -- bounded -- before they read anything of k_gprep's.  nullptr: ordered by an event
+    unsigned long long* gp;
+    unsigned long long gp_seq;
+    int gp_wait_ticks;
 };
 
 #if defined(GRAAL_STAMPS) && defined(GRAAL_S2_COUNTS)   // (work counters: per-lane atomics -- they distort the stamps' timeline)
@@ -29,10 +34,15 @@ struct S2Args {
 #define S2_COUNT(i, v) do { } while (0)
 #endif
 
+constexpr int GP_DONE = 32;            // S2Args::gp: [0] k_gprep's ticket, [GP_DONE] its completion word (a line of its own: 512 blocks poll it)
 constexpr int S2_BAL_MAX = 1024;       // units of a step up to which k_strict2 deals its waves to them by their classes
 constexpr int GPREP_CLS_BLOCKS = 144;  // blocks of k_gprep that build classes (one wave per piece pair: 561 pairs at most, 576 waves); the rest cull
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// device-scope (write-through) stores: what k_gprep hands to a k_strict2 that is not ordered behind it by an event must be visible to the
+// other XCDs without a write-back of the writer's L2 (__threadfence: a microsecond per block, one after the other) -- like the scan's queue
+__device__ __forceinline__ void st_dev(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_dev(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // old bp extent [lo, hi) of tile t (fragments of ONE global piece, consecutive positions of one contig)
 __device__ __forceinline__ void utile_extent(const USet& U, const int* __restrict__ pstart, int t, int& lo, int& hi, int& g, int& cnt)
@@ -89,7 +99,7 @@ __global__ __launch_bounds__(256) void k_gprep(const NbTables* __restrict__ tabs
     if (blockIdx.x == 0) {
         int* dst = reinterpret_cast<int*>(s2.uset);
         const int* src = reinterpret_cast<const int*>(&s_U);
-        for (int i = t; i < (int)(sizeof(USet) / 4); i += 256) dst[i] = src[i];
+        for (int i = t; i < (int)(sizeof(USet) / 4); i += 256) st_dev(&dst[i], src[i]);
     }
     const int np = U.n_pieces;
     STAMP(12, blockIdx.x == 0 && t == 0);
@@ -193,14 +203,19 @@ __global__ __launch_bounds__(256) void k_gprep(const NbTables* __restrict__ tabs
                     GClass c = gclass_make(xa[r], xb[r], lane + 64 * r);
                     c.m0 = mm0[r]; c.m1 = mm1[r]; c.m2 = mm2[r] & 3u;
                     c.w0 = mm0[r] & ms0; c.w1 = mm1[r] & ms1; c.w2 = mm2[r] & (unsigned)(ms2 & 3ull);
-                    out[idx] = c;
+                    {   // (eight 8-byte device-scope stores)
+                        static_assert(sizeof(GClass) == 64, "GClass is written as eight 64-bit words");
+                        const unsigned long long* w = reinterpret_cast<const unsigned long long*>(&c);
+                        unsigned long long* o = reinterpret_cast<unsigned long long*>(&out[idx]);
+#pragma unroll
+                        for (int q = 0; q < 8; q++) st_dev(&o[q], w[q]);
+                    }
                 }
             WAVE_LDS_SYNC();   // (the next pair of this wave writes its keys over these)
-            if (lane == 0) s2.cls_n[pair] = nc;
+            if (lane == 0) st_dev(&s2.cls_n[pair], nc);
         }
         STAMP_MAX(13, lane == 0);
-        return;
-    }
+    } else {
     // ---- unit list: rows = tiles; a tile pair is listed iff some fragment pair of it can be inside the window under the current
     // layout or under some candidate whose inputs differ from the current layout's (interval arithmetic, no per-pair work)
     const int n_tiles = U.n_tiles;
@@ -258,7 +273,7 @@ __global__ __launch_bounds__(256) void k_gprep(const NbTables* __restrict__ tabs
                     const int e = o - s_off[lo], tp = s_tp[lo];
                     const int cs_o = (tp >> 17) & 127, j0 = (e / R) * seg, c = cs_o - j0 < seg ? cs_o - j0 : seg;
                     const unsigned long long at = base + (unsigned long long)o;
-                    if (at < cap) list[at] = uunit_pack(ti, tp & 0xffff, j0, c, (tp >> 16) & 1, e % R, R, s_pr[lo]);
+                    if (at < cap) st_dev(&list[at], uunit_pack(ti, tp & 0xffff, j0, c, (tp >> 16) & 1, e % R, R, s_pr[lo]));
                     else atomicOr(&counters[6], 2ull);   // (cannot happen: the host sizes the list)
                 }
             }
@@ -266,6 +281,23 @@ __global__ __launch_bounds__(256) void k_gprep(const NbTables* __restrict__ tabs
         }
     }
     STAMP_MAX(14, t == 0);
+    }
+    if (s2.gp != nullptr) {
+        // "k_gprep is complete": every block waits for its own device-scope stores (and the list's atomic) to be acknowledged and takes a ticket;
+        // the last one puts the ticket back and stores the step's number
+        ATOMICS_DONE();
+        __syncthreads();
+        if (t == 0) {
+            const unsigned long long ticket = atomicAdd(&s2.gp[0], 1ull);
+            if (ticket == (unsigned long long)gridDim.x - 1ull) {
+                st_dev(&s2.gp[0], 0ull);
+                // (relaxed: a release here is a write-back of this XCD's whole L2 -- 15 us with the step's dirty lines in it -- and nothing needs it: every
+                // block's results are device-scope stores, acknowledged before its ticket; the last ticket is taken behind all of them)
+                st_dev(&s2.gp[GP_DONE], s2.gp_seq);
+                STAMP(24, true);
+            }
+        }
+    }
 }
 
 struct STile2 { int start_bp, len_bp, flags, frag; Stat st; };   // one staged fragment of the segment side, 48 bytes
@@ -345,6 +377,33 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
     __shared__ unsigned long long s_ent[4][16];   // the unit-list entries a wave is working through
     __shared__ int s_pref[S2_BAL_MAX + 1], s_bsum[256], s_boff[257];   // the waves of a step's few units (see `bal`)
     STAMP(16, blockIdx.x == 0 && threadIdx.x == 0);
+    int skip = fa.skip;
+    if (s2.gp != nullptr) {
+        // no event in front of this kernel: k_gprep (on the other stream; launched first, and this grid leaves room for its blocks on every CU)
+        // says when the union set, the classes and the unit list are complete.  Bounded: if the two kernels do not run side by side -- a tool
+        // that serialises dispatches -- the step ends as failed and the host repeats it behind an event (eval_sync: spin_used)
+        if (threadIdx.x == 0) {
+            const unsigned long long t_end = wall_clock64() + (unsigned long long)s2.gp_wait_ticks;
+            bool ok = false, waited = false;
+            for (;;) {
+                if (__hip_atomic_load(&s2.gp[GP_DONE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == s2.gp_seq) { ok = true; break; }
+                if (wall_clock64() > t_end) break;
+                waited = true;
+                __builtin_amdgcn_s_sleep(16);   // (~0.4 us between polls: 512 blocks poll one word)
+            }
+            if (!ok) atomicOr(&fa.counters[6], 8ull);
+            s_last = ok ? 0 : 1;
+            // A block that found the word at once needs no invalidation: nothing of k_gprep's has been read by this grid before the word -- what
+            // the caches held of earlier steps went at the kernel's own start, and what they hold now was fetched behind the word.  A block that
+            // had to wait invalidates once, by ONE wave (the caches are the CU's and the XCD's, not the wave's: all 2,048 waves of the grid doing
+            // it were 15 us of this kernel's prologue, one wave per block still 3)
+            if (waited) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        STAMP(23, blockIdx.x == 0 && threadIdx.x == 0);
+        if (s_last) skip = 3;   // (gave up: no units, no contacts -- nothing of k_gprep's is trusted; the block still takes its ticket, the step fails)
+        __syncthreads();
+    }
     for (int i = threadIdx.x; i < US_NCAND; i += 256) s_acc[i] = 0;
     {
         const int* src = reinterpret_cast<const int*>(s2.uset);
@@ -383,7 +442,7 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
     // step waited for the waves of the heaviest one (C2 stand-in, 7 contigs: 348 units, wave 0 of the blocks done with its units after 17 us
     // on average, the last one after 47).  Every block derives the same plan: classes per unit from the entries' pair index, q classes per
     // wave so that the plan fits the grid, units u's waves = [s_pref[u], s_pref[u + 1]).
-    const bool bal = mrg == 1 && n_units > 0ull && n_units <= (unsigned long long)S2_BAL_MAX && n_units * 2ull <= (unsigned long long)n_waves && s2.rep_max > 1;
+    const bool bal = !(skip & 1) && mrg == 1 && n_units > 0ull && n_units <= (unsigned long long)S2_BAL_MAX && n_units * 2ull <= (unsigned long long)n_waves && s2.rep_max > 1;
     if (bal) {
         const int nu = (int)n_units, t = threadIdx.x;
         int ncu[4], mine = 0;
@@ -417,7 +476,7 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
         if (t == 0) s_pref[nu] = s_boff[256];
         __syncthreads();
     }
-    const unsigned long long n_virtual = (fa.skip & 1) ? 0ull : (bal ? (unsigned long long)s_pref[(int)n_units] :
+    const unsigned long long n_virtual = (skip & 1) ? 0ull : (bal ? (unsigned long long)s_pref[(int)n_units] :
                                          ((n_units + (unsigned long long)mrg - 1ull) / (unsigned long long)mrg) * (unsigned long long)rep_n);
     // a wave's first unit is its own number; the others it draws from a counter -- the draw goes out when a unit is started and is read
     // when it is finished (units differ in cost by the classes of their piece pair and by the window: dealt round robin, the waves that
@@ -674,7 +733,7 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
         const int lpc = nq_total > 16ull * c_waves ? 1 : (nq_total > 4ull * c_waves ? 4 : 16);
         const int per_wave = 64 / lpc;
         const unsigned long long c_first = idle_take ? (unsigned long long)wave - n_virtual : (unsigned long long)(n_waves - 1 - wave);
-        const unsigned long long c_end = ((fa.skip & 2) || (idle_take && (unsigned long long)wave < n_virtual)) ? 0ull : nq_total;
+        const unsigned long long c_end = ((skip & 2) || (idle_take && (unsigned long long)wave < n_virtual)) ? 0ull : nq_total;
         for (unsigned long long b0 = c_first * (unsigned long long)per_wave; b0 < c_end; b0 += c_waves * (unsigned long long)per_wave) {
             const unsigned long long e = b0 + (unsigned long long)(lane / lpc);
             const int sub = lane % lpc;

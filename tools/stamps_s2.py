@@ -34,8 +34,8 @@ max_id = smp.modify_gl_cuda_buffer(0)
 L = lib.load()
 L.graal_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
 L.graal_debug_hitstat.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
-names = {0: "k_tm start", 3: "k_tm released its tables", 8: "k_scan start", 10: "k_scan block 0 loop done", 11: "k_gprep start", 12: "k_gprep: union set built", 13: "k_gprep: classes done (last wave)", 21: "k_gprep: ends and transforms loaded", 22: "k_gprep: geometry built (thread 0)", 23: "k_strict2: last block started",
-         24: "k_strict2: last block past its prologue", 25: "k_gprep: last block started", 28: "k_strict2: last unit's fragments and classes loaded", 29: "k_strict2: last unit's current-layout pass done", 26: "k_gprep: last class wave has its keys",
+names = {0: "k_tm start", 3: "k_tm released its tables", 8: "k_scan start", 10: "k_scan block 0 loop done", 11: "k_gprep start", 12: "k_gprep: union set built", 13: "k_gprep: classes done (last wave)", 21: "k_gprep: ends and transforms loaded", 22: "k_gprep: geometry built (thread 0)", 23: "k_strict2: block 0 past its wait for k_gprep's word",
+         24: "k_gprep: completion word stored", 25: "k_gprep: last block started", 28: "k_strict2: last unit's fragments and classes loaded", 29: "k_strict2: last unit's current-layout pass done", 26: "k_gprep: last class wave has its keys",
          14: "k_gprep: unit list done (last block)", 16: "k_strict2 start", 17: "k_strict2 prologue done", 18: "k_strict2 units done (last wave)", 19: "k_strict2 contacts done (last wave)",
          20: "k_strict2 sums handed out"}
 acc = np.zeros(32); cnt = np.zeros(32); hs = np.zeros(8); n = 0
