@@ -290,7 +290,11 @@ int hc_union_check(int fA, const int32_t* fB, int K, int max_id, int32_t* const*
             const int cs = lanes_first ? cj : ci;            // fragments of the segment side
             for (int j0 = 0; j0 < cs; j0 += seg) {
                 const int cnt = cs - j0 < seg ? cs - j0 : seg;
-                const unsigned long long u = uunit_pack(ti, tj, j0, cnt, lanes_first);
+                int offi_, offj_;
+                const int gi = utile_piece(U, ti, offi_), gj = utile_piece(U, tj, offj_);
+                const int pair = upair_index(gi, gj);                          // (tiles are numbered piece by piece: gi <= gj)
+                const unsigned long long u = uunit_pack(ti, tj, j0, cnt, lanes_first, 0, 1, pair);
+                if (gi > gj || pair < 0 || pair >= US_MAXPAIRS || uunit_pair(u) != pair) bad++;   // the entry carries its piece pair (k_strict2's plan reads it)
                 n_units++;
                 // decode as k_strict2 does
                 const int dti = (int)(u & 0xffffull), dtj = (int)((u >> 16) & 0xffffull), dj0 = (int)((u >> 32) & 63ull), dcnt = (int)((u >> 38) & 63ull);
