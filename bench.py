@@ -80,34 +80,53 @@ def exploded_layout(P):
     return s
 
 
-def cpu_baseline(P, state, budget_s=24.0):
-    """numpy re-score (oracle/sparse_numpy.py) of whole candidates on the host: the checker, timed, never shipped."""
+CPU_BASELINE_PAIRS = ((1234, 4321), (777, 31337), (20141, 217), (4242, 12345), (9001, 40404), (27182, 31415))
+CPU_BASELINE_OPS = (0, 6, 3, 4)   # eject; insert right of fB; split-insert @ left, reversed; split-insert @ right
+
+
+def cpu_baseline(P, state, budget_s=24.0, param=None, gpu_deltas=None):
+    """numpy re-score (oracle/sparse_numpy.py) of whole candidates on the host: the checker, timed, never shipped.
+    The candidates are the reference's mutation kernels (the oracle's restatement) applied to the layout the GPU holds; with
+    `gpu_deltas` -- the engine's candidate deltas for the same (fA, fB, op), scored OUTSIDE every timed region -- the values do not go to
+    waste: re-score(candidate) - re-score(current) is held against them (`max_rel_diff_vs_gpu`, in units of |logL|; the reference's own
+    cross-check, cuda_lib_gl.py:2196-2220)."""
     from oracle import oracle as O
     from oracle.sparse_numpy import SparseScorer
     sc = SparseScorer(P["coo_row"], P["coo_col"], P["coo_val"], P["np_sub_frags_id"], P["np_sub_frags_len_bp"],
-                      P["np_sub_frags_accu"], P["mean_squared_frags_per_bin"], P["param_simu"])
+                      P["np_sub_frags_accu"], P["mean_squared_frags_per_bin"], P["param_simu"] if param is None else param)
     n = P["n_frags"]
     max_id = int(state["id_c"].max())
     pop, ids = O.new_state(n), np.zeros(n, np.int32)
     cands = []
-    for fA, fB in ((1234 % n, 4321 % n), (777 % n, 31337 % n), (20141 % n, 217 % n), (4242 % n, 12345 % n), (9001 % n, 40404 % n),
-                   (27182 % n, 31415 % n)):
+    for fA, fB in CPU_BASELINE_PAIRS:
+        fA, fB = fA % n, fB % n
         O.DenseOracle.pop_out(pop, state, ids, fA, max_id)
-        cands.append(O.copy_state(pop))                                    # op 0: eject
-        for which, ori in ((3, 1), (1, -1), (2, 1)):                       # ops 6, 3, 4
+        cands.append(((fA, fB, 0), O.copy_state(pop)))                     # op 0: eject
+        for op, which, ori in ((6, 3, 1), (3, 1, -1), (4, 2, 1)):
             out = O.new_state(n)
             O.DenseOracle.pop_in(which, out, pop, fA, fB, int(ids.max()), ori)
-            cands.append(out)
+            cands.append(((fA, fB, op), out))
+    base = sc.full(state, same_bin=False) if gpu_deltas is not None else None   # (the current layout: untimed, not a candidate)
     done, t0 = 0, time.perf_counter()
-    for c in cands:                                                        # ~0.7 s each: 24 candidates, ~17 s of CPU work (SURVEY 8d: >= 20)
-        sc.full(c, same_bin=False)
+    values = []
+    for key, c in cands:                                                   # ~0.7 s each: 24 candidates, ~17 s of CPU work (SURVEY 8d: >= 20)
+        values.append((key, sc.full(c, same_bin=False)))
         done += 1
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "candidate logL evals/s", "cores": 1, "kind": "port",
-            "sample": "%d whole-candidate numpy float32/float64 re-scores of the same %d-contact state (%.1f s)" % (
-                done, len(P["coo_row"]), dt)}
+    out = {"value": done / dt, "unit": "candidate logL evals/s", "cores": 1, "kind": "port",
+           "sample": "%d whole-candidate numpy float32/float64 re-scores of the same %d-contact state (%.1f s)" % (
+               done, len(P["coo_row"]), dt)}
+    if gpu_deltas is not None:
+        diffs = [abs((v - base) - gpu_deltas[key]) for key, v in values if key in gpu_deltas]
+        out["candidates_compared_with_gpu"] = len(diffs)
+        out["max_abs_diff_vs_gpu_logL_units"] = max(diffs) if diffs else None
+        out["max_rel_diff_vs_gpu"] = max(diffs) / abs(base) if diffs else None
+        out["max_rel_diff_note"] = ("max over the candidates of |(re-score(candidate) - re-score(current)) - GPU strict delta| / |logL|; "
+                                    "the GPU values were computed outside the timed regions for the same (fA, fB, op)")
+        out["largest_abs_delta_compared"] = max(abs(gpu_deltas[key]) for key, _ in values if key in gpu_deltas) if diffs else None
+    return out
 
 
 def cpu_baseline_dense(budget_s=8.0):
@@ -710,8 +729,15 @@ def main():
         if late is not None:
             out["late_stage"] = late
         if world == 1 and not args.no_cpu_baseline:
+            # the engine's deltas of the candidates the numpy re-score is about to price (untimed; K = 1 per pair), then the re-score
+            mid_b = smp.modify_gl_cuda_buffer(0)
             smp.gpu_vect_frags.copy_from_gpu()
-            out["cpu_baseline"] = cpu_baseline(P, smp.gpu_vect_frags.as_dict(), budget_s=16.0)
+            gpu_d = {}
+            for fA_, fB_ in CPU_BASELINE_PAIRS:
+                d_ = smp._candidate_deltas(fA_ % n, [fB_ % n], mid_b)
+                for op_ in CPU_BASELINE_OPS:
+                    gpu_d[(fA_ % n, fB_ % n, op_)] = float(d_[0, op_])
+            out["cpu_baseline"] = cpu_baseline(P, smp.gpu_vect_frags.as_dict(), budget_s=16.0, param=smp._param_flat, gpu_deltas=gpu_d)
             out["cpu_baseline"]["host_cpus"] = os.cpu_count()
             try:
                 out["cpu_baseline_dense"] = cpu_baseline_dense()

@@ -186,10 +186,82 @@ class SparseScorer:
             k += 1
         return tot
 
-    def full(self, state, same_bin=True):
+    def mass_cis_windowed(self, state, centres=None, same_bin=True, in_set=None, block=1 << 22):
+        """The sum of ``mass_cis`` enumerated differently -- every sub-fragment's partners inside its reach found by ONE binary
+        search on a globally monotone key (contig rank x span + centre), the pairs priced in blocks of ``block`` -- so that long
+        contigs (thousands of fragments inside the window: 1e8 pairs at C5's 7 contigs) cost large vector operations instead of
+        thousands of short ones.  ``in_set`` (bool per bin) restricts the sum to pairs whose two bins are both in the set.
+        tests/test_sparse_reformulation.py holds it to ``mass_cis``."""
+        centres = self.centres(state) if centres is None else centres
+        b = self.bin_of
+        sub = np.arange(self.S) if in_set is None else np.flatnonzero(np.asarray(in_set, dtype=bool)[b])
+        if len(sub) < 2:
+            return 0.0
+        bs = b[sub]
+        key = state["id_c"][bs].astype(np.int64)
+        walk = np.where(state["ori"][bs] == 1, self.slot_of[sub], (self.n_sub[bs] - 1) - self.slot_of[sub])
+        order = np.lexsort((walk, state["pos"][bs], key))
+        so, ko, wo = sub[order], key[order], walk[order]
+        bo = b[so]
+        co = centres[bo, self.slot_of[so]].astype(np.float64)
+        d_max = float(self.param[5])
+        span = float(co.max() - min(co.min(), 0.0)) + d_max + 4.0
+        rank = np.cumsum(np.concatenate([[0], ko[1:] != ko[:-1]]))
+        g = rank * span + co                      # monotone along a contig, and a contig's reach never enters the next one
+        m = len(so)
+        hi = np.searchsorted(g, g + (d_max + 1.0), side="left")
+        if same_bin:                              # a bin's own pairs are priced whatever their distance (they follow each other)
+            hi = np.maximum(hi, np.arange(m) + (self.n_sub[bo] - 1 - wo) + 1)
+        cnt = np.maximum(hi - (np.arange(m) + 1), 0)
+        cum = np.concatenate([[0], np.cumsum(cnt)])
+        tot = 0.0
+        i0 = 0
+        while i0 < m:
+            i1 = int(np.searchsorted(cum, cum[i0] + block, side="right")) - 1
+            i1 = min(max(i1, i0 + 1), m)
+            c = cnt[i0:i1]
+            n_pairs = int(cum[i1] - cum[i0])
+            if n_pairs:
+                xi = np.repeat(np.arange(i0, i1), c)
+                yi = np.arange(n_pairs) - np.repeat(cum[i0:i1] - cum[i0], c) + xi + 1
+                x, y = so[xi], so[yi]
+                ex, norm = self._ex(state, centres, x, y)
+                samebin = b[x] == b[y]
+                ctr = (self.param[7] * norm).astype(np.float32)
+                term = ex.astype(np.float64) - np.where(samebin, 0.0, ctr.astype(np.float64))
+                if not same_bin:
+                    term = np.where(samebin, 0.0, term)
+                tot += float(term.sum())
+            i0 = i1
+        return tot
+
+    def set_contacts(self, in_set):
+        """Indices of the contacts that join two DIFFERENT bins of the set (bool per bin)."""
+        in_set = np.asarray(in_set, dtype=bool)
+        br, bc = self.bin_of[self.row], self.bin_of[self.col]
+        return np.flatnonzero(in_set[br] & in_set[bc] & (br != bc))
+
+    def restricted(self, state, in_set, contacts=None):
+        """The part of ``full(state, same_bin=False)`` that a move inside the set can change: the contacts between two different
+        bins of the set, minus the windowed cis correction of the set's sub-fragment pairs.  What is left out -- pixels with a bin
+        outside the set, the all-trans mass, the log-factorial constant -- is the same for every layout that differs from another
+        only inside the set (bins of different contigs are priced as trans whatever their labels), so
+
+            restricted(candidate) - restricted(current) == full(candidate, same_bin=False) - full(current, same_bin=False)
+
+        with the set = contig(fA) u contig(fB) of the current layout: the pixel set sub_compute_likelihood revisits
+        (kernels3.cu:3356-3380).  The large-size checker of the GPU suite (tests/test_independent_checker_gpu.py)."""
+        centres = self.centres(state)
+        idx = self.set_contacts(in_set) if contacts is None else contacts
+        ex, _ = self._ex(state, centres, self.row[idx], self.col[idx])
+        nnz = float((self.count[idx] * np.log(ex.astype(np.float64))).sum())
+        return nnz - self.mass_cis_windowed(state, centres, same_bin=False, in_set=in_set)
+
+    def full(self, state, same_bin=True, windowed=False):
         """same_bin=False leaves out every bin's own (diagonal) pixel: the pixel set sub_compute_likelihood
         revisits for a candidate never contains them (kernels3.cu:3356-3380, repeats aside), so candidate deltas
         are differences of full(..., same_bin=False)."""
         centres = self.centres(state)
+        mass = self.mass_cis_windowed if windowed else self.mass_cis
         return (self.nnz_part(state, centres, same_bin=same_bin) - self.c_lf
-                - (self.t_all() + self.mass_cis(state, centres, same_bin=same_bin)))
+                - (self.t_all() + mass(state, centres, same_bin=same_bin)))

@@ -80,3 +80,62 @@ def test_candidate_delta_sparse_equals_dense(n_sub, seed):
             want = dense.sub_compute(cand, np.sort(sub), [], np.arange(n, dtype=np.int32), per_pix)
             got = sparse.full(cand, same_bin=False) - base
             assert got == pytest.approx(want, abs=1e-7 * abs(base)), (fA, fB, op)  # float32 libm noise of two full re-scores
+
+
+def _layout_with_real_lengths(P, rng, n_contigs=5, p_circ=0.4):
+    n = P["n_frags"]
+    s = util.random_layout(rng, n, n_contigs=n_contigs, p_circ=p_circ)
+    s["len_bp"][:] = P["S_o_A_frags"]["len_bp"]
+    for lab in np.unique(s["id_c"]):
+        m = np.nonzero(s["id_c"] == lab)[0]
+        order = m[np.argsort(s["pos"][m])]
+        s["start_bp"][order] = np.cumsum(s["len_bp"][order]) - s["len_bp"][order]
+        s["l_cont_bp"][order] = s["len_bp"][order].sum()
+    return s
+
+
+@pytest.mark.parametrize("n_sub,seed", [(1, 11), (3, 12), (3, 13)])
+def test_windowed_enumeration_of_the_cis_mass_equals_the_offset_loop(n_sub, seed):
+    """mass_cis_windowed (one binary search per sub-fragment, pairs priced in blocks: the form the full-size checker of the GPU
+    suite can afford) against mass_cis (the offset loop the dense oracle pinned above), also with a tiny block size, a window
+    shorter than a bin and both same-bin settings."""
+    rng = np.random.RandomState(seed)
+    for d_max in (None, 2.5):
+        par = synth.make_param_simu(fact=300.0, v_inter=0.03, d_max=d_max)
+        P = synth.with_dense(synth.make_problem(n_bins=80, nnz=900, n_sub=n_sub, seed=seed, contig_weights=(5, 3, 2), mean_len_bp=1500.0,
+                                                accu=1 if n_sub == 1 else 9, param=par))
+        _, sparse = scorers(P)
+        for _ in range(3):
+            s = _layout_with_real_lengths(P, rng, n_contigs=int(rng.randint(1, 7)), p_circ=0.5)
+            for same_bin in (True, False):
+                want = sparse.mass_cis(s, same_bin=same_bin)
+                for block in (1 << 22, 37):
+                    got = sparse.mass_cis_windowed(s, same_bin=same_bin, block=block)
+                    assert got == pytest.approx(want, rel=1e-12, abs=1e-9), (n_sub, seed, d_max, same_bin, block)
+            assert sparse.full(s, windowed=True) == pytest.approx(sparse.full(s), rel=1e-13)
+
+
+@pytest.mark.parametrize("n_sub,seed", [(1, 17), (3, 18)])
+def test_restricted_rescore_gives_the_candidate_deltas(n_sub, seed):
+    """SparseScorer.restricted: the difference of two re-scores of contig(A) u contig(B) only == the difference of two FULL re-scores
+    == the dense oracle's sub_compute_likelihood, for all 13 candidates of a few proposals (circular contigs, reversed bins)."""
+    P = small_problem(n_sub, seed, n_bins=70, nnz=900, accu=1 if n_sub == 1 else 9)
+    dense, sparse = scorers(P)
+    rng = np.random.RandomState(seed)
+    n = P["n_frags"]
+    s = _layout_with_real_lengths(P, rng)
+    max_id = int(s["id_c"].max())
+    base = sparse.full(s, same_bin=False)
+    per_pix = np.zeros(dense.n_pix)
+    dense.evaluate(s, per_pix)
+    for _ in range(4):
+        fA, fB = rng.choice(n, 2, replace=False)
+        in_set = (s["id_c"] == s["id_c"][fA]) | (s["id_c"] == s["id_c"][fB])
+        idx = sparse.set_contacts(in_set)
+        base_r = sparse.restricted(s, in_set, idx)
+        for op in range(13):
+            cand, _ = util.oracle_candidate(s, fA, fB, op, max_id)
+            got = sparse.restricted(cand, in_set, idx) - base_r
+            assert got == pytest.approx(sparse.full(cand, same_bin=False) - base, abs=1e-11 * abs(base)), (fA, fB, op)
+            want = dense.sub_compute(cand, np.sort(np.nonzero(in_set)[0]), [], np.arange(n, dtype=np.int32), per_pix)
+            assert got == pytest.approx(want, abs=1e-7 * abs(base)), (fA, fB, op)
