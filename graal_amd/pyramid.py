@@ -61,13 +61,26 @@ def _coo_sum(fa, fb, nc):
 
 
 def abs_contacts_to_coo(abs_contact_file):
-    """``abs_contact_2_coo_file``: one line per contact with two 1-based fragment ids -> 0-based COO counts."""
-    with open(abs_contact_file) as f:
-        f.readline()
-        ab = [line.split()[:2] for line in f if line.strip()]
-    if not ab:
+    """``abs_contact_2_coo_file``: one line per contact with two 1-based fragment ids -> 0-based COO counts.
+    (pandas' C reader when it is importable -- a level-0 dataset holds 1e7-1e8 read lines --, plain Python otherwise: same result)"""
+    ab = None
+    try:
+        import pandas as pd
+        df = pd.read_csv(abs_contact_file, sep=r"\s+", header=0, usecols=[0, 1], dtype=np.int64, engine="c")
+        ab = df.to_numpy(dtype=np.int64) - 1
+    except ImportError:
+        pass
+    except Exception:      # (an unusual file: the plain reader judges it)
+        ab = None
+    if ab is None:
+        with open(abs_contact_file) as f:
+            f.readline()
+            rows = [line.split()[:2] for line in f if line.strip()]
+        if not rows:
+            return _coo_sum([], [], [])
+        ab = np.array(rows, dtype=np.int64) - 1
+    if len(ab) == 0:
         return _coo_sum([], [], [])
-    ab = np.array(ab, dtype=np.int64) - 1
     return _coo_sum(ab[:, 0], ab[:, 1], np.ones(len(ab), np.int64))
 
 
@@ -424,25 +437,35 @@ def select_repeated_frags(level_coo, n_frags, allow_repeats):
     return [(int(e), int(max(1, np.round(cov[e] / ext) - 1))) for e in cand]
 
 
-def simulation_inputs(pyramid, level, candidates_blacklist=(0,), allow_repeats=False):
+def simulation_inputs(pyramid, level, candidates_blacklist=(0,), allow_repeats=False, level0_accu_from_file=False):
     """What ``simulation.__init__`` hands to the sampler constructor (``simulation_loader.py:41-107``), from level `level`
     (bins) and level - 1 (sub-fragments = observations), with the contact matrices as COO triples; with ``allow_repeats``
     the high-coverage bins get extra copies (``modify_vect_frags``, ``simulation_loader.py:182-280``).  Returns a dict whose
-    keys are the constructor's argument names."""
-    lev, sub = pyramid.get_level(level), pyramid.get_level(level - 1)
+    keys are the constructor's argument names.
+
+    ``level == 0`` -- BASELINE.json's "pyramid level 0 (full restriction-fragment resolution)", SURVEY.md section 8d "C4" -- is what the
+    reference cannot run (``simulation_loader.py:45,68`` needs level - 1, the GUI offers levels 1.. ``main_window.py:452``, and the dense
+    pixel index stops at ~4,500 bins): the loader of ``pyramid_sparse.py:1206-1380`` generalised so that the bins ARE the level-0
+    fragments.  Every bin is its own single sub-fragment (``np_sub_frags_id[i] = (i, 0, 0, 1)``, length ``len_bp / 1000`` kb), counts
+    as ONE restriction fragment (``accu = 1``, ``mean_squared_frags_per_bin = 1.0``: the pixel of two bins is their contact count, no
+    area normalisation; ``level0_accu_from_file=True`` takes the filter's ``accu_frag`` column instead -- a merged bin then weighs as the
+    fragments it swallowed, ``simulation_loader.py:695``), both contact matrices are the level-0 COO list, ``mean_value_trans`` and the
+    Rippe fit's histogram come from level 0 too."""
+    lev = pyramid.get_level(level)
+    sub = pyramid.get_level(level - 1) if level > 0 else lev
     frags = pyramid.spec_level[str(level)]["fragments"]
     n = lev.n_frags
     ids, lens, accu, collect = np.zeros((n, 4), np.int32), np.zeros((n, 3), np.float32), np.zeros((n, 3), np.int32), []
     n_sub_total = 0
     for i, f in enumerate(frags):               # create_sub_frags, simulation_loader.py:673-704
-        lo, hi = f["sub_low_index"] - 1, f["sub_high_index"] - 1
+        lo, hi = (f["sub_low_index"] - 1, f["sub_high_index"] - 1) if level > 0 else (i, i)
         ns = hi - lo + 1
         ids[i, 3] = ns
         n_sub_total += ns
         for j in range(ns):
             lens[i, j] = np.float32(sub.S_o_A_frags["len_bp"][lo + j]) / np.float32(1000.0)
             ids[i, j] = lo + j
-            accu[i, j] = sub.S_o_A_frags["n_accu"][lo + j]
+            accu[i, j] = sub.S_o_A_frags["n_accu"][lo + j] if (level > 0 or level0_accu_from_file) else 1
             collect.append(accu[i, j])
     S = {k: np.array(lev.S_o_A_frags[k], dtype=np.int32) for k in ("pos", "id_c", "start_bp", "len_bp", "circ", "id", "prev",
                                                                      "next", "l_cont", "l_cont_bp")}

@@ -78,7 +78,8 @@ def mean_contacts_per_bin(S_o_A_sub_frags, sub_coo, bins, max_dist_kb, size_bin_
     d = dist(row[cis], col[cis])
     ok = d < max_dist_kb
     idx = (d[ok] / size_bin_kb).astype(np.int64)
-    np.add.at(sums, np.clip(idx, 0, n_bins - 1), np.asarray(val)[cis][ok])
+    # (bincount accumulates in list order like np.add.at: the same float64 sums, ~30x faster -- level 0 holds 1e7 contacts)
+    sums += np.bincount(np.clip(idx, 0, n_bins - 1), weights=np.asarray(val, dtype=np.float64)[cis][ok], minlength=n_bins)
     # number of cis pairs per distance bin: per contig, pairs at position offset k while the distance is in range
     counts = np.zeros(n_bins)
     for c in np.unique(id_c):
@@ -89,7 +90,7 @@ def mean_contacts_per_bin(S_o_A_sub_frags, sub_coo, bins, max_dist_kb, size_bin_
             okk = dk < max_dist_kb
             if not okk.any():
                 break
-            np.add.at(counts, np.clip((dk[okk] / size_bin_kb).astype(np.int64), 0, n_bins - 1), 1)
+            counts += np.bincount(np.clip((dk[okk] / size_bin_kb).astype(np.int64), 0, n_bins - 1), minlength=n_bins)
     mean = np.full(n_bins, 1e-10, dtype=np.float32)
     good = (counts > 0) & (sums > 0)
     mean[good] = (sums[good] / counts[good]).astype(np.float32)

@@ -2,6 +2,7 @@
 ``simulation_loader.simulation.__init__`` -> ``main_gl.window.start_EM``), without wx / GLUT:
 
     python -m graal_amd.run --dataset DIR [--fasta genome.fa] --level 3 --cycles 100 --neighbours 3 --out OUT
+    python -m graal_amd.run --dataset DIR --size-pyramid 1 --level 0 ...      (restriction-fragment resolution, BASELINE config 4)
 
 DIR holds ``info_contigs.txt``, ``fragments_list.txt``, ``abs_fragments_contacts_weighted.txt`` (``README.md:111-113``).
 Steps: build (or reuse) the pyramid, build the sampler inputs of the chosen level, fit the Rippe contact model, run the
@@ -23,7 +24,9 @@ def main(argv=None):
     ap.add_argument("--fasta", default=None)
     ap.add_argument("--size-pyramid", type=int, default=4)
     ap.add_argument("--factor", type=int, default=3)
-    ap.add_argument("--level", type=int, default=3, help="pyramid level of the bins (1 .. size-pyramid - 1)")
+    ap.add_argument("--level", type=int, default=3, help="pyramid level of the bins: 1 .. size-pyramid - 1 as in the reference's GUI (main_window.py:452), "
+                                                         "or 0 = full restriction-fragment resolution (bins = the filtered level-0 fragments, one "
+                                                         "sub-fragment each: what the dense reference cannot run, BASELINE config 4)")
     ap.add_argument("--cycles", type=int, default=10)
     ap.add_argument("--neighbours", type=int, default=3)
     ap.add_argument("--blacklist", type=int, nargs="*", default=[0], help="contig ids to blacklist (0 = none)")
@@ -36,9 +39,11 @@ def main(argv=None):
                     help="strict = the reference's float32 pixel arithmetic (default: traces are the reference's); exact = "
                          "mathematically exact candidate deltas (faster on long contigs)")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--no-fit", action="store_true", help="skip the Rippe fit; needs --param (8 floats: kuhn lm c1 slope d d_max fact v_inter)")
+    ap.add_argument("--param", type=float, nargs=8, default=None, help="param_simu to run with instead of the fit's")
     args = ap.parse_args(argv)
-    if not 1 <= args.level < args.size_pyramid:
-        raise SystemExit("--level must be in 1 .. size-pyramid - 1 (the level below it holds the observations)")
+    if not 0 <= args.level < args.size_pyramid:
+        raise SystemExit("--level must be in 0 .. size-pyramid - 1 (levels >= 1: the level below holds the observations; 0: the level itself)")
     from .sampler import sampler
     root = os.path.join(args.dataset, "pyramids", "pyramid_%d_thresh_auto" % args.size_pyramid)
     if os.path.exists(os.path.join(root, "pyramid.npz")):
@@ -58,7 +63,14 @@ def main(argv=None):
     g.copy_from_gpu()
     mean_dist_kb = float(g.l_cont_bp[g.start_bp == 0].mean()) / 1000.0
     size_bin_kb = float(g.len_bp.mean()) / 1000.0
-    smp.estimate_parameters(mean_dist_kb, size_bin_kb)
+    if args.no_fit:
+        if args.param is None:
+            raise SystemExit("--no-fit needs --param")
+        smp.set_param_simu(np.asarray(args.param, dtype=np.float32))
+    else:
+        smp.estimate_parameters(mean_dist_kb, size_bin_kb)
+        if args.param is not None:
+            smp.set_param_simu(np.asarray(args.param, dtype=np.float32))
     t0 = time.perf_counter()
     trace = em.run_em(smp, args.cycles, args.neighbours, rng=rng, sample_param=args.sample_params, scrambled=not args.no_explode)
     dt = time.perf_counter() - t0

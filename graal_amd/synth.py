@@ -252,6 +252,49 @@ def add_repeats(problem, dup_bins, n_copies):
     return p
 
 
+def write_dataset(problem, folder, max_reads=None):
+    """A synthetic problem (n_sub = 1: bins = restriction fragments) as the reference's 3-file TEXT dataset (``README.md:111-113``):
+    ``info_contigs.txt``, ``fragments_list.txt`` and ``abs_fragments_contacts_weighted.txt`` -- ONE line per read pair, so a contact of
+    count c is written c times (``abs_contact_2_coo_file``, ``pyramid_sparse.py:222-264``, counts lines).  What ``python -m graal_amd.run
+    --dataset folder --size-pyramid 1 --level 0`` starts from: BASELINE config 4's data path on a stand-in.
+    ``max_reads``: cap the number of read lines (contacts keep at least one read each).  Returns the number of read lines."""
+    import os
+    S = problem["S_o_A_frags"]
+    n = int(problem["n_frags"])
+    if int(problem["init_n_sub_frags"]) != n:
+        raise ValueError("write_dataset needs a problem with one sub-fragment per bin")
+    os.makedirs(folder, exist_ok=True)
+    id_c = np.asarray(S["id_c"])
+    labels = np.unique(id_c)
+    with open(os.path.join(folder, "info_contigs.txt"), "w") as f:
+        f.write("contig\tlength_kb\tn_frags\tcumul_length\n")
+        cum = 0
+        for c in labels:
+            m = id_c == c
+            f.write("contig%d\t%d\t%d\t%d\n" % (int(c), int(np.asarray(S["len_bp"])[m].sum()), int(m.sum()), cum))
+            cum += int(m.sum())
+    start, length, pos = (np.asarray(S[k]).astype(np.int64) for k in ("start_bp", "len_bp", "pos"))
+    with open(os.path.join(folder, "fragments_list.txt"), "w") as f:
+        f.write("id\tchrom\tstart_pos\tend_pos\tsize\tgc_content\n")
+        f.write("".join("%d\tcontig%d\t%d\t%d\t%d\t0.5\n" % (pos[i] + 1, id_c[i], start[i], start[i] + length[i], length[i]) for i in range(n)))
+    row, col, val = (np.asarray(problem[k]).astype(np.int64) for k in ("coo_row", "coo_col", "coo_val"))
+    if max_reads is not None and val.sum() > max_reads:
+        extra = np.maximum(val - 1, 0)
+        keep = max(0, int(max_reads) - len(val))
+        val = 1 + np.floor(extra * (keep / max(1, int(extra.sum())))).astype(np.int64)
+    a, b = np.repeat(row + 1, val), np.repeat(col + 1, val)
+    path = os.path.join(folder, "abs_fragments_contacts_weighted.txt")
+    try:
+        import pandas as pd
+        pd.DataFrame({"id_read_a": a, "id_read_b": b, "w": np.ones(len(a), np.int8)}).to_csv(path, sep="\t", index=False)
+    except ImportError:
+        with open(path, "w") as f:
+            f.write("id_read_a\tid_read_b\tw\n")
+            for i in range(0, len(a), 1 << 20):
+                f.write("".join("%d\t%d\t1\n" % t for t in zip(a[i:i + (1 << 20)].tolist(), b[i:i + (1 << 20)].tolist())))
+    return int(len(a))
+
+
 def dense_from_coo(row, col, val, n, dtype=np.float32):
     """Symmetric dense matrix with a zero diagonal, as ``simulation_loader.py:81-82`` +
     ``cuda_lib_gl.py:155-160`` build it.  Test / oracle helper for SMALL problems only."""

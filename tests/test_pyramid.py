@@ -302,3 +302,58 @@ def test_pyramid_matches_the_reference_run(tmp_path):
             for k, v in r["S_o_A_frags"].items():
                 assert np.array_equal(np.asarray(L.S_o_A_frags[k]).astype(int), np.array(v)), (lev, k)
             assert float(L.mean_value_trans) == pytest.approx(r["mean_value_trans"], rel=1e-12)
+
+
+def test_level0_simulation_inputs(tmp_path):
+    """simulation_inputs(pyramid, 0) -- BASELINE.json's "pyramid level 0 (full restriction-fragment resolution)", SURVEY 8d C4, which the
+    reference cannot run (simulation_loader.py:45,68 needs level - 1): bins = the filtered level-0 fragments, one sub-fragment each,
+    accu = 1, n_frags_per_bins = 1, both matrices the level-0 COO list, mean_value_trans and the fit's layout from level 0."""
+    rng = np.random.RandomState(4)
+    base = str(tmp_path / "ds")
+    make_dataset(base, rng)
+    P = pyr.build_and_filter(base, 1, 3)                  # a pyramid of ONE level is enough
+    lev = P.get_level(0)
+    inp = pyr.simulation_inputs(P, 0, candidates_blacklist=[3])
+    n = inp["n_frags"]
+    assert n == lev.n_frags == 21 == inp["n_new_frags"] == inp["init_n_sub_frags"] == inp["n_new_sub_frags"]
+    assert np.array_equal(inp["np_sub_frags_id"], np.stack([np.arange(n), np.zeros(n), np.zeros(n), np.ones(n)], 1).astype(np.int32))
+    assert np.array_equal(inp["np_sub_frags_len_bp"][:, 0], np.float32(lev.S_o_A_frags["len_bp"]) / np.float32(1000.0))
+    assert not inp["np_sub_frags_len_bp"][:, 1:].any()
+    assert np.array_equal(inp["np_sub_frags_accu"], np.stack([np.ones(n), np.zeros(n), np.zeros(n)], 1).astype(np.int32))
+    assert inp["mean_squared_frags_per_bin"] == np.float32(1.0)
+    for k in range(3):
+        assert np.array_equal(inp["hic_matrix"][k], lev.coo[k]) and np.array_equal(inp["hic_matrix_sub_sampled"][k], lev.coo[k])
+    assert inp["mean_value_trans"] == lev.mean_value_trans
+    for k in lev.S_o_A_frags:
+        assert np.array_equal(inp["S_o_A_sub_frags"][k], lev.S_o_A_frags[k]), k
+    assert np.array_equal(inp["S_o_A_frags"]["id_d"], np.arange(n)) and (inp["S_o_A_frags"]["ori"] == 1).all()
+    assert inp["id_frags_blacklisted"] == list(np.nonzero(lev.S_o_A_frags["id_c"] == 3)[0])
+    assert np.array_equal(inp["frag_dispatcher"], np.stack([np.arange(n), np.arange(n) + 1], 1))
+    # the merged level-0 bin (two restriction fragments swallowed by the sparsity filter) weighs as one bin by default, as the
+    # fragments it holds with level0_accu_from_file (simulation_loader.py:695 at the levels above)
+    inp2 = pyr.simulation_inputs(P, 0, level0_accu_from_file=True)
+    assert np.array_equal(inp2["np_sub_frags_accu"][:, 0], lev.S_o_A_frags["n_accu"]) and inp2["np_sub_frags_accu"][:, 0].max() == 2
+    assert inp2["mean_squared_frags_per_bin"] == np.float32(np.float32(lev.S_o_A_frags["n_accu"]).mean() ** 2)
+    # the Rippe histogram comes from the same COO list / layout (cuda_lib_gl.py:1236-1270)
+    from graal_amd import rippe_fit
+    bins = np.arange(1.0, 12.0, 1.0)
+    mc = rippe_fit.mean_contacts_per_bin(inp["S_o_A_sub_frags"], inp["hic_matrix"], bins, 11.0, 1.0)
+    assert mc.shape == bins.shape and (mc > 0).all() and mc[0] > mc[-1]
+
+
+def test_synthetic_problem_as_a_three_file_dataset(tmp_path):
+    """synth.write_dataset: a synthetic level-0 problem written as the reference's text dataset and read back through the pyramid
+    builder (one line per read pair: counts come back as the numbers of lines) -- tools/run_configs.py feeds C4 this way."""
+    from graal_amd import synth
+    P = synth.make_problem(n_bins=300, nnz=12000, n_sub=1, seed=5, contig_weights=(5, 3, 2), mean_len_bp=1500.0)
+    base = str(tmp_path / "ds")
+    n_reads = synth.write_dataset(P, base)
+    assert n_reads == int(P["coo_val"].sum())
+    r, c, v = pyr.abs_contacts_to_coo(os.path.join(base, "abs_fragments_contacts_weighted.txt"))
+    assert np.array_equal(r, P["coo_row"]) and np.array_equal(c, P["coo_col"]) and np.array_equal(v, P["coo_val"])
+    py = pyr.build_and_filter(base, 1, 3)
+    inp = pyr.simulation_inputs(py, 0)
+    kept = inp["n_frags"]
+    assert 0.7 * 300 <= kept <= 300                      # the sparsity filter merges / drops the sparsest rows
+    assert inp["S_o_A_frags"]["len_bp"].sum() <= P["S_o_A_frags"]["len_bp"].sum()
+    assert int(inp["hic_matrix"][2].sum()) <= n_reads

@@ -204,6 +204,46 @@ def test_headless_run_from_a_dataset_folder(tmp_path):
     assert np.array_equal(tr2.mutations(), tr.mutations())
 
 
+def test_level0_headless_run_equals_the_oracle(tmp_path):
+    """BASELINE.json's headline configuration, "pyramid level 0 (full restriction-fragment resolution)" -- SURVEY 8d C4 -- from a dataset
+    folder: python -m graal_amd.run --size-pyramid 1 --level 0 (bins = the filtered level-0 fragments, one sub-fragment each, both
+    matrices the level-0 COO list; graal_amd/pyramid.py:simulation_inputs).  The reference cannot run this level
+    (simulation_loader.py:45,68); its algorithm can: the oracle's literal restatement fed with the DENSE matrix of the same inputs gives
+    the trace the headless run must reproduce -- accepted moves, contig counts and distances bit for bit."""
+    import os
+    from graal_amd import pyramid as pyr
+    from graal_amd import run
+    from tests.test_pyramid import make_dataset
+    base = str(tmp_path / "ds")
+    make_dataset(base, np.random.RandomState(31), contig_sizes=(40, 30, 20), n_pairs=40000, empty=(4, 45), polymer_like=True)
+    P0 = pyr.build_and_filter(base, 1, 3)
+    inp = pyr.simulation_inputs(P0, 0)
+    n = inp["n_frags"]
+    assert 80 <= n <= 90 and inp["init_n_sub_frags"] == n
+    par = synth.make_param_simu(fact=200.0, v_inter=max(float(inp["mean_value_trans"]), 0.02))
+    P = dict(inp)
+    P["param_simu"] = par
+    r, c, v = inp["hic_matrix"]
+    P["hic_matrix"] = synth.dense_from_coo(r, c, v, n)
+    P["hic_matrix_sub_sampled"] = synth.dense_from_coo(r, c, v, n)
+    seed = 32
+    ora = O.OracleSampler(P, np.random.RandomState(seed), fix_trans_accu=False)
+    t_ref = em.run_em(ora, 2, 4, rng=ora.rng)
+    out = str(tmp_path / "out")
+    tr = run.main(["--dataset", base, "--size-pyramid", "1", "--level", "0", "--cycles", "2", "--neighbours", "4", "--seed", str(seed),
+                   "--no-fit", "--param"] + [repr(float(x)) for x in par] + ["--fasta", os.path.join(base, "genome.fa"), "--out", out])
+    assert len(tr.likelihood) == 2 * n
+    assert np.array_equal(tr.mutations(), t_ref.mutations())
+    assert tr.n_contigs == t_ref.n_contigs and tr.dist == t_ref.dist
+    assert np.allclose(tr.likelihood, t_ref.likelihood, rtol=1e-5, atol=0)     # generic bp coordinates: north_star's tolerance
+    assert np.array_equal(em.load_mutations(os.path.join(out, "list_mutations.txt")), tr.mutations())
+    assert open(os.path.join(out, "genome.fasta")).read().count(">") >= 1
+    # and with the Rippe fit of the level-0 histogram in front (cuda_lib_gl.py:1229-1294), as the GUI's start button would run it
+    tr2 = run.main(["--dataset", base, "--size-pyramid", "1", "--level", "0", "--cycles", "1", "--neighbours", "3", "--seed", "5",
+                    "--out", str(tmp_path / "out2")])
+    assert len(tr2.likelihood) == n and np.isfinite(tr2.likelihood).all() and tr2.n_contigs[-1] < n
+
+
 @pytest.mark.parametrize("n_sub,black", [(1, False), (3, False), (3, True)])
 def test_genome_distance_kernel_equals_the_host_loop(n_sub, black):
     """k_dist (graal_genome_distance) against the vectorised host restatement of dist_inter_genome and the oracle's literal

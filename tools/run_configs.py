@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """GPU box: the BASELINE.json configurations 2-4 on synthetic stand-ins of the documented shapes (the
 S1 / T. reesei tarballs are not in this image): full headless start_EM runs (explode + n cycles) through the drop-in
-sampler, wall time per MCMC step, contigs left, final log-likelihood.  Usage: python tools/run_configs.py [C2 C3 C4] [--arithmetic strict|exact] [--cycles N]"""
+sampler, wall time per MCMC step, contigs left, final log-likelihood.  Usage: python tools/run_configs.py [C2 C3 C4 C4D] [--arithmetic strict|exact] [--cycles N]
+
+C4D = BASELINE config 4 through its DATA PATH: the C4 stand-in written as the reference's 3-file text dataset (synth.write_dataset: one line
+per read pair), then `python -m graal_amd.run --dataset ... --size-pyramid 1 --level 0` -- pyramid builder with its sparsity filter, level-0
+sampler inputs (graal_amd/pyramid.py:simulation_inputs), Rippe fit of the level-0 histogram, explode + MCMC cycles, trace files."""
 import os
 import sys
 import time
@@ -20,12 +24,40 @@ CONFIGS = {  # name: (n_bins, nnz, n_sub, cycles, neighbours, accu)
 }
 
 
+def run_c4_from_a_dataset(arith, cycles):
+    import shutil
+    import tempfile
+    from graal_amd import run
+    n_bins, nnz, n_sub, _, K, accu = CONFIGS["C4"]
+    t0 = time.perf_counter()
+    P = synth.make_problem(n_bins=n_bins, nnz=nnz, n_sub=1, seed=2014, contig_weights=(6.8, 6.2, 5.3, 4.6, 4.0, 3.4, 2.7), mean_len_bp=660.0, accu=1)
+    t_gen = time.perf_counter() - t0
+    base = tempfile.mkdtemp(prefix="graal_c4_dataset_")
+    try:
+        t0 = time.perf_counter()
+        n_reads = synth.write_dataset(P, base)
+        t_write = time.perf_counter() - t0
+        size_mb = os.path.getsize(os.path.join(base, "abs_fragments_contacts_weighted.txt")) / 1e6
+        print("C4D: stand-in generated in %.1f s, written as a 3-file dataset in %.1f s: %d fragments, %d contacts = %d read lines (%.0f MB)"
+              % (t_gen, t_write, n_bins, nnz, n_reads, size_mb), flush=True)
+        t0 = time.perf_counter()
+        tr = run.main(["--dataset", base, "--size-pyramid", "1", "--level", "0", "--cycles", str(cycles), "--neighbours", str(K), "--seed", "1",
+                       "--arithmetic", arith, "--out", os.path.join(base, "out")])
+        print("C4D [%s]: dataset -> pyramid -> level-0 inputs -> fit -> explode + %d cycles -> traces: %.1f s in all, %d MCMC steps, %d contigs left"
+              % (arith, cycles, time.perf_counter() - t0, len(tr.likelihood), tr.n_contigs[-1]), flush=True)
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+
+
 def main():
     args = sys.argv[1:]
     arith = args[args.index("--arithmetic") + 1] if "--arithmetic" in args else "strict"
     cyc = int(args[args.index("--cycles") + 1]) if "--cycles" in args else None
-    names = [a for a in args if a in CONFIGS] or ["C2", "C3", "C4"]
+    names = [a for a in args if a in CONFIGS or a == "C4D"] or ["C2", "C3", "C4"]
     for name in names:
+        if name == "C4D":
+            run_c4_from_a_dataset(arith, cyc or 2)
+            continue
         n_bins, nnz, n_sub, cycles, K, accu = CONFIGS[name]
         cycles = cyc or cycles
         P = synth.make_problem(n_bins=n_bins, nnz=nnz, n_sub=n_sub, seed=2014, contig_weights=(6.8, 6.2, 5.3, 4.6, 4.0, 3.4, 2.7),
