@@ -384,6 +384,7 @@ def main():
         for _ in range(5):
             smp2.engine.eval_full_q()
         late["full_eval_ms"] = 1e3 * (time.perf_counter() - tl) / 5
+        late["fallbacks"] = smp2.engine.run_counters()["fallbacks"]
         smp2.free_gpu()
         return late
 
@@ -717,6 +718,12 @@ def main():
             "full_mcmc_step_sample_param_ms": 1e3 * full_step_sp_s,
             "setup_s": {"generate": t_gen, "sampler": t_setup, "mcmc_warmup": t_mcmc},
         }
+        # steps the engine had to REPEAT behind events because an in-kernel wait between two kernels of a step ran out (k_tm waiting for the
+        # scan's announcement, k_strict2 for k_gprep's completion word: include/graal_hip.h, graal_run_counters) over this handle's whole
+        # life -- warm-up, settling, timed regions and extras; 0 unless a tool serialises the dispatches
+        rc_ = smp.engine.run_counters()
+        out["fallbacks"] = rc_["fallbacks"]
+        out["engine_counters"] = rc_
         out["other_arithmetic"] = other_block
         if long_region:
             out.update(long_region)

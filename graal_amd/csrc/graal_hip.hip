@@ -4220,6 +4220,15 @@ struct Ctx {
     bool pub_in_flight = false;   // ... and its k_tm carries the statistics' publication block (re-armed if the evaluation is repeated)
     unsigned long long tm_spin_ticks = getenv("GRAAL_TM_SPIN_TICKS") ? strtoull(getenv("GRAAL_TM_SPIN_TICKS"), nullptr, 10) : 2000000ull;   // 100 MHz ticks
     bool spin_used = false;       // the evaluation in flight relies on the flag (eval_sync repeats it with an event if k_tm gives up)
+    // k_strict2 behind k_gprep through a word in memory instead of an event (launch_strict): GRAAL_STRICT_GWAIT=0 orders them by the event,
+    // GRAAL_GP_WAIT_TICKS bounds the in-kernel wait (100 MHz ticks; 1 = give up at once: the test hook that forces the repeat-behind-events path),
+    // GRAAL_GP_ACQUIRE=1 makes every block's first wave run the agent-scope acquire even when it found the word at once
+    bool gwait_env = getenv("GRAAL_STRICT_GWAIT") == nullptr || atoi(getenv("GRAAL_STRICT_GWAIT")) != 0;
+    int gp_wait_ticks = getenv("GRAAL_GP_WAIT_TICKS") ? std::max(1, atoi(getenv("GRAAL_GP_WAIT_TICKS"))) : 200000;   // 2 ms
+    int gp_acquire = getenv("GRAAL_GP_ACQUIRE") ? atoi(getenv("GRAAL_GP_ACQUIRE")) : 0;
+    // run counters (graal_run_counters): evaluations, steps repeated behind events after an in-kernel wait ran out, k_strict2 launches that
+    // followed k_gprep through the word / behind the event, k_strict_flat launches, steps k_tm's finisher handed to a finishing kernel
+    long long rc_evals = 0, rc_repeats = 0, rc_gwait = 0, rc_gevent = 0, rc_flat = 0, rc_need_fin = 0;
     bool begin_launched = false;  // graal_begin_step_launch ran for the current layout; graal_begin_step only has to wait
     bool stats_from_apply = false; // the last commit published the statistics of the layout it produced (sequence stats_seq)
     bool fin_pending = false;
@@ -4708,12 +4717,12 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
         // (512 blocks: two per CU; cf. fin_blocks_no_wait), only one rank (a repeated step must not leave the ranks out of step), only while
         // the engine's streams are known to run side by side (spin_ok).  (768 blocks -- three per CU, still room -- with the wait instead of 1,024
         // behind the event: C3 / C4 stand-ins 214-221 / 238-243 us per step against 200-203 / 222-225.)
-        static const bool gwait_env = getenv("GRAAL_STRICT_GWAIT") == nullptr || atoi(getenv("GRAAL_STRICT_GWAIT")) != 0;
-        const bool gwait = gwait_env && publish && world == 1 && h->spin_ok && blocks <= 512;
+        const bool gwait = h->gwait_env && publish && world == 1 && h->spin_ok && blocks <= 512;
         s2.gp = gwait ? s2.next + 32 : nullptr;   // (ticket: 256 bytes behind the draw counter; the completion word 256 bytes behind the ticket: GP_DONE)
         s2.gp_seq = (unsigned long long)h->seq;
-        s2.gp_wait_ticks = 200000;   // 2 ms
-        if (gwait) h->spin_used = true;
+        s2.gp_wait_ticks = h->gp_wait_ticks;
+        s2.gp_acquire = h->gp_acquire;
+        if (gwait) { h->spin_used = true; h->rc_gwait += 1; } else h->rc_gevent += 1;
         const int cull_blocks = (int)std::min<unsigned long long>(1024ull, std::max<unsigned long long>(1ull, nt));
         // Where k_gprep goes.  A long scan (millions of contacts): on the auxiliary stream behind k_tm, under the scan; k_strict2 waits for both
         // through an event.  A short one (a map of a few thousand bins: the scan is over before k_tm's tables are): on the MAIN stream, behind
@@ -4812,6 +4821,7 @@ int launch_flat(Ctx* h, int fA, const Neigh* nbp /* nullptr: the neighbours of t
     const int blocks = blocks_env > 0 ? std::min(blocks_env, FLAT_BLOCKS) : FLAT_BLOCKS;
     Neigh nb;
     for (int k = 0; k < MAXK; k++) nb.fB[k] = nbp ? nbp->fB[k] : h->last_fB[k];
+    h->rc_flat += 1;
     if (h->single_sub) k_strict_flat<false><<<blocks, 256, 0, st>>>(fa, sx, fA, nb, K, rank, world, d_q_out, publish ? h->res_dev : nullptr, h->seq);
     else k_strict_flat<true><<<blocks, 256, 0, st>>>(fa, sx, fA, nb, K, rank, world, d_q_out, publish ? h->res_dev : nullptr, h->seq);
     CK(hipGetLastError());
@@ -5813,6 +5823,7 @@ static int eval_sync(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int
     h->publish = true;
     h->step_needed_fin = false;
     h->step_needed_geom = false;
+    h->rc_evals += 1;
     int rc = graal_eval_candidates_q(h, fA, fB, K, max_id, rank, world, (int64_t*)h->d_qout, nullptr);
     h->publish = false;
     if (rc) return rc;
@@ -5830,6 +5841,7 @@ static int eval_sync(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int
             if (h->eval_timing) t2 = now_us();
             h->publish = true;
             h->step_needed_fin = true;
+            h->rc_need_fin += 1;
             if ((h->mode & GRAAL_MODE_STRICT) && flat_allowed(h, world) && !h->flat_tried) { // small sets first; if they are not, it says NEED_FIN again
                 h->flat_tried = true;
                 rc = launch_flat(h, fA, nullptr, K, rank, world, (long long*)h->d_qout, true, h->stream);
@@ -5875,6 +5887,7 @@ static int eval_sync(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int
         // Everything of the step has ended by now; put the step's accumulators back to rest and repeat it ordered by the host --
         // and stay with events from here on.
         h->spin_ok = false; h->spin_used = false;
+        h->rc_repeats += 1;
         fprintf(stderr, "graal: kernels of the engine's two streams did not run side by side (a tool that serialises dispatches?): step repeated, "
                         "the steps are ordered through events from here on\n");
         if (h->pub_in_flight) h->stats_pub_pending = true;   // (its publication block gave up with the others)
@@ -6272,6 +6285,14 @@ int graal_last_counters(graal_ctx* h, int64_t out[4])
     CK(hipStreamSynchronize(h->stream));
     CK(hipMemcpy(res, h->d_scalars + 18, sizeof res, hipMemcpyDeviceToHost));
     out[0] = h->nnz; out[1] = res[0]; out[2] = res[2]; out[3] = res[1];
+    return GRAAL_OK;
+}
+
+int graal_run_counters(graal_ctx* h, int64_t out[8])
+{
+    if (!h || !out) return GRAAL_E_ARG;
+    out[0] = h->rc_evals; out[1] = h->rc_repeats; out[2] = h->spin_ok ? 1 : 0; out[3] = h->rc_gwait; out[4] = h->rc_gevent;
+    out[5] = h->rc_flat; out[6] = h->rc_need_fin; out[7] = h->gave_up;
     return GRAAL_OK;
 }
 

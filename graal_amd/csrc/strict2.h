@@ -26,6 +26,7 @@ struct S2Args {
     unsigned long long* gp;
     unsigned long long gp_seq;
     int gp_wait_ticks;
+    int gp_acquire;              // 1: a block's first wave runs the agent-scope acquire also when it found the word at once
 };
 
 #if defined(GRAAL_STAMPS) && defined(GRAAL_S2_COUNTS)   // (work counters: per-lane atomics -- they distort the stamps' timeline)
@@ -397,7 +398,10 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
             // the caches held of earlier steps went at the kernel's own start, and what they hold now was fetched behind the word.  A block that
             // had to wait invalidates once, by ONE wave (the caches are the CU's and the XCD's, not the wave's: all 2,048 waves of the grid doing
             // it were 15 us of this kernel's prologue, one wave per block still 3)
-            if (waited) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (waited || s2.gp_acquire) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the invalidate completes asynchronously: the barrier below must not release the other waves before it has)
+            }
         }
         __syncthreads();
         STAMP(23, blockIdx.x == 0 && threadIdx.x == 0);

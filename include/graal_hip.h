@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GRAAL_ABI_VERSION 6
+#define GRAAL_ABI_VERSION 7
 #define GRAAL_N_OPS 13        /* candidates per (fA, fB): cuda_lib_gl.py:112 n_tmp_struct */
 #define GRAAL_MAX_NEIGHBOURS 10 /* neighbours scored by one scan pass (the reference proposes at most n_neighbors = 10, cuda_lib_gl.py:444) */
 #define GRAAL_Q_BITS 30
@@ -208,6 +208,14 @@ int graal_time_scan(graal_ctx* h, int32_t K, int32_t reps, float* avg_ms);
  * out[2]=queue slots (contacts with both ends in an affected contig; the few the third test rejects leave empty entries)
  * out[3]=mass work items (task x 64-fragment chunk) */
 int graal_last_counters(graal_ctx* h, int64_t out[4]);
+/* counters of the handle's whole life (no device access): out[0] = candidate evaluations started, out[1] = evaluations REPEATED behind
+ * events because an in-kernel wait between two kernels of a step ran out (k_tm waiting for the scan's announcement, k_strict2 waiting for
+ * k_gprep's completion word: the kernels were not resident together -- a profiler serialising dispatches; results are the same, the
+ * engine stays with events from then on), out[2] = 1 while the in-kernel waits are still in use, out[3] / out[4] = launches of the tiled
+ * reference-arithmetic kernel that followed k_gprep through the completion word / behind the event, out[5] = k_strict_flat launches,
+ * out[6] = evaluations the table kernel handed to a finishing kernel through the host, out[7] = times its finisher gave up waiting for
+ * the scan.  bench.py reports out[1] as `fallbacks`. */
+int graal_run_counters(graal_ctx* h, int64_t out[8]);
 
 /* ---- the sampler's per-step HOST logic behind the boundary (graal_amd/csrc/host_step.h) --------------------------------
  * What cuda_lib_gl.sampler.step_max_likelihood does on the host between its launches: return_neighbours

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, sym), sym
     L.graal_abi_version.restype = ctypes.c_int
     from graal_amd import lib
-    assert L.graal_abi_version() == lib.ABI_VERSION == 6
+    assert L.graal_abi_version() == lib.ABI_VERSION == 7
 
 
 def test_no_gpu_means_a_loud_error_not_a_fallback():

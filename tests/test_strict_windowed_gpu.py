@@ -170,3 +170,50 @@ def test_strict_total_carried_over_equals_a_full_evaluation():
     g3 = make_gpu_sampler(P3, np.random.RandomState(5), reference_arithmetic="strict")
     assert g3.resync_every == 1
     g3.free_gpu()
+
+
+@pytest.mark.timeout(1500)
+def test_hand_off_behind_k_gprep_survives_its_time_out(monkeypatch):
+    """k_strict2 follows k_gprep through a word in memory instead of an event (grids of <= 512 blocks, one rank: launch_strict,
+    strict2.h).  The same 150 MCMC steps at the C2 stand-in's shape from its 7 original contigs (every step through k_gprep + k_strict2)
+    (a) behind the event (GRAAL_STRICT_GWAIT=0: the anchor), (b) through the word (the default), (c) with the wait made to run out at
+    once (GRAAL_GP_WAIT_TICKS=1: a block that does not find the word gives up, the step is flagged failed, repeated behind events and the
+    engine stays with events -- asserted through graal_run_counters), (d) with the acquire forced on every block (GRAAL_GP_ACQUIRE=1):
+    every step's 13 x K scores, the accepted-move trace, the likelihood series and the generator state must be the same."""
+    from tests.test_sampler_gpu import make_gpu_sampler
+    from tests.test_strict_gpu import ref_problem
+    P = ref_problem(1086, 120_000, 2016, contig_weights=synth.C5_CONTIG_WEIGHTS, mean_len_bp=660.0, fact=200.0, v_inter=0.02)
+    n_steps = 150
+
+    def go(env):
+        for k in ("GRAAL_STRICT_GWAIT", "GRAAL_GP_WAIT_TICKS", "GRAAL_GP_ACQUIRE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        rng = np.random.RandomState(31)
+        g = make_gpu_sampler(P, rng, reference_arithmetic="strict")
+        g.init_likelihood()
+        order = np.arange(int(g.n_new_frags), dtype=np.int32)
+        rng.shuffle(order)
+        scores, trace = [], []
+        for i in order[:n_steps]:
+            r = g.step_max_likelihood(int(i), 3)
+            scores.append(np.array(g.score, dtype=np.float64, copy=True))
+            trace.append((int(i), int(r[6]), int(r[5]), float(r[0]), int(r[1])))
+        st = rng.get_state(legacy=False)["state"]
+        rc = g.engine.run_counters()
+        g.free_gpu()
+        return scores, trace, int(st["pos"]), st["key"].copy(), rc
+    want = go({"GRAAL_STRICT_GWAIT": "0"})
+    assert want[4]["strict2_behind_the_word"] == 0 and want[4]["strict2_behind_the_event"] >= n_steps // 2 and want[4]["fallbacks"] == 0
+    for env in ({}, {"GRAAL_GP_WAIT_TICKS": "1"}, {"GRAAL_GP_ACQUIRE": "1"}):
+        got = go(env)
+        rc = got[4]
+        if env.get("GRAAL_GP_WAIT_TICKS"):
+            assert rc["fallbacks"] >= 1 and rc["in_kernel_waits_in_use"] == 0, rc      # the time-out did fire, the engine went back to events
+        else:
+            assert rc["fallbacks"] == 0 and rc["strict2_behind_the_word"] >= n_steps // 2, rc
+        assert got[1] == want[1], env
+        assert got[2] == want[2] and np.array_equal(got[3], want[3]), env
+        for a, b in zip(got[0], want[0]):
+            assert np.array_equal(a, b), env
