@@ -4222,10 +4222,12 @@ struct Ctx {
     bool spin_used = false;       // the evaluation in flight relies on the flag (eval_sync repeats it with an event if k_tm gives up)
     // k_strict2 behind k_gprep through a word in memory instead of an event (launch_strict): GRAAL_STRICT_GWAIT=0 orders them by the event,
     // GRAAL_GP_WAIT_TICKS bounds the in-kernel wait (100 MHz ticks; 1 = give up at once: the test hook that forces the repeat-behind-events path),
-    // GRAAL_GP_ACQUIRE=1 makes every block's first wave run the agent-scope acquire even when it found the word at once
+    // GRAAL_GP_ACQUIRE=0: only a block that had to wait runs the agent-scope acquire (round 4's form).  Default 1: every block's first wave runs
+    // it behind its poll -- poll, acquire, wait for the invalidate, barrier, plain loads: the consumer form the memory model asks for, whatever
+    // the caches held (MI355X_MICROARCH.md, inter-workgroup visibility); not measurable at the C2 stand-in (117-127 us per step either way)
     bool gwait_env = getenv("GRAAL_STRICT_GWAIT") == nullptr || atoi(getenv("GRAAL_STRICT_GWAIT")) != 0;
     int gp_wait_ticks = getenv("GRAAL_GP_WAIT_TICKS") ? std::max(1, atoi(getenv("GRAAL_GP_WAIT_TICKS"))) : 200000;   // 2 ms
-    int gp_acquire = getenv("GRAAL_GP_ACQUIRE") ? atoi(getenv("GRAAL_GP_ACQUIRE")) : 0;
+    int gp_acquire = getenv("GRAAL_GP_ACQUIRE") ? atoi(getenv("GRAAL_GP_ACQUIRE")) : 1;
     // run counters (graal_run_counters): evaluations, steps repeated behind events after an in-kernel wait ran out, k_strict2 launches that
     // followed k_gprep through the word / behind the event, k_strict_flat launches, steps k_tm's finisher handed to a finishing kernel
     long long rc_evals = 0, rc_repeats = 0, rc_gwait = 0, rc_gevent = 0, rc_flat = 0, rc_need_fin = 0;

@@ -394,10 +394,12 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
             }
             if (!ok) atomicOr(&fa.counters[6], 8ull);
             s_last = ok ? 0 : 1;
-            // A block that found the word at once needs no invalidation: nothing of k_gprep's has been read by this grid before the word -- what
-            // the caches held of earlier steps went at the kernel's own start, and what they hold now was fetched behind the word.  A block that
-            // had to wait invalidates once, by ONE wave (the caches are the CU's and the XCD's, not the wave's: all 2,048 waves of the grid doing
-            // it were 15 us of this kernel's prologue, one wave per block still 3)
+            // The consumer side of the hand-off as the memory model asks for it: ONE relaxed poll, ONE agent-scope acquire by ONE wave of the block
+            // (the caches are the CU's and the XCD's, not the wave's: all 2,048 waves of the grid doing it were 15 us of this kernel's prologue),
+            // the wait for the invalidate, the barrier, then plain loads.  Round 4 skipped the acquire in a block that found the word at once
+            // (nothing of k_gprep's is read by this grid before the word, and the kernel's own start invalidated what earlier steps left: an
+            // argument from cache behaviour, not from the model; GRAAL_GP_ACQUIRE=0 keeps that form for A/B -- 21,720 steps x 39 sums at the C2
+            // stand-in were bit-identical either way, profiles/r05_handoff_soak.log, and the step costs the same, 117-127 us)
             if (waited || s2.gp_acquire) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the invalidate completes asynchronously: the barrier below must not release the other waves before it has)

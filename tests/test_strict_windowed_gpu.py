@@ -178,7 +178,8 @@ def test_hand_off_behind_k_gprep_survives_its_time_out(monkeypatch):
     strict2.h).  The same 150 MCMC steps at the C2 stand-in's shape from its 7 original contigs (every step through k_gprep + k_strict2)
     (a) behind the event (GRAAL_STRICT_GWAIT=0: the anchor), (b) through the word (the default), (c) with the wait made to run out at
     once (GRAAL_GP_WAIT_TICKS=1: a block that does not find the word gives up, the step is flagged failed, repeated behind events and the
-    engine stays with events -- asserted through graal_run_counters), (d) with the acquire forced on every block (GRAAL_GP_ACQUIRE=1):
+    engine stays with events -- asserted through graal_run_counters), (d) with the acquire only in blocks that had to wait (GRAAL_GP_ACQUIRE=0,
+    round 4's form):
     every step's 13 x K scores, the accepted-move trace, the likelihood series and the generator state must be the same."""
     from tests.test_sampler_gpu import make_gpu_sampler
     from tests.test_strict_gpu import ref_problem
@@ -206,7 +207,7 @@ def test_hand_off_behind_k_gprep_survives_its_time_out(monkeypatch):
         return scores, trace, int(st["pos"]), st["key"].copy(), rc
     want = go({"GRAAL_STRICT_GWAIT": "0"})
     assert want[4]["strict2_behind_the_word"] == 0 and want[4]["strict2_behind_the_event"] >= n_steps // 2 and want[4]["fallbacks"] == 0
-    for env in ({}, {"GRAAL_GP_WAIT_TICKS": "1"}, {"GRAAL_GP_ACQUIRE": "1"}):
+    for env in ({}, {"GRAAL_GP_WAIT_TICKS": "1"}, {"GRAAL_GP_ACQUIRE": "0"}):
         got = go(env)
         rc = got[4]
         if env.get("GRAAL_GP_WAIT_TICKS"):

@@ -5,7 +5,7 @@ Two samplers on the same problem, seed and arithmetic run the same MCMC side by 
 word; GRAAL_STRICT_GWAIT unset), B ordered by the event (GRAAL_STRICT_GWAIT=0, the anchor) -- and EVERY ONE of the 13 x K candidate scores
 of EVERY step is compared (float64 values of the int64 sums: bit equality), next to the accepted move.  Usage:
 
-    python tools/handoff_soak.py [C2|C3|C4] [--cycles N] [--acquire]      (--acquire: A with GRAAL_GP_ACQUIRE=1)
+    python tools/handoff_soak.py [C2|C3|C4] [--cycles N] [--no-acquire]      (--no-acquire: A with GRAAL_GP_ACQUIRE=0, round 4's form)
 
 Prints one line per shape: steps, steps whose tiled kernel followed the word (A) / the event (B), differing steps (must be 0), fallbacks,
 us per step of each."""
@@ -39,7 +39,7 @@ def build(P, seed, env):
 def main():
     args = sys.argv[1:]
     cyc = int(args[args.index("--cycles") + 1]) if "--cycles" in args else None
-    env_a = {"GRAAL_GP_ACQUIRE": "1"} if "--acquire" in args else {}
+    env_a = {"GRAAL_GP_ACQUIRE": "0"} if "--no-acquire" in args else {}
     names = [a for a in args if a in SHAPES] or ["C2", "C4"]
     for name in names:
         n_bins, nnz, n_sub, cycles, K, accu = SHAPES[name]
@@ -82,7 +82,7 @@ def main():
         print("%s: %d bins x %d sub, %d contacts, K = %d, %d cycles = %d steps x %d scores: steps with differing scores %d, differing moves %d | "
               "A (%s): tiled kernel behind the word %d / the event %d, flat %d, fallbacks %d, %.1f us/step | B (event): behind the word %d / the event %d, "
               "flat %d, fallbacks %d, %.1f us/step" % (name, n_bins, n_sub, nnz, K, cycles, steps, 13 * K, differing, moves_differ,
-                                                       "word + forced acquire" if env_a else "word", ca["strict2_behind_the_word"],
+                                                       "word, acquire only after a wait" if env_a else "word + acquire", ca["strict2_behind_the_word"],
                                                        ca["strict2_behind_the_event"], ca["flat_launches"], ca["fallbacks"], 1e6 * ta / steps,
                                                        cb["strict2_behind_the_word"], cb["strict2_behind_the_event"], cb["flat_launches"],
                                                        cb["fallbacks"], 1e6 * tb / steps), flush=True)
