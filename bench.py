@@ -629,7 +629,7 @@ def main():
             return None
         smp.engine.detach_exchange()
         smp.exchange = "rccl"
-        smp._attach_rccl_c()
+        smp._attach_rccl_c(opt_in=True)   # (the library-driven all-reduce is opt-in -- GRAAL_RCCL_C -- until a multi-GPU run has covered it: this IS that run, last in the job)
         for f, nb in props[:args.warmup]:
             smp._candidate_deltas(f, nb, max_id)
         sync_all()

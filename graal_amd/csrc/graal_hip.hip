@@ -2039,9 +2039,11 @@ __global__ void k_ln_tab(double* __restrict__ tab, int n, float nfpb, Par par)
     if (p < n) tab[p] = mm_ln(par.v_inter * ((float)p / nfpb));
 }
 
+constexpr long long Q_STEP_FAILED = 1ll << 32;   // added to d_q_out's first not-finite flag word by a rank whose step failed (hand_out)
 constexpr int X_SLOT_WORDS = 512;         // exchange slot: sequence word + MAXK*13 sums [+ a word of k_strict_flat]; from word X_COARSE the coarse sums; 4 KB
 constexpr int X_COARSE = 256;
-static_assert(2 + MAXK * N_OPS <= X_COARSE && X_COARSE + MAXK * N_OPS < X_SLOT_WORDS, "exchange slot too small");
+constexpr int X_WHY = 2 + MAXK * N_OPS;   // a failed step's reason bits (counters[6]), behind the sums and k_strict_flat's word
+static_assert(X_WHY < X_COARSE && 2 + MAXK * N_OPS <= X_COARSE && X_COARSE + MAXK * N_OPS < X_SLOT_WORDS, "exchange slot too small");
 // the last block of a step: read the K*13 sums, reset the accumulators and counters for the next step, hand the sums
 // out -- to d_q_out (device; the caller all-reduces them) or to PINNED HOST memory followed by the step's sequence
 // number (the host spins on that word instead of paying for a device->host copy and a stream-synchronise wake-up).
@@ -2049,7 +2051,9 @@ static_assert(2 + MAXK * N_OPS <= X_COARSE && X_COARSE + MAXK * N_OPS < X_SLOT_W
 __device__ __forceinline__ void hand_out(long long* out, unsigned long long* counters, unsigned long long* sync, int K,
                                          long long* d_q_out, volatile long long* host_res, long long seq)
 {
-    const bool failed = atomicAdd(&counters[6], 0ull) != 0ull;
+    const unsigned long long why = atomicAdd(&counters[6], 0ull);   // 1 / 4 / 8: an in-kernel wait ran out (tables or scan / relabel flag / k_gprep's word); 2: a work list overflowed
+    const bool failed = why != 0ull;
+    if (host_res && threadIdx.x == 0) host_res[X_WHY] = (long long)why;
     for (int i = threadIdx.x; i < K * N_OPS; i += TM_THREADS) {
         long long v = (long long)atomicExch((unsigned long long*)&out[i], 0ull); // read the final sum, reset for the next step
         const long long c = (long long)atomicExch((unsigned long long*)&out[MAXK * N_OPS + i], 0ull);   // the coarse sum (to_coarse), zero but for a rare candidate
@@ -2058,6 +2062,11 @@ __device__ __forceinline__ void hand_out(long long* out, unsigned long long* cou
         else { d_q_out[i] = flagged ? 0ll : v; d_q_out[MAXK * N_OPS + i] = c; d_q_out[2 * MAXK * N_OPS + i] = flagged ? 1ll : 0ll; }
     }
     __syncthreads();
+    // a FAILED step (counters[6]: a kernel of the step gave up waiting, a list overflowed) handed out to a device buffer: the failure must
+    // survive the ranks' all-reduce, or the partial sums come back as valid scores.  It travels in the first flag word as 2^32 -- a legitimate
+    // flag count is at most the number of ranks -- so the summed buffer says "some rank failed" on EVERY rank (Q_STEP_FAILED: k_qout_pub,
+    // graal_amd/sampler.py)
+    if (!host_res && failed && threadIdx.x == 0) d_q_out[2 * MAXK * N_OPS] += Q_STEP_FAILED;
     if (threadIdx.x >= 4 && threadIdx.x < 7) counters[NF_OFF + threadIdx.x - 4] = 0;
     if (threadIdx.x < 3) counters[8 + threadIdx.x] = atomicExch(&counters[threadIdx.x], 0ull);
     if (threadIdx.x == 3) { counters[5] = 0; counters[6] = 0; sync[0] = 0; }
@@ -4216,6 +4225,7 @@ struct Ctx {
     // next k_scan sets, not by an event; and it publishes the layout statistics in an extra block
     bool relabel_spin_pending = false, stats_pub_pending = false;
     bool spin_ok = getenv("GRAAL_NO_TM_SPIN") == nullptr;   // switched off when k_tm and k_scan turn out not to run concurrently
+    bool spin_ok_saved = true;                                // ... and while an RCCL communicator is attached (graal_attach_rccl / graal_detach_rccl)
     unsigned long long relabel_flag_seq = 0, scan_relabel_seq = 0;
     bool pub_in_flight = false;   // ... and its k_tm carries the statistics' publication block (re-armed if the evaluation is repeated)
     unsigned long long tm_spin_ticks = getenv("GRAAL_TM_SPIN_TICKS") ? strtoull(getenv("GRAAL_TM_SPIN_TICKS"), nullptr, 10) : 2000000ull;   // 100 MHz ticks
@@ -4317,6 +4327,11 @@ struct Ctx {
     unsigned long long* d_slist = nullptr;   // k_strict's unit list (k_strict_cull fills it), slist_cap entries
     unsigned long long* d_slist_n = nullptr; // its length, a word of d_scalars (zero at rest: k_strict's last block clears it)
     unsigned long long slist_cap = 0;
+    unsigned long long slist_floor = 0;      // entries the list holds at least: raised when a step's list overflowed (eval_sync grows it and repeats the step)
+    unsigned long long slist_worst = 0;      // the last launch's worst case (every tile pair of the union set listed)
+    long long rc_list_grown = 0;
+    unsigned long long slist_soft_cap = getenv("GRAAL_SLIST_SOFT_CAP") ? std::max<unsigned long long>(64ull, strtoull(getenv("GRAAL_SLIST_SOFT_CAP"), nullptr, 10))
+                                                                        : (1ull << 23);   // 8 M entries = 64 MB (C5's 7 contigs list ~1e5); tests set it small
     USet* d_uset = nullptr;       // reference arithmetic over the step's union set (strict2.h): the set, the classes per pair of global pieces
     GClass* d_cls = nullptr;
     int* d_cls_n = nullptr;
@@ -4690,13 +4705,21 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
         const int rep_max = rep_env >= 16 ? 16 : (rep_env >= 8 ? 8 : (rep_env >= 4 ? 4 : (rep_env >= 2 ? 2 : 1)));
         const unsigned long long target = 6ull * 4ull * (unsigned long long)blocks;
         const unsigned long long pairs_max = nt * (nt + 1ull) / 2ull;
-        const unsigned long long need = pairs_max * (unsigned long long)(64 / seg_unit) + 64ull;
+        const unsigned long long worst = pairs_max * (unsigned long long)(64 / seg_unit) + 64ull;
+        // The worst case -- EVERY tile pair of the union listed -- is quadratic in the union's size (2e9 entries for 1e6 fragments in a few
+        // contigs), while the interval cull lists the pairs within reach of each other under some candidate: orders of magnitude fewer.  One
+        // rank: the list holds SLIST_SOFT_CAP entries at most to begin with; if a step's list overflows, k_gprep says so (counters[6] bit 1),
+        // the step ends as failed, eval_sync grows the floor and repeats it.  Several ranks: the worst case (a repeated step on ONE rank would
+        // leave the ranks out of step).
+        const unsigned long long SLIST_SOFT_CAP = h->slist_soft_cap;   // (GRAAL_SLIST_SOFT_CAP, read when the handle is created)
+        h->slist_worst = worst;
+        const unsigned long long need = (world == 1 && publish) ? std::min(worst, std::max(SLIST_SOFT_CAP, h->slist_floor)) : worst;
         if (need > h->slist_cap) {
             CK(hipStreamSynchronize(st));
             CK(hipStreamSynchronize(h->aux));
             if (h->d_slist) CK(hipFree(h->d_slist));
             h->d_slist = nullptr;
-            const unsigned long long cap = std::max<unsigned long long>(need + need / 2ull, 1ull << 16);
+            const unsigned long long cap = std::max<unsigned long long>(need == worst ? need + need / 2ull : need, 1ull << 16);
             CK(hipMalloc(&h->d_slist, cap * sizeof(unsigned long long)));
             h->slist_cap = cap;
         }
@@ -4901,7 +4924,7 @@ static Rccl* rccl_load(std::string* err)
     const char* names[] = {getenv("GRAAL_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
     void* lib = nullptr;
     for (const char* n : names) if (n && !lib) lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-    if (!lib) { if (err) *err = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "dlopen failed"); return nullptr; }
+    if (!lib) { const char* e = dlerror(); if (err) *err = std::string("RCCL not found: ") + (e ? e : "dlopen failed"); return nullptr; }   // (dlerror() clears its state: once)
     R.GetUniqueId = (int (*)(NcclId*))dlsym(lib, "ncclGetUniqueId");
     R.CommInitRank = (int (*)(void**, int, NcclId, int))dlsym(lib, "ncclCommInitRank");
     R.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(lib, "ncclAllReduce");
@@ -5767,13 +5790,14 @@ int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t
 // layout the single-rank step publishes, the sequence word last
 __global__ void k_qout_pub(const long long* __restrict__ q, volatile long long* host, int K, long long seq)
 {
+    const bool failed = q[2 * MAXK * N_OPS] >= Q_STEP_FAILED;   // (some rank's step failed: every rank reads the same sum and publishes -seq)
     for (int i = threadIdx.x; i < K * N_OPS; i += blockDim.x) {
-        host[1 + i] = q[2 * MAXK * N_OPS + i] != 0 ? Q_NAN : q[i];
+        host[1 + i] = (q[2 * MAXK * N_OPS + i] & (Q_STEP_FAILED - 1)) != 0 ? Q_NAN : q[i];
         host[X_COARSE + i] = q[MAXK * N_OPS + i];
     }
     __threadfence_system();
     __syncthreads();
-    if (threadIdx.x == 0) { host[0] = seq; __threadfence_system(); }
+    if (threadIdx.x == 0) { host[0] = failed ? -seq : seq; __threadfence_system(); }
 }
 
 // synchronous evaluation: launch the step, spin on the sequence word its last block writes into pinned host memory (fall
@@ -5800,15 +5824,19 @@ static int eval_sync(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int
         volatile long long* res = h->h_res;
         bool seen = false;
         for (long long spin = 0; spin < 2000000000ll; spin++) {
-            if (res[0] == want) { seen = true; break; }
-            if ((spin & 0xfffff) == 0xfffff && hipStreamQuery(h->stream) != hipErrorNotReady) { seen = res[0] == want; break; }
+            if (res[0] == want || res[0] == -want) { seen = true; break; }
+            if ((spin & 0xfffff) == 0xfffff && hipStreamQuery(h->stream) != hipErrorNotReady) { seen = res[0] == want || res[0] == -want; break; }
             __builtin_ia32_pause();
         }
         if (!seen) {   // (bounded: a collective that a peer never enters must not hang this rank for ever)
             const auto t0 = std::chrono::steady_clock::now();
-            while (res[0] != want && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(60)) __builtin_ia32_pause();
-            if (res[0] != want) return fail(h, GRAAL_E_HIP, "RCCL exchange: the all-reduced sums were not published within 60 s (a rank out of step, or the collective hangs)");
+            while (res[0] != want && res[0] != -want && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(60)) __builtin_ia32_pause();
+            if (res[0] != want && res[0] != -want) return fail(h, GRAAL_E_HIP, "RCCL exchange: the all-reduced sums were not published within 60 s (a rank out of step, or the collective hangs)");
         }
+        // A failed step on ANY rank (hand_out: Q_STEP_FAILED travels through the all-reduce) is an error on EVERY rank, the same one, at the same
+        // step: no rank returns partial sums as scores, none repeats alone.  (With a communicator attached the engine uses no in-kernel waits --
+        // graal_attach_rccl switches them off -- so a failure here is a kernel that did not run, not a wait that a repeat behind events would cure.)
+        if (res[0] == -want) return fail(h, GRAAL_E_HIP, "RCCL exchange: the step failed on some rank (a kernel of the step gave up or a list overflowed); no scores were returned on any rank");
         __sync_synchronize();
         for (int i = 0; i < K * N_OPS; i++) { q_sum[i] = res[1 + i]; c_sum[i] = res[X_COARSE + i]; }
         return GRAAL_OK;
@@ -5884,14 +5912,22 @@ static int eval_sync(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int
         if (t2 > 0.0) { h->et_n[1] += 1; h->et[1] += t2 - t1; h->et[2] += t3 - t2; h->et[3] += t4 - t3; h->et[5] += t4 - t0; }
         else h->et[4] += t4 - t1;
     }
-    if (res[0] == -want && h->spin_used) {
-        // k_tm gave up waiting for k_scan's announcement: the two kernels did not run side by side (a tool serialising dispatches).
-        // Everything of the step has ended by now; put the step's accumulators back to rest and repeat it ordered by the host --
-        // and stay with events from here on.
-        h->spin_ok = false; h->spin_used = false;
-        h->rc_repeats += 1;
-        fprintf(stderr, "graal: kernels of the engine's two streams did not run side by side (a tool that serialises dispatches?): step repeated, "
-                        "the steps are ordered through events from here on\n");
+    const unsigned long long why = res[0] == -want ? (unsigned long long)res[X_WHY] : 0ull;
+    // (a step's unit list overflowed its soft cap -- launch_strict -- and can still grow: one rank only, see there)
+    const bool grow = (why & 2ull) != 0ull && world == 1 && h->slist_cap < h->slist_worst;
+    const bool waits = res[0] == -want && h->spin_used && ((why & ~2ull) != 0ull || !grow);
+    if (res[0] == -want && (waits || grow)) {
+        // k_tm gave up waiting for k_scan's announcement (or k_strict2 for k_gprep's word): the two kernels did not run side by side (a tool
+        // serialising dispatches).  Everything of the step has ended by now; put the step's accumulators back to rest and repeat it ordered
+        // by the host -- and stay with events from here on.  Or the step's unit list was too short: repeat with a longer one.
+        if (waits) {
+            h->spin_ok = false;
+            h->rc_repeats += 1;
+            fprintf(stderr, "graal: kernels of the engine's two streams did not run side by side (a tool that serialises dispatches?): step repeated, "
+                            "the steps are ordered through events from here on\n");
+        }
+        h->spin_used = false;
+        if (grow) { h->slist_floor = std::min(h->slist_worst, std::max<unsigned long long>(h->slist_cap, 1ull << 16) * 8ull); h->rc_list_grown += 1; }
         if (h->pub_in_flight) h->stats_pub_pending = true;   // (its publication block gave up with the others)
         CK(hipStreamSynchronize(h->stream));
         CK(hipStreamSynchronize(h->aux));
@@ -6039,6 +6075,12 @@ int graal_attach_rccl(graal_ctx* h, const void* id128, int32_t rank, int32_t wor
     const int nrc = R->CommInitRank(&comm, world, id, rank);
     if (nrc != 0 || !comm) { h->err = std::string("ncclCommInitRank failed: ") + (R->GetErrorString ? R->GetErrorString(nrc) : "?"); return GRAAL_E_HIP; }
     h->nccl_comm = comm; h->n_rank = rank; h->n_world = world;
+    // no in-kernel waits between the kernels of a step while a communicator is attached (k_tm behind the relabel through the scan's flag, the
+    // deferred statistics, k_strict2 behind k_gprep's word): their remedy -- one rank repeating its step behind events -- would leave the ranks
+    // out of step inside a collective.  Everything is ordered by events.
+    h->spin_ok_saved = h->spin_ok;
+    h->spin_ok = false;
+    h->relabel_spin_pending = false;
     return GRAAL_OK;
 }
 
@@ -6052,6 +6094,7 @@ int graal_detach_rccl(graal_ctx* h)
     Rccl* R = rccl_load(nullptr);
     if (R) (void)R->CommDestroy(h->nccl_comm);
     h->nccl_comm = nullptr; h->n_rank = 0; h->n_world = 1;
+    h->spin_ok = h->spin_ok_saved;
     return GRAAL_OK;
 }
 
@@ -6290,11 +6333,12 @@ int graal_last_counters(graal_ctx* h, int64_t out[4])
     return GRAAL_OK;
 }
 
-int graal_run_counters(graal_ctx* h, int64_t out[8])
+int graal_run_counters(graal_ctx* h, int64_t out[12])
 {
     if (!h || !out) return GRAAL_E_ARG;
     out[0] = h->rc_evals; out[1] = h->rc_repeats; out[2] = h->spin_ok ? 1 : 0; out[3] = h->rc_gwait; out[4] = h->rc_gevent;
-    out[5] = h->rc_flat; out[6] = h->rc_need_fin; out[7] = h->gave_up;
+    out[5] = h->rc_flat; out[6] = h->rc_need_fin; out[7] = h->gave_up; out[8] = h->rc_list_grown; out[9] = (int64_t)h->slist_cap;
+    out[10] = out[11] = 0;
     return GRAAL_OK;
 }
 

@@ -15,6 +15,7 @@ ABI_VERSION = 7
 MODE_REF_TRANS_ACCU, MODE_STRICT = 1, 2
 MAX_NEIGHBOURS = 10
 Q_SCALE = float(1 << 30)
+Q_STEP_FAILED = 1 << 32  # graal_eval_candidates_q: added to the first not-finite flag word by a rank whose step failed (include/graal_hip.h)
 Q_NAN = -(1 << 63)      # a candidate's Q sum EXACTLY this (INT64_MIN) stands for NaN: a term was not finite (graal_hip.hip: Q_NAN)
 
 
@@ -30,7 +31,10 @@ def q_to_float(q, c=None, flags=None):
             out = np.where(c != 0, c.astype(np.float64) + out, out)
     bad = q == Q_NAN
     if flags is not None:          # (the device buffer of the RCCL path: flags summed over the ranks)
-        bad = bad | (np.asarray(flags) != 0)
+        flags = np.asarray(flags, dtype=np.int64)
+        if len(flags) and int(flags.flat[0]) >= Q_STEP_FAILED:
+            raise GraalError("the step failed on some rank (a kernel of the step gave up or a list overflowed): the ranks' sums are not scores")
+        bad = bad | (flags != 0)
     if bad.any():
         out = np.where(bad, np.nan, out)
     return out
@@ -352,6 +356,12 @@ class Engine:
         return rc == 0
 
     @staticmethod
+    def rccl_available():
+        """True if librccl can be loaded in this process (what graal_attach_rccl needs; no communicator is made)."""
+        buf = ctypes.create_string_buffer(128)
+        return load().graal_rccl_unique_id(buf) == 0
+
+    @staticmethod
     def rccl_unique_id():
         """The 128-byte id of a new RCCL communicator (rank 0 makes it, every rank attaches with it)."""
         buf = ctypes.create_string_buffer(128)
@@ -479,10 +489,11 @@ class Engine:
     def run_counters(self):
         """include/graal_hip.h: graal_run_counters -- evaluations, repeats behind events (`fallbacks`), in-kernel waits in use,
         k_strict2 launches behind k_gprep's word / behind the event, k_strict_flat launches, hand-overs to a finishing kernel, finisher give-ups."""
-        c = np.zeros(8, dtype=np.int64)
+        c = np.zeros(12, dtype=np.int64)
         self._ck(self._L.graal_run_counters(self._h, c.ctypes.data_as(_i64p)), "graal_run_counters")
         return dict(zip(("evaluations", "fallbacks", "in_kernel_waits_in_use", "strict2_behind_the_word", "strict2_behind_the_event",
-                         "flat_launches", "handed_to_a_finishing_kernel", "finisher_gave_up"), (int(x) for x in c)))
+                         "flat_launches", "handed_to_a_finishing_kernel", "finisher_gave_up", "unit_list_grown", "unit_list_capacity"),
+                        (int(x) for x in c[:10])))
 
     def last_counters(self):
         c = np.zeros(4, dtype=np.int64)

@@ -616,30 +616,51 @@ class sampler(object):
         self.group.barrier()
         return "host"
 
-    def _attach_rccl_c(self):
+    def _attach_rccl_c(self, opt_in=None):
         """exchange="rccl" driven by the library (include/graal_hip.h: graal_attach_rccl): one ncclAllReduce per step on the engine's
         stream, the step's host logic in C.  Only when torch.distributed itself runs on RCCL (one process per GPU); with the gloo
-        rehearsal -- several ranks on ONE GPU, which RCCL refuses -- the all-reduce stays torch's (the Python path below)."""
+        rehearsal -- several ranks on ONE GPU, which RCCL refuses -- the all-reduce stays torch's (the Python path below).
+
+        OPT-IN (``GRAAL_RCCL_C=1``, or ``opt_in=True`` as bench.py's `exchange_alt` passes): no box this was built on holds two GPUs,
+        so a communicator of several ranks has never run; until it has, exchange="rccl" means torch's all-reduce unless asked otherwise.
+
+        Collective by construction: every rank reaches every collective below whatever happened to it locally -- failures travel as
+        VALUES (an all-reduce before ncclCommInitRank, which is itself a collective: a rank that cannot load librccl must not leave
+        its peers inside it; rank 0's id or None through the broadcast; an all-reduce behind the attach), never as a rank that
+        skipped a collective; the collectives themselves are not wrapped -- if one of them raises, it raises on every rank."""
         import os
         self._rccl_c = False
+        import torch.distributed as td
+        if opt_in is None:
+            opt_in = bool(os.environ.get("GRAAL_RCCL_C"))
+        if not (td.is_initialized() and td.get_backend() == "nccl") or os.environ.get("GRAAL_RCCL_TORCH") or not opt_in:
+            return          # (the same on every rank: the backend and the environment are the launcher's)
         try:
-            import torch.distributed as td
-            if not td.is_initialized() or td.get_backend() != "nccl" or os.environ.get("GRAAL_RCCL_TORCH"):
-                return
-            box = [self.engine.rccl_unique_id() if self.group.rank == 0 else None]
-            td.broadcast_object_list(box, src=0)
-            ok = 1
-            try:
-                self.engine.attach_rccl(box[0], self.group.rank, self.group.world)
-            except Exception:
-                ok = 0
-            if self.group.all_reduce_max_int(1 - ok) != 0:     # all or none
-                if ok:
-                    self.engine.detach_rccl()
-                return
-            self._rccl_c = True
+            can = Engine.rccl_available()
         except Exception:
-            self._rccl_c = False
+            can = False
+        if self.group.all_reduce_max_int(0 if can else 1) != 0:     # all or none, BEFORE anybody enters ncclCommInitRank
+            return
+        uid = None
+        if self.group.rank == 0:
+            try:
+                uid = self.engine.rccl_unique_id()
+            except Exception:
+                uid = None                                          # (travels: every rank returns below)
+        box = [uid]
+        td.broadcast_object_list(box, src=0)
+        if box[0] is None:
+            return
+        ok = 1
+        try:
+            self.engine.attach_rccl(box[0], self.group.rank, self.group.world)
+        except Exception:
+            ok = 0
+        if self.group.all_reduce_max_int(1 - ok) != 0:              # all or none
+            if ok:
+                self.engine.detach_rccl()
+            return
+        self._rccl_c = True
 
     def _candidate_deltas(self, id_fA, id_neighbours, max_id):
         """float64 [K, 13]; one fused scan per group of <= 8 neighbours, one exchange per scan when sharded."""

@@ -110,8 +110,10 @@ int graal_eval_full_q(graal_ctx* h, int64_t q_out[2]);
  * [GRAAL_MAX_NEIGHBOURS*13, ... + K*13) and at [2*GRAAL_MAX_NEIGHBOURS*13, ... + K*13) 1 for a candidate that met a term that was not
  * finite (its Q value is then 0), else 0 -- on `stream` (asynchronous; a NULL stream means the engine's own stream, NOT the HIP
  * default stream -- pass an explicit stream to order a collective after it): sum all three over ranks (one RCCL all-reduce of the
- * whole buffer); a candidate's value is NaN where the flags' sum is not 0, else coarse + Q / 2^GRAAL_Q_BITS.  max_id must be the value returned by
- * graal_relabel_contigs for the current layout.
+ * whole buffer); a candidate's value is NaN where the flags' sum is not 0, else coarse + Q / 2^GRAAL_Q_BITS.  A rank whose step FAILED (a kernel of
+ * the step gave up waiting for another, a work list overflowed) adds 2^32 to the FIRST flag word: a summed first flag >= 2^32 means "no scores
+ * this step, on any rank" -- every rank sees it, none may use the sums (graal_eval_candidates_x with graal_attach_rccl returns an error then).
+ * max_id must be the value returned by graal_relabel_contigs for the current layout.
  * Replaces new_perform_modificationS + 13 x sub_compute_likelihood per neighbour
  * (cuda_lib_gl.py:2392-2546). */
 int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int32_t max_id, int32_t rank,
@@ -214,8 +216,10 @@ int graal_last_counters(graal_ctx* h, int64_t out[4]);
  * engine stays with events from then on), out[2] = 1 while the in-kernel waits are still in use, out[3] / out[4] = launches of the tiled
  * reference-arithmetic kernel that followed k_gprep through the completion word / behind the event, out[5] = k_strict_flat launches,
  * out[6] = evaluations the table kernel handed to a finishing kernel through the host, out[7] = times its finisher gave up waiting for
- * the scan.  bench.py reports out[1] as `fallbacks`. */
-int graal_run_counters(graal_ctx* h, int64_t out[8]);
+ * the scan, out[8] = evaluations repeated with a longer unit list (the tiled kernel's list starts at a soft cap instead of its quadratic
+ * worst case and grows when a step overflows it), out[9] = that list's capacity now (entries of 8 bytes), out[10..11] = 0 (reserved).
+ * bench.py reports out[1] as `fallbacks`. */
+int graal_run_counters(graal_ctx* h, int64_t out[12]);
 
 /* ---- the sampler's per-step HOST logic behind the boundary (graal_amd/csrc/host_step.h) --------------------------------
  * What cuda_lib_gl.sampler.step_max_likelihood does on the host between its launches: return_neighbours
@@ -249,7 +253,10 @@ int graal_upload_proposal_tables(graal_ctx* h, const int32_t* xk, const float* p
  * (graal_eval_candidates / _x), sampling, commit (graal_apply_move), optionally the genome distance.
  * flags: 1 = pause after the proposal if circular contigs exist now or did at the previous step (`prev_circ`); 2 = pause
  * always; 4 = genome distance; 8 = instead of pausing, re-evaluate the full likelihood INSIDE the step, next to the scoring
- * kernels (out->full_likelihood replaces `likelihood_t`; one rank only -- with an exchange attached the step pauses as before).  Returns GRAAL_STEP_DONE, GRAAL_STEP_PAUSED (the caller refreshes its total and calls
+ * kernels (out->full_likelihood replaces `likelihood_t`).  One rank, or several over the HOST exchange (graal_attach_exchange): every rank
+ * evaluates its shard, the contacts' parts are summed through spare words of the exchange slots -- which requires that EVERY rank
+ * passes flag 8 on the SAME steps (they do when they run the same sampler: the condition is a function of the layout and the step count).
+ * With an RCCL communicator of several ranks attached the step PAUSES as with flag 1 / 2 and the caller supplies the total.  Returns GRAAL_STEP_DONE, GRAAL_STEP_PAUSED (the caller refreshes its total and calls
  * graal_step_finish -- valid only then), GRAAL_STEP_FALLBACK (a blacklisted fragment, or an unusual proposal numpy itself has to judge:
  * NOTHING drawn from the generator, nothing committed: take the step through the individual entry points), GRAAL_STEP_SELECT (the
  * neighbours are drawn and out->neighbours / out->scores / out->stats / out->max_id [/ out->full_likelihood] valid, but the selection

@@ -218,3 +218,37 @@ def test_hand_off_behind_k_gprep_survives_its_time_out(monkeypatch):
         assert got[2] == want[2] and np.array_equal(got[3], want[3]), env
         for a, b in zip(got[0], want[0]):
             assert np.array_equal(a, b), env
+
+
+@pytest.mark.timeout(900)
+def test_unit_list_grows_when_a_step_overflows_it(monkeypatch):
+    """The tiled kernel's unit list starts at a soft cap instead of its quadratic worst case (launch_strict; advisor r04): with the cap
+    forced to 64 entries the first steps overflow it, k_gprep flags the step, eval_sync grows the list and repeats -- the candidates'
+    int64 sums must equal those of a run whose list never overflowed, and the repeats must show in graal_run_counters."""
+    name, pk, cfg, n_props, K = strict_cases.CASES[4]     # single sub-fragment, contigs of hundreds of bins, K = 10: hundreds of units per step
+    monkeypatch.delenv("GRAAL_SLIST_SOFT_CAP", raising=False)
+    want = strict_cases.run_cases(only=[4])[name]
+    monkeypatch.setenv("GRAAL_SLIST_SOFT_CAP", "64")
+    P = strict_cases._problem(**pk)
+    grown = 0
+    rows = []
+    for s, max_id, props in strict_cases.layouts_and_proposals(P, cfg, n_props, K, 1000 + 4):
+        from graal_amd.lib import Engine, Q_SCALE
+        e = Engine(0)
+        e.upload_subfrags(P["np_sub_frags_id"], P["np_sub_frags_len_bp"], P["np_sub_frags_accu"], P["init_n_sub_frags"], P["mean_squared_frags_per_bin"])
+        e.upload_contacts(P["coo_row"], P["coo_col"], P["coo_val"])
+        e.set_params(P["param_simu"])
+        e.upload_frags(s)
+        e.set_mode(ref_trans_accu=cfg["quirk"], strict=True)
+        assert e.relabel_contigs() == max_id
+        row = []
+        for fA, fBs in props:
+            d = e.eval_candidates(fA, fBs, max_id)
+            row.append(np.where(np.isfinite(d), np.rint(np.nan_to_num(d) * Q_SCALE), -2.0 ** 62).astype(np.int64))
+        rc = e.run_counters()
+        grown += rc["unit_list_grown"]
+        assert rc["fallbacks"] == 0
+        rows.append(np.stack(row))
+        e.close()
+    assert grown >= 1, "the forced soft cap never overflowed: the case no longer exercises the growth"
+    assert np.array_equal(np.stack(rows), want)
