@@ -309,7 +309,7 @@ def main():
 
     def phase(msg):   # (diagnostics: GRAAL_BENCH_PHASES=1 prints where the run is)
         if os.environ.get("GRAAL_BENCH_PHASES"):
-            print("[bench %.2f s] %s" % (time.perf_counter(), msg), file=sys.stderr, flush=True)
+            print("[bench rank %d, %.2f s] %s" % (rank, time.perf_counter(), msg), file=sys.stderr, flush=True)
     phase("start")
     t_gen = time.perf_counter()
     P = synth.make_problem(n_bins=args.n_bins, nnz=args.nnz, n_sub=1, seed=20141217)
@@ -331,6 +331,7 @@ def main():
         P2["S_o_A_frags"] = soa_original
         rng2 = np.random.RandomState(20141217)
         smp2 = build_sampler(P2, rng2, group, local if world > 1 else 0, args.arithmetic)
+        phase("late stage: sampler built")
         smp2.init_likelihood()
         max_id2 = smp2.modify_gl_cuda_buffer(0)
         props2 = []
@@ -362,6 +363,7 @@ def main():
             smp2.free_gpu()
             return late
         # a full MCMC step (+ the nuisance-parameter step of the reference GUI's default) in this regime
+        phase("late stage: scoring regions done")
         set_arithmetic(smp2, args.arithmetic)
         smp2.bins = np.arange(1.0, 41.0, 1.0)
         smp2.step_nuisance_parameters(0, 0, 1)
@@ -555,6 +557,7 @@ def main():
     smp.engine.set_timing(EVENT_EVERY if EVENT_EVERY > 0 else 8)
     counters = smp.engine.last_counters()
     # SURVEY 8d's region: 1,000 steps (the driver's 20 steps last under a millisecond)
+    phase("timed region and its event-pair repeat done")
     long_region = None
     if args.long_steps > 0:
         nc, tl_ = timed_region(smp, props[args.warmup:], max_id, args.long_steps)
@@ -613,9 +616,11 @@ def main():
     # expected-mass work items and millions of queued contacts, all of it sharded over the ranks) -- reported next to the
     # headline, which is the short-contig regime SURVEY 8d defines ----------------------------------------------------
     late = None
+    phase("headline, long region, other arithmetic, full evaluation, full steps and nuisance steps done")
     if args.layout == "exploded" and not args.no_late_stage:
         try:
             late = run_late()
+            phase("late stage done")
         except Exception as e:   # an extra must not cost the headline line (a rank that fails alone makes the others' next
             late = {"error": repr(e)}   # collective time out after 300 s: they land here too)
 
@@ -752,8 +757,10 @@ def main():
                 out["cpu_baseline_dense"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
+        phase("headline line printed; exchange_alt next")
         try:
             alt = run_exchange_alt()
+            phase("exchange_alt done")
         except Exception as e:
             alt = {"error": repr(e)}
         if rank == 0 and alt is not None:

@@ -4705,21 +4705,25 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
         const int rep_max = rep_env >= 16 ? 16 : (rep_env >= 8 ? 8 : (rep_env >= 4 ? 4 : (rep_env >= 2 ? 2 : 1)));
         const unsigned long long target = 6ull * 4ull * (unsigned long long)blocks;
         const unsigned long long pairs_max = nt * (nt + 1ull) / 2ull;
-        const unsigned long long worst = pairs_max * (unsigned long long)(64 / seg_unit) + 64ull;
-        // The worst case -- EVERY tile pair of the union listed -- is quadratic in the union's size (2e9 entries for 1e6 fragments in a few
-        // contigs), while the interval cull lists the pairs within reach of each other under some candidate: orders of magnitude fewer.  One
-        // rank: the list holds SLIST_SOFT_CAP entries at most to begin with; if a step's list overflows, k_gprep says so (counters[6] bit 1),
-        // the step ends as failed, eval_sync grows the floor and repeats it.  Several ranks: the worst case (a repeated step on ONE rank would
-        // leave the ranks out of step).
+        // The list's worst case -- EVERY tile pair of the union listed -- is quadratic in the union's size (2e9 entries for 1e6 fragments in a few
+        // contigs), while the interval cull lists the pairs within reach of each other under some candidate: orders of magnitude fewer.
+        // It is sized ONCE per layout size, for the largest union n fragments and MAXK neighbours can form -- not for this step's longest
+        // contig: growing it with the contigs meant a hipFree / hipMalloc behind two stream synchronizes in the middle of a run, again and
+        // again while an assembly's contigs grow.  One rank: SLIST_SOFT_CAP entries at most to begin with; if a step's list overflows,
+        // k_gprep says so (counters[6] bit 1), the step ends as failed, eval_sync raises the floor and repeats it.  Several ranks: the worst
+        // case (a repeated step on ONE rank would leave the ranks out of step).
+        const unsigned long long nt_n = (unsigned long long)((h->n + 63) / 64 + MAXK + 1) + (unsigned long long)US_MAXP;
+        const unsigned long long worst = (nt_n * (nt_n + 1ull) / 2ull) * (unsigned long long)(64 / seg_unit) + 64ull;
+        (void)pairs_max;
         const unsigned long long SLIST_SOFT_CAP = h->slist_soft_cap;   // (GRAAL_SLIST_SOFT_CAP, read when the handle is created)
         h->slist_worst = worst;
         const unsigned long long need = (world == 1 && publish) ? std::min(worst, std::max(SLIST_SOFT_CAP, h->slist_floor)) : worst;
         if (need > h->slist_cap) {
-            CK(hipStreamSynchronize(st));
-            CK(hipStreamSynchronize(h->aux));
+            CK(hipDeviceSynchronize());   // (rare: the first tiled step of a layout size, or a list that has just overflowed)
             if (h->d_slist) CK(hipFree(h->d_slist));
             h->d_slist = nullptr;
-            const unsigned long long cap = std::max<unsigned long long>(need == worst ? need + need / 2ull : need, 1ull << 16);
+            h->slist_cap = 0;
+            const unsigned long long cap = std::max<unsigned long long>(need, 64ull);
             CK(hipMalloc(&h->d_slist, cap * sizeof(unsigned long long)));
             h->slist_cap = cap;
         }
@@ -5927,7 +5931,7 @@ static int eval_sync(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int
                             "the steps are ordered through events from here on\n");
         }
         h->spin_used = false;
-        if (grow) { h->slist_floor = std::min(h->slist_worst, std::max<unsigned long long>(h->slist_cap, 1ull << 16) * 8ull); h->rc_list_grown += 1; }
+        if (grow) { h->slist_floor = std::min(h->slist_worst, std::max<unsigned long long>(h->slist_cap, 64ull) * 8ull); h->rc_list_grown += 1; }
         if (h->pub_in_flight) h->stats_pub_pending = true;   // (its publication block gave up with the others)
         CK(hipStreamSynchronize(h->stream));
         CK(hipStreamSynchronize(h->aux));

@@ -150,6 +150,7 @@ def test_bench_runs_two_ranks_from_one_command():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["GRAAL_BENCH_PHASES"] = "1"    # (where the run is, on stderr: shown if it fails)
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--n-bins", "2000",
                           "--nnz", "100000", "--steps", "6", "--warmup", "2", "--mcmc-warmup", "300"],
                          env=env, capture_output=True, text=True, timeout=850)
