@@ -4220,6 +4220,8 @@ struct Ctx {
     hipEvent_t ev_fin = nullptr;  // end of the last asynchronous evaluation (orders the next k_tm after it)
     hipEvent_t ev_relabel = nullptr; // end of the relabel kernels graal_begin_step left running (orders the next k_tm, on aux)
     hipEvent_t ev_tm = nullptr;   // end of the step's k_tm (orders a chip-filling k_fin behind it, see launch_fin)
+    hipEvent_t ev_par = nullptr, ev_par2 = nullptr;   // graal_set_params: the parameter update fenced against the auxiliary streams
+    bool args_synced = false;     // the device-resident argument blocks are complete (sync_args ran with parameters and sub-fragment tables in place)
     bool relabel_pending = false;
     // graal_step's deferred flow (begin_step_launch(defer)): the next k_tm is ordered behind the relabel by a device flag that the
     // next k_scan sets, not by an event; and it publishes the layout statistics in an extra block
@@ -4464,6 +4466,7 @@ int sync_args(Ctx* h)
         a[b].nfpb = h->nfpb; a[b].par = h->par;
     }
     CK(hipMemcpy(h->d_args, a, sizeof a, hipMemcpyHostToDevice));
+    h->args_synced = h->have_par && h->have_sub && h->d_args != nullptr;
     if (h->have_par && h->have_sub && h->ln_lut_n > 0) {
         if (!h->d_ln_tab) CK(hipMalloc(&h->d_ln_tab, sizeof(double) * LN_TRANS_LUT));
         k_ln_tab<<<blocks_for(h->ln_lut_n, 256), 256, 0, h->stream>>>(h->d_ln_tab, h->ln_lut_n, h->nfpb, h->par);
@@ -4974,6 +4977,8 @@ int graal_create(int device, graal_ctx** out)
     CK(hipEventCreateWithFlags(&h->ev_fin, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&h->ev_relabel, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&h->ev_tm, hipEventDisableTiming));
+    CK(hipEventCreateWithFlags(&h->ev_par, hipEventDisableTiming));
+    CK(hipEventCreateWithFlags(&h->ev_par2, hipEventDisableTiming));
     for (auto& ev : h->ev) CK(hipEventCreate(&ev));
     h->ring.resize(2 * 1024, nullptr);
     for (auto& ev : h->ring) CK(hipEventCreate(&ev));
@@ -5053,6 +5058,8 @@ void graal_destroy(graal_ctx* h)
         if (h->ev_fin) (void)hipEventDestroy(h->ev_fin);
         if (h->ev_relabel) (void)hipEventDestroy(h->ev_relabel);
         if (h->ev_tm) (void)hipEventDestroy(h->ev_tm);
+        if (h->ev_par) (void)hipEventDestroy(h->ev_par);
+        if (h->ev_par2) (void)hipEventDestroy(h->ev_par2);
         if (h->aux) (void)hipStreamDestroy(h->aux);
         if (h->fstream) (void)hipStreamDestroy(h->fstream);
         if (h->ev_full) (void)hipEventDestroy(h->ev_full);
@@ -5064,20 +5071,47 @@ void graal_destroy(graal_ctx* h)
 
 const char* graal_last_error(const graal_ctx* h) { return h ? h->err.c_str() : "null handle"; }
 
+// parameters only: the two device-resident argument blocks get the new Par (and the window derived from it) from a one-block kernel in
+// stream order -- no blocking copy, no synchronize (a nuisance-parameter step sends parameters twice: cuda_lib_gl.py:2073-2107)
+__global__ void k_set_par(DevArgs* a, Par par, int reach)
+{
+    if (threadIdx.x < 2) { a[threadIdx.x].par = par; a[threadIdx.x].reach_bp = reach; }
+}
+
 int graal_set_params(graal_ctx* h, const float* p)
 {
-    if (h && h->stream) (void)hipStreamSynchronize(h->stream); // (graal_begin_step may have left its relabel kernels running)
     if (!h || !p) return GRAAL_E_ARG;
     Par np_;   // (validated before it is compared or committed: h->par never holds rejected values)
     memcpy(&np_, p, sizeof(Par));
     if (!(np_.v_inter > 0.0f)) return fail(h, GRAAL_E_ARG, "v_inter must be > 0 (the sparse form prices every pixel at >= v_inter)");
     if (!(np_.d_max > 0.0f) || !(np_.d_max < 2.0e6f)) return fail(h, GRAAL_E_ARG, "d_max out of range");
     if (h->have_par && memcmp(&h->par, &np_, sizeof(Par)) == 0) return GRAAL_OK;   // (re-sending the parameters in force)
+    const bool first = !h->have_par;
+    const bool ln_same = !first && h->par.v_inter == np_.v_inter;      // (k_ln_tab: ln of v_inter x the products of RF counts / nfpb)
     h->par = np_;
     h->have_par = true;
     compute_t_all(h, h->t_hist.empty());
     CK(hipSetDevice(h->device));
-    return sync_args(h);
+    if (first || !h->args_synced) {   // (the blocks hold nothing yet, or an upload is pending: the whole blocks, synchronously)
+        if (h->stream) (void)hipStreamSynchronize(h->stream);
+        return sync_args(h);
+    }
+    // In stream order on the engine's stream, fenced against the two other streams both ways: no kernel of theirs still reads the old
+    // parameters when they are overwritten (their last work is waited for), none launched from now on starts before the new ones are in place
+    CK(hipEventRecord(h->ev_par, h->aux));
+    CK(hipStreamWaitEvent(h->stream, h->ev_par, 0));
+    CK(hipEventRecord(h->ev_par2, h->fstream));
+    CK(hipStreamWaitEvent(h->stream, h->ev_par2, 0));
+    k_set_par<<<1, 64, 0, h->stream>>>(h->d_args, h->par, reach_bp(h));
+    CK(hipGetLastError());
+    if (!ln_same && h->have_sub && h->ln_lut_n > 0 && h->d_ln_tab) {
+        k_ln_tab<<<blocks_for(h->ln_lut_n, 256), 256, 0, h->stream>>>(h->d_ln_tab, h->ln_lut_n, h->nfpb, h->par);
+        CK(hipGetLastError());
+    }
+    CK(hipEventRecord(h->ev_par, h->stream));
+    CK(hipStreamWaitEvent(h->aux, h->ev_par, 0));
+    CK(hipStreamWaitEvent(h->fstream, h->ev_par, 0));
+    return GRAAL_OK;
 }
 
 int graal_upload_subfrags(graal_ctx* h, const int32_t* sub_id, const float* sub_len, const int32_t* sub_accu, int32_t n_bins,
@@ -6347,5 +6381,6 @@ int graal_run_counters(graal_ctx* h, int64_t out[12])
 }
 
 #include "host_step.h"
+#include "host_fit.h"
 
 } // extern "C"

@@ -51,7 +51,7 @@ SYMBOLS = ("graal_abi_version", "graal_create", "graal_destroy", "graal_last_err
            "graal_upload_subfrags", "graal_upload_repeats", "graal_upload_contacts", "graal_upload_contacts_f32", "graal_upload_frags", "graal_download_frags",
            "graal_relabel_contigs", "graal_begin_step", "graal_begin_step_launch", "graal_layout_stats", "graal_eval_full_q", "graal_eval_candidates_q",
            "graal_eval_candidates", "graal_exchange_bytes", "graal_attach_exchange", "graal_eval_candidates_x", "graal_exchange_selftest", "graal_detach_exchange", "graal_rccl_unique_id", "graal_attach_rccl", "graal_detach_rccl", "graal_upload_distance_ref", "graal_genome_distance", "graal_apply_move", "graal_set_finisher", "graal_set_mode", "graal_set_timing", "graal_last_timing", "graal_scan_times", "graal_strict_times", "graal_time_scan", "graal_last_counters", "graal_run_counters",
-           "graal_upload_proposal_tables", "graal_step", "graal_step_finish", "graal_steps", "graal_host_np_sum", "graal_host_select_move", "graal_host_neighbours")
+           "graal_upload_proposal_tables", "graal_step", "graal_step_finish", "graal_steps", "graal_host_np_sum", "graal_host_select_move", "graal_host_neighbours", "graal_host_max_dist_intra")
 
 STEP_DONE, STEP_PAUSED, STEP_FALLBACK, STEP_SELECT = 0, 1, 2, 3
 STEPS_ROW = 10   # GRAAL_STEPS_ROW: doubles per step in graal_steps' rows
@@ -136,12 +136,28 @@ def load():
         L.graal_host_np_sum.argtypes = [_f64p, ctypes.c_int64]
         L.graal_host_select_move.argtypes = [ctypes.c_void_p, _f64p, ctypes.c_int32, ctypes.c_int32]
         L.graal_host_neighbours.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, _i32p, ctypes.c_int32]
+        L.graal_host_max_dist_intra.argtypes = [_f64p, ctypes.c_double, ctypes.c_int32, _f64p, _i32p]
         _lib = L
     return _lib
 
 
 class GraalError(RuntimeError):
     pass
+
+
+_mdi_p = (ctypes.c_double * 5)()
+_mdi_x = ctypes.c_double(0.0)
+_mdi_info = ctypes.c_int32(0)
+
+
+def host_max_dist_intra(p5, val_inter, f32):
+    """include/graal_hip.h: graal_host_max_dist_intra -- (x, MINPACK info).  No device needed."""
+    L = load()
+    _mdi_p[0], _mdi_p[1], _mdi_p[2], _mdi_p[3], _mdi_p[4] = (float(v) for v in p5)
+    rc = L.graal_host_max_dist_intra(_mdi_p, float(val_inter), 1 if f32 else 0, ctypes.byref(_mdi_x), ctypes.byref(_mdi_info))
+    if rc != 0:
+        raise GraalError("graal_host_max_dist_intra failed (%d)" % rc)
+    return _mdi_x.value, int(_mdi_info.value)
 
 
 def _c(a, dtype):

@@ -56,6 +56,25 @@ def estimate_max_dist_intra(p, val_inter):
     return x[0]
 
 
+def estimate_max_dist_intra_step(p, val_inter):
+    """The same root for the PER-STEP call of step_nuisance_parameters (cuda_lib_gl.py:2053, 2060, 2071): MINPACK's hybrd restated for
+    one unknown behind the C ABI (graal_amd/csrc/host_fit.h, graal_host_max_dist_intra) -- 3 us instead of 0.12-0.2 ms of fsolve
+    driving a numpy expression on a one-element array.  Same algorithm, same start value, same give-up behaviour; the residual's
+    pow / exp are glibc's instead of numpy's, so the float64 root may differ in its last bits (never, on the golden cases and 20,000
+    random ones, in the float32 it becomes in param_simu: tests/test_rippe_fit.py).  Argument types the C side does not model exactly
+    -- anything but five numpy float32 scalars, or five Python / float64 numbers -- take the scipy path above."""
+    vals = list(p) + [val_inter]
+    if all(isinstance(v, np.float32) for v in vals):
+        f32 = True
+    elif all(isinstance(v, (float, int, np.float64)) and not isinstance(v, bool) for v in vals):
+        f32 = False
+    else:
+        return estimate_max_dist_intra(p, val_inter)
+    from . import lib
+    x, _ = lib.host_max_dist_intra(vals[:5], vals[5], f32)
+    return np.float64(x)
+
+
 def mean_contacts_per_bin(S_o_A_sub_frags, sub_coo, bins, max_dist_kb, size_bin_kb):
     """Mean number of contacts of cis sub-fragment pairs per genomic-distance bin (cuda_lib_gl.py:1236-1270):
     d = ((start_j - start_i - len_i) + (len_i + len_j) / 2) / 1000 for the pair ordered by position; bins of width

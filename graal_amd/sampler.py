@@ -478,12 +478,12 @@ class sampler(object):
         id_modif = self.rng.choice(4)
         if id_modif == 0:
             new_fact = fact + self.rng.normal(loc=0.0, scale=self.sigma_fact)
-            new_d_max = opti.estimate_max_dist_intra([kuhn, lm, slope, d, new_fact], d_nuc)
+            new_d_max = opti.estimate_max_dist_intra_step([kuhn, lm, slope, d, new_fact], d_nuc)
             c1 = np.float32((0.53 * np.power(lm / kuhn, slope)) * np.power(kuhn, -3))
             out_test_param = [(kuhn, lm, c1, slope, d, new_d_max, new_fact, d_nuc)]
         elif id_modif == 1:
             new_slope = slope + self.rng.normal(loc=0.0, scale=self.sigma_slope)
-            new_d_max = opti.estimate_max_dist_intra([kuhn, lm, new_slope, d, fact], d_nuc)
+            new_d_max = opti.estimate_max_dist_intra_step([kuhn, lm, new_slope, d, fact], d_nuc)
             c1 = np.float32((0.53 * np.power(lm / kuhn, new_slope)) * np.power(kuhn, -3))
             out_test_param = [(kuhn, lm, c1, new_slope, d, new_d_max, fact, d_nuc)]
         elif id_modif == 2:
@@ -493,12 +493,12 @@ class sampler(object):
             out_test_param = [(kuhn, lm, c1, slope, d, new_d_max, fact, new_d_nuc)]
         elif id_modif == 3:
             new_d_nuc = d_nuc + self.rng.normal(loc=0.0, scale=self.sigma_d_nuc)
-            new_d_max = opti.estimate_max_dist_intra([kuhn, lm, slope, d, fact], new_d_nuc)
+            new_d_max = opti.estimate_max_dist_intra_step([kuhn, lm, slope, d, fact], new_d_nuc)
             c1 = np.float32((0.53 * np.power(lm / kuhn, slope)) * np.power(kuhn, -3))
             out_test_param = [(kuhn, lm, c1, slope, d, new_d_max, fact, new_d_nuc)]
         else:
             new_d = d + self.rng.normal(loc=0.0, scale=self.sigma_d)
-            new_d_max = opti.estimate_max_dist_intra([kuhn, lm, slope, new_d, fact], d_nuc)
+            new_d_max = opti.estimate_max_dist_intra_step([kuhn, lm, slope, new_d, fact], d_nuc)
             c1 = np.float32((0.53 * np.power(lm / kuhn, slope)) * np.power(kuhn, -3))
             out_test_param = [(kuhn, lm, c1, slope, new_d, new_d_max, fact, d_nuc)]
         out_test_param = np.array(out_test_param, dtype=self.param_simu_T)

@@ -276,6 +276,12 @@ int graal_steps(graal_ctx* h, void* mt_state, const int32_t* ids, int32_t n, int
 double graal_host_np_sum(const double* a, int64_t n);
 int graal_host_select_move(void* mt_state, const double* score, int32_t n, int32_t n_tmp);
 int graal_host_neighbours(graal_ctx* h, void* mt_state, int32_t fA, int32_t delta, int32_t* out, int32_t cap);
+/* estimate_max_dist_intra (optim_rippe_curve_update.py:117-135), which step_nuisance_parameters calls after three of its four
+ * perturbations (cuda_lib_gl.py:2053, 2060, 2071): the distance at which the Rippe curve of p5 = (kuhn, lm, slope, d, A) meets val_inter --
+ * scipy's fsolve = MINPACK hybrd from x0 = 500, restated for one unknown with the residual in C (graal_amd/csrc/host_fit.h; the case in
+ * which MINPACK gives up and hands the start value back, SURVEY H6, included).  f32 != 0: the parameters are numpy float32 scalars, as the
+ * nuisance step passes them.  *info = MINPACK's termination code.  No device needed. */
+int graal_host_max_dist_intra(const double* p5, double val_inter, int32_t f32, double* x_out, int32_t* info_out);
 
 #ifdef __cplusplus
 }

@@ -118,3 +118,51 @@ def test_estimate_param_rippe_matches_the_reference_module():
         assert _close(y_est, c["y_estim"], fx), c["kind"]
         kinds.add(c["kind"])
     assert len(kinds) == 3
+
+
+def test_c_restatement_of_the_scalar_root_solve_matches_the_reference_module():
+    """graal_host_max_dist_intra (graal_amd/csrc/host_fit.h: MINPACK's hybrd restated for one unknown, the residual in C) -- what
+    step_nuisance_parameters calls per step instead of scipy's fsolve -- against the outputs of the REFERENCE's
+    optim_rippe_curve_update.estimate_max_dist_intra (tests/golden/rippe_fit.json), the returns-500 case included: the float64 root to
+    1e-13 relative (the residual's pow / exp are glibc's here and numpy's there: last-place differences) and the SAME float32, the
+    precision in which d_max enters param_simu."""
+    fx = _golden()
+    n500 = 0
+    for c in fx["estimate_max_dist_intra"]:
+        p, v = c["p"], c["val_inter"]
+        if c.get("float32_inputs"):
+            p, v = [np.float32(a) for a in p], np.float32(v)
+        else:
+            p, v = [float(a) for a in p], float(v)
+        x = rippe_fit.estimate_max_dist_intra_step(p, v)
+        assert np.float32(x) == np.float32(c["x"]), c
+        assert abs(x - c["x"]) <= 1e-13 * abs(c["x"]), c
+        n500 += abs(c["x"] - 500.0) < 1e-6
+    assert n500 >= 1
+
+
+def test_c_restatement_of_the_scalar_root_solve_matches_scipy_on_random_parameters():
+    """... and against scipy's fsolve on 1,500 random parameter sets in the ranges the nuisance-parameter walk visits (float32 scalars as
+    the step passes them, and plain floats): same float32, <= 1e-13 relative, the same give-ups (x = 500 exactly)."""
+    import warnings
+    rng = np.random.RandomState(7)
+    n500 = n_conv = 0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for i in range(1500):
+            kuhn = np.float32(rng.choice([1.0, rng.uniform(0.5, 2.0)]))
+            lm, slope = np.float32(rng.uniform(5, 15)), np.float32(rng.uniform(-2.2, -0.8))
+            d = np.float32(3.0 if rng.rand() < 0.7 else rng.uniform(2.2, 5))
+            A, v = np.float32(10 ** rng.uniform(0.5, 5)), np.float32(10 ** rng.uniform(-4, 0.5))
+            p = [kuhn, lm, slope, d, A]
+            if i % 3 == 0:
+                p, v = [float(a) for a in p], float(v)
+            want, got = rippe_fit.estimate_max_dist_intra(p, v), rippe_fit.estimate_max_dist_intra_step(p, v)
+            assert np.float32(got) == np.float32(want), (p, v, want, got)
+            assert abs(got - want) <= 1e-13 * abs(want), (p, v, want, got)
+            n500 += want == 500.0
+            n_conv += want != 500.0
+    assert n500 > 100 and n_conv > 100
+    # argument types the C side does not model exactly take the scipy path (same numbers as estimate_max_dist_intra)
+    mixed = [np.float32(1.0), 9.6, np.float32(-1.5), 3, np.float32(5000.0)]
+    assert rippe_fit.estimate_max_dist_intra_step(mixed, np.float32(0.01)) == rippe_fit.estimate_max_dist_intra(mixed, np.float32(0.01))
