@@ -5710,6 +5710,29 @@ int graal_eval_full_q(graal_ctx* h, int64_t q_out[2])
     return rc ? rc : full_collect(h, h->stream, q_out);
 }
 
+// set parameters + relabel + full evaluation with ONE wait: what compute_likelihood_4_nuisance (cuda_lib_gl.py:1986-2017) does between two
+// MCMC steps -- memcpy_htod of the test parameters, the relabel of the layout the last step committed, evaluate_likelihood + sum -- as one
+// call: the relabel and the evaluation's kernels go out back to back (the longest contig the launch shapes are sized with is one commit
+// stale, as in graal_step), the statistics are collected behind the sums (published long before them)
+int graal_eval_full_params(graal_ctx* h, const float* param8, int64_t stats[8], int32_t* max_id, int64_t q_out[2])
+{
+    if (!h || !q_out) return GRAAL_E_ARG;
+    if (!h->have_frags) return fail(h, GRAAL_E_STATE, "no fragments uploaded");
+    if (param8) { const int rc = graal_set_params(h, param8); if (rc) return rc; }
+    if (!h->begin_launched) { const int rc = begin_step_launch(h); if (rc) return rc; }
+    if (h->stats_pub_pending) {   // (graal_step deferred the publication to the scoring kernels and then handed the step back)
+        k_stats_pub<<<1, 64, 0, h->stream>>>(h->d_part, h->apply_blocks, h->d_scalars, h->h_stats, h->stats_seq);
+        CK(hipGetLastError());
+        h->stats_pub_pending = false;
+    }
+    begin_step_assume(h);
+    int rc = full_launch(h, h->stream);
+    if (rc) { (void)begin_step_collect(h, stats, max_id); return rc; }
+    rc = full_collect(h, h->stream, q_out);
+    const int rc2 = begin_step_collect(h, stats, max_id);
+    return rc ? rc : rc2;
+}
+
 int graal_eval_candidates_q(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int32_t max_id, int32_t rank, int32_t world,
                             int64_t* d_q_out, void* stream_v)
 {

@@ -49,7 +49,7 @@ _f64p = ctypes.POINTER(ctypes.c_double)
 
 SYMBOLS = ("graal_abi_version", "graal_create", "graal_destroy", "graal_last_error", "graal_set_params",
            "graal_upload_subfrags", "graal_upload_repeats", "graal_upload_contacts", "graal_upload_contacts_f32", "graal_upload_frags", "graal_download_frags",
-           "graal_relabel_contigs", "graal_begin_step", "graal_begin_step_launch", "graal_layout_stats", "graal_eval_full_q", "graal_eval_candidates_q",
+           "graal_relabel_contigs", "graal_begin_step", "graal_begin_step_launch", "graal_layout_stats", "graal_eval_full_q", "graal_eval_full_params", "graal_eval_candidates_q",
            "graal_eval_candidates", "graal_exchange_bytes", "graal_attach_exchange", "graal_eval_candidates_x", "graal_exchange_selftest", "graal_detach_exchange", "graal_rccl_unique_id", "graal_attach_rccl", "graal_detach_rccl", "graal_upload_distance_ref", "graal_genome_distance", "graal_apply_move", "graal_set_finisher", "graal_set_mode", "graal_set_timing", "graal_last_timing", "graal_scan_times", "graal_strict_times", "graal_time_scan", "graal_last_counters", "graal_run_counters",
            "graal_upload_proposal_tables", "graal_step", "graal_step_finish", "graal_steps", "graal_host_np_sum", "graal_host_select_move", "graal_host_neighbours", "graal_host_max_dist_intra")
 
@@ -99,6 +99,7 @@ def load():
         L.graal_begin_step.argtypes = [ctypes.c_void_p, _i64p, _i32p]
         L.graal_begin_step_launch.argtypes = [ctypes.c_void_p]
         L.graal_eval_full_q.argtypes = [ctypes.c_void_p, _i64p]
+        L.graal_eval_full_params.argtypes = [ctypes.c_void_p, _f32p, _i64p, _i32p, _i64p]
         L.graal_eval_candidates_q.argtypes = [ctypes.c_void_p, ctypes.c_int32, _i32p, ctypes.c_int32, ctypes.c_int32,
                                               ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
         L.graal_eval_candidates.argtypes = [ctypes.c_void_p, ctypes.c_int32, _i32p, ctypes.c_int32, ctypes.c_int32, _f64p]
@@ -306,6 +307,16 @@ class Engine:
         q = np.zeros(2, dtype=np.int64)
         self._ck(self._L.graal_eval_full_q(self._h, q.ctypes.data_as(_i64p)), "graal_eval_full_q")
         return q
+
+    def eval_full_params(self, param8=None):
+        """graal_eval_full_params: (q[2], stats[8], max_id) -- new parameters (kept in force), relabel, full evaluation, one wait."""
+        q = np.zeros(2, dtype=np.int64)
+        p = None if param8 is None else _c(np.asarray(param8, dtype=np.float32).reshape(8), np.float32)
+        rc = self._L.graal_eval_full_params(self._h, None if p is None else p.ctypes.data_as(_f32p), self._st_ptr, self._max_id_ref,
+                                            q.ctypes.data_as(_i64p))
+        if rc != 0:
+            self._ck(rc, "graal_eval_full_params")
+        return q, self._st_buf.copy(), int(self._max_id.value)
 
     def eval_full(self):
         q = self.eval_full_q()

@@ -454,8 +454,13 @@ class sampler(object):
         """Full likelihood of the current layout under TEST parameters (``cuda_lib_gl.py:1986-2017``).  ``restore=False`` leaves
         the test parameters in force on the device (the caller accepts them or puts ``_param_flat`` back itself)."""
         keep = np.copy(self._param_flat)
-        self.engine.set_params(test_param)
         try:
+            if self.group.world == 1:
+                # parameters + relabel + evaluation behind ONE wait (include/graal_hip.h: graal_eval_full_params)
+                q, st, _ = self.engine.eval_full_params(test_param)
+                self.n_stale_paste += int(st[7])
+                return float("nan") if int(q[0]) == Q_FULL_BAD else float(int(q[0]) + int(q[1])) / Q_SCALE
+            self.engine.set_params(test_param)
             return self.eval_likelihood()
         except BaseException:
             restore = True

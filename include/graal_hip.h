@@ -102,6 +102,10 @@ int graal_layout_stats(graal_ctx* h, int64_t out[8]);
  * logL = (sum over ranks of q_out[0] + q_out[1]) / 2^GRAAL_Q_BITS.
  * Replaces evaluate_likelihood + gpuarray.sum (cuda_lib_gl.py:543-631, 1473-1509). */
 int graal_eval_full_q(graal_ctx* h, int64_t q_out[2]);
+/* The same behind new parameters and the relabel of the current layout, with ONE wait: graal_set_params(param8) (skipped when NULL; the
+ * parameters stay in force) + graal_begin_step (stats[8], *max_id as there; either may be NULL) + graal_eval_full_q.  What a
+ * nuisance-parameter step does between two MCMC steps: compute_likelihood_4_nuisance, cuda_lib_gl.py:1986-2017. */
+int graal_eval_full_params(graal_ctx* h, const float* param8, int64_t stats[8], int32_t* max_id, int64_t q_out[2]);
 
 /* delta log-likelihood of the 13 candidates of each of K (<= GRAAL_MAX_NEIGHBOURS) neighbours fB[k]
  * of fA, over this rank's contact shard; rank / world shard the expected-mass work.
