@@ -32,6 +32,16 @@ if [ -z "${PROF_TRACE_ONLY:-}" ]; then
 timeout -k 10 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d $OUT/sq -- python3 $ARGS > $OUT/sq.log 2>&1
 echo "sq rc=$?"
 fi
+if [ -n "${PROF_VALU_MIX:-}" ]; then
+# the instruction MIX of the vector instructions (round-4 review item 5: a wave64 float64 FMA and a float32 add do not cost a SIMD the same):
+# per-type counters in passes of their own (SQ counter slots), priced by tools/summarize_prof.py with the rates of tools/valu_issue_micro.hip
+timeout -k 10 400 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 --kernel-trace --output-format csv -d $OUT/mix64 -- python3 $ARGS > $OUT/mix64.log 2>&1
+echo "mix64 rc=$?"
+timeout -k 10 400 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 --kernel-trace --output-format csv -d $OUT/mix32 -- python3 $ARGS > $OUT/mix32.log 2>&1
+echo "mix32 rc=$?"
+timeout -k 10 400 rocprofv3 --pmc SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $OUT/mixint -- python3 $ARGS > $OUT/mixint.log 2>&1
+echo "mixint rc=$?"
+fi
 cd $REPO
 python3 tools/summarize_prof.py $OUT $TAG
 # raw CSVs are too big to travel back (64 MiB cap): keep only the summaries and logs

@@ -77,7 +77,7 @@ def main():
     ks = find(os.path.join(d, "trace"), "*kernel_stats.csv")
     if ks:
         res["kernel_stats_csv"] = open(ks).read()
-    for name in ("fetch", "write", "sq"):
+    for name in ("fetch", "write", "sq", "mix64", "mix32", "mixint"):
         c = find(os.path.join(d, name), "*counter_collection.csv")
         if c:
             res["pmc_" + name] = counter_stats(c)
@@ -107,6 +107,32 @@ def main():
                            "achieved_wave_instr_per_s": instr / (us * 1e-6), "peak": peak, "frac": instr / (us * 1e-6) / peak,
                            "wait_frac": (cs["SQ_WAIT_ANY"]["mean"] / cs["SQ_WAVE_CYCLES"]["mean"]) if "SQ_WAIT_ANY" in cs and "SQ_WAVE_CYCLES" in cs and cs["SQ_WAVE_CYCLES"]["mean"] > 0 else None}
     res["valu_roofline"] = valu
+    # The ceiling for the kernel's instruction MIX.  Sustained chip-wide issue rates by instruction class, wave instructions per second at 4 waves
+    # per SIMD (what k_strict2 runs), measured by tools/valu_issue_micro.hip on this pool (profiles/r05_valu_issue.log: the clock the chip holds under
+    # such a stream -- 1.6-2.1 GHz, not the 2.4 GHz of the data sheet -- is in these rates).  The remainder of SQ_INSTS_VALU that no per-type counter
+    # claims (moves, compares, selects, lane reads) and all of INT32 are priced at the fastest class: the ceiling errs high, the fraction low.
+    RATE = {"ADD_F64": 0.5265e12, "MUL_F64": 0.5240e12, "FMA_F64": 0.4987e12, "TRANS_F64": 0.1509e12, "ADD_F32": 0.9369e12, "MUL_F32": 0.9307e12,
+            "FMA_F32": 0.5857e12, "TRANS_F32": 0.2984e12, "INT32": 1.0266e12, "INT64": 0.5588e12, "CVT": 0.5588e12, "OTHER": 1.0266e12}
+    mix = {}
+    for k, v in valu.items():
+        counts = {}
+        for grp in ("pmc_mix64", "pmc_mix32", "pmc_mixint"):
+            for c, st in res.get(grp, {}).get(k, {}).items():
+                if c.startswith("SQ_INSTS_VALU_"):
+                    counts[c[len("SQ_INSTS_VALU_"):]] = st["mean"]
+        if len(counts) < 11:
+            continue
+        total = v["wave_instr_per_launch"]
+        other = max(0.0, total - sum(counts.values()))
+        secs = sum(n / RATE[c] for c, n in counts.items()) + other / RATE["OTHER"]
+        peak_mix = total / secs if secs > 0 else None
+        act = res.get("pmc_mixint", {}).get(k, {}).get("SQ_ACTIVE_INST_VALU", {}).get("mean")
+        mix[k] = {"counts_per_launch": dict(counts, OTHER=other), "wave_instr_per_launch": total, "ceiling_s_per_launch": secs,
+                  "peak_for_the_mix_wave_instr_per_s": peak_mix, "achieved_wave_instr_per_s": v["achieved_wave_instr_per_s"],
+                  "frac_of_the_mix_ceiling": v["achieved_wave_instr_per_s"] / peak_mix if peak_mix else None,
+                  "f64_share": sum(counts.get(c, 0.0) for c in ("ADD_F64", "MUL_F64", "FMA_F64", "TRANS_F64")) / total if total else None,
+                  "SQ_ACTIVE_INST_VALU_per_launch": act, "rates_source": "tools/valu_issue_micro.hip at 4 waves per SIMD (profiles/r05_valu_issue.log)"}
+    res["valu_mix"] = mix
     with open(os.path.join(d, "summary_%s.json" % tag), "w") as f:
         json.dump(res, f, indent=1)
     # human readable
@@ -116,7 +142,7 @@ def main():
         for k, v in sorted(res.get("kernel_trace", {}).items(), key=lambda kv: -kv[1]["total_ms"]):
             f.write("| %s | %d | %.3f | %.2f | %.2f | %.2f | %.2f |\n" % (k[:70], v["calls"], v["total_ms"], v["avg_us"], v["min_us"],
                                                                   v["max_us"], v["avg_us_last_100"]))
-        for name in ("fetch", "write", "sq"):
+        for name in ("fetch", "write", "sq", "mix64", "mix32", "mixint"):
             if "pmc_" + name in res:
                 f.write("\n## PMC pass: %s (KiB per dispatch for the TCC counters)\n\n| kernel | counter | n | mean | mean last 100 | min | max |\n|---|---|---|---|---|---|---|\n" % name)
                 for k, cs in res["pmc_" + name].items():
@@ -132,6 +158,15 @@ def main():
             for k, v in sorted(res["valu_roofline"].items(), key=lambda kv: -kv[1]["wave_instr_per_launch"] * kv[1]["launches"]):
                 f.write("| %s | %d | %.4g | %.2f | %.3g | %.3f | %s |\n" % (k[:70], v["launches"], v["wave_instr_per_launch"], v["kernel_avg_us_rocprof"],
                                                                         v["achieved_wave_instr_per_s"], v["frac"], "%.2f" % v["wait_frac"] if v["wait_frac"] is not None else "-"))
+        if res.get("valu_mix"):
+            f.write("\n## VALU ceiling for the instruction MIX (per-type SQ_INSTS_VALU_* counters x the sustained issue rates of tools/valu_issue_micro.hip, 4 waves per SIMD)\n\n"
+                    "| kernel | wave instr / launch | float64 share | ADD/MUL/FMA/TRANS F64 | ADD/MUL/FMA/TRANS F32 | INT32 / INT64 / CVT / other | ceiling for the mix (wave instr / s) | achieved | fraction |\n|---|---|---|---|---|---|---|---|---|\n")
+            for k, v in sorted(res["valu_mix"].items(), key=lambda kv: -kv[1]["wave_instr_per_launch"]):
+                c = v["counts_per_launch"]
+                f.write("| %s | %.4g | %.2f | %.3g / %.3g / %.3g / %.3g | %.3g / %.3g / %.3g / %.3g | %.3g / %.3g / %.3g / %.3g | %.3g | %.3g | %.3f |\n" % (
+                    k[:60], v["wave_instr_per_launch"], v["f64_share"], c["ADD_F64"], c["MUL_F64"], c["FMA_F64"], c["TRANS_F64"], c["ADD_F32"], c["MUL_F32"],
+                    c["FMA_F32"], c["TRANS_F32"], c["INT32"], c["INT64"], c["CVT"], c["OTHER"], v["peak_for_the_mix_wave_instr_per_s"],
+                    v["achieved_wave_instr_per_s"], v["frac_of_the_mix_ceiling"]))
         if "k_scan_hbm_bytes_per_launch" in res:
             f.write("\nk_scan HBM bytes / launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 = %.0f\n" % res["k_scan_hbm_bytes_per_launch"])
         if "kernel_stats_csv" in res:
