@@ -322,6 +322,7 @@ __device__ __forceinline__ int4 ld_stream(const int4* p)
 // Debug build (-DGRAAL_STAMPS): selected threads write the 100 MHz wall clock at a few points of the per-step kernels
 #ifdef GRAAL_STAMPS
 __device__ unsigned long long g_stamps[32];
+__device__ unsigned long long g_s2eq[8];      // (GRAAL_S2_COUNTS: k_strict2's evaluations whose float32 inputs equal the current layout's, strict2.h)
 __device__ unsigned long long g_hitstat[8];   // [0] launches' max third-stage duration (ticks) [1] latest third-stage end [2] count [3] sum of durations [4] max passes
 #define STAMP(i, cond) do { if (cond) g_stamps[i] = wall_clock64(); } while (0)
 #define STAMP_MAX(i, cond) do { if (cond) atomicMax(&g_stamps[i], wall_clock64()); } while (0)   // (the clock only grows: the latest wave of the latest step)
@@ -6350,6 +6351,20 @@ int graal_debug_stamps(graal_ctx* h, uint64_t out[32])
     CK(hipSetDevice(h->device));
     CK(hipDeviceSynchronize());
     CK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), 32 * sizeof(unsigned long long)));
+    return GRAAL_OK;
+#else
+    return fail(h, GRAAL_E_UNSUPPORTED, "library built without GRAAL_STAMPS");
+#endif
+}
+
+int graal_debug_s2eq(graal_ctx* h, uint64_t out[8], int reset)
+{
+    if (!h || !out) return GRAAL_E_ARG;
+#ifdef GRAAL_STAMPS
+    CK(hipSetDevice(h->device));
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_s2eq), 8 * sizeof(unsigned long long)));
+    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_s2eq), z, sizeof z)); }
     return GRAAL_OK;
 #else
     return fail(h, GRAAL_E_UNSUPPORTED, "library built without GRAAL_STAMPS");

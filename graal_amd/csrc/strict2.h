@@ -377,6 +377,9 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
     __shared__ GClass s_cls[4][CLS_CHUNK];
     __shared__ unsigned long long s_ent[4][16];   // the unit-list entries a wave is working through
     __shared__ int s_pref[S2_BAL_MAX + 1], s_bsum[256], s_boff[257];   // the waves of a step's few units (see `bal`)
+#if defined(GRAAL_STAMPS) && defined(GRAAL_S2_COUNTS)
+    __shared__ float s_sold[4][SEG][64];       // (counting build: the current layout's float32 distance of every pair of the unit)
+#endif
     STAMP(16, blockIdx.x == 0 && threadIdx.x == 0);
     int skip = fa.skip;
     if (s2.gp != nullptr) {
@@ -679,6 +682,25 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
                         const float ex = s2_ex(true, lf ? cl[0] : c_s, lf ? c_s : cl[0], norm_u, circ, s_tot, par);
                         if (c < 0) exo[j][lane] = ex;
                         else add_pair_fast(j, (double)exo[j][lane] - (double)ex);
+#if defined(GRAAL_STAMPS) && defined(GRAAL_S2_COUNTS)
+                        {   // (round-4 review item 6: how many (pair, class) evaluations hand the model the float32 inputs of the CURRENT layout?)
+                            const float s_dbg = fabsf((lf ? c_s : cl[0]) - (lf ? cl[0] : c_s));
+                            if (c < 0) s_sold[wib][j][lane] = s_dbg;
+                            else {
+                                const bool valid = ((vmask >> j) & 1u) != 0;
+                                const bool same = valid && cis_old && circ == circ_old && (!circ || lbp == lbp_old) && s_dbg == s_sold[wib][j][lane];
+                                const int n_valid = __popcll(__ballot(valid)), n_same = __popcll(__ballot(same));
+                                if (lane == 0 && n_valid > 0) {
+                                    atomicAdd(&g_s2eq[0], (unsigned long long)n_valid);
+                                    atomicAdd(&g_s2eq[1], (unsigned long long)n_same);
+                                    atomicAdd(&g_s2eq[2], n_same == n_valid ? (unsigned long long)n_valid : 0ull);      // evaluations in passes a whole wave could skip
+                                    atomicAdd(&g_s2eq[3], 2 * n_same >= n_valid ? (unsigned long long)n_same : 0ull);   // ... that lane compaction could drop (>= half agree)
+                                    atomicAdd(&g_s2eq[4], 1ull);                                                          // (wave, segment fragment, class) passes
+                                    atomicAdd(&g_s2eq[5], !cis_old ? (unsigned long long)n_valid : 0ull);                 // pairs that are trans in the current layout
+                                }
+                            }
+                        }
+#endif
                     }
                 }
                 accq += acc_hi * (1ll << 30) + acc_lo;
