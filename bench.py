@@ -352,6 +352,14 @@ def main():
             c2 = smp2.engine.last_counters()
             blk = {"value": n_cand2 / tl, "unit": "candidate logL evals/s", "ms_per_step": 1e3 * tl / n_timed, "steps": n_timed,
                    "queued_contacts_last_step_this_rank": int(c2[2]), "work_units_last_step_this_rank": int(c2[3])}
+            if rank == 0:
+                # what of the step shards over the ranks (the streaming pass and the tiled pricing kernel: their durations by HIP events on this
+                # rank) and what does not (the rest of the step: tables, union set and classes, hand-out, host) -- the line the driver's multi-GPU
+                # run can be read against
+                sc_us = 1e3 * float(np.median(smp2.engine.scan_times(n_timed)))
+                st_us = 1e3 * float(np.mean(smp2.engine.strict_times(n_timed))) if which == "strict" else None
+                blk["sharded_kernels_us_this_rank"] = {"k_scan": sc_us, "k_strict2": st_us}
+                blk["non_sharded_us_per_step"] = 1e3 * blk["ms_per_step"] - sc_us - (st_us or 0.0) if which == "strict" else None
             if which == "strict" and rank == 0:
                 blk["roofline"] = valu_roofline(smp2, n_timed)
             if which == args.arithmetic:
@@ -409,7 +417,23 @@ def main():
                     r["frac"] = r["achieved"] / VALU_PEAK_WAVE_INSTR
                     r["kernel_trace_avg_ms"] = vj.get("kernel_avg_us_rocprof", 0.0) * 1e-3
                     r["frac_kernel_trace"] = vj["wave_instr_per_launch"] / (vj["kernel_avg_us_rocprof"] * 1e-6) / VALU_PEAK_WAVE_INSTR
-                    r["instr_source"] = "committed rocprofv3 --pmc SQ_INSTS_VALU pass of `bench.py --late-only` (profiles/valu_late.json, profiles/r04_rocprof_late.md): mean over the same launches, not measured in this run"
+                    r["instr_source"] = "committed rocprofv3 --pmc SQ_INSTS_VALU pass of `bench.py --late-only` (profiles/valu_late.json, " + str(vj.get("source", "profiles/")) + "): mean over the same launches, not measured in this run"
+                    if vj.get("peak_for_the_mix_wave_instr_per_s"):
+                        # the ceiling for THIS kernel's instruction mix (round-4 review item 5): per-type SQ_INSTS_VALU_* counts of the same launches priced
+                        # with the sustained issue rates measured by tools/valu_issue_micro.hip at 4 waves per SIMD (profiles/r05_valu_issue.log; what
+                        # no per-type counter claims is priced at the fastest class, so the ceiling errs high).  `peak` / `frac` are against it;
+                        # the round-4 figure -- 1,024 SIMDs x 2.4 GHz / 4 cycles, one float64 instruction stream of one wave per SIMD -- stays next to it
+                        r["peak_one_wave_f64_stream"] = VALU_PEAK_WAVE_INSTR
+                        r["frac_of_the_one_wave_f64_stream"] = r["frac"]
+                        r["peak"] = vj["peak_for_the_mix_wave_instr_per_s"]
+                        r["frac"] = r["achieved"] / r["peak"]
+                        r["frac_kernel_trace"] = vj["wave_instr_per_launch"] / (vj["kernel_avg_us_rocprof"] * 1e-6) / r["peak"]
+                        r["peak_basis"] = ("ceiling for the kernel's measured instruction mix: sum over instruction classes of (wave instructions per launch, rocprofv3 "
+                                           "--pmc SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_{F32,F64}, _INT32, _INT64, _CVT) / (sustained chip-wide issue rate of that class at 4 "
+                                           "waves per SIMD, tools/valu_issue_micro.hip: 0.50-0.53e12/s float64 add / mul / fma, 0.93e12 float32 add / mul and int32, "
+                                           "0.59e12 float32 fma, 0.56e12 conversions and 64-bit integer, 0.30e12 float32 transcendental); %.0f %% of the instructions are float64"
+                                           % (100.0 * vj.get("float64_share", 0.0)))
+                        r["simd_cycles_per_valu_instr"] = vj.get("simd_cycles_per_valu_instr")
             except Exception:
                 pass
         return r
@@ -732,10 +756,25 @@ def main():
         out["other_arithmetic"] = other_block
         if long_region:
             out.update(long_region)
+        # per regime: the step, the part of it that shards over the ranks (kernel durations by HIP events on this rank) and the part that does not,
+        # next to what DESIGN.md section 6 expects of 8 GPUs -- so that the driver's scaling run can be read against the estimate
+        out["regimes"] = {
+            "headline (exploded + MCMC warm-up: contigs of a few fragments)": {
+                "ms_per_step": 1e3 * elapsed / args.steps, "sharded_kernels_us_this_rank": {"k_scan": scan_s * 1e6},
+                "non_sharded_us_per_step": 1e6 * elapsed / args.steps - scan_s * 1e6,
+                "expected_at_8_gpus": "the pass over an 8th of the list keeps its launch floor (~5 us), tables + finish + host round trip stay: <= 1.5x"},
+            "late stage (the map's 7 original contigs)": None if not late or "error" in late else {
+                "ms_per_step": late.get("ms_per_step"), "sharded_kernels_us_this_rank": late.get("sharded_kernels_us_this_rank"),
+                "non_sharded_us_per_step": late.get("non_sharded_us_per_step"),
+                "expected_at_8_gpus": "units dealt (ti + tj) % world, contacts by shard: ~0.23 ms per step, ~6x -- the regime that can meet north_star's >= 6x"}}
         if world > 1:
             out["distributed"] = {"backend": td.get_backend(), "ranks": int(td.get_world_size()), "exchange": smp.exchange,
                                   "rccl_ranks": int(td.get_world_size()) if td.get_backend() == "nccl" else 0,
-                                  "value_produced_by_exchange": smp.exchange}
+                                  "value_produced_by_exchange": smp.exchange,
+                                  "north_star_exchange": "one RCCL all-reduce of the per-shard candidate vector per MCMC step over xGMI: timed as `exchange_alt` "
+                                                         "(last in the job); `value` is produced by the exchange named in value_produced_by_exchange -- 'host' = "
+                                                         "the ranks' 65 int64 sums through pinned host memory of the node (bit-identical sums, nothing added to the "
+                                                         "GPU timeline), DESIGN.md section 6"}
         if alt is not None:
             out["exchange_alt"] = alt
         if late is not None:

@@ -4126,11 +4126,13 @@ __device__ __forceinline__ bool rep_pixel(const RepArgs& R, int ui, int v, int& 
 }
 
 // full likelihood of the repeated bins' pixels in the current layout (Q sum)
-__global__ __launch_bounds__(256) void k_rep_full(RepArgs R, long long* __restrict__ out, long long* __restrict__ bad_flag)
+__global__ __launch_bounds__(256) void k_rep_full(RepArgs R, int rank, int world, long long* __restrict__ out, long long* __restrict__ bad_flag)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     long long q = 0;
-    if (i < (long long)R.n_dup * R.n_bins) {
+    // (several ranks: the repeated bins' pixels are dealt to them one by one -- each is rounded to Q by itself, so the ranks' sums add up to the
+    // single rank's bit for bit)
+    if (i < (long long)R.n_dup * R.n_bins && (int)(i % (long long)world) == rank) {
         int lo, hi;
         CandCtx C; C.T = nullptr; C.op = 0; C.fA = -1;
         if (rep_pixel(R, (int)(i / R.n_bins), (int)(i % R.n_bins), lo, hi)) q = to_q(pixel_lik<0>(R, lo, hi, C));
@@ -4222,6 +4224,7 @@ struct Ctx {
     hipEvent_t ev_relabel = nullptr; // end of the relabel kernels graal_begin_step left running (orders the next k_tm, on aux)
     hipEvent_t ev_tm = nullptr;   // end of the step's k_tm (orders a chip-filling k_fin behind it, see launch_fin)
     hipEvent_t ev_par = nullptr, ev_par2 = nullptr;   // graal_set_params: the parameter update fenced against the auxiliary streams
+    bool full_rep_sharded = false; // the full evaluation in flight dealt the repeated bins' pixels to the ranks (full_launch -> full_collect)
     bool args_synced = false;     // the device-resident argument blocks are complete (sync_args ran with parameters and sub-fragment tables in place)
     bool relabel_pending = false;
     // graal_step's deferred flow (begin_step_launch(defer)): the next k_tm is ordered behind the relabel by a device flag that the
@@ -5618,9 +5621,12 @@ static int full_launch(graal_ctx* h, hipStream_t fs)
         k_full_mass<16><<<blocks_for(h->n, 16), 256, 0, fs>>>(h->n, h->perm, h->contig_off2[h->cur], h->geo, h->stat_frag, s.p[F_LCONT],
                                                                      s.p[F_LCONTBP], s.p[F_POS], h->nfpb, h->par, reach_bp(h),
                                                                      h->d_scalars + 9, h->d_scalars + FULL_BAD);
-    if (h->has_rep) { // every pixel of a repeated bin, densely (identical on every rank: it goes with the mass part)
+    if (h->has_rep) { // every pixel of a repeated bin, densely.  With an exchange attached the pixels are dealt to the ranks and the sum travels
+                      // with the contacts' part (full_collect), which the callers add up over the ranks; otherwise every rank computes all of it
         const RepArgs R = rep_args(h);
-        k_rep_full<<<blocks_for((long long)h->n_dup * h->n_bins, 256), 256, 0, fs>>>(R, h->d_scalars + 17, h->d_scalars + FULL_BAD);
+        const int fw = h->x_host ? h->x_world : (h->nccl_comm ? h->n_world : 1), fr = h->x_host ? h->x_rank : (h->nccl_comm ? h->n_rank : 0);
+        h->full_rep_sharded = fw > 1;
+        k_rep_full<<<blocks_for((long long)h->n_dup * h->n_bins, 256), 256, 0, fs>>>(R, fr, fw, h->d_scalars + 17, h->d_scalars + FULL_BAD);
     }
     // the accumulators (d_scalars[8], [9], [17], [FULL_BAD]) are zero at rest because k_full_pub clears them behind the sums it
     // publishes: a call that fails between its first kernel and that publication must not leave partial sums to the next one
@@ -5663,8 +5669,11 @@ static int full_collect(graal_ctx* h, hipStream_t fs, int64_t q_out[2])
     }
     const long long res[2] = {h->h_full[1], h->h_full[2]};
     const long long bad = h->h_full[3], rep_q = h->has_rep ? h->h_full[4] : 0;
-    q_out[0] = res[0] - (int64_t)h->c_lf_q;
-    q_out[1] = -(res[1] + (int64_t)llrint(h->t_all * Q_SCALE)) + rep_q;
+    // (q[0]: what the callers add up over the ranks -- the contacts of this rank's shard and, when the repeated bins' pixels were dealt to the
+    // ranks, this rank's share of them; q[1]: what every rank computes alike)
+    const bool rep_sharded = h->has_rep && h->full_rep_sharded;
+    q_out[0] = res[0] - (int64_t)h->c_lf_q + (rep_sharded ? rep_q : 0);
+    q_out[1] = -(res[1] + (int64_t)llrint(h->t_all * Q_SCALE)) + (rep_sharded ? 0 : rep_q);
     if (bad) { q_out[0] = Q_BAD; q_out[1] = 0; } // a term was not finite / out of range: INT64_MIN exactly, the host reports NaN
     return GRAAL_OK;
 }

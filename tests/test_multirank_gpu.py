@@ -21,13 +21,18 @@ def _problem(which="sub3"):
         # reference arithmetic (the default)
         # (10 contigs of ~50 bins: not the late stage's direct launch of the tiled kernels -- k_tm sends every rank to k_strict_flat)
         return synth.make_problem(n_bins=500, nnz=15000, n_sub=1, seed=19, contig_weights=(1,) * 10, mean_len_bp=1500.0, accu=1, param=par)
+    if which == "rep":
+        # repeated bins (allow_repeats: simulation_loader.py:182-280): their pixels are priced densely over the active copies -- the candidates'
+        # part dealt to the ranks item by item, the full evaluation's part pixel by pixel (k_rep_delta, k_rep_full)
+        P = synth.make_problem(n_bins=60, nnz=1500, n_sub=3, seed=23, contig_weights=(5, 4, 3), mean_len_bp=2000.0, accu=("random", 1, 9), param=par)
+        return synth.add_repeats(P, (7, 21, 40), 2)
     return synth.make_problem(n_bins=90, nnz=2500, n_sub=3, seed=17, contig_weights=(5, 4, 3), mean_len_bp=2000.0, accu=9,
                               param=par, grid_bp=2000)
 
 
 def _make(P, rng, group, exchange=None):
     from graal_amd.sampler import sampler
-    return sampler(True, P["S_o_A_frags"], P["collector_id_repeats"], P["frag_dispatcher"], [], [], P["n_frags"],
+    return sampler(True, P["S_o_A_frags"], P["collector_id_repeats"], P["frag_dispatcher"], P.get("id_frag_duplicated", []), [], P["n_frags"],
                    P["n_new_frags"], P["init_n_sub_frags"], P["n_new_sub_frags"], None,
                    (P["bin_coo_row"], P["bin_coo_col"], P["bin_coo_val"]), P["np_sub_frags_len_bp"], P["np_sub_frags_id"],
                    P["np_sub_frags_accu"], P["mean_squared_frags_per_bin"], None, None,
@@ -80,7 +85,8 @@ _REF = {}
 
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("world,exchange,which", [(2, "host", "sub3"), (3, "host", "sub3"), (2, "rccl", "sub3"), (2, "auto-fallback", "sub3"),
-                                                  (2, "host", "mid"), (3, "host", "mid"), (2, "rccl", "mid")])
+                                                  (2, "host", "mid"), (3, "host", "mid"), (2, "rccl", "mid"),
+                                                  (2, "host", "rep"), (3, "host", "rep"), (2, "rccl", "rep")])
 def test_ranks_reproduce_the_single_rank_run_bit_for_bit(world, exchange, which):
     import torch.multiprocessing as mp
     from graal_amd import dist as gdist
