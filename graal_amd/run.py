@@ -68,9 +68,22 @@ def main(argv=None):
             raise SystemExit("--no-fit needs --param")
         smp.set_param_simu(np.asarray(args.param, dtype=np.float32))
     else:
-        smp.estimate_parameters(mean_dist_kb, size_bin_kb)
+        fit_ok = True
+        try:
+            with np.errstate(all="ignore"):
+                smp.estimate_parameters(mean_dist_kb, size_bin_kb)
+            fit_ok = bool(np.all(np.isfinite(smp._param_flat)))
+        except Exception as e:      # (graal_set_params refuses parameters that are not finite / out of range)
+            fit_ok = False
+            print("graal_amd.run: the Rippe fit of this dataset gave no usable parameters (%s)" % e)
         if args.param is not None:
             smp.set_param_simu(np.asarray(args.param, dtype=np.float32))
+        elif not fit_ok:
+            # the reference would carry on with whatever leastsq returned (optim_rippe_curve_update.py:93-115) and score NaN from the first
+            # step on; a headless run says so instead
+            raise SystemExit("graal_amd.run: the Rippe fit did not converge to finite parameters on this dataset (histogram of %d distance bins, "
+                             "%d of them without contacts): pass --param kuhn lm c1 slope d d_max fact v_inter" % (
+                                 len(smp.bins), int(np.sum(np.asarray(smp.mean_contacts) <= 1e-10))))
     t0 = time.perf_counter()
     trace = em.run_em(smp, args.cycles, args.neighbours, rng=rng, sample_param=args.sample_params, scrambled=not args.no_explode)
     dt = time.perf_counter() - t0

@@ -41,8 +41,10 @@ def run_c4_from_a_dataset(arith, cycles):
         print("C4D: stand-in generated in %.1f s, written as a 3-file dataset in %.1f s: %d fragments, %d contacts = %d read lines (%.0f MB)"
               % (t_gen, t_write, n_bins, nnz, n_reads, size_mb), flush=True)
         t0 = time.perf_counter()
+        # (the stand-in's contacts stop at the generator's d_max while the fit's histogram runs to the mean contig length: its last bins are
+        # empty and the reference's log-space least squares does not converge on them -- the run takes the generator's parameters, the fit still runs)
         tr = run.main(["--dataset", base, "--size-pyramid", "1", "--level", "0", "--cycles", str(cycles), "--neighbours", str(K), "--seed", "1",
-                       "--arithmetic", arith, "--out", os.path.join(base, "out")])
+                       "--arithmetic", arith, "--out", os.path.join(base, "out"), "--param"] + [repr(float(x)) for x in P["param_simu"]])
         print("C4D [%s]: dataset -> pyramid -> level-0 inputs -> fit -> explode + %d cycles -> traces: %.1f s in all, %d MCMC steps, %d contigs left"
               % (arith, cycles, time.perf_counter() - t0, len(tr.likelihood), tr.n_contigs[-1]), flush=True)
     finally:
