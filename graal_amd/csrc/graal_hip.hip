@@ -5045,6 +5045,9 @@ void graal_destroy(graal_ctx* h)
         (void)hipStreamSynchronize(h->stream);
         if (h->aux) (void)hipStreamSynchronize(h->aux);
         if (h->fstream) (void)hipStreamSynchronize(h->fstream);
+        // ... and whatever this handle's kernels were launched on besides its own streams (graal_eval_candidates_q takes the CALLER'S stream: the
+        // torch path of exchange="rccl"): nothing of this process may still touch the buffers, pinned words and the registered segment freed below
+        (void)hipDeviceSynchronize();
         void* ptrs[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->stat, h->sub_rec, h->sub_rec8, h->sub_lab16, h->d_ubins, h->d_ln_tab, h->sub2bin, h->row, h->col, h->cnt, h->queue, h->d_sub_ids, h->d_acc, h->tm_done, h->d_sync, h->d_done, h->d_wq, h->d_flags, h->d_slist, h->d_uset, h->d_cls, h->d_cls_n, h->stat_frag, h->d_dup_bins, h->d_dup_index,
                         h->d_dispatcher, h->d_collector, h->d_sub_ids_all, h->d_rep_obs,
                         h->keys, h->keys_sorted, h->o2n, h->len_of2[0], h->len_of2[1], h->contig_off2[0], h->contig_off2[1], h->perm, h->pstart, h->cbase, h->link, h->mates, h->cub_tmp, h->tabs, h->step_hdr, h->d_args, h->d_chg, h->d_part,
@@ -6116,6 +6119,7 @@ int graal_detach_exchange(graal_ctx* h)
     CK(hipStreamSynchronize(h->aux));
     CK(hipStreamSynchronize(h->fstream));   // (the in-step full evaluation publishes the ranks' contact parts into the segment from ITS stream: one still
                                             // in flight at the unregistration was a GPU memory fault at the segment's host address -- seen once, two ranks)
+    CK(hipDeviceSynchronize());             // (and a caller's stream that graal_eval_candidates_q was given)
     CK(hipHostUnregister(h->x_host));
     h->x_host = nullptr; h->x_dev = nullptr; h->x_bytes = 0; h->x_rank = 0; h->x_world = 1;
     h->res_host = h->res_dev = h->h_res;

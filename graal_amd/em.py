@@ -26,11 +26,15 @@ class Trace(object):
         return np.array([self.id_fA, self.id_fB, self.op_sampled], dtype=np.int64).T.reshape(-1, 3)
 
 
-def run_em(sampler, n_cycles, n_neighbours, rng=None, sample_param=False, scrambled=True, dt=0, on_step=None):
+def run_em(sampler, n_cycles, n_neighbours, rng=None, sample_param=False, scrambled=True, dt=0, on_step=None, matrix_files=None):
+    """``matrix_files = (before, after)``: the two images start_EM writes through display_current_matrix (``main_gl.py:213, 283``:
+    pre_simu.tiff before the first step -- of the layout as loaded --, post_em.tiff behind the last cycle); None: no images."""
     if rng is None and getattr(getattr(sampler, "group", None), "world", 1) > 1:
         raise ValueError("run_em over a sharded sampler needs the sampler's (identically seeded) rng: every rank shuffles itself")
     rng = np.random if rng is None else rng
     trace = Trace()
+    if matrix_files and matrix_files[0]:
+        sampler.display_current_matrix(matrix_files[0])
     sampler.init_likelihood()
     sampler.modify_gl_cuda_buffer(0, dt)
     if scrambled:
@@ -88,6 +92,8 @@ def run_em(sampler, n_cycles, n_neighbours, rng=None, sample_param=False, scramb
             trace.success.append(success)
             if on_step is not None:
                 on_step(j, i, trace)
+    if matrix_files and len(matrix_files) > 1 and matrix_files[1]:
+        sampler.display_current_matrix(matrix_files[1])
     return trace
 
 

@@ -39,6 +39,8 @@ def main(argv=None):
                     help="strict = the reference's float32 pixel arithmetic (default: traces are the reference's); exact = "
                          "mathematically exact candidate deltas (faster on long contigs)")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--images", action="store_true", help="write pre_simu.tiff / post_em.tiff (the contact matrix in the genome's order before and after, "
+                                                           "main_gl.py:213, 283) into the output folder")
     ap.add_argument("--no-fit", action="store_true", help="skip the Rippe fit; needs --param (8 floats: kuhn lm c1 slope d d_max fact v_inter)")
     ap.add_argument("--param", type=float, nargs=8, default=None, help="param_simu to run with instead of the fit's")
     args = ap.parse_args(argv)
@@ -84,10 +86,13 @@ def main(argv=None):
             raise SystemExit("graal_amd.run: the Rippe fit did not converge to finite parameters on this dataset (histogram of %d distance bins, "
                              "%d of them without contacts): pass --param kuhn lm c1 slope d d_max fact v_inter" % (
                                  len(smp.bins), int(np.sum(np.asarray(smp.mean_contacts) <= 1e-10))))
-    t0 = time.perf_counter()
-    trace = em.run_em(smp, args.cycles, args.neighbours, rng=rng, sample_param=args.sample_params, scrambled=not args.no_explode)
-    dt = time.perf_counter() - t0
     out = args.out or os.path.join(args.dataset, "graal_out")
+    os.makedirs(out, exist_ok=True)
+    images = (os.path.join(out, "pre_simu.tiff"), os.path.join(out, "post_em.tiff")) if args.images else None
+    t0 = time.perf_counter()
+    trace = em.run_em(smp, args.cycles, args.neighbours, rng=rng, sample_param=args.sample_params, scrambled=not args.no_explode,
+                      matrix_files=images)
+    dt = time.perf_counter() - t0
     em.save_behaviour_to_txt(trace, out)
     lev = P.get_level(args.level)
     if args.fasta:

@@ -538,8 +538,10 @@ class sampler(object):
     def load_gl_cuda_tex_buffer(self, im_init):
         pass
 
-    def display_current_matrix(self, file=None):
-        """Fragment order by contig (``cuda_lib_gl.py:1581-1624``); the TIFF dump is dropped (display only)."""
+    def display_current_matrix(self, file=None, max_px=2048):
+        """Fragment order by contig (``cuda_lib_gl.py:1581-1624``) and, when ``file`` is given, the sub-level contact matrix in that order
+        as a 32-bit float TIFF like the reference's ``Image.fromarray(hic_matrix[np.ix_(full_order_high, full_order_high)]).save(file)`` --
+        from the COO list; binned beyond ``max_px`` sub-fragments (graal_amd/image.py)."""
         self.gpu_vect_frags.copy_from_gpu()
         c = self.gpu_vect_frags
         dict_contig, full_order, full_order_high = dict(), [], []
@@ -556,6 +558,9 @@ class sampler(object):
                     if c.ori[i] == -1:
                         id_2_push.reverse()
                     full_order_high.extend(id_2_push)
+        if file:
+            from . import image
+            image.write_tiff_f32(file, image.matrix_image(self.sub_coo_full, full_order_high, max_px))
         return full_order, dict_contig, full_order_high
 
     def free_gpu(self):

@@ -231,13 +231,18 @@ def test_level0_headless_run_equals_the_oracle(tmp_path):
     t_ref = em.run_em(ora, 2, 4, rng=ora.rng)
     out = str(tmp_path / "out")
     tr = run.main(["--dataset", base, "--size-pyramid", "1", "--level", "0", "--cycles", "2", "--neighbours", "4", "--seed", str(seed),
-                   "--no-fit", "--param"] + [repr(float(x)) for x in par] + ["--fasta", os.path.join(base, "genome.fa"), "--out", out])
+                   "--no-fit", "--param"] + [repr(float(x)) for x in par] + ["--fasta", os.path.join(base, "genome.fa"), "--out", out, "--images"])
     assert len(tr.likelihood) == 2 * n
     assert np.array_equal(tr.mutations(), t_ref.mutations())
     assert tr.n_contigs == t_ref.n_contigs and tr.dist == t_ref.dist
     assert np.allclose(tr.likelihood, t_ref.likelihood, rtol=1e-5, atol=0)     # generic bp coordinates: north_star's tolerance
     assert np.array_equal(em.load_mutations(os.path.join(out, "list_mutations.txt")), tr.mutations())
     assert open(os.path.join(out, "genome.fasta")).read().count(">") >= 1
+    # the two images of start_EM (display_current_matrix, main_gl.py:213, 283): the contact matrix in the genome's order before and after
+    from graal_amd import image
+    pre, post = image.read_tiff_f32(os.path.join(out, "pre_simu.tiff")), image.read_tiff_f32(os.path.join(out, "post_em.tiff"))
+    assert pre.shape == post.shape == (n, n) and np.array_equal(pre, synth.dense_from_coo(r, c, v, n))   # (the layout as loaded: the identity order)
+    assert float(pre.sum()) == float(post.sum()) and not np.array_equal(pre, post)
     # and with the Rippe fit of the level-0 histogram in front (cuda_lib_gl.py:1229-1294), as the GUI's start button would run it
     tr2 = run.main(["--dataset", base, "--size-pyramid", "1", "--level", "0", "--cycles", "1", "--neighbours", "3", "--seed", "5",
                     "--out", str(tmp_path / "out2")])
