@@ -4753,6 +4753,8 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
         // (512 blocks: two per CU; cf. fin_blocks_no_wait), only one rank (a repeated step must not leave the ranks out of step), only while
         // the engine's streams are known to run side by side (spin_ok).  (768 blocks -- three per CU, still room -- with the wait instead of 1,024
         // behind the event: C3 / C4 stand-ins 214-221 / 238-243 us per step against 200-203 / 222-225.)
+        // (round 5 tried the word with the 1,024-block grids too: the wait ran out in every run -- C3 and C4 stand-ins -- and the engine went back to
+        // events, as the argument above predicts)
         const bool gwait = h->gwait_env && publish && world == 1 && h->spin_ok && blocks <= 512;
         s2.gp = gwait ? s2.next + 32 : nullptr;   // (ticket: 256 bytes behind the draw counter; the completion word 256 bytes behind the ticket: GP_DONE)
         s2.gp_seq = (unsigned long long)h->seq;
