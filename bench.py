@@ -293,7 +293,9 @@ def main():
     def max_over_ranks(x):
         if world == 1:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        # (a device tensor only with RCCL: gloo's handling of device tensors is a side path of a CPU backend -- two GPU memory faults at the base of
+        # torch's small-tensor pool, in the 2-rank rehearsal of this file, both between two calls of this function, went away with it)
+        t = torch.tensor([x], dtype=torch.float64, device="cuda" if td.get_backend() == "nccl" else "cpu")
         td.all_reduce(t, op=td.ReduceOp.MAX)
         return float(t.cpu()[0])
 

@@ -682,6 +682,8 @@ class sampler(object):
         out = np.zeros((len(id_neighbours), N_OPS), dtype=np.float64)
         dev = torch.device("cuda", self.engine.device)
         if self._d_q is None:
+            import torch.distributed as td
+            self._torch_nccl = td.is_initialized() and td.get_backend() == "nccl"
             self._d_q = torch.zeros(3 * MAX_NEIGHBOURS * N_OPS, dtype=torch.int64, device=dev)   # (fine sums, coarse sums, not-finite flags: include/graal_hip.h)
             # a dedicated, non-null stream: the C ABI reads a null handle as "the engine's own stream", and the
             # collective must be ordered after the kernels that fill the buffer
@@ -691,8 +693,15 @@ class sampler(object):
                 part = id_neighbours[k0:k0 + MAX_NEIGHBOURS]
                 self.engine.eval_candidates_q_async(id_fA, part, max_id, self._d_q.data_ptr(),
                                                     self._torch_stream.cuda_stream, self.group.rank, self.group.world)
-                self.group.all_reduce_sum_(self._d_q)
-                qc = self._d_q.cpu().numpy()
+                if self._torch_nccl:
+                    self.group.all_reduce_sum_(self._d_q)                    # one RCCL all-reduce of the device buffer over xGMI
+                    qc = self._d_q.cpu().numpy()
+                else:
+                    # (the gloo rehearsal -- several ranks on ONE GPU: gloo is a CPU backend, the buffer goes through the host explicitly
+                    # instead of through gloo's own handling of device tensors)
+                    q_host = self._d_q.cpu()
+                    self.group.all_reduce_sum_(q_host)
+                    qc = q_host.numpy()
                 nq = len(part) * N_OPS
                 m = MAX_NEIGHBOURS * N_OPS
                 out[k0:k0 + len(part)] = q_to_float(qc[:nq], qc[m:m + nq], qc[2 * m:2 * m + nq]).reshape(len(part), N_OPS)
