@@ -373,9 +373,9 @@ __global__ void k_mates(int n, const int* __restrict__ perm, const int* __restri
 //      [5] min l_cont [6] #(rep != 0 or activ != 1 or id_d != f)  [7] max label  [14] #(circ == 1)
 constexpr int NC_WORD = 29;   // d_scalars[NC_WORD]: number of contigs of the ranked layout (= max_id + 1), kept on the device so that the
                               // scoring kernels can be launched before the host has read the statistics
-constexpr int N_STAT = 9;
-struct StatAcc { long long v[9]; }; // heads, sum l_cont, #start0, sum lbp, max, min, bad, max label, #circ
-__device__ __forceinline__ StatAcc stat_zero() { StatAcc a = {{0, 0, 0, 0, 0, 0x7fffffff, 0, -1, 0}}; return a; }
+constexpr int N_STAT = 11;
+struct StatAcc { long long v[11]; }; // heads, sum l_cont, #start0, sum lbp, max, min, bad, max label, #circ; [9] the commit's own-pixel correction (Q), [10] its bad terms
+__device__ __forceinline__ StatAcc stat_zero() { StatAcc a = {{0, 0, 0, 0, 0, 0x7fffffff, 0, -1, 0, 0, 0}}; return a; }
 __device__ __forceinline__ void stat_add(StatAcc& a, int f, int pos, int lc, int start_bp, int lbp, int rep, int activ, int id_d, int c, int circ)
 {
     a.v[0] += pos == 0;
@@ -603,12 +603,40 @@ struct Changed {
     int exists[4];
 };
 
+// A bin's OWN pixel -- its sub-fragment pairs (a < b) -- as the full evaluation prices it (evaluate_likelihood's on_diag pixels,
+// kernels3.cu:3213): the contacts between two of its sub-fragments, each rounded to Q like k_full_nnz's terms, minus the expected mass of
+// its pairs, rounded once like k_full_mass's.  No candidate delta of the reference contains it (sub_compute_likelihood's pixel set has no
+// diagonal pixels, kernels3.cu:3356-3380), yet its float32 value moves with the bin's coordinates and with its contig's circular model: it is
+// what separates a candidate's delta from full(after) - full(before) when bins hold several sub-fragments (RF counts uniform or the
+// trans-branch indexing off: tests/test_carried_total_gpu.py).  own[3] = the observed counts of the pairs (0,1), (0,2), (1,2), 0 = none.
+__device__ __forceinline__ long long own_pixel_q(const Rec& r, const Stat& st, const float* __restrict__ own, float nfpb, const Par& par, bool& bad)
+{
+    End X; X.label = 0; X.start_bp = r.start_bp; X.fwd = r.ori == 1; X.circ = r.circ; X.lbp = r.l_cont_bp;
+    long long q = 0;
+    double acc = 0.0;
+    int pair = 0;
+    for (int a = 0; a < st.n; a++)
+        for (int b = a + 1; b < st.n; b++) {
+            const float ex = ex_pair(X, st, a, X, st, b, nfpb, par);
+            acc += (double)ex;
+            const float ob = own[a == 0 ? b - 1 : 2];
+            if (ob != 0.0f) { const long long t = to_q((double)ob * mm_ln(ex)); if (t == Q_BAD) bad = true; else q += t; }
+            pair++;
+        }
+    (void)pair;
+    const long long m = to_q(acc);
+    if (m == Q_BAD) bad = true; else q -= m;
+    return q;
+}
+
 // commit one candidate (test_copy_struct, cuda_lib_gl.py:1156): out = apply_move(in); also records which contigs exist
 // afterwards among the <= 4 labels the move can touch (for the incremental relabel of the next graal_begin_step), and -- it
 // has every new record in registers anyway -- the statistics of the NEW layout, which its last block publishes to pinned host
 // memory: the next graal_begin_step finds them there and needs no statistics kernel.
 __global__ __launch_bounds__(256) void k_apply(SoaPtr in, SoaPtr out, int n, int op, int fA, int fB, int max_id, int* __restrict__ n_stale,
-                                               Changed* __restrict__ chg, long long* __restrict__ part)
+                                               Changed* __restrict__ chg, long long* __restrict__ part,
+                                               const Stat* __restrict__ stat /* nullptr: no own-pixel correction */, const float* __restrict__ own_obs,
+                                               float nfpb, Par par, int quirk /* GRAAL_MODE_REF_TRANS_ACCU */)
 {
     STAMP(7, blockIdx.x == 0 && threadIdx.x == 0);
     StatAcc a = stat_zero();
@@ -618,8 +646,22 @@ __global__ __launch_bounds__(256) void k_apply(SoaPtr in, SoaPtr out, int n, int
     // 64 x 256 threads 15 us; 49 blocks x 1024 threads ~28 us; 196 x 256 ~25 us)
     for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < n; f += gridDim.x * blockDim.x) {
         bool stale;
-        const Rec r = apply_move(m, f, ld_rec(in, f), &stale);
+        const Rec r0 = ld_rec(in, f);
+        const Rec r = apply_move(m, f, r0, &stale);
         st_rec(out, f, r);
+        if (stat != nullptr && (r.start_bp != r0.start_bp || r.ori != r0.ori || r.circ != r0.circ || (r.circ == 1 && r.l_cont_bp != r0.l_cont_bp))) {
+            // the commit's own-pixel correction: what this move does to the pixels no delta contains (own_pixel_q), summed over the bins it moves
+            const Stat st = stat[f];
+            if (st.n > 1) {
+                // (the trans-branch indexing prices a reversed bin with its LAST RF count, kernels3.cu:3155: mirroring a bin whose sub-fragments
+                // carry different counts also changes its trans pixels with every bin OUTSIDE the two contigs -- in no delta, not an own pixel:
+                // this commit's correction is unknown and the step that follows evaluates the layout in full)
+                bool bad = quirk && r.ori != r0.ori && !stat_uniform(st);
+                const float* own = own_obs + 3 * (size_t)r.id_d;
+                const long long qn = own_pixel_q(r, st, own, nfpb, par, bad), qo = own_pixel_q(r0, st, own, nfpb, par, bad);
+                if (bad) a.v[10] += 1; else a.v[9] += qn - qo;
+            }
+        }
         if (stale) atomicAdd(n_stale, 1);
         if (f == 0) { chg->cA = A0.id_c; chg->cB = B0.id_c; chg->lab[0] = A0.id_c; chg->lab[1] = B0.id_c; chg->lab[2] = max_id + 1; chg->lab[3] = max_id + 2; }
         if (r.pos == 0) {
@@ -663,10 +705,10 @@ __device__ __forceinline__ void publish_partials(const long long* __restrict__ p
                 const long long y = __shfl_down(x, o, 64);
                 x = (i == 4 || i == 7) ? (y > x ? y : x) : (i == 5 ? (y < x ? y : x) : x + y);
             }
-            if (u == 0) host[1 + (i < 8 ? i : 14)] = x;
+            if (u == 0) host[1 + (i < 8 ? i : (i == 8 ? 14 : (i == 9 ? 15 : 8)))] = x;   // ([9] -> word 15, [10] -> word 8: the commit's own-pixel correction and its bad terms)
         }
         if (u == 0) host[1 + 13] = stale;
-        // (words 8..12 and 15 of the host block are not statistics: nobody reads them)
+        // (words 9..12 of the host block are not statistics: nobody reads them)
         __threadfence_system();
     }
     if (u == 0) stats[13] = 0;   // (re-armed for the next commit)
@@ -4224,6 +4266,16 @@ struct Ctx {
     hipEvent_t ev_relabel = nullptr; // end of the relabel kernels graal_begin_step left running (orders the next k_tm, on aux)
     hipEvent_t ev_tm = nullptr;   // end of the step's k_tm (orders a chip-filling k_fin behind it, see launch_fin)
     hipEvent_t ev_par = nullptr, ev_par2 = nullptr;   // graal_set_params: the parameter update fenced against the auxiliary streams
+    // the commit's own-pixel correction (k_apply, own_pixel_q): observed counts of every bin's own sub-fragment pairs; what the statistics'
+    // publications have delivered since somebody last took it (graal_take_carry_correction / graal_step with flag 16)
+    float* d_own_obs = nullptr;
+    bool apply_had_own = false;      // the last commit computed it
+    bool all_uniform = false;        // every bin's sub-fragments carry ONE RF count: the trans-branch indexing (GRAAL_MODE_REF_TRANS_ACCU) changes nothing
+    int corr_src = 0;                // the statistics in flight come from: 1 = exactly one commit (k_apply's rows), 2 = no change, 0 = neither (unknown)
+    long long carry_q = 0;
+    bool carry_bad = false;
+    bool corr_inflight = false;      // between begin_step_launch and begin_step_collect
+    bool corr_skip = false;          // the caller holds a full evaluation of the layout whose commit has not been relabelled yet: its correction is void
     bool full_rep_sharded = false; // the full evaluation in flight dealt the repeated bins' pixels to the ranks (full_launch -> full_collect)
     bool args_synced = false;     // the device-resident argument blocks are complete (sync_args ran with parameters and sub-fragment tables in place)
     bool relabel_pending = false;
@@ -4336,6 +4388,7 @@ struct Ctx {
     unsigned long long slist_floor = 0;      // entries the list holds at least: raised when a step's list overflowed (eval_sync grows it and repeats the step)
     unsigned long long slist_worst = 0;      // the last launch's worst case (every tile pair of the union set listed)
     long long rc_list_grown = 0;
+    long long rc_carry_repairs = 0;  // graal_step (flag 16): steps whose own-pixel correction was unknown and that evaluated the layout in full instead
     unsigned long long slist_soft_cap = getenv("GRAAL_SLIST_SOFT_CAP") ? std::max<unsigned long long>(64ull, strtoull(getenv("GRAAL_SLIST_SOFT_CAP"), nullptr, 10))
                                                                         : (1ull << 23);   // 8 M entries = 64 MB (C5's 7 contigs list ~1e5); tests set it small
     USet* d_uset = nullptr;       // reference arithmetic over the step's union set (strict2.h): the set, the classes per pair of global pieces
@@ -5056,6 +5109,7 @@ void graal_destroy(graal_ctx* h)
                         h->d_scalars, h->d_qout, h->d_dref, h->d_dist};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (h->nccl_comm) { Rccl* R = rccl_load(nullptr); if (R) (void)R->CommDestroy(h->nccl_comm); h->nccl_comm = nullptr; }
+        if (h->d_own_obs) (void)hipFree(h->d_own_obs);
         if (h->x_host) (void)hipHostUnregister(h->x_host);
         if (h->h_res) (void)hipHostFree(h->h_res);
         if (h->h_stats) (void)hipHostFree(h->h_stats);
@@ -5139,6 +5193,7 @@ int graal_upload_subfrags(graal_ctx* h, const int32_t* sub_id, const float* sub_
     }
     h->h_nsub.resize(n_bins);
     bool single = true;
+    bool uniform = true;   // every bin's sub-fragments carry one RF count (stat_uniform)
     for (int b = 0; b < n_bins; b++) {
         const int ns = sub_id[4 * b + 3];
         if (ns < 1 || ns > 3) return fail(h, GRAAL_E_ARG, "n_sub must be 1..3 (sub-sampling factor 3 is baked in, simulation_loader.py:682-698)");
@@ -5155,7 +5210,9 @@ int graal_upload_subfrags(graal_ctx* h, const int32_t* sub_id, const float* sub_
             s2b[sid] = b * 4 + k;
         }
         st[b] = s;
+        uniform &= (ns < 2 || s.a1 == s.a0) && (ns < 3 || s.a2 == s.a0);
     }
+    h->all_uniform = uniform;
     for (int v : s2b) if (v < 0) return fail(h, GRAAL_E_ARG, "every sub-fragment must belong to a bin");
     h->h_stat = st;
     h->h_sub2bin = s2b;
@@ -5294,6 +5351,21 @@ static int upload_contacts_impl(graal_ctx* h, const int32_t* row, const int32_t*
         CK(hipMemcpy(h->cnt, count, sizeof(float) * (size_t)nnz, hipMemcpyHostToDevice));
     }
     h->nnz = nnz; h->c_lf_q = c_lf_q; h->have_contacts = true;
+    // the observed counts of every bin's OWN sub-fragment pairs (own_pixel_q): contacts whose two sub-fragments belong to one bin
+    if (h->d_own_obs) { (void)hipFree(h->d_own_obs); h->d_own_obs = nullptr; }
+    if (!h->single_sub && !h->has_rep) {
+        std::vector<float> own(3 * (size_t)h->n_bins, 0.0f);
+        for (int64_t i = 0; i < nnz; i++) {
+            const int ra = h->h_sub2bin[(size_t)row[i]], rb = h->h_sub2bin[(size_t)col[i]];
+            if ((ra >> 2) != (rb >> 2)) continue;
+            const int sa = std::min(ra & 3, rb & 3), sb = std::max(ra & 3, rb & 3);
+            if (sa == sb) continue;
+            own[3 * (size_t)(ra >> 2) + (sa == 0 ? sb - 1 : 2)] = count[i];
+        }
+        CK(hipMalloc(&h->d_own_obs, sizeof(float) * own.size()));
+        CK(hipMemcpy(h->d_own_obs, own.data(), sizeof(float) * own.size(), hipMemcpyHostToDevice));
+    }
+    h->carry_q = 0; h->carry_bad = true;   // (whatever was pending belonged to another problem)
     return sync_args(h);
 }
 
@@ -5426,6 +5498,9 @@ static int begin_step_launch(graal_ctx* h, bool defer = false)
     bool full_relabel = false;
     const bool from_apply = incr && h->stats_from_apply;
     const bool defer_stats = defer && h->spin_ok && from_apply;   // k_tm's extra block publishes them (graal_step reads them with the scores)
+    h->corr_src = (from_apply && h->apply_had_own) ? 1 : ((h->ranks_valid && h->pending_commits == 0) ? 2 : 0);
+    if (h->corr_skip) { h->corr_src = 2; h->corr_skip = false; }
+    h->corr_inflight = true;
     if (from_apply) {
         // nothing to launch for the statistics: the commit kernel left its rows, k_incr (below) publishes them
     } else if (early) {
@@ -5534,6 +5609,10 @@ static int begin_step_collect(graal_ctx* h, int64_t stats[8], int32_t* max_id)
     if (nc <= 0 || nc > n || res[7] >= 2 * n + 8) return fail(h, GRAAL_E_STATE, "corrupt layout: contig heads / labels out of range");
     if (res[6] != 0 && !h->has_rep) return fail(h, GRAAL_E_STATE, "corrupt layout: rep / activ / id_d changed without repeats");
     h->n_contigs = nc; h->order_valid = true; h->ranks_valid = true; h->pending_commits = 0; h->incr_ok = false;
+    // the commit's own-pixel correction rides on the statistics of the layout it produced
+    if (h->corr_src == 1) { if (res[8] != 0) h->carry_bad = true; else h->carry_q += res[15]; }
+    else if (h->corr_src == 0) h->carry_bad = true;    // (a layout that is not one commit away from the last one: the correction is unknown)
+    h->corr_src = 2; h->corr_inflight = false;
     h->max_lcont = (int)res[4];
     h->lcont_bound = h->max_lcont;
     if (max_id) *max_id = nc - 1;
@@ -6264,10 +6343,16 @@ int graal_apply_move(graal_ctx* h, int32_t fA, int32_t fB, int32_t op, int32_t m
     // words, the stores -- and no longer pays atomics per block, so more, shorter blocks win: 12.4 -> ~6 us at 50k fragments)
     static const int apply_blocks_env = getenv("GRAAL_APPLY_BLOCKS") ? atoi(getenv("GRAAL_APPLY_BLOCKS")) : 256;
     h->apply_blocks = std::min(blocks_for(h->n, 256), std::max(1, std::min(apply_blocks_env, 1024)));
-    k_apply<<<h->apply_blocks, 256, 0, h->stream>>>(h->soa[h->cur], h->soa[1 - h->cur], h->n, op, fA, fB, max_id, d_stale, h->d_chg + h->chg_w, h->d_part);
+    const bool own_on = !h->single_sub && !h->has_rep && h->d_own_obs != nullptr && h->stat_frag != nullptr && h->have_par &&
+                        !h->x_host && !(h->nccl_comm && h->n_world > 1);
+    k_apply<<<h->apply_blocks, 256, 0, h->stream>>>(h->soa[h->cur], h->soa[1 - h->cur], h->n, op, fA, fB, max_id, d_stale, h->d_chg + h->chg_w, h->d_part,
+                                                    own_on ? h->stat_frag : nullptr, h->d_own_obs, h->nfpb, h->par,
+                                                    (h->mode & GRAAL_MODE_REF_TRANS_ACCU) && !h->all_uniform ? 1 : 0);
+    h->apply_had_own = own_on;
     h->chg_last = h->chg_w; h->chg_w ^= 1;
     CK(hipGetLastError());
     h->begin_launched = false;
+    h->corr_skip = false;
     h->stats_from_apply = true; // statistics of the new layout are on their way to pinned host memory (sequence stats_seq)
     h->incr_ok = h->ranks_valid && h->pending_commits == 0 && max_id == h->n_contigs - 1;
     h->pending_commits += 1;
@@ -6424,12 +6509,26 @@ int graal_last_counters(graal_ctx* h, int64_t out[4])
     return GRAAL_OK;
 }
 
+int graal_take_carry_correction(graal_ctx* h, int64_t* q_out, int32_t* valid_out)
+{
+    if (!h) return GRAAL_E_ARG;
+    if (!q_out || !valid_out) {   // discard: the caller evaluated the current layout in full -- the commits up to it are accounted for
+        if (h->corr_inflight) h->corr_src = 2;
+        else if (h->pending_commits > 0) h->corr_skip = true;
+    } else {
+        *q_out = h->carry_bad ? 0 : h->carry_q;
+        *valid_out = h->carry_bad ? 0 : 1;
+    }
+    h->carry_q = 0; h->carry_bad = false;
+    return GRAAL_OK;
+}
+
 int graal_run_counters(graal_ctx* h, int64_t out[12])
 {
     if (!h || !out) return GRAAL_E_ARG;
     out[0] = h->rc_evals; out[1] = h->rc_repeats; out[2] = h->spin_ok ? 1 : 0; out[3] = h->rc_gwait; out[4] = h->rc_gevent;
     out[5] = h->rc_flat; out[6] = h->rc_need_fin; out[7] = h->gave_up; out[8] = h->rc_list_grown; out[9] = (int64_t)h->slist_cap;
-    out[10] = out[11] = 0;
+    out[10] = h->rc_carry_repairs; out[11] = 0;
     return GRAAL_OK;
 }
 

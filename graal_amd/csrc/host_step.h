@@ -241,7 +241,7 @@ static int hs_select(MtState* mt, const double* score, int n, int n_tmp)
 // GRAAL_STEP_SELECT or 16 + a GRAAL_E_* code (error codes 1 .. 3 must not be taken for PAUSED / FALLBACK / SELECT)
 #define CK16(call) do { const hipError_t e16_ = (call); if (e16_ != hipSuccess) { h->err = hipGetErrorString(e16_); return 16 + GRAAL_E_HIP; } } while (0)
 static int hs_finish(graal_ctx* h, MtState* mt, double likelihood_t, int want_dist, graal_step_out* out, bool deferred = false,
-                     bool full_inside = false)
+                     bool full_inside = false, bool carry_corr = false)
 {
     if (!h->hs) return 16 + fail(h, GRAAL_E_STATE, "graal_upload_proposal_tables first");
     HostStep& S = *h->hs;
@@ -273,15 +273,35 @@ static int hs_finish(graal_ctx* h, MtState* mt, double likelihood_t, int want_di
         likelihood_t = fq[0] == Q_BAD ? (double)NAN : (double)(fq[0] + fq[1]) / Q_SCALE;
         out->full_likelihood = likelihood_t;
     }
-    for (int i = 0; i < K * N_OPS; i++) {
-        const double d = q_value(q[i], qc[i]);
-        out->scores[i] = d + likelihood_t;
-    }
     const double t2 = S.timing ? hs_now() : 0.0;
     if (deferred) {   // the statistics of the layout this step started from: published long ago, read now
         const int rc = begin_step_collect(h, out->stats, &out->max_id);
         if (rc) return 16 + rc;
         S.max_id = out->max_id;
+    }
+    {   // The total carried from the last step's accepted candidate lacks what that commit did to the pixels no delta contains -- the moved bins'
+        // OWN pixels (k_apply: own_pixel_q) --, which arrived with this layout's statistics.  Flag 16: add it, i.e. start from the full
+        // likelihood of this layout as the reference does (cuda_lib_gl.py:1828-1848) without evaluating it; a full evaluation (flag 8, or
+        // the caller's after a pause) supersedes it; a correction that is unknown -- a layout not one commit away from the last, a term out
+        // of range -- is replaced by the evaluation itself.
+        int64_t cq = 0;
+        int32_t cv = 0;
+        (void)graal_take_carry_correction(h, &cq, &cv);
+        if (carry_corr && !full_inside) {
+            if (cv) likelihood_t += (double)cq / Q_SCALE;
+            else {
+                int64_t fq[2];
+                h->rc_carry_repairs += 1;
+                const int rc = graal_eval_full_q(h, fq);
+                if (rc) return 16 + rc;
+                likelihood_t = fq[0] == Q_BAD ? (double)NAN : (double)(fq[0] + fq[1]) / Q_SCALE;
+                out->full_likelihood = likelihood_t;
+            }
+        }
+    }
+    for (int i = 0; i < K * N_OPS; i++) {
+        const double d = q_value(q[i], qc[i]);
+        out->scores[i] = d + likelihood_t;
     }
     const double t3 = S.timing ? hs_now() : 0.0;
     const int pos_before = mt->pos;
@@ -340,7 +360,7 @@ int graal_step(graal_ctx* h, void* mt_state, int32_t fA, int32_t delta, double l
         begin_step_assume(h);
         S.max_id = -1;
         if (S.timing) { S.t_mark = hs_now(); S.t_acc[0] += t1 - t0; S.t_acc[1] += S.t_mark - t1; }
-        return hs_finish(h, mt, likelihood_t, (flags & 4) != 0, out, true);   // (GRAAL_STEP_DONE / _FALLBACK, or 16 + an error code)
+        return hs_finish(h, mt, likelihood_t, (flags & 4) != 0, out, true, false, (flags & 16) != 0);   // (GRAAL_STEP_DONE / _FALLBACK, or 16 + an error code)
     }
     rc = graal_begin_step(h, out->stats, &out->max_id);
     if (rc) { *mt = keep; S.nb.clear(); return 16 + rc; }
@@ -352,7 +372,7 @@ int graal_step(graal_ctx* h, void* mt_state, int32_t fA, int32_t delta, double l
         S.paused = true;
         return GRAAL_STEP_PAUSED;
     }
-    return hs_finish(h, mt, likelihood_t, (flags & 4) != 0, out);
+    return hs_finish(h, mt, likelihood_t, (flags & 4) != 0, out, false, false, (flags & 16) != 0);
 }
 
 int graal_step_finish(graal_ctx* h, void* mt_state, double likelihood_t, int32_t flags, graal_step_out* out)

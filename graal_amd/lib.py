@@ -50,7 +50,7 @@ _f64p = ctypes.POINTER(ctypes.c_double)
 SYMBOLS = ("graal_abi_version", "graal_create", "graal_destroy", "graal_last_error", "graal_set_params",
            "graal_upload_subfrags", "graal_upload_repeats", "graal_upload_contacts", "graal_upload_contacts_f32", "graal_upload_frags", "graal_download_frags",
            "graal_relabel_contigs", "graal_begin_step", "graal_begin_step_launch", "graal_layout_stats", "graal_eval_full_q", "graal_eval_full_params", "graal_eval_candidates_q",
-           "graal_eval_candidates", "graal_exchange_bytes", "graal_attach_exchange", "graal_eval_candidates_x", "graal_exchange_selftest", "graal_detach_exchange", "graal_rccl_unique_id", "graal_attach_rccl", "graal_detach_rccl", "graal_upload_distance_ref", "graal_genome_distance", "graal_apply_move", "graal_set_finisher", "graal_set_mode", "graal_set_timing", "graal_last_timing", "graal_scan_times", "graal_strict_times", "graal_time_scan", "graal_last_counters", "graal_run_counters",
+           "graal_eval_candidates", "graal_exchange_bytes", "graal_attach_exchange", "graal_eval_candidates_x", "graal_exchange_selftest", "graal_detach_exchange", "graal_rccl_unique_id", "graal_attach_rccl", "graal_detach_rccl", "graal_upload_distance_ref", "graal_genome_distance", "graal_apply_move", "graal_set_finisher", "graal_set_mode", "graal_set_timing", "graal_last_timing", "graal_scan_times", "graal_strict_times", "graal_time_scan", "graal_last_counters", "graal_take_carry_correction", "graal_run_counters",
            "graal_upload_proposal_tables", "graal_step", "graal_step_finish", "graal_steps", "graal_host_np_sum", "graal_host_select_move", "graal_host_neighbours", "graal_host_max_dist_intra")
 
 STEP_DONE, STEP_PAUSED, STEP_FALLBACK, STEP_SELECT = 0, 1, 2, 3
@@ -119,6 +119,7 @@ def load():
         L.graal_last_timing.argtypes = [ctypes.c_void_p, _f32p]
         L.graal_last_counters.argtypes = [ctypes.c_void_p, _i64p]
         L.graal_run_counters.argtypes = [ctypes.c_void_p, _i64p]
+        L.graal_take_carry_correction.argtypes = [ctypes.c_void_p, _i64p, _i32p]
         L.graal_set_timing.argtypes = [ctypes.c_void_p, ctypes.c_int32]
         L.graal_set_finisher.argtypes = [ctypes.c_void_p, ctypes.c_int32]
         L.graal_set_mode.argtypes = [ctypes.c_void_p, ctypes.c_int32]
@@ -513,14 +514,25 @@ class Engine:
         self._ck(self._L.graal_time_scan(self._h, int(K), int(reps), ctypes.byref(ms)), "graal_time_scan")
         return float(ms.value)
 
+    def take_carry_correction(self):
+        """graal_take_carry_correction: (correction in log-likelihood units, valid) of the commits since the last take."""
+        q, v = ctypes.c_int64(0), ctypes.c_int32(0)
+        self._ck(self._L.graal_take_carry_correction(self._h, ctypes.byref(q), ctypes.byref(v)), "graal_take_carry_correction")
+        return float(q.value) / Q_SCALE, bool(v.value)
+
+    def discard_carry_correction(self):
+        """The caller holds a full evaluation of the current layout: the corrections of the commits up to it are void."""
+        self._ck(self._L.graal_take_carry_correction(self._h, None, None), "graal_take_carry_correction")
+
     def run_counters(self):
         """include/graal_hip.h: graal_run_counters -- evaluations, repeats behind events (`fallbacks`), in-kernel waits in use,
         k_strict2 launches behind k_gprep's word / behind the event, k_strict_flat launches, hand-overs to a finishing kernel, finisher give-ups."""
         c = np.zeros(12, dtype=np.int64)
         self._ck(self._L.graal_run_counters(self._h, c.ctypes.data_as(_i64p)), "graal_run_counters")
         return dict(zip(("evaluations", "fallbacks", "in_kernel_waits_in_use", "strict2_behind_the_word", "strict2_behind_the_event",
-                         "flat_launches", "handed_to_a_finishing_kernel", "finisher_gave_up", "unit_list_grown", "unit_list_capacity"),
-                        (int(x) for x in c[:10])))
+                         "flat_launches", "handed_to_a_finishing_kernel", "finisher_gave_up", "unit_list_grown", "unit_list_capacity",
+                         "carried_totals_repaired"),
+                        (int(x) for x in c[:11])))
 
     def last_counters(self):
         c = np.zeros(4, dtype=np.int64)

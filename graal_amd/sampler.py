@@ -388,6 +388,7 @@ class sampler(object):
         self._dist_ref_uploaded = False
         self._dist_counted_mask = None
         self.exchange = self._setup_exchange(exchange)
+        import os as _os
         # MCMC steps between full re-evaluations of the carried-over likelihood.  With repeats every step: the reference's
         # candidate pixel ranges miss some pixels an activity swap changes (kernels3.cu:3368-3373), so its per-step total
         # (always a full evaluation, cuda_lib_gl.py:1828-1848) is not the previous score
@@ -398,8 +399,23 @@ class sampler(object):
         # contains; its per-step full evaluation does.
         # And with several sub-fragments per bin, a bin's OWN pixel (its sub-fragment pairs) is in no candidate delta either
         # (kernels3.cu:3356-3380) while its float32 value moves with the bin's coordinates: 1e-7 relative per 100 steps, measured.
-        # So the strict total is carried only at one sub-fragment per bin (level 0: the C4 / C5 shapes).
-        self.resync_every = 1 if (len(self.id_frag_duplicated) or (self.reference_arithmetic and not self._single_sub)) else 512
+        # So the strict total is carried as it is only at one sub-fragment per bin (level 0: the C4 / C5 shapes).  With sub-fragments
+        # the commit kernel computes what it does to the own pixels of the bins it moves and the next step adds that to the carried
+        # total (include/graal_hip.h: graal_take_carry_correction, graal_step flag 16) -- which makes it the full likelihood of the
+        # committed layout again, without the 35-50 us evaluation per step; one rank, no repeats.  A commit that mirrors a bin whose
+        # sub-fragments carry DIFFERENT RF counts reports its correction as unknown (the trans-branch indexing above moves that bin's
+        # trans pixels too) and the next step evaluates in full: in a pyramid those are the ragged last bins of the initial contigs;
+        # where they are more than a tenth of the bins the per-step evaluation stays (it overlaps the scoring kernels, a repair does not).
+        accu = self.np_sub_frags_accu
+        nsub = self.np_sub_frags_id[:, 3]
+        mixed = ((nsub >= 2) & (accu[:, 1] != accu[:, 0])) | ((nsub >= 3) & (accu[:, 2] != accu[:, 0]))
+        self._own_corr = bool(self.reference_arithmetic == "strict" and not self._single_sub and not len(self.id_frag_duplicated)
+                              and self.group.world == 1 and mixed.mean() <= 0.1 and not _os.environ.get("GRAAL_NO_OWN_PIXEL_CARRY"))
+        self.resync_every = 512
+        if len(self.id_frag_duplicated) or (self.reference_arithmetic and not self._single_sub and not self._own_corr):
+            self.resync_every = 1
+        if _os.environ.get("GRAAL_RESYNC_EVERY"):     # (measurement switch: what the reference's per-step full evaluation costs a run)
+            self.resync_every = max(1, int(_os.environ["GRAAL_RESYNC_EVERY"]))
         self._steps_since_full = 0
         self._force_full = False   # the carried-over total is not a likelihood of the current layout / parameters
         # ---- proposal ----------------------------------------------------------------------------------------
@@ -425,6 +441,7 @@ class sampler(object):
         self.param_simu = np.array([tuple(flat)], dtype=self.param_simu_rippe)
         self._param_flat = flat
         self.engine.set_params(flat)
+        self._force_full = True    # (the carried total was a likelihood under the old parameters)
 
     def setup_rippe_parameters(self, param, d_max):
         kuhn, lm, slope, d, fact = param
@@ -509,7 +526,7 @@ class sampler(object):
         out_test_param = np.array(out_test_param, dtype=self.param_simu_T)
         flat = np.array([out_test_param[0][k] for k in out_test_param.dtype.names], dtype=np.float32)
         if self.likelihood_t is None:
-            self.likelihood_t = self.eval_likelihood()
+            self._set_total_from_full(self.eval_likelihood())
         valid = bool(np.isfinite(flat).all() and flat[7] > 0 and 0 < flat[5] < 2.0e6)
         test_likelihood = self.compute_likelihood_4_nuisance(flat, restore=False) if valid else -np.inf
         F_t = self.temperature(t, n_step)
@@ -520,7 +537,7 @@ class sampler(object):
         if ratio >= u:
             success = 1
             self.set_param_simu(out_test_param)
-            self.likelihood_t = test_likelihood
+            self._set_total_from_full(test_likelihood)
             self._force_full = False   # a full evaluation of the current layout under the parameters now in force
         elif valid:
             self.engine.set_params(self._param_flat)   # rejected: back to the parameters in force
@@ -582,7 +599,7 @@ class sampler(object):
         return self._full_likelihood()
 
     def init_likelihood(self):
-        self.likelihood_t = self.eval_likelihood()
+        self._set_total_from_full(self.eval_likelihood())
         self._force_full = False
 
     def _setup_exchange(self, mode):
@@ -831,6 +848,17 @@ class sampler(object):
                                            self.collector_id_repeats, dup, black)
         self._c_step = True
 
+    def _step_flags(self):
+        """graal_step's flags (include/graal_hip.h): 16 = the carried total + the last commit's own-pixel correction; else 1 = with
+        sub-fragments, re-evaluate whenever circular contigs are around (their own pixels follow the circular model); 4 = distance."""
+        return (16 if self._own_corr else (0 if self._single_sub else 1)) | (4 if self.compute_dist else 0)
+
+    def _set_total_from_full(self, value):
+        """The carried total := a full evaluation of the CURRENT layout: the own-pixel corrections of the commits up to it are void."""
+        self.likelihood_t = value
+        if self._own_corr:
+            self.engine.discard_carry_correction()
+
     def _step_c(self, id_fA, delta, t, n_step):
         """step_max_likelihood through graal_step (include/graal_hip.h): the proposal, the score post-processing, the sampling and
         the commit run behind the C ABI, on this sampler's own generator state; the rare full re-evaluations stay here.
@@ -840,7 +868,7 @@ class sampler(object):
         if F_t != 1.0:
             return None
         so = e.step_out
-        flags = (0 if self._single_sub else 1) | (4 if self.compute_dist else 0)
+        flags = self._step_flags()
         resync = self.likelihood_t is None or self._force_full or self._steps_since_full + 1 >= self.resync_every
         if resync:
             flags |= 2
@@ -872,7 +900,7 @@ class sampler(object):
                 self.likelihood_t = self._full_likelihood()
                 self._steps_since_full = 0
                 self._force_full = False
-            elif (n_circ or self._n_circ_prev) and not self._single_sub:
+            elif (n_circ or self._n_circ_prev) and not self._single_sub and not self._own_corr:
                 self.likelihood_t = self._full_likelihood()
             rc = e.step_finish(self._mt_addr, float(self.likelihood_t), flags)
         self._n_circ_prev = n_circ
@@ -925,7 +953,7 @@ class sampler(object):
                 i += 1
                 continue
             e = self.engine
-            flags = (0 if self._single_sub else 1) | (4 if self.compute_dist else 0)
+            flags = self._step_flags()
             rc, rows = e.steps(self._mt_addr, ids[i:j], int(delta), float(self.likelihood_t), flags, self._n_circ_prev)
             for r in rows:
                 o = float(r[0])
@@ -994,12 +1022,15 @@ class sampler(object):
             self._force_full = True
             return o, n_contigs, min_len, mean_len_bp, max_len, -1, id_fA, dist, self.temperature(t, n_step)
         self._steps_since_full += 1
-        if self.likelihood_t is None or self._force_full or self._steps_since_full >= self.resync_every:
+        corr, corr_ok = self.engine.take_carry_correction() if self._own_corr else (0.0, True)
+        if self.likelihood_t is None or self._force_full or self._steps_since_full >= self.resync_every or not corr_ok:
             # the carried-over total drifts by ~1e-10 |logL| per step against a full evaluation (deviation 1):
             # re-evaluate now and then (the reference does it every step, cuda_lib_gl.py:1828-1848)
             self.likelihood_t = self._full_likelihood()
             self._steps_since_full = 0
             self._force_full = False
+        elif self._own_corr:
+            self.likelihood_t += corr          # (what the last commit did to its bins' own pixels: graal_take_carry_correction)
         elif (n_circ or self._n_circ_prev) and not self._single_sub:
             # candidate deltas never include a bin's own pixel (as in the reference); those pixels only change with
             # the circular model, so resynchronise the carried-over total whenever circular contigs are around

@@ -214,6 +214,19 @@ int graal_time_scan(graal_ctx* h, int32_t K, int32_t reps, float* avg_ms);
  * out[2]=queue slots (contacts with both ends in an affected contig; the few the third test rejects leave empty entries)
  * out[3]=mass work items (task x 64-fragment chunk) */
 int graal_last_counters(graal_ctx* h, int64_t out[4]);
+/* What the commits since the last call did to the pixels NO candidate delta contains: with several sub-fragments per bin the reference's
+ * sub_compute_likelihood revisits the pixels between DIFFERENT bins of contig(A) u contig(B) only (kernels3.cu:3356-3380), while a bin's
+ * own pixel -- its sub-fragment pairs, evaluate_likelihood's on_diag pixels (:3213) -- moves with the bin's float32 coordinates and with its
+ * contig's circular model.  The commit kernel computes that difference for the bins it moves (same terms, same roundings as the full
+ * evaluation), it rides on the layout statistics, and *q_out (Q: value x 2^30) is its sum over the graal_begin_step calls since the last
+ * take:  score of the accepted candidate + *q_out / 2^30 == the full likelihood of the committed layout (to the rounding of one term per
+ * pair), without repeats.  *valid_out = 0: unknown -- a layout that is not one commit away from the last one, a term out of range,
+ * repeats, a sharded list, or, with the trans-branch indexing (GRAAL_MODE_REF_TRANS_ACCU), a commit that mirrored a bin whose
+ * sub-fragments carry different RF counts (that also changes the bin's trans pixels with every bin outside the two contigs) --: evaluate
+ * instead.  q_out = NULL: DISCARD -- the caller
+ * holds a full evaluation of the current layout, which accounts for every commit so far, the one whose statistics have not been collected
+ * included.  No device access. */
+int graal_take_carry_correction(graal_ctx* h, int64_t* q_out, int32_t* valid_out);
 /* counters of the handle's whole life (no device access): out[0] = candidate evaluations started, out[1] = evaluations REPEATED behind
  * events because an in-kernel wait between two kernels of a step ran out (k_tm waiting for the scan's announcement, k_strict2 waiting for
  * k_gprep's completion word: the kernels were not resident together -- a profiler serialising dispatches; results are the same, the
@@ -221,7 +234,8 @@ int graal_last_counters(graal_ctx* h, int64_t out[4]);
  * reference-arithmetic kernel that followed k_gprep through the completion word / behind the event, out[5] = k_strict_flat launches,
  * out[6] = evaluations the table kernel handed to a finishing kernel through the host, out[7] = times its finisher gave up waiting for
  * the scan, out[8] = evaluations repeated with a longer unit list (the tiled kernel's list starts at a soft cap instead of its quadratic
- * worst case and grows when a step overflows it), out[9] = that list's capacity now (entries of 8 bytes), out[10..11] = 0 (reserved).
+ * worst case and grows when a step overflows it), out[9] = that list's capacity now (entries of 8 bytes), out[10] = graal_step calls with flag 16 whose own-pixel
+ * correction was unknown and that evaluated the layout in full instead (graal_take_carry_correction), out[11] = 0 (reserved).
  * bench.py reports out[1] as `fallbacks`. */
 int graal_run_counters(graal_ctx* h, int64_t out[12]);
 
@@ -264,7 +278,11 @@ int graal_upload_proposal_tables(graal_ctx* h, const int32_t* xk, const float* p
  * graal_step_finish -- valid only then), GRAAL_STEP_FALLBACK (a blacklisted fragment, or an unusual proposal numpy itself has to judge:
  * NOTHING drawn from the generator, nothing committed: take the step through the individual entry points), GRAAL_STEP_SELECT (the
  * neighbours are drawn and out->neighbours / out->scores / out->stats / out->max_id [/ out->full_likelihood] valid, but the selection
- * is left to the caller -- nothing drawn for it, nothing committed: select, then graal_apply_move) or 16 + an error code. */
+ * is left to the caller -- nothing drawn for it, nothing committed: select, then graal_apply_move) or 16 + an error code.
+ * flag 16 = `likelihood_t` is the score of the LAST step's accepted candidate, carried over: add the own-pixel correction of that commit
+ * (graal_take_carry_correction) so that the step starts from the full likelihood of its layout, as the reference's per-step
+ * evaluate_likelihood does (cuda_lib_gl.py:1828-1848), without evaluating it (a full evaluation -- flag 8, or the caller's behind a pause --
+ * supersedes the correction; an unknown correction is replaced by the evaluation itself, out->full_likelihood). */
 int graal_step(graal_ctx* h, void* mt_state, int32_t fA, int32_t delta, double likelihood_t, int32_t flags, int32_t prev_circ,
                graal_step_out* out);
 int graal_step_finish(graal_ctx* h, void* mt_state, double likelihood_t, int32_t flags, graal_step_out* out);

@@ -150,7 +150,7 @@ def test_strict_total_carried_over_equals_a_full_evaluation():
     """In reference arithmetic the candidate delta IS full(after) - full(before) pixel by pixel (pixels outside the set get the
     same inputs), so at one sub-fragment per bin -- no bin has a pixel of its own -- the carried-over total needs no per-step
     re-evaluation: after 150 steps on generic coordinates it equals a full pass to summation rounding.  (With sub-fragments the
-    sampler re-evaluates every step, like the reference: sampler.resync_every.)"""
+    sampler adds each commit's own-pixel correction, or re-evaluates every step like the reference: sampler.resync_every.)"""
     from tests.test_sampler_gpu import make_gpu_sampler
     par = synth.make_param_simu(fact=200.0, v_inter=0.02)
     P = synth.with_dense(synth.make_problem(n_bins=150, nnz=5000, n_sub=1, seed=77, contig_weights=(5, 4, 3), mean_len_bp=1800.0,
@@ -168,7 +168,11 @@ def test_strict_total_carried_over_equals_a_full_evaluation():
     g.free_gpu()
     P3 = synth.with_dense(synth.make_problem(n_bins=60, nnz=900, n_sub=3, seed=78, contig_weights=(5, 4, 3), mean_len_bp=1800.0, accu=9, param=par))
     g3 = make_gpu_sampler(P3, np.random.RandomState(5), reference_arithmetic="strict")
-    assert g3.resync_every == 1
+    assert g3.resync_every == 512 and g3._own_corr      # (one RF count per bin: the commit's own-pixel correction, tests/test_carried_total_gpu.py)
+    g3.free_gpu()
+    P3 = synth.with_dense(synth.make_problem(n_bins=60, nnz=900, n_sub=3, seed=78, contig_weights=(5, 4, 3), mean_len_bp=1800.0, accu=("random", 1, 9), param=par))
+    g3 = make_gpu_sampler(P3, np.random.RandomState(5), reference_arithmetic="strict")
+    assert g3.resync_every == 1 and not g3._own_corr     # (mixed RF counts in most bins: the reference's per-step evaluation)
     g3.free_gpu()
 
 
