@@ -73,10 +73,14 @@ def main():
         dt = time.perf_counter() - t0
         n_steps = len(tr.likelihood)
         full = smp.eval_likelihood()
+        carried, how = tr.likelihood[-1], "carried logL"
+        if getattr(smp, "_own_corr", False):     # the last commit's own-pixel correction is still pending (the next step would add it)
+            corr, ok = smp.engine.take_carry_correction()
+            carried, how = carried + (corr if ok else float("nan")), "carried logL + the last commit's own pixels (%.3e)" % corr
         print("%s [%s]: %d bins x %d sub, %d contacts, %d cycles x %d neighbours: setup %.1f s, explode + %d MCMC steps in %.1f s = %.0f us/step, "
-              "%d contigs left (started exploded: %d), carried logL %.6e vs full re-evaluation %.6e (rel %.1e)"
+              "%d contigs left (started exploded: %d), %s %.6e vs full re-evaluation %.6e (rel %.1e), %d steps repaired by an evaluation"
               % (name, arith, n_bins, n_sub, nnz, cycles, K, t_setup, n_steps, dt, 1e6 * dt / n_steps, tr.n_contigs[-1], n_bins,
-                 tr.likelihood[-1], full, abs(full - tr.likelihood[-1]) / abs(full)), flush=True)
+                 how, carried, full, abs(full - carried) / abs(full), smp.engine.run_counters()["carried_totals_repaired"]), flush=True)
         smp.free_gpu()
 
 
