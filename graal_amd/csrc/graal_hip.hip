@@ -633,6 +633,8 @@ __device__ __forceinline__ long long own_pixel_q(const Rec& r, const Stat& st, c
 // afterwards among the <= 4 labels the move can touch (for the incremental relabel of the next graal_begin_step), and -- it
 // has every new record in registers anyway -- the statistics of the NEW layout, which its last block publishes to pinned host
 // memory: the next graal_begin_step finds them there and needs no statistics kernel.
+template <bool OWN /* the commit's own-pixel correction: only with several sub-fragments per bin (the plain commit is a chain of dependent round
+                      trips on every step's critical path: 6 us at 50,000 fragments, 8.5 with this code merely compiled in) */>
 __global__ __launch_bounds__(256) void k_apply(SoaPtr in, SoaPtr out, int n, int op, int fA, int fB, int max_id, int* __restrict__ n_stale,
                                                Changed* __restrict__ chg, long long* __restrict__ part,
                                                const Stat* __restrict__ stat /* nullptr: no own-pixel correction */, const float* __restrict__ own_obs,
@@ -649,7 +651,7 @@ __global__ __launch_bounds__(256) void k_apply(SoaPtr in, SoaPtr out, int n, int
         const Rec r0 = ld_rec(in, f);
         const Rec r = apply_move(m, f, r0, &stale);
         st_rec(out, f, r);
-        if (stat != nullptr && (r.start_bp != r0.start_bp || r.ori != r0.ori || r.circ != r0.circ || (r.circ == 1 && r.l_cont_bp != r0.l_cont_bp))) {
+        if (OWN && (r.start_bp != r0.start_bp || r.ori != r0.ori || r.circ != r0.circ || (r.circ == 1 && r.l_cont_bp != r0.l_cont_bp))) {
             // the commit's own-pixel correction: what this move does to the pixels no delta contains (own_pixel_q), summed over the bins it moves
             const Stat st = stat[f];
             if (st.n > 1) {
@@ -6345,9 +6347,12 @@ int graal_apply_move(graal_ctx* h, int32_t fA, int32_t fB, int32_t op, int32_t m
     h->apply_blocks = std::min(blocks_for(h->n, 256), std::max(1, std::min(apply_blocks_env, 1024)));
     const bool own_on = !h->single_sub && !h->has_rep && h->d_own_obs != nullptr && h->stat_frag != nullptr && h->have_par &&
                         !h->x_host && !(h->nccl_comm && h->n_world > 1);
-    k_apply<<<h->apply_blocks, 256, 0, h->stream>>>(h->soa[h->cur], h->soa[1 - h->cur], h->n, op, fA, fB, max_id, d_stale, h->d_chg + h->chg_w, h->d_part,
-                                                    own_on ? h->stat_frag : nullptr, h->d_own_obs, h->nfpb, h->par,
-                                                    (h->mode & GRAAL_MODE_REF_TRANS_ACCU) && !h->all_uniform ? 1 : 0);
+    if (own_on)
+        k_apply<true><<<h->apply_blocks, 256, 0, h->stream>>>(h->soa[h->cur], h->soa[1 - h->cur], h->n, op, fA, fB, max_id, d_stale, h->d_chg + h->chg_w, h->d_part,
+                                                              h->stat_frag, h->d_own_obs, h->nfpb, h->par, (h->mode & GRAAL_MODE_REF_TRANS_ACCU) && !h->all_uniform ? 1 : 0);
+    else
+        k_apply<false><<<h->apply_blocks, 256, 0, h->stream>>>(h->soa[h->cur], h->soa[1 - h->cur], h->n, op, fA, fB, max_id, d_stale, h->d_chg + h->chg_w, h->d_part,
+                                                               nullptr, nullptr, h->nfpb, h->par, 0);
     h->apply_had_own = own_on;
     h->chg_last = h->chg_w; h->chg_w ^= 1;
     CK(hipGetLastError());

@@ -490,39 +490,25 @@ class sampler(object):
         """Random-walk Metropolis step on (fact, slope, d_max, v_inter): ``cuda_lib_gl.py:2022-2107`` with its quirks kept
         (``np.random.choice(4)`` never picks the ``d`` branch; ``peval`` gets a 5-list so ``d`` acts as the amplitude)."""
         from . import rippe_fit as opti
-        curr_param = np.copy(self.param_simu)
-        kuhn, lm, c1, slope, d, d_max, fact, d_nuc = curr_param[0]
-        self.sigma_fact = 10 ** (np.log10(fact) - 2)
-        self.sigma_slope = 0.05
-        self.sigma_d_max = 100
-        self.sigma_d_nuc = 0.5
-        self.sigma_d = 10
-        id_modif = self.rng.choice(4)
-        if id_modif == 0:
-            new_fact = fact + self.rng.normal(loc=0.0, scale=self.sigma_fact)
-            new_d_max = opti.estimate_max_dist_intra_step([kuhn, lm, slope, d, new_fact], d_nuc)
-            c1 = np.float32((0.53 * np.power(lm / kuhn, slope)) * np.power(kuhn, -3))
-            out_test_param = [(kuhn, lm, c1, slope, d, new_d_max, new_fact, d_nuc)]
-        elif id_modif == 1:
-            new_slope = slope + self.rng.normal(loc=0.0, scale=self.sigma_slope)
-            new_d_max = opti.estimate_max_dist_intra_step([kuhn, lm, new_slope, d, fact], d_nuc)
-            c1 = np.float32((0.53 * np.power(lm / kuhn, new_slope)) * np.power(kuhn, -3))
-            out_test_param = [(kuhn, lm, c1, new_slope, d, new_d_max, fact, d_nuc)]
-        elif id_modif == 2:
-            new_d_max = d_max + self.rng.normal(loc=0.0, scale=self.sigma_d_max)
-            new_d_nuc = opti.peval(new_d_max, [kuhn, lm, slope, d, fact])
-            c1 = np.float32((0.53 * np.power(lm / kuhn, slope)) * np.power(kuhn, -3))
-            out_test_param = [(kuhn, lm, c1, slope, d, new_d_max, fact, new_d_nuc)]
-        elif id_modif == 3:
-            new_d_nuc = d_nuc + self.rng.normal(loc=0.0, scale=self.sigma_d_nuc)
-            new_d_max = opti.estimate_max_dist_intra_step([kuhn, lm, slope, d, fact], new_d_nuc)
-            c1 = np.float32((0.53 * np.power(lm / kuhn, slope)) * np.power(kuhn, -3))
-            out_test_param = [(kuhn, lm, c1, slope, d, new_d_max, fact, new_d_nuc)]
+        # the walk as a table: (perturbed field of param_simu, the attribute that holds its step width).  The reference sets the five widths
+        # on every call and draws the branch with choice(4): the fifth row is never picked.  After the perturbation EITHER the trans level
+        # follows the new cut-off (l_max perturbed: v_inter = the curve at l_max) OR the cut-off is re-solved for the trans level
+        # (everything else: fsolve for the distance where the curve reaches v_inter); c1 is recomputed from the slope in force.
+        # numpy's float32 scalars meet Python floats here (NEP 50: the sums stay float32) exactly as in the reference's expressions.
+        walk = (("fact", "sigma_fact"), ("slope", "sigma_slope"), ("l_max", "sigma_d_max"), ("v_inter", "sigma_d_nuc"), ("d", "sigma_d"))
+        names = self.param_simu.dtype.names
+        p = dict(zip(names, np.copy(self.param_simu)[0]))
+        self.sigma_fact = 10 ** (np.log10(p["fact"]) - 2)
+        self.sigma_slope, self.sigma_d_max, self.sigma_d_nuc, self.sigma_d = 0.05, 100, 0.5, 10
+        field, width = walk[self.rng.choice(4)]
+        p[field] = p[field] + self.rng.normal(loc=0.0, scale=getattr(self, width))
+        curve = [p["kuhn"], p["lm"], p["slope"], p["d"], p["fact"]]
+        if field == "l_max":
+            p["v_inter"] = opti.peval(p["l_max"], curve)
         else:
-            new_d = d + self.rng.normal(loc=0.0, scale=self.sigma_d)
-            new_d_max = opti.estimate_max_dist_intra_step([kuhn, lm, slope, new_d, fact], d_nuc)
-            c1 = np.float32((0.53 * np.power(lm / kuhn, slope)) * np.power(kuhn, -3))
-            out_test_param = [(kuhn, lm, c1, slope, new_d, new_d_max, fact, d_nuc)]
+            p["l_max"] = opti.estimate_max_dist_intra_step(curve, p["v_inter"])
+        p["c1"] = np.float32((0.53 * np.power(p["lm"] / p["kuhn"], p["slope"])) * np.power(p["kuhn"], -3))
+        out_test_param = [tuple(p[k] for k in names)]
         out_test_param = np.array(out_test_param, dtype=self.param_simu_T)
         flat = np.array([out_test_param[0][k] for k in out_test_param.dtype.names], dtype=np.float32)
         if self.likelihood_t is None:

@@ -31,6 +31,9 @@ def short(name):
     return name.split("(")[0].split("<")[0].strip() + ("<true>" if "k_scan<true>" in name else "<false>" if "k_scan<false>" in name else "")
 
 
+HIST_EDGES_US = [0, 25, 50, 100, 200, 400, 800, 1600, 3200, 1e9]
+
+
 def trace_stats(path, last_n=100):
     per = defaultdict(list)
     rows = []
@@ -50,6 +53,13 @@ def trace_stats(path, last_n=100):
         tail = v[-last_n:]
         out[k] = {"calls": len(v), "total_ms": sum(v) / 1e6, "avg_us": sum(v) / len(v) / 1e3, "min_us": min(v) / 1e3,
                   "max_us": max(v) / 1e3, "avg_us_last_%d" % last_n: sum(tail) / len(tail) / 1e3}
+        if len(v) >= 1000:   # where a kernel's time goes by the duration of its launches (a run's launches differ by orders of magnitude)
+            hist = []
+            for lo, hi in zip(HIST_EDGES_US[:-1], HIST_EDGES_US[1:]):
+                sel = [x for x in v if lo * 1e3 <= x < hi * 1e3]
+                if sel:
+                    hist.append({"from_us": lo, "to_us": hi, "calls": len(sel), "total_ms": sum(sel) / 1e6})
+            out[k]["by_duration"] = hist
     return out
 
 
@@ -142,6 +152,13 @@ def main():
         for k, v in sorted(res.get("kernel_trace", {}).items(), key=lambda kv: -kv[1]["total_ms"]):
             f.write("| %s | %d | %.3f | %.2f | %.2f | %.2f | %.2f |\n" % (k[:70], v["calls"], v["total_ms"], v["avg_us"], v["min_us"],
                                                                   v["max_us"], v["avg_us_last_100"]))
+        top = sorted(res.get("kernel_trace", {}).items(), key=lambda kv: -kv[1]["total_ms"])
+        for k, v in top[:3]:
+            if v.get("by_duration"):
+                f.write("\n## %s: launches and time by launch duration\n\n| duration (us) | launches | total ms | share of the kernel's time |\n|---|---|---|---|\n" % k[:70])
+                for h in v["by_duration"]:
+                    f.write("| %g - %s | %d | %.1f | %.1f %% |\n" % (h["from_us"], ("%g" % h["to_us"]) if h["to_us"] < 1e8 else "", h["calls"], h["total_ms"],
+                                                                 100.0 * h["total_ms"] / v["total_ms"]))
         for name in ("fetch", "write", "sq", "mix64", "mix32", "mixint"):
             if "pmc_" + name in res:
                 f.write("\n## PMC pass: %s (KiB per dispatch for the TCC counters)\n\n| kernel | counter | n | mean | mean last 100 | min | max |\n|---|---|---|---|---|---|---|\n" % name)
