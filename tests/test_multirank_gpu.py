@@ -83,6 +83,22 @@ def _worker(rank, world, port, q, exchange, which="sub3"):
 _REF = {}
 
 
+def _ref(which, several_ranks):
+    """The one-rank anchor of a run.  With sub-fragments ONE rank carries its total with the commits' own-pixel corrections
+    (tests/test_carried_total_gpu.py) while several ranks evaluate the full likelihood every step, as the reference does: the bit-for-bit
+    anchor of a several-rank run is the one-rank run that does the same (GRAAL_NO_OWN_PIXEL_CARRY=1)."""
+    from graal_amd import dist as gdist
+    key = (which, bool(several_ranks))
+    if key not in _REF:
+        if several_ranks:
+            os.environ["GRAAL_NO_OWN_PIXEL_CARRY"] = "1"
+        try:
+            _REF[key] = _run(gdist.Group(0, 1), which=which)
+        finally:
+            os.environ.pop("GRAAL_NO_OWN_PIXEL_CARRY", None)
+    return _REF[key]
+
+
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("world,exchange,which", [(2, "host", "sub3"), (3, "host", "sub3"), (2, "rccl", "sub3"), (2, "auto-fallback", "sub3"),
                                                   (2, "host", "mid"), (3, "host", "mid"), (2, "rccl", "mid"),
@@ -90,9 +106,7 @@ _REF = {}
 def test_ranks_reproduce_the_single_rank_run_bit_for_bit(world, exchange, which):
     import torch.multiprocessing as mp
     from graal_amd import dist as gdist
-    if which not in _REF:
-        _REF[which] = _run(gdist.Group(0, 1), which=which)
-    ref_mut, ref_scores, ref_soa, ref_full = _REF[which]
+    ref_mut, ref_scores, ref_soa, ref_full = _ref(which, several_ranks=True)
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -131,9 +145,7 @@ def test_rccl_all_reduce_driven_by_the_library_on_the_gpu_timeline(which, tmp_pa
     import sys
     from graal_amd import dist as gdist
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    if which not in _REF:
-        _REF[which] = _run(gdist.Group(0, 1), which=which)
-    ref_mut, ref_scores, ref_soa, ref_full = _REF[which]
+    ref_mut, ref_scores, ref_soa, ref_full = _ref(which, several_ranks=False)   # (a one-rank communicator: the child carries its total like any single rank)
     out = str(tmp_path / "rccl.npz")
     env = dict(os.environ, GRAAL_RCCL_FORCE="1", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
     r = subprocess.run([sys.executable, "-c", "import tests.test_multirank_gpu as t; t._rccl_child(%r, %r)" % (out, which)], cwd=root, env=env,
