@@ -4396,7 +4396,6 @@ struct Ctx {
     USet* d_uset = nullptr;       // reference arithmetic over the step's union set (strict2.h): the set, the classes per pair of global pieces
     GClass* d_cls = nullptr;
     int* d_cls_n = nullptr;
-    int* d_plan = nullptr;        // S2Args::plan
     unsigned scan_token = 0x5ca90000u; // k_scan launches so far (ScanArgs.token)
     double* d_ln_tab = nullptr;   // [LN_TRANS_LUT] ln of the trans value by RF-count product (k_ln_tab; rebuilt by sync_args)
     int* d_ubins = nullptr;       // bins whose sub-fragments carry different RF counts (k_quirk_mass)
@@ -4749,8 +4748,6 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
             CK(hipMalloc(&h->d_cls, sizeof(GClass) * (size_t)US_MAXPAIRS * US_NCAND));
             CK(hipMalloc(&h->d_cls_n, sizeof(int) * US_MAXPAIRS + 1024));   // (+ the units' draw counter, k_gprep's ticket and completion word: a line of its own each)
             CK(hipMemset(h->d_cls_n, 0, sizeof(int) * US_MAXPAIRS + 1024));
-            CK(hipMalloc(&h->d_plan, sizeof(int) * (size_t)(S2_PLAN_MAX + 4)));
-            CK(hipMemset(h->d_plan, 0, sizeof(int) * (size_t)(S2_PLAN_MAX + 4)));
             CK(hipDeviceSynchronize());
         }
         const int lc = std::max(std::max(h->max_lcont, h->lcont_bound), 1);
@@ -4814,12 +4811,7 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
         // (round 5 tried the word with the 1,024-block grids too: the wait ran out in every run -- C3 and C4 stand-ins -- and the engine went back to
         // events, as the argument above predicts)
         const bool gwait = h->gwait_env && publish && world == 1 && h->spin_ok && blocks <= 512;
-        s2.gp = s2.next + 32;                     // (ticket: 256 bytes behind the draw counter; the completion word 256 bytes behind the ticket: GP_DONE)
-        s2.gwait = gwait ? 1 : 0;
-        // the plan of a step with more units than k_strict2's blocks plan in LDS (S2Args::plan): written by k_gprep's last block
-        static const bool no_plan = getenv("GRAAL_S2_NO_PLAN") != nullptr;   // (A/B: the units dealt one after the other, as in round 4)
-        s2.plan = h->d_plan;
-        s2.plan_min = no_plan ? 0x7fffffff : std::min(S2_BAL_MAX, blocks * 4 / 2);
+        s2.gp = gwait ? s2.next + 32 : nullptr;   // (ticket: 256 bytes behind the draw counter; the completion word 256 bytes behind the ticket: GP_DONE)
         s2.gp_seq = (unsigned long long)h->seq;
         s2.gp_wait_ticks = h->gp_wait_ticks;
         s2.gp_acquire = h->gp_acquire;
@@ -5113,7 +5105,7 @@ void graal_destroy(graal_ctx* h)
         // ... and whatever this handle's kernels were launched on besides its own streams (graal_eval_candidates_q takes the CALLER'S stream: the
         // torch path of exchange="rccl"): nothing of this process may still touch the buffers, pinned words and the registered segment freed below
         (void)hipDeviceSynchronize();
-        void* ptrs[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->stat, h->sub_rec, h->sub_rec8, h->sub_lab16, h->d_ubins, h->d_ln_tab, h->sub2bin, h->row, h->col, h->cnt, h->queue, h->d_sub_ids, h->d_acc, h->tm_done, h->d_sync, h->d_done, h->d_wq, h->d_flags, h->d_slist, h->d_uset, h->d_cls, h->d_cls_n, h->d_plan, h->stat_frag, h->d_dup_bins, h->d_dup_index,
+        void* ptrs[] = {h->soa_mem[0], h->soa_mem[1], h->geo, h->stat, h->sub_rec, h->sub_rec8, h->sub_lab16, h->d_ubins, h->d_ln_tab, h->sub2bin, h->row, h->col, h->cnt, h->queue, h->d_sub_ids, h->d_acc, h->tm_done, h->d_sync, h->d_done, h->d_wq, h->d_flags, h->d_slist, h->d_uset, h->d_cls, h->d_cls_n, h->stat_frag, h->d_dup_bins, h->d_dup_index,
                         h->d_dispatcher, h->d_collector, h->d_sub_ids_all, h->d_rep_obs,
                         h->keys, h->keys_sorted, h->o2n, h->len_of2[0], h->len_of2[1], h->contig_off2[0], h->contig_off2[1], h->perm, h->pstart, h->cbase, h->link, h->mates, h->cub_tmp, h->tabs, h->step_hdr, h->d_args, h->d_chg, h->d_part,
                         h->d_scalars, h->d_qout, h->d_dref, h->d_dist};

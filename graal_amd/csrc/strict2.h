@@ -23,17 +23,10 @@ struct S2Args {
     unsigned long long* next;    // the next unit nobody has taken yet, minus the grid's waves (zero at rest: the step's last block clears it)
     // k_strict2 WITHOUT an event behind k_gprep (a grid of <= 512 blocks, one rank): k_gprep's last block stores the step's number in gp[GP_DONE] (gp[0]
     // is its blocks' ticket), k_strict2's blocks wait for it -- bounded -- before they read anything of k_gprep's.  nullptr: ordered by an event
-    unsigned long long* gp;      // (always set: the ticket is taken by every k_gprep)
-    int gwait;                   // 1: k_strict2 waits for gp[GP_DONE] in the kernel; 0: it is ordered behind k_gprep by an event
+    unsigned long long* gp;
     unsigned long long gp_seq;
     int gp_wait_ticks;
     int gp_acquire;              // 1: a block's first wave runs the agent-scope acquire also when it found the word at once
-    // THE PLAN (more units than the blocks' prologue can plan in LDS, fewer than make the draw worth it): k_gprep's last block -- the one that
-    // takes the last ticket: list and classes are complete -- writes plan[0] = the step's number, plan[1] = the units planned, plan[2 + u] = the
-    // work in front of unit u (exclusive prefix of the units' weights: S2_SETUP_W + its piece pair's classes, 1 for a pair without classes),
-    // plan[2 + n] = all of it.  k_strict2's wave w takes the work [w q, (w + 1) q): whole light units, class RANGES of heavy ones.
-    int* plan;
-    int plan_min;                // units from which a plan is written (below: k_strict2's own `bal` plan in LDS)
 };
 
 #if defined(GRAAL_STAMPS) && defined(GRAAL_S2_COUNTS)   // (work counters: per-lane atomics -- they distort the stamps' timeline)
@@ -44,8 +37,6 @@ struct S2Args {
 
 constexpr int GP_DONE = 32;            // S2Args::gp: [0] k_gprep's ticket, [GP_DONE] its completion word (a line of its own: 512 blocks poll it)
 constexpr int S2_BAL_MAX = 1024;       // units of a step up to which k_strict2 deals its waves to them by their classes
-constexpr int S2_PLAN_MAX = 32767;     // units of a step up to which k_gprep's last block writes the plan (beyond: the waves draw units from a counter)
-constexpr int S2_SETUP_W = 3;          // a unit's set-up (entry, fragments, class records, the current layout's values) in class passes: ~13 us against ~4
 constexpr int GPREP_CLS_BLOCKS = 144;  // blocks of k_gprep that build classes (one wave per piece pair: 561 pairs at most, 576 waves); the rest cull
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -53,9 +44,6 @@ __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlan
 // other XCDs without a write-back of the writer's L2 (__threadfence: a microsecond per block, one after the other) -- like the scan's queue
 __device__ __forceinline__ void st_dev(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_dev(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// device-scope loads: what ANOTHER block of the same kernel wrote with st_dev (this XCD's L2 may hold the line from the last step)
-__device__ __forceinline__ int ld_dev(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ unsigned long long ld_dev(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // old bp extent [lo, hi) of tile t (fragments of ONE global piece, consecutive positions of one contig)
 __device__ __forceinline__ void utile_extent(const USet& U, const int* __restrict__ pstart, int t, int& lo, int& hi, int& g, int& cnt)
@@ -295,52 +283,20 @@ __global__ __launch_bounds__(256) void k_gprep(const NbTables* __restrict__ tabs
     }
     STAMP_MAX(14, t == 0);
     }
-    // "k_gprep is complete": every block waits for its own device-scope stores (and the list's atomic) to be acknowledged and takes a ticket;
-    // the last one puts the ticket back, writes the plan (S2Args::plan) and, for a k_strict2 that waits in the kernel, stores the step's number
-    ATOMICS_DONE();
-    __syncthreads();
-    if (t == 0) {
-        const unsigned long long ticket = atomicAdd(&s2.gp[0], 1ull);
-        s_live = ticket == (unsigned long long)gridDim.x - 1ull ? 1u : 0u;    // (s_live: no longer needed for what it held)
-    }
-    __syncthreads();
-    if (!s_live) return;
-    {
-        const unsigned long long n64 = ld_dev(list_n);
-        const int nu = (int)(n64 < cap ? n64 : cap);
-        const bool want = nu > s2.plan_min && nu <= S2_PLAN_MAX && n64 <= cap;
-        if (want) {
-            // weights (kept in the plan's own words), their sum per thread over a run of consecutive units; a block scan; the running sums
-            const int per = (nu + 255) / 256, u0 = t * per, u1 = min(nu, u0 + per);
-            int sum = 0;
-            for (int u = u0; u < u1; u++) {
-                const int nc = ld_dev(&s2.cls_n[uunit_pair(ld_dev(&list[u]))]);
-                const int w = nc > 0 ? S2_SETUP_W + nc : 1;
-                st_dev(&s2.plan[2 + u], w);
-                sum += w;
-            }
-            s_ne[t] = sum;
-            ATOMICS_DONE();
-            __syncthreads();
-            if (t < 64) wave_excl_scan(s_ne, s_off, 256);
-            __syncthreads();
-            int run = s_off[t];
-            for (int u = u0; u < u1; u++) {
-                const int w = ld_dev(&s2.plan[2 + u]);
-                st_dev(&s2.plan[2 + u], run);
-                run += w;
-            }
-            if (t == 255) st_dev(&s2.plan[2 + nu], s_off[256]);
-        }
-        if (t == 0) { st_dev(&s2.plan[1], want ? nu : -1); st_dev(&s2.plan[0], (int)(unsigned)s2.gp_seq); }
+    if (s2.gp != nullptr) {
+        // "k_gprep is complete": every block waits for its own device-scope stores (and the list's atomic) to be acknowledged and takes a ticket;
+        // the last one puts the ticket back and stores the step's number
         ATOMICS_DONE();
         __syncthreads();
         if (t == 0) {
-            st_dev(&s2.gp[0], 0ull);
-            // (relaxed: a release here is a write-back of this XCD's whole L2 -- 15 us with the step's dirty lines in it -- and nothing needs it: every
-            // block's results are device-scope stores, acknowledged before its ticket; the last ticket is taken behind all of them)
-            if (s2.gwait) st_dev(&s2.gp[GP_DONE], s2.gp_seq);
-            STAMP(24, true);
+            const unsigned long long ticket = atomicAdd(&s2.gp[0], 1ull);
+            if (ticket == (unsigned long long)gridDim.x - 1ull) {
+                st_dev(&s2.gp[0], 0ull);
+                // (relaxed: a release here is a write-back of this XCD's whole L2 -- 15 us with the step's dirty lines in it -- and nothing needs it: every
+                // block's results are device-scope stores, acknowledged before its ticket; the last ticket is taken behind all of them)
+                st_dev(&s2.gp[GP_DONE], s2.gp_seq);
+                STAMP(24, true);
+            }
         }
     }
 }
@@ -426,7 +382,7 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
 #endif
     STAMP(16, blockIdx.x == 0 && threadIdx.x == 0);
     int skip = fa.skip;
-    if (s2.gwait) {
+    if (s2.gp != nullptr) {
         // no event in front of this kernel: k_gprep (on the other stream; launched first, and this grid leaves room for its blocks on every CU)
         // says when the union set, the classes and the unit list are complete.  Bounded: if the two kernels do not run side by side -- a tool
         // that serialises dispatches -- the step ends as failed and the host repeats it behind an event (eval_sync: spin_used)
@@ -529,33 +485,8 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
         if (t == 0) s_pref[nu] = s_boff[256];
         __syncthreads();
     }
-    // More units than that, fewer than the draw wants: THE PLAN k_gprep's last block left (S2Args::plan).  Dealt one after the other -- or drawn,
-    // GRAAL_STRICT_DRAW=1: slower still -- such a step waits for the waves that got the pairs with 30-60 classes: a unit is 13 us of set-up and
-    // ~4 us per class, one wave's chain (C4 stand-in mid-run, 4,830 units: the blocks' wave 0 done after 63 us on average, the last after 124).
-    // Wave w takes the work [w q, (w + 1) q) of the units' weights: light units whole, heavy ones by class RANGES.
-    const int* __restrict__ plan = s2.plan;
-    const bool planned = !(skip & 1) && !bal && mrg == 1 && n_units > 0ull && plan[0] == (int)(unsigned)s2.gp_seq && plan[1] == (int)n_units;
-    const int plan_waves = planned ? (nq_total > 0ull ? n_waves - n_waves / 8 : n_waves) : 0;   // (an eighth of the grid for the queued contacts, as above)
-    const int plan_total = planned ? plan[2 + (int)n_units] : 0;
-    const int plan_q = planned ? (plan_total + plan_waves - 1) / plan_waves : 0;
-    int plan_u = 0;                                                     // the unit this wave is at
-    const int plan_p0 = wave * plan_q, plan_p1 = min(plan_total, plan_p0 + plan_q);
-    if (planned && wave < plan_waves && plan_p0 < plan_total) {
-        // the unit that holds work item p0: the largest u with plan[2 + u] <= p0 (64-ary search: the lanes probe, a ballot picks; the weights are >= 1)
-        int lo = 0, span = (int)n_units;
-        while (span > 1) {
-            const int stride = (span + 63) >> 6, idx = lo + lane * stride;
-            const bool ok = idx < lo + span && plan[2 + idx] <= plan_p0;
-            const unsigned long long b = __ballot(ok);
-            const int l = 63 - __clzll((long long)b);                   // (lane 0 always holds: plan[2 + lo] <= p0)
-            const int nlo = lo + l * stride;
-            span = min(stride, lo + span - nlo);
-            lo = nlo;
-        }
-        plan_u = rfl(lo);
-    }
-    const unsigned long long n_virtual = (skip & 1) ? 0ull : (planned ? (unsigned long long)plan_waves : (bal ? (unsigned long long)s_pref[(int)n_units] :
-                                         ((n_units + (unsigned long long)mrg - 1ull) / (unsigned long long)mrg) * (unsigned long long)rep_n));
+    const unsigned long long n_virtual = (skip & 1) ? 0ull : (bal ? (unsigned long long)s_pref[(int)n_units] :
+                                         ((n_units + (unsigned long long)mrg - 1ull) / (unsigned long long)mrg) * (unsigned long long)rep_n);
     // a wave's first unit is its own number; the others it draws from a counter -- the draw goes out when a unit is started and is read
     // when it is finished (units differ in cost by the classes of their piece pair and by the window: dealt round robin, the waves that
     // got the heavy ones finished a fifth of the kernel after the others)
@@ -566,18 +497,6 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
       if (draw && lane == 0) drawn = atomicAdd(s2.next, 1ull);
       int rep_r = (int)(v & (unsigned long long)(rep_n - 1));                             // (rep_n, mrg: powers of two)
       unsigned long long e0 = (v >> rep_sh) * (unsigned long long)mrg;
-      int c_cap = 0x7fffffff;                                                             // this wave's classes of the unit end here (the plan's ranges)
-      if (planned) {
-          if (plan_p0 >= plan_total) break;
-          // this wave's part of unit plan_u: work items [a, b) of its weight; the first S2_SETUP_W are the set-up (whoever takes a class pays it)
-          const int pr0 = plan[2 + plan_u], pr1 = plan[2 + plan_u + 1];
-          const int a = max(plan_p0 - pr0, 0), b = min(plan_p1, pr1) - pr0;
-          e0 = (unsigned long long)plan_u;
-          rep_r = max(a - S2_SETUP_W, 0); rep_n = 1; c_cap = max(b - S2_SETUP_W, 0);
-          plan_u += 1;
-          if (pr1 >= plan_p1 || plan_u >= (int)n_units) v = n_virtual;                    // (the last unit of this wave's range)
-          if (c_cap <= rep_r) continue;                                                   // (a pair without classes, or only the set-up's items: the next wave's)
-      }
       if (bal) {   // the unit whose waves hold number v
           int lo = 0, hi = (int)n_units - 1;
           while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_pref[mid] <= (int)v) lo = mid; else hi = mid - 1; }
@@ -660,8 +579,7 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
         }
         // is there anything to price?  (a listed unit has, but for the finer extents of its segment)
         bool any = false;
-        const int c_end = min(nc, c_cap);
-        for (int c = rep_r; c < c_end && !any; c += rep_n) {
+        for (int c = rep_r; c < nc && !any; c += rep_n) {
             if (c < c_base || c >= c_base + CLS_CHUNK) stage(c);
             const GClass& cr = cp[c - c_base];
             if (!(cr.w0 | cr.w1 | (unsigned long long)cr.w2)) continue;   // (a class of neighbours priced by the table kernel)
@@ -683,7 +601,7 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
         for (int j = 0; j < cnt; j++)
             if (has_l && stL.n > 0 && tile[j].st.n > 0 && !(diag && !(lane < j0 + j))) vmask |= 1u << j;
         STAMP_FBLK(3, threadIdx.x == 0 && v == (unsigned long long)wave && pos == run);
-        for (int c = -1; c < c_end; c = c < 0 ? rep_r : c + rep_n) {  // c = -1: the current layout (its values are kept in LDS), then this wave's classes
+        for (int c = -1; c < nc; c = c < 0 ? rep_r : c + rep_n) {     // c = -1: the current layout (its values are kept in LDS), then this wave's classes
             bool cis = cis_old;
             int circ = cis_old ? circ_old : 0, lbp = lbp_old, sig_l = 1, sig_s = 1, off_l = 0, off_s = 0;
             unsigned long long m0 = 0, m1 = 0;
@@ -823,8 +741,7 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
         }
       }
       WAVE_LDS_SYNC();
-      if (planned) { }                                                                    // (advanced at the top: v jumps to the end behind the range's last unit)
-      else if (draw) v = (unsigned long long)n_waves + (((unsigned long long)(unsigned)rfl((int)(drawn >> 32)) << 32) | (unsigned long long)(unsigned)rfl((int)drawn));
+      if (draw) v = (unsigned long long)n_waves + (((unsigned long long)(unsigned)rfl((int)(drawn >> 32)) << 32) | (unsigned long long)(unsigned)rfl((int)drawn));
       else v += (unsigned long long)n_waves;
     }
     STAMP_MAX(18, lane == 0);
