@@ -609,36 +609,26 @@ struct Changed {
 // diagonal pixels, kernels3.cu:3356-3380), yet its float32 value moves with the bin's coordinates and with its contig's circular model: it is
 // what separates a candidate's delta from full(after) - full(before) when bins hold several sub-fragments (RF counts uniform or the
 // trans-branch indexing off: tests/test_carried_total_gpu.py).  own[3] = the observed counts of the pairs (0,1), (0,2), (1,2), 0 = none.
-__device__ __forceinline__ long long own_pixel_q(const Rec& r, const Stat& st, const float* __restrict__ own, float nfpb, const Par& par, bool& bad)
+// One lane's part of it: sub-fragment pair `pair` ((0,1), (0,2), (1,2)) of the bin in the layout record r -- its expected value and, rounded to Q, its
+// observed contacts' term (0 without contacts); `valid` = the bin has that pair.
+__device__ __forceinline__ void own_pixel_pair(const Rec& r, const Stat& st, const float* __restrict__ own, int pair, float nfpb, const Par& par,
+                                               bool valid, float& ex, long long& t, bool& bad)
 {
+    ex = 0.0f; t = 0;
+    if (!valid) return;
     End X; X.label = 0; X.start_bp = r.start_bp; X.fwd = r.ori == 1; X.circ = r.circ; X.lbp = r.l_cont_bp;
-    long long q = 0;
-    double acc = 0.0;
-    int pair = 0;
-    for (int a = 0; a < st.n; a++)
-        for (int b = a + 1; b < st.n; b++) {
-            const float ex = ex_pair(X, st, a, X, st, b, nfpb, par);
-            acc += (double)ex;
-            const float ob = own[a == 0 ? b - 1 : 2];
-            if (ob != 0.0f) { const long long t = to_q((double)ob * mm_ln(ex)); if (t == Q_BAD) bad = true; else q += t; }
-            pair++;
-        }
-    (void)pair;
-    const long long m = to_q(acc);
-    if (m == Q_BAD) bad = true; else q -= m;
-    return q;
+    const int a = pair == 2 ? 1 : 0, b = pair == 0 ? 1 : 2;
+    ex = ex_pair(X, st, a, X, st, b, nfpb, par);
+    const float ob = own[pair];
+    if (ob != 0.0f) { t = to_q((double)ob * mm_ln(ex)); if (t == Q_BAD) { bad = true; t = 0; } }
 }
 
 // commit one candidate (test_copy_struct, cuda_lib_gl.py:1156): out = apply_move(in); also records which contigs exist
 // afterwards among the <= 4 labels the move can touch (for the incremental relabel of the next graal_begin_step), and -- it
 // has every new record in registers anyway -- the statistics of the NEW layout, which its last block publishes to pinned host
 // memory: the next graal_begin_step finds them there and needs no statistics kernel.
-template <bool OWN /* the commit's own-pixel correction: only with several sub-fragments per bin (the plain commit is a chain of dependent round
-                      trips on every step's critical path: 6 us at 50,000 fragments, 8.5 with this code merely compiled in) */>
 __global__ __launch_bounds__(256) void k_apply(SoaPtr in, SoaPtr out, int n, int op, int fA, int fB, int max_id, int* __restrict__ n_stale,
-                                               Changed* __restrict__ chg, long long* __restrict__ part,
-                                               const Stat* __restrict__ stat /* nullptr: no own-pixel correction */, const float* __restrict__ own_obs,
-                                               float nfpb, Par par, int quirk /* GRAAL_MODE_REF_TRANS_ACCU */)
+                                               Changed* __restrict__ chg, long long* __restrict__ part)
 {
     STAMP(7, blockIdx.x == 0 && threadIdx.x == 0);
     StatAcc a = stat_zero();
@@ -651,19 +641,6 @@ __global__ __launch_bounds__(256) void k_apply(SoaPtr in, SoaPtr out, int n, int
         const Rec r0 = ld_rec(in, f);
         const Rec r = apply_move(m, f, r0, &stale);
         st_rec(out, f, r);
-        if (OWN && (r.start_bp != r0.start_bp || r.ori != r0.ori || r.circ != r0.circ || (r.circ == 1 && r.l_cont_bp != r0.l_cont_bp))) {
-            // the commit's own-pixel correction: what this move does to the pixels no delta contains (own_pixel_q), summed over the bins it moves
-            const Stat st = stat[f];
-            if (st.n > 1) {
-                // (the trans-branch indexing prices a reversed bin with its LAST RF count, kernels3.cu:3155: mirroring a bin whose sub-fragments
-                // carry different counts also changes its trans pixels with every bin OUTSIDE the two contigs -- in no delta, not an own pixel:
-                // this commit's correction is unknown and the step that follows evaluates the layout in full)
-                bool bad = quirk && r.ori != r0.ori && !stat_uniform(st);
-                const float* own = own_obs + 3 * (size_t)r.id_d;
-                const long long qn = own_pixel_q(r, st, own, nfpb, par, bad), qo = own_pixel_q(r0, st, own, nfpb, par, bad);
-                if (bad) a.v[10] += 1; else a.v[9] += qn - qo;
-            }
-        }
         if (stale) atomicAdd(n_stale, 1);
         if (f == 0) { chg->cA = A0.id_c; chg->cB = B0.id_c; chg->lab[0] = A0.id_c; chg->lab[1] = B0.id_c; chg->lab[2] = max_id + 1; chg->lab[3] = max_id + 2; }
         if (r.pos == 0) {
@@ -677,6 +654,68 @@ __global__ __launch_bounds__(256) void k_apply(SoaPtr in, SoaPtr out, int n, int
     // the relabel and the whole next step; now the rows go to the relabel kernel, whose block 0 publishes them next to its own work)
     stat_block_partials(a, part);
     STAMP(15, blockIdx.x == gridDim.x - 1 && threadIdx.x == 0);
+}
+
+// The commit WITH its own-pixel correction (several sub-fragments per bin: graal_take_carry_correction).  Eight lanes per fragment: every lane
+// derives the fragment's new record (the loads coalesce), lane 0 of the eight commits it and counts the statistics like k_apply; lanes 0-2 price
+// the bin's three sub-fragment pairs in the NEW layout, lanes 3-5 in the OLD one -- one evaluation deep instead of six in one thread (13.9 us per
+// commit at the C2 shape that way, on every step's critical path, against 6 for the plain commit) --; the mass of a side is the float64 sum of its
+// pairs' expected values in the full evaluation's order (0,1), (0,2), (1,2), rounded to Q once (k_full_mass's own-pair term), gathered by shuffles.
+// A's pixel = sum of its pairs' observed terms - that mass; the correction = new - old, summed over the eight lanes.
+__global__ __launch_bounds__(256) void k_apply_own(SoaPtr in, SoaPtr out, int n, int op, int fA, int fB, int max_id, int* __restrict__ n_stale,
+                                                   Changed* __restrict__ chg, long long* __restrict__ part, const Stat* __restrict__ stat,
+                                                   const float* __restrict__ own_obs, float nfpb, Par par, int quirk /* GRAAL_MODE_REF_TRANS_ACCU, mixed RF counts exist */)
+{
+    StatAcc a = stat_zero();
+    const Rec A0 = ld_rec(in, fA), B0 = ld_rec(in, fB);
+    const Move m = make_move(op, fA, fB, max_id, A0, B0);
+    const int lane = threadIdx.x & 63, sub = lane & 7, oct = lane & ~7;
+    const int per_pass = (int)((gridDim.x * blockDim.x) >> 3);
+    // (whole octets run the loop together: the shuffles below need all eight lanes of a fragment, so the bound is on the octet's fragment alone)
+    for (int f = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 3); f < n; f += per_pass) {
+        bool stale;
+        const Rec r0 = ld_rec(in, f);
+        const Rec r = apply_move(m, f, r0, &stale);
+        if (sub == 0) st_rec(out, f, r);
+        const bool changed = r.start_bp != r0.start_bp || r.ori != r0.ori || r.circ != r0.circ || (r.circ == 1 && r.l_cont_bp != r0.l_cont_bp);
+        const Stat st = stat[f];
+        if (changed && st.n > 1) {   // (octet-uniform)
+            // (the trans-branch indexing prices a reversed bin with its LAST RF count, kernels3.cu:3155: mirroring a bin whose sub-fragments
+            // carry different counts also changes its trans pixels with every bin OUTSIDE the two contigs -- in no delta, not an own pixel:
+            // this commit's correction is unknown and the step that follows evaluates the layout in full)
+            bool bad = quirk && r.ori != r0.ori && !stat_uniform(st);
+            const int pair = sub % 3, side = sub / 3;                 // side 0: the new record, 1: the old one; lanes 6, 7: nothing
+            const bool valid = sub < 6 && (pair == 0 || st.n > 2);
+            float ex; long long t;
+            own_pixel_pair(side == 0 ? r : r0, st, own_obs + 3 * (size_t)r.id_d, pair, nfpb, par, valid, ex, t, bad);
+            // the side's mass: its pairs' expected values summed in float64 in the full evaluation's order, rounded once -- by the side's first lane
+            const int base = oct + 3 * (sub < 3 ? 0 : 1);
+            const float e0 = __shfl(ex, base, 64), e1 = __shfl(ex, base + 1, 64), e2 = __shfl(ex, base + 2, 64);
+            long long c = side == 0 ? t : -t;
+            if (sub == 0 || sub == 3) {
+                double acc = 0.0;
+                acc += (double)e0;
+                if (st.n > 2) { acc += (double)e1; acc += (double)e2; }
+                const long long mq = to_q(acc);
+                if (mq == Q_BAD) bad = true; else c += sub == 0 ? -mq : mq;
+            }
+            if (sub >= 6) c = 0;
+            for (int o = 1; o < 8; o <<= 1) c += __shfl_xor(c, o, 64);
+            const unsigned any_bad = (unsigned)((__ballot(bad) >> oct) & 0xffull);
+            if (sub == 0) { if (any_bad) a.v[10] += 1; else a.v[9] += c; }
+        }
+        if (sub == 0) {
+            if (stale) atomicAdd(n_stale, 1);
+            if (f == 0) { chg->cA = A0.id_c; chg->cB = B0.id_c; chg->lab[0] = A0.id_c; chg->lab[1] = B0.id_c; chg->lab[2] = max_id + 1; chg->lab[3] = max_id + 2; }
+            if (r.pos == 0) {
+                const int c = r.id_c;
+                const int j = c == A0.id_c ? 0 : (c == B0.id_c ? 1 : (c == max_id + 1 ? 2 : (c == max_id + 2 ? 3 : -1)));
+                if (j >= 0) { chg->len[j] = r.l_cont; chg->exists[j] = 1; }
+            }
+            stat_add(a, f, r.pos, r.l_cont, r.start_bp, r.l_cont_bp, r.rep, r.activ, r.id_d, r.id_c, r.circ);
+        }
+    }
+    stat_block_partials(a, part);
 }
 
 // ---- incremental relabel.  Invariant after every graal_begin_step: labels ARE ranks (contigs sorted by (l_cont, label)),
@@ -6347,12 +6386,12 @@ int graal_apply_move(graal_ctx* h, int32_t fA, int32_t fB, int32_t op, int32_t m
     h->apply_blocks = std::min(blocks_for(h->n, 256), std::max(1, std::min(apply_blocks_env, 1024)));
     const bool own_on = !h->single_sub && !h->has_rep && h->d_own_obs != nullptr && h->stat_frag != nullptr && h->have_par &&
                         !h->x_host && !(h->nccl_comm && h->n_world > 1);
-    if (own_on)
-        k_apply<true><<<h->apply_blocks, 256, 0, h->stream>>>(h->soa[h->cur], h->soa[1 - h->cur], h->n, op, fA, fB, max_id, d_stale, h->d_chg + h->chg_w, h->d_part,
-                                                              h->stat_frag, h->d_own_obs, h->nfpb, h->par, (h->mode & GRAAL_MODE_REF_TRANS_ACCU) && !h->all_uniform ? 1 : 0);
-    else
-        k_apply<false><<<h->apply_blocks, 256, 0, h->stream>>>(h->soa[h->cur], h->soa[1 - h->cur], h->n, op, fA, fB, max_id, d_stale, h->d_chg + h->chg_w, h->d_part,
-                                                               nullptr, nullptr, h->nfpb, h->par, 0);
+    if (own_on) {
+        h->apply_blocks = std::min(blocks_for(h->n * 8, 256), 1024);   // (eight lanes per fragment; d_part holds 1,024 rows)
+        k_apply_own<<<h->apply_blocks, 256, 0, h->stream>>>(h->soa[h->cur], h->soa[1 - h->cur], h->n, op, fA, fB, max_id, d_stale, h->d_chg + h->chg_w, h->d_part,
+                                                            h->stat_frag, h->d_own_obs, h->nfpb, h->par, (h->mode & GRAAL_MODE_REF_TRANS_ACCU) && !h->all_uniform ? 1 : 0);
+    } else
+        k_apply<<<h->apply_blocks, 256, 0, h->stream>>>(h->soa[h->cur], h->soa[1 - h->cur], h->n, op, fA, fB, max_id, d_stale, h->d_chg + h->chg_w, h->d_part);
     h->apply_had_own = own_on;
     h->chg_last = h->chg_w; h->chg_w ^= 1;
     CK(hipGetLastError());
