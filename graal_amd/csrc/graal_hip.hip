@@ -373,9 +373,9 @@ __global__ void k_mates(int n, const int* __restrict__ perm, const int* __restri
 //      [5] min l_cont [6] #(rep != 0 or activ != 1 or id_d != f)  [7] max label  [14] #(circ == 1)
 constexpr int NC_WORD = 29;   // d_scalars[NC_WORD]: number of contigs of the ranked layout (= max_id + 1), kept on the device so that the
                               // scoring kernels can be launched before the host has read the statistics
-constexpr int N_STAT = 11;
-struct StatAcc { long long v[11]; }; // heads, sum l_cont, #start0, sum lbp, max, min, bad, max label, #circ; [9] the commit's own-pixel correction (Q), [10] its bad terms
-__device__ __forceinline__ StatAcc stat_zero() { StatAcc a = {{0, 0, 0, 0, 0, 0x7fffffff, 0, -1, 0, 0, 0}}; return a; }
+constexpr int N_STAT = 9;
+struct StatAcc { long long v[9]; }; // heads, sum l_cont, #start0, sum lbp, max, min, bad, max label, #circ
+__device__ __forceinline__ StatAcc stat_zero() { StatAcc a = {{0, 0, 0, 0, 0, 0x7fffffff, 0, -1, 0}}; return a; }
 __device__ __forceinline__ void stat_add(StatAcc& a, int f, int pos, int lc, int start_bp, int lbp, int rep, int activ, int id_d, int c, int circ)
 {
     a.v[0] += pos == 0;
@@ -656,66 +656,73 @@ __global__ __launch_bounds__(256) void k_apply(SoaPtr in, SoaPtr out, int n, int
     STAMP(15, blockIdx.x == gridDim.x - 1 && threadIdx.x == 0);
 }
 
-// The commit WITH its own-pixel correction (several sub-fragments per bin: graal_take_carry_correction).  Eight lanes per fragment: every lane
-// derives the fragment's new record (the loads coalesce), lane 0 of the eight commits it and counts the statistics like k_apply; lanes 0-2 price
-// the bin's three sub-fragment pairs in the NEW layout, lanes 3-5 in the OLD one -- one evaluation deep instead of six in one thread (13.9 us per
-// commit at the C2 shape that way, on every step's critical path, against 6 for the plain commit) --; the mass of a side is the float64 sum of its
-// pairs' expected values in the full evaluation's order (0,1), (0,2), (1,2), rounded to Q once (k_full_mass's own-pair term), gathered by shuffles.
-// A's pixel = sum of its pairs' observed terms - that mass; the correction = new - old, summed over the eight lanes.
-__global__ __launch_bounds__(256) void k_apply_own(SoaPtr in, SoaPtr out, int n, int op, int fA, int fB, int max_id, int* __restrict__ n_stale,
-                                                   Changed* __restrict__ chg, long long* __restrict__ part, const Stat* __restrict__ stat,
-                                                   const float* __restrict__ own_obs, float nfpb, Par par, int quirk /* GRAAL_MODE_REF_TRANS_ACCU, mixed RF counts exist */)
+// The commit's OWN-PIXEL CORRECTION (several sub-fragments per bin: graal_take_carry_correction), next to the commit on a stream of its own:
+// nobody needs it before the NEXT step forms its scores, and inside the commit kernel it was 7 us of every step's critical path (the
+// sub-fragment centres, the contact model, a float64 logarithm: 13 us per commit at the C2 shape against 6 for the plain commit).  It reads the
+// layout the commit reads and derives every fragment's new record itself (apply_move: registers only).  Eight lanes per fragment: lanes 0-2 price
+// the bin's three sub-fragment pairs in the NEW layout, lanes 3-5 in the OLD one; the mass of a side is the float64 sum of its pairs' expected
+// values in the full evaluation's order (0,1), (0,2), (1,2), rounded to Q once (k_full_mass's own-pair term), gathered by shuffles.  A bin's pixel
+// = its pairs' observed terms - that mass; the correction = new - old.  Block sums by atomics, the last block (a ticket) publishes
+// {sum, unknown terms} and the commit's number to pinned host memory and re-arms the words.
+__global__ __launch_bounds__(256) void k_own_corr(SoaPtr in, int n, int op, int fA, int fB, int max_id, const Stat* __restrict__ stat,
+                                                  const float* __restrict__ own_obs, float nfpb, Par par, int quirk /* GRAAL_MODE_REF_TRANS_ACCU, mixed RF counts exist */,
+                                                  long long* __restrict__ acc /* [0] sum, [1] unknown, [2] ticket */, volatile long long* host, long long seq)
 {
-    StatAcc a = stat_zero();
     const Rec A0 = ld_rec(in, fA), B0 = ld_rec(in, fB);
     const Move m = make_move(op, fA, fB, max_id, A0, B0);
     const int lane = threadIdx.x & 63, sub = lane & 7, oct = lane & ~7;
     const int per_pass = (int)((gridDim.x * blockDim.x) >> 3);
-    // (whole octets run the loop together: the shuffles below need all eight lanes of a fragment, so the bound is on the octet's fragment alone)
+    long long my_q = 0, my_bad = 0;
+    // (whole octets run the loop together: the shuffles below need all eight lanes of a fragment, and the bound is on the octet's fragment alone)
     for (int f = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 3); f < n; f += per_pass) {
         bool stale;
         const Rec r0 = ld_rec(in, f);
         const Rec r = apply_move(m, f, r0, &stale);
-        if (sub == 0) st_rec(out, f, r);
         const bool changed = r.start_bp != r0.start_bp || r.ori != r0.ori || r.circ != r0.circ || (r.circ == 1 && r.l_cont_bp != r0.l_cont_bp);
+        if (!changed) continue;
         const Stat st = stat[f];
-        if (changed && st.n > 1) {   // (octet-uniform)
-            // (the trans-branch indexing prices a reversed bin with its LAST RF count, kernels3.cu:3155: mirroring a bin whose sub-fragments
-            // carry different counts also changes its trans pixels with every bin OUTSIDE the two contigs -- in no delta, not an own pixel:
-            // this commit's correction is unknown and the step that follows evaluates the layout in full)
-            bool bad = quirk && r.ori != r0.ori && !stat_uniform(st);
-            const int pair = sub % 3, side = sub / 3;                 // side 0: the new record, 1: the old one; lanes 6, 7: nothing
-            const bool valid = sub < 6 && (pair == 0 || st.n > 2);
-            float ex; long long t;
-            own_pixel_pair(side == 0 ? r : r0, st, own_obs + 3 * (size_t)r.id_d, pair, nfpb, par, valid, ex, t, bad);
-            // the side's mass: its pairs' expected values summed in float64 in the full evaluation's order, rounded once -- by the side's first lane
-            const int base = oct + 3 * (sub < 3 ? 0 : 1);
-            const float e0 = __shfl(ex, base, 64), e1 = __shfl(ex, base + 1, 64), e2 = __shfl(ex, base + 2, 64);
-            long long c = side == 0 ? t : -t;
-            if (sub == 0 || sub == 3) {
-                double acc = 0.0;
-                acc += (double)e0;
-                if (st.n > 2) { acc += (double)e1; acc += (double)e2; }
-                const long long mq = to_q(acc);
-                if (mq == Q_BAD) bad = true; else c += sub == 0 ? -mq : mq;
-            }
-            if (sub >= 6) c = 0;
-            for (int o = 1; o < 8; o <<= 1) c += __shfl_xor(c, o, 64);
-            const unsigned any_bad = (unsigned)((__ballot(bad) >> oct) & 0xffull);
-            if (sub == 0) { if (any_bad) a.v[10] += 1; else a.v[9] += c; }
+        if (st.n < 2) continue;                                       // (octet-uniform, like `changed`)
+        // (the trans-branch indexing prices a reversed bin with its LAST RF count, kernels3.cu:3155: mirroring a bin whose sub-fragments
+        // carry different counts also changes its trans pixels with every bin OUTSIDE the two contigs -- in no delta, not an own pixel:
+        // this commit's correction is unknown and the step that follows evaluates the layout in full)
+        bool bad = quirk && r.ori != r0.ori && !stat_uniform(st);
+        const int pair = sub % 3, side = sub / 3;                     // side 0: the new record, 1: the old one; lanes 6, 7: nothing
+        const bool valid = sub < 6 && (pair == 0 || st.n > 2);
+        float ex; long long t;
+        own_pixel_pair(side == 0 ? r : r0, st, own_obs + 3 * (size_t)r.id_d, pair, nfpb, par, valid, ex, t, bad);
+        const int base = oct + 3 * (sub < 3 ? 0 : 1);
+        const float e0 = __shfl(ex, base, 64), e1 = __shfl(ex, base + 1, 64), e2 = __shfl(ex, base + 2, 64);
+        long long c = sub >= 6 ? 0ll : (side == 0 ? t : -t);
+        if (sub == 0 || sub == 3) {                                   // the side's mass, by its first lane
+            double mass = 0.0;
+            mass += (double)e0;
+            if (st.n > 2) { mass += (double)e1; mass += (double)e2; }
+            const long long mq = to_q(mass);
+            if (mq == Q_BAD) bad = true; else c += sub == 0 ? -mq : mq;
         }
-        if (sub == 0) {
-            if (stale) atomicAdd(n_stale, 1);
-            if (f == 0) { chg->cA = A0.id_c; chg->cB = B0.id_c; chg->lab[0] = A0.id_c; chg->lab[1] = B0.id_c; chg->lab[2] = max_id + 1; chg->lab[3] = max_id + 2; }
-            if (r.pos == 0) {
-                const int c = r.id_c;
-                const int j = c == A0.id_c ? 0 : (c == B0.id_c ? 1 : (c == max_id + 1 ? 2 : (c == max_id + 2 ? 3 : -1)));
-                if (j >= 0) { chg->len[j] = r.l_cont; chg->exists[j] = 1; }
-            }
-            stat_add(a, f, r.pos, r.l_cont, r.start_bp, r.l_cont_bp, r.rep, r.activ, r.id_d, r.id_c, r.circ);
+        for (int o = 1; o < 8; o <<= 1) c += __shfl_xor(c, o, 64);
+        const unsigned any_bad = (unsigned)((__ballot(bad) >> oct) & 0xffull);
+        if (sub == 0) { if (any_bad) my_bad += 1; else my_q += c; }
+    }
+    const long long wq = wave_sum_ll(my_q), wb = wave_sum_ll(my_bad);
+    if (lane == 0) {
+        if (wq != 0) atomicAdd((unsigned long long*)&acc[0], (unsigned long long)wq);
+        if (wb != 0) atomicAdd((unsigned long long*)&acc[1], (unsigned long long)wb);
+    }
+    ATOMICS_DONE();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long ticket = atomicAdd((unsigned long long*)&acc[2], 1ull);
+        if (ticket == (unsigned long long)gridDim.x - 1ull) {
+            // (device-scope atomic reads: the other blocks' atomics were performed at the memory side)
+            host[1] = (long long)atomicExch((unsigned long long*)&acc[0], 0ull);
+            host[2] = (long long)atomicExch((unsigned long long*)&acc[1], 0ull);
+            atomicExch((unsigned long long*)&acc[2], 0ull);
+            __threadfence_system();
+            host[0] = seq;
+            __threadfence_system();
         }
     }
-    stat_block_partials(a, part);
 }
 
 // ---- incremental relabel.  Invariant after every graal_begin_step: labels ARE ranks (contigs sorted by (l_cont, label)),
@@ -746,7 +753,7 @@ __device__ __forceinline__ void publish_partials(const long long* __restrict__ p
                 const long long y = __shfl_down(x, o, 64);
                 x = (i == 4 || i == 7) ? (y > x ? y : x) : (i == 5 ? (y < x ? y : x) : x + y);
             }
-            if (u == 0) host[1 + (i < 8 ? i : (i == 8 ? 14 : (i == 9 ? 15 : 8)))] = x;   // ([9] -> word 15, [10] -> word 8: the commit's own-pixel correction and its bad terms)
+            if (u == 0) host[1 + (i < 8 ? i : 14)] = x;
         }
         if (u == 0) host[1 + 13] = stale;
         // (words 9..12 of the host block are not statistics: nobody reads them)
@@ -4315,6 +4322,10 @@ struct Ctx {
     int corr_src = 0;                // the statistics in flight come from: 1 = exactly one commit (k_apply's rows), 2 = no change, 0 = neither (unknown)
     long long carry_q = 0;
     bool carry_bad = false;
+    long long* d_own_acc = nullptr;  // k_own_corr: [0] sum, [1] unknown terms, [2] ticket
+    long long* h_own = nullptr;      // pinned host: [0] the commit's number, [1] its correction (Q), [2] its unknown terms
+    long long own_seq = 0;
+    bool own_pending = false;        // a correction kernel is out and its result has not been taken from h_own
     bool corr_inflight = false;      // between begin_step_launch and begin_step_collect
     bool corr_skip = false;          // the caller holds a full evaluation of the layout whose commit has not been relabelled yet: its correction is void
     bool full_rep_sharded = false; // the full evaluation in flight dealt the repeated bins' pixels to the ranks (full_launch -> full_collect)
@@ -4991,6 +5002,28 @@ static int wait_stats(Ctx* h, long long res[16])
     return GRAAL_OK;
 }
 
+// the last commit's own-pixel correction (k_own_corr, on the full evaluation's stream): published long before anybody asks
+static int wait_own(Ctx* h, long long* q, long long* bad)
+{
+    if (!h->own_pending) { if (q) *q = 0; if (bad) *bad = 1; return GRAAL_OK; }   // (nothing out: unknown)
+    volatile long long* p = h->h_own;
+    bool seen = false;
+    for (long long spin = 0; spin < 400000000ll; spin++) {
+        if (p[0] == h->own_seq) { seen = true; break; }
+        if ((spin & 0xfffff) == 0xfffff && hipStreamQuery(h->fstream) != hipErrorNotReady) { seen = (p[0] == h->own_seq); break; }
+        __builtin_ia32_pause();
+    }
+    if (!seen) {
+        CK(hipStreamSynchronize(h->fstream));
+        if (p[0] != h->own_seq) return fail(h, GRAAL_E_HIP, "the commit's own-pixel correction was not published");
+    }
+    __sync_synchronize();
+    if (q) *q = p[1];
+    if (bad) *bad = p[2];
+    h->own_pending = false;
+    return GRAAL_OK;
+}
+
 static int fetch_stats(Ctx* h, long long res[16], bool reset_stale)
 {
     h->stats_seq += 1;
@@ -5119,6 +5152,10 @@ int graal_create(int device, graal_ctx** out)
     memset(h->h_full, 0, 8 * sizeof(long long));
     CK(hipHostMalloc((void**)&h->h_stats, 17 * sizeof(long long), hipHostMallocDefault));
     memset(h->h_stats, 0, 17 * sizeof(long long));
+    CK(hipHostMalloc((void**)&h->h_own, 4 * sizeof(long long), hipHostMallocDefault));
+    memset(h->h_own, 0, 4 * sizeof(long long));
+    CK(hipMalloc(&h->d_own_acc, 4 * sizeof(long long)));
+    CK(hipMemset(h->d_own_acc, 0, 4 * sizeof(long long)));
     {
         const long long init[8] = {0, 0, 0, 0, 0, 0x7fffffff, 0, -1}; // k_stats accumulators (re-armed by k_stats_fin)
         CK(hipMemcpy(h->d_scalars, init, sizeof init, hipMemcpyHostToDevice));
@@ -5154,6 +5191,8 @@ void graal_destroy(graal_ctx* h)
         if (h->x_host) (void)hipHostUnregister(h->x_host);
         if (h->h_res) (void)hipHostFree(h->h_res);
         if (h->h_stats) (void)hipHostFree(h->h_stats);
+        if (h->h_own) (void)hipHostFree(h->h_own);
+        if (h->d_own_acc) (void)hipFree(h->d_own_acc);
         if (h->h_full) (void)hipHostFree(h->h_full);
         if (h->h_dist) (void)hipHostFree(h->h_dist);
         for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
@@ -5431,6 +5470,7 @@ int graal_upload_contacts_f32(graal_ctx* h, const int32_t* row, const int32_t* c
 int graal_upload_frags(graal_ctx* h, const int32_t* const soa[GRAAL_N_FIELDS], int32_t n)
 {
     if (h && h->stream) (void)hipStreamSynchronize(h->stream); // (graal_begin_step may have left its relabel kernels running)
+    if (h && h->fstream) (void)hipStreamSynchronize(h->fstream); // (... and the last commit its own-pixel correction, which reads the layout)
     if (!h || !soa || n <= 0) return GRAAL_E_ARG;
     if (!h->have_sub) return fail(h, GRAAL_E_STATE, "upload_subfrags first");
     if (n != h->n_bins && !h->has_rep) return fail(h, GRAAL_E_STATE, "n differs from the number of bins: upload the repeats (graal_upload_repeats) first");
@@ -5651,7 +5691,11 @@ static int begin_step_collect(graal_ctx* h, int64_t stats[8], int32_t* max_id)
     if (res[6] != 0 && !h->has_rep) return fail(h, GRAAL_E_STATE, "corrupt layout: rep / activ / id_d changed without repeats");
     h->n_contigs = nc; h->order_valid = true; h->ranks_valid = true; h->pending_commits = 0; h->incr_ok = false;
     // the commit's own-pixel correction rides on the statistics of the layout it produced
-    if (h->corr_src == 1) { if (res[8] != 0) h->carry_bad = true; else h->carry_q += res[15]; }
+    if (h->corr_src == 1) {
+        long long cq = 0, cb = 0;
+        { const int rc = wait_own(h, &cq, &cb); if (rc) return rc; }
+        if (cb != 0) h->carry_bad = true; else h->carry_q += cq;
+    }
     else if (h->corr_src == 0) h->carry_bad = true;    // (a layout that is not one commit away from the last one: the correction is unknown)
     h->corr_src = 2; h->corr_inflight = false;
     h->max_lcont = (int)res[4];
@@ -6386,12 +6430,19 @@ int graal_apply_move(graal_ctx* h, int32_t fA, int32_t fB, int32_t op, int32_t m
     h->apply_blocks = std::min(blocks_for(h->n, 256), std::max(1, std::min(apply_blocks_env, 1024)));
     const bool own_on = !h->single_sub && !h->has_rep && h->d_own_obs != nullptr && h->stat_frag != nullptr && h->have_par &&
                         !h->x_host && !(h->nccl_comm && h->n_world > 1);
+    // (the layout the last correction kernel reads is the buffer THIS commit writes: it has published long ago -- the host collected it with the
+    // step's statistics -- unless the caller commits without stepping; then wait here)
+    if (h->own_pending) { const int rc = wait_own(h, nullptr, nullptr); if (rc) return rc; }
+    k_apply<<<h->apply_blocks, 256, 0, h->stream>>>(h->soa[h->cur], h->soa[1 - h->cur], h->n, op, fA, fB, max_id, d_stale, h->d_chg + h->chg_w, h->d_part);
     if (own_on) {
-        h->apply_blocks = std::min(blocks_for(h->n * 8, 256), 1024);   // (eight lanes per fragment; d_part holds 1,024 rows)
-        k_apply_own<<<h->apply_blocks, 256, 0, h->stream>>>(h->soa[h->cur], h->soa[1 - h->cur], h->n, op, fA, fB, max_id, d_stale, h->d_chg + h->chg_w, h->d_part,
-                                                            h->stat_frag, h->d_own_obs, h->nfpb, h->par, (h->mode & GRAAL_MODE_REF_TRANS_ACCU) && !h->all_uniform ? 1 : 0);
-    } else
-        k_apply<<<h->apply_blocks, 256, 0, h->stream>>>(h->soa[h->cur], h->soa[1 - h->cur], h->n, op, fA, fB, max_id, d_stale, h->d_chg + h->chg_w, h->d_part);
+        // (on the full evaluation's stream -- idle but for the rare resyncs --, next to the commit: it reads what the commit reads, and the host has
+        // seen this step's scores, so everything that wrote that layout is complete)
+        h->own_seq += 1;
+        k_own_corr<<<std::min(blocks_for(h->n * 8, 256), 1024), 256, 0, h->fstream>>>(h->soa[h->cur], h->n, op, fA, fB, max_id, h->stat_frag, h->d_own_obs, h->nfpb, h->par,
+                                                                                     (h->mode & GRAAL_MODE_REF_TRANS_ACCU) && !h->all_uniform ? 1 : 0,
+                                                                                     h->d_own_acc, h->h_own, h->own_seq);
+        h->own_pending = true;
+    }
     h->apply_had_own = own_on;
     h->chg_last = h->chg_w; h->chg_w ^= 1;
     CK(hipGetLastError());

@@ -217,9 +217,9 @@ int graal_last_counters(graal_ctx* h, int64_t out[4]);
 /* What the commits since the last call did to the pixels NO candidate delta contains: with several sub-fragments per bin the reference's
  * sub_compute_likelihood revisits the pixels between DIFFERENT bins of contig(A) u contig(B) only (kernels3.cu:3356-3380), while a bin's
  * own pixel -- its sub-fragment pairs, evaluate_likelihood's on_diag pixels (:3213) -- moves with the bin's float32 coordinates and with its
- * contig's circular model.  The commit kernel computes that difference for the bins it moves (same terms, same roundings as the full
- * evaluation), it rides on the layout statistics, and *q_out (Q: value x 2^30) is its sum over the graal_begin_step calls since the last
- * take:  score of the accepted candidate + *q_out / 2^30 == the full likelihood of the committed layout (to the rounding of one term per
+ * contig's circular model.  A kernel next to the commit (k_own_corr, on a stream of its own) computes that difference for the bins the
+ * commit moves (same terms, same roundings as the full evaluation), graal_begin_step collects it with the layout statistics, and *q_out
+ * (Q: value x 2^30) is its sum over the graal_begin_step calls since the last take:  score of the accepted candidate + *q_out / 2^30 == the full likelihood of the committed layout (to the rounding of one term per
  * pair), without repeats.  *valid_out = 0: unknown -- a layout that is not one commit away from the last one, a term out of range,
  * repeats, a sharded list, or, with the trans-branch indexing (GRAAL_MODE_REF_TRANS_ACCU), a commit that mirrored a bin whose
  * sub-fragments carry different RF counts (that also changes the bin's trans pixels with every bin outside the two contigs) --: evaluate
