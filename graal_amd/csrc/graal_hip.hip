@@ -4326,6 +4326,8 @@ struct Ctx {
     long long* h_own = nullptr;      // pinned host: [0] the commit's number, [1] its correction (Q), [2] its unknown terms
     long long own_seq = 0;
     bool own_pending = false;        // a correction kernel is out and its result has not been taken from h_own
+    bool carry_wanted = false;       // somebody takes the corrections (graal_take_carry_correction was called): only then are they computed
+    bool own_complete = false;       // d_own_obs was handed in by the caller (graal_upload_own_obs): it covers the WHOLE contact list, not this rank's shard
     bool corr_inflight = false;      // between begin_step_launch and begin_step_collect
     bool corr_skip = false;          // the caller holds a full evaluation of the layout whose commit has not been relabelled yet: its correction is void
     bool full_rep_sharded = false; // the full evaluation in flight dealt the repeated bins' pixels to the ranks (full_launch -> full_collect)
@@ -5445,6 +5447,7 @@ static int upload_contacts_impl(graal_ctx* h, const int32_t* row, const int32_t*
         CK(hipMalloc(&h->d_own_obs, sizeof(float) * own.size()));
         CK(hipMemcpy(h->d_own_obs, own.data(), sizeof(float) * own.size(), hipMemcpyHostToDevice));
     }
+    h->own_complete = false;
     h->carry_q = 0; h->carry_bad = true;   // (whatever was pending belonged to another problem)
     return sync_args(h);
 }
@@ -6428,8 +6431,11 @@ int graal_apply_move(graal_ctx* h, int32_t fA, int32_t fB, int32_t op, int32_t m
     // words, the stores -- and no longer pays atomics per block, so more, shorter blocks win: 12.4 -> ~6 us at 50k fragments)
     static const int apply_blocks_env = getenv("GRAAL_APPLY_BLOCKS") ? atoi(getenv("GRAAL_APPLY_BLOCKS")) : 256;
     h->apply_blocks = std::min(blocks_for(h->n, 256), std::max(1, std::min(apply_blocks_env, 1024)));
+    // (several ranks: a rank's own table covers its shard of the list only -- unless the caller handed in the whole one, graal_upload_own_obs:
+    // then every rank computes the same correction and nothing has to be exchanged; with an RCCL communicator of several ranks a repair could
+    // not be exchanged inside the step: not offered)
     const bool own_on = !h->single_sub && !h->has_rep && h->d_own_obs != nullptr && h->stat_frag != nullptr && h->have_par &&
-                        !h->x_host && !(h->nccl_comm && h->n_world > 1);
+                        (h->own_complete || !h->x_host) && !(h->nccl_comm && h->n_world > 1) && h->carry_wanted;
     // (the layout the last correction kernel reads is the buffer THIS commit writes: it has published long ago -- the host collected it with the
     // step's statistics -- unless the caller commits without stepping; then wait here)
     if (h->own_pending) { const int rc = wait_own(h, nullptr, nullptr); if (rc) return rc; }
@@ -6604,15 +6610,32 @@ int graal_last_counters(graal_ctx* h, int64_t out[4])
     return GRAAL_OK;
 }
 
+int graal_upload_own_obs(graal_ctx* h, const float* own, int32_t n_bins)
+{
+    if (!h || !own) return GRAAL_E_ARG;
+    if (!h->have_sub || !h->have_contacts) return fail(h, GRAAL_E_STATE, "graal_upload_own_obs: upload sub-fragments and contacts first");
+    if (n_bins != h->n_bins) return fail(h, GRAAL_E_ARG, "graal_upload_own_obs: one row of three counts per bin");
+    if (h->single_sub || h->has_rep) return GRAAL_OK;      // (no own pixels to correct / not carried with repeats)
+    CK(hipSetDevice(h->device));
+    if (h->fstream) CK(hipStreamSynchronize(h->fstream));   // (a correction kernel may be reading the old table)
+    if (!h->d_own_obs) CK(hipMalloc(&h->d_own_obs, sizeof(float) * 3 * (size_t)n_bins));
+    CK(hipMemcpy(h->d_own_obs, own, sizeof(float) * 3 * (size_t)n_bins, hipMemcpyHostToDevice));
+    h->own_complete = true;
+    h->carry_q = 0; h->carry_bad = true;
+    return GRAAL_OK;
+}
+
 int graal_take_carry_correction(graal_ctx* h, int64_t* q_out, int32_t* valid_out)
 {
     if (!h) return GRAAL_E_ARG;
     if (!q_out || !valid_out) {   // discard: the caller evaluated the current layout in full -- the commits up to it are accounted for
         if (h->corr_inflight) h->corr_src = 2;
         else if (h->pending_commits > 0) h->corr_skip = true;
+        h->carry_wanted = true;      // (a caller that anchors its total means to carry it)
     } else {
         *q_out = h->carry_bad ? 0 : h->carry_q;
-        *valid_out = h->carry_bad ? 0 : 1;
+        *valid_out = (h->carry_bad || !h->carry_wanted) ? 0 : 1;
+        h->carry_wanted = true;      // (from the next commit on the corrections are computed: nobody pays for them who never asks)
     }
     h->carry_q = 0; h->carry_bad = false;
     return GRAAL_OK;

@@ -286,14 +286,17 @@ static int hs_finish(graal_ctx* h, MtState* mt, double likelihood_t, int want_di
         // of range -- is replaced by the evaluation itself.
         int64_t cq = 0;
         int32_t cv = 0;
-        (void)graal_take_carry_correction(h, &cq, &cv);
+        if (carry_corr) (void)graal_take_carry_correction(h, &cq, &cv);
         if (carry_corr && !full_inside) {
             if (cv) likelihood_t += (double)cq / Q_SCALE;
             else {
                 int64_t fq[2];
                 h->rc_carry_repairs += 1;
-                const int rc = graal_eval_full_q(h, fq);
+                int rc = graal_eval_full_q(h, fq);
                 if (rc) return 16 + rc;
+                // (several ranks over the host exchange: every rank is here at the same step -- the correction is the same number on all of
+                // them -- and the contacts' part is the sum over their shards, as for the in-step evaluation above)
+                if (h->x_host) { rc = full_exchange(h, fq); if (rc) return 16 + rc; }
                 likelihood_t = fq[0] == Q_BAD ? (double)NAN : (double)(fq[0] + fq[1]) / Q_SCALE;
                 out->full_likelihood = likelihood_t;
             }

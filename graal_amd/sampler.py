@@ -57,6 +57,26 @@ def as_coo_upper(m):
     return r[order].astype(np.int32), c[order].astype(np.int32), v[order]
 
 
+def own_pair_counts(sub_coo, np_sub_frags_id, n_sub_total):
+    """float32 [n_bins, 3]: the observed contacts between the sub-fragments of ONE bin, by data-slot pair (0,1), (0,2), (1,2) -- the
+    diagonal pixels of the bin-level matrix the reference's evaluate_likelihood sums (kernels3.cu:3213), which no candidate delta contains
+    (include/graal_hip.h: graal_upload_own_obs)."""
+    ids = np.asarray(np_sub_frags_id)
+    n_bins = ids.shape[0]
+    bin_of = np.full(n_sub_total, -1, dtype=np.int64)
+    slot_of = np.zeros(n_sub_total, dtype=np.int64)
+    for k in range(3):
+        has = ids[:, 3] > k
+        bin_of[ids[has, k]] = np.nonzero(has)[0]
+        slot_of[ids[has, k]] = k
+    row, col, val = (np.asarray(a) for a in sub_coo[:3])
+    same = (bin_of[row] == bin_of[col]) & (row != col) & (bin_of[row] >= 0)
+    a, b = np.minimum(slot_of[row[same]], slot_of[col[same]]), np.maximum(slot_of[row[same]], slot_of[col[same]])
+    own = np.zeros((n_bins, 3), dtype=np.float32)
+    own[bin_of[row[same]], np.where(a == 0, b - 1, 2)] = val[same].astype(np.float32)
+    return own
+
+
 def split_repeat_observations(sub_coo, sub_ids_of_bins, dup_bins, n_sub_total):
     """Contacts without the repeated bins' sub-fragments + the rows of the (symmetric, zero-diagonal) observation matrix
     of those sub-fragments, [n_dup, 3, n_sub_total] float32 -- what ``graal_upload_repeats`` takes."""
@@ -388,6 +408,10 @@ class sampler(object):
         self._dist_ref_uploaded = False
         self._dist_counted_mask = None
         self.exchange = self._setup_exchange(exchange)
+        if group.world > 1 and self.exchange == "host" and not len(self.id_frag_duplicated) and not self._single_sub:
+            # every rank holds a shard of the list but prices the commits' own-pixel corrections in full (graal_upload_own_obs): the observed
+            # counts of each bin's own sub-fragment pairs, from the WHOLE list
+            self.engine.upload_own_obs(own_pair_counts(self.sub_coo, self.np_sub_frags_id, int(self.init_n_sub_frags)))
         import os as _os
         # MCMC steps between full re-evaluations of the carried-over likelihood.  With repeats every step: the reference's
         # candidate pixel ranges miss some pixels an activity swap changes (kernels3.cu:3368-3373), so its per-step total
@@ -409,8 +433,11 @@ class sampler(object):
         accu = self.np_sub_frags_accu
         nsub = self.np_sub_frags_id[:, 3]
         mixed = ((nsub >= 2) & (accu[:, 1] != accu[:, 0])) | ((nsub >= 3) & (accu[:, 2] != accu[:, 0]))
+        # (several ranks: over the host exchange every rank computes the same correction from the whole list's own-pair table; behind an RCCL
+        # all-reduce a repair could not be summed inside the step: per-step evaluation there)
         self._own_corr = bool(self.reference_arithmetic == "strict" and not self._single_sub and not len(self.id_frag_duplicated)
-                              and self.group.world == 1 and mixed.mean() <= 0.1 and not _os.environ.get("GRAAL_NO_OWN_PIXEL_CARRY"))
+                              and (self.group.world == 1 or self.exchange == "host") and mixed.mean() <= 0.1
+                              and not _os.environ.get("GRAAL_NO_OWN_PIXEL_CARRY"))
         self.resync_every = 512
         if len(self.id_frag_duplicated) or (self.reference_arithmetic and not self._single_sub and not self._own_corr):
             self.resync_every = 1

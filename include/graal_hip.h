@@ -225,8 +225,16 @@ int graal_last_counters(graal_ctx* h, int64_t out[4]);
  * sub-fragments carry different RF counts (that also changes the bin's trans pixels with every bin outside the two contigs) --: evaluate
  * instead.  q_out = NULL: DISCARD -- the caller
  * holds a full evaluation of the current layout, which accounts for every commit so far, the one whose statistics have not been collected
- * included.  No device access. */
+ * included.  The corrections are computed from the first take on (the first one reports "unknown"): a caller that never asks pays nothing.
+ * No device access. */
 int graal_take_carry_correction(graal_ctx* h, int64_t* q_out, int32_t* valid_out);
+/* The observed counts of every bin's OWN sub-fragment pairs, own[3 * bin + {0, 1, 2}] = the contacts between the bin's sub-fragments in
+ * data slots (0,1), (0,2), (1,2) (0 = none), for the correction above.  graal_upload_contacts builds this table from the list it is given;
+ * a rank that holds a SHARD of the list hands in the table of the WHOLE list here (after its contacts): every rank then computes the same
+ * correction, nothing is exchanged, and graal_step's flag 16 works over the host exchange as on one rank (an unknown correction is
+ * replaced by a full evaluation whose contact part is summed over the ranks, like flag 8's).  Not with an RCCL communicator of several
+ * ranks.  No-op at one sub-fragment per bin and with repeats. */
+int graal_upload_own_obs(graal_ctx* h, const float* own, int32_t n_bins);
 /* counters of the handle's whole life (no device access): out[0] = candidate evaluations started, out[1] = evaluations REPEATED behind
  * events because an in-kernel wait between two kernels of a step ran out (k_tm waiting for the scan's announcement, k_strict2 waiting for
  * k_gprep's completion word: the kernels were not resident together -- a profiler serialising dispatches; results are the same, the

@@ -26,8 +26,15 @@ def _problem(which="sub3"):
         # part dealt to the ranks item by item, the full evaluation's part pixel by pixel (k_rep_delta, k_rep_full)
         P = synth.make_problem(n_bins=60, nnz=1500, n_sub=3, seed=23, contig_weights=(5, 4, 3), mean_len_bp=2000.0, accu=("random", 1, 9), param=par)
         return synth.add_repeats(P, (7, 21, 40), 2)
-    return synth.make_problem(n_bins=90, nnz=2500, n_sub=3, seed=17, contig_weights=(5, 4, 3), mean_len_bp=2000.0, accu=9,
-                              param=par, grid_bp=2000)
+    P = synth.make_problem(n_bins=90, nnz=2500, n_sub=3, seed=17, contig_weights=(5, 4, 3), mean_len_bp=2000.0, accu=9,
+                           param=par, grid_bp=2000)
+    if which == "sub3mix":
+        # nine bins of mixed RF counts (a pyramid's ragged last bins): a commit that mirrors one of them reports its own-pixel correction as
+        # unknown, and the step that follows evaluates in full -- on several ranks with the contacts' part summed over their shards
+        acc = P["np_sub_frags_accu"].copy()
+        acc[[3, 11, 17, 29, 37, 44, 61, 73, 88], 0] = 5
+        P["np_sub_frags_accu"] = acc
+    return P
 
 
 def _make(P, rng, group, exchange=None):
@@ -60,6 +67,8 @@ def _run(group, exchange=None, which="sub3"):
     t = em.run_em(g, 1, 4, rng=rng, scrambled=which != "mid", on_step=lambda j, i, tr: scores.append(np.copy(g.score)))
     if which == "mid":
         assert max(t.n_contigs) < 60, "the run left the regime of contigs of tens to hundreds of bins"
+    if which == "sub3mix" and g._own_corr:
+        assert g.engine.run_counters()["carried_totals_repaired"] > 0, "no commit mirrored a bin of mixed RF counts: the case tests nothing"
     g.gpu_vect_frags.copy_from_gpu()
     out = (t.mutations(), np.concatenate(scores), {k: np.copy(v) for k, v in g.gpu_vect_frags.as_dict().items()},
            g.eval_likelihood())
@@ -83,12 +92,13 @@ def _worker(rank, world, port, q, exchange, which="sub3"):
 _REF = {}
 
 
-def _ref(which, several_ranks):
-    """The one-rank anchor of a run.  With sub-fragments ONE rank carries its total with the commits' own-pixel corrections
-    (tests/test_carried_total_gpu.py) while several ranks evaluate the full likelihood every step, as the reference does: the bit-for-bit
-    anchor of a several-rank run is the one-rank run that does the same (GRAAL_NO_OWN_PIXEL_CARRY=1)."""
+def _ref(which, per_step_evaluation):
+    """The one-rank anchor of a run.  With sub-fragments one rank -- and several ranks over the host exchange -- carry the total with the
+    commits' own-pixel corrections (tests/test_carried_total_gpu.py); ranks behind an all-reduce evaluate the full likelihood every step, as
+    the reference does: their bit-for-bit anchor is the one-rank run that does the same (GRAAL_NO_OWN_PIXEL_CARRY=1)."""
     from graal_amd import dist as gdist
-    key = (which, bool(several_ranks))
+    several_ranks = bool(per_step_evaluation) and which in ("sub3", "sub3mix")      # (the other problems never carry: one anchor)
+    key = (which, several_ranks)
     if key not in _REF:
         if several_ranks:
             os.environ["GRAAL_NO_OWN_PIXEL_CARRY"] = "1"
@@ -102,11 +112,11 @@ def _ref(which, several_ranks):
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("world,exchange,which", [(2, "host", "sub3"), (3, "host", "sub3"), (2, "rccl", "sub3"), (2, "auto-fallback", "sub3"),
                                                   (2, "host", "mid"), (3, "host", "mid"), (2, "rccl", "mid"),
-                                                  (2, "host", "rep"), (3, "host", "rep"), (2, "rccl", "rep")])
+                                                  (2, "host", "rep"), (3, "host", "rep"), (2, "rccl", "rep"), (2, "host", "sub3mix")])
 def test_ranks_reproduce_the_single_rank_run_bit_for_bit(world, exchange, which):
     import torch.multiprocessing as mp
     from graal_amd import dist as gdist
-    ref_mut, ref_scores, ref_soa, ref_full = _ref(which, several_ranks=True)
+    ref_mut, ref_scores, ref_soa, ref_full = _ref(which, per_step_evaluation=exchange != "host")
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -145,7 +155,7 @@ def test_rccl_all_reduce_driven_by_the_library_on_the_gpu_timeline(which, tmp_pa
     import sys
     from graal_amd import dist as gdist
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    ref_mut, ref_scores, ref_soa, ref_full = _ref(which, several_ranks=False)   # (a one-rank communicator: the child carries its total like any single rank)
+    ref_mut, ref_scores, ref_soa, ref_full = _ref(which, per_step_evaluation=False)   # (a one-rank communicator: the child carries its total like any single rank)
     out = str(tmp_path / "rccl.npz")
     env = dict(os.environ, GRAAL_RCCL_FORCE="1", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
     r = subprocess.run([sys.executable, "-c", "import tests.test_multirank_gpu as t; t._rccl_child(%r, %r)" % (out, which)], cwd=root, env=env,
