@@ -139,3 +139,25 @@ def test_restricted_rescore_gives_the_candidate_deltas(n_sub, seed):
             assert got == pytest.approx(sparse.full(cand, same_bin=False) - base, abs=1e-11 * abs(base)), (fA, fB, op)
             want = dense.sub_compute(cand, np.sort(np.nonzero(in_set)[0]), [], np.arange(n, dtype=np.int32), per_pix)
             assert got == pytest.approx(want, abs=1e-7 * abs(base)), (fA, fB, op)
+
+
+def test_own_pair_counts_are_the_diagonal_pixels_contacts():
+    """graal_amd.sampler.own_pair_counts (the table graal_upload_own_obs takes: the observed contacts between the sub-fragments of ONE bin,
+    by data-slot pair) against a loop over the contact list."""
+    from graal_amd import synth
+    from graal_amd.sampler import own_pair_counts
+    P = synth.make_problem(n_bins=40, nnz=3000, n_sub=3, seed=5, contig_weights=(3, 2), mean_len_bp=1500.0, accu=9)
+    ids = P["np_sub_frags_id"]
+    got = own_pair_counts((P["coo_row"], P["coo_col"], P["coo_val"]), ids, P["init_n_sub_frags"])
+    want = np.zeros((len(ids), 3), dtype=np.float32)
+    where = {}
+    for b in range(len(ids)):
+        for k in range(ids[b, 3]):
+            where[int(ids[b, k])] = (b, k)
+    for r, c, v in zip(P["coo_row"], P["coo_col"], P["coo_val"]):
+        (b1, k1), (b2, k2) = where[int(r)], where[int(c)]
+        if b1 == b2 and k1 != k2:
+            lo, hi = min(k1, k2), max(k1, k2)
+            want[b1, hi - 1 if lo == 0 else 2] = v
+    assert want.sum() > 0
+    assert np.array_equal(got, want)
