@@ -182,6 +182,13 @@ def test_bench_runs_two_ranks_from_one_command():
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--n-bins", "2000",
                           "--nnz", "100000", "--steps", "6", "--warmup", "2", "--mcmc-warmup", "300"],
                          env=env, capture_output=True, text=True, timeout=850)
+    if out.returncode != 0:      # (keep everything the ranks said: gpurun_out/ travels back from the GPU box)
+        try:
+            os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(root, "gpurun_out", "bench_two_ranks_failure.log"), "w") as f:
+                f.write("returncode %d\n--- stdout\n%s\n--- stderr\n%s\n" % (out.returncode, out.stdout, out.stderr))
+        except OSError:
+            pass
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["distributed"]["ranks"] == 2
