@@ -119,3 +119,14 @@ def test_a_mirrored_bin_of_mixed_rf_counts_makes_the_next_step_evaluate(monkeypa
     assert a["counters"]["carried_totals_repaired"] > 0, "no commit mirrored one of the nine bins: pick another seed"
     assert [t[1:] for t in a["trace"]] == [t[1:] for t in b["trace"]]
     assert np.allclose([t[0] for t in a["trace"]], [t[0] for t in b["trace"]], rtol=REL, atol=0)
+
+
+@pytest.mark.parametrize("seed,n_bins,nnz,delta,circles", [(101, 60, 1500, 3, (1,)), (102, 140, 5000, 5, (2, 3)), (103, 75, 2200, 10, ())])
+def test_carried_total_along_other_runs(seed, n_bins, nnz, delta, circles, monkeypatch):
+    """More layouts and neighbour counts (3, 5, 10), ragged bins of one to three sub-fragments, from circular and from exploded starts:
+    carried + correction == a full evaluation every 11 steps, and no step needed a repair."""
+    P = close_into_circles(problem(n_bins=n_bins, nnz=nnz, seed=seed), circles)
+    for explode in (False, True):
+        a = run(P, seed, 330, 11, monkeypatch, delta=delta, explode=explode)
+        assert a["own"] and a["counters"]["carried_totals_repaired"] == 0
+        assert a["worst"] < REL
