@@ -4326,6 +4326,7 @@ struct Ctx {
     long long* h_own = nullptr;      // pinned host: [0] the commit's number, [1] its correction (Q), [2] its unknown terms
     long long own_seq = 0;
     bool own_pending = false;        // a correction kernel is out and its result has not been taken from h_own
+    int peer_repeats = 0;            // eval_sync: repeats of the step in progress because ANOTHER rank's part of it failed (host exchange)
     bool carry_wanted = false;       // somebody takes the corrections (graal_take_carry_correction was called): only then are they computed
     bool own_complete = false;       // d_own_obs was handed in by the caller (graal_upload_own_obs): it covers the WHOLE contact list, not this rank's shard
     bool corr_inflight = false;      // between begin_step_launch and begin_step_collect
@@ -6194,13 +6195,27 @@ static int eval_sync(graal_ctx* h, int32_t fA, const int32_t* fB, int32_t K, int
         volatile long long* o = h->x_host + ((size_t)(want & 1) * (size_t)world + (size_t)r) * X_SLOT_WORDS;
         const auto t0 = std::chrono::steady_clock::now();
         long long spin = 0;
+        bool peer_failed = false;
         for (;;) {
             const long long v = o[0];
             if (v == want) break;
-            if (v == -want) return fail(h, GRAAL_E_HIP, "another rank's step failed (exchange)");
+            if (v == -want) { peer_failed = true; break; }
             if ((++spin & 0xfffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60))
                 return fail(h, GRAAL_E_STATE, "exchange: another rank did not publish this step within 60 s (ranks out of step, or a rank died)");
             __builtin_ia32_pause();
+        }
+        if (peer_failed) {
+            // That rank's step ended as failed -- an in-kernel wait of its engine ran out (its two kernels did not run side by side: several
+            // ranks on ONE GPU in a rehearsal, a tool that serialises dispatches, a hiccup) -- and it repeats the step behind events under the
+            // NEXT step number.  Every rank must repeat with it, or the ranks are out of step: its -want stays in this parity's slot until
+            // the step after next, so every peer sees it, whenever it looks.  (This rank's own part ended regularly: nothing to put back.)
+            // A rank that fails for good returns an error and never publishes the repeat: its peers time out above.
+            if (h->peer_repeats >= 3) return fail(h, GRAAL_E_HIP, "another rank's step failed again and again (exchange)");
+            h->peer_repeats += 1;
+            h->rc_repeats += 1;
+            const int rc2 = eval_sync(h, fA, fB, K, max_id, rank, world, q_sum, c_sum);
+            h->peer_repeats -= 1;
+            return rc2;
         }
         __sync_synchronize();
         for (int i = 0; i < K * N_OPS; i++) {

@@ -47,7 +47,7 @@ def _make(P, rng, group, exchange=None):
                    device=0, rng=rng, group=group, param_simu=P["param_simu"], compute_dist=False, exchange=exchange)
 
 
-def _run(group, exchange=None, which="sub3"):
+def _run(group, exchange=None, which="sub3", expect_repeat=False):
     from graal_amd import em
     P = _problem(which)
     rng = np.random.RandomState(5)
@@ -67,6 +67,8 @@ def _run(group, exchange=None, which="sub3"):
     t = em.run_em(g, 1, 4, rng=rng, scrambled=which != "mid", on_step=lambda j, i, tr: scores.append(np.copy(g.score)))
     if which == "mid":
         assert max(t.n_contigs) < 60, "the run left the regime of contigs of tens to hundreds of bins"
+    if expect_repeat:     # (on the rank whose wait ran out AND on its peers, which repeated the step with it)
+        assert g.engine.run_counters()["fallbacks"] >= 1, "no step was repeated on rank %d" % group.rank
     if which == "sub3mix" and g._own_corr:
         assert g.engine.run_counters()["carried_totals_repaired"] > 0, "no commit mirrored a bin of mixed RF counts: the case tests nothing"
     g.gpu_vect_frags.copy_from_gpu()
@@ -81,9 +83,16 @@ def _worker(rank, world, port, q, exchange, which="sub3"):
     from graal_amd import dist as gdist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    expect_repeat = which.endswith("+timeout")
+    if which.endswith("+timeout"):
+        # ONE rank's in-kernel wait for its scan runs out at once (the engine reads the bound when the handle is created): its step ends as
+        # failed and is repeated behind events -- and every other rank has to repeat that step with it
+        which = which[:-len("+timeout")]
+        if rank == 1:
+            os.environ["GRAAL_TM_SPIN_TICKS"] = "1"
     td.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        mut, scores, soa, full = _run(gdist.Group(rank, world), exchange, which)
+        mut, scores, soa, full = _run(gdist.Group(rank, world), exchange, which, expect_repeat)
         q.put((rank, mut, scores, soa, full))
     finally:
         td.destroy_process_group()
@@ -112,11 +121,12 @@ def _ref(which, per_step_evaluation):
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("world,exchange,which", [(2, "host", "sub3"), (3, "host", "sub3"), (2, "rccl", "sub3"), (2, "auto-fallback", "sub3"),
                                                   (2, "host", "mid"), (3, "host", "mid"), (2, "rccl", "mid"),
-                                                  (2, "host", "rep"), (3, "host", "rep"), (2, "rccl", "rep"), (2, "host", "sub3mix")])
+                                                  (2, "host", "rep"), (3, "host", "rep"), (2, "rccl", "rep"), (2, "host", "sub3mix"),
+                                                  (2, "host", "sub3+timeout"), (3, "host", "mid+timeout")])
 def test_ranks_reproduce_the_single_rank_run_bit_for_bit(world, exchange, which):
     import torch.multiprocessing as mp
     from graal_amd import dist as gdist
-    ref_mut, ref_scores, ref_soa, ref_full = _ref(which, per_step_evaluation=exchange != "host")
+    ref_mut, ref_scores, ref_soa, ref_full = _ref(which.replace("+timeout", ""), per_step_evaluation=exchange != "host")
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
