@@ -241,7 +241,7 @@ static int hs_select(MtState* mt, const double* score, int n, int n_tmp)
 // GRAAL_STEP_SELECT or 16 + a GRAAL_E_* code (error codes 1 .. 3 must not be taken for PAUSED / FALLBACK / SELECT)
 #define CK16(call) do { const hipError_t e16_ = (call); if (e16_ != hipSuccess) { h->err = hipGetErrorString(e16_); return 16 + GRAAL_E_HIP; } } while (0)
 static int hs_finish(graal_ctx* h, MtState* mt, double likelihood_t, int want_dist, graal_step_out* out, bool deferred = false,
-                     bool full_inside = false, bool carry_corr = false)
+                     bool full_inside = false, bool carry_corr = false /* flag 16 */, bool total_is_full = false /* the caller's total is a full evaluation of this layout */)
 {
     if (!h->hs) return 16 + fail(h, GRAAL_E_STATE, "graal_upload_proposal_tables first");
     HostStep& S = *h->hs;
@@ -286,8 +286,11 @@ static int hs_finish(graal_ctx* h, MtState* mt, double likelihood_t, int want_di
         // of range -- is replaced by the evaluation itself.
         int64_t cq = 0;
         int32_t cv = 0;
-        if (carry_corr) (void)graal_take_carry_correction(h, &cq, &cv);
-        if (carry_corr && !full_inside) {
+        // (a step that starts from a full evaluation -- inside the step, or the caller's behind a pause -- voids whatever has accumulated:
+        // the commits of an explode_genome in front of the first step, the last step's)
+        if (carry_corr && (full_inside || total_is_full)) (void)graal_take_carry_correction(h, nullptr, nullptr);
+        else if (carry_corr) (void)graal_take_carry_correction(h, &cq, &cv);
+        if (carry_corr && !full_inside && !total_is_full) {
             if (cv) likelihood_t += (double)cq / Q_SCALE;
             else {
                 int64_t fq[2];
@@ -371,7 +374,7 @@ int graal_step(graal_ctx* h, void* mt_state, int32_t fA, int32_t delta, double l
     if ((flags & 2) || ((flags & 1) && (out->stats[6] != 0 || prev_circ != 0))) {
         // a full re-evaluation is due: inside the step (flag 8; with an exchange attached the ranks' contact parts are summed through
         // it, full_exchange) or by the caller
-        if ((flags & 8) && !(h->nccl_comm && h->n_world > 1)) return hs_finish(h, mt, likelihood_t, (flags & 4) != 0, out, false, true);
+        if ((flags & 8) && !(h->nccl_comm && h->n_world > 1)) return hs_finish(h, mt, likelihood_t, (flags & 4) != 0, out, false, true, (flags & 16) != 0);
         S.paused = true;
         return GRAAL_STEP_PAUSED;
     }
@@ -384,7 +387,7 @@ int graal_step_finish(graal_ctx* h, void* mt_state, double likelihood_t, int32_t
     if (!h->hs || !h->hs->paused) return 16 + fail(h, GRAAL_E_STATE, "graal_step_finish: no paused step (graal_step did not return GRAAL_STEP_PAUSED)");
     MtState* mt = (MtState*)mt_state;
     if (mt->pos < 0 || mt->pos > 624) return 16 + fail(h, GRAAL_E_ARG, "graal_step_finish: not an MT19937 state");
-    return hs_finish(h, mt, likelihood_t, (flags & 4) != 0, out);
+    return hs_finish(h, mt, likelihood_t, (flags & 4) != 0, out, false, false, (flags & 16) != 0, true);   // (the caller re-evaluated behind the pause)
 }
 
 /* A run of MCMC steps in one call (the inner loop of start_EM, cuda_lib_gl.py:2196-2220: one step_max_likelihood per fragment of the

@@ -130,3 +130,52 @@ def test_carried_total_along_other_runs(seed, n_bins, nnz, delta, circles, monke
         a = run(P, seed, 330, 11, monkeypatch, delta=delta, explode=explode)
         assert a["own"] and a["counters"]["carried_totals_repaired"] == 0
         assert a["worst"] < REL
+
+
+def test_headless_loop_equals_the_per_step_evaluation_run(monkeypatch):
+    """The outer loop as start_EM runs it (em.run_em: init_likelihood, THEN explode_genome -- its commits' corrections pile up in front of the
+    first step, which starts from a full evaluation and must void them --, then cycles of steps in runs behind graal_steps): the carried run
+    and the per-step-evaluation run give the same moves and the same likelihood series (1e-10), 1,800 steps."""
+    from graal_amd import em
+    from tests.test_sampler_gpu import make_gpu_sampler
+    P = problem(n_bins=300, nnz=20000, seed=7)
+
+    def go(carry):
+        monkeypatch.delenv("GRAAL_NO_OWN_PIXEL_CARRY", raising=False)
+        if not carry:
+            monkeypatch.setenv("GRAAL_NO_OWN_PIXEL_CARRY", "1")
+        rng = np.random.RandomState(3)
+        g = make_gpu_sampler(P, rng, reference_arithmetic="strict")
+        assert g._own_corr == carry
+        tr = em.run_em(g, 6, 3, rng=rng)
+        out = (np.asarray(tr.likelihood), tr.mutations(), g.engine.run_counters()["carried_totals_repaired"])
+        g.free_gpu()
+        return out
+
+    a, b = go(True), go(False)
+    assert np.array_equal(a[1], b[1])
+    assert np.allclose(a[0], b[0], rtol=REL, atol=0), float(np.max(np.abs(a[0] - b[0]) / np.abs(b[0])))
+    assert a[2] == 0
+
+
+@pytest.mark.parametrize("scrambled", [True, False])
+def test_carried_run_against_the_oracle(scrambled):
+    """The carried total against an anchor that is not the engine: 250 steps of start_EM (from the exploded genome / from three contigs, two of
+    them circular) at three sub-fragments per bin, one RF count, generic coordinates, against the oracle run the reference's way (a full
+    dense evaluation at the top of every step): accepted moves and layout bit for bit, the likelihood series to 1e-8."""
+    from oracle import oracle as O
+    from tests.test_strict_gpu import _run, _samplers
+    P = problem(n_bins=75, nnz=2400, seed=95)
+    if not scrambled:
+        close_into_circles(P, (1, 3))
+    ora, g, gpu_rng = _samplers(P, 9, "strict")
+    assert g._own_corr
+    t_ref = _run(ora, ora.rng, 4, 250, scrambled=scrambled)
+    t_gpu = _run(g, gpu_rng, 4, 250, scrambled=scrambled)
+    assert np.array_equal(t_gpu.mutations(), t_ref.mutations())
+    assert np.allclose(t_gpu.likelihood, t_ref.likelihood, rtol=1e-8, atol=0), float(np.max(np.abs(np.asarray(t_gpu.likelihood) / np.asarray(t_ref.likelihood) - 1)))
+    g.gpu_vect_frags.copy_from_gpu()
+    for k in O.FIELDS:
+        assert np.array_equal(getattr(g.gpu_vect_frags, k), ora.gpu_vect_frags[k]), k
+    assert g.engine.run_counters()["carried_totals_repaired"] == 0
+    g.free_gpu()
