@@ -132,7 +132,8 @@ def test_carried_total_along_other_runs(seed, n_bins, nnz, delta, circles, monke
         assert a["worst"] < REL
 
 
-def test_headless_loop_equals_the_per_step_evaluation_run(monkeypatch):
+@pytest.mark.parametrize("sample_param", [False, True])
+def test_headless_loop_equals_the_per_step_evaluation_run(sample_param, monkeypatch):
     """The outer loop as start_EM runs it (em.run_em: init_likelihood, THEN explode_genome -- its commits' corrections pile up in front of the
     first step, which starts from a full evaluation and must void them --, then cycles of steps in runs behind graal_steps): the carried run
     and the per-step-evaluation run give the same moves and the same likelihood series (1e-10), 1,800 steps."""
@@ -147,8 +148,10 @@ def test_headless_loop_equals_the_per_step_evaluation_run(monkeypatch):
         rng = np.random.RandomState(3)
         g = make_gpu_sampler(P, rng, reference_arithmetic="strict")
         assert g._own_corr == carry
-        tr = em.run_em(g, 6, 3, rng=rng)
-        out = (np.asarray(tr.likelihood), tr.mutations(), g.engine.run_counters()["carried_totals_repaired"])
+        # (sample_param: a nuisance-parameter step behind every MCMC step, the reference GUI's default -- it compares a full evaluation under
+        # test parameters with the carried score and, when it rejects, leaves the commit's correction for the next step)
+        tr = em.run_em(g, 2 if sample_param else 6, 3, rng=rng, sample_param=sample_param)
+        out = (np.asarray(tr.likelihood), tr.mutations(), g.engine.run_counters()["carried_totals_repaired"], np.asarray(tr.success), np.asarray(tr.fact))
         g.free_gpu()
         return out
 
@@ -156,6 +159,7 @@ def test_headless_loop_equals_the_per_step_evaluation_run(monkeypatch):
     assert np.array_equal(a[1], b[1])
     assert np.allclose(a[0], b[0], rtol=REL, atol=0), float(np.max(np.abs(a[0] - b[0]) / np.abs(b[0])))
     assert a[2] == 0
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])       # (the parameter walk: accepted at the same steps, the same values)
 
 
 @pytest.mark.parametrize("scrambled", [True, False])
