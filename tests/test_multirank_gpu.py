@@ -26,6 +26,11 @@ def _problem(which="sub3"):
         # part dealt to the ranks item by item, the full evaluation's part pixel by pixel (k_rep_delta, k_rep_full)
         P = synth.make_problem(n_bins=60, nnz=1500, n_sub=3, seed=23, contig_weights=(5, 4, 3), mean_len_bp=2000.0, accu=("random", 1, 9), param=par)
         return synth.add_repeats(P, (7, 21, 40), 2)
+    if which == "c2":
+        # the C2 stand-in (BASELINE config 2's shape: 1,086 bins x 3 sub-fragments, 120,000 contacts), generic coordinates: one cycle from the
+        # exploded genome -- the table kernel, the flat kernel and the tiled kernels, the total carried with the commits' corrections
+        return synth.make_problem(n_bins=1086, nnz=120_000, n_sub=3, seed=2014, contig_weights=(6.8, 6.2, 5.3, 4.6, 4.0, 3.4, 2.7),
+                                  mean_len_bp=660.0 * 9, accu=9, param=par)
     P = synth.make_problem(n_bins=90, nnz=2500, n_sub=3, seed=17, contig_weights=(5, 4, 3), mean_len_bp=2000.0, accu=9,
                            param=par, grid_bp=2000)
     if which == "sub3mix":
@@ -106,7 +111,7 @@ def _ref(which, per_step_evaluation):
     commits' own-pixel corrections (tests/test_carried_total_gpu.py); ranks behind an all-reduce evaluate the full likelihood every step, as
     the reference does: their bit-for-bit anchor is the one-rank run that does the same (GRAAL_NO_OWN_PIXEL_CARRY=1)."""
     from graal_amd import dist as gdist
-    several_ranks = bool(per_step_evaluation) and which in ("sub3", "sub3mix")      # (the other problems never carry: one anchor)
+    several_ranks = bool(per_step_evaluation) and which in ("sub3", "sub3mix", "c2")      # (the other problems never carry: one anchor)
     key = (which, several_ranks)
     if key not in _REF:
         if several_ranks:
@@ -122,7 +127,7 @@ def _ref(which, per_step_evaluation):
 @pytest.mark.parametrize("world,exchange,which", [(2, "host", "sub3"), (3, "host", "sub3"), (2, "rccl", "sub3"), (2, "auto-fallback", "sub3"),
                                                   (2, "host", "mid"), (3, "host", "mid"), (2, "rccl", "mid"),
                                                   (2, "host", "rep"), (3, "host", "rep"), (2, "rccl", "rep"), (2, "host", "sub3mix"),
-                                                  (2, "host", "sub3+timeout"), (3, "host", "mid+timeout")])
+                                                  (2, "host", "sub3+timeout"), (3, "host", "mid+timeout"), (2, "host", "c2")])
 def test_ranks_reproduce_the_single_rank_run_bit_for_bit(world, exchange, which):
     import torch.multiprocessing as mp
     from graal_amd import dist as gdist
