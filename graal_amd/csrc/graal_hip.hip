@@ -4806,19 +4806,33 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
         const int lc = std::max(std::max(h->max_lcont, h->lcont_bound), 1);
         static const int blocks_env = getenv("GRAAL_STRICT_BLOCKS") ? atoi(getenv("GRAAL_STRICT_BLOCKS")) : 0;
         const int blocks = blocks_env > 0 ? blocks_env : (lc <= 64 ? 32 : (lc <= 256 ? 512 : 1024));
+        // fragments per tile: 64 (one per lane); with several sub-fragments per bin 32 -- the halves of a wave hold the same 32 fragments and
+        // take two fragments of the segment at a time (k_strict2): a unit is a 32 x 4 block instead of a 64 x 2 strip, which wastes fewer lanes
+        // on pieces of a few dozen bins and at the window's edge (GRAAL_S2_TILE=64: the strips, for A/B)
+        static const int tile_env = getenv("GRAAL_S2_TILE") ? atoi(getenv("GRAAL_S2_TILE")) : 0;
+        const int TILE = h->single_sub ? 64 : (tile_env == 64 ? 64 : 32);
         // tiles of the union: at most K + 1 contigs, at most every fragment; + one partial tile per global piece
-        const unsigned long long nt = std::min<unsigned long long>((unsigned long long)(K + 1) * (unsigned long long)((lc + 63) / 64),
-                                                                   (unsigned long long)((h->n + 63) / 64 + K + 1)) + (unsigned long long)US_MAXP;
+        const unsigned long long nt = std::min<unsigned long long>((unsigned long long)(K + 1) * (unsigned long long)((lc + TILE - 1) / TILE),
+                                                                   (unsigned long long)((h->n + TILE - 1) / TILE + K + 1)) + (unsigned long long)US_MAXP;
         if (nt >= 65536ull) return fail(h, GRAAL_E_STATE, "reference arithmetic: more than 65,535 tiles in a step's union set");
         // the unit list's entries: 4 fragments of the segment side (one sub-fragment per bin; k_strict2 merges up to 4 of them) or 1 (several:
         // up to 2); GRAAL_STRICT_SEG fixes the entry size (entries of one fragment at one sub-fragment per bin: the list's traffic cost the C4
         // stand-in 20 % of its run), GRAAL_STRICT_REP the waves that may share one unit's classes (1, 2, 4, 8)
         static const int seg_env = getenv("GRAAL_STRICT_SEG") ? atoi(getenv("GRAAL_STRICT_SEG")) : 0;
-        const int seg_max = h->single_sub ? 16 : 2;   // (k_strict2's SEG)
-        const int seg_unit = ((seg_env == 1 || seg_env == 2 || seg_env == 4 || seg_env == 8 || seg_env == 16) && seg_env <= seg_max) ? seg_env : (h->single_sub ? 4 : 1);
+        const int seg_max = h->single_sub ? 16 : (TILE == 32 ? 4 : 2);   // (k_strict2's segment: SEG, seg_cap)
+        // (tiles of 32: entries of TWO fragments, one per half of the wave -- FOUR once the longest contig may hold more than 512 bins (the bound,
+        // one commit stale: twice the longest + 2): a step there has a few thousand units, more than half the grid's waves, so no two waves share
+        // one; with half as many, twice as long, every unit is shared by two waves and none idles.  C3 stand-in (contigs of 350 bins): 142 us
+        // per step against 157; C2 stand-in (contigs of 150-220): 108 against 99)
+        const int seg_unit = ((seg_env == 1 || seg_env == 2 || seg_env == 4 || seg_env == 8 || seg_env == 16) && seg_env <= seg_max) ? seg_env
+                                                                                                 : (h->single_sub ? 4 : (TILE == 32 ? (lc > 512 ? 4 : 2) : 1));
         static const int rep_env = getenv("GRAAL_STRICT_REP") ? atoi(getenv("GRAAL_STRICT_REP")) : 8;
         const int rep_max = rep_env >= 16 ? 16 : (rep_env >= 8 ? 8 : (rep_env >= 4 ? 4 : (rep_env >= 2 ? 2 : 1)));
-        const unsigned long long target = 6ull * 4ull * (unsigned long long)blocks;
+        // units the grid wants before k_strict2 merges neighbouring entries into longer units (per wave: 6 at one sub-fragment per bin; with
+        // several, a unit's fragment pairs are nine evaluations each -- GRAAL_S2_TARGET_X4: the figure in quarters, for A/B)
+        static const int target_env = getenv("GRAAL_S2_TARGET_X4") ? atoi(getenv("GRAAL_S2_TARGET_X4")) : 0;
+        const unsigned long long target_x4 = target_env > 0 ? (unsigned long long)target_env : (h->single_sub ? 24ull : 24ull);
+        const unsigned long long target = std::max<unsigned long long>(1ull, target_x4 * 4ull * (unsigned long long)blocks / 4ull);
         const unsigned long long pairs_max = nt * (nt + 1ull) / 2ull;
         // The list's worst case -- EVERY tile pair of the union listed -- is quadratic in the union's size (2e9 entries for 1e6 fragments in a few
         // contigs), while the interval cull lists the pairs within reach of each other under some candidate: orders of magnitude fewer.
@@ -4827,8 +4841,8 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
         // again while an assembly's contigs grow.  One rank: SLIST_SOFT_CAP entries at most to begin with; if a step's list overflows,
         // k_gprep says so (counters[6] bit 1), the step ends as failed, eval_sync raises the floor and repeats it.  Several ranks: the worst
         // case (a repeated step on ONE rank would leave the ranks out of step).
-        const unsigned long long nt_n = (unsigned long long)((h->n + 63) / 64 + MAXK + 1) + (unsigned long long)US_MAXP;
-        const unsigned long long worst = (nt_n * (nt_n + 1ull) / 2ull) * (unsigned long long)(64 / seg_unit) + 64ull;
+        const unsigned long long nt_n = (unsigned long long)((h->n + TILE - 1) / TILE + MAXK + 1) + (unsigned long long)US_MAXP;
+        const unsigned long long worst = (nt_n * (nt_n + 1ull) / 2ull) * (unsigned long long)(TILE / seg_unit) + 64ull;
         (void)pairs_max;
         const unsigned long long SLIST_SOFT_CAP = h->slist_soft_cap;   // (GRAAL_SLIST_SOFT_CAP, read when the handle is created)
         h->slist_worst = worst;
@@ -4882,7 +4896,7 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
             CK(hipStreamWaitEvent(st, h->ev_tm, 0));
         }
         k_gprep<<<GPREP_CLS_BLOCKS + cull_blocks, 256, 0, inorder ? st : h->aux>>>(h->tabs, h->pstart, fA, K, rank, world, sx.reach_bp, no_window, sx.quirk,
-                                                                     seg_unit, h->d_slist, h->d_slist_n, h->slist_cap,
+                                                                     seg_unit, TILE, h->d_slist, h->d_slist_n, h->slist_cap,
                                                                      (unsigned long long*)(h->d_scalars + 10), s2);
         CK(hipGetLastError());
         // (k_strict2 on the auxiliary stream right behind k_gprep -- stream order instead of the event, next to the scan, its waves waiting for the

@@ -115,7 +115,7 @@ int hc_inputs_key_disagreements(int n, unsigned seed, int quirk)
 //   (4) the unit list with every tile pair alive covers every unordered pair of union fragments exactly once.
 // Returns the number of violations (0 = fine); info[0..9]: pieces, tiles, contigs, piece pairs with classes, classes, units, pairs, candidates checked, model evaluations
 // (no window) over the union's classes, the same one neighbour at a time.
-int hc_union_check(int fA, const int32_t* fB, int K, int max_id, int32_t* const* s, int n, int quirk, int seg, int64_t* info)
+int hc_union_check(int fA, const int32_t* fB, int K, int max_id, int32_t* const* s, int n, int quirk, int seg, int64_t* info, int tile_frags)
 {
     int bad = 0;
     // position index
@@ -158,7 +158,7 @@ int hc_union_check(int fA, const int32_t* fB, int K, int max_id, int32_t* const*
     auto XF = [&](int k, int op, int p) -> const Xf& { return xf[((size_t)k * N_OPS + op) * (MAX_PIECES + 1) + p]; };
     USet U;
     int cuts[US_MAXC * (US_MAXK + 1)], ncut[US_MAXC];
-    uset_build(U, end_of(fA), B.data(), keys.data(), K, live, live, cuts, ncut);
+    uset_build(U, end_of(fA), B.data(), keys.data(), K, live, live, cuts, ncut, tile_frags == 32 ? 32 : US_TILE);
     info[0] = U.n_pieces; info[1] = U.n_tiles; info[2] = U.n_contigs;
     if (U.n_pieces > US_MAXP || U.n_contigs > US_MAXC) return 1000000;
     // (1) membership
@@ -282,7 +282,7 @@ int hc_union_check(int fA, const int32_t* fB, int K, int max_id, int32_t* const*
     // (4) the unit list, every tile pair alive
     std::map<std::pair<int, int>, int> seen;
     long long n_units = 0;
-    auto frag_at = [&](int t, int l) { int off; const int g = utile_piece(U, t, off); return perm[U.c[U.p[g].contig].base + U.p[g].lo + off * US_TILE + l]; };
+    auto frag_at = [&](int t, int l) { int off; const int g = utile_piece(U, t, off); return perm[U.c[U.p[g].contig].base + U.p[g].lo + off * U.tile + l]; };
     for (int ti = 0; ti < U.n_tiles; ti++)
         for (int tj = ti; tj < U.n_tiles; tj++) {
             const int ci = utile_count(U, ti), cj = utile_count(U, tj);
@@ -300,7 +300,7 @@ int hc_union_check(int fA, const int32_t* fB, int K, int max_id, int32_t* const*
                 const int dti = (int)(u & 0xffffull), dtj = (int)((u >> 16) & 0xffffull), dj0 = (int)((u >> 32) & 63ull), dcnt = (int)((u >> 38) & 63ull);
                 const int lf = (int)((u >> 44) & 1ull);
                 const int tl = lf ? dti : dtj, ts = lf ? dtj : dti, cl = utile_count(U, tl);
-                for (int lane = 0; lane < US_TILE; lane++) {
+                for (int lane = 0; lane < U.tile; lane++) {
                     if (lane >= cl) continue;
                     for (int j = 0; j < dcnt; j++) {
                         if (dti == dtj && !(lane < dj0 + j)) continue;     // the diagonal tile pair: every unordered pair once

@@ -52,15 +52,15 @@ __device__ __forceinline__ void utile_extent(const USet& U, const int* __restric
     g = utile_piece(U, t, off);
     const UPiece& P = U.p[g];
     const UContig& C = U.c[P.contig];
-    const int first = P.lo + off * US_TILE;
-    const int left = P.n - off * US_TILE;
-    cnt = left < US_TILE ? left : US_TILE;
+    const int first = P.lo + off * U.tile;
+    const int left = P.n - off * U.tile;
+    cnt = left < U.tile ? left : U.tile;
     lo = pstart[C.base + first];
     hi = first + cnt >= C.len ? C.lbp : pstart[C.base + first + cnt];
 }
 
 __global__ __launch_bounds__(256) void k_gprep(const NbTables* __restrict__ tabs, const int* __restrict__ pstart, int fA, int K, int rank, int world,
-                                                int reach_bp, int no_window, int quirk, int seg_unit, unsigned long long* __restrict__ list,
+                                                int reach_bp, int no_window, int quirk, int seg_unit, int tile_frags, unsigned long long* __restrict__ list,
                                                 unsigned long long* __restrict__ list_n, unsigned long long cap,
                                                 unsigned long long* __restrict__ counters, S2Args s2)
 {
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void k_gprep(const NbTables* __restrict__ tabs
     for (int i = t; i < K * N_OPS * NP; i += 256) { const int k = i / (N_OPS * NP), r = i - k * (N_OPS * NP); s_xf[k][r / NP][r % NP] = tabs[k].xf[r / NP][r % NP]; }
     __syncthreads();
     STAMP(21, blockIdx.x == 0 && t == 0);
-    if (t == 0) uset_build_geometry(s_U, s_A, s_B, K, s_live, s_mass, s_cuts, s_ncut);
+    if (t == 0) uset_build_geometry(s_U, s_A, s_B, K, s_live, s_mass, s_cuts, s_ncut, tile_frags);
     __syncthreads();
     STAMP(22, blockIdx.x == 0 && t == 0);
     for (int i = t; i < s_U.n_pieces * US_MAXK; i += 256) uset_piece_pk(s_U, s_keys, K, i / US_MAXK, i % US_MAXK);
@@ -356,8 +356,12 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
                                                   unsigned long long* __restrict__ list_n, long long* __restrict__ d_q_out,
                                                   volatile long long* host_res, long long seq)
 {
-    constexpr int SEG = MULTI ? 2 : 16;        // fragments of a unit's segment at most (several sub-fragments: 9 slot pairs per fragment pair
-                                               // already amortise a class's set-up, and the current layout's values of a unit live in LDS)
+    constexpr int SEG = MULTI ? 4 : 16;        // fragments of a unit's segment at most (several sub-fragments: 9 slot pairs per fragment pair
+                                               // already amortise a class's set-up, and the current layout's values of a unit live in LDS: two
+                                               // fragments of the segment per lane -- with tiles of 32 fragments the two HALVES of the wave take two
+                                               // fragments of the segment at a time, so a unit is 32 x 4 instead of 64 x 2: the same work in a squarer
+                                               // block, which wastes fewer lanes on pieces of a few dozen bins and at the window's edge)
+    constexpr int EXO_SEG = MULTI ? 2 : 16;    // ... segment fragments PER LANE whose current-layout values are kept
     constexpr int NS = MULTI ? 3 : 1;          // sub-fragment slots per bin at most
     constexpr int NSP = NS * NS;
     const Geo* __restrict__ geo = fa.geo;
@@ -371,7 +375,7 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
     __shared__ long long s_acc[US_NCAND];
     __shared__ STile2 s_tile[4][SEG];
     __shared__ float s_cy[4][SEG][4];          // the segment side's centres (and its orientation, [3]) in the layout being priced
-    __shared__ float s_exo[4][SEG * NSP][64];  // the current layout's values of the unit's slot pairs, [segment fragment][slot pair][lane]
+    __shared__ float s_exo[4][EXO_SEG * NSP][64];  // the current layout's values of the unit's slot pairs, [segment fragment of the lane][slot pair][lane]
     __shared__ int s_last;
     constexpr int CLS_CHUNK = 32;              // class records of a unit's piece pair staged per wave (a pair has up to 130; most have a dozen)
     __shared__ GClass s_cls[4][CLS_CHUNK];
@@ -421,6 +425,10 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
     }
     __syncthreads();
     const USet& U = s_U;
+    const int TL = MULTI ? U.tile : US_TILE;                      // fragments per tile: 64, or 32 (several sub-fragments per bin)
+    const bool halves = MULTI && TL == 32;                        // lanes 0-31 and 32-63 hold the SAME 32 fragments and take two fragments of the segment at a time
+    const int xi = lane & (TL - 1), half = halves ? (lane >> 5) : 0;
+    const int seg_cap = MULTI ? (halves ? 4 : 2) : SEG;           // fragments of a unit's segment
     const unsigned long long nq_total = counters[2];              // written by k_scan, an earlier kernel on the stream
     const unsigned long long n_units = min(*list_n, sa.list_cap); // written by k_gprep (ordered by an event)
     const float nfpb = sa.nfpb;
@@ -439,7 +447,7 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
     // step of a few hundred fragments waits for)
     int mrg = 1, rep_n = 1;
     {
-        const int m_max = SEG / s2.seg_unit;
+        const int m_max = seg_cap / s2.seg_unit;
         while (mrg < m_max && n_units / (unsigned long long)(2 * mrg) >= s2.target) mrg <<= 1;
         // (sharing a unit costs every sharing wave the current layout's values again: only while there are fewer units than waves)
         // ... and never more than one unit per wave through sharing (a second unit is a second chain of dependent loads and passes)
@@ -517,7 +525,7 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
         const bool cont = lane >= pos && lane < m_in && my_key == key0 && my_lf == lf && my_j0 == j0 + (lane - pos) * s2.seg_unit;
         const unsigned long long bl = __ballot(cont) >> pos;          // bit i: entry pos + i continues the run (bit 0: the entry itself)
         int run = (int)__ffsll((long long)~bl) - 1;
-        run = min(run, SEG / s2.seg_unit);
+        run = min(run, max(seg_cap / s2.seg_unit, 1));
         const int cnt = rfl((run - 1) * s2.seg_unit + __shfl(my_cnt, pos + run - 1, 64));
         const int ti = rfl(key0 & 0xffff), tj = rfl((key0 >> 16) & 0xffff);
         pos += run;
@@ -535,15 +543,15 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
         const GClass* __restrict__ cg = s2.cls + (size_t)pair * US_NCAND;
         const uint4 cls_pre0 = reinterpret_cast<const uint4*>(cg)[lane], cls_pre1 = reinterpret_cast<const uint4*>(cg)[64 + lane];
         const int nc_pre = s2.cls_n[pair];
-        const int nl = rfl(min(US_TILE, PL.n - offl * US_TILE));
-        const bool has_l = lane < nl;
-        const int fl = has_l ? sa.perm[CL.base + PL.lo + offl * US_TILE + lane] : 0;
+        const int nl = rfl(min(TL, PL.n - offl * TL));
+        const bool has_l = xi < nl;
+        const int fl = has_l ? sa.perm[CL.base + PL.lo + offl * TL + xi] : 0;
         Geo gL = {0, 0, 0, 0};
         Stat stL = {0.0f, 0.0f, 0.0f, 0, 0, 0, 0, 0};
         if (has_l) { gL = geo[fl]; stL = stat[fl]; }
         if (lane < cnt) {
             STile2 y;
-            y.frag = sa.perm[CS.base + PS.lo + offs * US_TILE + j0 + lane];
+            y.frag = sa.perm[CS.base + PS.lo + offs * TL + j0 + lane];
             const Geo gy = geo[y.frag];
             y.start_bp = gy.start_bp; y.len_bp = gy.len_bp; y.flags = gy.flags; y.st = stat[y.frag];
             tile[lane] = y;
@@ -599,7 +607,7 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
         unsigned vmask = 0;   // bit j: this lane's fragment and fragment j of the segment are a pair to price (every unordered pair once; never a
                               // bin with itself; copies of repeated bins -- no sub-fragments here -- are priced by k_rep_delta)
         for (int j = 0; j < cnt; j++)
-            if (has_l && stL.n > 0 && tile[j].st.n > 0 && !(diag && !(lane < j0 + j))) vmask |= 1u << j;
+            if (has_l && stL.n > 0 && tile[j].st.n > 0 && !(diag && !(xi < j0 + j))) vmask |= 1u << j;
         STAMP_FBLK(3, threadIdx.x == 0 && v == (unsigned long long)wave && pos == run);
         for (int c = -1; c < nc; c = c < 0 ? rep_r : c + rep_n) {     // c = -1: the current layout (its values are kept in LDS), then this wave's classes
             bool cis = cis_old;
@@ -705,7 +713,11 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
                 }
                 accq += acc_hi * (1ll << 30) + acc_lo;
             } else
-            for (int j = 0; j < cnt; j++) {
+            for (int jb = 0; jb < cnt; jb += (halves ? 2 : 1)) {
+                // (tiles of 32: this half of the wave takes fragment jb + half of the segment; a lane without one computes on the last and adds nothing)
+                const int j_mine = jb + half, j = j_mine < cnt ? j_mine : cnt - 1;
+                const bool j_ok = j_mine < cnt;
+                const int jrow = halves ? (jb >> 1) : jb;                  // the lane's row of current-layout values
                 const STile2& y = tile[j];
                 const int ny = y.st.n, fs = y.frag;
                 const bool fwdSn = cy[j][3] != 0.0f;
@@ -726,11 +738,11 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
                         }
                         const float norm = norm_u >= 0.0f ? norm_u : (float)(ax * ay) / nfpb;
                         const float ex = s2_ex(cis, lf ? c_l : c_s, lf ? c_s : c_l, norm, circ, s_tot, par);
-                        float* const slot = &exo[j * NSP + a * NS + b][lane];
+                        float* const slot = &exo[jrow * NSP + a * NS + b][lane];
                         if (c < 0) *slot = ex;
                         else acc += (double)*slot - (double)ex;
                     }
-                if (c >= 0) add_pair(j, acc);
+                if (c >= 0 && j_ok) add_pair(j, acc);
             }
             if (c >= 0) {
                 const long long qs = wave_sum_ll(accq);

@@ -21,7 +21,8 @@ constexpr int US_MAXC = US_MAXK + 1;                          // contigs of a st
 constexpr int US_MAXP = 3 * US_MAXK + 3;                      // global pieces: 2 per cut fragment (itself, the run behind it) + 1 per contig
 constexpr int US_MAXPAIRS = US_MAXP * (US_MAXP + 1) / 2;      // unordered pairs (g <= h) of global pieces
 constexpr int US_NCAND = US_MAXK * N_OPS;                     // candidates of a step, index k * 13 + op
-constexpr int US_TILE = 64;                                   // fragments per tile (one wave)
+constexpr int US_TILE = 64;                                   // fragments per tile at most (one wave); a set is tiled by USet::tile of them: 64, or 32 with
+                                                              // several sub-fragments per bin (the two halves of a wave then take two fragments of the segment)
 
 struct UContig { int label, base, len, lbp, circ, pad; };     // perm[base .. base + len): its fragments in position order
 struct UPiece {
@@ -33,14 +34,14 @@ struct USet {
     int n_contigs, n_pieces, n_tiles;
     unsigned live;                                            // bit k: neighbour k is a real pair (fB_k != fA): its set is part of the union
     unsigned mass;                                            // bit k: ... and its fragment pairs are priced here (else the table kernel did: small sets)
-    int pad;
+    int tile;                                                 // fragments per tile (US_TILE or 32)
     UContig c[US_MAXC];
     UPiece p[US_MAXP];
 };
 // what the layout says about one end of a proposal (fA, or a neighbour fB_k): its contig
 struct UEnd { int label, pos, base, len, lbp, circ; };
 
-GR_HD int upiece_tiles(int n) { return (n + US_TILE - 1) / US_TILE; }
+GR_HD int upiece_tiles(int n, int tile) { return (n + tile - 1) / tile; }
 GR_HD int upair_index(int g, int h) { return g * US_MAXP - g * (g - 1) / 2 + (h - g); }   // g <= h
 
 // Build the union set, in two parts: the contigs, cuts, pieces and tiles (one thread), then every piece's id under every neighbour
@@ -52,12 +53,12 @@ GR_HD void uset_add_piece(USet& U, int& np, int& tile, int ci, int lo, int n)
     np += 1;
     P.contig = ci; P.lo = lo; P.n = n; P.tile0 = tile;
     P.pad[0] = 0; P.pad[1] = 0;
-    tile += upiece_tiles(n);
+    tile += upiece_tiles(n, U.tile);
 }
-GR_HD void uset_build_geometry(USet& U, const UEnd& A, const UEnd* B, int K, unsigned live, unsigned mass, int* cuts, int* ncut)
+GR_HD void uset_build_geometry(USet& U, const UEnd& A, const UEnd* B, int K, unsigned live, unsigned mass, int* cuts, int* ncut, int tile_frags = US_TILE)
 {
     constexpr int CW = US_MAXK + 1;
-    U.live = live; U.mass = mass & live; U.pad = 0;
+    U.live = live; U.mass = mass & live; U.tile = tile_frags;
     int nc = 1;
     U.c[0].label = A.label; U.c[0].base = A.base; U.c[0].len = A.len; U.c[0].lbp = A.lbp; U.c[0].circ = A.circ; U.c[0].pad = 0;
     cuts[0] = A.pos; ncut[0] = 1;
@@ -100,9 +101,9 @@ GR_HD void uset_piece_pk(USet& U, const PieceKey* keys, int K, int g, int k)
     UPiece& P = U.p[g];
     P.pk[k] = (unsigned char)((k < K && ((U.live >> k) & 1u)) ? piece_of(keys[k], U.c[P.contig].label, P.lo) : 0);
 }
-GR_HD void uset_build(USet& U, const UEnd& A, const UEnd* B, const PieceKey* keys, int K, unsigned live, unsigned mass, int* cuts, int* ncut)
+GR_HD void uset_build(USet& U, const UEnd& A, const UEnd* B, const PieceKey* keys, int K, unsigned live, unsigned mass, int* cuts, int* ncut, int tile_frags = US_TILE)
 {
-    uset_build_geometry(U, A, B, K, live, mass, cuts, ncut);
+    uset_build_geometry(U, A, B, K, live, mass, cuts, ncut, tile_frags);
     for (int g = 0; g < U.n_pieces; g++)
         for (int k = 0; k < US_MAXK; k++) uset_piece_pk(U, keys, K, g, k);
 }
@@ -180,8 +181,8 @@ GR_HD int utile_count(const USet& U, int t)
 {
     int off;
     const int g = utile_piece(U, t, off);
-    const int left = U.p[g].n - off * US_TILE;
-    return left < US_TILE ? left : US_TILE;
+    const int left = U.p[g].n - off * U.tile;
+    return left < U.tile ? left : U.tile;
 }
 
 } // namespace graal

@@ -12,13 +12,13 @@ from tests import util
 _i32p = ctypes.POINTER(ctypes.c_int32)
 
 
-def union_check(s, fA, fBs, max_id, quirk, seg):
+def union_check(s, fA, fBs, max_id, quirk, seg, tile=64):
     hc = util.hostcheck()
     hc.hc_union_check.restype = ctypes.c_int
     fb = np.asarray(fBs, np.int32)
     info = np.zeros(10, np.int64)
     bad = hc.hc_union_check(int(fA), fb.ctypes.data_as(_i32p), len(fb), int(max_id), util._ptrs(s), len(s["pos"]), int(quirk), int(seg),
-                            info.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)))
+                            info.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), int(tile))
     return bad, info
 
 
@@ -46,7 +46,8 @@ def test_union_set_classes_and_units_against_brute_force(seed, n, n_contigs, K, 
             else:
                 fBs = sorted(int(v) for v in rng.choice(n, K, replace=False))   # (may contain fA: that neighbour is not live)
             for quirk in (0, 1):
-                bad, info = union_check(s, fA, fBs, max_id, quirk, seg=int(rng.choice([1, 4, 16])))
+                # (tiles of 64 fragments, or 32: what several sub-fragments per bin are tiled by)
+                bad, info = union_check(s, fA, fBs, max_id, quirk, seg=int(rng.choice([1, 2, 4, 16])), tile=int(rng.choice([64, 32])))
                 assert bad == 0, (seed, trial, fA, fBs, quirk, info)
                 assert info[0] <= 3 * K + 3 and info[2] <= K + 1
                 tot_classes += info[4]; tot_cands += info[7]

@@ -5,6 +5,7 @@
 #   c5   : the bench workload (C5 exploded + 2,000 warm-up steps), 100 timed steps
 #   late : C5 on its 7 original contigs, the late stage's reference-arithmetic scoring steps of bench.py (--late-only): 3 + 3 x 12 steps
 #   c4   : the C4 stand-in (40,000 bins, 8 M contacts), explode + 2 cycles of a headless run (PROF_TRACE_ONLY=1: kernel trace only)
+#   c3   : the C3 stand-in (3,500 bins x 3 sub-fragments, 600 k contacts), explode + 20 cycles (PROF_TRACE_ONLY=1)
 #   c2   : the C2 stand-in (1,086 bins x 3 sub-fragments) on its 7 contigs, 400 full MCMC steps (tools/step_breakdown.py)
 set -u
 TAG=${1:-r02}
@@ -18,6 +19,7 @@ case $WHAT in
   late) ARGS="$REPO/bench.py --late-only --late-repeats 3" ;;   # exactly the launches bench.py's late_stage.roofline is quoted on (3 warm-up + 3 x 12 timed steps)
   c2)   ARGS="$REPO/tools/step_breakdown.py --n-bins 1086 --nnz 120000 --n-sub 3 --original --steps 400" ;;
   c4)   ARGS="$REPO/tools/run_configs.py C4 --cycles ${C4_CYCLES:-2}" ;;
+  c3)   ARGS="$REPO/tools/run_configs.py C3 --cycles ${C3_CYCLES:-20}" ;;
 esac
 cd /tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
