@@ -4810,7 +4810,7 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
         // take two fragments of the segment at a time (k_strict2): a unit is a 32 x 4 block instead of a 64 x 2 strip, which wastes fewer lanes
         // on pieces of a few dozen bins and at the window's edge (GRAAL_S2_TILE=64: the strips, for A/B)
         static const int tile_env = getenv("GRAAL_S2_TILE") ? atoi(getenv("GRAAL_S2_TILE")) : 0;
-        const int TILE = h->single_sub ? 64 : (tile_env == 64 ? 64 : 32);
+        const int TILE = tile_env == 64 ? 64 : (tile_env == 32 ? 32 : (h->single_sub ? 64 : 32));
         // tiles of the union: at most K + 1 contigs, at most every fragment; + one partial tile per global piece
         const unsigned long long nt = std::min<unsigned long long>((unsigned long long)(K + 1) * (unsigned long long)((lc + TILE - 1) / TILE),
                                                                    (unsigned long long)((h->n + TILE - 1) / TILE + K + 1)) + (unsigned long long)US_MAXP;

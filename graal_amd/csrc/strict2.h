@@ -425,8 +425,8 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
     }
     __syncthreads();
     const USet& U = s_U;
-    const int TL = MULTI ? U.tile : US_TILE;                      // fragments per tile: 64, or 32 (several sub-fragments per bin)
-    const bool halves = MULTI && TL == 32;                        // lanes 0-31 and 32-63 hold the SAME 32 fragments and take two fragments of the segment at a time
+    const int TL = U.tile;                                        // fragments per tile: 64, or 32 (several sub-fragments per bin)
+    const bool halves = TL == 32;                                 // lanes 0-31 and 32-63 hold the SAME 32 fragments and take two fragments of the segment at a time
     const int xi = lane & (TL - 1), half = halves ? (lane >> 5) : 0;
     const int seg_cap = MULTI ? (halves ? 4 : 2) : SEG;           // fragments of a unit's segment
     const unsigned long long nq_total = counters[2];              // written by k_scan, an earlier kernel on the stream
@@ -663,8 +663,8 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
             // the same without branches for the common case (to_q_fast: |v| < 2^30 is v = hi + lo, hi = rint(v), both parts int32; summed apart,
             // joined behind the loop); a larger term takes the slow way
             long long acc_hi = 0, acc_lo = 0;
-            auto add_pair_fast = [&](int j, double v) {
-                const bool ok = ((vmask >> j) & 1u) != 0;
+            auto add_pair_fast = [&](int j, double v, bool mine = true) {
+                const bool ok = mine && ((vmask >> j) & 1u) != 0;
                 const bool big = ok && !(fabs(v) < 1073741824.0);
                 const double hi = rint(v);
                 const int ih = __double2int_rn(hi), il = __double2int_rn((v - hi) * Q_SCALE);
@@ -678,18 +678,22 @@ __global__ __launch_bounds__(256, 4) void k_strict2(FinArgs fa, StrictArgs sa, S
             };
             if (!MULTI && norm_u >= 0.0f && !(quirk && !cis)) {
                 // one sub-fragment per bin, one RF count: nothing per pair but the model
+                // (tiles of 32: this half of the wave takes fragment jb + half of the segment; its values of the current layout in row jb / 2)
+                const int jstep = halves ? 2 : 1;
                 if (!cis) {
                     const float ex = par.v_inter * norm_u;
-                    for (int j = 0; j < cnt; j++) {
-                        if (c < 0) exo[j][lane] = ex;
-                        else add_pair_fast(j, (double)exo[j][lane] - (double)ex);
+                    for (int jb = 0; jb < cnt; jb += jstep) {
+                        const int j_mine = jb + half, j = j_mine < cnt ? j_mine : cnt - 1, jrow = halves ? (jb >> 1) : jb;
+                        if (c < 0) exo[jrow][lane] = ex;
+                        else add_pair_fast(j, (double)exo[jrow][lane] - (double)ex, j_mine < cnt);
                     }
                 } else {
-                    for (int j = 0; j < cnt; j++) {
+                    for (int jb = 0; jb < cnt; jb += jstep) {
+                        const int j_mine = jb + half, j = j_mine < cnt ? j_mine : cnt - 1, jrow = halves ? (jb >> 1) : jb;
                         const float c_s = cy[j][0];
                         const float ex = s2_ex(true, lf ? cl[0] : c_s, lf ? c_s : cl[0], norm_u, circ, s_tot, par);
-                        if (c < 0) exo[j][lane] = ex;
-                        else add_pair_fast(j, (double)exo[j][lane] - (double)ex);
+                        if (c < 0) exo[jrow][lane] = ex;
+                        else add_pair_fast(j, (double)exo[jrow][lane] - (double)ex, j_mine < cnt);
 #if defined(GRAAL_STAMPS) && defined(GRAAL_S2_COUNTS)
                         {   // (round-4 review item 6: how many (pair, class) evaluations hand the model the float32 inputs of the CURRENT layout?)
                             const float s_dbg = fabsf((lf ? c_s : cl[0]) - (lf ? cl[0] : c_s));
