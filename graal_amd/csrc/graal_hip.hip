@@ -4820,12 +4820,15 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
         // stand-in 20 % of its run), GRAAL_STRICT_REP the waves that may share one unit's classes (1, 2, 4, 8)
         static const int seg_env = getenv("GRAAL_STRICT_SEG") ? atoi(getenv("GRAAL_STRICT_SEG")) : 0;
         const int seg_max = h->single_sub ? 16 : (TILE == 32 ? 4 : 2);   // (k_strict2's segment: SEG, seg_cap)
+        // (one sub-fragment per bin: entries of 4 fragments -- of 16, a whole unit, once a contig may exceed 512 bins: a unit of 64 x 4 pairs is
+        // 13 us of set-up for ~1 us per class, and the kernel merges neighbouring entries only from 49,000 of them on; C4 stand-in, 4 cycles:
+        // 214 us per step against 224, the late stage unchanged)
         // (tiles of 32: entries of TWO fragments, one per half of the wave -- FOUR once the longest contig may hold more than 512 bins (the bound,
         // one commit stale: twice the longest + 2): a step there has a few thousand units, more than half the grid's waves, so no two waves share
         // one; with half as many, twice as long, every unit is shared by two waves and none idles.  C3 stand-in (contigs of 350 bins): 142 us
         // per step against 157; C2 stand-in (contigs of 150-220): 108 against 99)
         const int seg_unit = ((seg_env == 1 || seg_env == 2 || seg_env == 4 || seg_env == 8 || seg_env == 16) && seg_env <= seg_max) ? seg_env
-                                                                                                 : (h->single_sub ? 4 : (TILE == 32 ? (lc > 512 ? 4 : 2) : 1));
+                                                                                                 : (h->single_sub ? (lc > 512 ? 16 : 4) : (TILE == 32 ? (lc > 512 ? 4 : 2) : 1));
         static const int rep_env = getenv("GRAAL_STRICT_REP") ? atoi(getenv("GRAAL_STRICT_REP")) : 8;
         const int rep_max = rep_env >= 16 ? 16 : (rep_env >= 8 ? 8 : (rep_env >= 4 ? 4 : (rep_env >= 2 ? 2 : 1)));
         // units the grid wants before k_strict2 merges neighbouring entries into longer units (per wave: 6 at one sub-fragment per bin; with
