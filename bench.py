@@ -584,6 +584,7 @@ def main():
     if args.long_steps > 0:
         nc, tl_ = timed_region(smp, props[args.warmup:], max_id, args.long_steps)
         long_region = {"value_1000": nc / tl_, "ms_per_step_1000": 1e3 * tl_ / args.long_steps, "steps_1000": args.long_steps}
+    phase("long region done")
     # the same steps in the OTHER arithmetic (same engine, same proposals)
     set_arithmetic(smp, other)
     for f, nb in props[:args.warmup]:
@@ -592,10 +593,12 @@ def main():
     nc, to_ = timed_region(smp, props[args.warmup:], max_id, n_other)
     other_block = {"arithmetic": other, "value": nc / to_, "unit": "candidate logL evals/s", "ms_per_step": 1e3 * to_ / n_other, "steps": n_other}
     set_arithmetic(smp, args.arithmetic)
+    phase("other arithmetic done")
     alt = None
     # for reference: back-to-back replays of the last step's scan between two events (per-launch event overhead amortised)
     scan_replay_ms = smp.engine.time_scan(len(props[-1][1]), reps=100)
     scan_isolated_ms = smp.engine.time_scan(len(props[-1][1]), reps=-40)   # median of isolated replays (device idle in between)
+    phase("scan replays done")
 
     # ---- Infinity-Cache control of the roofline figure (rank 0's GPU, N = 1) ---------------------------------------
     control = None
@@ -613,6 +616,7 @@ def main():
     for _ in range(n_fe):
         smp.engine.eval_full_q()
     full_eval_s = (time.perf_counter() - t1) / n_fe
+    phase("full evaluations done")
 
     # ---- full MCMC steps (scoring + sampling + commit + relabel), reported as an extra ----------------------------
     t1 = time.perf_counter()
@@ -621,6 +625,7 @@ def main():
         smp.step_max_likelihood(int(i), K)
     torch.cuda.synchronize()
     full_step_s = (time.perf_counter() - t1) / n_full
+    phase("full MCMC steps done")
     # the same with the reference GUI's default "sample parameters" (main_gl.py:258-262): one nuisance-parameter Metropolis
     # step -- one full evaluation under test parameters, plus a scipy fsolve for d_max on the host -- after every MCMC step
     smp.bins = np.arange(1.0, 41.0, 1.0)
