@@ -4805,7 +4805,12 @@ int launch_strict(Ctx* h, int fA, int K, int rank, int world, long long* d_q_out
         }
         const int lc = std::max(std::max(h->max_lcont, h->lcont_bound), 1);
         static const int blocks_env = getenv("GRAAL_STRICT_BLOCKS") ? atoi(getenv("GRAAL_STRICT_BLOCKS")) : 0;
-        const int blocks = blocks_env > 0 ? blocks_env : (lc <= 64 ? 32 : (lc <= 256 ? 512 : 1024));
+        // (the GRID by the longest contig as last seen -- one commit stale: a performance choice; everything that must HOLD the step is sized by
+        // the bound `lc`, twice that + 2.  By the bound, contigs of 130-256 bins went to the 1,024-block grid behind an event instead of the
+        // 512-block one that follows k_gprep through its word: GRAAL_S2_GRID_BY_BOUND=1 for A/B)
+        static const bool grid_by_bound = getenv("GRAAL_S2_GRID_BY_BOUND") != nullptr;
+        const int lg = grid_by_bound ? lc : std::max(h->max_lcont, 1);
+        const int blocks = blocks_env > 0 ? blocks_env : (lg <= 64 ? 32 : (lg <= 256 ? 512 : 1024));
         // fragments per tile: 64 (one per lane); with several sub-fragments per bin 32 -- the halves of a wave hold the same 32 fragments and
         // take two fragments of the segment at a time (k_strict2): a unit is a 32 x 4 block instead of a 64 x 2 strip, which wastes fewer lanes
         // on pieces of a few dozen bins and at the window's edge (GRAAL_S2_TILE=64: the strips, for A/B)
