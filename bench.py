@@ -621,8 +621,10 @@ def main():
     # ---- full MCMC steps (scoring + sampling + commit + relabel), reported as an extra ----------------------------
     t1 = time.perf_counter()
     n_full = 500   # (an extra next to the headline: always enough steps for a stable figure, 30 ms)
-    for i in order[args.mcmc_warmup:args.mcmc_warmup + n_full]:
+    for j, i in enumerate(order[args.mcmc_warmup:args.mcmc_warmup + n_full]):
         smp.step_max_likelihood(int(i), K)
+        if os.environ.get("GRAAL_BENCH_PHASES") and j % 25 == 24:     # (diagnostics of the open two-ranks-on-one-GPU fault: DESIGN.md section 9)
+            phase("full MCMC step %d done (%d since the last full evaluation)" % (j, smp._steps_since_full))
     torch.cuda.synchronize()
     full_step_s = (time.perf_counter() - t1) / n_full
     phase("full MCMC steps done")
