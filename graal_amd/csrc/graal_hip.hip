@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <chrono>
 #include <dlfcn.h>
+#include <unistd.h>
 #include <map>
 #include <string>
 #include <vector>
@@ -4559,9 +4560,27 @@ void compute_t_all(Ctx* h, bool rebuild = true)
 
 int reach_bp(const Ctx* h) { return (int)ceil((double)h->par.d_max * 1000.0) + 1000; }
 
+// GRAAL_DEBUG_ADDR=1: where the engine's buffers are (stderr, whenever a pointer changes) -- so that the address of a "Memory access fault by GPU"
+// can be matched to a buffer (the open fault of the two-ranks-on-one-GPU rehearsal)
+void debug_print_buffers(const Ctx* h, const char* when)
+{
+    static const bool on = getenv("GRAAL_DEBUG_ADDR") != nullptr;
+    if (!on) return;
+    const size_t n = (size_t)h->n, nnz = (size_t)h->nnz;
+    fprintf(stderr, "[graal addr, pid %d, %s] n %zu nnz %zu | soa0 %p soa1 %p | row %p col %p cnt %p (%zu B each) queue %p (%zu B) | geo %p link %p perm %p pstart %p cbase %p mates %p | "
+                    "stat_frag %p sub2bin %p sub_rec %p | tabs %p d_args %p d_scalars %p d_acc %p d_sync %p d_done %p d_flags %p tm_done %p d_part %p d_chg %p | "
+                    "d_slist %p (%llu entries) d_uset %p d_cls %p d_cls_n %p | x_dev %p x_host %p res_dev %p h_res %p h_stats %p h_full %p h_own %p\n",
+            (int)getpid(), when, n, nnz, (void*)h->soa_mem[0], (void*)h->soa_mem[1], (void*)h->row, (void*)h->col, (void*)h->cnt, nnz * 4, (void*)h->queue, (nnz + 8) * sizeof(QRaw),
+            (void*)h->geo, (void*)h->link, (void*)h->perm, (void*)h->pstart, (void*)h->cbase, (void*)h->mates, (void*)h->stat_frag, (void*)h->sub2bin, (void*)h->sub_rec,
+            (void*)h->tabs, (void*)h->d_args, (void*)h->d_scalars, (void*)h->d_acc, (void*)h->d_sync, (void*)h->d_done, (void*)h->d_flags, (void*)h->tm_done, (void*)h->d_part, (void*)h->d_chg,
+            (void*)h->d_slist, (unsigned long long)h->slist_cap, (void*)h->d_uset, (void*)h->d_cls, (void*)h->d_cls_n, (void*)h->x_dev, (void*)h->x_host, (void*)h->res_dev, (void*)h->h_res,
+            (void*)h->h_stats, (void*)h->h_full, (void*)h->h_own);
+}
+
 // (re)write the two device-resident argument blocks; called whenever a pointer, size or parameter changes
 int sync_args(Ctx* h)
 {
+    debug_print_buffers(h, "sync_args");
     DevArgs a[2];
     for (int b = 0; b < 2; b++) {
         memset(&a[b], 0, sizeof(DevArgs));
@@ -6286,6 +6305,7 @@ int graal_attach_exchange(graal_ctx* h, void* segment, int64_t bytes, int32_t ra
     // the published word is the step's sequence number: all ranks continue from the same one
     if (seq_floor > h->seq) h->seq = seq_floor;
     if (seq_now) *seq_now = h->seq;
+    debug_print_buffers(h, "attach_exchange");
     return GRAAL_OK;
 }
 

@@ -194,6 +194,7 @@ def test_bench_runs_two_ranks_from_one_command():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["GRAAL_BENCH_PHASES"] = "1"    # (where the run is, on stderr: shown if it fails)
+    env["GRAAL_DEBUG_ADDR"] = "1"      # (... and where the engines' buffers are: a fault's address can be matched to one)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--n-bins", "2000",
            "--nnz", "100000", "--steps", "6", "--warmup", "2", "--mcmc-warmup", "300"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
