@@ -781,7 +781,8 @@ __global__ __launch_bounds__(256) void k_incr(SoaPtr s, int n, const Changed* __
                                               int* __restrict__ off_new, int* __restrict__ perm, int* __restrict__ pstart, int* __restrict__ cbase,
                                               Geo* __restrict__ geo, Link* __restrict__ link, long long* __restrict__ stats,
                                               int* __restrict__ mates, int* __restrict__ chg_clear, int chg_n,
-                                              const long long* __restrict__ part, int n_part, volatile long long* host, long long seq)
+                                              const long long* __restrict__ part, int n_part, volatile long long* host, long long seq,
+                                              volatile long long* guard /* pinned host, 8 words: an index out of range (never yet seen to be this kernel's) */)
 {
     __shared__ IncrPlan sp;
     __shared__ int s_lb[4], s_ub[4];
@@ -888,6 +889,16 @@ __global__ __launch_bounds__(256) void k_incr(SoaPtr s, int n, const Changed* __
             if (i < p.n_new && key_less(p.new_len[i], p.new_lab[i], lenc, c)) { rank += 1; off += p.new_len[i]; }
     }
     const int pos = s.p[F_POS][f];
+    if ((unsigned)(off + pos) >= (unsigned)n || (unsigned)rank >= (unsigned)n) {
+        // GUARD (the open fault of the two-rank rehearsal: an access 48+ words behind the position index's twin): an
+        // index this relabel would write out of range is recorded for the host -- graal_begin_step fails with it -- and not written
+        if (atomicAdd((unsigned long long*)&stats[31], 1ull) == 0ull) {
+            guard[1] = f; guard[2] = c; guard[3] = rank; guard[4] = off; guard[5] = pos; guard[6] = lenc; guard[7] = ((long long)p.n_new << 32) | (unsigned)p.nc_new;
+            __threadfence_system();
+            guard[0] = seq != 0 ? seq : 1;
+        }
+        return;
+    }
     s.p[F_IDC][f] = rank;
     if (pos == 0) { len_new[rank] = lenc; off_new[rank] = off; }
     perm[off + pos] = f;
@@ -4324,6 +4335,7 @@ struct Ctx {
     long long carry_q = 0;
     bool carry_bad = false;
     long long* d_own_acc = nullptr;  // k_own_corr: [0] sum, [1] unknown terms, [2] ticket
+    long long* h_guard = nullptr;    // pinned host, 8 words: k_incr's out-of-range record ([0] != 0: tripped)
     long long* h_own = nullptr;      // pinned host: [0] the commit's number, [1] its correction (Q), [2] its unknown terms
     long long own_seq = 0;
     bool own_pending = false;        // a correction kernel is out and its result has not been taken from h_own
@@ -5196,6 +5208,8 @@ int graal_create(int device, graal_ctx** out)
     memset(h->h_full, 0, 8 * sizeof(long long));
     CK(hipHostMalloc((void**)&h->h_stats, 17 * sizeof(long long), hipHostMallocDefault));
     memset(h->h_stats, 0, 17 * sizeof(long long));
+    CK(hipHostMalloc((void**)&h->h_guard, 8 * sizeof(long long), hipHostMallocDefault));
+    memset(h->h_guard, 0, 8 * sizeof(long long));
     CK(hipHostMalloc((void**)&h->h_own, 4 * sizeof(long long), hipHostMallocDefault));
     memset(h->h_own, 0, 4 * sizeof(long long));
     CK(hipMalloc(&h->d_own_acc, 4 * sizeof(long long)));
@@ -5236,6 +5250,7 @@ void graal_destroy(graal_ctx* h)
         if (h->h_res) (void)hipHostFree(h->h_res);
         if (h->h_stats) (void)hipHostFree(h->h_stats);
         if (h->h_own) (void)hipHostFree(h->h_own);
+        if (h->h_guard) (void)hipHostFree(h->h_guard);
         if (h->d_own_acc) (void)hipFree(h->d_own_acc);
         if (h->h_full) (void)hipHostFree(h->h_full);
         if (h->h_dist) (void)hipHostFree(h->h_dist);
@@ -5603,7 +5618,12 @@ int graal_layout_stats(graal_ctx* h, int64_t out[8])
     { int rc = fetch_stats(h, res, false); if (rc) return rc; }
     out[0] = res[0]; out[1] = res[1]; out[2] = res[2]; out[3] = res[3]; out[4] = res[4]; out[5] = res[5];
     out[6] = res[14]; out[7] = 0;
-    h->n_contigs = (int)res[0];
+    // (h->n_contigs is the contig count of the RANKED layout -- what the next incremental relabel counts from (k_incr's nc_old) and what
+    // graal_apply_move checks max_id against.  With a commit pending these statistics are of the layout BEHIND it: taking them over made the
+    // relabel that followed count from the wrong number whenever that commit had changed the number of contigs -- bench.py's
+    // layout_stats() / modify_gl_cuda_buffer(0) pair behind its MCMC warm-up; found in round 5 by a guard in k_incr, after a year of
+    // silently misplaced entries of the position index in that one flow and four GPU faults in its two-rank rehearsal)
+    if (h->pending_commits == 0 && h->ranks_valid) h->n_contigs = (int)res[0];
     return GRAAL_OK;
 }
 
@@ -5641,7 +5661,7 @@ static int begin_step_launch(graal_ctx* h, bool defer = false)
         k_incr<<<blocks_for(n + 1, bs) + 1, bs, 0, h->stream>>>(s, n, h->d_chg + h->chg_last, h->len_of2[1 - cur], h->contig_off2[1 - cur], h->n_contigs,
                                                            h->len_of2[cur], h->contig_off2[cur], h->perm, h->pstart, h->cbase, h->geo, h->link, h->d_scalars,
                                                            h->mates, (int*)(h->d_chg + (1 - h->chg_last)), (int)(sizeof(Changed) / sizeof(int)),
-                                                           (defer_stats ? nullptr : h->d_part), h->apply_blocks, from_apply ? h->h_stats : nullptr, h->stats_seq);
+                                                           (defer_stats ? nullptr : h->d_part), h->apply_blocks, from_apply ? h->h_stats : nullptr, h->stats_seq, h->h_guard);
         CK(hipGetLastError());
         if (defer && h->spin_ok) {
             // graal_step: k_tm goes out next, without an event: it spins until the step's k_scan (behind this kernel on the stream) starts
@@ -5729,6 +5749,14 @@ static int begin_step_collect(graal_ctx* h, int64_t stats[8], int32_t* max_id)
     const int n = h->n;
     long long res[16];
     { int rc = wait_stats(h, res); if (rc) return rc; }
+    if (h->h_guard && ((volatile long long*)h->h_guard)[0] != 0) {
+        volatile long long* g = h->h_guard;
+        char msg[320];
+        snprintf(msg, sizeof msg, "relabel: an index out of range was caught (fragment %lld, old label %lld, new rank %lld, offset %lld, position %lld, length %lld, "
+                 "new contigs %lld, contigs %lld, n %d): the layout's position index is not to be trusted", g[1], g[2], g[3], g[4], g[5], g[6], g[7] >> 32, g[7] & 0xffffffffll, n);
+        g[0] = 0;
+        return fail(h, GRAAL_E_STATE, msg);
+    }
     const int nc = (int)res[0];
     // (a corrupt layout could have made the kernels above index out of range; the uploads validate labels and the
     // mutations keep them in [0, n_contigs + 2], so this is a consistency check, not a guard)

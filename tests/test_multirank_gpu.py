@@ -198,20 +198,15 @@ def test_bench_runs_two_ranks_from_one_command():
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--n-bins", "2000",
            "--nnz", "100000", "--steps", "6", "--warmup", "2", "--mcmc-warmup", "300"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
-    if out.returncode != 0:
-        # OPEN ISSUE: about one run in five of THIS rehearsal -- two ranks sharing ONE GPU -- ends in "Memory access fault by
-        # GPU" on one rank, somewhere behind the timed region (bench.py's phase markers, kept below, say where).  Not reproduced with one rank per
-        # process group, never seen with one rank.  Everything the ranks said is kept (gpurun_out/ travels back from the GPU box) and the
-        # command gets ONE more try: the test is about the launcher, the sharding and the one JSON line, and fails if the second run fails too.
-        import warnings
+    if out.returncode != 0:      # (keep everything the ranks said -- phase markers, the engines' buffer map: gpurun_out/ travels back from the GPU box.
+        # This rehearsal died of a GPU memory fault about one run in five until round 5 found the cause with exactly these diagnostics:
+        # graal_layout_stats behind a commit made the next relabel count from the wrong number of contigs -- DESIGN.md section 9)
         try:
             os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
             with open(os.path.join(root, "gpurun_out", "bench_two_ranks_failure.log"), "a") as f:
                 f.write("returncode %d\n--- stdout\n%s\n--- stderr\n%s\n" % (out.returncode, out.stdout, out.stderr))
         except OSError:
             pass
-        warnings.warn("bench.py --gpus 2 (two ranks on one GPU) failed once: %s" % (out.stderr[-600:],))
-        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["distributed"]["ranks"] == 2
