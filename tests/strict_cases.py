@@ -31,6 +31,10 @@ CASES = [
      dict(quirk=True, layouts=2, contigs=(3, 6), p_circ=0.2), 3, 10),
     ("single sub-fragment, one contig of 900 bins and short ones", dict(n_bins=1000, nnz=40000, seed=15, n_sub=1, weights=(90, 2, 2, 2, 2, 2), mean_len_bp=660.0, accu=1, fact=1e4, v_inter=1e-3, d_max=25.0),
      dict(quirk=False, layouts=1, contigs=None, p_circ=0.0), 4, 5),
+    # (round 5: with sub-fragments the union set is tiled by 32 fragments, and once a contig may hold more than 512 bins the unit list's entries
+    # are 4 fragments long -- the halves of a wave walk them two at a time)
+    ("contigs of 500-900 bins, 3 sub-fragments, uniform RF counts (tiles of 32, entries of 4)", dict(n_bins=1400, nnz=60000, seed=16, n_sub=3, weights=(5, 3), mean_len_bp=700.0, accu=9, d_max=60.0),
+     dict(quirk=True, layouts=1, contigs=(2, 3), p_circ=0.3), 2, 3),
 ]
 
 
