@@ -892,11 +892,12 @@ __global__ __launch_bounds__(256) void k_incr(SoaPtr s, int n, const Changed* __
     if ((unsigned)(off + pos) >= (unsigned)n || (unsigned)rank >= (unsigned)n) {
         // GUARD (the open fault of the two-rank rehearsal: an access 48+ words behind the position index's twin): an
         // index this relabel would write out of range is recorded for the host -- graal_begin_step fails with it -- and not written
+        // (the first offender of the handle's life with its details; every later one still trips the word the host looks at)
         if (atomicAdd((unsigned long long*)&stats[31], 1ull) == 0ull) {
             guard[1] = f; guard[2] = c; guard[3] = rank; guard[4] = off; guard[5] = pos; guard[6] = lenc; guard[7] = ((long long)p.n_new << 32) | (unsigned)p.nc_new;
-            __threadfence_system();
-            guard[0] = seq != 0 ? seq : 1;
         }
+        __threadfence_system();
+        guard[0] = seq != 0 ? seq : 1;
         return;
     }
     s.p[F_IDC][f] = rank;
