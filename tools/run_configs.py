@@ -68,6 +68,16 @@ def main():
         t0 = time.perf_counter()
         smp = bench.build_sampler(P, rng, None, 0, arith)
         t_setup = time.perf_counter() - t0
+        t_explode = [0.0]
+        explode = smp.explode_genome
+
+        def timed_explode(*a, **k):      # (start_EM's explode_genome -- one relabel + one commit per fragment, cuda_lib_gl.py:1539-1556 -- timed on its own)
+            te = time.perf_counter()
+            r = explode(*a, **k)
+            smp.engine.begin_step()
+            t_explode[0] = time.perf_counter() - te
+            return r
+        smp.explode_genome = timed_explode
         t0 = time.perf_counter()
         tr = em.run_em(smp, cycles, K, rng=rng)
         dt = time.perf_counter() - t0
@@ -77,9 +87,9 @@ def main():
         if getattr(smp, "_own_corr", False):     # the last commit's own-pixel correction is still pending (the next step would add it)
             corr, ok = smp.engine.take_carry_correction()
             carried, how = carried + (corr if ok else float("nan")), "carried logL + the last commit's own pixels (%.3e)" % corr
-        print("%s [%s]: %d bins x %d sub, %d contacts, %d cycles x %d neighbours: setup %.1f s, explode + %d MCMC steps in %.1f s = %.0f us/step, "
+        print("%s [%s]: %d bins x %d sub, %d contacts, %d cycles x %d neighbours: setup %.1f s, explode + %d MCMC steps in %.1f s = %.0f us/step (explode_genome alone %.2f s: %.0f us per MCMC step without it), "
               "%d contigs left (started exploded: %d), %s %.6e vs full re-evaluation %.6e (rel %.1e), %d steps repaired by an evaluation"
-              % (name, arith, n_bins, n_sub, nnz, cycles, K, t_setup, n_steps, dt, 1e6 * dt / n_steps, tr.n_contigs[-1], n_bins,
+              % (name, arith, n_bins, n_sub, nnz, cycles, K, t_setup, n_steps, dt, 1e6 * dt / n_steps, t_explode[0], 1e6 * (dt - t_explode[0]) / n_steps, tr.n_contigs[-1], n_bins,
                  how, carried, full, abs(full - carried) / abs(full), smp.engine.run_counters()["carried_totals_repaired"]), flush=True)
         smp.free_gpu()
 
