@@ -417,6 +417,28 @@ int graal_steps(graal_ctx* h, void* mt_state, const int32_t* ids, int32_t n, int
     return rc;
 }
 
+/* explode_genome (cuda_lib_gl.py:1539-1556): every fragment 0 .. n-1 in index order is ejected from its contig -- the contig relabel in front of
+ * each (modify_gl_cuda_buffer), then the commit of candidate 0 of the pair (fragment, 0) (test_copy_struct(i, 0, 0, max_id)) -- as ONE call: the
+ * loop's two calls per fragment were 24 us of Python and ctypes each time (40,000 fragments: a second).  *n_stale = the unwritten-paste
+ * fragments the relabels reported (graal_begin_step's stats[7], summed).  The last commit is left pending, as after the loop. */
+int graal_explode(graal_ctx* h, int64_t* n_stale)
+{
+    if (!h) return GRAAL_E_ARG;
+    if (!h->have_frags) return fail(h, GRAAL_E_STATE, "no fragments uploaded");
+    long long stale = 0;
+    for (int i = 0; i < h->n; i++) {
+        int64_t st[8];
+        int32_t max_id = 0;
+        int rc = graal_begin_step(h, st, &max_id);
+        if (rc) return rc;
+        stale += st[7];
+        rc = graal_apply_move(h, i, 0, 0, max_id, nullptr);
+        if (rc) return rc;
+    }
+    if (n_stale) *n_stale = stale;
+    return GRAAL_OK;
+}
+
 /* test hooks of the host logic (CPU-only: no device call): numpy's sum, the neighbour draw and the move sampling */
 double graal_host_np_sum(const double* a, int64_t n) { return np_sum(a, (long)n); }
 int graal_host_select_move(void* mt_state, const double* score, int32_t n, int32_t n_tmp) { return hs_select((MtState*)mt_state, score, n, n_tmp); }

@@ -50,7 +50,7 @@ _f64p = ctypes.POINTER(ctypes.c_double)
 SYMBOLS = ("graal_abi_version", "graal_create", "graal_destroy", "graal_last_error", "graal_set_params",
            "graal_upload_subfrags", "graal_upload_repeats", "graal_upload_contacts", "graal_upload_contacts_f32", "graal_upload_frags", "graal_download_frags",
            "graal_relabel_contigs", "graal_begin_step", "graal_begin_step_launch", "graal_layout_stats", "graal_eval_full_q", "graal_eval_full_params", "graal_eval_candidates_q",
-           "graal_eval_candidates", "graal_exchange_bytes", "graal_attach_exchange", "graal_eval_candidates_x", "graal_exchange_selftest", "graal_detach_exchange", "graal_rccl_unique_id", "graal_attach_rccl", "graal_detach_rccl", "graal_upload_distance_ref", "graal_genome_distance", "graal_apply_move", "graal_set_finisher", "graal_set_mode", "graal_set_timing", "graal_last_timing", "graal_scan_times", "graal_strict_times", "graal_time_scan", "graal_last_counters", "graal_take_carry_correction", "graal_upload_own_obs", "graal_run_counters",
+           "graal_eval_candidates", "graal_exchange_bytes", "graal_attach_exchange", "graal_eval_candidates_x", "graal_exchange_selftest", "graal_detach_exchange", "graal_rccl_unique_id", "graal_attach_rccl", "graal_detach_rccl", "graal_upload_distance_ref", "graal_genome_distance", "graal_apply_move", "graal_set_finisher", "graal_set_mode", "graal_set_timing", "graal_last_timing", "graal_scan_times", "graal_strict_times", "graal_time_scan", "graal_last_counters", "graal_take_carry_correction", "graal_upload_own_obs", "graal_explode", "graal_run_counters",
            "graal_upload_proposal_tables", "graal_step", "graal_step_finish", "graal_steps", "graal_host_np_sum", "graal_host_select_move", "graal_host_neighbours", "graal_host_max_dist_intra")
 
 STEP_DONE, STEP_PAUSED, STEP_FALLBACK, STEP_SELECT = 0, 1, 2, 3
@@ -121,6 +121,7 @@ def load():
         L.graal_run_counters.argtypes = [ctypes.c_void_p, _i64p]
         L.graal_take_carry_correction.argtypes = [ctypes.c_void_p, _i64p, _i32p]
         L.graal_upload_own_obs.argtypes = [ctypes.c_void_p, _f32p, ctypes.c_int32]
+        L.graal_explode.argtypes = [ctypes.c_void_p, _i64p]
         L.graal_set_timing.argtypes = [ctypes.c_void_p, ctypes.c_int32]
         L.graal_set_finisher.argtypes = [ctypes.c_void_p, ctypes.c_int32]
         L.graal_set_mode.argtypes = [ctypes.c_void_p, ctypes.c_int32]
@@ -526,6 +527,12 @@ class Engine:
         own = _c(own, np.float32)
         assert own.ndim == 2 and own.shape[1] == 3
         self._ck(self._L.graal_upload_own_obs(self._h, own.ctypes.data_as(_f32p), own.shape[0]), "graal_upload_own_obs")
+
+    def explode(self):
+        """graal_explode: explode_genome's loop (relabel + eject, fragment by fragment) as one call; returns the stale-paste count."""
+        v = ctypes.c_int64(0)
+        self._ck(self._L.graal_explode(self._h, ctypes.byref(v)), "graal_explode")
+        return int(v.value)
 
     def discard_carry_correction(self):
         """The caller holds a full evaluation of the current layout: the corrections of the commits up to it are void."""

@@ -750,9 +750,14 @@ class sampler(object):
 
     def explode_genome(self, dt=0):
         """``cuda_lib_gl.py:1539-1556``: eject every fragment in index order (relabel before each)."""
-        for i in range(0, int(self.n_new_frags)):
-            max_id = self.modify_gl_cuda_buffer(i, dt)
-            self.test_copy_struct(i, 0, 0, max_id)
+        import os
+        if os.environ.get("GRAAL_PY_STEP"):          # (the loop as written, for comparison: tests/test_sampler_gpu.py)
+            for i in range(0, int(self.n_new_frags)):
+                max_id = self.modify_gl_cuda_buffer(i, dt)
+                self.test_copy_struct(i, 0, 0, max_id)
+            return
+        self.n_stale_paste += self.engine.explode()  # (the same loop behind the C ABI: include/graal_hip.h, graal_explode)
+        self.likelihood_t = None                     # (a layout change outside step_max_likelihood, as test_copy_struct notes)
 
     def define_repeats(self):
         """``cuda_lib_gl.py:452-473``: every copy of a duplicated bin (the original included) is a "repeat"."""

@@ -213,6 +213,10 @@ int graal_time_scan(graal_ctx* h, int32_t K, int32_t reps, float* avg_ms);
 /* counters of the last call: out[0]=contacts scanned out[1]=relevant (contact, neighbour) pairs
  * out[2]=queue slots (contacts with both ends in an affected contig; the few the third test rejects leave empty entries)
  * out[3]=mass work items (task x 64-fragment chunk) */
+/* explode_genome (cuda_lib_gl.py:1539-1556) as one call: for every fragment i = 0 .. n-1 the contig relabel (graal_begin_step) and the commit of
+ * candidate 0 of the pair (i, 0) (graal_apply_move(i, 0, 0, max_id): the fragment is ejected from its contig).  *n_stale (may be NULL) = the
+ * unwritten-paste fragments the relabels reported, summed.  The last commit is left pending, as after the reference's loop. */
+int graal_explode(graal_ctx* h, int64_t* n_stale);
 int graal_last_counters(graal_ctx* h, int64_t out[4]);
 /* What the commits since the last call did to the pixels NO candidate delta contains: with several sub-fragments per bin the reference's
  * sub_compute_likelihood revisits the pixels between DIFFERENT bins of contig(A) u contig(B) only (kernels3.cu:3356-3380), while a bin's

@@ -404,3 +404,28 @@ def test_runs_of_steps_in_one_call_equal_single_steps():
         assert a[5] == b[5] and np.array_equal(a[6], b[6]) and a[8] == b[8], resync
         for k in O.FIELDS:
             assert np.array_equal(a[7][k], b[7][k]), (resync, k)
+
+
+@pytest.mark.parametrize("n_sub,seed", [(1, 61), (3, 62)])
+def test_explode_genome_behind_the_c_abi_equals_the_loop(n_sub, seed, monkeypatch):
+    """explode_genome (cuda_lib_gl.py:1539-1556: relabel + eject, fragment by fragment) as ONE call (graal_explode) against the loop as
+    written (GRAAL_PY_STEP=1): the same layout field by field, the same stale-paste count, and every fragment its own contig."""
+    P = problem(n_sub, seed, 80, 1500)
+    out = []
+    for py in (False, True):
+        monkeypatch.delenv("GRAAL_PY_STEP", raising=False)
+        if py:
+            monkeypatch.setenv("GRAAL_PY_STEP", "1")
+        g = make_gpu_sampler(P, np.random.RandomState(seed))
+        g.init_likelihood()
+        g.explode_genome()
+        assert g.likelihood_t is None
+        g.modify_gl_cuda_buffer(0)
+        g.gpu_vect_frags.copy_from_gpu()
+        out.append(({k: np.copy(getattr(g.gpu_vect_frags, k)) for k in O.FIELDS}, g.n_stale_paste))
+        g.free_gpu()
+    (a, sa), (b, sb) = out
+    assert sa == sb
+    for k in O.FIELDS:
+        assert np.array_equal(a[k], b[k]), k
+    assert np.all(a["l_cont"] == 1) and len(np.unique(a["id_c"])) == P["n_new_frags"]
